@@ -1,0 +1,171 @@
+/*
+ * sfmloc.h -- C ABI of the MI355X-native query-localisation hot path.
+ *
+ * This is the drop-in boundary for ONE path of hulop/SfMLocalization: what
+ * OpenMVGLocalization_AKAZE's per-query loop (reference
+ * OpenMVGLocalization_AKAZE/src/localization.cpp:285-586) and its in-process
+ * twin LocalizeEngine::localize (VisionLocalizeServer/src/LocalizeEngine.cc:288-661)
+ * do between "query descriptors are known" and "pose is known".
+ * The reference has no FFI for this path (it is a CLI + files, or a C++ class);
+ * the entry points below are what a binding for it would call.  Each one
+ * cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, opaque handles, caller-owned output buffers, no torch types;
+ *   - every function returns an int status: 0 = ok, <0 = error, text via
+ *     sfmloc_last_error() (thread local);
+ *   - "localisation failed" is NOT an error: status 0 with n_inliers == 0
+ *     (reference: failure JSON without "t", localization.cpp:419-446,511-542);
+ *   - one handle = one map (or one shard of a map) on one GPU; calls on one
+ *     handle are serialised by the caller (the reference object is not
+ *     re-entrant either, LocalizeEngine.cc:398-399,627-628);
+ *   - there is no CPU fallback: without a HIP device every compute entry point
+ *     returns SFMLOC_ENODEV.
+ */
+#ifndef SFMLOC_H
+#define SFMLOC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFMLOC_ABI_VERSION 1
+#define SFMLOC_DESC_BYTES 64          /* FileUtils.cpp:77-92: 61 M-LDB bytes + 3 zero bytes */
+#define SFMLOC_NOMATCH 0xFFFFFFFFu
+#define SFMLOC_MAX_QUERY_ROWS 65535u  /* query feature index is packed into 16 bits of the match key */
+
+enum {
+  SFMLOC_OK = 0,
+  SFMLOC_EINVAL = -1, /* bad argument / shape */
+  SFMLOC_ENODEV = -2, /* no HIP device: the product path has no CPU fallback */
+  SFMLOC_EHIP = -3,   /* HIP runtime error */
+  SFMLOC_EIO = -4,    /* file contract violated */
+  SFMLOC_ECAP = -5,   /* caller buffer too small */
+  SFMLOC_ENOMEM = -6
+};
+
+const char *sfmloc_last_error(void);
+int sfmloc_abi_version(void);
+/* number of HIP devices visible (0 on a CPU-only box); never fails */
+int sfmloc_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Parameters: the reference's CLI keys (localization.cpp:64-82) and its      */
+/* compile-time constants (localization.cpp:56-58).                            */
+/* ------------------------------------------------------------------------- */
+typedef struct sfmloc_params {
+  float dist_ratio;         /* -f fDistRatio, default 0.6 */
+  int ransac_round;         /* -r ransacRound (F-matrix AC-RANSAC iterations), default 200; callers pass 25 */
+  double geom_precision;    /* -g geomLimit, default 4.0 px */
+  int bow_knn;              /* -k knnbow, 0 = no shortlist */
+  int min_putative;         /* MINUM_NUMBER_OF_POINT_PUTATIVE_MATCH = 16 */
+  int min_resection_points; /* MINUM_NUMBER_OF_POINT_RESECTION = 8 (test is ">") */
+  int min_inliers;          /* MINUM_NUMBER_OF_INLIER_RESECTION = 10 (test is ">") */
+  int p3p_max_iteration;    /* OpenMVG Image_Localizer_Match_Data::max_iteration default 4096 */
+  uint64_t seed;            /* counter-based RNG seed (the reference's RNG is unseeded) */
+  int refine_pose;          /* north-star extension A13; 0 = reference-equivalent output */
+  int device;               /* HIP device ordinal */
+  int profile;              /* 1 = bracket each kernel with HIP events on the handle's stream */
+} sfmloc_params;
+
+void sfmloc_default_params(sfmloc_params *p);
+
+/* ------------------------------------------------------------------------- */
+/* Map (= what the reference loads once: localization.cpp:238-280).            */
+/* Host arrays are copied to HBM; the caller may free them after the call.     */
+/* Views are the reconstruction's images in ascending view id; their           */
+/* descriptors are the rows [view_off[v], view_off[v+1]) of the bank, in .desc */
+/* file order (FileUtils.cpp:94-103).                                          */
+/* ------------------------------------------------------------------------- */
+typedef struct sfmloc_map_desc {
+  uint32_t n_views;
+  const uint32_t *view_id;      /* [n_views] strictly ascending */
+  const uint32_t *view_off;     /* [n_views+1] row offsets, view_off[0] = 0 */
+  const uint32_t *view_wh;      /* [n_views*2] image width,height (sfm_data views) or NULL */
+  uint64_t n_rows;              /* = view_off[n_views] */
+  const uint8_t *desc;          /* [n_rows*64] .desc payload rows */
+  const float *kpt_xy;          /* [n_rows*2] .feat x,y or NULL (needed from the F-matrix stage on) */
+  const int32_t *row_landmark;  /* [n_rows] landmark slot of (view,feat) or -1, or NULL */
+  uint32_t n_landmarks;
+  const uint32_t *landmark_id;  /* [n_landmarks] structure keys */
+  const double *landmark_X;     /* [n_landmarks*3] */
+  /* intrinsic id 0 (localization.cpp:484-487): pinhole or pinhole_radial_k3 */
+  double focal, ppx, ppy, k1, k2, k3;
+  uint32_t bow_dim;             /* 0 = no BoW */
+  const float *bow;             /* [n_views*bow_dim] .bow vectors as f32 (BoFUtils.cpp:43-45) or NULL */
+} sfmloc_map_desc;
+
+typedef struct sfmloc_map sfmloc_map;
+
+/* replaces: Load(sfm_data) + structureToMapViewFeatTo3D + HuloSfMRegionsProvider::load
+ * (localization.cpp:238-248,274-280), fed from memory */
+int sfmloc_map_create(const sfmloc_map_desc *desc, const sfmloc_params *params, sfmloc_map **out);
+void sfmloc_map_destroy(sfmloc_map *map);
+
+typedef struct sfmloc_map_info {
+  uint64_t n_rows;
+  uint32_t n_views;
+  uint32_t n_landmarks;
+  uint64_t hbm_bytes; /* device memory held by the handle */
+  int device;
+} sfmloc_map_info;
+int sfmloc_map_get_info(const sfmloc_map *map, sfmloc_map_info *info);
+
+/* ------------------------------------------------------------------------- */
+/* Query (= the output of extractAKAZESingleImg, AKAZEOpenCV.cpp:37-113).      */
+/* Uploading it is separate from matching so that callers (and bench.py) can   */
+/* have inputs resident in HBM before the timed region.                        */
+/* ------------------------------------------------------------------------- */
+typedef struct sfmloc_query sfmloc_query;
+
+int sfmloc_query_create(sfmloc_map *map, const uint8_t *desc /*[n*64]*/, const float *kpt_xy /*[n*2] or NULL*/,
+                        uint32_t n, uint32_t width, uint32_t height, sfmloc_query **out);
+void sfmloc_query_destroy(sfmloc_query *q);
+
+/* ------------------------------------------------------------------------- */
+/* Stage A6+A7: putative matching.                                             */
+/* replaces hulo::matchAKAZEToQuery (MatchUtils.cpp:283-367) with an exact     */
+/* 2-NN in place of the reference's LSH, then the "< 16 matches" filter        */
+/* (localization.cpp:408-415).                                                 */
+/*   view_sel: indices into the map's view table (NOT view ids), strictly      */
+/*   ascending, or NULL for all views (localization.cpp:386-392).              */
+/* Results stay on the device for the next stage; sfmloc_putative_read copies  */
+/* them out.  Asynchronous on the handle's stream.                             */
+/* ------------------------------------------------------------------------- */
+int sfmloc_match_putative(sfmloc_map *map, sfmloc_query *q, const uint32_t *view_sel, uint32_t n_sel);
+
+/* Blocks until the stream is idle, then copies out
+ *   view_count[n_views]          matches per view (0 for unselected views), BEFORE the >=16 filter
+ *   match_i/match_j/match_d[cap] per-view lists, view v's list starting at row offset view_off[v]
+ *                                (so cap must be >= n_rows), in ascending map-feature index i.
+ * Any pointer may be NULL. */
+int sfmloc_putative_read(sfmloc_map *map, uint32_t *view_count, uint32_t *match_i, uint32_t *match_j,
+                         uint32_t *match_d, uint64_t cap);
+
+/* Per-row view of the same stage (parity tests): key[r] = (d0<<16)|j0 of the nearest query
+ * descriptor and of the second nearest, for every bank row that was searched, SFMLOC_NOMATCH elsewhere. */
+int sfmloc_putative_read_rows(sfmloc_map *map, uint32_t *best0 /*[n_rows]*/, uint32_t *best1 /*[n_rows]*/);
+
+int sfmloc_sync(sfmloc_map *map);
+
+/* ------------------------------------------------------------------------- */
+/* Measurement (params.profile = 1): accumulated HIP-event time per kernel on  */
+/* the handle's stream.                                                        */
+/* ------------------------------------------------------------------------- */
+enum { SFMLOC_K_HAMMING = 0, SFMLOC_K_COMPACT = 1, SFMLOC_K_COUNT = 8 };
+typedef struct sfmloc_kernel_stats {
+  double total_ms[SFMLOC_K_COUNT];
+  uint64_t launches[SFMLOC_K_COUNT];
+  uint64_t hamming_pairs;      /* bank rows x query rows compared since reset */
+  uint64_t hamming_alg_bytes;  /* 64*rows + 64*Nq + 12*matches is finalised by the caller */
+} sfmloc_kernel_stats;
+int sfmloc_stats_read(sfmloc_map *map, sfmloc_kernel_stats *out); /* synchronises */
+int sfmloc_stats_reset(sfmloc_map *map);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFMLOC_H */

@@ -1,0 +1,13 @@
+"""MI355X-native query localisation for hulop/SfMLocalization maps.
+
+The compute path is libsfmloc_hip.so (hand-written HIP for gfx950) behind the C ABI of
+include/sfmloc.h; this package is the thin ctypes shim plus the host-side mirror of the
+reference's interface for that path.  There is no CPU fallback.
+"""
+from . import _lib  # noqa: F401
+from .capi import (  # noqa: F401
+    SfmlocError, Params, MapDesc, Map, Query, KernelStats, default_params, device_count, NOMATCH,
+)
+
+__all__ = ["SfmlocError", "Params", "MapDesc", "Map", "Query", "KernelStats", "default_params",
+           "device_count", "NOMATCH"]

@@ -1,0 +1,268 @@
+"""ctypes mirror of include/sfmloc.h (one Python method per C entry point, same names and meaning)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+NOMATCH = 0xFFFFFFFF
+K_HAMMING, K_COMPACT, K_COUNT = 0, 1, 8
+
+OK, EINVAL, ENODEV, EHIP, EIO, ECAP, ENOMEM = 0, -1, -2, -3, -4, -5, -6
+
+
+class SfmlocError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sfmloc error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("dist_ratio", C.c_float),
+        ("ransac_round", C.c_int),
+        ("geom_precision", C.c_double),
+        ("bow_knn", C.c_int),
+        ("min_putative", C.c_int),
+        ("min_resection_points", C.c_int),
+        ("min_inliers", C.c_int),
+        ("p3p_max_iteration", C.c_int),
+        ("seed", C.c_uint64),
+        ("refine_pose", C.c_int),
+        ("device", C.c_int),
+        ("profile", C.c_int),
+    ]
+
+
+class MapDesc(C.Structure):
+    _fields_ = [
+        ("n_views", C.c_uint32),
+        ("view_id", C.POINTER(C.c_uint32)),
+        ("view_off", C.POINTER(C.c_uint32)),
+        ("view_wh", C.POINTER(C.c_uint32)),
+        ("n_rows", C.c_uint64),
+        ("desc", C.POINTER(C.c_uint8)),
+        ("kpt_xy", C.POINTER(C.c_float)),
+        ("row_landmark", C.POINTER(C.c_int32)),
+        ("n_landmarks", C.c_uint32),
+        ("landmark_id", C.POINTER(C.c_uint32)),
+        ("landmark_X", C.POINTER(C.c_double)),
+        ("focal", C.c_double), ("ppx", C.c_double), ("ppy", C.c_double),
+        ("k1", C.c_double), ("k2", C.c_double), ("k3", C.c_double),
+        ("bow_dim", C.c_uint32),
+        ("bow", C.POINTER(C.c_float)),
+    ]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_views", C.c_uint32), ("n_landmarks", C.c_uint32),
+                ("hbm_bytes", C.c_uint64), ("device", C.c_int)]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("total_ms", C.c_double * K_COUNT), ("launches", C.c_uint64 * K_COUNT),
+                ("hamming_pairs", C.c_uint64), ("hamming_alg_bytes", C.c_uint64)]
+
+
+# every symbol include/sfmloc.h declares (tests check the library exports each one)
+SYMBOLS = [
+    "sfmloc_last_error", "sfmloc_abi_version", "sfmloc_device_count", "sfmloc_default_params",
+    "sfmloc_map_create", "sfmloc_map_destroy", "sfmloc_map_get_info",
+    "sfmloc_query_create", "sfmloc_query_destroy",
+    "sfmloc_match_putative", "sfmloc_putative_read", "sfmloc_putative_read_rows", "sfmloc_sync",
+    "sfmloc_stats_read", "sfmloc_stats_reset",
+]
+
+_bound = False
+
+
+def _L():
+    global _bound
+    L = _lib.load()
+    if not _bound:
+        L.sfmloc_last_error.restype = C.c_char_p
+        L.sfmloc_abi_version.restype = C.c_int
+        L.sfmloc_device_count.restype = C.c_int
+        L.sfmloc_default_params.restype = None
+        L.sfmloc_default_params.argtypes = [C.POINTER(Params)]
+        L.sfmloc_map_create.argtypes = [C.POINTER(MapDesc), C.POINTER(Params), C.POINTER(C.c_void_p)]
+        L.sfmloc_map_destroy.restype = None
+        L.sfmloc_map_destroy.argtypes = [C.c_void_p]
+        L.sfmloc_map_get_info.argtypes = [C.c_void_p, C.POINTER(MapInfo)]
+        L.sfmloc_query_create.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_uint32,
+                                          C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sfmloc_query_destroy.restype = None
+        L.sfmloc_query_destroy.argtypes = [C.c_void_p]
+        L.sfmloc_match_putative.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        L.sfmloc_putative_read.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4 + [C.c_uint64]
+        L.sfmloc_putative_read_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.sfmloc_sync.argtypes = [C.c_void_p]
+        L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
+        L.sfmloc_stats_reset.argtypes = [C.c_void_p]
+        _bound = True
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SfmlocError(rc, _L().sfmloc_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+def device_count():
+    return int(_L().sfmloc_device_count())
+
+
+def default_params(**overrides):
+    p = Params()
+    _L().sfmloc_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Map:
+    """Owns a sfmloc_map handle: the reconstruction's descriptor bank (and, later, its keypoints,
+    landmarks and BoW vectors) resident in HBM -- what localization.cpp:238-280 loads once."""
+
+    def __init__(self, view_id, view_off, desc, params=None, view_wh=None, kpt_xy=None, row_landmark=None,
+                 landmark_id=None, landmark_X=None, intrinsic=None, bow=None):
+        self._h = None
+        self.view_id = np.ascontiguousarray(view_id, dtype=np.uint32)
+        self.view_off = np.ascontiguousarray(view_off, dtype=np.uint32)
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 64)
+        self.n_rows = desc.shape[0]
+        self.n_views = self.view_id.shape[0]
+        keep = [self.view_id, self.view_off, desc]
+        d = MapDesc()
+        d.n_views = self.n_views
+        d.view_id = _ptr(self.view_id, C.c_uint32)
+        d.view_off = _ptr(self.view_off, C.c_uint32)
+        d.n_rows = self.n_rows
+        d.desc = _ptr(desc, C.c_uint8)
+        if view_wh is not None:
+            view_wh = np.ascontiguousarray(view_wh, dtype=np.uint32).reshape(-1, 2)
+            keep.append(view_wh)
+            d.view_wh = _ptr(view_wh, C.c_uint32)
+        if kpt_xy is not None:
+            kpt_xy = np.ascontiguousarray(kpt_xy, dtype=np.float32).reshape(-1, 2)
+            keep.append(kpt_xy)
+            d.kpt_xy = _ptr(kpt_xy, C.c_float)
+        if row_landmark is not None:
+            row_landmark = np.ascontiguousarray(row_landmark, dtype=np.int32)
+            landmark_id = np.ascontiguousarray(landmark_id, dtype=np.uint32)
+            landmark_X = np.ascontiguousarray(landmark_X, dtype=np.float64).reshape(-1, 3)
+            keep += [row_landmark, landmark_id, landmark_X]
+            d.row_landmark = _ptr(row_landmark, C.c_int32)
+            d.n_landmarks = landmark_id.shape[0]
+            d.landmark_id = _ptr(landmark_id, C.c_uint32)
+            d.landmark_X = _ptr(landmark_X, C.c_double)
+        if intrinsic is not None:
+            d.focal, d.ppx, d.ppy = intrinsic[:3]
+            if len(intrinsic) >= 6:
+                d.k1, d.k2, d.k3 = intrinsic[3:6]
+        if bow is not None:
+            bow = np.ascontiguousarray(bow, dtype=np.float32).reshape(self.n_views, -1)
+            keep.append(bow)
+            d.bow_dim = bow.shape[1]
+            d.bow = _ptr(bow, C.c_float)
+        self.params = params if params is not None else default_params()
+        h = C.c_void_p()
+        _check(_L().sfmloc_map_create(C.byref(d), C.byref(self.params), C.byref(h)))
+        self._h = h
+        del keep
+
+    def close(self):
+        if self._h is not None:
+            _L().sfmloc_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def info(self):
+        i = MapInfo()
+        _check(_L().sfmloc_map_get_info(self._h, C.byref(i)))
+        return {"n_rows": i.n_rows, "n_views": i.n_views, "n_landmarks": i.n_landmarks,
+                "hbm_bytes": i.hbm_bytes, "device": i.device}
+
+    def query(self, desc, kpt_xy=None, width=0, height=0):
+        return Query(self, desc, kpt_xy, width, height)
+
+    def match_putative(self, q, view_sel=None):
+        """sfmloc_match_putative: asynchronous; results stay on the device."""
+        if view_sel is None:
+            _check(_L().sfmloc_match_putative(self._h, q._h, None, 0))
+        else:
+            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
+            _check(_L().sfmloc_match_putative(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+
+    def putative_read(self):
+        """-> view_count[V], match_i, match_j, match_d (each [n_rows]; view v's list at view_off[v])."""
+        cnt = np.zeros(self.n_views, np.uint32)
+        mi = np.full(self.n_rows, NOMATCH, np.uint32)
+        mj = np.full(self.n_rows, NOMATCH, np.uint32)
+        md = np.full(self.n_rows, NOMATCH, np.uint32)
+        _check(_L().sfmloc_putative_read(self._h, _ptr(cnt, C.c_uint32), _ptr(mi, C.c_uint32),
+                                         _ptr(mj, C.c_uint32), _ptr(md, C.c_uint32), self.n_rows))
+        return cnt, mi, mj, md
+
+    def putative_read_rows(self):
+        b0 = np.empty(self.n_rows, np.uint32)
+        b1 = np.empty(self.n_rows, np.uint32)
+        _check(_L().sfmloc_putative_read_rows(self._h, _ptr(b0, C.c_uint32), _ptr(b1, C.c_uint32)))
+        return b0, b1
+
+    def sync(self):
+        _check(_L().sfmloc_sync(self._h))
+
+    def stats(self):
+        s = KernelStats()
+        _check(_L().sfmloc_stats_read(self._h, C.byref(s)))
+        return s
+
+    def stats_reset(self):
+        _check(_L().sfmloc_stats_reset(self._h))
+
+
+class Query:
+    """A query image's descriptors/keypoints resident in HBM (output of extractAKAZESingleImg,
+    AKAZEOpenCV.cpp:37-113)."""
+
+    def __init__(self, m, desc, kpt_xy=None, width=0, height=0):
+        self._h = None
+        self.map = m
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 64)
+        self.n = desc.shape[0]
+        if kpt_xy is not None:
+            kpt_xy = np.ascontiguousarray(kpt_xy, dtype=np.float32).reshape(-1, 2)
+            assert kpt_xy.shape[0] == self.n
+        h = C.c_void_p()
+        _check(_L().sfmloc_query_create(m._h, _ptr(desc, C.c_uint8), _ptr(kpt_xy, C.c_float), self.n,
+                                        int(width), int(height), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            _L().sfmloc_query_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,204 @@
+// K1 / K2 of the query-localisation path, written for gfx950 (MI355X, wave64).
+//
+//   K1  k_hamming_top2          exact 2-NN (Hamming over 64 stored bytes) of every bank row among the
+//                               query's descriptors                      [reference: MatchUtils.cpp:331-340,
+//                               where an approximate LSH index stands in for this search]
+//   K2  k_merge_ratio_compact   Lowe ratio in the reference's float32 expression + per-view ordered
+//                               compaction + per-view count              [MatchUtils.cpp:343-355,
+//                               localization.cpp:408-415]
+//
+// Search direction is map -> query: one LANE owns one bank row (16 dwords in VGPRs), the
+// query block sits in LDS and every lane of a wave reads the same query row (LDS broadcast).  Per
+// (bank row, query row) pair the VALU cost is 16 v_xor_b32 + 16 v_bcnt_u32_b32 (accumulating form) +
+// 1 v_lshl_or_b32 (pack (distance<<16)|query index) + v_med3_u32 + v_min_u32 (running top-2 on the
+// packed key; lower query index wins ties because it makes the key smaller).  The kernel is VALU bound
+// for N_q >~ 10; the bank is read exactly once per launch in fully coalesced 1 KiB pieces
+// thanks to the tiled64 layout (sfmloc_internal.h).
+#include "sfmloc_internal.h"
+
+namespace sfmloc {
+
+namespace {
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// keep (b0 <= b1) = two smallest keys seen so far
+__device__ __forceinline__ void top2_push(uint32_t &b0, uint32_t &b1, uint32_t key) {
+  b1 = umed3(b0, b1, key);
+  b0 = min(b0, key);
+}
+
+// row-major .desc rows -> tiled64 (see sfmloc_internal.h). One thread per uint4.
+__global__ __launch_bounds__(256) void k_tile_bank(const uint4 *__restrict__ rows, uint64_t row0,
+                                                   uint64_t n_rows_chunk, uint4 *__restrict__ bank) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index of uint4 inside the chunk
+  if (t >= n_rows_chunk * 4) return;
+  uint64_t row = row0 + (t >> 2);
+  uint32_t plane = (uint32_t)(t & 3);
+  uint64_t block = row >> 6;
+  uint32_t lane = (uint32_t)(row & 63);
+  bank[(block * 4 + plane) * 64 + lane] = rows[t];
+}
+
+template <int R, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
+    const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
+    const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t q_chunk, uint32_t lds_rows,
+    uint2 *__restrict__ part, uint64_t part_stride) {
+  extern __shared__ uint4 qs[];  // lds_rows x 4 uint4: a slice of the query block, row major
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t j_begin = blockIdx.y * q_chunk;
+  const uint32_t j_end = min(nq, j_begin + q_chunk);
+
+  // The R bank blocks of this wave; lane l owns row l of each.
+  const uint32_t w0 = (blockIdx.x * WAVES + wave) * R;
+  uint32_t blk[R];
+  uint32_t b[R][16];
+  uint32_t best0[R], best1[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t widx = w0 + r;
+    const bool valid = widx < n_work_blocks;
+    blk[r] = valid ? (block_list ? block_list[widx] : widx) : 0xFFFFFFFFu;
+    best0[r] = best1[r] = SFMLOC_NOMATCH;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (valid) v = bank[((uint64_t)blk[r] * 4 + c) * 64 + lane];
+      b[r][4 * c + 0] = v.x;
+      b[r][4 * c + 1] = v.y;
+      b[r][4 * c + 2] = v.z;
+      b[r][4 * c + 3] = v.w;
+    }
+  }
+  const bool wave_has_work = w0 < n_work_blocks;  // wave uniform
+
+  for (uint32_t j0 = j_begin; j0 < j_end; j0 += lds_rows) {
+    const uint32_t cnt = min(lds_rows, j_end - j0);
+    __syncthreads();  // the previous slice has been consumed by every wave
+    for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
+    __syncthreads();
+    if (wave_has_work) {
+#pragma unroll 2
+      for (uint32_t jj = 0; jj < cnt; ++jj) {
+        const uint4 q0 = qs[jj * 4 + 0];
+        const uint4 q1 = qs[jj * 4 + 1];
+        const uint4 q2 = qs[jj * 4 + 2];
+        const uint4 q3 = qs[jj * 4 + 3];
+        const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        const uint32_t j = j0 + jj;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          uint32_t acc = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[r][k] ^ q[k]);
+          top2_push(best0[r], best1[r], (acc << 16) | j);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (blk[r] != 0xFFFFFFFFu)
+      part[(uint64_t)blockIdx.y * part_stride + (uint64_t)blk[r] * 64 + lane] = make_uint2(best0[r], best1[r]);
+  }
+}
+
+// One wave per selected view.  Merges the per-split partial top-2, applies the ratio test through a
+// 513-entry table (ratio_cnt[d1] = number of d0 values for which the reference's float expression
+// (0.0f + d0) / d1 < ratio holds; the accepted d0 are exactly 0..cnt-1 because IEEE division is
+// monotone), and compacts accepted rows in ascending row order.
+__global__ __launch_bounds__(256) void k_merge_ratio_compact(
+    const uint2 *__restrict__ part, uint64_t part_stride, uint32_t split, const uint32_t *__restrict__ view_sel,
+    uint32_t n_sel, const uint32_t *__restrict__ view_off, const uint16_t *__restrict__ ratio_cnt,
+    uint32_t *__restrict__ view_count, uint32_t *__restrict__ match_i, uint32_t *__restrict__ match_key) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= n_sel) return;
+  const uint32_t v = view_sel ? view_sel[gw] : gw;
+  const uint32_t off = view_off[v], end = view_off[v + 1];
+  uint32_t base = 0;
+  for (uint32_t r0 = off; r0 < end; r0 += 64) {
+    const uint32_t r = r0 + lane;
+    const bool valid = r < end;
+    uint32_t b0 = SFMLOC_NOMATCH, b1 = SFMLOC_NOMATCH;
+    if (valid) {
+      for (uint32_t s = 0; s < split; ++s) {
+        const uint2 p = part[(uint64_t)s * part_stride + r];
+        top2_push(b0, b1, p.x);
+        top2_push(b0, b1, p.y);
+      }
+    }
+    // b1 == NOMATCH <=> fewer than two query descriptors: the reference then has no second
+    // neighbour (MatchUtils.cpp:349) -> reject.
+    const bool accept = valid && b1 != SFMLOC_NOMATCH && (b0 >> 16) < (uint32_t)ratio_cnt[b1 >> 16];
+    const unsigned long long mask = __ballot(accept);
+    if (accept) {
+      const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      match_i[off + pos] = r - off;
+      match_key[off + pos] = b0;
+    }
+    base += (uint32_t)__popcll(mask);
+  }
+  if (lane == 0) view_count[v] = base;
+}
+
+template <int R, int WAVES>
+int launch_hamming_t(Map *m, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
+  const uint32_t nq = q->n;
+  const uint32_t q_chunk = (nq + split - 1) / split;
+  // LDS slice: as much of the split's query rows as fit in 128 KiB (gfx950 has 160 KiB per CU)
+  uint32_t lds_rows = q_chunk < 2048u ? q_chunk : 2048u;
+  if (lds_rows == 0) lds_rows = 1;
+  const size_t lds_bytes = (size_t)lds_rows * 64;
+  auto kern = k_hamming_top2<R, WAVES>;
+  SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes));
+  dim3 grid((n_work_blocks + WAVES * R - 1) / (WAVES * R), split);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, m->stream, m->d_bank,
+                     use_list ? m->d_block_list : nullptr, n_work_blocks, q->d_desc, nq, q_chunk, lds_rows,
+                     m->d_part, (uint64_t)m->n_blocks * 64);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+}  // namespace
+
+int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, uint4 *d_bank, hipStream_t s) {
+  if (n_rows_chunk == 0) return SFMLOC_OK;
+  const uint64_t n = n_rows_chunk * 4;
+  hipLaunchKernelGGL(k_tile_bank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_rows, row0, n_rows_chunk,
+                     d_bank);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_hamming_top2(Map *m, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
+  if (n_work_blocks == 0 || q->n == 0) return SFMLOC_OK;
+  // Geometry: 16 waves x 4 blocks when there is enough work to fill the chip twice over, smaller
+  // tiles otherwise so that a short list still spreads over the 256 CUs.
+  const uint64_t big = (uint64_t)m->n_cu * 16 * 4;
+  if ((uint64_t)n_work_blocks * split >= 2 * big) return launch_hamming_t<4, 16>(m, q, n_work_blocks, use_list, split);
+  if ((uint64_t)n_work_blocks * split >= big / 2) return launch_hamming_t<2, 8>(m, q, n_work_blocks, use_list, split);
+  return launch_hamming_t<1, 4>(m, q, n_work_blocks, use_list, split);
+}
+
+int launch_merge_ratio_compact(Map *m, const Query *q, uint32_t n_sel, bool all_views, uint32_t split) {
+  (void)q;
+  if (n_sel == 0) return SFMLOC_OK;
+  hipLaunchKernelGGL(k_merge_ratio_compact, dim3((n_sel + 3) / 4), dim3(256), 0, m->stream, m->d_part,
+                     (uint64_t)m->n_blocks * 64, split, all_views ? nullptr : m->d_view_sel, n_sel, m->d_view_off,
+                     m->d_ratio_cnt, m->d_view_count, m->d_match_i, m->d_match_key);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+}  // namespace sfmloc

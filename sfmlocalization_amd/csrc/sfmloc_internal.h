@@ -1,0 +1,114 @@
+// Internal declarations shared by the HIP translation units of libsfmloc_hip.so.
+// Nothing here is part of the C ABI (include/sfmloc.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/sfmloc.h"
+
+namespace sfmloc {
+
+void set_error(const char *fmt, ...);
+
+#define SFM_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      ::sfmloc::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? SFMLOC_ENODEV           \
+             : (e_ == hipErrorOutOfMemory)                            ? SFMLOC_ENOMEM          \
+                                                                      : SFMLOC_EHIP;           \
+    }                                                                                          \
+  } while (0)
+
+#define SFM_CHECK(cond, code, ...)     \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::sfmloc::set_error(__VA_ARGS__); \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// HBM layout of the descriptor bank ("tiled64").
+// The .desc payload is row major, 64 B per descriptor.  A lane that owns one bank
+// row needs all 64 B of it in registers; loading that straight from the row-major
+// image makes every wave-instruction touch 64 different 64-B segments.  The bank is
+// therefore re-tiled ONCE at map load: rows are grouped in blocks of 64 (one per
+// lane of a wavefront) and each block is stored as 4 planes of 64 x 16 B:
+//     tiled[(block*4 + plane)*64 + lane] = row(block*64 + lane).uint4[plane]
+// so that the four global_load_dwordx4 a wave issues for a block are each one
+// contiguous, fully coalesced 1 KiB.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kBlockRows = 64;
+
+struct KernelTimer;  // capi.hip
+
+struct Map {
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  sfmloc_params params{};
+
+  // --- static map data ---
+  uint64_t n_rows = 0;
+  uint32_t n_blocks = 0;  // ceil(n_rows / 64)
+  uint32_t n_views = 0;
+  uint32_t n_landmarks = 0;
+  std::vector<uint32_t> h_view_id, h_view_off, h_view_wh;
+  uint4 *d_bank = nullptr;         // tiled64, n_blocks*64 rows (zero padded)
+  uint32_t *d_view_off = nullptr;  // [n_views+1]
+  uint32_t *d_view_id = nullptr;   // [n_views]
+  float2 *d_kpt = nullptr;         // [n_rows]
+  int32_t *d_row_landmark = nullptr;
+  uint32_t *d_landmark_id = nullptr;
+  double *d_landmark_X = nullptr;
+  double focal = 0, ppx = 0, ppy = 0, k1 = 0, k2 = 0, k3 = 0;
+  uint32_t bow_dim = 0;
+  float *d_bow = nullptr;
+  uint64_t hbm_bytes = 0;
+
+  // --- per-call workspace (putative stage) ---
+  uint32_t max_split = 8;
+  uint2 *d_part = nullptr;        // [max_split][n_blocks*64] partial (best0,best1)
+  uint32_t *d_view_sel = nullptr;  // [n_views] selected view indices
+  uint32_t *d_block_list = nullptr;  // [n_blocks]
+  uint32_t *h_pinned = nullptr;      // pinned staging for view_sel + block_list
+  uint32_t *d_view_count = nullptr;  // [n_views]
+  uint32_t *d_match_i = nullptr;     // [n_rows]
+  uint32_t *d_match_key = nullptr;   // [n_rows]  (d0<<16)|j0
+  uint16_t *d_ratio_cnt = nullptr;   // [513]
+  float ratio_cnt_for = -1.0f;       // ratio the table was built for
+
+  // state of the last putative call
+  uint32_t last_split = 0;
+  uint32_t last_nq = 0;
+  uint32_t last_n_sel = 0;
+  bool last_all_views = false;
+  uint32_t last_n_work_blocks = 0;
+  std::vector<uint32_t> last_blocks;  // host copy of the block list (empty = all)
+
+  // --- measurement ---
+  sfmloc_kernel_stats stats{};
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+};
+
+struct Query {
+  Map *map = nullptr;
+  uint32_t n = 0, width = 0, height = 0;
+  uint4 *d_desc = nullptr;  // [n_pad*4], row major, zero padded to a multiple of 64 rows
+  float2 *d_kpt = nullptr;
+  std::vector<float> h_kpt;
+};
+
+// hamming.hip
+int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, uint4 *d_bank, hipStream_t s);
+int launch_hamming_top2(Map *m, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split);
+int launch_merge_ratio_compact(Map *m, const Query *q, uint32_t n_sel, bool all_views, uint32_t split);
+
+}  // namespace sfmloc

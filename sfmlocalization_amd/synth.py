@@ -1,0 +1,253 @@
+"""Seeded synthetic maps and queries in the reference's data model.
+
+A map is what ExtFeatAndMatch + OpenMVG leave on disk for OpenMVGLocalization_AKAZE: per view a list of
+64-byte M-LDB rows (.desc) with keypoints (.feat), a structure of landmarks observed by (view, feat)
+pairs (sfm_data.json), one pinhole intrinsic.  Geometry is consistent (keypoints are projections of the
+landmarks), so every stage of the path has a planted answer: the query's true pose, the landmarks it
+sees and which of its descriptor copies sit at wrong image positions (outliers).
+
+Descriptor bytes: uniform random with bytes 61..63 and the top two bits of byte 60 zero (486 valid bits,
+FileUtils.cpp:77-92).  Not used by the product's compute path; bench.py and the tests build inputs here.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+VALID_BITS = 486
+
+
+def random_descriptors(rng, n):
+    d = rng.integers(0, 256, size=(n, 64), dtype=np.uint8)
+    d[:, 61:] = 0
+    d[:, 60] &= 0x3F
+    return d
+
+
+def flip_bits(rng, desc, max_flips):
+    """XOR up to max_flips random valid bit positions into each row (duplicates cancel)."""
+    n = desc.shape[0]
+    if n == 0 or max_flips <= 0:
+        return desc.copy()
+    k = rng.integers(0, max_flips + 1, size=n)
+    pos = rng.integers(0, VALID_BITS, size=(n, max_flips))
+    use = np.arange(max_flips)[None, :] < k[:, None]
+    rows = np.broadcast_to(np.arange(n)[:, None], pos.shape)[use]
+    p = pos[use]
+    out = desc.copy()
+    np.bitwise_xor.at(out, (rows, p >> 3), (1 << (p & 7)).astype(np.uint8))
+    return out
+
+
+def look_at(C, target, rng=None, jitter=0.0):
+    """World->camera rotations (rows = camera axes) for centres C [n,3] looking at target [n,3]."""
+    z = target - C
+    z /= np.linalg.norm(z, axis=1, keepdims=True)
+    if rng is not None and jitter > 0:
+        z = z + rng.normal(0, jitter, size=z.shape)
+        z /= np.linalg.norm(z, axis=1, keepdims=True)
+    up = np.array([0.0, 0.0, 1.0])
+    x = np.cross(np.broadcast_to(up, z.shape), z)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = np.cross(z, x)
+    return np.stack([x, y, z], axis=1)
+
+
+def project(R, C, X, f, ppx, ppy):
+    """Pinhole projection x = K (R (X - C)); returns pixel [n,2] and depth [n]."""
+    Xc = (X - C) @ R.T
+    z = Xc[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = f * Xc[:, 0] / z + ppx
+        v = f * Xc[:, 1] / z + ppy
+    return np.stack([u, v], axis=1), z
+
+
+def round6(a):
+    """What a float keeps after `ostream << float` at default precision and a read back
+    (AKAZEOpenCV.cpp:80-81 writes .feat that way; Regions::Load reads it back, :106-111)."""
+    a = np.asarray(a, dtype=np.float32)
+    flat = np.array([np.float32(float("%.6g" % v)) for v in a.ravel()], dtype=np.float32)
+    return flat.reshape(a.shape)
+
+
+@dataclass
+class SynthMap:
+    view_id: np.ndarray
+    view_off: np.ndarray
+    view_wh: np.ndarray
+    desc: np.ndarray            # [n_rows, 64] u8
+    kpt_xy: np.ndarray          # [n_rows, 2] f32
+    row_landmark: np.ndarray    # [n_rows] i32 slot or -1
+    landmark_id: np.ndarray     # [L] u32
+    landmark_X: np.ndarray      # [L, 3] f64
+    landmark_desc: np.ndarray   # [L, 64] u8 (generator's base descriptor, not part of the contract)
+    landmark_place: np.ndarray  # [L]
+    view_place: np.ndarray      # [V]
+    view_R: np.ndarray          # [V,3,3]
+    view_C: np.ndarray          # [V,3]
+    place_center: np.ndarray    # [P,3]
+    intrinsic: tuple            # (focal, ppx, ppy)
+    width: int = 640
+    height: int = 480
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def n_views(self):
+        return len(self.view_id)
+
+    @property
+    def n_rows(self):
+        return self.desc.shape[0]
+
+
+def make_map(seed, n_views, desc_per_view=2000, views_per_place=20, landmarks_per_place=600,
+             obs_per_view=250, map_flips=12, width=640, height=480, focal=800.0, kpt_noise=0.25,
+             ragged=False, view_id_stride=1):
+    """V views of `desc_per_view` rows; each view observes up to `obs_per_view` landmarks of its place,
+    the rest of its rows are clutter (random descriptor, random keypoint, no landmark)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ppx, ppy = width / 2.0, height / 2.0
+    n_places = max(1, (n_views + views_per_place - 1) // views_per_place)
+    side = int(np.ceil(np.sqrt(n_places)))
+    pc = np.array([[30.0 * (p % side), 30.0 * (p // side), 0.0] for p in range(n_places)])
+    L = n_places * landmarks_per_place
+    lm_place = np.repeat(np.arange(n_places), landmarks_per_place)
+    lm_X = pc[lm_place] + rng.uniform(-5.0, 5.0, size=(L, 3))
+    lm_desc = random_descriptors(rng, L)
+    lm_id = (np.arange(L, dtype=np.uint32) * 3 + 7).astype(np.uint32)  # structure keys need not be dense
+
+    view_place = (np.arange(n_views) // views_per_place).astype(np.int64)
+    # camera centres on a ring/cap 12..16 m from the place centre
+    az = rng.uniform(0, 2 * np.pi, n_views)
+    el = rng.uniform(-0.3, 0.6, n_views)
+    dist = rng.uniform(12.0, 16.0, n_views)
+    dirs = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=1)
+    vC = pc[view_place] + dirs * dist[:, None]
+    vR = look_at(vC, pc[view_place].copy(), rng, jitter=0.03)
+
+    if ragged:
+        counts = rng.integers(max(1, desc_per_view // 2), desc_per_view + 1, size=n_views)
+        counts[rng.integers(0, n_views)] = 0 if n_views > 3 else counts[0]
+    else:
+        counts = np.full(n_views, desc_per_view)
+    view_off = np.zeros(n_views + 1, dtype=np.uint32)
+    view_off[1:] = np.cumsum(counts)
+    n_rows = int(view_off[-1])
+
+    desc = random_descriptors(rng, n_rows)
+    kpt = np.stack([rng.uniform(0, width, n_rows), rng.uniform(0, height, n_rows)], axis=1).astype(np.float32)
+    row_lm = np.full(n_rows, -1, dtype=np.int32)
+
+    for v in range(n_views):
+        n_v = int(counts[v])
+        if n_v == 0:
+            continue
+        p = int(view_place[v])
+        cand = np.arange(p * landmarks_per_place, (p + 1) * landmarks_per_place)
+        px, z = project(vR[v], vC[v], lm_X[cand], focal, ppx, ppy)
+        ok = (z > 0.5) & (px[:, 0] >= 1) & (px[:, 0] < width - 1) & (px[:, 1] >= 1) & (px[:, 1] < height - 1)
+        vis = cand[ok]
+        pxv = px[ok]
+        n_obs = min(len(vis), obs_per_view, n_v)
+        if n_obs == 0:
+            continue
+        pick = rng.choice(len(vis), size=n_obs, replace=False)
+        rows = int(view_off[v]) + rng.choice(n_v, size=n_obs, replace=False)
+        row_lm[rows] = vis[pick]
+        kpt[rows] = (pxv[pick] + rng.normal(0, kpt_noise, size=(n_obs, 2))).astype(np.float32)
+        desc[rows] = flip_bits(rng, lm_desc[vis[pick]], map_flips)
+    kpt = round6(kpt) if n_rows <= 200000 else kpt  # .feat text round trip (exact for small maps; skipped for bench-size maps)
+    view_id = (np.arange(n_views, dtype=np.uint32) * view_id_stride).astype(np.uint32)
+    view_wh = np.tile(np.array([[width, height]], dtype=np.uint32), (n_views, 1))
+    return SynthMap(view_id=view_id, view_off=view_off, view_wh=view_wh, desc=desc, kpt_xy=kpt,
+                    row_landmark=row_lm, landmark_id=lm_id, landmark_X=lm_X, landmark_desc=lm_desc,
+                    landmark_place=lm_place, view_place=view_place, view_R=vR, view_C=vC, place_center=pc,
+                    intrinsic=(focal, ppx, ppy), width=width, height=height)
+
+
+@dataclass
+class SynthQuery:
+    desc: np.ndarray          # [n, 64]
+    kpt_xy: np.ndarray        # [n, 2] f32 (full precision, as locFeat, AKAZEOpenCV.cpp:77-79)
+    width: int
+    height: int
+    R_true: np.ndarray
+    C_true: np.ndarray
+    place: int
+    landmark: np.ndarray      # [n] landmark slot the descriptor was copied from, or -1
+    is_inlier: np.ndarray     # [n] bool: copy sits at its true projection
+
+
+def make_query(m: SynthMap, seed, n_feat=2000, n_copies=300, outlier_frac=0.3, query_flips=40,
+               noise_px=1.0, place=None):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    f, ppx, ppy = m.intrinsic
+    n_places = len(m.place_center)
+    p = int(rng.integers(0, n_places)) if place is None else int(place)
+    az, el, dist = rng.uniform(0, 2 * np.pi), rng.uniform(-0.2, 0.5), rng.uniform(12.0, 16.0)
+    d = np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    C = m.place_center[p] + d * dist
+    R = look_at(C[None, :], m.place_center[p][None, :].copy(), rng, jitter=0.03)[0]
+    cand = np.nonzero(m.landmark_place == p)[0]
+    px, z = project(R, C, m.landmark_X[cand], f, ppx, ppy)
+    ok = (z > 0.5) & (px[:, 0] >= 1) & (px[:, 0] < m.width - 1) & (px[:, 1] >= 1) & (px[:, 1] < m.height - 1)
+    vis, pxv = cand[ok], px[ok]
+    n_copies = min(n_copies, len(vis), n_feat)
+    pick = rng.choice(len(vis), size=n_copies, replace=False) if n_copies else np.zeros(0, np.int64)
+    n_out = int(round(n_copies * outlier_frac))
+    desc = random_descriptors(rng, n_feat)
+    kpt = np.stack([rng.uniform(0, m.width, n_feat), rng.uniform(0, m.height, n_feat)], axis=1)
+    lm = np.full(n_feat, -1, dtype=np.int64)
+    inl = np.zeros(n_feat, dtype=bool)
+    rows = rng.choice(n_feat, size=n_copies, replace=False) if n_copies else np.zeros(0, np.int64)
+    desc[rows] = flip_bits(rng, m.landmark_desc[vis[pick]], query_flips)
+    lm[rows] = vis[pick]
+    true_px = pxv[pick] + rng.normal(0, noise_px, size=(n_copies, 2))
+    is_out = np.zeros(n_copies, dtype=bool)
+    is_out[:n_out] = True
+    rng.shuffle(is_out)
+    kpt[rows[~is_out]] = true_px[~is_out]
+    inl[rows[~is_out]] = True
+    return SynthQuery(desc=desc, kpt_xy=kpt.astype(np.float32), width=m.width, height=m.height, R_true=R,
+                      C_true=C, place=p, landmark=lm, is_inlier=inl)
+
+
+def planted_bank(seed, n_rows=512, n_query=96):
+    """Small bank with planted near-duplicates at known distances, exact ties and d1 = 0 cases
+    (SURVEY.md 8c golden (i)).  Returns (query, bank)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    q = random_descriptors(rng, n_query)
+    bank = random_descriptors(rng, n_rows)
+
+    def flipped(row, k):
+        out = row.copy()
+        pos = rng.choice(VALID_BITS, size=k, replace=False)
+        for p_ in pos:
+            out[p_ >> 3] ^= np.uint8(1 << (p_ & 7))
+        return out
+
+    # query-side plants first (so that bank rows derived below stay consistent)
+    q[10] = q[3]           # exact ties: three identical query rows
+    q[50] = q[3]
+    a = q[20].copy()
+    b = flipped(a, 20)
+    q[21] = b              # rows 20/21 differ in exactly 20 bits
+
+    r = 0
+    for k in (0, 1, 5, 17, 40, 80, 120, 150):  # near-duplicates of query rows at known distances
+        for _ in range(8):
+            bank[r] = flipped(q[rng.integers(0, n_query)], k)
+            r += 1
+    # d0 == d1 == k, nearest must be the lower index (3, then 10)
+    for k in (0, 4, 33):
+        bank[r] = flipped(q[3], k)
+        r += 1
+    # equidistant from two different rows: 10 bits from a (index 20) and 10 from b (index 21)
+    mid = a.copy()
+    diff = np.unpackbits(a ^ b, bitorder="little")
+    idx = np.nonzero(diff)[0][:10]
+    for p_ in idx:
+        mid[p_ >> 3] ^= np.uint8(1 << (p_ & 7))
+    bank[r] = mid
+    r += 1
+    return q, bank

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_c():
+    from oracle import oracle_c as oc
+    oc.build()
+    return oc
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    import sfmlocalization_amd as s
+    return s.device_count() > 0
