@@ -14,7 +14,8 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "sfm_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle.c", "sfm_oracle_geom.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs if os.path.exists(f)):
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -29,6 +30,15 @@ def lib():
         _lib.orc_max_threads.restype = C.c_int
         _lib.orc_ratio_accept.restype = C.c_int
         _lib.orc_ratio_accept.argtypes = [C.c_int, C.c_int, C.c_float]
+        _lib.orc_det_log10.restype = C.c_double
+        _lib.orc_det_log10.argtypes = [C.c_double]
+        _lib.orc_solve_cubic.restype = C.c_int
+        _lib.orc_solve_cubic.argtypes = [C.c_double] * 4 + [C.POINTER(C.c_double)]
+        _lib.orc_seven_point.restype = C.c_int
+        _lib.orc_p3p_kneip.restype = C.c_int
+        _lib.orc_fmatrix_filter.restype = C.c_int
+        _lib.orc_p3p_localize.restype = C.c_int
+        _lib.orc_match_set.restype = C.c_int
     return _lib
 
 
@@ -74,3 +84,128 @@ def match_to_query(query, bank, view_off, view_sel=None, ratio=0.6, threads=1):
                              _p(cnt, C.c_uint32), _p(mi, C.c_uint32), _p(mj, C.c_uint32), _p(md, C.c_uint32),
                              C.c_int(threads))
     return cnt, mi, mj, md
+
+
+# ---------------------------------------------------------------------------------------------------
+# geometry (sfm_oracle_geom.c)
+# ---------------------------------------------------------------------------------------------------
+STAGE_FMATRIX, STAGE_P3P = 1, 2
+
+
+def det_log10(x):
+    return float(lib().orc_det_log10(C.c_double(x)))
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    lib().orc_philox4x32_10(c, C.c_uint32(key[0]), C.c_uint32(key[1]))
+    return [int(v) for v in c]
+
+
+def ac_sample(X, vec_index, seed, stage, stream, it):
+    vi = np.ascontiguousarray(vec_index, dtype=np.int32)
+    out = np.zeros(X, np.int32)
+    lib().orc_ac_sample(C.c_int(X), _p(vi, C.c_int32), C.c_int(len(vi)), C.c_uint64(seed), C.c_uint32(stage),
+                        C.c_uint32(stream), C.c_uint32(it), _p(out, C.c_int32))
+    return out
+
+
+def solve_cubic(a3, a2, a1, a0):
+    r = (C.c_double * 3)()
+    n = lib().orc_solve_cubic(a3, a2, a1, a0, r)
+    return [r[i] for i in range(n)]
+
+
+def solve_quartic_real(a):
+    a = (C.c_double * 5)(*a)
+    out = (C.c_double * 4)()
+    lib().orc_solve_quartic_real(a, out)
+    return [out[i] for i in range(4)]
+
+
+def seven_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(7, 2)
+    x2 = np.ascontiguousarray(x2, np.float64).reshape(7, 2)
+    F = np.zeros((3, 9), np.float64)
+    n = lib().orc_seven_point(_p(x1, C.c_double), _p(x2, C.c_double), _p(F, C.c_double))
+    return F[:n].reshape(n, 3, 3)
+
+
+def p3p_kneip(x2d, X):
+    x2d = np.ascontiguousarray(x2d, np.float64).reshape(3, 2)
+    X = np.ascontiguousarray(X, np.float64).reshape(3, 3)
+    M = np.zeros((4, 12), np.float64)
+    n = lib().orc_p3p_kneip(_p(x2d, C.c_double), _p(X, C.c_double), _p(M, C.c_double))
+    return M[:n].reshape(n, 3, 4)
+
+
+def logcombi_tables(s, n):
+    a = np.zeros(n + 1, np.float32)
+    b = np.zeros(n + 1, np.float32)
+    lib().orc_logcombi_tables(C.c_int(s), C.c_int(n), _p(a, C.c_float), _p(b, C.c_float))
+    return a, b
+
+
+def fmatrix_filter(x1, wh1, x2, wh2, precision, n_iter, seed, stream):
+    """-> dict(n, inliers, F, nfa, errmax, iters); GeometricFilter_FMatrix_AC for one pair."""
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 2)
+    m = x1.shape[0]
+    inl = np.full(max(m, 1), -1, np.int32)
+    F = np.zeros(9, np.float64)
+    nfa = C.c_double()
+    em = C.c_double()
+    it = C.c_int()
+    n = lib().orc_fmatrix_filter(_p(x1, C.c_double), C.c_int(wh1[0]), C.c_int(wh1[1]), _p(x2, C.c_double),
+                                 C.c_int(wh2[0]), C.c_int(wh2[1]), C.c_int(m), C.c_double(precision),
+                                 C.c_int(n_iter), C.c_uint64(seed), C.c_uint32(stream), _p(inl, C.c_int32),
+                                 _p(F, C.c_double), C.byref(nfa), C.byref(em), C.byref(it))
+    return {"n": n, "inliers": inl[:n].copy(), "F": F.reshape(3, 3), "nfa": nfa.value, "errmax": em.value,
+            "iters": it.value}
+
+
+def p3p_localize(pt2d, pt3d, focal, ppx, ppy, max_iteration, seed, stream=0):
+    pt2d = np.ascontiguousarray(pt2d, np.float64).reshape(-1, 2)
+    pt3d = np.ascontiguousarray(pt3d, np.float64).reshape(-1, 3)
+    n = pt2d.shape[0]
+    inl = np.full(max(n, 1), -1, np.int32)
+    P = np.zeros(12, np.float64)
+    nfa = C.c_double()
+    em = C.c_double()
+    it = C.c_int()
+    k = lib().orc_p3p_localize(_p(pt2d, C.c_double), _p(pt3d, C.c_double), C.c_int(n), C.c_double(focal),
+                               C.c_double(ppx), C.c_double(ppy), C.c_int(max_iteration), C.c_uint64(seed),
+                               C.c_uint32(stream), _p(inl, C.c_int32), _p(P, C.c_double), C.byref(em),
+                               C.byref(nfa), C.byref(it))
+    return {"n": k, "inliers": inl[:k].copy(), "P": P.reshape(3, 4), "nfa": nfa.value, "errmax": em.value,
+            "iters": it.value}
+
+
+def krt_from_p(P):
+    P = np.ascontiguousarray(P, np.float64).reshape(12)
+    K = np.zeros(9)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    lib().orc_krt_from_p(_p(P, C.c_double), _p(K, C.c_double), _p(R, C.c_double), _p(t, C.c_double))
+    c = np.zeros(3)
+    lib().orc_center_from_rt(_p(R, C.c_double), _p(t, C.c_double), _p(c, C.c_double))
+    return K.reshape(3, 3), R.reshape(3, 3), t, c
+
+
+def match_set(geo_view, geo_i, geo_j, view_off, put_count, put_i, put_j, put_d, row_landmark, nq):
+    gv = np.ascontiguousarray(geo_view, np.uint32)
+    gi = np.ascontiguousarray(geo_i, np.uint32)
+    gj = np.ascontiguousarray(geo_j, np.uint32)
+    vo = np.ascontiguousarray(view_off, np.uint32)
+    pc = np.ascontiguousarray(put_count, np.uint32)
+    pi = np.ascontiguousarray(put_i, np.uint32)
+    pj = np.ascontiguousarray(put_j, np.uint32)
+    pd = np.ascontiguousarray(put_d, np.uint32)
+    rl = np.ascontiguousarray(row_landmark, np.int32)
+    oq = np.zeros(max(nq, 1), np.uint32)
+    ol = np.zeros(max(nq, 1), np.int32)
+    n = lib().orc_match_set(_p(gv, C.c_uint32), _p(gi, C.c_uint32), _p(gj, C.c_uint32), C.c_int(len(gv)),
+                            _p(vo, C.c_uint32), _p(pc, C.c_uint32), _p(pi, C.c_uint32), _p(pj, C.c_uint32),
+                            _p(pd, C.c_uint32), _p(rl, C.c_int32), C.c_uint32(nq), _p(oq, C.c_uint32),
+                            _p(ol, C.c_int32))
+    return oq[:n].copy(), ol[:n].copy()
