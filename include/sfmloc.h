@@ -152,10 +152,79 @@ int sfmloc_putative_read_rows(sfmloc_map *map, uint32_t *best0 /*[n_rows]*/, uin
 int sfmloc_sync(sfmloc_map *map);
 
 /* ------------------------------------------------------------------------- */
+/* Stage A8: geometric filter.                                                 */
+/* replaces hulo::geometricMatch (MatchUtils.cpp:372-420) = OpenMVG            */
+/* GeometricFilter_FMatrix_AC(geomPrec, ransacRound) per (view, query) pair,   */
+/* on the result of the last sfmloc_match_putative call; views with fewer than */
+/* params.min_putative matches are dropped first (localization.cpp:408-415).   */
+/* Query keypoints are the .feat-rounded ones (6 significant digits), map      */
+/* keypoints come from the map's .feat (no undistortion: MatchUtils.cpp:381).  */
+/* ------------------------------------------------------------------------- */
+int sfmloc_geometric_filter(sfmloc_map *map, sfmloc_query *q);
+/* geo_count[n_views]; geo_idx[n_rows]: view v's inliers as indices into ITS putative list, stored at
+ * view_off[v], in AC-RANSAC's inlier order (ascending residual).  Synchronises. */
+int sfmloc_geometric_read(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_idx, uint64_t cap);
+
+/* ------------------------------------------------------------------------- */
+/* Stage A9+A10: 2D-3D match set.                                              */
+/* replaces hulo::matchProviderToMatchSet (SfMDataUtils.cpp:59-125) and the    */
+/* pt2D/pt3D assembly (localization.cpp:479-501).                              */
+/* ------------------------------------------------------------------------- */
+int sfmloc_match_set(sfmloc_map *map, sfmloc_query *q);
+int sfmloc_match_set_read(sfmloc_map *map, uint32_t *n, uint32_t *qfeat, uint32_t *landmark_id, double *pt2d,
+                          double *pt3d, uint32_t cap);
+
+/* ------------------------------------------------------------------------- */
+/* Stage A11+A12: resection and pose.                                          */
+/* replaces sfm::SfM_Localizer::Localize (localization.cpp:504-509; P3P        */
+/* AC-RANSAC, max_iteration = params.p3p_max_iteration), the inlier gate       */
+/* (localization.cpp:511) and KRt_From_P / t_out = -R^T t (:544-547).          */
+/* ------------------------------------------------------------------------- */
+typedef struct sfmloc_pose {
+  int32_t ok;                /* 1 = localised: what the reference signals by writing "t" into the result JSON */
+  int32_t n_inliers;         /* resection_data.vec_inliers.size() */
+  int32_t n_matches_2d3d;    /* mapFeatTo3DFeat.size() (cpt, localization.cpp:502) */
+  int32_t iterations;        /* AC-RANSAC iterations actually run */
+  int32_t status;            /* bit 0/1/2: a capacity of the device workspace was exceeded */
+  int32_t n_putative_views;  /* views with >= min_putative matches */
+  int32_t n_geometric_views; /* views that passed the F-matrix filter */
+  int32_t reserved;
+  double nfa;                /* AC-RANSAC minimum NFA (log10) */
+  double error_max;          /* resection_data.error_max (pixels) */
+  double P[12];              /* projection_matrix, row-major 3x4 */
+  double K[9], R[9], t[3];   /* KRt_From_P, row-major */
+  double center[3];          /* t_out = -R^T t: the "t" of the result JSON */
+  double stage_seconds[7];   /* LocalizeEngine.cc:643-658 buckets: selectBeacon, selectBow, extFeat, putMatch,
+                                geoMatch, PnP, others */
+} sfmloc_pose;
+
+int sfmloc_resection(sfmloc_map *map, sfmloc_query *q);
+/* pair_*: the "pair" list of the result JSON (localization.cpp:132-141): (query feature, landmark id) per
+ * inlier; inlier_idx: indices into the 2D-3D match set.  Synchronises. */
+int sfmloc_pose_read(sfmloc_map *map, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,
+                     uint32_t *inlier_idx, uint32_t cap);
+
+/* The whole per-query path: putative -> >=16 filter -> F-matrix filter -> 2D-3D set -> P3P -> pose
+ * (localization.cpp:395-547 / LocalizeEngine.cc:423-585).  One host synchronisation at the end. */
+int sfmloc_localize(sfmloc_map *map, sfmloc_query *q, const uint32_t *view_sel, uint32_t n_sel, sfmloc_pose *out,
+                    uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t cap);
+
+/* Parity probe: runs one of the f64 device building blocks over n items (tests compare with the oracle).
+ * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample */
+int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride);
+
+/* ------------------------------------------------------------------------- */
 /* Measurement (params.profile = 1): accumulated HIP-event time per kernel on  */
 /* the handle's stream.                                                        */
 /* ------------------------------------------------------------------------- */
-enum { SFMLOC_K_HAMMING = 0, SFMLOC_K_COMPACT = 1, SFMLOC_K_COUNT = 8 };
+enum {
+  SFMLOC_K_HAMMING = 0,
+  SFMLOC_K_COMPACT = 1,
+  SFMLOC_K_FMATRIX = 2,
+  SFMLOC_K_MATCHSET = 3,
+  SFMLOC_K_P3P = 4,
+  SFMLOC_K_COUNT = 8
+};
 typedef struct sfmloc_kernel_stats {
   double total_ms[SFMLOC_K_COUNT];
   uint64_t launches[SFMLOC_K_COUNT];

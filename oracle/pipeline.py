@@ -1,0 +1,68 @@
+"""The per-query path of the reference composed from the oracle's stage functions, in the order of
+OpenMVGLocalization_AKAZE/src/localization.cpp:395-547.  TEST INFRASTRUCTURE ONLY (parity unpinned)."""
+import numpy as np
+
+from . import oracle_c
+
+
+def round6(a):
+    """.feat text round trip: `ostream << float` (6 significant digits) then read back
+    (AKAZEOpenCV.cpp:80-81,106-111)."""
+    a = np.asarray(a, dtype=np.float32)
+    flat = np.array([np.float32(float("%.6g" % float(v))) for v in a.ravel()], dtype=np.float32)
+    return flat.reshape(a.shape)
+
+
+def localize(m, q_desc, q_kpt, q_wh, view_sel=None, ratio=0.6, ransac_round=25, geom_precision=4.0,
+             min_putative=16, min_resection_points=8, min_inliers=10, p3p_max_iteration=4096,
+             seed=0x5f3759df12345678, threads=4):
+    """m: object with view_id, view_off, view_wh, desc, kpt_xy, row_landmark, landmark_id, landmark_X,
+    intrinsic.  Returns a dict with every intermediate the product exposes."""
+    out = {}
+    nq = q_desc.shape[0]
+    cnt, mi, mj, md = oracle_c.match_to_query(q_desc, m.desc, m.view_off, view_sel, ratio, threads=threads)
+    out["put_count"], out["put_i"], out["put_j"], out["put_d"] = cnt, mi, mj, md
+    nv = len(m.view_id)
+    q6 = round6(q_kpt).astype(np.float64)
+    geo_count = np.zeros(nv, np.uint32)
+    geo_idx = np.full(m.desc.shape[0], 0xFFFFFFFF, np.uint32)
+    gv, gi, gj = [], [], []
+    f_stats = {}
+    for v in range(nv):
+        c = int(cnt[v])
+        if c < min_putative:               # localization.cpp:408-415
+            continue
+        off = int(m.view_off[v])
+        ii = mi[off:off + c].astype(np.int64)
+        jj = mj[off:off + c].astype(np.int64)
+        x1 = m.kpt_xy[off + ii].astype(np.float64)
+        x2 = q6[jj]
+        r = oracle_c.fmatrix_filter(x1, tuple(int(t) for t in m.view_wh[v]), x2, q_wh, geom_precision,
+                                    ransac_round, seed, stream=int(m.view_id[v]))
+        f_stats[v] = r
+        if r["n"] > 0:
+            geo_count[v] = r["n"]
+            geo_idx[off:off + r["n"]] = r["inliers"]
+            for p in r["inliers"]:
+                gv.append(v)
+                gi.append(int(ii[p]))
+                gj.append(int(jj[p]))
+    out["geo_count"], out["geo_idx"], out["f_stats"] = geo_count, geo_idx, f_stats
+    qf, lm_slot = oracle_c.match_set(gv, gi, gj, m.view_off, cnt, mi, mj, md, m.row_landmark, nq)
+    out["ms_qfeat"] = qf
+    out["ms_landmark"] = m.landmark_id[lm_slot] if len(lm_slot) else np.zeros(0, np.uint32)
+    pt2d = q_kpt[qf].astype(np.float64) if len(qf) else np.zeros((0, 2))
+    pt3d = m.landmark_X[lm_slot] if len(lm_slot) else np.zeros((0, 3))
+    out["pt2d"], out["pt3d"] = pt2d, pt3d
+    out["ok"] = False
+    out["n_inliers"] = 0
+    if len(qf) > min_resection_points:      # localization.cpp:506
+        f, ppx, ppy = m.intrinsic[:3]
+        r = oracle_c.p3p_localize(pt2d, pt3d, f, ppx, ppy, p3p_max_iteration, seed, stream=0)
+        out["p3p"] = r
+        out["n_inliers"] = r["n"] if r["n"] > 0 else 0
+        if r["n"] > 0 and r["n"] > min_inliers:   # localization.cpp:511
+            K, R, t, c = oracle_c.krt_from_p(r["P"])
+            out.update(ok=True, K=K, R=R, t=t, center=c, P=r["P"], inlier_idx=r["inliers"],
+                       pair_qfeat=qf[r["inliers"]], pair_landmark=out["ms_landmark"][r["inliers"]])
+    return out

@@ -6,7 +6,7 @@ import numpy as np
 from . import _lib
 
 NOMATCH = 0xFFFFFFFF
-K_HAMMING, K_COMPACT, K_COUNT = 0, 1, 8
+K_HAMMING, K_COMPACT, K_FMATRIX, K_MATCHSET, K_P3P, K_COUNT = 0, 1, 2, 3, 4, 8
 
 OK, EINVAL, ENODEV, EHIP, EIO, ECAP, ENOMEM = 0, -1, -2, -3, -4, -5, -6
 
@@ -59,6 +59,15 @@ class MapInfo(C.Structure):
                 ("hbm_bytes", C.c_uint64), ("device", C.c_int)]
 
 
+class Pose(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("n_inliers", C.c_int32), ("n_matches_2d3d", C.c_int32),
+                ("iterations", C.c_int32), ("status", C.c_int32), ("n_putative_views", C.c_int32),
+                ("n_geometric_views", C.c_int32), ("reserved", C.c_int32),
+                ("nfa", C.c_double), ("error_max", C.c_double),
+                ("P", C.c_double * 12), ("K", C.c_double * 9), ("R", C.c_double * 9), ("t", C.c_double * 3),
+                ("center", C.c_double * 3), ("stage_seconds", C.c_double * 7)]
+
+
 class KernelStats(C.Structure):
     _fields_ = [("total_ms", C.c_double * K_COUNT), ("launches", C.c_uint64 * K_COUNT),
                 ("hamming_pairs", C.c_uint64), ("hamming_alg_bytes", C.c_uint64)]
@@ -70,6 +79,8 @@ SYMBOLS = [
     "sfmloc_map_create", "sfmloc_map_destroy", "sfmloc_map_get_info",
     "sfmloc_query_create", "sfmloc_query_destroy",
     "sfmloc_match_putative", "sfmloc_putative_read", "sfmloc_putative_read_rows", "sfmloc_sync",
+    "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
+    "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
     "sfmloc_stats_read", "sfmloc_stats_reset",
 ]
 
@@ -97,6 +108,16 @@ def _L():
         L.sfmloc_putative_read.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4 + [C.c_uint64]
         L.sfmloc_putative_read_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.sfmloc_sync.argtypes = [C.c_void_p]
+        U32P, F64P = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+        L.sfmloc_geometric_filter.argtypes = [C.c_void_p, C.c_void_p]
+        L.sfmloc_geometric_read.argtypes = [C.c_void_p, U32P, U32P, C.c_uint64]
+        L.sfmloc_match_set.argtypes = [C.c_void_p, C.c_void_p]
+        L.sfmloc_match_set_read.argtypes = [C.c_void_p, U32P, U32P, U32P, F64P, F64P, C.c_uint32]
+        L.sfmloc_resection.argtypes = [C.c_void_p, C.c_void_p]
+        L.sfmloc_pose_read.argtypes = [C.c_void_p, C.POINTER(Pose), U32P, U32P, U32P, C.c_uint32]
+        L.sfmloc_localize.argtypes = [C.c_void_p, C.c_void_p, U32P, C.c_uint32, C.POINTER(Pose), U32P, U32P,
+                                      C.c_uint32]
+        L.sfmloc_debug_math.argtypes = [C.c_int, C.c_int, F64P, C.c_int, C.c_int, F64P, C.c_int]
         L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
         L.sfmloc_stats_reset.argtypes = [C.c_void_p]
         _bound = True
@@ -124,6 +145,17 @@ def default_params(**overrides):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def debug_math(op, x, out_stride, device=0):
+    """sfmloc_debug_math: run an f64 device building block over the rows of x."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[:, None]
+    out = np.zeros((x.shape[0], out_stride), np.float64)
+    _check(_L().sfmloc_debug_math(device, op, _ptr(x, C.c_double), x.shape[0], x.shape[1], _ptr(out, C.c_double),
+                                  out_stride))
+    return out
 
 
 class Map:
@@ -229,6 +261,58 @@ class Map:
 
     def sync(self):
         _check(_L().sfmloc_sync(self._h))
+
+    def geometric_filter(self, q):
+        _check(_L().sfmloc_geometric_filter(self._h, q._h))
+
+    def geometric_read(self):
+        """-> geo_count[V], geo_idx[n_rows] (indices into each view's putative list, AC-RANSAC inlier order)."""
+        cnt = np.zeros(self.n_views, np.uint32)
+        idx = np.full(self.n_rows, NOMATCH, np.uint32)
+        _check(_L().sfmloc_geometric_read(self._h, _ptr(cnt, C.c_uint32), _ptr(idx, C.c_uint32), self.n_rows))
+        return cnt, idx
+
+    def match_set(self, q):
+        _check(_L().sfmloc_match_set(self._h, q._h))
+
+    def match_set_read(self, cap=65536):
+        n = C.c_uint32()
+        qf = np.zeros(cap, np.uint32)
+        lm = np.zeros(cap, np.uint32)
+        p2 = np.zeros((cap, 2), np.float64)
+        p3 = np.zeros((cap, 3), np.float64)
+        _check(_L().sfmloc_match_set_read(self._h, C.byref(n), _ptr(qf, C.c_uint32), _ptr(lm, C.c_uint32),
+                                          _ptr(p2, C.c_double), _ptr(p3, C.c_double), cap))
+        k = n.value
+        return qf[:k].copy(), lm[:k].copy(), p2[:k].copy(), p3[:k].copy()
+
+    def resection(self, q):
+        _check(_L().sfmloc_resection(self._h, q._h))
+
+    def pose_read(self, cap=4096):
+        pose = Pose()
+        pq = np.zeros(cap, np.uint32)
+        pl = np.zeros(cap, np.uint32)
+        ii = np.zeros(cap, np.uint32)
+        _check(_L().sfmloc_pose_read(self._h, C.byref(pose), _ptr(pq, C.c_uint32), _ptr(pl, C.c_uint32),
+                                     _ptr(ii, C.c_uint32), cap))
+        k = pose.n_inliers if pose.ok else 0
+        return pose, pq[:k].copy(), pl[:k].copy(), ii[:k].copy()
+
+    def localize(self, q, view_sel=None, cap=4096):
+        """sfmloc_localize: the whole per-query path; -> (Pose, pair_qfeat, pair_landmark)."""
+        pose = Pose()
+        pq = np.zeros(cap, np.uint32)
+        pl = np.zeros(cap, np.uint32)
+        if view_sel is None:
+            sel_p, n_sel = None, 0
+        else:
+            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
+            sel_p, n_sel = _ptr(sel, C.c_uint32), sel.shape[0]
+        _check(_L().sfmloc_localize(self._h, q._h, sel_p, n_sel, C.byref(pose), _ptr(pq, C.c_uint32),
+                                    _ptr(pl, C.c_uint32), cap))
+        k = pose.n_inliers if pose.ok else 0
+        return pose, pq[:k].copy(), pl[:k].copy()
 
     def stats(self):
         s = KernelStats()

@@ -1,0 +1,846 @@
+// K3 / K4 / K5 of the query-localisation path for gfx950.
+//
+//   K3  k_fmatrix_filter     per surviving (view, query) pair: AC-RANSAC with the 7-point solver
+//                            [reference: hulo::geometricMatch -> GeometricFilter_FMatrix_AC, MatchUtils.cpp:372-420]
+//   K4  k_emit_candidates /  matchProviderToMatchSet: per query feature keep the landmark whose match has the
+//       k_select_candidates  smallest descriptor distance, first one on ties   [SfMDataUtils.cpp:59-125]
+//   K5  k_p3p_*              SfM_Localizer::Localize: AC-RANSAC with Kneip P3P on K^-1-normalised points,
+//                            then KRt_From_P                                    [localization.cpp:504-509,544-547]
+//
+// AC-RANSAC is sequential by definition (the first meaningful model redirects sampling to its inliers and
+// cuts the iteration budget to the reserved 10 %).  The kernels keep those semantics exactly and get their
+// parallelism from speculation: hypotheses whose samples come from the CURRENT index set are evaluated in
+// parallel, one workgroup per hypothesis (residuals -> LDS -> bitonic sort -> NFA scan -> block argmin), and
+// a selection step replays the sequential rule over them in iteration order, discarding everything after
+// the first hypothesis that changes the index set.  Samples come from a counter-based generator
+// (Philox4x32-10 keyed by seed/stage/stream/iteration), so iteration i draws the same sample no matter
+// which round evaluates it.  All arithmetic is f64, in the operation order of geom_device.h.
+#include <float.h>
+
+#include "geom_device.h"
+#include "sfmloc_internal.h"
+
+namespace sfmloc {
+using namespace geom;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------------------
+// block-wide helpers (256 threads)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+  return ka < kb || (ka == kb && ia < ib);
+}
+
+// ascending bitonic sort of (key, idx) pairs, P a power of two
+__device__ void bitonic_sort(uint64_t *key, uint32_t *idx, int P) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (P >> 1); t += kThreads) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i + j;
+        const bool up = (i & k) == 0;
+        const uint64_t ka = key[i], kb = key[l];
+        const uint32_t ia = idx[i], ib = idx[l];
+        const bool a_gt_b = pair_less(kb, ib, ka, ia);
+        if (a_gt_b == up) {
+          key[i] = kb;
+          key[l] = ka;
+          idx[i] = ib;
+          idx[l] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct NfaBest {
+  double nfa;
+  int k;
+};
+
+// bestNFA of OpenMVG over the sorted residuals key[0..n): min over k in (s, n] with e_k <= max_thr of
+//   loge0 + logalpha(e_k) * (k - s) + logc_n[k] + logc_k[k];  first k on ties.  All threads return the result.
+__device__ NfaBest best_nfa_block(const uint64_t *key, int n, int s, double max_thr, double logalpha0, double mult,
+                                  double loge0, const float *logc_n, const float *logc_k, double *red_nfa,
+                                  int *red_k) {
+  double lb = pos_inf();
+  int lk = 0x7FFFFFFF;
+  for (int kk = s + 1 + (int)threadIdx.x; kk <= n; kk += kThreads) {
+    const double ek = u2d(key[kk - 1]);
+    if (ek <= max_thr) {
+      const double logalpha = logalpha0 + mult * det_log10(ek + (double)FLT_EPSILON);
+      const double nfa = loge0 + logalpha * (double)(kk - s) + (double)logc_n[kk] + (double)logc_k[kk];
+      if (nfa < lb) {
+        lb = nfa;
+        lk = kk;
+      }
+    }
+  }
+  // wave reduce (64 lanes), then across the 4 waves through LDS
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ob = __shfl_down(lb, off, 64);
+    const int ok = __shfl_down(lk, off, 64);
+    if (ob < lb || (ob == lb && ok < lk)) {
+      lb = ob;
+      lk = ok;
+    }
+  }
+  __syncthreads();  // red_* may still be read by the previous call's consumers
+  if ((threadIdx.x & 63) == 0) {
+    red_nfa[threadIdx.x >> 6] = lb;
+    red_k[threadIdx.x >> 6] = lk;
+  }
+  __syncthreads();
+  NfaBest r{red_nfa[0], red_k[0]};
+  for (int w = 1; w < kThreads / 64; ++w) {
+    if (red_nfa[w] < r.nfa || (red_nfa[w] == r.nfa && red_k[w] < r.k)) {
+      r.nfa = red_nfa[w];
+      r.k = red_k[w];
+    }
+  }
+  return r;
+}
+
+// logcombi tables of OpenMVG (float): logc_n[k] = log10 C(n,k), logc_k[m] = log10 C(m,s); L10[i] = log10(i).
+// logcombi(k,n) = sum_{i=1..min(k,n-k)} (L10[n-i+1] - L10[i]) accumulated in double in that order, so the
+// values for k = 0..n/2 are the running sums of one sequential pass (thread 0); the rest is symmetry.
+__device__ void logcombi_tables_block(int s, int n, const double *__restrict__ L10, float *logc_n, float *logc_k) {
+  if (threadIdx.x == 0) {
+    double r = 0.0;
+    logc_n[0] = 0.0f;
+    logc_n[n] = 0.0f;
+    for (int k = 1; 2 * k <= n; ++k) {
+      if (k < n) {
+        r += L10[n - k + 1] - L10[k];
+        logc_n[k] = (float)r;
+        logc_n[n - k] = (float)r;
+      }
+    }
+  }
+  for (int m = threadIdx.x; m <= n; m += kThreads) {
+    float v = 0.0f;
+    if (s < m) {
+      int k = s;
+      if (m - k < k) k = m - k;
+      double r = 0.0;
+      for (int i = 1; i <= k; ++i) r += L10[m - i + 1] - L10[i];
+      v = (float)r;
+    }
+    logc_k[m] = v;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+  int p = 64;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: F-matrix AC-RANSAC, one workgroup per selected view
+// ---------------------------------------------------------------------------------------------------
+constexpr int kFMaxM = 2048;  // putative matches per view the LDS sort holds
+constexpr int kFPre = 64;     // hypotheses solved speculatively per batch while sampling is still uniform
+
+struct FFilterArgs {
+  const uint32_t *view_sel;
+  uint32_t n_sel;
+  const uint32_t *view_off, *view_id, *view_wh;
+  const uint32_t *put_count, *match_i, *match_key;
+  const float2 *map_kpt, *q_kpt6;
+  uint32_t qw, qh;
+  double precision;
+  int n_iter;
+  uint64_t seed;
+  int min_putative;
+  const double *L10;
+  uint32_t *geo_count, *geo_idx;
+  int *status;
+};
+
+struct FShared {
+  uint64_t key[kFMaxM];
+  uint32_t idx[kFMaxM];
+  int32_t vec_index[kFMaxM];
+  int32_t best_inl[kFMaxM];
+  float logc_n[kFMaxM + 1];
+  float logc_k[kFMaxM + 1];
+  double pre_models[kFPre][27];
+  int pre_nm[kFPre];
+  double cur_models[27];
+  int cur_nm;
+  double red_nfa[kThreads / 64];
+  int red_k[kThreads / 64];
+};
+
+__global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
+  extern __shared__ unsigned char smem_raw[];
+  FShared &S = *reinterpret_cast<FShared *>(smem_raw);
+  const int tid = threadIdx.x;
+  const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
+  const int m = (int)A.put_count[v];
+  const uint32_t off = A.view_off[v];
+  constexpr int s = 7;
+  if (m < A.min_putative || m <= s) {  // localization.cpp:408-415 ; ACRANSAC: nData <= sizeSample
+    if (tid == 0) A.geo_count[v] = 0;
+    return;
+  }
+  if (m > kFMaxM) {
+    if (tid == 0) {
+      A.geo_count[v] = 0;
+      atomicOr(A.status, 1);
+    }
+    return;
+  }
+  // NormalizePoints(x, w, h) for both images
+  const int w1 = (int)A.view_wh[2 * v], h1 = (int)A.view_wh[2 * v + 1];
+  const int w2 = (int)A.qw, h2 = (int)A.qh;
+  const double s1 = 1.0 / sqrt((double)(w1 * h1)), s2 = 1.0 / sqrt((double)(w2 * h2));
+  const double t1x = -0.5 * (double)w1 * s1, t1y = -0.5 * (double)h1 * s1;
+  const double t2x = -0.5 * (double)w2 * s2, t2y = -0.5 * (double)h2 * s2;
+  const double Dg = sqrt((double)w2 * (double)w2 + (double)h2 * (double)h2);
+  const double Ar = (double)w2 * (double)h2;
+  const double logalpha0 = det_log10(2.0 * Dg / Ar / s2);
+  const double max_thr = (A.precision * A.precision) * s2 * s2;
+  const double loge0 = det_log10(3.0 * (double)(m - s));
+  const uint32_t stream = A.view_id[v];
+  const int P = next_pow2(m);
+
+  auto point = [&](int p, double &x, double &y, double &u, double &w) {
+    const uint32_t i = A.match_i[off + p];
+    const uint32_t j = A.match_key[off + p] & 0xFFFFu;
+    const float2 a = A.map_kpt[off + i];
+    const float2 b = A.q_kpt6[j];
+    x = s1 * (double)a.x + t1x;
+    y = s1 * (double)a.y + t1y;
+    u = s2 * (double)b.x + t2x;
+    w = s2 * (double)b.y + t2y;
+  };
+  auto solve = [&](const int32_t *smp, double *models) -> int {
+    double x1[14], x2[14];
+    for (int i = 0; i < 7; ++i) point(smp[i], x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]);
+    return seven_point(x1, x2, models);
+  };
+
+  logcombi_tables_block(s, m, A.L10, S.logc_n, S.logc_k);
+
+  double min_nfa = pos_inf();
+  int n_in = 0;
+  long n_iter = A.n_iter;
+  long n_reserve = n_iter / 10;
+  n_iter -= n_reserve;
+  bool identity = true;
+  int n_index = m;
+  long pre_base = -1;
+
+  for (long iter = 0; iter < n_iter; ++iter) {
+    const double *models;
+    int nm;
+    if (identity) {
+      if (pre_base < 0 || iter >= pre_base + kFPre) {
+        __syncthreads();
+        pre_base = iter;
+        if (tid < kFPre) {
+          int32_t smp[7];
+          double mm[27];
+          ac_sample<7>(nullptr, m, A.seed, STAGE_FMATRIX, stream, (uint32_t)(pre_base + tid), smp);
+          const int k = solve(smp, mm);
+          S.pre_nm[tid] = k;
+          for (int q = 0; q < 9 * k; ++q) S.pre_models[tid][q] = mm[q];
+        }
+        __syncthreads();
+      }
+      models = S.pre_models[iter - pre_base];
+      nm = S.pre_nm[iter - pre_base];
+    } else {
+      __syncthreads();
+      if (tid == 0) {
+        int32_t smp[7];
+        double mm[27];
+        ac_sample<7>(S.vec_index, n_index, A.seed, STAGE_FMATRIX, stream, (uint32_t)iter, smp);
+        const int k = solve(smp, mm);
+        S.cur_nm = k;
+        for (int q = 0; q < 9 * k; ++q) S.cur_models[q] = mm[q];
+      }
+      __syncthreads();
+      models = S.cur_models;
+      nm = S.cur_nm;
+    }
+    bool better = false;
+    for (int k = 0; k < nm; ++k) {
+      double M[9];
+      for (int q = 0; q < 9; ++q) M[q] = models[9 * k + q];
+      __syncthreads();  // key/idx of the previous model are no longer read
+      for (int p = tid; p < P; p += kThreads) {
+        uint64_t kv = ~0ull;
+        if (p < m) {
+          double x, y, u, w;
+          point(p, x, y, u, w);
+          kv = d2u(err_fmatrix(M, x, y, u, w));
+        }
+        S.key[p] = kv;
+        S.idx[p] = (uint32_t)p;
+      }
+      __syncthreads();
+      bitonic_sort(S.key, S.idx, P);
+      const NfaBest b = best_nfa_block(S.key, m, s, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k, S.red_nfa,
+                                       S.red_k);
+      if (b.nfa < min_nfa) {
+        better = true;
+        min_nfa = b.nfa;
+        n_in = b.k;
+        for (int p = tid; p < n_in; p += kThreads) S.best_inl[p] = (int32_t)S.idx[p];
+      }
+    }
+    if ((better && min_nfa < 0.0) || (iter + 1 == n_iter && n_reserve)) {
+      if (n_in == 0) {
+        n_iter++;
+        n_reserve--;
+      } else {
+        __syncthreads();
+        for (int p = tid; p < n_in; p += kThreads) S.vec_index[p] = S.best_inl[p];
+        n_index = n_in;
+        identity = false;
+        if (n_reserve) {
+          n_iter = iter + 1 + n_reserve;
+          n_reserve = 0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (min_nfa >= 0.0) n_in = 0;
+  if ((double)n_in > 7 * 2.5) {
+    for (int p = tid; p < n_in; p += kThreads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
+    if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
+  } else if (tid == 0) {
+    A.geo_count[v] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4: 2D-3D candidates and their de-duplication
+// ---------------------------------------------------------------------------------------------------
+// One wave per selected view: every geometric match whose map feature has a landmark becomes a candidate
+//   order key = dist << 48 | view_id << 24 | position in the view's geometric list
+// (smaller is better; equal distance -> earlier in std::map iteration order = lower view id, then list order).
+// dist = featDist[(v,q)][j] = d0 of the LAST putative match of the view that hit query feature j.
+__global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_sel, uint32_t n_sel,
+                                                         const uint32_t *view_off, const uint32_t *view_id,
+                                                         const uint32_t *put_count, const uint32_t *match_i,
+                                                         const uint32_t *match_key, const uint32_t *geo_count,
+                                                         const uint32_t *geo_idx, const int32_t *row_landmark,
+                                                         const uint32_t *landmark_id, const double *landmark_X,
+                                                         Candidate *cand, uint32_t cap, uint32_t *n_cand,
+                                                         int *status) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= n_sel) return;
+  const uint32_t v = view_sel ? view_sel[gw] : gw;
+  const uint32_t ng = geo_count[v];
+  if (ng == 0) return;
+  const uint32_t off = view_off[v];
+  const uint32_t np = put_count[v];
+  for (uint32_t p = lane; p < ng; p += 64) {
+    const uint32_t pp = geo_idx[off + p];
+    const uint32_t i = match_i[off + pp];
+    const uint32_t j = match_key[off + pp] & 0xFFFFu;
+    const int32_t lm = row_landmark[off + i];
+    if (lm < 0) continue;
+    uint32_t dist = 0;
+    for (int32_t k = (int32_t)np - 1; k >= 0; --k) {  // last putative match with the same query feature
+      const uint32_t kk = match_key[off + k];
+      if ((kk & 0xFFFFu) == j) {
+        dist = kk >> 16;
+        break;
+      }
+    }
+    const uint32_t slot = atomicAdd(n_cand, 1u);
+    if (slot >= cap) {
+      atomicOr(status, 2);
+      continue;
+    }
+    Candidate c;
+    c.order = ((uint64_t)dist << 48) | ((uint64_t)(view_id[v] & 0xFFFFFFu) << 24) | (uint64_t)(p & 0xFFFFFFu);
+    c.qfeat = j;
+    c.landmark_id = landmark_id[lm];
+    c.X[0] = landmark_X[3 * lm];
+    c.X[1] = landmark_X[3 * lm + 1];
+    c.X[2] = landmark_X[3 * lm + 2];
+    cand[slot] = c;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_candidates_min(const Candidate *cand, const uint32_t *n_cand, uint32_t cap,
+                                                        unsigned long long *best) {
+  const uint32_t n = min(*n_cand, cap);
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+    atomicMin(&best[cand[c].qfeat], (unsigned long long)cand[c].order);
+}
+
+__global__ __launch_bounds__(256) void k_candidates_win(const Candidate *cand, const uint32_t *n_cand, uint32_t cap,
+                                                        const unsigned long long *best, uint32_t *winner) {
+  const uint32_t n = min(*n_cand, cap);
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+    if (best[cand[c].qfeat] == (unsigned long long)cand[c].order) winner[cand[c].qfeat] = c;
+}
+
+// single wave: compact the winners in ascending query-feature order (SfMDataUtils.cpp:121-124) and assemble
+// pt2D / pt3D (localization.cpp:479-501; pinhole get_ud_pixel is the identity)
+__global__ __launch_bounds__(64) void k_match_set_finish(const Candidate *cand, const unsigned long long *best,
+                                                         const uint32_t *winner, uint32_t nq, const float2 *q_kpt,
+                                                         uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
+                                                         double *pt2d, double *pt3d) {
+  const uint32_t lane = threadIdx.x;
+  uint32_t base = 0;
+  for (uint32_t j0 = 0; j0 < nq; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    const bool has = j < nq && best[j] != ~0ull;
+    const unsigned long long mask = __ballot(has);
+    if (has) {
+      const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      const Candidate c = cand[winner[j]];
+      ms_qfeat[pos] = j;
+      ms_landmark[pos] = c.landmark_id;
+      const float2 kp = q_kpt[j];
+      pt2d[2 * pos] = (double)kp.x;
+      pt2d[2 * pos + 1] = (double)kp.y;
+      pt3d[3 * pos] = c.X[0];
+      pt3d[3 * pos + 1] = c.X[1];
+      pt3d[3 * pos + 2] = c.X[2];
+    }
+    base += (uint32_t)__popcll(mask);
+  }
+  if (lane == 0) *ms_n = base;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5: P3P AC-RANSAC as rounds of (evaluate a batch of hypotheses | replay the sequential rule)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
+  P3pState &st = *A.state;
+  const int n = (int)*A.ms_n;
+  __shared__ int go;
+  if (threadIdx.x == 0) {
+    st.n = n;
+    st.iter = 0;
+    const long maxit = A.max_iteration;
+    st.n_reserve = (int)(maxit / 10);
+    st.n_iter = (int)(maxit - maxit / 10);
+    st.n_index = n;
+    st.identity = 1;
+    st.n_in = 0;
+    st.done = 0;
+    st.rounds = 0;
+    st.status = 0;
+    st.min_nfa = pos_inf();
+    st.errmax = pos_inf();
+    for (int i = 0; i < 12; ++i) st.model[i] = 0.0;
+    go = 1;
+    // localization.cpp:506 "cpt > MINUM_NUMBER_OF_POINT_RESECTION"; ACRANSAC: nData <= sizeSample -> nothing
+    if (n <= A.min_resection_points || n <= 3) {
+      st.done = 1;
+      go = 0;
+    }
+    if (n > A.max_n) {
+      st.done = 1;
+      st.status = 4;
+      go = 0;
+    }
+    A.result->ok = 0;
+    A.result->n_inliers = 0;
+    A.result->n_matches_2d3d = n;
+    A.result->iterations = 0;
+    A.result->status = st.status;
+  }
+  __syncthreads();
+  if (!go) return;
+  // normalise by K^-1: x * (1/f) + (-pp/f)
+  const double inv_f = 1.0 / A.focal;
+  const double cx = -A.ppx * inv_f, cy = -A.ppy * inv_f;
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    A.xn[2 * i] = A.pt2d[2 * i] * inv_f + cx;
+    A.xn[2 * i + 1] = A.pt2d[2 * i + 1] * inv_f + cy;
+  }
+  logcombi_tables_block(3, n, A.L10, A.logc_n, A.logc_k);
+}
+
+struct P3pShared {
+  uint64_t key[kP3pMaxN];
+  uint32_t idx[kP3pMaxN];
+  double models[48];
+  int nm;
+  double red_nfa[kThreads / 64];
+  int red_k[kThreads / 64];
+};
+
+__global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
+  const P3pState &st = *A.state;
+  if (st.done) return;
+  const int b = blockIdx.x;
+  if (b >= batch) return;
+  const long it = (long)st.iter + b;
+  if (it >= st.n_iter) return;
+  extern __shared__ unsigned char smem_raw[];
+  P3pShared &S = *reinterpret_cast<P3pShared *>(smem_raw);
+  const int tid = threadIdx.x;
+  const int n = st.n;
+  constexpr int s = 3;
+  const int P = next_pow2(n);
+  if (tid == 0) {
+    int32_t smp[3];
+    ac_sample<3>(st.identity ? nullptr : A.vec_index, st.n_index, A.seed, STAGE_P3P, A.stream, (uint32_t)it, smp);
+    double x[6], X[9], mm[48];
+    for (int i = 0; i < 3; ++i) {
+      x[2 * i] = A.xn[2 * smp[i]];
+      x[2 * i + 1] = A.xn[2 * smp[i] + 1];
+      X[3 * i] = A.pt3d[3 * smp[i]];
+      X[3 * i + 1] = A.pt3d[3 * smp[i] + 1];
+      X[3 * i + 2] = A.pt3d[3 * smp[i] + 2];
+    }
+    const int k = p3p_kneip(x, X, mm);
+    S.nm = k;
+    for (int q = 0; q < 12 * k; ++q) S.models[q] = mm[q];
+  }
+  __syncthreads();
+  const int nm = S.nm;
+  const double logalpha0 = det_log10(3.14159265358979323846);
+  const double loge0 = det_log10(4.0 * (double)(n - s));
+  double best = pos_inf();
+  int best_k = 0, best_m = -1;
+  double best_err = pos_inf();
+  for (int k = 0; k < nm; ++k) {
+    double M[12];
+    for (int q = 0; q < 12; ++q) M[q] = S.models[12 * k + q];
+    __syncthreads();
+    for (int p = tid; p < P; p += kThreads) {
+      uint64_t kv = ~0ull;
+      if (p < n)
+        kv = d2u(err_resection(M, A.pt3d[3 * p], A.pt3d[3 * p + 1], A.pt3d[3 * p + 2], A.xn[2 * p], A.xn[2 * p + 1]));
+      S.key[p] = kv;
+      S.idx[p] = (uint32_t)p;
+    }
+    __syncthreads();
+    bitonic_sort(S.key, S.idx, P);
+    const NfaBest r = best_nfa_block(S.key, n, s, pos_inf(), logalpha0, 1.0, loge0, A.logc_n, A.logc_k, S.red_nfa,
+                                     S.red_k);
+    if (r.nfa < best) {  // strict: the first model of the hypothesis wins ties, as the sequential loop does
+      best = r.nfa;
+      best_k = r.k;
+      best_m = k;
+      best_err = u2d(S.key[r.k - 1]);
+      int32_t *dst = A.hyp_inl + (size_t)b * A.max_n;
+      for (int p = tid; p < best_k; p += kThreads) dst[p] = (int32_t)S.idx[p];
+    }
+  }
+  if (tid == 0) {
+    A.hyp_nfa[b] = best;
+    A.hyp_k[b] = best_k;
+    A.hyp_err[b] = best_err;
+    if (best_m >= 0)
+      for (int q = 0; q < 12; ++q) A.hyp_model[12 * b + q] = S.models[12 * best_m + q];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
+  P3pState &st = *A.state;
+  if (st.done) return;
+  const int tid = threadIdx.x;
+  // every thread replays the same scalar state machine; only the copies are cooperative
+  long iter0 = st.iter, n_iter = st.n_iter, n_reserve = st.n_reserve;
+  const long n_iter_evaluated = n_iter;  // k_p3p_eval ran hypotheses iter0 <= it < min(iter0+batch, n_iter)
+  double min_nfa = st.min_nfa, errmax = st.errmax;
+  int n_in = st.n_in, n_index = st.n_index, identity = st.identity;
+  int best_b = -1;  // hypothesis of this batch that currently holds the best model
+  long processed = 0;
+  bool index_changed = false;
+  for (int b = 0; b < batch; ++b) {
+    const long it = iter0 + b;
+    if (it >= n_iter || it >= n_iter_evaluated) break;
+    const double nfa = A.hyp_nfa[b];
+    bool better = false;
+    if (nfa < min_nfa) {
+      better = true;
+      min_nfa = nfa;
+      n_in = A.hyp_k[b];
+      errmax = A.hyp_err[b];
+      best_b = b;
+    }
+    processed = b + 1;
+    if ((better && min_nfa < 0.0) || (it + 1 == n_iter && n_reserve)) {
+      if (n_in == 0) {
+        n_iter++;
+        n_reserve--;
+      } else {
+        index_changed = true;
+        n_index = n_in;
+        identity = 0;
+        if (n_reserve) {
+          n_iter = it + 1 + n_reserve;
+          n_reserve = 0;
+        }
+        break;  // later hypotheses of this batch sampled from the old index set
+      }
+    }
+  }
+  if (best_b >= 0) {
+    const int32_t *src = A.hyp_inl + (size_t)best_b * A.max_n;
+    for (int p = tid; p < n_in; p += kThreads) A.best_inl[p] = src[p];
+    if (index_changed)
+      for (int p = tid; p < n_in; p += kThreads) A.vec_index[p] = src[p];
+  } else if (index_changed) {
+    // the index set switches to the inliers of a model found in an EARLIER round (end of the main phase)
+    for (int p = tid; p < n_in; p += kThreads) A.vec_index[p] = A.best_inl[p];
+  }
+  __syncthreads();
+  const bool done = (iter0 + processed >= n_iter);
+  if (tid == 0) {
+    st.iter = (int)(iter0 + processed);
+    st.n_iter = (int)n_iter;
+    st.n_reserve = (int)n_reserve;
+    st.min_nfa = min_nfa;
+    st.errmax = errmax;
+    st.n_in = n_in;
+    st.n_index = n_index;
+    st.identity = identity;
+    st.rounds += 1;
+    if (best_b >= 0)
+      for (int q = 0; q < 12; ++q) st.model[q] = A.hyp_model[12 * best_b + q];
+    if (done) st.done = 1;
+  }
+  if (!done) return;
+  // ----- ACRANSAC epilogue + SfM_Localizer::Localize + localization.cpp:511-547 -----
+  __shared__ double Msh[12];
+  if (tid == 0)
+    for (int q = 0; q < 12; ++q) Msh[q] = (best_b >= 0) ? A.hyp_model[12 * best_b + q] : st.model[q];
+  __syncthreads();
+  int n_final = n_in;
+  if (min_nfa >= 0.0) n_final = 0;
+  const bool resection = (double)n_final > 2.5 * 3;
+  const bool ok = resection && n_final > A.min_inliers;
+  Pose &R = *A.result;
+  if (ok)
+    for (int p = tid; p < n_final; p += kThreads) {
+      const int32_t c = A.best_inl[p];
+      A.pair_qfeat[p] = A.ms_qfeat[c];
+      A.pair_landmark[p] = A.ms_landmark[c];
+      A.inlier_idx[p] = c;
+    }
+  if (tid == 0) {
+    R.ok = ok ? 1 : 0;
+    R.n_inliers = n_final;
+    R.n_matches_2d3d = st.n;
+    R.iterations = (int)(iter0 + processed);
+    R.nfa = min_nfa;
+    R.status = st.status;
+    const double inv_f = 1.0 / A.focal;
+    R.error_max = (n_final > 0) ? sqrt(errmax) / inv_f : errmax;
+    double Pm[12];
+    for (int j = 0; j < 4; ++j) {  // P = K * [R|t]
+      Pm[j] = A.focal * Msh[j] + A.ppx * Msh[8 + j];
+      Pm[4 + j] = A.focal * Msh[4 + j] + A.ppy * Msh[8 + j];
+      Pm[8 + j] = Msh[8 + j];
+    }
+    if (n_final == 0)
+      for (int j = 0; j < 12; ++j) Pm[j] = 0.0;
+    for (int j = 0; j < 12; ++j) R.P[j] = Pm[j];
+    if (ok) {
+      double Kq[9], Rq[9], tq[3], cq[3];
+      krt_from_p(Pm, Kq, Rq, tq);
+      center_from_rt(Rq, tq, cq);
+      for (int j = 0; j < 9; ++j) {
+        R.K[j] = Kq[j];
+        R.R[j] = Rq[j];
+      }
+      for (int j = 0; j < 3; ++j) {
+        R.t[j] = tq[j];
+        R.center[j] = cq[j];
+      }
+    }
+  }
+}
+
+// L10[i] = log10(i) for the logcombi tables, computed once per map on the device
+__global__ void k_fill_log10(double *L10, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) L10[i] = (i == 0) ? 0.0 : det_log10((double)i);
+}
+
+// parity probes for the f64 building blocks (sfmloc_debug_math)
+__global__ void k_debug_math(int op, const double *in, int n, int in_stride, double *out, int out_stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double *x = in + (size_t)i * in_stride;
+  double *o = out + (size_t)i * out_stride;
+  switch (op) {
+    case 0: o[0] = det_log10(x[0]); break;
+    case 1: o[0] = sqrt(x[0]); o[1] = x[0] / x[1]; break;
+    case 2: {
+      double r[3] = {0, 0, 0};
+      o[0] = (double)solve_cubic(x[0], x[1], x[2], x[3], r);
+      o[1] = r[0]; o[2] = r[1]; o[3] = r[2];
+    } break;
+    case 3: solve_quartic_real(x, o); break;
+    case 4: {
+      double F[27];
+      for (int k = 0; k < 27; ++k) F[k] = 0.0;
+      o[0] = (double)seven_point(x, x + 14, F);
+      for (int k = 0; k < 27; ++k) o[1 + k] = F[k];
+    } break;
+    case 5: {
+      double M[48];
+      for (int k = 0; k < 48; ++k) M[k] = 0.0;
+      o[0] = (double)p3p_kneip(x, x + 6, M);
+      for (int k = 0; k < 48; ++k) o[1 + k] = M[k];
+    } break;
+    case 6: {
+      double c[3];
+      krt_from_p(x, o, o + 9, o + 18);
+      center_from_rt(o + 9, o + 18, c);
+      o[21] = c[0]; o[22] = c[1]; o[23] = c[2];
+    } break;
+    case 7: {
+      int32_t smp[7];
+      const uint64_t seed = (uint64_t)x[0] | ((uint64_t)x[1] << 32);
+      ac_sample<7>(nullptr, (int)x[2], seed, (uint32_t)x[3], (uint32_t)x[4], (uint32_t)x[5], smp);
+      for (int k = 0; k < 7; ++k) o[k] = (double)smp[k];
+    } break;
+    default: break;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+int launch_fill_log10(double *d_L10, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill_log10, dim3((n + 255) / 256), dim3(256), 0, s, d_L10, n);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *d_out, int out_stride,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 63) / 64), dim3(64), 0, s, op, d_in, n, in_stride, d_out, out_stride);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_fmatrix_filter(Map *m, const Query *q, uint32_t n_sel, bool all_views) {
+  if (n_sel == 0) return SFMLOC_OK;
+  FFilterArgs A;
+  A.view_sel = all_views ? nullptr : m->d_view_sel;
+  A.n_sel = n_sel;
+  A.view_off = m->d_view_off;
+  A.view_id = m->d_view_id;
+  A.view_wh = m->d_view_wh;
+  A.put_count = m->d_view_count;
+  A.match_i = m->d_match_i;
+  A.match_key = m->d_match_key;
+  A.map_kpt = m->d_kpt;
+  A.q_kpt6 = q->d_kpt6;
+  A.qw = q->width;
+  A.qh = q->height;
+  A.precision = m->params.geom_precision;
+  A.n_iter = m->params.ransac_round;
+  A.seed = m->params.seed;
+  A.min_putative = m->params.min_putative;
+  A.L10 = m->d_L10;
+  A.geo_count = m->d_geo_count;
+  A.geo_idx = m->d_geo_idx;
+  A.status = m->d_status;
+  const size_t lds = sizeof(FShared);
+  SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_filter),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_fmatrix_filter, dim3(n_sel), dim3(kThreads), lds, m->stream, A);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_match_set(Map *m, const Query *q, uint32_t n_sel, bool all_views) {
+  SFM_HIP(hipMemsetAsync(m->d_n_cand, 0, sizeof(uint32_t), m->stream));
+  SFM_HIP(hipMemsetAsync(m->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), m->stream));
+  SFM_HIP(hipMemsetAsync(m->d_ms_n, 0, sizeof(uint32_t), m->stream));
+  if (n_sel == 0 || q->n == 0) return SFMLOC_OK;
+  hipLaunchKernelGGL(k_emit_candidates, dim3((n_sel + 3) / 4), dim3(256), 0, m->stream,
+                     all_views ? nullptr : m->d_view_sel, n_sel, m->d_view_off, m->d_view_id, m->d_view_count,
+                     m->d_match_i, m->d_match_key, m->d_geo_count, m->d_geo_idx, m->d_row_landmark,
+                     m->d_landmark_id, m->d_landmark_X, m->d_cand, m->cand_cap, m->d_n_cand, m->d_status);
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_candidates_min, dim3(64), dim3(256), 0, m->stream, m->d_cand, m->d_n_cand, m->cand_cap,
+                     m->d_best64);
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_candidates_win, dim3(64), dim3(256), 0, m->stream, m->d_cand, m->d_n_cand, m->cand_cap,
+                     m->d_best64, m->d_winner);
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(64), 0, m->stream, m->d_cand, m->d_best64, m->d_winner, q->n,
+                     q->d_kpt, m->d_ms_n, m->d_ms_qfeat, m->d_ms_landmark, m->d_pt2d, m->d_pt3d);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+static P3pArgs make_p3p_args(Map *m) {
+  P3pArgs A;
+  A.state = m->d_p3p_state;
+  A.result = m->d_pose;
+  A.ms_n = m->d_ms_n;
+  A.ms_qfeat = m->d_ms_qfeat;
+  A.ms_landmark = m->d_ms_landmark;
+  A.pt2d = m->d_pt2d;
+  A.pt3d = m->d_pt3d;
+  A.xn = m->d_xn;
+  A.L10 = m->d_L10;
+  A.logc_n = m->d_logc_n;
+  A.logc_k = m->d_logc_k;
+  A.vec_index = m->d_vec_index;
+  A.best_inl = m->d_best_inl;
+  A.hyp_nfa = m->d_hyp_nfa;
+  A.hyp_k = m->d_hyp_k;
+  A.hyp_err = m->d_hyp_err;
+  A.hyp_model = m->d_hyp_model;
+  A.hyp_inl = m->d_hyp_inl;
+  A.pair_qfeat = m->d_pair_qfeat;
+  A.pair_landmark = m->d_pair_landmark;
+  A.inlier_idx = m->d_inlier_idx;
+  A.focal = m->focal;
+  A.ppx = m->ppx;
+  A.ppy = m->ppy;
+  A.max_iteration = m->params.p3p_max_iteration;
+  A.min_resection_points = m->params.min_resection_points;
+  A.min_inliers = m->params.min_inliers;
+  A.max_n = kP3pMaxN;
+  A.seed = m->params.seed;
+  A.stream = 0;
+  return A;
+}
+
+int launch_p3p_init(Map *m) {
+  P3pArgs A = make_p3p_args(m);
+  hipLaunchKernelGGL(k_p3p_init, dim3(1), dim3(kThreads), 0, m->stream, A);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_p3p_round(Map *m, int batch) {
+  P3pArgs A = make_p3p_args(m);
+  const size_t lds = sizeof(P3pShared);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_p3p_eval),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_p3p_eval, dim3(batch), dim3(kThreads), lds, m->stream, A, batch);
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_p3p_select, dim3(1), dim3(kThreads), 0, m->stream, A, batch);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+}  // namespace sfmloc

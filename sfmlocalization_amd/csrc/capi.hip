@@ -1,6 +1,8 @@
 // C ABI of libsfmloc_hip.so (include/sfmloc.h): handles, HBM residency, stream, measurement.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
+#include <chrono>
 
 #include <algorithm>
 #include <new>
@@ -106,7 +108,13 @@ void free_map(Map *m) {
   }
   void *ptrs[] = {m->d_bank,       m->d_view_off,   m->d_view_id,    m->d_kpt,        m->d_row_landmark,
                   m->d_landmark_id, m->d_landmark_X, m->d_bow,        m->d_part,       m->d_view_sel,
-                  m->d_block_list,  m->d_view_count, m->d_match_i,    m->d_match_key,  m->d_ratio_cnt};
+                  m->d_block_list,  m->d_view_count, m->d_match_i,    m->d_match_key,  m->d_ratio_cnt,
+                  m->d_view_wh,     m->d_L10,        m->d_geo_count,  m->d_geo_idx,    m->d_status,
+                  m->d_cand,        m->d_n_cand,     m->d_best64,     m->d_winner,     m->d_ms_n,
+                  m->d_ms_qfeat,    m->d_ms_landmark, m->d_pt2d,      m->d_pt3d,       m->d_xn,
+                  m->d_logc_n,      m->d_logc_k,     m->d_vec_index,  m->d_best_inl,   m->d_hyp_nfa,
+                  m->d_hyp_err,     m->d_hyp_model,  m->d_hyp_k,      m->d_hyp_inl,    m->d_pair_qfeat,
+                  m->d_pair_landmark, m->d_inlier_idx, m->d_p3p_state, m->d_pose};
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (m->h_pinned) hipHostFree(m->h_pinned);
@@ -281,6 +289,50 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
   SFM_TRY(dev_alloc(m, &m->d_match_i, (size_t)m->n_rows));
   SFM_TRY(dev_alloc(m, &m->d_match_key, (size_t)m->n_rows));
   SFM_TRY(dev_alloc(m, &m->d_ratio_cnt, (size_t)513));
+  // workspace of the geometric stages
+  if (d->view_wh) SFM_TRY(dev_upload(m, &m->d_view_wh, d->view_wh, (size_t)d->n_views * 2));
+  m->have_geometry = d->view_wh && d->kpt_xy && d->row_landmark && d->focal > 0.0;
+  SFM_TRY(dev_alloc(m, &m->d_L10, (size_t)65538));
+  SFM_TRY(launch_fill_log10(m->d_L10, 65538, m->stream));
+  SFM_TRY(dev_alloc(m, &m->d_geo_count, (size_t)m->n_views));
+  SFM_TRY(dev_alloc(m, &m->d_geo_idx, (size_t)m->n_rows));
+  SFM_TRY(dev_alloc(m, &m->d_status, (size_t)1));
+  SFM_TRY(dev_alloc(m, &m->d_cand, (size_t)m->cand_cap));
+  SFM_TRY(dev_alloc(m, &m->d_n_cand, (size_t)1));
+  SFM_TRY(dev_alloc(m, &m->d_best64, (size_t)65536));
+  SFM_TRY(dev_alloc(m, &m->d_winner, (size_t)65536));
+  SFM_TRY(dev_alloc(m, &m->d_ms_n, (size_t)1));
+  SFM_TRY(dev_alloc(m, &m->d_ms_qfeat, (size_t)65536));
+  SFM_TRY(dev_alloc(m, &m->d_ms_landmark, (size_t)65536));
+  SFM_TRY(dev_alloc(m, &m->d_pt2d, (size_t)65536 * 2));
+  SFM_TRY(dev_alloc(m, &m->d_pt3d, (size_t)65536 * 3));
+  SFM_TRY(dev_alloc(m, &m->d_xn, (size_t)kP3pMaxN * 2));
+  SFM_TRY(dev_alloc(m, &m->d_logc_n, (size_t)kP3pMaxN + 1));
+  SFM_TRY(dev_alloc(m, &m->d_logc_k, (size_t)kP3pMaxN + 1));
+  SFM_TRY(dev_alloc(m, &m->d_vec_index, (size_t)kP3pMaxN));
+  SFM_TRY(dev_alloc(m, &m->d_best_inl, (size_t)kP3pMaxN));
+  SFM_TRY(dev_alloc(m, &m->d_hyp_nfa, (size_t)kP3pBatchMax));
+  SFM_TRY(dev_alloc(m, &m->d_hyp_err, (size_t)kP3pBatchMax));
+  SFM_TRY(dev_alloc(m, &m->d_hyp_model, (size_t)kP3pBatchMax * 12));
+  SFM_TRY(dev_alloc(m, &m->d_hyp_k, (size_t)kP3pBatchMax));
+  SFM_TRY(dev_alloc(m, &m->d_hyp_inl, (size_t)kP3pBatchMax * kP3pMaxN));
+  SFM_TRY(dev_alloc(m, &m->d_pair_qfeat, (size_t)kP3pMaxN));
+  SFM_TRY(dev_alloc(m, &m->d_pair_landmark, (size_t)kP3pMaxN));
+  SFM_TRY(dev_alloc(m, &m->d_inlier_idx, (size_t)kP3pMaxN));
+  SFM_TRY(dev_alloc(m, &m->d_p3p_state, (size_t)1));
+  SFM_TRY(dev_alloc(m, &m->d_pose, (size_t)1));
+  {
+    hipError_t ze = hipMemsetAsync(m->d_status, 0, sizeof(int), m->stream);
+    if (ze == hipSuccess) ze = hipMemsetAsync(m->d_geo_count, 0, (size_t)m->n_views * sizeof(uint32_t), m->stream);
+    if (ze == hipSuccess) ze = hipMemsetAsync(m->d_ms_n, 0, sizeof(uint32_t), m->stream);
+    if (ze == hipSuccess) ze = hipMemsetAsync(m->d_pose, 0, sizeof(Pose), m->stream);
+    if (ze == hipSuccess) ze = hipMemsetAsync(m->d_p3p_state, 0, sizeof(P3pState), m->stream);
+    if (ze != hipSuccess) {
+      set_error("workspace init: %s", hipGetErrorString(ze));
+      free_map(m);
+      return SFMLOC_EHIP;
+    }
+  }
   {
     hipError_t he = hipHostMalloc((void **)&m->h_pinned, ((size_t)m->n_views + m->n_blocks + 16) * sizeof(uint32_t),
                                   hipHostMallocDefault);
@@ -337,11 +389,24 @@ int sfmloc_query_create(sfmloc_map *map, const uint8_t *desc, const float *kpt_x
     e = hipMalloc((void **)&q->d_desc, n_pad * 64);
     if (e == hipSuccess) e = hipMemsetAsync(q->d_desc, 0, n_pad * 64, m->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(q->d_desc, desc, (size_t)n * 64, hipMemcpyHostToDevice, m->stream);
+    std::vector<float> k6;
     if (e == hipSuccess && kpt_xy) {
       q->h_kpt.assign(kpt_xy, kpt_xy + 2 * (size_t)n);
+      // The reference writes the query's keypoints to <tmp>/<base>.feat with `ostream << float`
+      // (6 significant digits, AKAZEOpenCV.cpp:80-81) and the F-matrix filter reads them back through
+      // Regions::Load (:106-111); pt2D keeps the unrounded values (:77-79).  Reproduce the round trip.
+      k6.resize(2 * (size_t)n);
+      char buf[64];
+      for (size_t i = 0; i < 2 * (size_t)n; ++i) {
+        snprintf(buf, sizeof(buf), "%.6g", (double)kpt_xy[i]);
+        k6[i] = strtof(buf, nullptr);
+      }
       e = hipMalloc((void **)&q->d_kpt, (size_t)n * sizeof(float2));
+      if (e == hipSuccess) e = hipMalloc((void **)&q->d_kpt6, (size_t)n * sizeof(float2));
       if (e == hipSuccess)
         e = hipMemcpyAsync(q->d_kpt, kpt_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, m->stream);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(q->d_kpt6, k6.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice, m->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
   }
@@ -349,6 +414,7 @@ int sfmloc_query_create(sfmloc_map *map, const uint8_t *desc, const float *kpt_x
     set_error("sfmloc_query_create: %s", hipGetErrorString(e));
     if (q->d_desc) hipFree(q->d_desc);
     if (q->d_kpt) hipFree(q->d_kpt);
+    if (q->d_kpt6) hipFree(q->d_kpt6);
     delete q;
     return e == hipErrorOutOfMemory ? SFMLOC_ENOMEM : SFMLOC_EHIP;
   }
@@ -365,6 +431,7 @@ void sfmloc_query_destroy(sfmloc_query *query) {
   }
   if (q->d_desc) hipFree(q->d_desc);
   if (q->d_kpt) hipFree(q->d_kpt);
+  if (q->d_kpt6) hipFree(q->d_kpt6);
   delete q;
 }
 
@@ -514,6 +581,195 @@ int sfmloc_putative_read_rows(sfmloc_map *map, uint32_t *best0, uint32_t *best1)
     for (uint32_t b : m->last_blocks) do_block(b);
   }
   return SFMLOC_OK;
+}
+
+static int check_stage(Map *m, Query *q, const char *who) {
+  SFM_CHECK(m && q, SFMLOC_EINVAL, "%s: null argument", who);
+  SFM_CHECK(q->map == m, SFMLOC_EINVAL, "%s: query belongs to another map", who);
+  SFM_CHECK(m->have_geometry, SFMLOC_EINVAL,
+            "%s: the map was created without view sizes / keypoints / landmarks / intrinsics", who);
+  SFM_CHECK(q->n == 0 || q->d_kpt, SFMLOC_EINVAL, "%s: the query was created without keypoints", who);
+  SFM_CHECK(q->n == 0 || (q->width > 0 && q->height > 0), SFMLOC_EINVAL, "%s: query image size missing", who);
+  SFM_CHECK(m->last_nq == q->n, SFMLOC_EINVAL, "%s: run sfmloc_match_putative with this query first", who);
+  return SFMLOC_OK;
+}
+
+int sfmloc_geometric_filter(sfmloc_map *map, sfmloc_query *query) {
+  Map *m = reinterpret_cast<Map *>(map);
+  Query *q = reinterpret_cast<Query *>(query);
+  int rc = check_stage(m, q, "sfmloc_geometric_filter");
+  if (rc) return rc;
+  SFM_HIP(hipSetDevice(m->device));
+  SFM_HIP(hipMemsetAsync(m->d_geo_count, 0, (size_t)m->n_views * sizeof(uint32_t), m->stream));
+  SFM_HIP(hipMemsetAsync(m->d_status, 0, sizeof(int), m->stream));
+  if (q->n == 0 || m->last_n_sel == 0) return SFMLOC_OK;
+  EventScope ev(m, SFMLOC_K_FMATRIX);
+  return launch_fmatrix_filter(m, q, m->last_n_sel, m->last_all_views);
+}
+
+int sfmloc_geometric_read(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_idx, uint64_t cap) {
+  SFM_CHECK(map, SFMLOC_EINVAL, "sfmloc_geometric_read: null map");
+  Map *m = reinterpret_cast<Map *>(map);
+  SFM_HIP(hipSetDevice(m->device));
+  SFM_HIP(hipStreamSynchronize(m->stream));
+  std::vector<uint32_t> cnt(m->n_views);
+  SFM_HIP(hipMemcpy(cnt.data(), m->d_geo_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (geo_count) memcpy(geo_count, cnt.data(), cnt.size() * sizeof(uint32_t));
+  if (geo_idx) {
+    SFM_CHECK(cap >= m->n_rows, SFMLOC_ECAP, "sfmloc_geometric_read: cap too small");
+    std::vector<uint32_t> gi(m->n_rows);
+    SFM_HIP(hipMemcpy(gi.data(), m->d_geo_idx, gi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t v = 0; v < m->n_views; ++v)
+      for (uint32_t k = 0; k < cnt[v]; ++k) geo_idx[m->h_view_off[v] + k] = gi[m->h_view_off[v] + k];
+  }
+  int st = 0;
+  SFM_HIP(hipMemcpy(&st, m->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  SFM_CHECK((st & 1) == 0, SFMLOC_ECAP, "a view has more than 2048 putative matches (F-matrix workspace)");
+  return SFMLOC_OK;
+}
+
+int sfmloc_match_set(sfmloc_map *map, sfmloc_query *query) {
+  Map *m = reinterpret_cast<Map *>(map);
+  Query *q = reinterpret_cast<Query *>(query);
+  int rc = check_stage(m, q, "sfmloc_match_set");
+  if (rc) return rc;
+  SFM_HIP(hipSetDevice(m->device));
+  EventScope ev(m, SFMLOC_K_MATCHSET);
+  return launch_match_set(m, q, m->last_n_sel, m->last_all_views);
+}
+
+int sfmloc_match_set_read(sfmloc_map *map, uint32_t *n, uint32_t *qfeat, uint32_t *landmark_id, double *pt2d,
+                          double *pt3d, uint32_t cap) {
+  SFM_CHECK(map && n, SFMLOC_EINVAL, "sfmloc_match_set_read: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  SFM_HIP(hipSetDevice(m->device));
+  SFM_HIP(hipStreamSynchronize(m->stream));
+  uint32_t k = 0;
+  SFM_HIP(hipMemcpy(&k, m->d_ms_n, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  *n = k;
+  int st = 0;
+  SFM_HIP(hipMemcpy(&st, m->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  SFM_CHECK((st & 2) == 0, SFMLOC_ECAP, "more than %u 2D-3D candidates (match-set workspace)", m->cand_cap);
+  if (k == 0) return SFMLOC_OK;
+  SFM_CHECK(cap >= k, SFMLOC_ECAP, "sfmloc_match_set_read: cap %u < %u", cap, k);
+  if (qfeat) SFM_HIP(hipMemcpy(qfeat, m->d_ms_qfeat, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (landmark_id) SFM_HIP(hipMemcpy(landmark_id, m->d_ms_landmark, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (pt2d) SFM_HIP(hipMemcpy(pt2d, m->d_pt2d, (size_t)k * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  if (pt3d) SFM_HIP(hipMemcpy(pt3d, m->d_pt3d, (size_t)k * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  return SFMLOC_OK;
+}
+
+// Enqueues the P3P AC-RANSAC rounds.  The device-side state machine makes surplus rounds no-ops, so a fixed
+// number is enqueued without synchronising; the host only looks at the state when that number is spent.
+static int run_resection(Map *m) {
+  int rc = launch_p3p_init(m);
+  if (rc) return rc;
+  P3pState st;
+  int first = 1;
+  for (int guard = 0; guard < 64; ++guard) {
+    for (int r = 0; r < 12; ++r) {
+      rc = launch_p3p_round(m, first ? 64 : kP3pBatchMax);
+      first = 0;
+      if (rc) return rc;
+    }
+    SFM_HIP(hipMemcpyAsync(&st, m->d_p3p_state, sizeof(st), hipMemcpyDeviceToHost, m->stream));
+    SFM_HIP(hipStreamSynchronize(m->stream));
+    if (st.done) return SFMLOC_OK;
+  }
+  set_error("P3P AC-RANSAC did not finish in %d rounds (iter %d of %d)", 64 * 12, st.iter, st.n_iter);
+  return SFMLOC_EHIP;
+}
+
+int sfmloc_resection(sfmloc_map *map, sfmloc_query *query) {
+  Map *m = reinterpret_cast<Map *>(map);
+  Query *q = reinterpret_cast<Query *>(query);
+  int rc = check_stage(m, q, "sfmloc_resection");
+  if (rc) return rc;
+  SFM_HIP(hipSetDevice(m->device));
+  EventScope ev(m, SFMLOC_K_P3P);
+  return run_resection(m);
+}
+
+int sfmloc_pose_read(sfmloc_map *map, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,
+                     uint32_t *inlier_idx, uint32_t cap) {
+  SFM_CHECK(map && out, SFMLOC_EINVAL, "sfmloc_pose_read: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  SFM_HIP(hipSetDevice(m->device));
+  SFM_HIP(hipStreamSynchronize(m->stream));
+  SFM_HIP(hipMemcpy(out, m->d_pose, sizeof(Pose), hipMemcpyDeviceToHost));
+  SFM_CHECK((out->status & 4) == 0, SFMLOC_ECAP, "more than %d 2D-3D correspondences (P3P workspace)", kP3pMaxN);
+  if (out->ok && out->n_inliers > 0) {
+    const uint32_t k = (uint32_t)out->n_inliers;
+    if (pair_qfeat || pair_landmark || inlier_idx)
+      SFM_CHECK(cap >= k, SFMLOC_ECAP, "sfmloc_pose_read: cap %u < %u inliers", cap, k);
+    if (pair_qfeat) SFM_HIP(hipMemcpy(pair_qfeat, m->d_pair_qfeat, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (pair_landmark)
+      SFM_HIP(hipMemcpy(pair_landmark, m->d_pair_landmark, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (inlier_idx) SFM_HIP(hipMemcpy(inlier_idx, m->d_inlier_idx, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  return SFMLOC_OK;
+}
+
+int sfmloc_localize(sfmloc_map *map, sfmloc_query *query, const uint32_t *view_sel, uint32_t n_sel,
+                    sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t cap) {
+  SFM_CHECK(map && query && out, SFMLOC_EINVAL, "sfmloc_localize: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  Query *q = reinterpret_cast<Query *>(query);
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  int rc = sfmloc_match_putative(map, query, view_sel, n_sel);
+  if (rc) return rc;
+  rc = check_stage(m, q, "sfmloc_localize");
+  if (rc) return rc;
+  rc = sfmloc_geometric_filter(map, query);
+  if (rc) return rc;
+  rc = sfmloc_match_set(map, query);
+  if (rc) return rc;
+  {
+    EventScope ev(m, SFMLOC_K_P3P);
+    rc = run_resection(m);
+  }
+  if (rc) return rc;
+  rc = sfmloc_pose_read(map, out, pair_qfeat, pair_landmark, nullptr, cap);
+  if (rc) return rc;
+  int st = 0;
+  SFM_HIP(hipMemcpy(&st, m->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  out->status |= st;
+  SFM_CHECK((st & 3) == 0, SFMLOC_ECAP, "device workspace exceeded (status %d)", st);
+  const auto t1 = clk::now();
+  for (int i = 0; i < 7; ++i) out->stage_seconds[i] = 0.0;
+  out->stage_seconds[6] = std::chrono::duration<double>(t1 - t0).count();  // split per stage: sfmloc_stats_read
+  return SFMLOC_OK;
+}
+
+int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride) {
+  SFM_CHECK(in && out && n > 0 && in_stride > 0 && out_stride > 0, SFMLOC_EINVAL, "sfmloc_debug_math: bad argument");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  SFM_CHECK(e == hipSuccess && ndev > 0, SFMLOC_ENODEV, "no HIP device visible; this library has no CPU fallback");
+  SFM_HIP(hipSetDevice(device));
+  double *d_in = nullptr, *d_out = nullptr;
+  SFM_HIP(hipMalloc((void **)&d_in, (size_t)n * in_stride * sizeof(double)));
+  hipError_t e2 = hipMalloc((void **)&d_out, (size_t)n * out_stride * sizeof(double));
+  if (e2 != hipSuccess) {
+    hipFree(d_in);
+    set_error("hipMalloc: %s", hipGetErrorString(e2));
+    return SFMLOC_ENOMEM;
+  }
+  int rc = SFMLOC_OK;
+  e = hipMemcpy(d_in, in, (size_t)n * in_stride * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(d_out, 0, (size_t)n * out_stride * sizeof(double));
+  if (e == hipSuccess) rc = launch_debug_math(op, d_in, n, in_stride, d_out, out_stride, nullptr);
+  if (e == hipSuccess && rc == SFMLOC_OK) e = hipDeviceSynchronize();
+  if (e == hipSuccess && rc == SFMLOC_OK)
+    e = hipMemcpy(out, d_out, (size_t)n * out_stride * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d_in);
+  hipFree(d_out);
+  if (e != hipSuccess) {
+    set_error("sfmloc_debug_math: %s", hipGetErrorString(e));
+    return SFMLOC_EHIP;
+  }
+  return rc;
 }
 
 int sfmloc_sync(sfmloc_map *map) {

@@ -45,6 +45,45 @@ void set_error(const char *fmt, ...);
 // contiguous, fully coalesced 1 KiB.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kBlockRows = 64;
+constexpr int kP3pMaxN = 4096;     // 2D-3D correspondences the P3P LDS sort holds
+constexpr int kP3pBatchMax = 512;  // hypotheses evaluated per round
+
+using Pose = sfmloc_pose;
+
+// one 2D-3D candidate (K4); `order` sorts candidates of one query feature exactly as the reference's
+// sequential scan would meet them (distance, then view id, then position in the view's list)
+struct Candidate {
+  uint64_t order;
+  uint32_t qfeat;
+  uint32_t landmark_id;
+  double X[3];
+};
+
+struct P3pState {
+  int n, iter, n_iter, n_reserve, n_index, identity, n_in, done, rounds, status;
+  double min_nfa, errmax;
+  double model[12];
+};
+
+struct P3pArgs {
+  P3pState *state;
+  Pose *result;
+  const uint32_t *ms_n, *ms_qfeat, *ms_landmark;
+  const double *pt2d, *pt3d;
+  double *xn;
+  const double *L10;
+  float *logc_n, *logc_k;
+  int32_t *vec_index, *best_inl;
+  double *hyp_nfa;
+  int *hyp_k;
+  double *hyp_err, *hyp_model;
+  int32_t *hyp_inl;
+  uint32_t *pair_qfeat, *pair_landmark, *inlier_idx;
+  double focal, ppx, ppy;
+  int max_iteration, min_resection_points, min_inliers, max_n;
+  uint64_t seed;
+  uint32_t stream;
+};
 
 struct KernelTimer;  // capi.hip
 
@@ -63,6 +102,7 @@ struct Map {
   uint4 *d_bank = nullptr;         // tiled64, n_blocks*64 rows (zero padded)
   uint32_t *d_view_off = nullptr;  // [n_views+1]
   uint32_t *d_view_id = nullptr;   // [n_views]
+  uint32_t *d_view_wh = nullptr;   // [n_views*2]
   float2 *d_kpt = nullptr;         // [n_rows]
   int32_t *d_row_landmark = nullptr;
   uint32_t *d_landmark_id = nullptr;
@@ -84,6 +124,29 @@ struct Map {
   uint16_t *d_ratio_cnt = nullptr;   // [513]
   float ratio_cnt_for = -1.0f;       // ratio the table was built for
 
+  // --- geometric stages ---
+  double *d_L10 = nullptr;           // [65538] log10(i)
+  uint32_t *d_geo_count = nullptr;   // [n_views]
+  uint32_t *d_geo_idx = nullptr;     // [n_rows]
+  int *d_status = nullptr;
+  Candidate *d_cand = nullptr;
+  uint32_t cand_cap = 1u << 16;
+  uint32_t *d_n_cand = nullptr;
+  unsigned long long *d_best64 = nullptr;  // [65536]
+  uint32_t *d_winner = nullptr;            // [65536]
+  uint32_t *d_ms_n = nullptr, *d_ms_qfeat = nullptr, *d_ms_landmark = nullptr;  // [65536]
+  double *d_pt2d = nullptr, *d_pt3d = nullptr;                                  // [65536*2], [65536*3]
+  double *d_xn = nullptr;                                                       // [kP3pMaxN*2]
+  float *d_logc_n = nullptr, *d_logc_k = nullptr;                               // [kP3pMaxN+1]
+  int32_t *d_vec_index = nullptr, *d_best_inl = nullptr;                        // [kP3pMaxN]
+  double *d_hyp_nfa = nullptr, *d_hyp_err = nullptr, *d_hyp_model = nullptr;
+  int *d_hyp_k = nullptr;
+  int32_t *d_hyp_inl = nullptr;  // [kP3pBatchMax * kP3pMaxN]
+  uint32_t *d_pair_qfeat = nullptr, *d_pair_landmark = nullptr, *d_inlier_idx = nullptr;  // [kP3pMaxN]
+  P3pState *d_p3p_state = nullptr;
+  Pose *d_pose = nullptr;
+  bool have_geometry = false;  // kpts + landmarks + view sizes were supplied
+
   // state of the last putative call
   uint32_t last_split = 0;
   uint32_t last_nq = 0;
@@ -102,7 +165,8 @@ struct Query {
   Map *map = nullptr;
   uint32_t n = 0, width = 0, height = 0;
   uint4 *d_desc = nullptr;  // [n_pad*4], row major, zero padded to a multiple of 64 rows
-  float2 *d_kpt = nullptr;
+  float2 *d_kpt = nullptr;   // full precision (locFeat, AKAZEOpenCV.cpp:77-79): used for pt2D
+  float2 *d_kpt6 = nullptr;  // after the .feat text round trip (6 significant digits): used by the F-matrix filter
   std::vector<float> h_kpt;
 };
 
@@ -110,5 +174,14 @@ struct Query {
 int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, uint4 *d_bank, hipStream_t s);
 int launch_hamming_top2(Map *m, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split);
 int launch_merge_ratio_compact(Map *m, const Query *q, uint32_t n_sel, bool all_views, uint32_t split);
+
+
+// acransac.hip
+int launch_fill_log10(double *d_L10, int n, hipStream_t s);
+int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *d_out, int out_stride, hipStream_t s);
+int launch_fmatrix_filter(Map *m, const Query *q, uint32_t n_sel, bool all_views);
+int launch_match_set(Map *m, const Query *q, uint32_t n_sel, bool all_views);
+int launch_p3p_init(Map *m);
+int launch_p3p_round(Map *m, int batch);
 
 }  // namespace sfmloc

@@ -38,7 +38,7 @@ def test_struct_layout_matches_header():
 #include <stddef.h>
 #include "sfmloc.h"
 int main(void){
-  printf("%zu %zu %zu %zu\n", sizeof(sfmloc_params), sizeof(sfmloc_map_desc), sizeof(sfmloc_map_info), sizeof(sfmloc_kernel_stats));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(sfmloc_params), sizeof(sfmloc_map_desc), sizeof(sfmloc_map_info), sizeof(sfmloc_kernel_stats), sizeof(sfmloc_pose), offsetof(sfmloc_pose, center));
   printf("%zu %zu %zu %zu\n", offsetof(sfmloc_params, geom_precision), offsetof(sfmloc_params, seed), offsetof(sfmloc_params, profile), offsetof(sfmloc_map_desc, bow));
   return 0; }
 '''
@@ -53,10 +53,12 @@ int main(void){
     assert sizes[1] == ctypes.sizeof(capi.MapDesc)
     assert sizes[2] == ctypes.sizeof(capi.MapInfo)
     assert sizes[3] == ctypes.sizeof(capi.KernelStats)
-    assert sizes[4] == capi.Params.geom_precision.offset
-    assert sizes[5] == capi.Params.seed.offset
-    assert sizes[6] == capi.Params.profile.offset
-    assert sizes[7] == capi.MapDesc.bow.offset
+    assert sizes[4] == ctypes.sizeof(capi.Pose)
+    assert sizes[5] == capi.Pose.center.offset
+    assert sizes[6] == capi.Params.geom_precision.offset
+    assert sizes[7] == capi.Params.seed.offset
+    assert sizes[8] == capi.Params.profile.offset
+    assert sizes[9] == capi.MapDesc.bow.offset
 
 
 def test_default_params_are_the_reference_defaults():
