@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--desc-per-view", type=int, default=2000)
     ap.add_argument("--nq", type=int, default=2000)
     ap.add_argument("--queries", type=int, default=8, help="distinct synthetic queries cycled through")
+    ap.add_argument("--in-flight", type=int, default=4, help="queries in flight (contexts); 1 = latency mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -94,14 +95,33 @@ def main():
     dqs = [dev_map.query(q.desc, q.kpt_xy, q.width, q.height) for q in queries]
     lat = []
     n_ok = [0]
+    nctx = max(1, a.in_flight)
+    ctxs = [dev_map.context() for _ in range(nctx)]
+    t_begin = [0.0] * nctx
+    busy = [False] * nctx
+
+    def finish(k):
+        pose, _, _ = ctxs[k].end()
+        lat.append(time.perf_counter() - t_begin[k])
+        n_ok[0] += int(pose.ok)
+        busy[k] = False
 
     def step(i):
-        t_s = time.perf_counter()
-        pose, _, _ = dev_map.localize(dqs[i % len(dqs)])
-        lat.append(time.perf_counter() - t_s)
-        n_ok[0] += int(pose.ok)
+        # one step = one query through the whole path; up to `nctx` steps overlap on the GPU
+        k = i % nctx
+        if busy[k]:
+            finish(k)
+        t_begin[k] = time.perf_counter()
+        ctxs[k].begin(dqs[i % len(dqs)])
+        busy[k] = True
+
+    def drain():
+        for k in range(nctx):
+            if busy[k]:
+                finish(k)
 
     def fence():
+        drain()
         dev_map.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -150,7 +170,7 @@ def main():
             "config": {"workload": f"{a.views}-image / {m.n_rows}-descriptor synthetic map, {a.nq} feats/query, "
                                    "whole per-query path: brute-force Hamming 2-NN + Lowe ratio -> >=16 filter -> "
                                    "F-matrix AC-RANSAC (25 rounds) -> 2D-3D set -> P3P AC-RANSAC (4096) -> pose; "
-                                   "one query in flight (latency mode)",
+                                   f"{nctx} queries in flight",
                        "views": a.views, "rows": int(m.n_rows), "nq": a.nq,
                        "parallelism": f"bank sharded by view x{world}",
                        "queries_localised": f"{n_ok[0]}/{a.steps}"},
@@ -168,6 +188,8 @@ def main():
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, queries, a.cpu_seconds)
         print(json.dumps(out), flush=True)
+    for c in ctxs:
+        c.close()
     for dq in dqs:
         dq.close()
     dev_map.close()

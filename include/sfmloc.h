@@ -209,6 +209,21 @@ int sfmloc_pose_read(sfmloc_map *map, sfmloc_pose *out, uint32_t *pair_qfeat, ui
 int sfmloc_localize(sfmloc_map *map, sfmloc_query *q, const uint32_t *view_sel, uint32_t n_sel, sfmloc_pose *out,
                     uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t cap);
 
+/* Concurrent queries.  A context is a HIP stream plus the workspace of one in-flight query; contexts of one
+ * map run concurrently on the GPU (the reference serves concurrent users with one engine per (user, map),
+ * localizeImage.cc:71-104 -- here they share one copy of the map).  _begin enqueues the whole path and
+ * returns; _end waits for it.  One query per context at a time.  Contexts are owned by the map. */
+typedef struct sfmloc_context sfmloc_context;
+int sfmloc_context_create(sfmloc_map *map, sfmloc_context **out);
+void sfmloc_context_destroy(sfmloc_context *ctx);
+int sfmloc_localize_begin(sfmloc_context *ctx, sfmloc_query *q, const uint32_t *view_sel, uint32_t n_sel);
+int sfmloc_localize_end(sfmloc_context *ctx, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,
+                        uint32_t cap);
+/* n queries against all views, n_contexts of them in flight (0 = 4).  poses[n]; pair buffers may be NULL,
+ * else query i's pairs start at i*pair_stride. */
+int sfmloc_localize_batch(sfmloc_map *map, sfmloc_query *const *queries, uint32_t n, uint32_t n_contexts,
+                          sfmloc_pose *poses, uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t pair_stride);
+
 /* Parity probe: runs one of the f64 device building blocks over n items (tests compare with the oracle).
  * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample */
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride);

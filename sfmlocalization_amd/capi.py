@@ -81,6 +81,8 @@ SYMBOLS = [
     "sfmloc_match_putative", "sfmloc_putative_read", "sfmloc_putative_read_rows", "sfmloc_sync",
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
     "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
+    "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
+    "sfmloc_localize_batch",
     "sfmloc_stats_read", "sfmloc_stats_reset",
 ]
 
@@ -118,6 +120,13 @@ def _L():
         L.sfmloc_localize.argtypes = [C.c_void_p, C.c_void_p, U32P, C.c_uint32, C.POINTER(Pose), U32P, U32P,
                                       C.c_uint32]
         L.sfmloc_debug_math.argtypes = [C.c_int, C.c_int, F64P, C.c_int, C.c_int, F64P, C.c_int]
+        L.sfmloc_context_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.sfmloc_context_destroy.restype = None
+        L.sfmloc_context_destroy.argtypes = [C.c_void_p]
+        L.sfmloc_localize_begin.argtypes = [C.c_void_p, C.c_void_p, U32P, C.c_uint32]
+        L.sfmloc_localize_end.argtypes = [C.c_void_p, C.POINTER(Pose), U32P, U32P, C.c_uint32]
+        L.sfmloc_localize_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32,
+                                            C.POINTER(Pose), U32P, U32P, C.c_uint32]
         L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
         L.sfmloc_stats_reset.argtypes = [C.c_void_p]
         _bound = True
@@ -314,6 +323,22 @@ class Map:
         k = pose.n_inliers if pose.ok else 0
         return pose, pq[:k].copy(), pl[:k].copy()
 
+    def context(self):
+        return Context(self)
+
+    def localize_batch(self, queries, n_contexts=4, cap=0):
+        """sfmloc_localize_batch: queries pipelined over n_contexts streams; -> list of Pose (+ pairs if cap)."""
+        n = len(queries)
+        arr = (C.c_void_p * n)(*[q._h for q in queries])
+        poses = (Pose * n)()
+        pq = np.zeros((n, cap), np.uint32) if cap else None
+        pl = np.zeros((n, cap), np.uint32) if cap else None
+        _check(_L().sfmloc_localize_batch(self._h, arr, n, n_contexts, poses, _ptr(pq, C.c_uint32),
+                                          _ptr(pl, C.c_uint32), cap))
+        if cap:
+            return list(poses), pq, pl
+        return list(poses)
+
     def stats(self):
         s = KernelStats()
         _check(_L().sfmloc_stats_read(self._h, C.byref(s)))
@@ -321,6 +346,37 @@ class Map:
 
     def stats_reset(self):
         _check(_L().sfmloc_stats_reset(self._h))
+
+
+class Context:
+    """sfmloc_context: one in-flight query (stream + workspace) on a map; begin() is asynchronous."""
+
+    def __init__(self, m):
+        self._h = None
+        self.map = m
+        h = C.c_void_p()
+        _check(_L().sfmloc_context_create(m._h, C.byref(h)))
+        self._h = h
+
+    def begin(self, q, view_sel=None):
+        if view_sel is None:
+            _check(_L().sfmloc_localize_begin(self._h, q._h, None, 0))
+        else:
+            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
+            _check(_L().sfmloc_localize_begin(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+
+    def end(self, cap=4096):
+        pose = Pose()
+        pq = np.zeros(cap, np.uint32)
+        pl = np.zeros(cap, np.uint32)
+        _check(_L().sfmloc_localize_end(self._h, C.byref(pose), _ptr(pq, C.c_uint32), _ptr(pl, C.c_uint32), cap))
+        k = pose.n_inliers if pose.ok else 0
+        return pose, pq[:k].copy(), pl[:k].copy()
+
+    def close(self):
+        if self._h is not None and self.map._h is not None:
+            _L().sfmloc_context_destroy(self._h)
+        self._h = None
 
 
 class Query:

@@ -337,12 +337,16 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
                                                          const uint32_t *geo_idx, const int32_t *row_landmark,
                                                          const uint32_t *landmark_id, const double *landmark_X,
                                                          Candidate *cand, uint32_t cap, uint32_t *n_cand,
-                                                         int *status) {
+                                                         int *status, uint32_t min_putative, uint32_t *view_stats) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= n_sel) return;
   const uint32_t v = view_sel ? view_sel[gw] : gw;
   const uint32_t ng = geo_count[v];
+  if (lane == 0) {  // the counts the reference prints (localization.cpp:416,458)
+    if (put_count[v] >= min_putative) atomicAdd(&view_stats[0], 1u);
+    if (ng > 0) atomicAdd(&view_stats[1], 1u);
+  }
   if (ng == 0) return;
   const uint32_t off = view_off[v];
   const uint32_t np = put_count[v];
@@ -732,17 +736,18 @@ int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *
   return SFMLOC_OK;
 }
 
-int launch_fmatrix_filter(Map *m, const Query *q, uint32_t n_sel, bool all_views) {
+int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views) {
+  Map *m = c->map;
   if (n_sel == 0) return SFMLOC_OK;
   FFilterArgs A;
-  A.view_sel = all_views ? nullptr : m->d_view_sel;
+  A.view_sel = all_views ? nullptr : c->d_view_sel;
   A.n_sel = n_sel;
   A.view_off = m->d_view_off;
   A.view_id = m->d_view_id;
   A.view_wh = m->d_view_wh;
-  A.put_count = m->d_view_count;
-  A.match_i = m->d_match_i;
-  A.match_key = m->d_match_key;
+  A.put_count = c->d_view_count;
+  A.match_i = c->d_match_i;
+  A.match_key = c->d_match_key;
   A.map_kpt = m->d_kpt;
   A.q_kpt6 = q->d_kpt6;
   A.qw = q->width;
@@ -752,62 +757,66 @@ int launch_fmatrix_filter(Map *m, const Query *q, uint32_t n_sel, bool all_views
   A.seed = m->params.seed;
   A.min_putative = m->params.min_putative;
   A.L10 = m->d_L10;
-  A.geo_count = m->d_geo_count;
-  A.geo_idx = m->d_geo_idx;
-  A.status = m->d_status;
+  A.geo_count = c->d_geo_count;
+  A.geo_idx = c->d_geo_idx;
+  A.status = c->d_status;
   const size_t lds = sizeof(FShared);
   SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_filter),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_fmatrix_filter, dim3(n_sel), dim3(kThreads), lds, m->stream, A);
+  hipLaunchKernelGGL(k_fmatrix_filter, dim3(n_sel), dim3(kThreads), lds, c->stream, A);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
-int launch_match_set(Map *m, const Query *q, uint32_t n_sel, bool all_views) {
-  SFM_HIP(hipMemsetAsync(m->d_n_cand, 0, sizeof(uint32_t), m->stream));
-  SFM_HIP(hipMemsetAsync(m->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), m->stream));
-  SFM_HIP(hipMemsetAsync(m->d_ms_n, 0, sizeof(uint32_t), m->stream));
+int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views) {
+  Map *m = c->map;
+  SFM_HIP(hipMemsetAsync(c->d_n_cand, 0, sizeof(uint32_t), c->stream));
+  SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
+  SFM_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
+  SFM_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
   if (n_sel == 0 || q->n == 0) return SFMLOC_OK;
-  hipLaunchKernelGGL(k_emit_candidates, dim3((n_sel + 3) / 4), dim3(256), 0, m->stream,
-                     all_views ? nullptr : m->d_view_sel, n_sel, m->d_view_off, m->d_view_id, m->d_view_count,
-                     m->d_match_i, m->d_match_key, m->d_geo_count, m->d_geo_idx, m->d_row_landmark,
-                     m->d_landmark_id, m->d_landmark_X, m->d_cand, m->cand_cap, m->d_n_cand, m->d_status);
+  hipLaunchKernelGGL(k_emit_candidates, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream,
+                     all_views ? nullptr : c->d_view_sel, n_sel, m->d_view_off, m->d_view_id, c->d_view_count,
+                     c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, m->d_row_landmark,
+                     m->d_landmark_id, m->d_landmark_X, c->d_cand, c->cand_cap, c->d_n_cand, c->d_status,
+                     (uint32_t)m->params.min_putative, c->d_view_stats);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_candidates_min, dim3(64), dim3(256), 0, m->stream, m->d_cand, m->d_n_cand, m->cand_cap,
-                     m->d_best64);
+  hipLaunchKernelGGL(k_candidates_min, dim3(64), dim3(256), 0, c->stream, c->d_cand, c->d_n_cand, c->cand_cap,
+                     c->d_best64);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_candidates_win, dim3(64), dim3(256), 0, m->stream, m->d_cand, m->d_n_cand, m->cand_cap,
-                     m->d_best64, m->d_winner);
+  hipLaunchKernelGGL(k_candidates_win, dim3(64), dim3(256), 0, c->stream, c->d_cand, c->d_n_cand, c->cand_cap,
+                     c->d_best64, c->d_winner);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(64), 0, m->stream, m->d_cand, m->d_best64, m->d_winner, q->n,
-                     q->d_kpt, m->d_ms_n, m->d_ms_qfeat, m->d_ms_landmark, m->d_pt2d, m->d_pt3d);
+  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(64), 0, c->stream, c->d_cand, c->d_best64, c->d_winner, q->n,
+                     q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
-static P3pArgs make_p3p_args(Map *m) {
+static P3pArgs make_p3p_args(Ctx *c) {
+  Map *m = c->map;
   P3pArgs A;
-  A.state = m->d_p3p_state;
-  A.result = m->d_pose;
-  A.ms_n = m->d_ms_n;
-  A.ms_qfeat = m->d_ms_qfeat;
-  A.ms_landmark = m->d_ms_landmark;
-  A.pt2d = m->d_pt2d;
-  A.pt3d = m->d_pt3d;
-  A.xn = m->d_xn;
+  A.state = c->d_p3p_state;
+  A.result = c->d_pose;
+  A.ms_n = c->d_ms_n;
+  A.ms_qfeat = c->d_ms_qfeat;
+  A.ms_landmark = c->d_ms_landmark;
+  A.pt2d = c->d_pt2d;
+  A.pt3d = c->d_pt3d;
+  A.xn = c->d_xn;
   A.L10 = m->d_L10;
-  A.logc_n = m->d_logc_n;
-  A.logc_k = m->d_logc_k;
-  A.vec_index = m->d_vec_index;
-  A.best_inl = m->d_best_inl;
-  A.hyp_nfa = m->d_hyp_nfa;
-  A.hyp_k = m->d_hyp_k;
-  A.hyp_err = m->d_hyp_err;
-  A.hyp_model = m->d_hyp_model;
-  A.hyp_inl = m->d_hyp_inl;
-  A.pair_qfeat = m->d_pair_qfeat;
-  A.pair_landmark = m->d_pair_landmark;
-  A.inlier_idx = m->d_inlier_idx;
+  A.logc_n = c->d_logc_n;
+  A.logc_k = c->d_logc_k;
+  A.vec_index = c->d_vec_index;
+  A.best_inl = c->d_best_inl;
+  A.hyp_nfa = c->d_hyp_nfa;
+  A.hyp_k = c->d_hyp_k;
+  A.hyp_err = c->d_hyp_err;
+  A.hyp_model = c->d_hyp_model;
+  A.hyp_inl = c->d_hyp_inl;
+  A.pair_qfeat = c->d_pair_qfeat;
+  A.pair_landmark = c->d_pair_landmark;
+  A.inlier_idx = c->d_inlier_idx;
   A.focal = m->focal;
   A.ppx = m->ppx;
   A.ppy = m->ppy;
@@ -820,15 +829,15 @@ static P3pArgs make_p3p_args(Map *m) {
   return A;
 }
 
-int launch_p3p_init(Map *m) {
-  P3pArgs A = make_p3p_args(m);
-  hipLaunchKernelGGL(k_p3p_init, dim3(1), dim3(kThreads), 0, m->stream, A);
+int launch_p3p_init(Ctx *c) {
+  P3pArgs A = make_p3p_args(c);
+  hipLaunchKernelGGL(k_p3p_init, dim3(1), dim3(kThreads), 0, c->stream, A);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
-int launch_p3p_round(Map *m, int batch) {
-  P3pArgs A = make_p3p_args(m);
+int launch_p3p_round(Ctx *c, int batch) {
+  P3pArgs A = make_p3p_args(c);
   const size_t lds = sizeof(P3pShared);
   static bool attr_set = false;
   if (!attr_set) {
@@ -836,9 +845,9 @@ int launch_p3p_round(Map *m, int batch) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_p3p_eval, dim3(batch), dim3(kThreads), lds, m->stream, A, batch);
+  hipLaunchKernelGGL(k_p3p_eval, dim3(batch), dim3(kThreads), lds, c->stream, A, batch);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_p3p_select, dim3(1), dim3(kThreads), 0, m->stream, A, batch);
+  hipLaunchKernelGGL(k_p3p_select, dim3(1), dim3(kThreads), 0, c->stream, A, batch);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

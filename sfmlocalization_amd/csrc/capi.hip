@@ -1,10 +1,17 @@
-// C ABI of libsfmloc_hip.so (include/sfmloc.h): handles, HBM residency, stream, measurement.
+// C ABI of libsfmloc_hip.so (include/sfmloc.h): handles, HBM residency, streams, measurement.
+//
+// Two kinds of state:
+//   Map  static, read-only after creation: tiled descriptor bank, view table, keypoints, landmarks, tables;
+//   Ctx  one in-flight query: a HIP stream plus the workspace of every stage.
+// The stage-level entry points (sfmloc_match_putative ... sfmloc_resection) run on the map's own context;
+// sfmloc_localize_begin/_end run a whole query asynchronously on any context, so that several queries
+// overlap (the latency-bound RANSAC kernels of one under the VALU-bound Hamming kernel of another).
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
-#include <chrono>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 
 #include "sfmloc_internal.h"
@@ -22,20 +29,24 @@ void set_error(const char *fmt, ...) {
 
 namespace {
 
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 template <typename T>
-int dev_alloc(Map *m, T **p, size_t n) {
+int dev_alloc(uint64_t *acct, T **p, size_t n) {
   *p = nullptr;
   if (n == 0) return SFMLOC_OK;
   SFM_HIP(hipMalloc((void **)p, n * sizeof(T)));
-  m->hbm_bytes += n * sizeof(T);
+  *acct += n * sizeof(T);
   return SFMLOC_OK;
 }
 
 template <typename T>
-int dev_upload(Map *m, T **p, const T *h, size_t n) {
-  int rc = dev_alloc(m, p, n);
+int dev_upload(uint64_t *acct, T **p, const T *h, size_t n, hipStream_t s) {
+  int rc = dev_alloc(acct, p, n);
   if (rc) return rc;
-  if (n) SFM_HIP(hipMemcpyAsync(*p, h, n * sizeof(T), hipMemcpyHostToDevice, m->stream));
+  if (n) SFM_HIP(hipMemcpyAsync(*p, h, n * sizeof(T), hipMemcpyHostToDevice, s));
   return SFMLOC_OK;
 }
 
@@ -55,71 +66,359 @@ void build_ratio_table(float ratio, uint16_t *cnt) {
   }
 }
 
+// what a finished query copies back in one asynchronous transfer
+struct HostResult {
+  P3pState state;
+  Pose pose;
+  int status;
+  uint32_t view_stats[2];
+  uint32_t pair_qfeat[kP3pMaxN];
+  uint32_t pair_landmark[kP3pMaxN];
+};
+
 struct EventScope {
-  Map *m;
+  Ctx *c;
   int which;
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
-  EventScope(Map *m_, int which_) : m(m_), which(which_), on(m_->params.profile != 0) {
+  EventScope(Ctx *c_, int which_) : c(c_), which(which_), on(c_->map->params.profile != 0) {
     if (!on) return;
-    if (!m->event_pool.empty()) {
-      a = m->event_pool.back().first;
-      b = m->event_pool.back().second;
-      m->event_pool.pop_back();
-    } else {
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
-        on = false;
-        return;
-      }
+    if (!c->event_pool.empty()) {
+      a = c->event_pool.back().first;
+      b = c->event_pool.back().second;
+      c->event_pool.pop_back();
+    } else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      on = false;
+      return;
     }
-    hipEventRecord(a, m->stream);
+    hipEventRecord(a, c->stream);
   }
   ~EventScope() {
     if (!on) return;
-    hipEventRecord(b, m->stream);
-    m->pending_events.push_back({which, {a, b}});
+    hipEventRecord(b, c->stream);
+    c->pending_events.push_back({which, {a, b}});
   }
 };
 
-int drain_events(Map *m) {
-  for (auto &pe : m->pending_events) {
+int drain_events(Ctx *c) {
+  for (auto &pe : c->pending_events) {
     float ms = 0.f;
     SFM_HIP(hipEventSynchronize(pe.second.second));
     SFM_HIP(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
-    m->stats.total_ms[pe.first] += ms;
-    m->stats.launches[pe.first] += 1;
-    m->event_pool.push_back(pe.second);
+    c->stats.total_ms[pe.first] += ms;
+    c->stats.launches[pe.first] += 1;
+    c->event_pool.push_back(pe.second);
   }
-  m->pending_events.clear();
+  c->pending_events.clear();
+  return SFMLOC_OK;
+}
+
+void free_ctx(Ctx *c) {
+  if (!c) return;
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto &pe : c->pending_events) {
+    hipEventDestroy(pe.second.first);
+    hipEventDestroy(pe.second.second);
+  }
+  for (auto &e : c->event_pool) {
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  void *ptrs[] = {c->d_part,      c->d_view_sel,  c->d_view_widx0, c->d_block_list, c->d_view_count, c->d_match_i,
+                  c->d_match_key, c->d_geo_count, c->d_geo_idx,    c->d_status,     c->d_cand,       c->d_n_cand,
+                  c->d_best64,    c->d_winner,    c->d_ms_n,       c->d_ms_qfeat,   c->d_ms_landmark, c->d_pt2d,
+                  c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
+                  c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,    c->d_pair_qfeat,
+                  c->d_pair_landmark, c->d_inlier_idx, c->d_p3p_state, c->d_pose,   c->d_view_stats};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->h_result) hipHostFree(c->h_result);
+  if (c->pinned_busy) hipEventDestroy(c->pinned_busy);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int make_ctx(Map *m, Ctx **out) {
+  *out = nullptr;
+  Ctx *c = new (std::nothrow) Ctx();
+  SFM_CHECK(c, SFMLOC_ENOMEM, "out of host memory");
+  c->map = m;
+  int rc = SFMLOC_OK;
+#define CTX_TRY(x)   \
+  do {               \
+    rc = (x);        \
+    if (rc) {        \
+      free_ctx(c);   \
+      return rc;     \
+    }                \
+  } while (0)
+#define CTX_HIP(x)                                              \
+  do {                                                          \
+    hipError_t e_ = (x);                                        \
+    if (e_ != hipSuccess) {                                     \
+      set_error("%s -> %s", #x, hipGetErrorString(e_));         \
+      free_ctx(c);                                              \
+      return e_ == hipErrorOutOfMemory ? SFMLOC_ENOMEM : SFMLOC_EHIP; \
+    }                                                           \
+  } while (0)
+  CTX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const uint64_t n_pad = (uint64_t)m->n_blocks * kBlockRows;
+  uint64_t *acct = &c->hbm_bytes;
+  CTX_TRY(dev_alloc(acct, &c->d_part, (size_t)n_pad));
+  CTX_TRY(dev_alloc(acct, &c->d_view_sel, (size_t)m->n_views));
+  CTX_TRY(dev_alloc(acct, &c->d_view_widx0, (size_t)m->n_views));
+  CTX_TRY(dev_alloc(acct, &c->d_block_list, (size_t)m->n_blocks));
+  CTX_TRY(dev_alloc(acct, &c->d_view_count, (size_t)m->n_views));
+  CTX_TRY(dev_alloc(acct, &c->d_match_i, (size_t)m->n_rows));
+  CTX_TRY(dev_alloc(acct, &c->d_match_key, (size_t)m->n_rows));
+  CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views));
+  CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
+  CTX_TRY(dev_alloc(acct, &c->d_status, (size_t)1));
+  CTX_TRY(dev_alloc(acct, &c->d_cand, (size_t)c->cand_cap));
+  CTX_TRY(dev_alloc(acct, &c->d_n_cand, (size_t)1));
+  CTX_TRY(dev_alloc(acct, &c->d_best64, (size_t)65536));
+  CTX_TRY(dev_alloc(acct, &c->d_winner, (size_t)65536));
+  CTX_TRY(dev_alloc(acct, &c->d_ms_n, (size_t)1));
+  CTX_TRY(dev_alloc(acct, &c->d_ms_qfeat, (size_t)65536));
+  CTX_TRY(dev_alloc(acct, &c->d_ms_landmark, (size_t)65536));
+  CTX_TRY(dev_alloc(acct, &c->d_pt2d, (size_t)65536 * 2));
+  CTX_TRY(dev_alloc(acct, &c->d_pt3d, (size_t)65536 * 3));
+  CTX_TRY(dev_alloc(acct, &c->d_xn, (size_t)kP3pMaxN * 2));
+  CTX_TRY(dev_alloc(acct, &c->d_logc_n, (size_t)kP3pMaxN + 1));
+  CTX_TRY(dev_alloc(acct, &c->d_logc_k, (size_t)kP3pMaxN + 1));
+  CTX_TRY(dev_alloc(acct, &c->d_vec_index, (size_t)kP3pMaxN));
+  CTX_TRY(dev_alloc(acct, &c->d_best_inl, (size_t)kP3pMaxN));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_nfa, (size_t)kP3pBatchMax));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_err, (size_t)kP3pBatchMax));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_model, (size_t)kP3pBatchMax * 12));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_k, (size_t)kP3pBatchMax));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_inl, (size_t)kP3pBatchMax * kP3pMaxN));
+  CTX_TRY(dev_alloc(acct, &c->d_pair_qfeat, (size_t)kP3pMaxN));
+  CTX_TRY(dev_alloc(acct, &c->d_pair_landmark, (size_t)kP3pMaxN));
+  CTX_TRY(dev_alloc(acct, &c->d_inlier_idx, (size_t)kP3pMaxN));
+  CTX_TRY(dev_alloc(acct, &c->d_p3p_state, (size_t)1));
+  CTX_TRY(dev_alloc(acct, &c->d_pose, (size_t)1));
+  CTX_TRY(dev_alloc(acct, &c->d_view_stats, (size_t)2));
+  CTX_HIP(hipHostMalloc((void **)&c->h_pinned, ((size_t)2 * m->n_views + m->n_blocks + 16) * sizeof(uint32_t),
+                        hipHostMallocDefault));
+  CTX_HIP(hipHostMalloc(&c->h_result, sizeof(HostResult), hipHostMallocDefault));
+  memset(c->h_result, 0, sizeof(HostResult));
+  CTX_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_view_count, 0, (size_t)m->n_views * sizeof(uint32_t), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_geo_count, 0, (size_t)m->n_views * sizeof(uint32_t), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_pose, 0, sizeof(Pose), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_p3p_state, 0, sizeof(P3pState), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
+  CTX_HIP(hipStreamSynchronize(c->stream));
+#undef CTX_TRY
+#undef CTX_HIP
+  *out = c;
   return SFMLOC_OK;
 }
 
 void free_map(Map *m) {
   if (!m) return;
   hipSetDevice(m->device);
-  if (m->stream) hipStreamSynchronize(m->stream);
-  for (auto &pe : m->pending_events) {
-    hipEventDestroy(pe.second.first);
-    hipEventDestroy(pe.second.second);
-  }
-  for (auto &e : m->event_pool) {
-    hipEventDestroy(e.first);
-    hipEventDestroy(e.second);
-  }
-  void *ptrs[] = {m->d_bank,       m->d_view_off,   m->d_view_id,    m->d_kpt,        m->d_row_landmark,
-                  m->d_landmark_id, m->d_landmark_X, m->d_bow,        m->d_part,       m->d_view_sel,
-                  m->d_block_list,  m->d_view_count, m->d_match_i,    m->d_match_key,  m->d_ratio_cnt,
-                  m->d_view_wh,     m->d_L10,        m->d_geo_count,  m->d_geo_idx,    m->d_status,
-                  m->d_cand,        m->d_n_cand,     m->d_best64,     m->d_winner,     m->d_ms_n,
-                  m->d_ms_qfeat,    m->d_ms_landmark, m->d_pt2d,      m->d_pt3d,       m->d_xn,
-                  m->d_logc_n,      m->d_logc_k,     m->d_vec_index,  m->d_best_inl,   m->d_hyp_nfa,
-                  m->d_hyp_err,     m->d_hyp_model,  m->d_hyp_k,      m->d_hyp_inl,    m->d_pair_qfeat,
-                  m->d_pair_landmark, m->d_inlier_idx, m->d_p3p_state, m->d_pose};
+  for (Ctx *c : m->pool) free_ctx(c);
+  free_ctx(m->ctx0);
+  void *ptrs[] = {m->d_bank,         m->d_view_off,   m->d_view_id, m->d_view_wh, m->d_kpt, m->d_row_landmark,
+                  m->d_landmark_id,  m->d_landmark_X, m->d_bow,     m->d_L10,     m->d_ratio_cnt};
   for (void *p : ptrs)
     if (p) hipFree(p);
-  if (m->h_pinned) hipHostFree(m->h_pinned);
-  if (m->stream) hipStreamDestroy(m->stream);
   delete m;
+}
+
+// ----- stages on a context --------------------------------------------------------------------------
+
+int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel) {
+  Map *m = c->map;
+  const bool all_views = (view_sel == nullptr);
+  if (all_views) n_sel = m->n_views;
+  SFM_CHECK(n_sel <= m->n_views, SFMLOC_EINVAL, "view selection: n_sel %u > n_views %u", n_sel, m->n_views);
+
+  // selected views -> ascending list of the 64-row bank blocks they overlap, plus per selected view the
+  // position of its first block in that list
+  uint32_t n_work_blocks = m->n_blocks;
+  c->last_blocks.clear();
+  if (!all_views) {
+    if (c->pinned_busy) SFM_HIP(hipEventSynchronize(c->pinned_busy));  // previous upload still reading the staging
+    uint32_t *h_sel = c->h_pinned;
+    uint32_t *h_w0 = c->h_pinned + m->n_views;
+    uint32_t *h_blk = c->h_pinned + 2 * (size_t)m->n_views;
+    uint32_t nb = 0;
+    for (uint32_t k = 0; k < n_sel; ++k) {
+      const uint32_t v = view_sel[k];
+      SFM_CHECK(v < m->n_views, SFMLOC_EINVAL, "view selection: index %u out of range", v);
+      SFM_CHECK(k == 0 || view_sel[k - 1] < v, SFMLOC_EINVAL, "view selection must be strictly ascending");
+      h_sel[k] = v;
+      h_w0[k] = 0;
+      const uint32_t r0 = m->h_view_off[v], r1 = m->h_view_off[v + 1];
+      if (r1 == r0) continue;
+      const uint32_t b0 = r0 / kBlockRows, b1 = (r1 - 1) / kBlockRows;
+      uint32_t b = b0;
+      if (nb && h_blk[nb - 1] == b0) {  // the previous selected view ends in this view's first block
+        h_w0[k] = nb - 1;
+        b = b0 + 1;
+      } else {
+        h_w0[k] = nb;
+      }
+      for (; b <= b1; ++b) h_blk[nb++] = b;
+    }
+    n_work_blocks = nb;
+    c->last_blocks.assign(h_blk, h_blk + nb);
+    if (n_sel) {
+      SFM_HIP(hipMemcpyAsync(c->d_view_sel, h_sel, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      SFM_HIP(hipMemcpyAsync(c->d_view_widx0, h_w0, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    if (nb) SFM_HIP(hipMemcpyAsync(c->d_block_list, h_blk, nb * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (!c->pinned_busy) SFM_HIP(hipEventCreateWithFlags(&c->pinned_busy, hipEventDisableTiming));
+    SFM_HIP(hipEventRecord(c->pinned_busy, c->stream));
+  }
+
+  // query split: spread a short block list over the chip (partial top-2 are merged in K2); the partial
+  // buffer holds n_blocks wave-blocks in all
+  uint32_t split = 1;
+  if (n_work_blocks && q->n >= 256) {
+    const uint64_t want = (uint64_t)m->n_cu * 8;
+    while (split < c->max_split && (uint64_t)n_work_blocks * split < want && q->n / (split * 2) >= 128 &&
+           (uint64_t)n_work_blocks * split * 2 <= m->n_blocks)
+      split *= 2;
+  }
+
+  SFM_HIP(hipMemsetAsync(c->d_view_count, 0, (size_t)m->n_views * sizeof(uint32_t), c->stream));
+  c->last_split = split;
+  c->last_nq = q->n;
+  c->last_n_sel = n_sel;
+  c->last_all_views = all_views;
+  c->last_n_work_blocks = n_work_blocks;
+  c->last_query = q;
+  if (q->n == 0 || n_sel == 0) return SFMLOC_OK;
+
+  int rc;
+  {
+    EventScope ev(c, SFMLOC_K_HAMMING);
+    rc = launch_hamming_top2(c, q, n_work_blocks, !all_views, split);
+  }
+  if (rc) return rc;
+  c->stats.hamming_pairs += (uint64_t)n_work_blocks * kBlockRows * q->n;
+  c->stats.hamming_alg_bytes += (uint64_t)n_work_blocks * kBlockRows * 64 + (uint64_t)q->n * 64;
+  {
+    EventScope ev(c, SFMLOC_K_COMPACT);
+    rc = launch_merge_ratio_compact(c, q, n_sel, all_views, split, n_work_blocks);
+  }
+  return rc;
+}
+
+int check_stage(Ctx *c, Query *q, const char *who) {
+  SFM_CHECK(c && q, SFMLOC_EINVAL, "%s: null argument", who);
+  Map *m = c->map;
+  SFM_CHECK(q->map == m, SFMLOC_EINVAL, "%s: query belongs to another map", who);
+  SFM_CHECK(m->have_geometry, SFMLOC_EINVAL,
+            "%s: the map was created without view sizes / keypoints / landmarks / intrinsics", who);
+  SFM_CHECK(q->n == 0 || q->d_kpt, SFMLOC_EINVAL, "%s: the query was created without keypoints", who);
+  SFM_CHECK(q->n == 0 || (q->width > 0 && q->height > 0), SFMLOC_EINVAL, "%s: query image size missing", who);
+  SFM_CHECK(c->last_query == q, SFMLOC_EINVAL, "%s: run sfmloc_match_putative with this query first", who);
+  return SFMLOC_OK;
+}
+
+int ctx_geometric_filter(Ctx *c, Query *q) {
+  Map *m = c->map;
+  SFM_HIP(hipMemsetAsync(c->d_geo_count, 0, (size_t)m->n_views * sizeof(uint32_t), c->stream));
+  SFM_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+  if (q->n == 0 || c->last_n_sel == 0) return SFMLOC_OK;
+  EventScope ev(c, SFMLOC_K_FMATRIX);
+  return launch_fmatrix_filter(c, q, c->last_n_sel, c->last_all_views);
+}
+
+int ctx_match_set(Ctx *c, Query *q) {
+  EventScope ev(c, SFMLOC_K_MATCHSET);
+  return launch_match_set(c, q, c->last_n_sel, c->last_all_views);
+}
+
+// Enqueues P3P AC-RANSAC rounds.  The device-side state machine turns surplus rounds into no-ops, so a fixed
+// number is enqueued without synchronising.
+int ctx_resection_enqueue(Ctx *c, bool first_call) {
+  int rc = SFMLOC_OK;
+  if (first_call) {
+    rc = launch_p3p_init(c);
+    if (rc) return rc;
+  }
+  for (int r = 0; r < 12 && rc == SFMLOC_OK; ++r) rc = launch_p3p_round(c, (first_call && r == 0) ? 64 : kP3pBatchMax);
+  return rc;
+}
+
+int ctx_fetch_result(Ctx *c) {
+  HostResult *h = reinterpret_cast<HostResult *>(c->h_result);
+  SFM_HIP(hipMemcpyAsync(&h->state, c->d_p3p_state, sizeof(P3pState), hipMemcpyDeviceToHost, c->stream));
+  SFM_HIP(hipMemcpyAsync(&h->pose, c->d_pose, sizeof(Pose), hipMemcpyDeviceToHost, c->stream));
+  SFM_HIP(hipMemcpyAsync(&h->status, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  SFM_HIP(hipMemcpyAsync(h->view_stats, c->d_view_stats, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  SFM_HIP(hipMemcpyAsync(h->pair_qfeat, c->d_pair_qfeat, sizeof(h->pair_qfeat), hipMemcpyDeviceToHost, c->stream));
+  SFM_HIP(hipMemcpyAsync(h->pair_landmark, c->d_pair_landmark, sizeof(h->pair_landmark), hipMemcpyDeviceToHost,
+                         c->stream));
+  return SFMLOC_OK;
+}
+
+int ctx_resection_wait(Ctx *c) {
+  HostResult *h = reinterpret_cast<HostResult *>(c->h_result);
+  for (int guard = 0; guard < 64; ++guard) {
+    SFM_HIP(hipStreamSynchronize(c->stream));
+    if (h->state.done) return SFMLOC_OK;
+    int rc = ctx_resection_enqueue(c, false);
+    if (rc) return rc;
+    rc = ctx_fetch_result(c);
+    if (rc) return rc;
+  }
+  set_error("P3P AC-RANSAC did not finish (iteration %d of %d)", h->state.iter, h->state.n_iter);
+  return SFMLOC_EHIP;
+}
+
+int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel) {
+  SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_localize_begin: context already has a query in flight");
+  c->t_begin = now_s();
+  int rc = ctx_match_putative(c, q, view_sel, n_sel);
+  if (rc) return rc;
+  rc = check_stage(c, q, "sfmloc_localize");
+  if (rc) return rc;
+  rc = ctx_geometric_filter(c, q);
+  if (rc) return rc;
+  rc = ctx_match_set(c, q);
+  if (rc) return rc;
+  {
+    EventScope ev(c, SFMLOC_K_P3P);
+    rc = ctx_resection_enqueue(c, true);
+  }
+  if (rc) return rc;
+  rc = ctx_fetch_result(c);
+  if (rc) return rc;
+  c->in_flight = q;
+  return SFMLOC_OK;
+}
+
+int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t cap) {
+  SFM_CHECK(c->in_flight != nullptr, SFMLOC_EINVAL, "sfmloc_localize_end: no query in flight on this context");
+  c->in_flight = nullptr;
+  int rc = ctx_resection_wait(c);
+  if (rc) return rc;
+  HostResult *h = reinterpret_cast<HostResult *>(c->h_result);
+  *out = h->pose;
+  out->status |= h->status;
+  out->n_putative_views = (int32_t)h->view_stats[0];
+  out->n_geometric_views = (int32_t)h->view_stats[1];
+  SFM_CHECK((out->status & 1) == 0, SFMLOC_ECAP, "a view has more than 2048 putative matches (F-matrix workspace)");
+  SFM_CHECK((out->status & 2) == 0, SFMLOC_ECAP, "more than %u 2D-3D candidates (match-set workspace)", c->cand_cap);
+  SFM_CHECK((out->status & 4) == 0, SFMLOC_ECAP, "more than %d 2D-3D correspondences (P3P workspace)", kP3pMaxN);
+  if (out->ok && out->n_inliers > 0 && (pair_qfeat || pair_landmark)) {
+    const uint32_t k = (uint32_t)out->n_inliers;
+    SFM_CHECK(cap >= k, SFMLOC_ECAP, "pair buffers hold %u entries, %u inliers", cap, k);
+    if (pair_qfeat) memcpy(pair_qfeat, h->pair_qfeat, k * sizeof(uint32_t));
+    if (pair_landmark) memcpy(pair_landmark, h->pair_landmark, k * sizeof(uint32_t));
+  }
+  for (int i = 0; i < 7; ++i) out->stage_seconds[i] = 0.0;
+  out->stage_seconds[6] = now_s() - c->t_begin;  // wall time begin -> end; per-kernel split: sfmloc_stats_read
+  return SFMLOC_OK;
 }
 
 }  // namespace
@@ -141,14 +440,14 @@ int sfmloc_device_count(void) {
 void sfmloc_default_params(sfmloc_params *p) {
   if (!p) return;
   memset(p, 0, sizeof(*p));
-  p->dist_ratio = 0.6f;       // localization.cpp:70
-  p->ransac_round = 200;      // localization.cpp:71
-  p->geom_precision = 4.0;    // localization.cpp:81
-  p->bow_knn = 0;             // localization.cpp:73
-  p->min_putative = 16;       // localization.cpp:56
-  p->min_resection_points = 8;   // localization.cpp:57
-  p->min_inliers = 10;        // localization.cpp:58
-  p->p3p_max_iteration = 4096;   // OpenMVG Image_Localizer_Match_Data default
+  p->dist_ratio = 0.6f;         // localization.cpp:70
+  p->ransac_round = 200;        // localization.cpp:71
+  p->geom_precision = 4.0;      // localization.cpp:81
+  p->bow_knn = 0;               // localization.cpp:73
+  p->min_putative = 16;         // localization.cpp:56
+  p->min_resection_points = 8;  // localization.cpp:57
+  p->min_inliers = 10;          // localization.cpp:58
+  p->p3p_max_iteration = 4096;  // OpenMVG Image_Localizer_Match_Data default
   p->seed = 0x5f3759df12345678ull;
   p->refine_pose = 0;
   p->device = 0;
@@ -167,6 +466,7 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
     SFM_CHECK(d->view_off[v] <= d->view_off[v + 1], SFMLOC_EINVAL, "sfmloc_map_create: view_off not monotone at %u", v);
     SFM_CHECK(v == 0 || d->view_id[v - 1] < d->view_id[v], SFMLOC_EINVAL,
               "sfmloc_map_create: view_id must be strictly ascending at %u", v);
+    SFM_CHECK(d->view_id[v] < (1u << 24), SFMLOC_EINVAL, "sfmloc_map_create: view id %u >= 2^24", d->view_id[v]);
   }
   if (d->row_landmark) {
     SFM_CHECK(d->n_landmarks == 0 || (d->landmark_id && d->landmark_X), SFMLOC_EINVAL,
@@ -197,22 +497,27 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, p.device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
   int rc = SFMLOC_OK;
-#define SFM_TRY(x)       \
-  do {                   \
-    rc = (x);            \
-    if (rc) {            \
-      free_map(m);       \
-      return rc;         \
-    }                    \
+  hipStream_t s = nullptr;  // upload stream
+#define SFM_TRY(x)                   \
+  do {                               \
+    rc = (x);                        \
+    if (rc) {                        \
+      if (s) hipStreamDestroy(s);    \
+      free_map(m);                   \
+      return rc;                     \
+    }                                \
   } while (0)
-  {
-    hipError_t se = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
-    if (se != hipSuccess) {
-      set_error("hipStreamCreate: %s", hipGetErrorString(se));
-      free_map(m);
-      return SFMLOC_EHIP;
-    }
-  }
+#define MAP_HIP(x)                                                    \
+  do {                                                                \
+    hipError_t e_ = (x);                                              \
+    if (e_ != hipSuccess) {                                           \
+      set_error("%s -> %s", #x, hipGetErrorString(e_));               \
+      if (s) hipStreamDestroy(s);                                     \
+      free_map(m);                                                    \
+      return e_ == hipErrorOutOfMemory ? SFMLOC_ENOMEM : SFMLOC_EHIP; \
+    }                                                                 \
+  } while (0)
+  MAP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   m->n_rows = d->n_rows;
   m->n_blocks = (uint32_t)((d->n_rows + kBlockRows - 1) / kBlockRows);
   m->n_views = d->n_views;
@@ -226,34 +531,23 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
   m->k1 = d->k1;
   m->k2 = d->k2;
   m->k3 = d->k3;
+  uint64_t *acct = &m->hbm_bytes;
 
   // bank: upload row-major chunks and re-tile on the device
   const uint64_t n_pad = (uint64_t)m->n_blocks * kBlockRows;
-  SFM_TRY(dev_alloc(m, &m->d_bank, (size_t)n_pad * 4));
+  SFM_TRY(dev_alloc(acct, &m->d_bank, (size_t)n_pad * 4));
   if (n_pad) {
-    hipError_t me = hipMemsetAsync(m->d_bank, 0, n_pad * 64, m->stream);
-    if (me != hipSuccess) {
-      set_error("hipMemsetAsync: %s", hipGetErrorString(me));
-      free_map(m);
-      return SFMLOC_EHIP;
-    }
+    MAP_HIP(hipMemsetAsync(m->d_bank, 0, n_pad * 64, s));
     const uint64_t chunk = 16ull << 20;  // rows per staging chunk (1 GiB)
     uint4 *d_stage = nullptr;
     const uint64_t stage_rows = std::min<uint64_t>(chunk, d->n_rows);
-    if (stage_rows) {
-      hipError_t ae = hipMalloc((void **)&d_stage, stage_rows * 64);
-      if (ae != hipSuccess) {
-        set_error("hipMalloc(stage): %s", hipGetErrorString(ae));
-        free_map(m);
-        return SFMLOC_ENOMEM;
-      }
-    }
+    if (stage_rows) MAP_HIP(hipMalloc((void **)&d_stage, stage_rows * 64));
     for (uint64_t r0 = 0; r0 < d->n_rows; r0 += chunk) {
       const uint64_t n = std::min<uint64_t>(chunk, d->n_rows - r0);
-      hipError_t ce = hipMemcpyAsync(d_stage, d->desc + r0 * 64, n * 64, hipMemcpyHostToDevice, m->stream);
+      hipError_t ce = hipMemcpyAsync(d_stage, d->desc + r0 * 64, n * 64, hipMemcpyHostToDevice, s);
       if (ce == hipSuccess) {
-        rc = launch_tile_bank(d_stage, r0, n, m->d_bank, m->stream);
-        if (!rc) ce = hipStreamSynchronize(m->stream);
+        rc = launch_tile_bank(d_stage, r0, n, m->d_bank, s);
+        if (!rc) ce = hipStreamSynchronize(s);
       }
       if (ce != hipSuccess || rc) {
         if (ce != hipSuccess) {
@@ -261,6 +555,7 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
           rc = SFMLOC_EHIP;
         }
         hipFree(d_stage);
+        hipStreamDestroy(s);
         free_map(m);
         return rc;
       }
@@ -268,89 +563,37 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
     if (d_stage) hipFree(d_stage);
   }
 
-  SFM_TRY(dev_upload(m, &m->d_view_off, d->view_off, (size_t)d->n_views + 1));
-  SFM_TRY(dev_upload(m, &m->d_view_id, d->view_id, (size_t)d->n_views));
-  if (d->kpt_xy) SFM_TRY(dev_upload(m, (float **)&m->d_kpt, d->kpt_xy, (size_t)d->n_rows * 2));
+  SFM_TRY(dev_upload(acct, &m->d_view_off, d->view_off, (size_t)d->n_views + 1, s));
+  SFM_TRY(dev_upload(acct, &m->d_view_id, d->view_id, (size_t)d->n_views, s));
+  if (d->view_wh) SFM_TRY(dev_upload(acct, &m->d_view_wh, d->view_wh, (size_t)d->n_views * 2, s));
+  if (d->kpt_xy) SFM_TRY(dev_upload(acct, (float **)&m->d_kpt, d->kpt_xy, (size_t)d->n_rows * 2, s));
   if (d->row_landmark) {
-    SFM_TRY(dev_upload(m, &m->d_row_landmark, d->row_landmark, (size_t)d->n_rows));
-    SFM_TRY(dev_upload(m, &m->d_landmark_id, d->landmark_id, (size_t)d->n_landmarks));
-    SFM_TRY(dev_upload(m, &m->d_landmark_X, d->landmark_X, (size_t)d->n_landmarks * 3));
+    SFM_TRY(dev_upload(acct, &m->d_row_landmark, d->row_landmark, (size_t)d->n_rows, s));
+    SFM_TRY(dev_upload(acct, &m->d_landmark_id, d->landmark_id, (size_t)d->n_landmarks, s));
+    SFM_TRY(dev_upload(acct, &m->d_landmark_X, d->landmark_X, (size_t)d->n_landmarks * 3, s));
   }
   if (d->bow && d->bow_dim) {
     m->bow_dim = d->bow_dim;
-    SFM_TRY(dev_upload(m, &m->d_bow, d->bow, (size_t)d->n_views * d->bow_dim));
+    SFM_TRY(dev_upload(acct, &m->d_bow, d->bow, (size_t)d->n_views * d->bow_dim, s));
   }
-
-  // workspace of the putative stage
-  SFM_TRY(dev_alloc(m, &m->d_part, (size_t)m->max_split * n_pad));
-  SFM_TRY(dev_alloc(m, &m->d_view_sel, (size_t)m->n_views));
-  SFM_TRY(dev_alloc(m, &m->d_block_list, (size_t)m->n_blocks));
-  SFM_TRY(dev_alloc(m, &m->d_view_count, (size_t)m->n_views));
-  SFM_TRY(dev_alloc(m, &m->d_match_i, (size_t)m->n_rows));
-  SFM_TRY(dev_alloc(m, &m->d_match_key, (size_t)m->n_rows));
-  SFM_TRY(dev_alloc(m, &m->d_ratio_cnt, (size_t)513));
-  // workspace of the geometric stages
-  if (d->view_wh) SFM_TRY(dev_upload(m, &m->d_view_wh, d->view_wh, (size_t)d->n_views * 2));
   m->have_geometry = d->view_wh && d->kpt_xy && d->row_landmark && d->focal > 0.0;
-  SFM_TRY(dev_alloc(m, &m->d_L10, (size_t)65538));
-  SFM_TRY(launch_fill_log10(m->d_L10, 65538, m->stream));
-  SFM_TRY(dev_alloc(m, &m->d_geo_count, (size_t)m->n_views));
-  SFM_TRY(dev_alloc(m, &m->d_geo_idx, (size_t)m->n_rows));
-  SFM_TRY(dev_alloc(m, &m->d_status, (size_t)1));
-  SFM_TRY(dev_alloc(m, &m->d_cand, (size_t)m->cand_cap));
-  SFM_TRY(dev_alloc(m, &m->d_n_cand, (size_t)1));
-  SFM_TRY(dev_alloc(m, &m->d_best64, (size_t)65536));
-  SFM_TRY(dev_alloc(m, &m->d_winner, (size_t)65536));
-  SFM_TRY(dev_alloc(m, &m->d_ms_n, (size_t)1));
-  SFM_TRY(dev_alloc(m, &m->d_ms_qfeat, (size_t)65536));
-  SFM_TRY(dev_alloc(m, &m->d_ms_landmark, (size_t)65536));
-  SFM_TRY(dev_alloc(m, &m->d_pt2d, (size_t)65536 * 2));
-  SFM_TRY(dev_alloc(m, &m->d_pt3d, (size_t)65536 * 3));
-  SFM_TRY(dev_alloc(m, &m->d_xn, (size_t)kP3pMaxN * 2));
-  SFM_TRY(dev_alloc(m, &m->d_logc_n, (size_t)kP3pMaxN + 1));
-  SFM_TRY(dev_alloc(m, &m->d_logc_k, (size_t)kP3pMaxN + 1));
-  SFM_TRY(dev_alloc(m, &m->d_vec_index, (size_t)kP3pMaxN));
-  SFM_TRY(dev_alloc(m, &m->d_best_inl, (size_t)kP3pMaxN));
-  SFM_TRY(dev_alloc(m, &m->d_hyp_nfa, (size_t)kP3pBatchMax));
-  SFM_TRY(dev_alloc(m, &m->d_hyp_err, (size_t)kP3pBatchMax));
-  SFM_TRY(dev_alloc(m, &m->d_hyp_model, (size_t)kP3pBatchMax * 12));
-  SFM_TRY(dev_alloc(m, &m->d_hyp_k, (size_t)kP3pBatchMax));
-  SFM_TRY(dev_alloc(m, &m->d_hyp_inl, (size_t)kP3pBatchMax * kP3pMaxN));
-  SFM_TRY(dev_alloc(m, &m->d_pair_qfeat, (size_t)kP3pMaxN));
-  SFM_TRY(dev_alloc(m, &m->d_pair_landmark, (size_t)kP3pMaxN));
-  SFM_TRY(dev_alloc(m, &m->d_inlier_idx, (size_t)kP3pMaxN));
-  SFM_TRY(dev_alloc(m, &m->d_p3p_state, (size_t)1));
-  SFM_TRY(dev_alloc(m, &m->d_pose, (size_t)1));
+  SFM_TRY(dev_alloc(acct, &m->d_L10, (size_t)65538));
+  SFM_TRY(launch_fill_log10(m->d_L10, 65538, s));
   {
-    hipError_t ze = hipMemsetAsync(m->d_status, 0, sizeof(int), m->stream);
-    if (ze == hipSuccess) ze = hipMemsetAsync(m->d_geo_count, 0, (size_t)m->n_views * sizeof(uint32_t), m->stream);
-    if (ze == hipSuccess) ze = hipMemsetAsync(m->d_ms_n, 0, sizeof(uint32_t), m->stream);
-    if (ze == hipSuccess) ze = hipMemsetAsync(m->d_pose, 0, sizeof(Pose), m->stream);
-    if (ze == hipSuccess) ze = hipMemsetAsync(m->d_p3p_state, 0, sizeof(P3pState), m->stream);
-    if (ze != hipSuccess) {
-      set_error("workspace init: %s", hipGetErrorString(ze));
-      free_map(m);
-      return SFMLOC_EHIP;
-    }
+    uint16_t tab[513];
+    build_ratio_table(p.dist_ratio, tab);
+    SFM_TRY(dev_alloc(acct, &m->d_ratio_cnt, (size_t)513));
+    MAP_HIP(hipMemcpyAsync(m->d_ratio_cnt, tab, sizeof(tab), hipMemcpyHostToDevice, s));
+    MAP_HIP(hipStreamSynchronize(s));  // tab lives on the stack
+    m->ratio_cnt_for = p.dist_ratio;
   }
-  {
-    hipError_t he = hipHostMalloc((void **)&m->h_pinned, ((size_t)m->n_views + m->n_blocks + 16) * sizeof(uint32_t),
-                                  hipHostMallocDefault);
-    if (he != hipSuccess) {
-      set_error("hipHostMalloc: %s", hipGetErrorString(he));
-      free_map(m);
-      return SFMLOC_ENOMEM;
-    }
-  }
-  {
-    hipError_t he = hipStreamSynchronize(m->stream);
-    if (he != hipSuccess) {
-      set_error("map upload: %s", hipGetErrorString(he));
-      free_map(m);
-      return SFMLOC_EHIP;
-    }
-  }
+  MAP_HIP(hipStreamSynchronize(s));
+  hipStreamDestroy(s);
+  s = nullptr;
+  SFM_TRY(make_ctx(m, &m->ctx0));
+  m->hbm_bytes += m->ctx0->hbm_bytes;
 #undef SFM_TRY
+#undef MAP_HIP
   *out = reinterpret_cast<sfmloc_map *>(m);
   return SFMLOC_OK;
 }
@@ -366,6 +609,32 @@ int sfmloc_map_get_info(const sfmloc_map *map, sfmloc_map_info *info) {
   info->hbm_bytes = m->hbm_bytes;
   info->device = m->device;
   return SFMLOC_OK;
+}
+
+int sfmloc_context_create(sfmloc_map *map, sfmloc_context **out) {
+  SFM_CHECK(map && out, SFMLOC_EINVAL, "sfmloc_context_create: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  SFM_HIP(hipSetDevice(m->device));
+  Ctx *c = nullptr;
+  int rc = make_ctx(m, &c);
+  if (rc) return rc;
+  m->pool.push_back(c);
+  m->hbm_bytes += c->hbm_bytes;
+  *out = reinterpret_cast<sfmloc_context *>(c);
+  return SFMLOC_OK;
+}
+
+void sfmloc_context_destroy(sfmloc_context *ctx) {
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  if (!c) return;
+  Map *m = c->map;
+  hipSetDevice(m->device);
+  auto it = std::find(m->pool.begin(), m->pool.end(), c);
+  if (it != m->pool.end()) m->pool.erase(it);
+  auto ib = std::find(m->batch_ctx.begin(), m->batch_ctx.end(), c);
+  if (ib != m->batch_ctx.end()) m->batch_ctx.erase(ib);
+  m->hbm_bytes -= c->hbm_bytes;
+  free_ctx(c);
 }
 
 int sfmloc_query_create(sfmloc_map *map, const uint8_t *desc, const float *kpt_xy, uint32_t n, uint32_t width,
@@ -385,10 +654,11 @@ int sfmloc_query_create(sfmloc_map *map, const uint8_t *desc, const float *kpt_x
   q->height = height;
   const size_t n_pad = ((size_t)n + 63) / 64 * 64;
   hipError_t e = hipSuccess;
+  hipStream_t s = m->ctx0->stream;
   if (n_pad) {
     e = hipMalloc((void **)&q->d_desc, n_pad * 64);
-    if (e == hipSuccess) e = hipMemsetAsync(q->d_desc, 0, n_pad * 64, m->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(q->d_desc, desc, (size_t)n * 64, hipMemcpyHostToDevice, m->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(q->d_desc, 0, n_pad * 64, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(q->d_desc, desc, (size_t)n * 64, hipMemcpyHostToDevice, s);
     std::vector<float> k6;
     if (e == hipSuccess && kpt_xy) {
       q->h_kpt.assign(kpt_xy, kpt_xy + 2 * (size_t)n);
@@ -403,12 +673,11 @@ int sfmloc_query_create(sfmloc_map *map, const uint8_t *desc, const float *kpt_x
       }
       e = hipMalloc((void **)&q->d_kpt, (size_t)n * sizeof(float2));
       if (e == hipSuccess) e = hipMalloc((void **)&q->d_kpt6, (size_t)n * sizeof(float2));
+      if (e == hipSuccess) e = hipMemcpyAsync(q->d_kpt, kpt_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s);
       if (e == hipSuccess)
-        e = hipMemcpyAsync(q->d_kpt, kpt_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, m->stream);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(q->d_kpt6, k6.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice, m->stream);
+        e = hipMemcpyAsync(q->d_kpt6, k6.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice, s);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
   }
   if (e != hipSuccess) {
     set_error("sfmloc_query_create: %s", hipGetErrorString(e));
@@ -427,7 +696,10 @@ void sfmloc_query_destroy(sfmloc_query *query) {
   if (!q) return;
   if (q->map) {
     hipSetDevice(q->map->device);
-    hipStreamSynchronize(q->map->stream);
+    hipDeviceSynchronize();  // any context may still be reading the query
+    for (Ctx *c : q->map->pool)
+      if (c->last_query == q) c->last_query = nullptr;
+    if (q->map->ctx0 && q->map->ctx0->last_query == q) q->map->ctx0->last_query = nullptr;
   }
   if (q->d_desc) hipFree(q->d_desc);
   if (q->d_kpt) hipFree(q->d_kpt);
@@ -435,99 +707,33 @@ void sfmloc_query_destroy(sfmloc_query *query) {
   delete q;
 }
 
+// ----- stage-level API on the map's own context -------------------------------------------------------
+
 int sfmloc_match_putative(sfmloc_map *map, sfmloc_query *query, const uint32_t *view_sel, uint32_t n_sel) {
   SFM_CHECK(map && query, SFMLOC_EINVAL, "sfmloc_match_putative: null argument");
   Map *m = reinterpret_cast<Map *>(map);
   Query *q = reinterpret_cast<Query *>(query);
   SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_match_putative: query belongs to another map");
   SFM_HIP(hipSetDevice(m->device));
-
-  const bool all_views = (view_sel == nullptr);
-  if (all_views) n_sel = m->n_views;
-  SFM_CHECK(n_sel <= m->n_views, SFMLOC_EINVAL, "sfmloc_match_putative: n_sel %u > n_views %u", n_sel, m->n_views);
-
-  // ratio table (only rebuilt when the ratio changes)
-  if (m->ratio_cnt_for != m->params.dist_ratio) {
-    uint16_t tab[513];
-    build_ratio_table(m->params.dist_ratio, tab);
-    SFM_HIP(hipMemcpyAsync(m->d_ratio_cnt, tab, sizeof(tab), hipMemcpyHostToDevice, m->stream));
-    SFM_HIP(hipStreamSynchronize(m->stream));  // tab is on the stack
-    m->ratio_cnt_for = m->params.dist_ratio;
-  }
-
-  // selected views -> list of 64-row bank blocks they overlap (ascending, unique)
-  uint32_t n_work_blocks = m->n_blocks;
-  m->last_blocks.clear();
-  if (!all_views) {
-    uint32_t *h_sel = m->h_pinned;
-    uint32_t *h_blk = m->h_pinned + m->n_views;
-    uint32_t nb = 0;
-    for (uint32_t k = 0; k < n_sel; ++k) {
-      const uint32_t v = view_sel[k];
-      SFM_CHECK(v < m->n_views, SFMLOC_EINVAL, "sfmloc_match_putative: view index %u out of range", v);
-      SFM_CHECK(k == 0 || view_sel[k - 1] < v, SFMLOC_EINVAL,
-                "sfmloc_match_putative: view_sel must be strictly ascending");
-      h_sel[k] = v;
-      const uint32_t r0 = m->h_view_off[v], r1 = m->h_view_off[v + 1];
-      if (r1 == r0) continue;
-      uint32_t b0 = r0 / kBlockRows;
-      const uint32_t b1 = (r1 - 1) / kBlockRows;
-      if (nb && h_blk[nb - 1] >= b0) b0 = h_blk[nb - 1] + 1;
-      for (uint32_t b = b0; b <= b1; ++b) h_blk[nb++] = b;
-    }
-    n_work_blocks = nb;
-    m->last_blocks.assign(h_blk, h_blk + nb);
-    // the pinned staging area is reused by the next call: the copies must have been consumed
-    if (n_sel) SFM_HIP(hipMemcpyAsync(m->d_view_sel, h_sel, n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
-    if (nb) SFM_HIP(hipMemcpyAsync(m->d_block_list, h_blk, nb * sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
-    SFM_HIP(hipStreamSynchronize(m->stream));
-  }
-
-  // query split: spread a short block list over the chip (partial top-2 are merged in K2)
-  uint32_t split = 1;
-  if (n_work_blocks && q->n >= 256) {
-    const uint64_t want = (uint64_t)m->n_cu * 8;  // wave-blocks in flight we would like at least
-    while (split < m->max_split && (uint64_t)n_work_blocks * split < want && q->n / (split * 2) >= 128) split *= 2;
-  }
-
-  SFM_HIP(hipMemsetAsync(m->d_view_count, 0, (size_t)m->n_views * sizeof(uint32_t), m->stream));
-  m->last_split = split;
-  m->last_nq = q->n;
-  m->last_n_sel = n_sel;
-  m->last_all_views = all_views;
-  m->last_n_work_blocks = n_work_blocks;
-  if (q->n == 0 || n_sel == 0) return SFMLOC_OK;
-
-  int rc;
-  {
-    EventScope ev(m, SFMLOC_K_HAMMING);
-    rc = launch_hamming_top2(m, q, n_work_blocks, !all_views, split);
-  }
-  if (rc) return rc;
-  m->stats.hamming_pairs += (uint64_t)n_work_blocks * kBlockRows * q->n;
-  m->stats.hamming_alg_bytes += (uint64_t)n_work_blocks * kBlockRows * 64 + (uint64_t)q->n * 64;
-  {
-    EventScope ev(m, SFMLOC_K_COMPACT);
-    rc = launch_merge_ratio_compact(m, q, n_sel, all_views, split);
-  }
-  return rc;
+  return ctx_match_putative(m->ctx0, q, view_sel, n_sel);
 }
 
 int sfmloc_putative_read(sfmloc_map *map, uint32_t *view_count, uint32_t *match_i, uint32_t *match_j,
                          uint32_t *match_d, uint64_t cap) {
   SFM_CHECK(map, SFMLOC_EINVAL, "sfmloc_putative_read: null map");
   Map *m = reinterpret_cast<Map *>(map);
+  Ctx *c = m->ctx0;
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipStreamSynchronize(m->stream));
+  SFM_HIP(hipStreamSynchronize(c->stream));
   std::vector<uint32_t> cnt(m->n_views);
-  SFM_HIP(hipMemcpy(cnt.data(), m->d_view_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  SFM_HIP(hipMemcpy(cnt.data(), c->d_view_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (view_count) memcpy(view_count, cnt.data(), cnt.size() * sizeof(uint32_t));
   if (match_i || match_j || match_d) {
     SFM_CHECK(cap >= m->n_rows, SFMLOC_ECAP, "sfmloc_putative_read: cap %llu < n_rows %llu", (unsigned long long)cap,
               (unsigned long long)m->n_rows);
     std::vector<uint32_t> hi(m->n_rows), hk(m->n_rows);
-    SFM_HIP(hipMemcpy(hi.data(), m->d_match_i, hi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    SFM_HIP(hipMemcpy(hk.data(), m->d_match_key, hk.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SFM_HIP(hipMemcpy(hi.data(), c->d_match_i, hi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SFM_HIP(hipMemcpy(hk.data(), c->d_match_key, hk.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t v = 0; v < m->n_views; ++v) {
       const uint32_t off = m->h_view_off[v];
       for (uint32_t k = 0; k < cnt[v]; ++k) {
@@ -543,16 +749,17 @@ int sfmloc_putative_read(sfmloc_map *map, uint32_t *view_count, uint32_t *match_
 int sfmloc_putative_read_rows(sfmloc_map *map, uint32_t *best0, uint32_t *best1) {
   SFM_CHECK(map, SFMLOC_EINVAL, "sfmloc_putative_read_rows: null map");
   Map *m = reinterpret_cast<Map *>(map);
+  Ctx *c = m->ctx0;
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipStreamSynchronize(m->stream));
-  const uint64_t n_pad = (uint64_t)m->n_blocks * kBlockRows;
+  SFM_HIP(hipStreamSynchronize(c->stream));
   for (uint64_t r = 0; r < m->n_rows; ++r) {
     if (best0) best0[r] = SFMLOC_NOMATCH;
     if (best1) best1[r] = SFMLOC_NOMATCH;
   }
-  if (m->last_nq == 0 || m->last_n_sel == 0 || m->last_split == 0) return SFMLOC_OK;
-  std::vector<uint2> part((size_t)m->last_split * n_pad);
-  SFM_HIP(hipMemcpy(part.data(), m->d_part, part.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+  if (c->last_nq == 0 || c->last_n_sel == 0 || c->last_split == 0 || c->last_n_work_blocks == 0) return SFMLOC_OK;
+  const uint64_t nwb = c->last_n_work_blocks;
+  std::vector<uint2> part((size_t)c->last_split * nwb * 64);
+  SFM_HIP(hipMemcpy(part.data(), c->d_part, part.size() * sizeof(uint2), hipMemcpyDeviceToHost));
   auto push = [](uint32_t &b0, uint32_t &b1, uint32_t k) {
     if (k < b0) {
       b1 = b0;
@@ -561,153 +768,144 @@ int sfmloc_putative_read_rows(sfmloc_map *map, uint32_t *best0, uint32_t *best1)
       b1 = k;
     }
   };
-  auto do_block = [&](uint32_t blk) {
+  for (uint64_t w = 0; w < nwb; ++w) {
+    const uint32_t blk = c->last_all_views ? (uint32_t)w : c->last_blocks[w];
     for (uint32_t l = 0; l < kBlockRows; ++l) {
       const uint64_t r = (uint64_t)blk * kBlockRows + l;
       if (r >= m->n_rows) break;
       uint32_t b0 = SFMLOC_NOMATCH, b1 = SFMLOC_NOMATCH;
-      for (uint32_t s = 0; s < m->last_split; ++s) {
-        const uint2 p = part[(size_t)s * n_pad + r];
+      for (uint32_t s = 0; s < c->last_split; ++s) {
+        const uint2 p = part[((size_t)s * nwb + w) * 64 + l];
         push(b0, b1, p.x);
         push(b0, b1, p.y);
       }
       if (best0) best0[r] = b0;
       if (best1) best1[r] = b1;
     }
-  };
-  if (m->last_all_views) {
-    for (uint32_t b = 0; b < m->n_blocks; ++b) do_block(b);
-  } else {
-    for (uint32_t b : m->last_blocks) do_block(b);
   }
   return SFMLOC_OK;
 }
 
-static int check_stage(Map *m, Query *q, const char *who) {
-  SFM_CHECK(m && q, SFMLOC_EINVAL, "%s: null argument", who);
-  SFM_CHECK(q->map == m, SFMLOC_EINVAL, "%s: query belongs to another map", who);
-  SFM_CHECK(m->have_geometry, SFMLOC_EINVAL,
-            "%s: the map was created without view sizes / keypoints / landmarks / intrinsics", who);
-  SFM_CHECK(q->n == 0 || q->d_kpt, SFMLOC_EINVAL, "%s: the query was created without keypoints", who);
-  SFM_CHECK(q->n == 0 || (q->width > 0 && q->height > 0), SFMLOC_EINVAL, "%s: query image size missing", who);
-  SFM_CHECK(m->last_nq == q->n, SFMLOC_EINVAL, "%s: run sfmloc_match_putative with this query first", who);
-  return SFMLOC_OK;
-}
-
 int sfmloc_geometric_filter(sfmloc_map *map, sfmloc_query *query) {
+  SFM_CHECK(map && query, SFMLOC_EINVAL, "sfmloc_geometric_filter: null argument");
   Map *m = reinterpret_cast<Map *>(map);
   Query *q = reinterpret_cast<Query *>(query);
-  int rc = check_stage(m, q, "sfmloc_geometric_filter");
+  int rc = check_stage(m->ctx0, q, "sfmloc_geometric_filter");
   if (rc) return rc;
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipMemsetAsync(m->d_geo_count, 0, (size_t)m->n_views * sizeof(uint32_t), m->stream));
-  SFM_HIP(hipMemsetAsync(m->d_status, 0, sizeof(int), m->stream));
-  if (q->n == 0 || m->last_n_sel == 0) return SFMLOC_OK;
-  EventScope ev(m, SFMLOC_K_FMATRIX);
-  return launch_fmatrix_filter(m, q, m->last_n_sel, m->last_all_views);
+  return ctx_geometric_filter(m->ctx0, q);
 }
 
 int sfmloc_geometric_read(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_idx, uint64_t cap) {
   SFM_CHECK(map, SFMLOC_EINVAL, "sfmloc_geometric_read: null map");
   Map *m = reinterpret_cast<Map *>(map);
+  Ctx *c = m->ctx0;
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipStreamSynchronize(m->stream));
+  SFM_HIP(hipStreamSynchronize(c->stream));
   std::vector<uint32_t> cnt(m->n_views);
-  SFM_HIP(hipMemcpy(cnt.data(), m->d_geo_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  SFM_HIP(hipMemcpy(cnt.data(), c->d_geo_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (geo_count) memcpy(geo_count, cnt.data(), cnt.size() * sizeof(uint32_t));
   if (geo_idx) {
     SFM_CHECK(cap >= m->n_rows, SFMLOC_ECAP, "sfmloc_geometric_read: cap too small");
     std::vector<uint32_t> gi(m->n_rows);
-    SFM_HIP(hipMemcpy(gi.data(), m->d_geo_idx, gi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SFM_HIP(hipMemcpy(gi.data(), c->d_geo_idx, gi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t v = 0; v < m->n_views; ++v)
       for (uint32_t k = 0; k < cnt[v]; ++k) geo_idx[m->h_view_off[v] + k] = gi[m->h_view_off[v] + k];
   }
   int st = 0;
-  SFM_HIP(hipMemcpy(&st, m->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  SFM_HIP(hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
   SFM_CHECK((st & 1) == 0, SFMLOC_ECAP, "a view has more than 2048 putative matches (F-matrix workspace)");
   return SFMLOC_OK;
 }
 
 int sfmloc_match_set(sfmloc_map *map, sfmloc_query *query) {
+  SFM_CHECK(map && query, SFMLOC_EINVAL, "sfmloc_match_set: null argument");
   Map *m = reinterpret_cast<Map *>(map);
   Query *q = reinterpret_cast<Query *>(query);
-  int rc = check_stage(m, q, "sfmloc_match_set");
+  int rc = check_stage(m->ctx0, q, "sfmloc_match_set");
   if (rc) return rc;
   SFM_HIP(hipSetDevice(m->device));
-  EventScope ev(m, SFMLOC_K_MATCHSET);
-  return launch_match_set(m, q, m->last_n_sel, m->last_all_views);
+  return ctx_match_set(m->ctx0, q);
 }
 
 int sfmloc_match_set_read(sfmloc_map *map, uint32_t *n, uint32_t *qfeat, uint32_t *landmark_id, double *pt2d,
                           double *pt3d, uint32_t cap) {
   SFM_CHECK(map && n, SFMLOC_EINVAL, "sfmloc_match_set_read: null argument");
   Map *m = reinterpret_cast<Map *>(map);
+  Ctx *c = m->ctx0;
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipStreamSynchronize(m->stream));
+  SFM_HIP(hipStreamSynchronize(c->stream));
   uint32_t k = 0;
-  SFM_HIP(hipMemcpy(&k, m->d_ms_n, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  SFM_HIP(hipMemcpy(&k, c->d_ms_n, sizeof(uint32_t), hipMemcpyDeviceToHost));
   *n = k;
   int st = 0;
-  SFM_HIP(hipMemcpy(&st, m->d_status, sizeof(int), hipMemcpyDeviceToHost));
-  SFM_CHECK((st & 2) == 0, SFMLOC_ECAP, "more than %u 2D-3D candidates (match-set workspace)", m->cand_cap);
+  SFM_HIP(hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  SFM_CHECK((st & 2) == 0, SFMLOC_ECAP, "more than %u 2D-3D candidates (match-set workspace)", c->cand_cap);
   if (k == 0) return SFMLOC_OK;
   SFM_CHECK(cap >= k, SFMLOC_ECAP, "sfmloc_match_set_read: cap %u < %u", cap, k);
-  if (qfeat) SFM_HIP(hipMemcpy(qfeat, m->d_ms_qfeat, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (landmark_id) SFM_HIP(hipMemcpy(landmark_id, m->d_ms_landmark, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (pt2d) SFM_HIP(hipMemcpy(pt2d, m->d_pt2d, (size_t)k * 2 * sizeof(double), hipMemcpyDeviceToHost));
-  if (pt3d) SFM_HIP(hipMemcpy(pt3d, m->d_pt3d, (size_t)k * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  if (qfeat) SFM_HIP(hipMemcpy(qfeat, c->d_ms_qfeat, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (landmark_id) SFM_HIP(hipMemcpy(landmark_id, c->d_ms_landmark, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (pt2d) SFM_HIP(hipMemcpy(pt2d, c->d_pt2d, (size_t)k * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  if (pt3d) SFM_HIP(hipMemcpy(pt3d, c->d_pt3d, (size_t)k * 3 * sizeof(double), hipMemcpyDeviceToHost));
   return SFMLOC_OK;
 }
 
-// Enqueues the P3P AC-RANSAC rounds.  The device-side state machine makes surplus rounds no-ops, so a fixed
-// number is enqueued without synchronising; the host only looks at the state when that number is spent.
-static int run_resection(Map *m) {
-  int rc = launch_p3p_init(m);
-  if (rc) return rc;
-  P3pState st;
-  int first = 1;
-  for (int guard = 0; guard < 64; ++guard) {
-    for (int r = 0; r < 12; ++r) {
-      rc = launch_p3p_round(m, first ? 64 : kP3pBatchMax);
-      first = 0;
-      if (rc) return rc;
-    }
-    SFM_HIP(hipMemcpyAsync(&st, m->d_p3p_state, sizeof(st), hipMemcpyDeviceToHost, m->stream));
-    SFM_HIP(hipStreamSynchronize(m->stream));
-    if (st.done) return SFMLOC_OK;
-  }
-  set_error("P3P AC-RANSAC did not finish in %d rounds (iter %d of %d)", 64 * 12, st.iter, st.n_iter);
-  return SFMLOC_EHIP;
-}
-
 int sfmloc_resection(sfmloc_map *map, sfmloc_query *query) {
+  SFM_CHECK(map && query, SFMLOC_EINVAL, "sfmloc_resection: null argument");
   Map *m = reinterpret_cast<Map *>(map);
   Query *q = reinterpret_cast<Query *>(query);
-  int rc = check_stage(m, q, "sfmloc_resection");
+  Ctx *c = m->ctx0;
+  int rc = check_stage(c, q, "sfmloc_resection");
   if (rc) return rc;
   SFM_HIP(hipSetDevice(m->device));
-  EventScope ev(m, SFMLOC_K_P3P);
-  return run_resection(m);
+  {
+    EventScope ev(c, SFMLOC_K_P3P);
+    rc = ctx_resection_enqueue(c, true);
+  }
+  if (rc) return rc;
+  rc = ctx_fetch_result(c);
+  if (rc) return rc;
+  return ctx_resection_wait(c);
 }
 
 int sfmloc_pose_read(sfmloc_map *map, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,
                      uint32_t *inlier_idx, uint32_t cap) {
   SFM_CHECK(map && out, SFMLOC_EINVAL, "sfmloc_pose_read: null argument");
   Map *m = reinterpret_cast<Map *>(map);
+  Ctx *c = m->ctx0;
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipStreamSynchronize(m->stream));
-  SFM_HIP(hipMemcpy(out, m->d_pose, sizeof(Pose), hipMemcpyDeviceToHost));
+  SFM_HIP(hipStreamSynchronize(c->stream));
+  SFM_HIP(hipMemcpy(out, c->d_pose, sizeof(Pose), hipMemcpyDeviceToHost));
   SFM_CHECK((out->status & 4) == 0, SFMLOC_ECAP, "more than %d 2D-3D correspondences (P3P workspace)", kP3pMaxN);
   if (out->ok && out->n_inliers > 0) {
     const uint32_t k = (uint32_t)out->n_inliers;
     if (pair_qfeat || pair_landmark || inlier_idx)
       SFM_CHECK(cap >= k, SFMLOC_ECAP, "sfmloc_pose_read: cap %u < %u inliers", cap, k);
-    if (pair_qfeat) SFM_HIP(hipMemcpy(pair_qfeat, m->d_pair_qfeat, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (pair_qfeat) SFM_HIP(hipMemcpy(pair_qfeat, c->d_pair_qfeat, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (pair_landmark)
-      SFM_HIP(hipMemcpy(pair_landmark, m->d_pair_landmark, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (inlier_idx) SFM_HIP(hipMemcpy(inlier_idx, m->d_inlier_idx, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      SFM_HIP(hipMemcpy(pair_landmark, c->d_pair_landmark, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (inlier_idx) SFM_HIP(hipMemcpy(inlier_idx, c->d_inlier_idx, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
   }
   return SFMLOC_OK;
+}
+
+// ----- whole queries --------------------------------------------------------------------------------
+
+int sfmloc_localize_begin(sfmloc_context *ctx, sfmloc_query *query, const uint32_t *view_sel, uint32_t n_sel) {
+  SFM_CHECK(ctx && query, SFMLOC_EINVAL, "sfmloc_localize_begin: null argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  Query *q = reinterpret_cast<Query *>(query);
+  SFM_CHECK(q->map == c->map, SFMLOC_EINVAL, "sfmloc_localize_begin: query belongs to another map");
+  SFM_HIP(hipSetDevice(c->map->device));
+  return ctx_localize_begin(c, q, view_sel, n_sel);
+}
+
+int sfmloc_localize_end(sfmloc_context *ctx, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,
+                        uint32_t cap) {
+  SFM_CHECK(ctx && out, SFMLOC_EINVAL, "sfmloc_localize_end: null argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  SFM_HIP(hipSetDevice(c->map->device));
+  return ctx_localize_end(c, out, pair_qfeat, pair_landmark, cap);
 }
 
 int sfmloc_localize(sfmloc_map *map, sfmloc_query *query, const uint32_t *view_sel, uint32_t n_sel,
@@ -715,31 +913,55 @@ int sfmloc_localize(sfmloc_map *map, sfmloc_query *query, const uint32_t *view_s
   SFM_CHECK(map && query && out, SFMLOC_EINVAL, "sfmloc_localize: null argument");
   Map *m = reinterpret_cast<Map *>(map);
   Query *q = reinterpret_cast<Query *>(query);
-  using clk = std::chrono::steady_clock;
-  const auto t0 = clk::now();
-  int rc = sfmloc_match_putative(map, query, view_sel, n_sel);
-  if (rc) return rc;
-  rc = check_stage(m, q, "sfmloc_localize");
-  if (rc) return rc;
-  rc = sfmloc_geometric_filter(map, query);
-  if (rc) return rc;
-  rc = sfmloc_match_set(map, query);
-  if (rc) return rc;
-  {
-    EventScope ev(m, SFMLOC_K_P3P);
-    rc = run_resection(m);
+  SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_localize: query belongs to another map");
+  SFM_HIP(hipSetDevice(m->device));
+  int rc = ctx_localize_begin(m->ctx0, q, view_sel, n_sel);
+  if (rc) {
+    m->ctx0->in_flight = nullptr;
+    return rc;
   }
-  if (rc) return rc;
-  rc = sfmloc_pose_read(map, out, pair_qfeat, pair_landmark, nullptr, cap);
-  if (rc) return rc;
-  int st = 0;
-  SFM_HIP(hipMemcpy(&st, m->d_status, sizeof(int), hipMemcpyDeviceToHost));
-  out->status |= st;
-  SFM_CHECK((st & 3) == 0, SFMLOC_ECAP, "device workspace exceeded (status %d)", st);
-  const auto t1 = clk::now();
-  for (int i = 0; i < 7; ++i) out->stage_seconds[i] = 0.0;
-  out->stage_seconds[6] = std::chrono::duration<double>(t1 - t0).count();  // split per stage: sfmloc_stats_read
-  return SFMLOC_OK;
+  return ctx_localize_end(m->ctx0, out, pair_qfeat, pair_landmark, cap);
+}
+
+int sfmloc_localize_batch(sfmloc_map *map, sfmloc_query *const *queries, uint32_t n, uint32_t n_contexts,
+                          sfmloc_pose *poses, uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t pair_stride) {
+  SFM_CHECK(map && (n == 0 || (queries && poses)), SFMLOC_EINVAL, "sfmloc_localize_batch: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  SFM_HIP(hipSetDevice(m->device));
+  if (n_contexts == 0) n_contexts = 4;
+  if (n_contexts > n) n_contexts = n ? n : 1;
+  while (m->batch_ctx.size() < n_contexts) {
+    Ctx *c = nullptr;
+    int rc = make_ctx(m, &c);
+    if (rc) return rc;
+    m->pool.push_back(c);
+    m->batch_ctx.push_back(c);
+    m->hbm_bytes += c->hbm_bytes;
+  }
+  int first_err = SFMLOC_OK;
+  auto finish = [&](uint32_t i) {
+    Ctx *c = m->batch_ctx[i % n_contexts];
+    int rc = ctx_localize_end(c, &poses[i], pair_qfeat ? pair_qfeat + (size_t)i * pair_stride : nullptr,
+                              pair_landmark ? pair_landmark + (size_t)i * pair_stride : nullptr, pair_stride);
+    if (rc && !first_err) first_err = rc;
+  };
+  for (uint32_t i = 0; i < n; ++i) {
+    if (i >= n_contexts) finish(i - n_contexts);
+    Ctx *c = m->batch_ctx[i % n_contexts];
+    Query *q = reinterpret_cast<Query *>(queries[i]);
+    int rc = (q && q->map == m) ? ctx_localize_begin(c, q, nullptr, 0) : SFMLOC_EINVAL;
+    if (rc) {
+      if (!first_err) {
+        first_err = rc;
+        if (!(q && q->map == m)) set_error("sfmloc_localize_batch: query %u is null or belongs to another map", i);
+      }
+      // drain what is in flight and stop
+      for (uint32_t k = (i >= n_contexts ? i - n_contexts + 1 : 0); k < i; ++k) finish(k);
+      return first_err;
+    }
+  }
+  for (uint32_t k = (n >= n_contexts ? n - n_contexts : 0); k < n; ++k) finish(k);
+  return first_err;
 }
 
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride) {
@@ -776,7 +998,8 @@ int sfmloc_sync(sfmloc_map *map) {
   SFM_CHECK(map, SFMLOC_EINVAL, "sfmloc_sync: null map");
   Map *m = reinterpret_cast<Map *>(map);
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipStreamSynchronize(m->stream));
+  SFM_HIP(hipStreamSynchronize(m->ctx0->stream));
+  for (Ctx *c : m->pool) SFM_HIP(hipStreamSynchronize(c->stream));
   return SFMLOC_OK;
 }
 
@@ -784,10 +1007,20 @@ int sfmloc_stats_read(sfmloc_map *map, sfmloc_kernel_stats *out) {
   SFM_CHECK(map && out, SFMLOC_EINVAL, "sfmloc_stats_read: null argument");
   Map *m = reinterpret_cast<Map *>(map);
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipStreamSynchronize(m->stream));
-  int rc = drain_events(m);
-  if (rc) return rc;
-  *out = m->stats;
+  memset(out, 0, sizeof(*out));
+  std::vector<Ctx *> all = m->pool;
+  all.push_back(m->ctx0);
+  for (Ctx *c : all) {
+    SFM_HIP(hipStreamSynchronize(c->stream));
+    int rc = drain_events(c);
+    if (rc) return rc;
+    for (int k = 0; k < SFMLOC_K_COUNT; ++k) {
+      out->total_ms[k] += c->stats.total_ms[k];
+      out->launches[k] += c->stats.launches[k];
+    }
+    out->hamming_pairs += c->stats.hamming_pairs;
+    out->hamming_alg_bytes += c->stats.hamming_alg_bytes;
+  }
   return SFMLOC_OK;
 }
 
@@ -795,10 +1028,14 @@ int sfmloc_stats_reset(sfmloc_map *map) {
   SFM_CHECK(map, SFMLOC_EINVAL, "sfmloc_stats_reset: null map");
   Map *m = reinterpret_cast<Map *>(map);
   SFM_HIP(hipSetDevice(m->device));
-  SFM_HIP(hipStreamSynchronize(m->stream));
-  int rc = drain_events(m);
-  if (rc) return rc;
-  memset(&m->stats, 0, sizeof(m->stats));
+  std::vector<Ctx *> all = m->pool;
+  all.push_back(m->ctx0);
+  for (Ctx *c : all) {
+    SFM_HIP(hipStreamSynchronize(c->stream));
+    int rc = drain_events(c);
+    if (rc) return rc;
+    memset(&c->stats, 0, sizeof(c->stats));
+  }
   return SFMLOC_OK;
 }
 

@@ -48,7 +48,7 @@ template <int R, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
     const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
     const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t q_chunk, uint32_t lds_rows,
-    uint2 *__restrict__ part, uint64_t part_stride) {
+    uint2 *__restrict__ part) {
   extern __shared__ uint4 qs[];  // lds_rows x 4 uint4: a slice of the query block, row major
 
   const uint32_t lane = threadIdx.x & 63u;
@@ -107,8 +107,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
 
 #pragma unroll
   for (int r = 0; r < R; ++r) {
+    // partials are indexed by WORK block (position in the block list), split-major
     if (blk[r] != 0xFFFFFFFFu)
-      part[(uint64_t)blockIdx.y * part_stride + (uint64_t)blk[r] * 64 + lane] = make_uint2(best0[r], best1[r]);
+      part[((uint64_t)blockIdx.y * n_work_blocks + (w0 + r)) * 64 + lane] = make_uint2(best0[r], best1[r]);
   }
 }
 
@@ -117,14 +118,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
 // (0.0f + d0) / d1 < ratio holds; the accepted d0 are exactly 0..cnt-1 because IEEE division is
 // monotone), and compacts accepted rows in ascending row order.
 __global__ __launch_bounds__(256) void k_merge_ratio_compact(
-    const uint2 *__restrict__ part, uint64_t part_stride, uint32_t split, const uint32_t *__restrict__ view_sel,
-    uint32_t n_sel, const uint32_t *__restrict__ view_off, const uint16_t *__restrict__ ratio_cnt,
-    uint32_t *__restrict__ view_count, uint32_t *__restrict__ match_i, uint32_t *__restrict__ match_key) {
+    const uint2 *__restrict__ part, uint32_t n_work_blocks, uint32_t split, const uint32_t *__restrict__ view_sel,
+    const uint32_t *__restrict__ view_widx0, uint32_t n_sel, const uint32_t *__restrict__ view_off,
+    const uint16_t *__restrict__ ratio_cnt, uint32_t *__restrict__ view_count, uint32_t *__restrict__ match_i,
+    uint32_t *__restrict__ match_key) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= n_sel) return;
   const uint32_t v = view_sel ? view_sel[gw] : gw;
   const uint32_t off = view_off[v], end = view_off[v + 1];
+  // bank row r lives in bank block r/64; a selected view's blocks are consecutive in the block list, so
+  // work index = (r/64 - first block of the view) + work index of that first block
+  const uint32_t blk0 = off >> 6;
+  const uint32_t widx0 = view_sel ? view_widx0[gw] : blk0;
   uint32_t base = 0;
   for (uint32_t r0 = off; r0 < end; r0 += 64) {
     const uint32_t r = r0 + lane;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void k_merge_ratio_compact(
     uint32_t b0 = SFMLOC_NOMATCH, b1 = SFMLOC_NOMATCH;
     if (valid) {
       for (uint32_t s = 0; s < split; ++s) {
-        const uint2 p = part[(uint64_t)s * part_stride + r];
+        const uint2 p = part[((uint64_t)s * n_work_blocks + (widx0 + ((r >> 6) - blk0))) * 64 + (r & 63u)];
         top2_push(b0, b1, p.x);
         top2_push(b0, b1, p.y);
       }
@@ -152,7 +158,8 @@ __global__ __launch_bounds__(256) void k_merge_ratio_compact(
 }
 
 template <int R, int WAVES>
-int launch_hamming_t(Map *m, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
+int launch_hamming_t(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
+  Map *m = c->map;
   const uint32_t nq = q->n;
   const uint32_t q_chunk = (nq + split - 1) / split;
   // LDS slice: as much of the split's query rows as fit in 128 KiB (gfx950 has 160 KiB per CU)
@@ -163,9 +170,9 @@ int launch_hamming_t(Map *m, const Query *q, uint32_t n_work_blocks, bool use_li
   SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes));
   dim3 grid((n_work_blocks + WAVES * R - 1) / (WAVES * R), split);
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, m->stream, m->d_bank,
-                     use_list ? m->d_block_list : nullptr, n_work_blocks, q->d_desc, nq, q_chunk, lds_rows,
-                     m->d_part, (uint64_t)m->n_blocks * 64);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds_bytes, c->stream, m->d_bank,
+                     use_list ? c->d_block_list : nullptr, n_work_blocks, q->d_desc, nq, q_chunk, lds_rows,
+                     c->d_part);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
@@ -181,22 +188,26 @@ int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, 
   return SFMLOC_OK;
 }
 
-int launch_hamming_top2(Map *m, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
+int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
+  Map *m = c->map;
   if (n_work_blocks == 0 || q->n == 0) return SFMLOC_OK;
   // Geometry: 16 waves x 4 blocks when there is enough work to fill the chip twice over, smaller
   // tiles otherwise so that a short list still spreads over the 256 CUs.
   const uint64_t big = (uint64_t)m->n_cu * 16 * 4;
-  if ((uint64_t)n_work_blocks * split >= 2 * big) return launch_hamming_t<4, 16>(m, q, n_work_blocks, use_list, split);
-  if ((uint64_t)n_work_blocks * split >= big / 2) return launch_hamming_t<2, 8>(m, q, n_work_blocks, use_list, split);
-  return launch_hamming_t<1, 4>(m, q, n_work_blocks, use_list, split);
+  if ((uint64_t)n_work_blocks * split >= 2 * big) return launch_hamming_t<4, 16>(c, q, n_work_blocks, use_list, split);
+  if ((uint64_t)n_work_blocks * split >= big / 2) return launch_hamming_t<2, 8>(c, q, n_work_blocks, use_list, split);
+  return launch_hamming_t<1, 4>(c, q, n_work_blocks, use_list, split);
 }
 
-int launch_merge_ratio_compact(Map *m, const Query *q, uint32_t n_sel, bool all_views, uint32_t split) {
+int launch_merge_ratio_compact(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, uint32_t split,
+                               uint32_t n_work_blocks) {
   (void)q;
+  Map *m = c->map;
   if (n_sel == 0) return SFMLOC_OK;
-  hipLaunchKernelGGL(k_merge_ratio_compact, dim3((n_sel + 3) / 4), dim3(256), 0, m->stream, m->d_part,
-                     (uint64_t)m->n_blocks * 64, split, all_views ? nullptr : m->d_view_sel, n_sel, m->d_view_off,
-                     m->d_ratio_cnt, m->d_view_count, m->d_match_i, m->d_match_key);
+  hipLaunchKernelGGL(k_merge_ratio_compact, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream, c->d_part,
+                     n_work_blocks, split, all_views ? nullptr : c->d_view_sel,
+                     all_views ? nullptr : c->d_view_widx0, n_sel, m->d_view_off, m->d_ratio_cnt, c->d_view_count,
+                     c->d_match_i, c->d_match_key);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -85,15 +85,14 @@ struct P3pArgs {
   uint32_t stream;
 };
 
-struct KernelTimer;  // capi.hip
+struct Ctx;
 
+// Static, read-only after creation: the map as it sits in HBM.
 struct Map {
   int device = 0;
   int n_cu = 256;
-  hipStream_t stream = nullptr;
   sfmloc_params params{};
 
-  // --- static map data ---
   uint64_t n_rows = 0;
   uint32_t n_blocks = 0;  // ceil(n_rows / 64)
   uint32_t n_views = 0;
@@ -110,24 +109,39 @@ struct Map {
   double focal = 0, ppx = 0, ppy = 0, k1 = 0, k2 = 0, k3 = 0;
   uint32_t bow_dim = 0;
   float *d_bow = nullptr;
+  double *d_L10 = nullptr;          // [65538] log10(i)
+  uint16_t *d_ratio_cnt = nullptr;  // [513]
+  float ratio_cnt_for = -1.0f;      // ratio the table was built for
+  bool have_geometry = false;       // kpts + landmarks + view sizes + intrinsic were supplied
   uint64_t hbm_bytes = 0;
 
-  // --- per-call workspace (putative stage) ---
+  Ctx *ctx0 = nullptr;              // the handle's own context (stage-level API)
+  std::vector<Ctx *> pool;          // every other context of this map (owned by the map)
+  std::vector<Ctx *> batch_ctx;     // the subset sfmloc_localize_batch round-robins over
+};
+
+// Everything one in-flight query needs: a stream and the workspace of every stage.  Several contexts
+// of one map run concurrently (the latency-bound RANSAC stages of one query overlap the VALU-bound
+// Hamming kernel of another).
+struct Ctx {
+  Map *map = nullptr;
+  hipStream_t stream = nullptr;
+  uint64_t hbm_bytes = 0;
+
+  // --- putative stage ---
   uint32_t max_split = 8;
-  uint2 *d_part = nullptr;        // [max_split][n_blocks*64] partial (best0,best1)
-  uint32_t *d_view_sel = nullptr;  // [n_views] selected view indices
-  uint32_t *d_block_list = nullptr;  // [n_blocks]
-  uint32_t *h_pinned = nullptr;      // pinned staging for view_sel + block_list
-  uint32_t *d_view_count = nullptr;  // [n_views]
-  uint32_t *d_match_i = nullptr;     // [n_rows]
-  uint32_t *d_match_key = nullptr;   // [n_rows]  (d0<<16)|j0
-  uint16_t *d_ratio_cnt = nullptr;   // [513]
-  float ratio_cnt_for = -1.0f;       // ratio the table was built for
+  uint2 *d_part = nullptr;          // [n_blocks*64] partial (best0,best1), laid out [split][work block][lane]
+  uint32_t *d_view_sel = nullptr;   // [n_views] selected view indices
+  uint32_t *d_view_widx0 = nullptr; // [n_views] work-block index of each selected view's first bank block
+  uint32_t *d_block_list = nullptr; // [n_blocks]
+  uint32_t *h_pinned = nullptr;     // pinned staging: view_sel | view_widx0 | block_list
+  uint32_t *d_view_count = nullptr; // [n_views]
+  uint32_t *d_match_i = nullptr;    // [n_rows]
+  uint32_t *d_match_key = nullptr;  // [n_rows]  (d0<<16)|j0
 
   // --- geometric stages ---
-  double *d_L10 = nullptr;           // [65538] log10(i)
-  uint32_t *d_geo_count = nullptr;   // [n_views]
-  uint32_t *d_geo_idx = nullptr;     // [n_rows]
+  uint32_t *d_geo_count = nullptr;  // [n_views]
+  uint32_t *d_geo_idx = nullptr;    // [n_rows]
   int *d_status = nullptr;
   Candidate *d_cand = nullptr;
   uint32_t cand_cap = 1u << 16;
@@ -145,7 +159,9 @@ struct Map {
   uint32_t *d_pair_qfeat = nullptr, *d_pair_landmark = nullptr, *d_inlier_idx = nullptr;  // [kP3pMaxN]
   P3pState *d_p3p_state = nullptr;
   Pose *d_pose = nullptr;
-  bool have_geometry = false;  // kpts + landmarks + view sizes were supplied
+  uint32_t *d_view_stats = nullptr;  // [2] views with >= min_putative matches, views passing the F filter
+  void *h_result = nullptr;  // pinned: what a finished query copies back in one go (capi.hip HostResult)
+  hipEvent_t pinned_busy = nullptr;  // recorded after the last upload out of h_pinned
 
   // state of the last putative call
   uint32_t last_split = 0;
@@ -154,6 +170,9 @@ struct Map {
   bool last_all_views = false;
   uint32_t last_n_work_blocks = 0;
   std::vector<uint32_t> last_blocks;  // host copy of the block list (empty = all)
+  struct Query *last_query = nullptr;  // query of the last putative call
+  struct Query *in_flight = nullptr;   // query of a begun, not yet ended, localisation
+  double t_begin = 0.0;
 
   // --- measurement ---
   sfmloc_kernel_stats stats{};
@@ -172,16 +191,17 @@ struct Query {
 
 // hamming.hip
 int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, uint4 *d_bank, hipStream_t s);
-int launch_hamming_top2(Map *m, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split);
-int launch_merge_ratio_compact(Map *m, const Query *q, uint32_t n_sel, bool all_views, uint32_t split);
+int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split);
+int launch_merge_ratio_compact(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, uint32_t split,
+                               uint32_t n_work_blocks);
 
 
 // acransac.hip
 int launch_fill_log10(double *d_L10, int n, hipStream_t s);
 int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *d_out, int out_stride, hipStream_t s);
-int launch_fmatrix_filter(Map *m, const Query *q, uint32_t n_sel, bool all_views);
-int launch_match_set(Map *m, const Query *q, uint32_t n_sel, bool all_views);
-int launch_p3p_init(Map *m);
-int launch_p3p_round(Map *m, int batch);
+int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
+int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
+int launch_p3p_init(Ctx *c);
+int launch_p3p_round(Ctx *c, int batch);
 
 }  // namespace sfmloc

@@ -208,3 +208,47 @@ def test_localize_one_call(oracle_c):
                 np.testing.assert_array_equal(pl, exp["pair_landmark"])
                 np.testing.assert_array_equal(bits(np.array(pose.center)), bits(exp["center"]))
             dq.close()
+
+
+def test_concurrent_contexts_equal_sequential(oracle_c):
+    """sfmloc_localize_begin/_end on several contexts and sfmloc_localize_batch give exactly what one query
+    at a time gives (the RNG is keyed by query-independent counters, workspaces are per context)."""
+    m = make_scene(25)
+    with dev_map(m) as dm:
+        qs = [synth.make_query(m, 400 + k, n_feat=700, n_copies=200, outlier_frac=0.3) for k in range(7)]
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in qs]
+        seq = [dm.localize(dq) for dq in dqs]
+        ctxs = [dm.context() for _ in range(3)]
+        got = [None] * len(dqs)
+        for i, dq in enumerate(dqs):
+            c = ctxs[i % 3]
+            if i >= 3:
+                got[i - 3] = c.end()
+            c.begin(dq)
+        for i in range(len(dqs) - 3, len(dqs)):
+            got[i] = ctxs[i % 3].end()
+        poses, pq, pl = dm.localize_batch(dqs, n_contexts=4, cap=1024)
+        for i, (a, b) in enumerate(zip(seq, got)):
+            assert a[0].ok == b[0].ok == poses[i].ok
+            assert a[0].n_inliers == b[0].n_inliers == poses[i].n_inliers
+            assert a[0].n_putative_views == b[0].n_putative_views and a[0].n_geometric_views == b[0].n_geometric_views
+            np.testing.assert_array_equal(a[1], b[1])
+            np.testing.assert_array_equal(a[2], b[2])
+            np.testing.assert_array_equal(bits(np.array(a[0].P)), bits(np.array(b[0].P)))
+            np.testing.assert_array_equal(bits(np.array(a[0].P)), bits(np.array(poses[i].P)))
+            if a[0].ok:
+                np.testing.assert_array_equal(a[1], pq[i, :a[0].n_inliers])
+                np.testing.assert_array_equal(a[2], pl[i, :a[0].n_inliers])
+        assert sum(p.ok for p in poses) >= 5
+        assert seq[0][0].n_putative_views >= seq[0][0].n_geometric_views > 0
+        # misuse: begin twice on one context
+        ctxs[0].begin(dqs[0])
+        with pytest.raises(S.SfmlocError):
+            ctxs[0].begin(dqs[1])
+        ctxs[0].end()
+        with pytest.raises(S.SfmlocError):
+            ctxs[0].end()
+        for c in ctxs:
+            c.close()
+        for dq in dqs:
+            dq.close()
