@@ -14,6 +14,8 @@
 // packed key; lower query index wins ties because it makes the key smaller).  The kernel is VALU bound
 // for N_q >~ 10; the bank is read exactly once per launch in fully coalesced 1 KiB pieces
 // thanks to the tiled64 layout (sfmloc_internal.h).
+#include <stdlib.h>
+
 #include "sfmloc_internal.h"
 
 namespace sfmloc {
@@ -158,12 +160,13 @@ __global__ __launch_bounds__(256) void k_merge_ratio_compact(
 }
 
 template <int R, int WAVES>
-int launch_hamming_t(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
+int launch_hamming_t(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split,
+                     uint32_t lds_rows_cap) {
   Map *m = c->map;
   const uint32_t nq = q->n;
   const uint32_t q_chunk = (nq + split - 1) / split;
-  // LDS slice: as much of the split's query rows as fit in 128 KiB (gfx950 has 160 KiB per CU)
-  uint32_t lds_rows = q_chunk < 2048u ? q_chunk : 2048u;
+  // LDS slice of the split's query rows (gfx950: 160 KiB per CU; the cap trades slice reloads for occupancy)
+  uint32_t lds_rows = q_chunk < lds_rows_cap ? q_chunk : lds_rows_cap;
   if (lds_rows == 0) lds_rows = 1;
   const size_t lds_bytes = (size_t)lds_rows * 64;
   auto kern = k_hamming_top2<R, WAVES>;
@@ -175,6 +178,20 @@ int launch_hamming_t(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_li
                      c->d_part);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
+}
+
+// tuning hook: SFMLOC_K1_GEOM="R,WAVES,LDS_ROWS" overrides the geometry choice (read once)
+struct K1Geom {
+  int r = 0, waves = 0, lds_rows = 0;
+};
+const K1Geom &k1_override() {
+  static K1Geom g = [] {
+    K1Geom x;
+    const char *e = getenv("SFMLOC_K1_GEOM");
+    if (e) sscanf(e, "%d,%d,%d", &x.r, &x.waves, &x.lds_rows);
+    return x;
+  }();
+  return g;
 }
 
 }  // namespace
@@ -191,12 +208,39 @@ int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, 
 int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
   Map *m = c->map;
   if (n_work_blocks == 0 || q->n == 0) return SFMLOC_OK;
-  // Geometry: 16 waves x 4 blocks when there is enough work to fill the chip twice over, smaller
-  // tiles otherwise so that a short list still spreads over the 256 CUs.
-  const uint64_t big = (uint64_t)m->n_cu * 16 * 4;
-  if ((uint64_t)n_work_blocks * split >= 2 * big) return launch_hamming_t<4, 16>(c, q, n_work_blocks, use_list, split);
-  if ((uint64_t)n_work_blocks * split >= big / 2) return launch_hamming_t<2, 8>(c, q, n_work_blocks, use_list, split);
-  return launch_hamming_t<1, 4>(c, q, n_work_blocks, use_list, split);
+  int R, W, L;
+  const K1Geom &o = k1_override();
+  if (o.r) {
+    R = o.r;
+    W = o.waves;
+    L = o.lds_rows;
+  } else {
+    // Measured on MI355X (profiles/r01_valu_rates.jsonl, profiles/r01_k1_lab.txt): v_xor_b32 issues at 2
+    // cycles per wave64, v_bcnt_u32_b32 / v_med3 / v_lshl_or at ~4, and one wave alone gets an instruction
+    // only every ~4.8 cycles, so the loop reaches the VALU issue rate of its instruction mix only with >= 4
+    // waves per SIMD.  LDS vs scalar-cache query reads, register prefetch of the query row and split popcount
+    // chains all time within 5 % of each other: the loop is VALU-issue bound.  Geometry: one bank block per wave
+    // (42 VGPRs), 8-wave workgroups, 32 KiB LDS slices -> 4 workgroups = 32 waves per CU.
+    const uint64_t wave_blocks = (uint64_t)n_work_blocks * split;
+    if (wave_blocks >= (uint64_t)m->n_cu * 32) {
+      R = 1; W = 8; L = 512;
+    } else {
+      R = 1; W = 4; L = 512;
+    }
+  }
+#define K1_CASE(r, w)   if (R == r && W == w) return launch_hamming_t<r, w>(c, q, n_work_blocks, use_list, split, (uint32_t)L);
+  K1_CASE(4, 16)
+  K1_CASE(2, 16)
+  K1_CASE(1, 16)
+  K1_CASE(4, 8)
+  K1_CASE(2, 8)
+  K1_CASE(1, 8)
+  K1_CASE(4, 4)
+  K1_CASE(2, 4)
+  K1_CASE(1, 4)
+#undef K1_CASE
+  set_error("unsupported K1 geometry R=%d WAVES=%d", R, W);
+  return SFMLOC_EINVAL;
 }
 
 int launch_merge_ratio_compact(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, uint32_t split,
