@@ -105,6 +105,28 @@ typedef struct sfmloc_map sfmloc_map;
 int sfmloc_map_create(const sfmloc_map_desc *desc, const sfmloc_params *params, sfmloc_map **out);
 void sfmloc_map_destroy(sfmloc_map *map);
 
+/* replaces the same start-up sequence fed from disk: <sfm_dir>/sfm_data.json (cereal JSON: views, intrinsic 0,
+ * extrinsics, structure) and <match_dir>/<basename>.{desc,feat[,bow]} of every view that has a pose
+ * (localization.cpp:236-280,337-341; file layouts: SURVEY.md Appendix A).  Error text follows the reference's
+ * ("The input sfm_data.json file ... cannot be read.").  SFMLOC_EIO when the contract is violated. */
+int sfmloc_open(const char *sfm_dir, const char *match_dir, const sfmloc_params *params, sfmloc_map **out);
+
+/* Host-only half of sfmloc_open (no GPU needed): parses the same files and reports what it found. */
+typedef struct sfmloc_scan_info {
+  uint32_t n_views_total, n_views_posed;
+  uint64_t n_rows;
+  uint32_t n_landmarks, n_observations, bow_dim;
+  double focal, ppx, ppy, k1, k2, k3;
+  uint64_t desc_fnv1a;     /* FNV-1a over all descriptor bytes in bank order */
+  double kpt_sum;          /* sum of all keypoint coordinates */
+  int64_t row_landmark_sum;
+} sfmloc_scan_info;
+int sfmloc_scan(const char *sfm_dir, const char *match_dir, sfmloc_scan_info *info);
+
+/* view table of a map: ids [n_views], row offsets [n_views+1], camera centres [n_views*3] (only for maps opened
+ * from sfm_data.json; used for the dead-reckoning restriction getLocalViews, SfMDataUtils.cpp:210-227) */
+int sfmloc_map_views(const sfmloc_map *map, uint32_t *view_id, uint32_t *view_off, double *center);
+
 typedef struct sfmloc_map_info {
   uint64_t n_rows;
   uint32_t n_views;

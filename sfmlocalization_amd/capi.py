@@ -1,5 +1,6 @@
 """ctypes mirror of include/sfmloc.h (one Python method per C entry point, same names and meaning)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -68,6 +69,14 @@ class Pose(C.Structure):
                 ("center", C.c_double * 3), ("stage_seconds", C.c_double * 7)]
 
 
+class ScanInfo(C.Structure):
+    _fields_ = [("n_views_total", C.c_uint32), ("n_views_posed", C.c_uint32), ("n_rows", C.c_uint64),
+                ("n_landmarks", C.c_uint32), ("n_observations", C.c_uint32), ("bow_dim", C.c_uint32),
+                ("focal", C.c_double), ("ppx", C.c_double), ("ppy", C.c_double),
+                ("k1", C.c_double), ("k2", C.c_double), ("k3", C.c_double),
+                ("desc_fnv1a", C.c_uint64), ("kpt_sum", C.c_double), ("row_landmark_sum", C.c_int64)]
+
+
 class KernelStats(C.Structure):
     _fields_ = [("total_ms", C.c_double * K_COUNT), ("launches", C.c_uint64 * K_COUNT),
                 ("hamming_pairs", C.c_uint64), ("hamming_alg_bytes", C.c_uint64)]
@@ -76,7 +85,8 @@ class KernelStats(C.Structure):
 # every symbol include/sfmloc.h declares (tests check the library exports each one)
 SYMBOLS = [
     "sfmloc_last_error", "sfmloc_abi_version", "sfmloc_device_count", "sfmloc_default_params",
-    "sfmloc_map_create", "sfmloc_map_destroy", "sfmloc_map_get_info",
+    "sfmloc_map_create", "sfmloc_map_destroy", "sfmloc_map_get_info", "sfmloc_open", "sfmloc_scan",
+    "sfmloc_map_views",
     "sfmloc_query_create", "sfmloc_query_destroy",
     "sfmloc_match_putative", "sfmloc_putative_read", "sfmloc_putative_read_rows", "sfmloc_sync",
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
@@ -102,6 +112,10 @@ def _L():
         L.sfmloc_map_destroy.restype = None
         L.sfmloc_map_destroy.argtypes = [C.c_void_p]
         L.sfmloc_map_get_info.argtypes = [C.c_void_p, C.POINTER(MapInfo)]
+        L.sfmloc_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Params), C.POINTER(C.c_void_p)]
+        L.sfmloc_scan.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(ScanInfo)]
+        L.sfmloc_map_views.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_double)]
         L.sfmloc_query_create.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_uint32,
                                           C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.sfmloc_query_destroy.restype = None
@@ -144,6 +158,13 @@ def _ptr(a, ctype):
 
 def device_count():
     return int(_L().sfmloc_device_count())
+
+
+def scan(sfm_dir, match_dir):
+    """sfmloc_scan: parse <sfm_dir>/sfm_data.json + <match_dir>/*.desc|feat|bow on the host, no GPU."""
+    info = ScanInfo()
+    _check(_L().sfmloc_scan(os.fsencode(sfm_dir), os.fsencode(match_dir), C.byref(info)))
+    return {f: getattr(info, f) for f, _ in ScanInfo._fields_}
 
 
 def default_params(**overrides):
@@ -217,6 +238,24 @@ class Map:
         _check(_L().sfmloc_map_create(C.byref(d), C.byref(self.params), C.byref(h)))
         self._h = h
         del keep
+
+    @classmethod
+    def open(cls, sfm_dir, match_dir, params=None):
+        """sfmloc_open: load the reference's on-disk map (sfm_data.json + .desc/.feat[/.bow])."""
+        self = cls.__new__(cls)
+        self._h = None
+        self.params = params if params is not None else default_params()
+        h = C.c_void_p()
+        _check(_L().sfmloc_open(os.fsencode(sfm_dir), os.fsencode(match_dir), C.byref(self.params), C.byref(h)))
+        self._h = h
+        i = self.info()
+        self.n_rows, self.n_views = i["n_rows"], i["n_views"]
+        self.view_id = np.zeros(self.n_views, np.uint32)
+        self.view_off = np.zeros(self.n_views + 1, np.uint32)
+        self.view_center = np.zeros((self.n_views, 3), np.float64)
+        _check(_L().sfmloc_map_views(self._h, _ptr(self.view_id, C.c_uint32), _ptr(self.view_off, C.c_uint32),
+                                     _ptr(self.view_center, C.c_double)))
+        return self
 
     def close(self):
         if self._h is not None:

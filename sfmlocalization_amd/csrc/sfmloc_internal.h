@@ -98,6 +98,8 @@ struct Map {
   uint32_t n_views = 0;
   uint32_t n_landmarks = 0;
   std::vector<uint32_t> h_view_id, h_view_off, h_view_wh;
+  std::vector<double> h_view_center;     // [n_views*3], maps opened from sfm_data.json only
+  std::vector<std::string> h_view_file;  // view filenames, same
   uint4 *d_bank = nullptr;         // tiled64, n_blocks*64 rows (zero padded)
   uint32_t *d_view_off = nullptr;  // [n_views+1]
   uint32_t *d_view_id = nullptr;   // [n_views]

@@ -1,0 +1,205 @@
+"""Host-side mirror of the reference's two callers of the hot path, on top of the C ABI:
+
+* `LocalizeEngine`  -- VisionLocalizeServer/src/LocalizeEngine.{h,cc} (same constructor arguments, same return
+  convention: 12 doubles [t(3), R(9 row-major)], empty on failure, 6 stage times);
+* `main()`          -- the OpenMVGLocalization_AKAZE command line (localization.cpp:64-82,155-587): same positional
+  arguments and keys, writes the same <outDir>/<basename>.json files the Python orchestration consumes
+  (mergeSfM.py:50-66: success <=> "t" in json).
+
+Feature extraction (A2, extractAKAZESingleImg) is not on the GPU yet: a query image `foo.jpg` is localised from
+precomputed `foo.desc` / `foo.feat` next to it (or in --featdir), which is what the reference's own extractor
+writes (AKAZEOpenCV.cpp:80-81, FileUtils.cpp:77-92).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import capi, fileio
+
+IMAGE_EXT = ("jpg", "JPG", "jpeg", "JPEG", "png", "PNG")  # localization.cpp:204-206
+
+
+def _image_size(path, default):
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            return im.size
+    except Exception:
+        return default
+
+
+class LocalizeEngine:
+    """LocalizeEngine(sfmDataDir, matchDir, AmatFile, secondTestRatio, ransacRound, ransacPrecision,
+    guidedMatching, beaconKnnNum=0, bowKnnNum=0)   -- LocalizeEngine.h:75-77."""
+
+    def __init__(self, sfm_data_dir, match_dir, amat_file=None, second_test_ratio=0.6, ransac_round=25,
+                 ransac_precision=4.0, guided_matching=False, beacon_knn_num=0, bow_knn_num=0, device=0, profile=0):
+        if guided_matching:
+            raise NotImplementedError("guided matching (-gm) is off in every caller of the reference's localiser")
+        if beacon_knn_num:
+            raise NotImplementedError("iBeacon view pre-selection is out of scope (SURVEY.md 2.1)")
+        self.sfm_data_dir, self.match_dir = sfm_data_dir, match_dir
+        self.params = capi.default_params(dist_ratio=second_test_ratio, ransac_round=ransac_round,
+                                          geom_precision=ransac_precision, bow_knn=bow_knn_num, device=device,
+                                          profile=profile)
+        self.map = capi.Map.open(sfm_data_dir, match_dir, self.params)
+        self.A = None
+        if amat_file:
+            y = fileio.read_cv_yaml(amat_file)           # LocalizeEngine.cc:116-118
+            self.A = np.asarray(y["A"], dtype=np.float64).reshape(3, 4)
+
+    def close(self):
+        self.map.close()
+
+    # getLocalViews (SfMDataUtils.cpp:210-227 / LocalizeEngine.cc:200-): NOTE the reference compares the SQUARED
+    # distance with the un-squared radius; reproduced.
+    def local_views(self, center, radius):
+        c = self.map.view_center
+        if self.A is not None:  # the engine works in the A-transformed frame (TRANSFORM_SFM_DATA_BEFORE_LOCALIZE)
+            c = c @ self.A[:, :3].T + self.A[:, 3]
+        d2 = ((c - np.asarray(center, np.float64)[None, :]) ** 2).sum(1)
+        return np.nonzero(d2 <= radius)[0].astype(np.uint32)
+
+    def localize(self, desc, kpt_xy, width, height, return_keypoints=False, return_time=False, center=None,
+                 radius=-1.0):
+        """-> result (list of 12 doubles or []), extras dict.  LocalizeEngine.cc:288-661 from `endFeat` on."""
+        t0 = time.perf_counter()
+        view_sel = None
+        if center is not None and len(center) == 3 and radius > 0:
+            view_sel = self.local_views(center, radius)
+            if len(view_sel) == 0:
+                return [], {}
+        q = self.map.query(desc, kpt_xy, width, height)
+        try:
+            pose, pq, pl = self.map.localize(q, view_sel)
+        finally:
+            q.close()
+        extras = {"pose": pose, "pairs": list(zip(pq.tolist(), pl.tolist()))}
+        if return_time:
+            extras["times"] = [0.0, 0.0, 0.0, 0.0, 0.0, time.perf_counter() - t0]
+        if not pose.ok:
+            return [], extras
+        R = np.array(pose.R).reshape(3, 3)
+        c = np.array(pose.center)
+        if self.A is not None:
+            # localising in the A-transformed map (LocalizeEngine.cc:121-144) = transforming the result
+            A3 = self.A[:, :3]
+            s = np.cbrt(np.linalg.det(A3))
+            c = A3 @ c + self.A[:, 3]
+            R = R @ (A3 / s).T
+        return list(c) + list(R.ravel()), extras
+
+
+def parse_cv_args(argv, spec):
+    """cv::CommandLineParser syntax: positional arguments and -k=v / --key=v / bare flags."""
+    pos, opts = [], {}
+    for a in argv:
+        if a.startswith("-") and not _is_number(a):
+            k, eq, v = a.lstrip("-").partition("=")
+            opts[k] = v if eq else "true"
+        else:
+            pos.append(a)
+    out = {}
+    for names, default, conv in spec:
+        val = default
+        for n in names:
+            if n in opts:
+                val = opts[n]
+        out[names[-1]] = conv(val)
+    return pos, out
+
+
+def _is_number(s):
+    try:
+        float(s)
+        return True
+    except ValueError:
+        return False
+
+
+def _b(v):
+    return str(v).lower() in ("1", "true", "yes")
+
+
+KEYS = [  # localization.cpp:64-82
+    (("f", "fDistRatio"), "0.6", float), (("r", "ransacRound"), "200", int), (("w", "writematch"), "false", _b),
+    (("k", "knnbow"), "0", int), (("x", "cenLocX"), "0.0", float), (("y", "cenLocY"), "0.0", float),
+    (("z", "cenLocZ"), "0.0", float), (("d", "cenRadius"), "-1.0", float), (("a", "bowModelFile"), "", str),
+    (("p", "pcaModelFile"), "", str), (("i", "locEvryNFrame"), "1", int), (("g", "geomLimit"), "4.0", float),
+    (("gm", "guidedMatch"), "false", _b), (("featdir",), "", str), (("device",), "0", int),
+]
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    pos, o = parse_cv_args(argv, KEYS)
+    if len(pos) < 4 or "h" in argv or "--help" in argv:
+        print("usage: localize <queryImage|dir> <sfmDataDir> <matchDir> <outputFolder> [-f=0.6] [-r=200] [-k=0] "
+              "[-x= -y= -z= -d=-1] [-i=1] [-g=4.0] [--featdir=DIR]")
+        return 1
+    query, sfm_dir, match_dir, out_dir = pos[:4]
+    print("Start localizing input image.")
+    if os.path.isfile(query):
+        if query.rsplit(".", 1)[-1] not in IMAGE_EXT:
+            print("Input image is not JPEG or PNG file")
+            return 1
+        images = [query]
+    elif os.path.isdir(query):
+        images = [os.path.join(query, f) for f in sorted(os.listdir(query)) if f.rsplit(".", 1)[-1] in IMAGE_EXT]
+        if not images:
+            print("JPEG or PNG file is not found in input image directory")
+            return 1
+    else:
+        # the reference would fail in imread; with precomputed features the image itself may be absent
+        images = [query]
+    sfm_json = os.path.join(sfm_dir, "sfm_data.json")
+    try:
+        eng = LocalizeEngine(sfm_dir, match_dir, None, o["fDistRatio"], o["ransacRound"], o["geomLimit"],
+                             o["guidedMatch"], 0, o["knnbow"], device=o["device"])
+    except capi.SfmlocError as e:
+        print(str(e), file=sys.stderr)
+        return 1
+    sd = fileio.read_sfm_data(sfm_json)
+    v0 = sd["views"][0]["value"]["ptr_wrapper"]["data"]
+    default_wh = (int(v0["width"]), int(v0["height"]))
+    every = o["locEvryNFrame"] if o["locEvryNFrame"] > 0 else 1
+    os.makedirs(out_dir, exist_ok=True)
+    n_img, match_next = 0, 0
+    for img in images:
+        n_img += 1
+        if n_img % every == 0:      # localization.cpp:289-298
+            pass
+        elif match_next <= 0:
+            continue
+        else:
+            match_next -= 1
+        base = os.path.splitext(os.path.basename(img))[0]
+        fdir = o["featdir"] or os.path.dirname(img)
+        try:
+            desc = fileio.read_desc(os.path.join(fdir, base + ".desc"))
+            feat = fileio.read_feat(os.path.join(fdir, base + ".feat"))
+        except (IOError, OSError) as e:
+            print(f"cannot read precomputed features of {img}: {e}", file=sys.stderr)
+            fileio.write_result_json(out_dir, img, sfm_json, match_dir)
+            continue
+        w, h = _image_size(img, default_wh)
+        center = (o["cenLocX"], o["cenLocY"], o["cenLocZ"]) if o["cenRadius"] > 0 else None
+        res, ex = eng.localize(desc, feat[:, :2], w, h, center=center, radius=o["cenRadius"])
+        if not res:
+            print("Fail to estimate camera matrix" if ex else "Not enough putative matches")
+            fileio.write_result_json(out_dir, img, sfm_json, match_dir)
+            continue
+        pose = ex["pose"]
+        print(f"#inliers = {pose.n_inliers}")
+        fileio.write_result_json(out_dir, img, sfm_json, match_dir, K=np.array(pose.K), R=np.array(pose.R),
+                                 center=np.array(pose.center), pairs=ex["pairs"])
+        match_next = every - 1
+        print("complete")
+    eng.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

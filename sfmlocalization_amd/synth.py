@@ -251,3 +251,41 @@ def planted_bank(seed, n_rows=512, n_query=96):
     bank[r] = mid
     r += 1
     return q, bank
+
+
+def write_map_to_disk(m: SynthMap, sfm_dir, match_dir, unposed_views=(), with_bow=None):
+    """Lay the synthetic map out as the reference's tools would:
+    <sfm_dir>/sfm_data.json, <match_dir>/image_describer.txt, <match_dir>/<base>.{desc,feat[,bow]}.
+    `unposed_views`: view ids written without an extrinsic (they must be ignored by the localiser).
+    Returns the list of image basenames."""
+    import os
+    from . import fileio
+    os.makedirs(sfm_dir, exist_ok=True)
+    os.makedirs(match_dir, exist_ok=True)
+    names = [f"img{int(v):06d}" for v in m.view_id]
+    f, ppx, ppy = m.intrinsic
+    poses = {int(v): (m.view_R[k], m.view_C[k]) for k, v in enumerate(m.view_id) if int(v) not in set(unposed_views)}
+    slot_view = np.searchsorted(m.view_off, np.arange(m.n_rows), side="right") - 1
+    obs_rows = np.nonzero(m.row_landmark >= 0)[0]
+    per_lm = {}
+    for r in obs_rows:
+        k = int(slot_view[r])
+        per_lm.setdefault(int(m.row_landmark[r]), []).append(
+            (int(m.view_id[k]), int(r - m.view_off[k]), (float(m.kpt_xy[r, 0]), float(m.kpt_xy[r, 1]))))
+    structure = [(int(m.landmark_id[s]), m.landmark_X[s], obs) for s, obs in sorted(per_lm.items())]
+    # landmarks nobody observes still exist in the structure
+    seen = set(per_lm)
+    structure += [(int(m.landmark_id[s]), m.landmark_X[s], []) for s in range(len(m.landmark_id)) if s not in seen]
+    structure.sort(key=lambda t: t[0])
+    sd = fileio.make_sfm_data([int(v) for v in m.view_id], [n + ".jpg" for n in names], m.width, m.height, f, ppx,
+                              ppy, poses=poses, structure=structure, root_path=os.path.abspath(sfm_dir))
+    fileio.write_sfm_data(os.path.join(sfm_dir, "sfm_data.json"), sd)
+    fileio.write_image_describer(os.path.join(match_dir, "image_describer.txt"))
+    for k, n in enumerate(names):
+        a, b = int(m.view_off[k]), int(m.view_off[k + 1])
+        fileio.write_desc(os.path.join(match_dir, n + ".desc"), m.desc[a:b])
+        kp = np.concatenate([m.kpt_xy[a:b], np.full((b - a, 1), 4.8, np.float32), np.zeros((b - a, 1), np.float32)], 1)
+        fileio.write_feat(os.path.join(match_dir, n + ".feat"), kp)
+        if with_bow is not None:
+            fileio.write_mat_bin(os.path.join(match_dir, n + ".bow"), np.asarray(with_bow[k], np.float64).reshape(-1, 1))
+    return names

@@ -1,0 +1,129 @@
+"""CPU: the on-disk contract -- Python codecs round-trip byte for byte, and the native
+loader (sfmloc_scan, the host half of sfmloc_open) reads the same thing from the same files."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from sfmlocalization_amd import capi, fileio, synth
+
+
+def test_desc_layout_and_roundtrip(tmp_path):
+    rng = np.random.Generator(np.random.PCG64(1))
+    d61 = rng.integers(0, 256, (7, 61), dtype=np.uint8)
+    p = tmp_path / "a.desc"
+    fileio.write_desc(p, d61)
+    raw = p.read_bytes()
+    assert len(raw) == 8 + 7 * 64 and struct.unpack("<Q", raw[:8])[0] == 7     # u64 count, 64-byte rows
+    back = fileio.read_desc(p)
+    assert back.shape == (7, 64) and (back[:, :61] == d61).all() and (back[:, 61:] == 0).all()  # FileUtils.cpp:82-88
+    fileio.write_desc(p, np.zeros((0, 64), np.uint8))
+    assert fileio.read_desc(p).shape == (0, 64)
+    p.write_bytes(struct.pack("<Q", 3) + b"\0" * 100)
+    with pytest.raises(IOError):
+        fileio.read_desc(p)
+
+
+def test_feat_is_six_significant_digits(tmp_path):
+    k = np.array([[123.456789, 0.000123456789, 4.8, 359.9999], [1e-7, 639.5, 7.25, 0.0]], np.float32)
+    p = tmp_path / "a.feat"
+    fileio.write_feat(p, k)
+    lines = p.read_text().splitlines()
+    assert lines[0].split() == ["123.457", "0.000123457", "4.8", "360"]      # `ostream << float`, AKAZEOpenCV.cpp:80-81
+    back = fileio.read_feat(p)
+    np.testing.assert_allclose(back, synth.round6(k), rtol=0, atol=0)
+
+
+def test_bow_mat_bin(tmp_path):
+    v = np.linspace(0, 1, 500).reshape(500, 1)
+    p = tmp_path / "a.bow"
+    fileio.write_mat_bin(p, v)
+    raw = p.read_bytes()
+    assert struct.unpack("<iii", raw[:12]) == (500, 1, 6) and len(raw) == 12 + 4000    # CV_64F = 6, TrainBoW.cpp:268
+    np.testing.assert_array_equal(fileio.read_mat_bin(p), v)
+    fileio.write_mat_bin(p, None)
+    assert p.read_bytes() == struct.pack("<i", 0)                                   # empty mat: FileUtils.cpp:47-51
+    assert fileio.read_mat_bin(p).size == 0
+
+
+def test_cv_yaml_and_image_describer(tmp_path):
+    p = tmp_path / "image_describer.txt"
+    fileio.write_image_describer(p)
+    assert fileio.read_image_describer(p) == {"desc_ch": 3, "thres": 0.001, "nOct": 4, "nOctLay": 4}  # AKAZEOption.h:31-34
+    assert fileio.read_image_describer(tmp_path / "missing.txt")["nOct"] == 4
+    centers = np.arange(12, dtype=np.float32).reshape(3, 4)
+    fileio.write_cv_yaml(tmp_path / "BOWfile.yml", {"K": 3, "ResizedImageSize": 300, "NormBofFeatureType": "L1",
+                                                   "UseSpatialPyramid": 1, "PyramidLevel": 2, "Centers": centers})
+    y = fileio.read_cv_yaml(tmp_path / "BOWfile.yml")
+    assert y["K"] == 3 and y["NormBofFeatureType"] == "L1" and y["PyramidLevel"] == 2
+    np.testing.assert_array_equal(y["Centers"], centers)
+
+
+def test_result_json_format():
+    K = np.array([[800, 0, 320], [0, 800, 240], [0, 0, 1.0]])
+    R = np.array([[0.123456789, -0.5, 1e-7], [0, 1, 0], [-1.5, 2.25, 3]])
+    s = fileio.format_result_json("/q/img.jpg", "/sfm/sfm_data.json", "/m", K=K, R=R, center=[1.0, -2.5, 3.14159265],
+                                  pairs=[(5, 100), (7, 101)])
+    d = json.loads(s)
+    assert list(d) == ["filename", "sfm_data", "matches_dir", "K", "R", "t", "pair"]       # localization.cpp:125-143
+    assert d["K"] == K.tolist() and d["pair"] == [[5, 100], [7, 101]]
+    assert d["R"][0] == [0.123457, -0.5, 1e-07] and d["t"] == [1, -2.5, 3.14159]         # 6 significant digits
+    assert '"K": [[800,  0,320],\n[  0,800,240],\n[  0,  0,  1]],' in s                    # Eigen aligned columns
+    f = json.loads(fileio.format_result_json("/q/img.jpg", "/sfm/sfm_data.json", "/m"))
+    assert list(f) == ["filename", "sfm_data", "matches_dir"] and "t" not in f             # failure: localization.cpp:84-109
+
+
+@pytest.fixture(scope="module")
+def toy_map(tmp_path_factory):
+    root = tmp_path_factory.mktemp("toy")
+    m = synth.make_map(1, n_views=50, desc_per_view=300, views_per_place=10, landmarks_per_place=200,
+                       obs_per_view=90, ragged=True, view_id_stride=3)
+    bow = np.random.Generator(np.random.PCG64(3)).random((50, 500))
+    names = synth.write_map_to_disk(m, str(root / "sfm"), str(root / "matches"), unposed_views=(6, 9), with_bow=bow)
+    return m, str(root / "sfm"), str(root / "matches"), names
+
+
+def test_native_loader_reads_the_contract(toy_map):
+    m, sfm_dir, match_dir, names = toy_map
+    info = capi.scan(sfm_dir, match_dir)
+    posed = [k for k, v in enumerate(m.view_id) if int(v) not in (6, 9)]
+    rows = np.concatenate([np.arange(m.view_off[k], m.view_off[k + 1]) for k in posed]).astype(np.int64)
+    assert info["n_views_total"] == 50 and info["n_views_posed"] == 48                   # localization.cpp:337-341
+    assert info["n_rows"] == len(rows)
+    assert info["n_landmarks"] == len(m.landmark_id)
+    assert info["n_observations"] == int((m.row_landmark[rows] >= 0).sum())
+    assert (info["focal"], info["ppx"], info["ppy"]) == m.intrinsic and info["bow_dim"] == 500
+    h = 1469598103934665603
+    for b in m.desc[rows].tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert info["desc_fnv1a"] == h
+    k6 = np.concatenate([fileio.read_feat(os.path.join(match_dir, names[k] + ".feat"))[:, :2] for k in posed])
+    assert abs(info["kpt_sum"] - float(k6.astype(np.float64).sum())) < 1e-6
+    assert info["row_landmark_sum"] == int(m.row_landmark[rows].astype(np.int64).sum())
+
+
+def test_native_loader_errors(toy_map, tmp_path):
+    m, sfm_dir, match_dir, names = toy_map
+    with pytest.raises(capi.SfmlocError) as ei:
+        capi.scan(str(tmp_path), match_dir)
+    assert ei.value.code == capi.EIO and "cannot be read" in str(ei.value)              # localization.cpp:241
+    (tmp_path / "sfm_data.json").write_text('{"views": [ {"key": 0, ')
+    with pytest.raises(capi.SfmlocError) as ei:
+        capi.scan(str(tmp_path), match_dir)
+    assert "JSON error" in str(ei.value)
+    with pytest.raises(capi.SfmlocError) as ei:
+        capi.scan(sfm_dir, str(tmp_path))                                              # descriptor files missing
+    assert "cannot open" in str(ei.value)
+
+
+def test_cli_argument_syntax():
+    from sfmlocalization_amd import engine
+    pos, o = engine.parse_cv_args(["q.jpg", "sfm", "m", "out", "-f=0.7", "-r=25", "-k=20", "-d=-1.0", "-gm", "-x=-3.5"],
+                                  engine.KEYS)
+    assert pos == ["q.jpg", "sfm", "m", "out"]
+    assert o["fDistRatio"] == 0.7 and o["ransacRound"] == 25 and o["knnbow"] == 20 and o["guidedMatch"] is True
+    assert o["cenRadius"] == -1.0 and o["cenLocX"] == -3.5 and o["geomLimit"] == 4.0 and o["locEvryNFrame"] == 1
+    _, d = engine.parse_cv_args(["a", "b", "c", "d"], engine.KEYS)               # defaults: localization.cpp:70-82
+    assert (d["fDistRatio"], d["ransacRound"], d["knnbow"], d["geomLimit"]) == (0.6, 200, 0, 4.0)

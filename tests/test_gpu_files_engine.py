@@ -1,0 +1,144 @@
+"""GPU: BASELINE config 1 -- a 50-image toy OpenMVG map on disk, queries as .desc/.feat files, localised through
+sfmloc_open, the LocalizeEngine mirror and the OpenMVGLocalization_AKAZE-compatible command line; results
+equal the oracle's on the same inputs and land on the planted pose."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import sfmlocalization_amd as S
+from sfmlocalization_amd import capi, engine, fileio, synth
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def toy(tmp_path_factory):
+    root = tmp_path_factory.mktemp("cfg1")
+    m = synth.make_map(1, n_views=50, desc_per_view=400, views_per_place=10, landmarks_per_place=300,
+                       obs_per_view=130, view_id_stride=2)
+    names = synth.write_map_to_disk(m, str(root / "sfm"), str(root / "matches"), unposed_views=(4,))
+    qdir = root / "queries"
+    qdir.mkdir()
+    queries = []
+    for k in range(4):
+        q = synth.make_query(m, 50 + k, n_feat=500, n_copies=180, outlier_frac=0.25 if k < 3 else 0.0,
+                             place=k % 5)
+        if k == 3:
+            q = synth.make_query(m, 99, n_feat=300, n_copies=0)          # will not localise
+        base = f"q{k:03d}"
+        fileio.write_desc(qdir / (base + ".desc"), q.desc)
+        kp = np.concatenate([q.kpt_xy, np.zeros((len(q.kpt_xy), 2), np.float32)], 1)
+        # the reference keeps full-precision keypoints in memory (locFeat); a .feat file holds 6 digits, so the
+        # file-based query IS the rounded one
+        fileio.write_feat(qdir / (base + ".feat"), kp)
+        (qdir / (base + ".jpg")).write_bytes(b"")                          # image itself is not decoded
+        queries.append((base, q))
+    return m, root, names, queries
+
+
+def posed_submap(m, skip_ids):
+    """the synthetic map restricted to posed views, as the loader sees it"""
+    keep = [k for k, v in enumerate(m.view_id) if int(v) not in skip_ids]
+    rows = np.concatenate([np.arange(m.view_off[k], m.view_off[k + 1]) for k in keep]).astype(np.int64)
+    off = np.zeros(len(keep) + 1, np.uint32)
+    off[1:] = np.cumsum([m.view_off[k + 1] - m.view_off[k] for k in keep])
+
+    class Sub:
+        pass
+    s = Sub()
+    s.view_id, s.view_off, s.view_wh = m.view_id[keep], off, m.view_wh[keep]
+    s.desc, s.row_landmark = m.desc[rows], m.row_landmark[rows]
+    s.landmark_id, s.landmark_X, s.intrinsic = m.landmark_id, m.landmark_X, m.intrinsic
+    return s, keep, rows
+
+
+def test_open_equals_in_memory_map(toy, oracle_c):
+    m, root, names, queries = toy
+    sub, keep, rows = posed_submap(m, (4,))
+    # map keypoints as the files hold them
+    sub.kpt_xy = np.concatenate([fileio.read_feat(root / "matches" / (names[k] + ".feat"))[:, :2] for k in keep])
+    p = S.default_params(ransac_round=25)
+    with capi.Map.open(str(root / "sfm"), str(root / "matches"), p) as dm:
+        assert dm.n_views == 49 and dm.n_rows == len(rows)
+        np.testing.assert_array_equal(dm.view_id, sub.view_id)
+        np.testing.assert_array_equal(dm.view_off, sub.view_off)
+        np.testing.assert_allclose(dm.view_center, m.view_C[keep])
+        for base, q in queries:
+            desc = fileio.read_desc(root / "queries" / (base + ".desc"))
+            kp = fileio.read_feat(root / "queries" / (base + ".feat"))[:, :2]
+            dq = dm.query(desc, kp, 640, 480)
+            pose, pq, pl = dm.localize(dq)
+            dq.close()
+            exp = opipe.localize(sub, desc, kp, (640, 480))
+            assert bool(pose.ok) == exp["ok"]
+            if exp["ok"]:
+                np.testing.assert_array_equal(pq, exp["pair_qfeat"])
+                np.testing.assert_array_equal(pl, exp["pair_landmark"])
+                assert np.abs(np.array(pose.R).reshape(3, 3) - exp["R"]).max() <= 1e-4
+                assert np.abs(np.array(pose.center) - exp["center"]).max() <= 1e-4
+                assert np.abs(np.array(pose.center) - q.C_true).max() < 0.3
+
+
+def test_command_line_writes_the_reference_json(toy):
+    m, root, names, queries = toy
+    out = root / "loc_out"
+    rc = engine.main([str(root / "queries"), str(root / "sfm"), str(root / "matches"), str(out), "-f=0.6", "-r=25"])
+    assert rc == 0
+    files = sorted(os.listdir(out))
+    assert files == [b + ".json" for b, _ in queries]
+    n_ok = 0
+    for base, q in queries:
+        d = json.load(open(out / (base + ".json")))
+        assert d["filename"].endswith(base + ".jpg") and d["sfm_data"].endswith("sfm_data.json")
+        assert d["matches_dir"] == str(root / "matches")
+        if "t" in d:                                   # mergeSfM.py:61 success test
+            n_ok += 1
+            assert np.abs(np.array(d["t"]) - q.C_true).max() < 0.3
+            K = np.array(d["K"])
+            assert abs(K[0, 0] - 800) < 1e-3 and abs(K[0, 2] - 320) < 1e-3
+            assert len(d["pair"]) > 10
+            lm_ids = set(int(x) for x in m.landmark_id)
+            assert all(int(b) in lm_ids and 0 <= int(a) < 500 for a, b in d["pair"])
+        else:
+            assert list(d) == ["filename", "sfm_data", "matches_dir"]
+    assert n_ok == 3 and "t" not in json.load(open(out / "q003.json"))
+    # dead-reckoning restriction (-x -y -z -d): far away centre -> no view -> failure JSON
+    out2 = root / "loc_out2"
+    rc = engine.main([str(root / "queries" / "q000.jpg"), str(root / "sfm"), str(root / "matches"), str(out2),
+                      "-r=25", "-x=1000", "-y=1000", "-z=1000", "-d=4"])
+    assert rc == 0 and "t" not in json.load(open(out2 / "q000.json"))
+    # bad sfm dir -> error exit like the reference (EXIT_FAILURE)
+    assert engine.main([str(root / "queries"), str(root), str(root / "matches"), str(out)]) == 1
+
+
+def test_engine_mirror_return_convention(toy):
+    m, root, names, queries = toy
+    A = np.array([[0, -2.0, 0, 10], [2.0, 0, 0, -5], [0, 0, 2.0, 1]])      # similarity: scale 2, rot 90 deg about z
+    fileio.write_cv_yaml(root / "Amat.yml", {"A": A})
+    e0 = engine.LocalizeEngine(str(root / "sfm"), str(root / "matches"), None, 0.6, 25, 4.0, False)
+    e1 = engine.LocalizeEngine(str(root / "sfm"), str(root / "matches"), str(root / "Amat.yml"), 0.6, 25, 4.0, False)
+    base, q = queries[0]
+    desc = fileio.read_desc(root / "queries" / (base + ".desc"))
+    kp = fileio.read_feat(root / "queries" / (base + ".feat"))[:, :2]
+    r0, ex0 = e0.localize(desc, kp, 640, 480, return_time=True)
+    r1, _ = e1.localize(desc, kp, 640, 480)
+    assert len(r0) == 12 and len(r1) == 12 and len(ex0["times"]) == 6        # LocalizeEngine.cc:593-602,651-657
+    c0, R0 = np.array(r0[:3]), np.array(r0[3:]).reshape(3, 3)
+    c1, R1 = np.array(r1[:3]), np.array(r1[3:]).reshape(3, 3)
+    np.testing.assert_allclose(c1, A[:, :3] @ c0 + A[:, 3], atol=1e-9)
+    np.testing.assert_allclose(R1, R0 @ (A[:, :3] / 2.0).T, atol=1e-12)
+    np.testing.assert_allclose(R1 @ R1.T, np.eye(3), atol=1e-9)
+    # restricting to views near the true position keeps the answer; restricting far away gives the empty vector
+    near, _ = e0.localize(desc, kp, 640, 480, center=list(q.C_true), radius=40.0 ** 2)
+    assert len(near) == 12 and np.abs(np.array(near[:3]) - q.C_true).max() < 0.3
+    far, _ = e0.localize(desc, kp, 640, 480, center=[1e3, 1e3, 1e3], radius=1.0)
+    assert far == []
+    base3, _ = queries[3]
+    none, _ = e0.localize(fileio.read_desc(root / "queries" / (base3 + ".desc")),
+                          fileio.read_feat(root / "queries" / (base3 + ".feat"))[:, :2], 640, 480)
+    assert none == []                                                        # LocalizeEngine.cc:453,481,579
+    e0.close()
+    e1.close()
