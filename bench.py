@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 256 CU x 4 SIMD-32 x 2.4 GHz lane-ops/s (to be confirmed by microbench)
+VALU_PEAK_TOPS = 39.1  # measured ceiling of the xor+bcnt instruction mix at 8 waves/SIMD (profiles/r01_valu_rates.jsonl)
 OPS_PER_PAIR = 35  # 16 xor + 16 bcnt + lshl_or + med3 + min (hamming.hip)
 
 
@@ -34,36 +34,36 @@ def parse():
     ap.add_argument("--desc-per-view", type=int, default=2000)
     ap.add_argument("--nq", type=int, default=2000)
     ap.add_argument("--queries", type=int, default=8, help="distinct synthetic queries cycled through")
-    ap.add_argument("--in-flight", type=int, default=4, help="queries in flight (contexts); 1 = latency mode")
+    ap.add_argument("--in-flight", type=int, default=3, help="queries in flight (contexts); 1 = latency mode")
+    ap.add_argument("--batch", type=int, default=16, help="queries per all-gather when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
 def cpu_baseline(m, queries, seconds):
-    """The C oracle's matchAKAZEToQuery restatement on this host's cores, on a bounded sample of views of
-    the SAME workload; extrapolated to whole queries."""
-    from oracle import oracle_c
+    """The C oracle's restatement of the whole per-query path on this host's cores (OpenMP), on a bounded
+    sample of the SAME workload: exact 2-NN + ratio on a sample of views (scaled to the full bank: that stage is
+    linear in rows) plus the query's own place's views, where every later stage (F-matrix AC-RANSAC, 2D-3D set,
+    P3P AC-RANSAC) does all its work."""
+    from oracle import oracle_c, pipeline as opipe
     threads = max(1, min(16, os.cpu_count() or 1, oracle_c.max_threads()))
     q = queries[0]
-    # calibrate on 2% of the views, then size the sample for ~`seconds`
     n_cal = max(threads, m.n_views // 50)
-    sel = np.arange(n_cal, dtype=np.uint32)
     t0 = time.perf_counter()
-    oracle_c.match_to_query(q.desc, m.desc, m.view_off, sel, 0.6, threads=threads)
-    t_cal = time.perf_counter() - t0
-    per_view = t_cal / n_cal
+    oracle_c.match_to_query(q.desc, m.desc, m.view_off, np.arange(n_cal, dtype=np.uint32), 0.6, threads=threads)
+    per_view = (time.perf_counter() - t0) / n_cal
     n_sample = int(min(m.n_views, max(n_cal, seconds / max(per_view, 1e-9))))
-    sel = np.arange(n_sample, dtype=np.uint32)
-    t0 = time.perf_counter()
-    oracle_c.match_to_query(q.desc, m.desc, m.view_off, sel, 0.6, threads=threads)
-    t = time.perf_counter() - t0
-    rows = int(m.view_off[n_sample])
-    t_full = t * (m.n_rows / rows)
+    place_views = np.nonzero(m.view_place == q.place)[0]
+    sel = np.unique(np.concatenate([np.arange(n_sample), place_views])).astype(np.uint32)
+    r = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=sel, ransac_round=25, threads=threads)
+    rows = int(sum(int(m.view_off[v + 1] - m.view_off[v]) for v in sel))
+    t_full = r["t_putative"] * (m.n_rows / rows) + r["t_rest"]
     return {"value": 1.0 / t_full, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"putative matching (exact 2-NN + ratio) of 1 query ({q.desc.shape[0]} feats) against "
-                      f"{n_sample}/{m.n_views} views ({rows} rows) in {t:.2f}s, scaled to the full bank; "
-                      "OpenMP, -O3 -march=x86-64-v3"}
+            "sample": f"1 query ({q.desc.shape[0]} feats): exact 2-NN + ratio against {len(sel)}/{m.n_views} views "
+                      f"({rows} rows, {r['t_putative']:.2f}s, scaled to the full bank) + F-matrix AC-RANSAC, 2D-3D set "
+                      f"and P3P AC-RANSAC on the surviving views ({r['t_rest']:.3f}s, localised={r['ok']}); "
+                      "C oracle, OpenMP, -O3 -march=x86-64-v3"}
 
 
 def main():
@@ -96,7 +96,15 @@ def main():
     lat = []
     n_ok = [0]
     nctx = max(1, a.in_flight)
-    ctxs = [dev_map.context() for _ in range(nctx)]
+    sharded = None
+    if world > 1:
+        # bank sharded by view; per batch: stage 1 on every shard, ONE all-gather of candidate parts over RCCL,
+        # stage 2 of each query on its owner rank (sfmlocalization_amd/dist.py)
+        from sfmlocalization_amd import dist as D
+        cap = 4096
+        comp = D.HipShardCompute(dev_map, cap, n_contexts=nctx, device=torch.device("cuda", local_rank))
+        sharded = D.ShardedLocalizer(comp, cap, rank=rank, world=world)
+    ctxs = [dev_map.context() for _ in range(nctx)] if sharded is None else []
     t_begin = [0.0] * nctx
     busy = [False] * nctx
 
@@ -106,8 +114,24 @@ def main():
         n_ok[0] += int(pose.ok)
         busy[k] = False
 
+    batch = []
+
+    def flush():
+        if batch:
+            tb = time.perf_counter()
+            res = sharded.localize_batch([dqs[i % len(dqs)] for i in batch], gather_results=False)
+            dtb = time.perf_counter() - tb
+            lat.extend([dtb] * len(batch))          # a query's latency in batch mode = its batch's wall time
+            n_ok[0] += sum(int(r["ok"]) for r in res.values())
+            batch.clear()
+
     def step(i):
         # one step = one query through the whole path; up to `nctx` steps overlap on the GPU
+        if sharded is not None:
+            batch.append(i)
+            if len(batch) >= a.batch:
+                flush()
+            return
         k = i % nctx
         if busy[k]:
             finish(k)
@@ -116,6 +140,9 @@ def main():
         busy[k] = True
 
     def drain():
+        if sharded is not None:
+            flush()
+            return
         for k in range(nctx):
             if busy[k]:
                 finish(k)
@@ -145,8 +172,12 @@ def main():
         dt = float(t.item())
     st = dev_map.stats()
     k1_ms = st.total_ms[0] / max(1, st.launches[0])
-    cnt, _, _, _ = dev_map.putative_read()
-    n_match = int(cnt.sum())
+    dev_map.match_putative(dqs[0])  # outside the timed region: number of emitted matches for the byte count
+    n_match = int(dev_map.putative_read()[0].sum())
+    if world > 1:
+        ok_t = torch.tensor([n_ok[0]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ok_t)
+        n_ok[0] = int(ok_t.item())
     rows_rank = r1 - r0
     alg_bytes = 64 * rows_rank + 64 * a.nq + 12 * n_match
     achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
@@ -172,7 +203,8 @@ def main():
                                    "F-matrix AC-RANSAC (25 rounds) -> 2D-3D set -> P3P AC-RANSAC (4096) -> pose; "
                                    f"{nctx} queries in flight",
                        "views": a.views, "rows": int(m.n_rows), "nq": a.nq,
-                       "parallelism": f"bank sharded by view x{world}",
+                       "parallelism": (f"bank sharded by view x{world}, one all-gather of candidate parts per "
+                                       f"{a.batch}-query batch" if world > 1 else "1 GPU, whole bank"),
                        "queries_localised": f"{n_ok[0]}/{a.steps}"},
             "latency_ms": {"p50": float(np.percentile(lat, 50) * 1e3), "p95": float(np.percentile(lat, 95) * 1e3)},
             "stage_ms": {"putMatch(K1+K2)": (st.total_ms[0] + st.total_ms[1]) / a.steps,
@@ -190,6 +222,8 @@ def main():
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
+    if sharded is not None:
+        sharded.compute.close()
     for dq in dqs:
         dq.close()
     dev_map.close()

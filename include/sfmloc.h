@@ -246,6 +246,26 @@ int sfmloc_localize_end(sfmloc_context *ctx, sfmloc_pose *out, uint32_t *pair_qf
 int sfmloc_localize_batch(sfmloc_map *map, sfmloc_query *const *queries, uint32_t n, uint32_t n_contexts,
                           sfmloc_pose *poses, uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t pair_stride);
 
+/* ------------------------------------------------------------------------- */
+/* Sharded maps: one process per GPU, each holding a contiguous   */
+/* range of views.  Every bank row's decision depends only on the replicated     */
+/* query, so putative matching and the F-matrix filter are shard-local; what is   */
+/* exchanged is each shard's list of 2D-3D CANDIDATES (a "part": 16-byte header   */
+/* {u32 count} + cap 40-byte candidates whose order key carries the global view   */
+/* id).  The caller moves parts between ranks (torch.distributed all-gather over  */
+/* RCCL) and hands the concatenation to sfmloc_merge_begin, which reproduces      */
+/* matchProviderToMatchSet + Localize of the unsharded map bit for bit.           */
+/*   dst_dev / parts_dev are DEVICE pointers owned by the caller.                 */
+/* ------------------------------------------------------------------------- */
+uint64_t sfmloc_part_bytes(uint32_t cap);
+int sfmloc_shard_begin(sfmloc_context *ctx, sfmloc_query *q, const uint32_t *view_sel, uint32_t n_sel);
+int sfmloc_shard_export(sfmloc_context *ctx, void *dst_dev, uint32_t cap);
+int sfmloc_context_sync(sfmloc_context *ctx);
+/* part p starts at parts_dev + p*part_stride (part_stride = 0 means sfmloc_part_bytes(cap): back to back) */
+int sfmloc_merge_begin(sfmloc_context *ctx, sfmloc_query *q, const void *parts_dev, uint32_t n_parts, uint32_t cap,
+                       uint64_t part_stride);
+/* ... then sfmloc_localize_end(ctx, ...) */
+
 /* Parity probe: runs one of the f64 device building blocks over n items (tests compare with the oracle).
  * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample */
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride);

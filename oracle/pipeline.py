@@ -18,9 +18,13 @@ def localize(m, q_desc, q_kpt, q_wh, view_sel=None, ratio=0.6, ransac_round=25, 
              seed=0x5f3759df12345678, threads=4):
     """m: object with view_id, view_off, view_wh, desc, kpt_xy, row_landmark, landmark_id, landmark_X,
     intrinsic.  Returns a dict with every intermediate the product exposes."""
+    import time as _time
     out = {}
     nq = q_desc.shape[0]
+    _t0 = _time.perf_counter()
     cnt, mi, mj, md = oracle_c.match_to_query(q_desc, m.desc, m.view_off, view_sel, ratio, threads=threads)
+    out["t_putative"] = _time.perf_counter() - _t0
+    _t1 = _time.perf_counter()
     out["put_count"], out["put_i"], out["put_j"], out["put_d"] = cnt, mi, mj, md
     nv = len(m.view_id)
     q6 = round6(q_kpt).astype(np.float64)
@@ -65,4 +69,58 @@ def localize(m, q_desc, q_kpt, q_wh, view_sel=None, ratio=0.6, ransac_round=25, 
             K, R, t, c = oracle_c.krt_from_p(r["P"])
             out.update(ok=True, K=K, R=R, t=t, center=c, P=r["P"], inlier_idx=r["inliers"],
                        pair_qfeat=qf[r["inliers"]], pair_landmark=out["ms_landmark"][r["inliers"]])
+    out["t_rest"] = _time.perf_counter() - _t1
     return out
+
+
+def shard_candidates(m, q_desc, q_kpt, q_wh, v0, v1, **kw):
+    """What ONE shard (views [v0, v1) of map m) contributes for a query: the 2D-3D candidates of its geometric
+    matches, as the structured array of sfmlocalization_amd.dist.CANDIDATE_DTYPE.  Order keys carry the global
+    view id, so parts of different shards merge into exactly the unsharded candidate set."""
+    from sfmlocalization_amd import dist as D
+    sel = np.arange(v0, v1, dtype=np.uint32)
+    r = localize(m, q_desc, q_kpt, q_wh, view_sel=sel, **kw) if v1 > v0 else None
+    out = []
+    if r is not None:
+        cnt, mi, mj, md = r["put_count"], r["put_i"], r["put_j"], r["put_d"]
+        for v in range(v0, v1):
+            gc = int(r["geo_count"][v])
+            off = int(m.view_off[v])
+            for p in range(gc):
+                pp = int(r["geo_idx"][off + p])
+                i, j = int(mi[off + pp]), int(mj[off + pp])
+                lm = int(m.row_landmark[off + i])
+                if lm < 0:
+                    continue
+                same = np.nonzero(mj[off:off + int(cnt[v])] == j)[0]
+                dist = int(md[off + same[-1]])                      # featDist: last putative with this j
+                out.append((D.order_key(dist, int(m.view_id[v]), p), j, int(m.landmark_id[lm]), tuple(m.landmark_X[lm])))
+    return np.array(out, dtype=D.CANDIDATE_DTYPE)
+
+
+def merge_candidates(parts, q_kpt, intrinsic, min_resection_points=8, min_inliers=10, p3p_max_iteration=4096,
+                     seed=0x5f3759df12345678):
+    """Selection (min order key per query feature) + P3P on the union of the shards' candidates."""
+    allc = np.concatenate(parts) if len(parts) else np.zeros(0)
+    res = {"ok": False, "n_inliers": 0}
+    if len(allc) == 0:
+        return res
+    best = {}
+    for c in allc:
+        j = int(c["qfeat"])
+        if j not in best or c["order"] < best[j]["order"]:
+            best[j] = c
+    qf = np.array(sorted(best), dtype=np.uint32)
+    lm_id = np.array([best[int(j)]["landmark_id"] for j in qf], dtype=np.uint32)
+    pt3d = np.array([best[int(j)]["X"] for j in qf], dtype=np.float64).reshape(-1, 3)
+    pt2d = np.asarray(q_kpt)[qf].astype(np.float64)
+    res.update(ms_qfeat=qf, ms_landmark=lm_id)
+    if len(qf) > min_resection_points:
+        f, ppx, ppy = intrinsic[:3]
+        r = oracle_c.p3p_localize(pt2d, pt3d, f, ppx, ppy, p3p_max_iteration, seed, stream=0)
+        res["n_inliers"] = max(r["n"], 0)
+        if r["n"] > 0 and r["n"] > min_inliers:
+            K, R, t, c = oracle_c.krt_from_p(r["P"])
+            res.update(ok=True, K=K, R=R, center=c, P=r["P"], pair_qfeat=qf[r["inliers"]],
+                       pair_landmark=lm_id[r["inliers"]])
+    return res

@@ -1,6 +1,7 @@
 """ctypes mirror of include/sfmloc.h (one Python method per C entry point, same names and meaning)."""
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -92,7 +93,8 @@ SYMBOLS = [
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
     "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
     "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
-    "sfmloc_localize_batch",
+    "sfmloc_localize_batch", "sfmloc_part_bytes", "sfmloc_shard_begin", "sfmloc_shard_export",
+    "sfmloc_context_sync", "sfmloc_merge_begin",
     "sfmloc_stats_read", "sfmloc_stats_reset",
 ]
 
@@ -139,6 +141,12 @@ def _L():
         L.sfmloc_context_destroy.argtypes = [C.c_void_p]
         L.sfmloc_localize_begin.argtypes = [C.c_void_p, C.c_void_p, U32P, C.c_uint32]
         L.sfmloc_localize_end.argtypes = [C.c_void_p, C.POINTER(Pose), U32P, U32P, C.c_uint32]
+        L.sfmloc_part_bytes.restype = C.c_uint64
+        L.sfmloc_part_bytes.argtypes = [C.c_uint32]
+        L.sfmloc_shard_begin.argtypes = [C.c_void_p, C.c_void_p, U32P, C.c_uint32]
+        L.sfmloc_shard_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.sfmloc_context_sync.argtypes = [C.c_void_p]
+        L.sfmloc_merge_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
         L.sfmloc_localize_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32,
                                             C.POINTER(Pose), U32P, U32P, C.c_uint32]
         L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
@@ -158,6 +166,10 @@ def _ptr(a, ctype):
 
 def device_count():
     return int(_L().sfmloc_device_count())
+
+
+def part_bytes(cap):
+    return int(_L().sfmloc_part_bytes(cap))
 
 
 def scan(sfm_dir, match_dir):
@@ -195,6 +207,7 @@ class Map:
     def __init__(self, view_id, view_off, desc, params=None, view_wh=None, kpt_xy=None, row_landmark=None,
                  landmark_id=None, landmark_X=None, intrinsic=None, bow=None):
         self._h = None
+        self._children = weakref.WeakSet()
         self.view_id = np.ascontiguousarray(view_id, dtype=np.uint32)
         self.view_off = np.ascontiguousarray(view_off, dtype=np.uint32)
         desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 64)
@@ -244,6 +257,7 @@ class Map:
         """sfmloc_open: load the reference's on-disk map (sfm_data.json + .desc/.feat[/.bow])."""
         self = cls.__new__(cls)
         self._h = None
+        self._children = weakref.WeakSet()
         self.params = params if params is not None else default_params()
         h = C.c_void_p()
         _check(_L().sfmloc_open(os.fsencode(sfm_dir), os.fsencode(match_dir), C.byref(self.params), C.byref(h)))
@@ -259,6 +273,13 @@ class Map:
 
     def close(self):
         if self._h is not None:
+            # queries and contexts hold pointers into the map: release them first, whatever order the
+            # garbage collector would have chosen
+            for ch in list(self._children):
+                try:
+                    ch.close()
+                except Exception:
+                    pass
             _L().sfmloc_map_destroy(self._h)
             self._h = None
 
@@ -396,6 +417,7 @@ class Context:
         h = C.c_void_p()
         _check(_L().sfmloc_context_create(m._h, C.byref(h)))
         self._h = h
+        m._children.add(self)
 
     def begin(self, q, view_sel=None):
         if view_sel is None:
@@ -403,6 +425,23 @@ class Context:
         else:
             sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
             _check(_L().sfmloc_localize_begin(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+
+    def shard_begin(self, q, view_sel=None):
+        """K1..K3 + candidate emission on this shard (asynchronous)."""
+        if view_sel is None:
+            _check(_L().sfmloc_shard_begin(self._h, q._h, None, 0))
+        else:
+            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
+            _check(_L().sfmloc_shard_begin(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+
+    def shard_export(self, dst_dev_ptr, cap):
+        _check(_L().sfmloc_shard_export(self._h, C.c_void_p(dst_dev_ptr), cap))
+
+    def sync(self):
+        _check(_L().sfmloc_context_sync(self._h))
+
+    def merge_begin(self, q, parts_dev_ptr, n_parts, cap, part_stride=0):
+        _check(_L().sfmloc_merge_begin(self._h, q._h, C.c_void_p(parts_dev_ptr), n_parts, cap, part_stride))
 
     def end(self, cap=4096):
         pose = Pose()
@@ -416,6 +455,12 @@ class Context:
         if self._h is not None and self.map._h is not None:
             _L().sfmloc_context_destroy(self._h)
         self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Query:
@@ -434,11 +479,12 @@ class Query:
         _check(_L().sfmloc_query_create(m._h, _ptr(desc, C.c_uint8), _ptr(kpt_xy, C.c_float), self.n,
                                         int(width), int(height), C.byref(h)))
         self._h = h
+        m._children.add(self)
 
     def close(self):
-        if self._h is not None:
+        if self._h is not None and self.map._h is not None:
             _L().sfmloc_query_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:

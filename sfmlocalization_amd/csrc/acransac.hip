@@ -380,23 +380,47 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
   }
 }
 
-__global__ __launch_bounds__(256) void k_candidates_min(const Candidate *cand, const uint32_t *n_cand, uint32_t cap,
-                                                        unsigned long long *best) {
-  const uint32_t n = min(*n_cand, cap);
-  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
-    atomicMin(&best[cand[c].qfeat], (unsigned long long)cand[c].order);
+// A "part" is what one shard contributes for one query: 16-byte header {u32 n_cand, pad} + cap candidates.
+// The selection kernels run over n_parts parts laid out back to back (n_parts = 1 on a single GPU; after the
+// all-gather it is the number of shards).  Candidate c of part p has the global index p*cap + c.
+__device__ __forceinline__ const Candidate *part_cands(const unsigned char *parts, uint64_t part_bytes, uint32_t p) {
+  return reinterpret_cast<const Candidate *>(parts + (uint64_t)p * part_bytes + kPartHeaderBytes);
+}
+__device__ __forceinline__ uint32_t part_count(const unsigned char *parts, uint64_t part_bytes, uint32_t p,
+                                               uint32_t cap) {
+  return min(*reinterpret_cast<const uint32_t *>(parts + (uint64_t)p * part_bytes), cap);
 }
 
-__global__ __launch_bounds__(256) void k_candidates_win(const Candidate *cand, const uint32_t *n_cand, uint32_t cap,
+__global__ __launch_bounds__(256) void k_candidates_min(const unsigned char *parts, uint32_t n_parts,
+                                                        uint64_t part_bytes, uint32_t cap, uint32_t nq,
+                                                        unsigned long long *best, int *status) {
+  for (uint32_t p = blockIdx.y; p < n_parts; p += gridDim.y) {
+    const Candidate *cand = part_cands(parts, part_bytes, p);
+    const uint32_t n = part_count(parts, part_bytes, p, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0 &&
+        *reinterpret_cast<const uint32_t *>(parts + (uint64_t)p * part_bytes) > cap)
+      atomicOr(status, 2);  // a shard produced more candidates than its part holds
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+      if (cand[c].qfeat < nq) atomicMin(&best[cand[c].qfeat], (unsigned long long)cand[c].order);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_candidates_win(const unsigned char *parts, uint32_t n_parts,
+                                                        uint64_t part_bytes, uint32_t cap, uint32_t nq,
                                                         const unsigned long long *best, uint32_t *winner) {
-  const uint32_t n = min(*n_cand, cap);
-  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
-    if (best[cand[c].qfeat] == (unsigned long long)cand[c].order) winner[cand[c].qfeat] = c;
+  for (uint32_t p = blockIdx.y; p < n_parts; p += gridDim.y) {
+    const Candidate *cand = part_cands(parts, part_bytes, p);
+    const uint32_t n = part_count(parts, part_bytes, p, cap);
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+      if (cand[c].qfeat < nq && best[cand[c].qfeat] == (unsigned long long)cand[c].order)
+        winner[cand[c].qfeat] = p * cap + c;
+  }
 }
 
 // single wave: compact the winners in ascending query-feature order (SfMDataUtils.cpp:121-124) and assemble
 // pt2D / pt3D (localization.cpp:479-501; pinhole get_ud_pixel is the identity)
-__global__ __launch_bounds__(64) void k_match_set_finish(const Candidate *cand, const unsigned long long *best,
+__global__ __launch_bounds__(64) void k_match_set_finish(const unsigned char *parts, uint64_t part_bytes,
+                                                         uint32_t cap, const unsigned long long *best,
                                                          const uint32_t *winner, uint32_t nq, const float2 *q_kpt,
                                                          uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
                                                          double *pt2d, double *pt3d) {
@@ -408,7 +432,8 @@ __global__ __launch_bounds__(64) void k_match_set_finish(const Candidate *cand, 
     const unsigned long long mask = __ballot(has);
     if (has) {
       const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      const Candidate c = cand[winner[j]];
+      const uint32_t w = winner[j];
+      const Candidate c = part_cands(parts, part_bytes, w / cap)[w % cap];
       ms_qfeat[pos] = j;
       ms_landmark[pos] = c.landmark_id;
       const float2 kp = q_kpt[j];
@@ -768,29 +793,45 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
   return SFMLOC_OK;
 }
 
-int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views) {
+int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_views) {
   Map *m = c->map;
-  SFM_HIP(hipMemsetAsync(c->d_n_cand, 0, sizeof(uint32_t), c->stream));
-  SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
-  SFM_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
+  SFM_HIP(hipMemsetAsync(c->d_cand_part, 0, kPartHeaderBytes, c->stream));
   SFM_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
   if (n_sel == 0 || q->n == 0) return SFMLOC_OK;
   hipLaunchKernelGGL(k_emit_candidates, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream,
                      all_views ? nullptr : c->d_view_sel, n_sel, m->d_view_off, m->d_view_id, c->d_view_count,
                      c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, m->d_row_landmark,
-                     m->d_landmark_id, m->d_landmark_X, c->d_cand, c->cand_cap, c->d_n_cand, c->d_status,
-                     (uint32_t)m->params.min_putative, c->d_view_stats);
-  SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_candidates_min, dim3(64), dim3(256), 0, c->stream, c->d_cand, c->d_n_cand, c->cand_cap,
-                     c->d_best64);
-  SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_candidates_win, dim3(64), dim3(256), 0, c->stream, c->d_cand, c->d_n_cand, c->cand_cap,
-                     c->d_best64, c->d_winner);
-  SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(64), 0, c->stream, c->d_cand, c->d_best64, c->d_winner, q->n,
-                     q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d);
+                     m->d_landmark_id, m->d_landmark_X,
+                     reinterpret_cast<Candidate *>(c->d_cand_part + kPartHeaderBytes), c->cand_cap,
+                     reinterpret_cast<uint32_t *>(c->d_cand_part), c->d_status, (uint32_t)m->params.min_putative,
+                     c->d_view_stats);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
+}
+
+int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
+                             uint64_t part_bytes, uint32_t cap) {
+  SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
+  SFM_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
+  if (q->n == 0 || n_parts == 0) return SFMLOC_OK;
+  const dim3 grid(16, n_parts < 64 ? n_parts : 64);
+  hipLaunchKernelGGL(k_candidates_min, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
+                     c->d_best64, c->d_status);
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_candidates_win, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
+                     c->d_best64, c->d_winner);
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(64), 0, c->stream, parts, part_bytes, cap, c->d_best64,
+                     c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views) {
+  int rc = launch_emit_candidates(c, q, n_sel, all_views);
+  if (rc) return rc;
+  return launch_select_candidates(c, q, c->d_cand_part, 1, kPartHeaderBytes + (uint64_t)c->cand_cap * sizeof(Candidate),
+                                  c->cand_cap);
 }
 
 static P3pArgs make_p3p_args(Ctx *c) {

@@ -125,7 +125,7 @@ void free_ctx(Ctx *c) {
     hipEventDestroy(e.second);
   }
   void *ptrs[] = {c->d_part,      c->d_view_sel,  c->d_view_widx0, c->d_block_list, c->d_view_count, c->d_match_i,
-                  c->d_match_key, c->d_geo_count, c->d_geo_idx,    c->d_status,     c->d_cand,       c->d_n_cand,
+                  c->d_match_key, c->d_geo_count, c->d_geo_idx,    c->d_status,     c->d_cand_part,
                   c->d_best64,    c->d_winner,    c->d_ms_n,       c->d_ms_qfeat,   c->d_ms_landmark, c->d_pt2d,
                   c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
                   c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,    c->d_pair_qfeat,
@@ -175,8 +175,7 @@ int make_ctx(Map *m, Ctx **out) {
   CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views));
   CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_status, (size_t)1));
-  CTX_TRY(dev_alloc(acct, &c->d_cand, (size_t)c->cand_cap));
-  CTX_TRY(dev_alloc(acct, &c->d_n_cand, (size_t)1));
+  CTX_TRY(dev_alloc(acct, &c->d_cand_part, (size_t)kPartHeaderBytes + (size_t)c->cand_cap * sizeof(Candidate)));
   CTX_TRY(dev_alloc(acct, &c->d_best64, (size_t)65536));
   CTX_TRY(dev_alloc(acct, &c->d_winner, (size_t)65536));
   CTX_TRY(dev_alloc(acct, &c->d_ms_n, (size_t)1));
@@ -906,6 +905,78 @@ int sfmloc_localize_end(sfmloc_context *ctx, sfmloc_pose *out, uint32_t *pair_qf
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   SFM_HIP(hipSetDevice(c->map->device));
   return ctx_localize_end(c, out, pair_qfeat, pair_landmark, cap);
+}
+
+// ----- sharded maps: one process per GPU, bank sharded by view ------------------------------
+
+uint64_t sfmloc_part_bytes(uint32_t cap) { return (uint64_t)kPartHeaderBytes + (uint64_t)cap * sizeof(Candidate); }
+
+int sfmloc_shard_begin(sfmloc_context *ctx, sfmloc_query *query, const uint32_t *view_sel, uint32_t n_sel) {
+  SFM_CHECK(ctx && query, SFMLOC_EINVAL, "sfmloc_shard_begin: null argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  Query *q = reinterpret_cast<Query *>(query);
+  SFM_CHECK(q->map == c->map, SFMLOC_EINVAL, "sfmloc_shard_begin: query belongs to another map");
+  SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_shard_begin: context has a query in flight");
+  SFM_HIP(hipSetDevice(c->map->device));
+  int rc = ctx_match_putative(c, q, view_sel, n_sel);
+  if (rc) return rc;
+  rc = check_stage(c, q, "sfmloc_shard_begin");
+  if (rc) return rc;
+  rc = ctx_geometric_filter(c, q);
+  if (rc) return rc;
+  EventScope ev(c, SFMLOC_K_MATCHSET);
+  return launch_emit_candidates(c, q, c->last_n_sel, c->last_all_views);
+}
+
+int sfmloc_shard_export(sfmloc_context *ctx, void *dst_dev, uint32_t cap) {
+  SFM_CHECK(ctx && dst_dev && cap > 0, SFMLOC_EINVAL, "sfmloc_shard_export: bad argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  SFM_HIP(hipSetDevice(c->map->device));
+  const uint32_t n = cap < c->cand_cap ? cap : c->cand_cap;
+  // header (with the true count: the merging side flags count > cap) + the first n candidates
+  SFM_HIP(hipMemcpyAsync(dst_dev, c->d_cand_part, kPartHeaderBytes + (size_t)n * sizeof(Candidate),
+                         hipMemcpyDeviceToDevice, c->stream));
+  return SFMLOC_OK;
+}
+
+int sfmloc_context_sync(sfmloc_context *ctx) {
+  SFM_CHECK(ctx, SFMLOC_EINVAL, "sfmloc_context_sync: null context");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  SFM_HIP(hipSetDevice(c->map->device));
+  SFM_HIP(hipStreamSynchronize(c->stream));
+  return SFMLOC_OK;
+}
+
+int sfmloc_merge_begin(sfmloc_context *ctx, sfmloc_query *query, const void *parts_dev, uint32_t n_parts,
+                       uint32_t cap, uint64_t part_stride) {
+  SFM_CHECK(ctx && query && parts_dev && n_parts > 0 && cap > 0, SFMLOC_EINVAL, "sfmloc_merge_begin: bad argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  Query *q = reinterpret_cast<Query *>(query);
+  Map *m = c->map;
+  SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_merge_begin: query belongs to another map");
+  SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_merge_begin: context has a query in flight");
+  SFM_CHECK(m->focal > 0.0, SFMLOC_EINVAL, "sfmloc_merge_begin: the map has no intrinsic");
+  SFM_CHECK(q->n == 0 || q->d_kpt, SFMLOC_EINVAL, "sfmloc_merge_begin: the query was created without keypoints");
+  SFM_HIP(hipSetDevice(m->device));
+  c->t_begin = now_s();
+  SFM_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+  int rc;
+  {
+    EventScope ev(c, SFMLOC_K_MATCHSET);
+    if (part_stride == 0) part_stride = sfmloc_part_bytes(cap);
+    SFM_CHECK(part_stride >= sfmloc_part_bytes(cap), SFMLOC_EINVAL, "sfmloc_merge_begin: part_stride too small");
+    rc = launch_select_candidates(c, q, reinterpret_cast<const unsigned char *>(parts_dev), n_parts, part_stride, cap);
+  }
+  if (rc) return rc;
+  {
+    EventScope ev(c, SFMLOC_K_P3P);
+    rc = ctx_resection_enqueue(c, true);
+  }
+  if (rc) return rc;
+  rc = ctx_fetch_result(c);
+  if (rc) return rc;
+  c->in_flight = q;
+  return SFMLOC_OK;
 }
 
 int sfmloc_localize(sfmloc_map *map, sfmloc_query *query, const uint32_t *view_sel, uint32_t n_sel,

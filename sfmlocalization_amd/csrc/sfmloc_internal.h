@@ -47,6 +47,7 @@ void set_error(const char *fmt, ...);
 constexpr uint32_t kBlockRows = 64;
 constexpr int kP3pMaxN = 4096;     // 2D-3D correspondences the P3P LDS sort holds
 constexpr int kP3pBatchMax = 512;  // hypotheses evaluated per round
+constexpr uint32_t kPartHeaderBytes = 16;  // candidate part: {u32 n_cand, pad[3]} then the candidates
 
 using Pose = sfmloc_pose;
 
@@ -145,9 +146,8 @@ struct Ctx {
   uint32_t *d_geo_count = nullptr;  // [n_views]
   uint32_t *d_geo_idx = nullptr;    // [n_rows]
   int *d_status = nullptr;
-  Candidate *d_cand = nullptr;
-  uint32_t cand_cap = 1u << 16;
-  uint32_t *d_n_cand = nullptr;
+  unsigned char *d_cand_part = nullptr;  // this context's candidate part: header + cand_cap candidates
+  uint32_t cand_cap = 1u << 14;
   unsigned long long *d_best64 = nullptr;  // [65536]
   uint32_t *d_winner = nullptr;            // [65536]
   uint32_t *d_ms_n = nullptr, *d_ms_qfeat = nullptr, *d_ms_landmark = nullptr;  // [65536]
@@ -203,6 +203,9 @@ int launch_fill_log10(double *d_L10, int n, hipStream_t s);
 int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *d_out, int out_stride, hipStream_t s);
 int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
 int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
+int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
+int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
+                             uint64_t part_bytes, uint32_t cap);
 int launch_p3p_init(Ctx *c);
 int launch_p3p_round(Ctx *c, int batch);
 

@@ -1,0 +1,119 @@
+"""CPU, world_size 2 over gloo: the sharded-localisation protocol of sfmlocalization_amd/dist.py (view sharding,
+part layout, one all-gather per batch, query ownership, result gather) with the oracle standing in for the HIP
+stages.  The merged result must equal the unsharded oracle pipeline's exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sfmlocalization_amd import dist as D
+from sfmlocalization_amd import synth
+
+
+def test_shard_views_balanced_and_contiguous():
+    off = np.concatenate([[0], np.cumsum([5, 0, 100, 100, 3, 50, 50, 200, 1, 1])])
+    for world in (1, 2, 3, 4, 8):
+        r = D.shard_views(off, world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == 10
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(a <= b for a, b in r)
+    assert D.shard_views(off, 2) == [(0, 6), (6, 10)]
+
+
+def test_part_layout_roundtrip():
+    c = np.zeros(3, D.CANDIDATE_DTYPE)
+    c["order"] = [D.order_key(12, 7, 3), D.order_key(0, 0xFFFFFF, 0), D.order_key(512, 1, 2)]
+    c["qfeat"] = [5, 6, 7]
+    c["landmark_id"] = [100, 200, 300]
+    c["X"] = np.arange(9).reshape(3, 3)
+    assert D.CANDIDATE_DTYPE.itemsize == 40 and D.part_bytes(10) == 16 + 400
+    buf = D.pack_part(c, 10)
+    back = D.unpack_part(buf, 10)
+    assert (back == c).all()
+    assert int(c["order"][0]) == (12 << 48) | (7 << 24) | 3
+    with pytest.raises(OverflowError):
+        D.unpack_part(D.pack_part(c, 2), 2)          # header keeps the true count -> overflow is detected
+
+
+class OracleShardCompute:
+    """stand-in for HipShardCompute built on the oracle (tests only)"""
+
+    def __init__(self, m, v0, v1, cap):
+        self.m, self.v0, self.v1, self.cap = m, v0, v1, cap
+        self.device = torch.device("cpu")
+
+    def stage1(self, queries):
+        from oracle import pipeline as opipe
+        self.queries = queries
+        rows = [D.pack_part(opipe.shard_candidates(self.m, q.desc, q.kpt_xy, (q.width, q.height), self.v0, self.v1),
+                            self.cap) for q in queries]
+        return torch.from_numpy(np.stack(rows))
+
+    def stage2(self, indices, gathered):
+        from oracle import pipeline as opipe
+        g = gathered.numpy()
+        out = {}
+        for i in indices:
+            parts = [D.unpack_part(g[r, i], self.cap) for r in range(g.shape[0])]
+            out[i] = opipe.merge_candidates(parts, self.queries[i].kpt_xy, self.m.intrinsic)
+        return out
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle_c
+        oracle_c.build()
+        m = synth.make_map(31, n_views=24, desc_per_view=220, views_per_place=8, landmarks_per_place=200,
+                           obs_per_view=90, ragged=True)
+        queries = [synth.make_query(m, 700 + k, n_feat=260, n_copies=110, outlier_frac=0.2, place=k % 3) for k in range(3)]
+        v0, v1 = D.shard_views(m.view_off, world)[rank]
+        loc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), cap=2048)
+        res = loc.localize_batch(queries)
+        if rank == 0:
+            q.put({i: {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for i, r in res.items()})
+    except Exception as e:  # surface the failure instead of letting the parent time out
+        import traceback
+        q.put({"error": f"rank {rank}: {e}\n{traceback.format_exc()}"})
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_unsharded():
+    from oracle import pipeline as opipe
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    assert "error" not in res, res.get("error")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = synth.make_map(31, n_views=24, desc_per_view=220, views_per_place=8, landmarks_per_place=200,
+                       obs_per_view=90, ragged=True)
+    n_ok = 0
+    for k in range(3):
+        qq = synth.make_query(m, 700 + k, n_feat=260, n_copies=110, outlier_frac=0.2, place=k % 3)
+        exp = opipe.localize(m, qq.desc, qq.kpt_xy, (qq.width, qq.height))
+        got = res[k]
+        assert got["ok"] == exp["ok"]
+        np.testing.assert_array_equal(got["ms_qfeat"], exp["ms_qfeat"])
+        np.testing.assert_array_equal(got["ms_landmark"], exp["ms_landmark"])
+        if exp["ok"]:
+            n_ok += 1
+            np.testing.assert_array_equal(got["pair_qfeat"], exp["pair_qfeat"])
+            np.testing.assert_array_equal(got["pair_landmark"], exp["pair_landmark"])
+            assert (np.array(got["P"]) == exp["P"]).all() and (np.array(got["center"]) == exp["center"]).all()
+    assert n_ok >= 2

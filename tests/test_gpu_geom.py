@@ -252,3 +252,73 @@ def test_concurrent_contexts_equal_sequential(oracle_c):
             c.close()
         for dq in dqs:
             dq.close()
+
+
+def test_sharded_map_equals_unsharded(oracle_c):
+    """Two shards of one map on one GPU: parts exported by sfmloc_shard_begin/_export, concatenated as the
+    all-gather would, merged by sfmloc_merge_begin -> exactly the unsharded sfmloc_localize result; the exported
+    candidates are the oracle's."""
+    import torch
+    from sfmlocalization_amd import dist as D
+    m = make_scene(26, ragged=True)
+    cap = 4096
+    full = dev_map(m)
+    ranges = D.shard_views(m.view_off, 2)
+    shards = []
+    for v0, v1 in ranges:
+        r0, r1 = int(m.view_off[v0]), int(m.view_off[v1])
+        shards.append(S.Map(m.view_id[v0:v1], m.view_off[v0:v1 + 1] - m.view_off[v0], m.desc[r0:r1],
+                            params=S.default_params(ransac_round=25), view_wh=m.view_wh[v0:v1],
+                            kpt_xy=m.kpt_xy[r0:r1], row_landmark=m.row_landmark[r0:r1], landmark_id=m.landmark_id,
+                            landmark_X=m.landmark_X, intrinsic=m.intrinsic))
+    pb = D.part_bytes(cap)
+    for k in range(4):
+        q = synth.make_query(m, 800 + k, n_feat=600, n_copies=200, outlier_frac=0.3, place=k % 4)
+        fq = full.query(q.desc, q.kpt_xy, q.width, q.height)
+        ref = full.localize(fq)
+        parts = torch.zeros((2, pb), dtype=torch.uint8, device="cuda")
+        qs = []
+        for s, sm in enumerate(shards):
+            sq = sm.query(q.desc, q.kpt_xy, q.width, q.height)
+            qs.append(sq)
+            c = sm.context()
+            c.shard_begin(sq)
+            c.shard_export(parts.data_ptr() + s * pb, cap)
+            c.sync()
+            c.close()
+            v0, v1 = ranges[s]
+            exp_c = opipe.shard_candidates(m, q.desc, q.kpt_xy, (q.width, q.height), v0, v1)
+            got_c = D.unpack_part(parts[s].cpu().numpy(), cap)
+            got_c, exp_c = np.sort(got_c, order="order"), np.sort(exp_c, order="order")   # arrival order is free
+            assert len(got_c) == len(exp_c)
+            for f in ("order", "qfeat", "landmark_id", "X"):
+                np.testing.assert_array_equal(got_c[f], exp_c[f], err_msg=f)
+        c = shards[1].context()                                               # any rank can own the merge
+        c.merge_begin(qs[1], parts.data_ptr(), 2, cap)
+        pose, pq, pl = c.end()
+        c.close()
+        assert pose.ok == ref[0].ok and pose.n_inliers == ref[0].n_inliers
+        np.testing.assert_array_equal(pq, ref[1])
+        np.testing.assert_array_equal(pl, ref[2])
+        np.testing.assert_array_equal(bits(np.array(pose.P)), bits(np.array(ref[0].P)))
+        np.testing.assert_array_equal(bits(np.array(pose.center)), bits(np.array(ref[0].center)))
+        for sq in qs:
+            sq.close()
+        fq.close()
+    # the torch.distributed layer on one rank (world 1) drives the same entry points
+    comp = D.HipShardCompute(full, cap, n_contexts=2)
+    qobjs = [synth.make_query(m, 800 + k, n_feat=600, n_copies=200, outlier_frac=0.3, place=k % 4) for k in range(3)]
+    dqs = [full.query(q.desc, q.kpt_xy, q.width, q.height) for q in qobjs]
+    loc = D.ShardedLocalizer(comp, cap, rank=0, world=1)
+    res = loc.localize_batch(dqs)
+    for i, dq in enumerate(dqs):
+        ref = full.localize(dq)
+        assert res[i]["ok"] == bool(ref[0].ok)
+        np.testing.assert_array_equal(res[i]["pair_qfeat"], ref[1])
+        np.testing.assert_array_equal(bits(res[i]["P"].ravel()), bits(np.array(ref[0].P)))
+    comp.close()
+    for dq in dqs:
+        dq.close()
+    for sm in shards:
+        sm.close()
+    full.close()
