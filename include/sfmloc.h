@@ -266,6 +266,42 @@ int sfmloc_merge_begin(sfmloc_context *ctx, sfmloc_query *q, const void *parts_d
                        uint64_t part_stride);
 /* ... then sfmloc_localize_end(ctx, ...) */
 
+/* ------------------------------------------------------------------------- */
+/* Stage A5: bag-of-words view shortlist.                                        */
+/* sfmloc_bow_select replaces hulo::selectViewByBoF (BoFUtils.cpp:27-68) with the */
+/* exact k-NN its FLANN KD-tree approximates: the k candidate views whose .bow    */
+/* vector (as float32, BoFUtils.cpp:43-45) is nearest in L2 to the query's; ties  */
+/* to the lower view; result ascending (the reference returns a std::set).        */
+/* cand_views: ascending view-table indices or NULL for all; requires k < n_cand  */
+/* (CV_Assert, BoFUtils.cpp:30); callers skip the shortlist when the candidate    */
+/* set is not larger than k (localization.cpp:346).  Synchronises.                */
+/* ------------------------------------------------------------------------- */
+int sfmloc_bow_select(sfmloc_map *map, const float *query_bow, const uint32_t *cand_views, uint32_t n_cand,
+                      uint32_t k, uint32_t *out_sel, uint32_t *n_out);
+
+/* The query's BoW vector from its dense local features: PcaWrapper::calcPcaProject (PcaWrapper.cpp:67-89) +
+ * BoFSpatialPyramids::calcBoF (BoFSpatialPyramids.cpp:108-302) with an exact nearest-centre search.
+ * Model = what BOWfile.yml / PCAfile.yml hold (BoFSpatialPyramids.cpp:57-83, PcaWrapper.cpp:53-65). */
+typedef struct sfmloc_bof_desc {
+  int K;                     /* "K" */
+  int in_dim;                /* dense descriptor length (61 for M-LDB bytes as floats) */
+  const float *centers;      /* "Centers" [K x (n_pca ? n_pca : in_dim)] */
+  int resized_image_size;    /* "ResizedImageSize" (300) */
+  int use_spatial_pyramid;   /* "UseSpatialPyramid" */
+  int pyramid_level;         /* "PyramidLevel" (2) */
+  int norm_type;             /* "NormBofFeatureType": 0 NONE, 1 L2, 2 L1 (square root) */
+  int n_pca;                 /* "DimPCA", 0 = no PCA */
+  const float *pca_mean;     /* "MeanPCA" [in_dim] */
+  const float *pca_eigvec;   /* "EigenVectorsPCA" first n_pca rows [n_pca x in_dim] */
+  const float *pca_eigval;   /* "EigenValuesPCA" first n_pca */
+} sfmloc_bof_desc;
+typedef struct sfmloc_bof sfmloc_bof;
+int sfmloc_bof_create(const sfmloc_bof_desc *desc, int device, sfmloc_bof **out);
+void sfmloc_bof_destroy(sfmloc_bof *bof);
+int sfmloc_bof_dim(const sfmloc_bof *bof); /* K x pyramid cells (500) */
+/* desc [n x in_dim] f32, kpt_xy [n x 2] in the resized image; out_bow [sfmloc_bof_dim] f64.  Synchronises. */
+int sfmloc_bof_compute(sfmloc_bof *bof, const float *desc, const float *kpt_xy, uint32_t n, double *out_bow);
+
 /* Parity probe: runs one of the f64 device building blocks over n items (tests compare with the oracle).
  * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample */
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride);
@@ -280,6 +316,7 @@ enum {
   SFMLOC_K_FMATRIX = 2,
   SFMLOC_K_MATCHSET = 3,
   SFMLOC_K_P3P = 4,
+  SFMLOC_K_BOW = 5,
   SFMLOC_K_COUNT = 8
 };
 typedef struct sfmloc_kernel_stats {

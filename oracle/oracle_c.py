@@ -14,7 +14,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle.c", "sfm_oracle_geom.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle.c", "sfm_oracle_geom.c", "sfm_oracle_bow.c", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs if os.path.exists(f)):
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
     return _SO
@@ -39,6 +39,8 @@ def lib():
         _lib.orc_fmatrix_filter.restype = C.c_int
         _lib.orc_p3p_localize.restype = C.c_int
         _lib.orc_match_set.restype = C.c_int
+        _lib.orc_bow_dist.restype = C.c_float
+        _lib.orc_bof_cells.restype = C.c_int
     return _lib
 
 
@@ -209,3 +211,40 @@ def match_set(geo_view, geo_i, geo_j, view_off, put_count, put_i, put_j, put_d, 
                             _p(pd, C.c_uint32), _p(rl, C.c_int32), C.c_uint32(nq), _p(oq, C.c_uint32),
                             _p(ol, C.c_int32))
     return oq[:n].copy(), ol[:n].copy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# bag of words (sfm_oracle_bow.c)
+# ---------------------------------------------------------------------------------------------------
+def bow_dist(a, b):
+    a = np.ascontiguousarray(a, np.float32).ravel()
+    b = np.ascontiguousarray(b, np.float32).ravel()
+    return float(lib().orc_bow_dist(_p(a, C.c_float), _p(b, C.c_float), C.c_int(a.shape[0])))
+
+
+def bow_select(bow, query, k, cand=None):
+    bow = np.ascontiguousarray(bow, np.float32)
+    query = np.ascontiguousarray(query, np.float32).ravel()
+    cv = None if cand is None else np.ascontiguousarray(cand, np.uint32)
+    n_cand = bow.shape[0] if cv is None else cv.shape[0]
+    out = np.zeros(max(min(k, n_cand), 1), np.uint32)
+    lib().orc_bow_select(_p(bow, C.c_float), C.c_int(bow.shape[1]), C.c_uint32(bow.shape[0]), _p(cv, C.c_uint32),
+                         C.c_uint32(n_cand), _p(query, C.c_float), C.c_uint32(k), _p(out, C.c_uint32))
+    return out[:min(k, n_cand)].copy()
+
+
+def bof(desc, kxy, centers, resized=300, levels=2, norm_type=2, pca_mean=None, pca_eigvec=None, pca_eigval=None, n_pca=0):
+    desc = np.ascontiguousarray(desc, np.float32)
+    kxy = np.ascontiguousarray(kxy, np.float32).reshape(-1, 2)
+    centers = np.ascontiguousarray(centers, np.float32)
+    cells = int(lib().orc_bof_cells(C.c_int(levels)))
+    out = np.zeros(centers.shape[0] * cells, np.float64)
+    pm = pe = pv = None
+    if n_pca:
+        pm = np.ascontiguousarray(pca_mean, np.float32).ravel()
+        pe = np.ascontiguousarray(np.asarray(pca_eigvec, np.float32)[:n_pca])
+        pv = np.ascontiguousarray(np.asarray(pca_eigval, np.float32).ravel()[:n_pca])
+    lib().orc_bof(_p(desc, C.c_float), _p(kxy, C.c_float), C.c_int(desc.shape[0]), C.c_int(desc.shape[1]),
+                  _p(pm, C.c_float), _p(pe, C.c_float), _p(pv, C.c_float), C.c_int(n_pca), _p(centers, C.c_float),
+                  C.c_int(centers.shape[0]), C.c_int(resized), C.c_int(levels), C.c_int(norm_type), _p(out, C.c_double))
+    return out

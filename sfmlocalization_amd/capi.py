@@ -8,7 +8,7 @@ import numpy as np
 from . import _lib
 
 NOMATCH = 0xFFFFFFFF
-K_HAMMING, K_COMPACT, K_FMATRIX, K_MATCHSET, K_P3P, K_COUNT = 0, 1, 2, 3, 4, 8
+K_HAMMING, K_COMPACT, K_FMATRIX, K_MATCHSET, K_P3P, K_BOW, K_COUNT = 0, 1, 2, 3, 4, 5, 8
 
 OK, EINVAL, ENODEV, EHIP, EIO, ECAP, ENOMEM = 0, -1, -2, -3, -4, -5, -6
 
@@ -70,6 +70,13 @@ class Pose(C.Structure):
                 ("center", C.c_double * 3), ("stage_seconds", C.c_double * 7)]
 
 
+class BofDesc(C.Structure):
+    _fields_ = [("K", C.c_int), ("in_dim", C.c_int), ("centers", C.POINTER(C.c_float)),
+                ("resized_image_size", C.c_int), ("use_spatial_pyramid", C.c_int), ("pyramid_level", C.c_int),
+                ("norm_type", C.c_int), ("n_pca", C.c_int), ("pca_mean", C.POINTER(C.c_float)),
+                ("pca_eigvec", C.POINTER(C.c_float)), ("pca_eigval", C.POINTER(C.c_float))]
+
+
 class ScanInfo(C.Structure):
     _fields_ = [("n_views_total", C.c_uint32), ("n_views_posed", C.c_uint32), ("n_rows", C.c_uint64),
                 ("n_landmarks", C.c_uint32), ("n_observations", C.c_uint32), ("bow_dim", C.c_uint32),
@@ -94,7 +101,8 @@ SYMBOLS = [
     "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
     "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
     "sfmloc_localize_batch", "sfmloc_part_bytes", "sfmloc_shard_begin", "sfmloc_shard_export",
-    "sfmloc_context_sync", "sfmloc_merge_begin",
+    "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
+    "sfmloc_bof_dim", "sfmloc_bof_compute",
     "sfmloc_stats_read", "sfmloc_stats_reset",
 ]
 
@@ -147,6 +155,12 @@ def _L():
         L.sfmloc_shard_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.sfmloc_context_sync.argtypes = [C.c_void_p]
         L.sfmloc_merge_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.sfmloc_bow_select.argtypes = [C.c_void_p, C.POINTER(C.c_float), U32P, C.c_uint32, C.c_uint32, U32P, U32P]
+        L.sfmloc_bof_create.argtypes = [C.POINTER(BofDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.sfmloc_bof_destroy.restype = None
+        L.sfmloc_bof_destroy.argtypes = [C.c_void_p]
+        L.sfmloc_bof_dim.argtypes = [C.c_void_p]
+        L.sfmloc_bof_compute.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, F64P]
         L.sfmloc_localize_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32,
                                             C.POINTER(Pose), U32P, U32P, C.c_uint32]
         L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
@@ -386,6 +400,19 @@ class Map:
     def context(self):
         return Context(self)
 
+    def bow_select(self, query_bow, k, cand_views=None):
+        """sfmloc_bow_select (selectViewByBoF): -> ascending view-table indices of the k nearest .bow vectors."""
+        qb = np.ascontiguousarray(query_bow, dtype=np.float32).ravel()
+        out = np.zeros(max(k, 1), np.uint32)
+        n = C.c_uint32()
+        if cand_views is None:
+            cp, nc = None, 0
+        else:
+            cv = np.ascontiguousarray(cand_views, dtype=np.uint32)
+            cp, nc = _ptr(cv, C.c_uint32), cv.shape[0]
+        _check(_L().sfmloc_bow_select(self._h, _ptr(qb, C.c_float), cp, nc, k, _ptr(out, C.c_uint32), C.byref(n)))
+        return out[:n.value].copy()
+
     def localize_batch(self, queries, n_contexts=4, cap=0):
         """sfmloc_localize_batch: queries pipelined over n_contexts streams; -> list of Pose (+ pairs if cap)."""
         n = len(queries)
@@ -406,6 +433,65 @@ class Map:
 
     def stats_reset(self):
         _check(_L().sfmloc_stats_reset(self._h))
+
+
+NORM_TYPES = {"NONE": 0, "L2": 1, "L1": 2}
+
+
+class BofModel:
+    """sfmloc_bof: BOWfile.yml (+ PCAfile.yml) on the GPU; compute() = calcPcaProject + calcBoF."""
+
+    def __init__(self, centers, in_dim, resized=300, use_pyramid=True, pyramid_level=2, norm="L1", pca_mean=None,
+                 pca_eigvec=None, pca_eigval=None, n_pca=0, device=0):
+        self._h = None
+        centers = np.ascontiguousarray(centers, np.float32)
+        d = BofDesc()
+        d.K, d.in_dim = centers.shape[0], int(in_dim)
+        d.centers = _ptr(centers, C.c_float)
+        d.resized_image_size, d.use_spatial_pyramid, d.pyramid_level = int(resized), int(bool(use_pyramid)), int(pyramid_level)
+        d.norm_type = NORM_TYPES[norm] if isinstance(norm, str) else int(norm)
+        keep = [centers]
+        if n_pca:
+            pm = np.ascontiguousarray(pca_mean, np.float32).ravel()
+            pe = np.ascontiguousarray(np.asarray(pca_eigvec, np.float32)[:n_pca])
+            pv = np.ascontiguousarray(np.asarray(pca_eigval, np.float32).ravel()[:n_pca])
+            keep += [pm, pe, pv]
+            d.n_pca, d.pca_mean, d.pca_eigvec, d.pca_eigval = int(n_pca), _ptr(pm, C.c_float), _ptr(pe, C.c_float), _ptr(pv, C.c_float)
+        h = C.c_void_p()
+        _check(_L().sfmloc_bof_create(C.byref(d), device, C.byref(h)))
+        self._h = h
+        self.dim = int(_L().sfmloc_bof_dim(h))
+
+    @classmethod
+    def from_files(cls, bow_file, pca_file=None, in_dim=61, device=0):
+        from . import fileio
+        b = fileio.read_cv_yaml(bow_file)
+        kw = {}
+        if pca_file:
+            p = fileio.read_cv_yaml(pca_file)
+            kw = dict(pca_mean=p["MeanPCA"], pca_eigvec=p["EigenVectorsPCA"], pca_eigval=p["EigenValuesPCA"],
+                      n_pca=int(p["DimPCA"]))
+        return cls(b["Centers"], in_dim, resized=int(b["ResizedImageSize"]), use_pyramid=bool(b["UseSpatialPyramid"]),
+                   pyramid_level=int(b["PyramidLevel"]), norm=b["NormBofFeatureType"], device=device, **kw)
+
+    def compute(self, desc, kpt_xy):
+        desc = np.ascontiguousarray(desc, np.float32)
+        kpt_xy = np.ascontiguousarray(kpt_xy, np.float32).reshape(-1, 2)
+        out = np.zeros(self.dim, np.float64)
+        _check(_L().sfmloc_bof_compute(self._h, _ptr(desc, C.c_float), _ptr(kpt_xy, C.c_float), desc.shape[0],
+                                       _ptr(out, C.c_double)))
+        return out
+
+    def close(self):
+        if self._h is not None:
+            _L().sfmloc_bof_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

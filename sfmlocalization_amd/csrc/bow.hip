@@ -1,0 +1,241 @@
+// K7 / K8: the bag-of-words view shortlist for gfx950.
+//
+//   K8  k_bow_dist + k_bow_topk   selectViewByBoF (BoFUtils.cpp:27-68) made exact: squared L2 between the query's
+//                                 BoW vector and every candidate view's (V x dim f32, resident in HBM), k smallest,
+//                                 ties to the lower view index.  HBM-bound: V*dim*4 bytes per query (20 MB at
+//                                 V = 10 k), one wave per view, coalesced 256-B reads.
+//   K7  k_bof_assign + k_bof_finish  PcaWrapper::calcPcaProject (PcaWrapper.cpp:67-89) + BoFSpatialPyramids::calcBoF
+//                                 (BoFSpatialPyramids.cpp:108-302) on the query's dense descriptors.
+// float32 sums run in the fixed order the oracle documents (64 strided partials + butterfly for K8, sequential
+// for K7) so that ranks and bins can be compared bit for bit.
+#include <math.h>
+
+#include "sfmloc_internal.h"
+
+namespace sfmloc {
+namespace {
+
+__global__ __launch_bounds__(256) void k_bow_dist(const float *__restrict__ bow, uint32_t dim,
+                                                  const uint32_t *__restrict__ cand, uint32_t n_cand,
+                                                  const float *__restrict__ query, uint32_t *__restrict__ dist_bits) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_cand) return;
+  const uint32_t v = cand ? cand[p] : p;
+  const float *row = bow + (size_t)v * dim;
+  float s = 0.0f;
+  for (uint32_t i = lane; i < dim; i += 64) {
+    const float d = row[i] - query[i];
+    const float d2 = d * d;
+    s = s + d2;
+  }
+  for (int stride = 32; stride >= 1; stride >>= 1) s = s + __shfl_xor(s, stride, 64);
+  if (lane == 0) dist_bits[p] = __float_as_uint(s);
+}
+
+// One 1024-thread workgroup: exact k-th smallest distance by a 3-pass radix select on the float bits
+// (11+11+10), then an order-preserving compaction of {dist < T} plus the first (k - #less) of {dist == T}.
+__global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ dist_bits, uint32_t n,
+                                                   const uint32_t *__restrict__ cand, uint32_t k,
+                                                   uint32_t *__restrict__ out_sel) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t scan[1024];
+  __shared__ uint32_t sh_prefix, sh_rank, sh_less;
+  const uint32_t tid = threadIdx.x;
+  if (k > n) k = n;
+  if (k == 0) return;
+  uint32_t prefix = 0, rank = k;  // the k-th smallest (1-based) within the elements matching `prefix`
+  const int shifts[3] = {21, 10, 0};
+  const uint32_t widths[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    const uint32_t bins = 1u << widths[pass];
+    for (uint32_t b = tid; b < bins; b += 1024) hist[b] = 0;
+    __syncthreads();
+    const uint32_t hi_shift = shifts[pass] + widths[pass];
+    for (uint32_t i = tid; i < n; i += 1024) {
+      const uint32_t x = dist_bits[i];
+      const bool match = (pass == 0) || ((x >> hi_shift) == (prefix >> hi_shift));
+      if (match) atomicAdd(&hist[(x >> shifts[pass]) & (bins - 1)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0, b = 0;
+      for (; b < bins; ++b) {
+        if (acc + hist[b] >= rank) break;
+        acc += hist[b];
+      }
+      sh_prefix = prefix | (b << shifts[pass]);
+      sh_rank = rank - acc;
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    rank = sh_rank;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;  // bit pattern of the k-th smallest distance; `rank` of the equal ones are taken
+  // contiguous chunk per thread keeps index order
+  const uint32_t chunk = (n + 1023) / 1024;
+  const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+  uint32_t c_eq = 0;
+  for (uint32_t i = lo; i < hi; ++i) c_eq += (dist_bits[i] == T);
+  scan[tid] = c_eq;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < 1024; ++t) {
+      const uint32_t v = scan[t];
+      scan[t] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  uint32_t eq_before = scan[tid];
+  __syncthreads();
+  uint32_t c_sel = 0;
+  {
+    uint32_t e = eq_before;
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t x = dist_bits[i];
+      if (x < T) ++c_sel;
+      else if (x == T) {
+        if (e < rank) ++c_sel;
+        ++e;
+      }
+    }
+  }
+  scan[tid] = c_sel;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < 1024; ++t) {
+      const uint32_t v = scan[t];
+      scan[t] = acc;
+      acc += v;
+    }
+    sh_less = acc;
+  }
+  __syncthreads();
+  uint32_t pos = scan[tid];
+  uint32_t e = eq_before;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t x = dist_bits[i];
+    bool take = x < T;
+    if (x == T) {
+      take = e < rank;
+      ++e;
+    }
+    if (take) out_sel[pos++] = cand ? cand[i] : i;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bof_assign(const float *__restrict__ desc, const float *__restrict__ kxy,
+                                                    int n, int in_dim, const float *__restrict__ pca_mean,
+                                                    const float *__restrict__ pca_evec,
+                                                    const float *__restrict__ pca_eval, int n_pca,
+                                                    const float *__restrict__ centers, int K, int resized, int levels,
+                                                    uint32_t *__restrict__ counts) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const float *x = desc + (size_t)r * in_dim;
+  const int cdim = n_pca > 0 ? n_pca : in_dim;
+  float y[128];
+  if (n_pca > 0) {
+    for (int d = 0; d < n_pca; ++d) {
+      float acc = 0.0f;
+      for (int i = 0; i < in_dim; ++i) {
+        const float c = x[i] - pca_mean[i];
+        const float pr = c * pca_evec[(size_t)d * in_dim + i];
+        acc = acc + pr;
+      }
+      y[d] = acc / pca_eval[d];
+    }
+  } else {
+    for (int i = 0; i < in_dim; ++i) y[i] = x[i];
+  }
+  int best = 0;
+  float bestd = INFINITY;
+  for (int c = 0; c < K; ++c) {
+    float s = 0.0f;
+    for (int i = 0; i < cdim; ++i) {
+      const float d = y[i] - centers[(size_t)c * cdim + i];
+      const float d2 = d * d;
+      s = s + d2;
+    }
+    if (s < bestd) {
+      bestd = s;
+      best = c;
+    }
+  }
+  const float px = kxy[2 * r], py = kxy[2 * r + 1];
+  int cell0 = 0;
+  for (int level = 0; level < levels; ++level) {
+    const int len = level + 1;
+    const int edge = resized / len;
+    if (level == 2) {
+      for (int cy = 0; cy < len; ++cy)
+        if (px >= 0 && px < (float)resized && py >= (float)(edge * cy) && py < (float)(edge * (cy + 1)))
+          atomicAdd(&counts[(size_t)K * (cell0 + cy) + best], 1u);
+      cell0 += 3;
+    } else {
+      for (int cx = 0; cx < len; ++cx)
+        for (int cy = 0; cy < len; ++cy)
+          if (px >= (float)(edge * cx) && px < (float)(edge * (cx + 1)) && py >= (float)(edge * cy) &&
+              py < (float)(edge * (cy + 1)))
+            atomicAdd(&counts[(size_t)K * (cell0 + cy * len + cx) + best], 1u);
+      cell0 += len * len;
+    }
+  }
+}
+
+// one thread per pyramid cell: counts -> /n -> per-cell normalisation, sequential in the reference's order
+__global__ void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, int cells, int norm_type,
+                             double *__restrict__ out, float *__restrict__ out_f32) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cells) return;
+  double *h = out + (size_t)K * c;
+  for (int i = 0; i < K; ++i) h[i] = (double)counts[(size_t)K * c + i] / (double)n;
+  if (norm_type == 2) {
+    double norm = 0.0;
+    for (int i = 0; i < K; ++i) norm += h[i];
+    if (norm > 0.0)
+      for (int i = 0; i < K; ++i) h[i] = sqrt(h[i] / norm);
+  } else if (norm_type == 1) {
+    double norm = 0.0;
+    for (int i = 0; i < K; ++i) norm += h[i] * h[i];
+    norm = sqrt(norm);
+    if (norm > 0.0)
+      for (int i = 0; i < K; ++i) h[i] = h[i] / norm;
+  }
+  if (out_f32)
+    for (int i = 0; i < K; ++i) out_f32[(size_t)K * c + i] = (float)h[i];  // BoFUtils.cpp:51-54 converts to CV_32F
+}
+
+}  // namespace
+
+int launch_bow_select(Map *m, hipStream_t s, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
+                      uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel) {
+  if (n_cand == 0 || k == 0) return SFMLOC_OK;
+  hipLaunchKernelGGL(k_bow_dist, dim3((n_cand + 3) / 4), dim3(256), 0, s, m->d_bow, m->bow_dim, d_cand, n_cand,
+                     d_query, d_dist_bits);
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, s, d_dist_bits, n_cand, d_cand, k, d_out_sel);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const float *d_kxy, int n, uint32_t *d_counts,
+               double *d_out, float *d_out_f32) {
+  const int cells = b->cells;
+  SFM_HIP(hipMemsetAsync(d_counts, 0, (size_t)b->K * cells * sizeof(uint32_t), s));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_bof_assign, dim3((n + 255) / 256), dim3(256), 0, s, d_desc, d_kxy, n, b->in_dim, b->d_pca_mean,
+                       b->d_pca_evec, b->d_pca_eval, b->n_pca, b->d_centers, b->K, b->resized, b->levels, d_counts);
+    SFM_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_bof_finish, dim3(1), dim3(64), 0, s, d_counts, n > 0 ? n : 1, b->K, cells, b->norm_type, d_out,
+                     d_out_f32);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+}  // namespace sfmloc

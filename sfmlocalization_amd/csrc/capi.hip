@@ -129,7 +129,8 @@ void free_ctx(Ctx *c) {
                   c->d_best64,    c->d_winner,    c->d_ms_n,       c->d_ms_qfeat,   c->d_ms_landmark, c->d_pt2d,
                   c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
                   c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,    c->d_pair_qfeat,
-                  c->d_pair_landmark, c->d_inlier_idx, c->d_p3p_state, c->d_pose,   c->d_view_stats};
+                  c->d_pair_landmark, c->d_inlier_idx, c->d_p3p_state, c->d_pose,   c->d_view_stats,
+                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel};
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -199,6 +200,12 @@ int make_ctx(Map *m, Ctx **out) {
   CTX_TRY(dev_alloc(acct, &c->d_p3p_state, (size_t)1));
   CTX_TRY(dev_alloc(acct, &c->d_pose, (size_t)1));
   CTX_TRY(dev_alloc(acct, &c->d_view_stats, (size_t)2));
+  if (m->bow_dim) {
+    CTX_TRY(dev_alloc(acct, &c->d_bow_query, (size_t)m->bow_dim));
+    CTX_TRY(dev_alloc(acct, &c->d_bow_dist, (size_t)m->n_views));
+    CTX_TRY(dev_alloc(acct, &c->d_bow_cand, (size_t)m->n_views));
+    CTX_TRY(dev_alloc(acct, &c->d_bow_sel, (size_t)m->n_views));
+  }
   CTX_HIP(hipHostMalloc((void **)&c->h_pinned, ((size_t)2 * m->n_views + m->n_blocks + 16) * sizeof(uint32_t),
                         hipHostMallocDefault));
   CTX_HIP(hipHostMalloc(&c->h_result, sizeof(HostResult), hipHostMallocDefault));
@@ -1033,6 +1040,128 @@ int sfmloc_localize_batch(sfmloc_map *map, sfmloc_query *const *queries, uint32_
   }
   for (uint32_t k = (n >= n_contexts ? n - n_contexts : 0); k < n; ++k) finish(k);
   return first_err;
+}
+
+// ----- BoW shortlist ---------------------------------------------------------------------------------------
+
+int sfmloc_bow_select(sfmloc_map *map, const float *query_bow, const uint32_t *cand_views, uint32_t n_cand,
+                      uint32_t k, uint32_t *out_sel, uint32_t *n_out) {
+  SFM_CHECK(map && query_bow && out_sel && n_out, SFMLOC_EINVAL, "sfmloc_bow_select: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  Ctx *c = m->ctx0;
+  SFM_CHECK(m->bow_dim > 0 && m->d_bow, SFMLOC_EINVAL, "sfmloc_bow_select: the map has no .bow vectors");
+  if (!cand_views) n_cand = m->n_views;
+  SFM_CHECK(n_cand <= m->n_views, SFMLOC_EINVAL, "sfmloc_bow_select: n_cand > n_views");
+  // CV_Assert(knn < viewList.size()) (BoFUtils.cpp:30)
+  SFM_CHECK(k < n_cand, SFMLOC_EINVAL, "sfmloc_bow_select: knn %u must be smaller than the %u candidate views", k,
+            n_cand);
+  SFM_HIP(hipSetDevice(m->device));
+  if (cand_views) {
+    for (uint32_t i = 0; i < n_cand; ++i) {
+      SFM_CHECK(cand_views[i] < m->n_views, SFMLOC_EINVAL, "sfmloc_bow_select: view index out of range");
+      SFM_CHECK(i == 0 || cand_views[i - 1] < cand_views[i], SFMLOC_EINVAL,
+                "sfmloc_bow_select: candidate views must be strictly ascending");
+    }
+    SFM_HIP(hipMemcpyAsync(c->d_bow_cand, cand_views, n_cand * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  }
+  SFM_HIP(hipMemcpyAsync(c->d_bow_query, query_bow, m->bow_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  int rc;
+  {
+    EventScope ev(c, SFMLOC_K_BOW);
+    rc = launch_bow_select(m, c->stream, c->d_bow_query, cand_views ? c->d_bow_cand : nullptr, n_cand, k,
+                           c->d_bow_dist, c->d_bow_sel);
+  }
+  if (rc) return rc;
+  SFM_HIP(hipMemcpyAsync(out_sel, c->d_bow_sel, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  SFM_HIP(hipStreamSynchronize(c->stream));
+  *n_out = k;
+  return SFMLOC_OK;
+}
+
+int sfmloc_bof_create(const sfmloc_bof_desc *d, int device, sfmloc_bof **out) {
+  SFM_CHECK(d && out, SFMLOC_EINVAL, "sfmloc_bof_create: null argument");
+  *out = nullptr;
+  SFM_CHECK(d->K > 0 && d->centers && d->in_dim > 0 && d->in_dim <= 128, SFMLOC_EINVAL,
+            "sfmloc_bof_create: bad model (K %d, in_dim %d)", d->K, d->in_dim);
+  SFM_CHECK(d->pyramid_level >= 1 && d->pyramid_level <= 3, SFMLOC_EINVAL, "PYRAMID_LEVEL must be 1..3");
+  SFM_CHECK(d->n_pca == 0 || (d->pca_mean && d->pca_eigvec && d->pca_eigval && d->n_pca <= 128), SFMLOC_EINVAL,
+            "sfmloc_bof_create: PCA arrays missing");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  SFM_CHECK(e == hipSuccess && ndev > 0, SFMLOC_ENODEV, "no HIP device visible; this library has no CPU fallback");
+  SFM_HIP(hipSetDevice(device));
+  BofModel *b = new (std::nothrow) BofModel();
+  SFM_CHECK(b, SFMLOC_ENOMEM, "out of host memory");
+  b->device = device;
+  b->K = d->K;
+  b->in_dim = d->in_dim;
+  b->n_pca = d->n_pca;
+  b->cdim = d->n_pca > 0 ? d->n_pca : d->in_dim;
+  b->resized = d->resized_image_size;
+  b->levels = d->use_spatial_pyramid ? d->pyramid_level : 1;
+  b->norm_type = d->norm_type;
+  b->cells = 0;
+  for (int l = 0; l < b->levels; ++l) b->cells += (l == 0) ? 1 : (l == 2 ? 3 : (l + 1) * (l + 1));
+  uint64_t acct = 0;
+  int rc = SFMLOC_OK;
+  hipError_t se = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) rc = SFMLOC_EHIP;
+  if (!rc) rc = dev_upload(&acct, &b->d_centers, d->centers, (size_t)d->K * b->cdim, b->stream);
+  if (!rc && d->n_pca > 0) {
+    rc = dev_upload(&acct, &b->d_pca_mean, d->pca_mean, (size_t)d->in_dim, b->stream);
+    if (!rc) rc = dev_upload(&acct, &b->d_pca_evec, d->pca_eigvec, (size_t)d->n_pca * d->in_dim, b->stream);
+    if (!rc) rc = dev_upload(&acct, &b->d_pca_eval, d->pca_eigval, (size_t)d->n_pca, b->stream);
+  }
+  if (!rc) rc = dev_alloc(&acct, &b->d_counts, (size_t)b->K * b->cells);
+  if (!rc) rc = dev_alloc(&acct, &b->d_out, (size_t)b->K * b->cells);
+  if (!rc && hipStreamSynchronize(b->stream) != hipSuccess) rc = SFMLOC_EHIP;
+  if (rc) {
+    sfmloc_bof_destroy(reinterpret_cast<sfmloc_bof *>(b));
+    return rc;
+  }
+  *out = reinterpret_cast<sfmloc_bof *>(b);
+  return SFMLOC_OK;
+}
+
+void sfmloc_bof_destroy(sfmloc_bof *bof) {
+  BofModel *b = reinterpret_cast<BofModel *>(bof);
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->stream) hipStreamSynchronize(b->stream);
+  void *ptrs[] = {b->d_centers, b->d_pca_mean, b->d_pca_evec, b->d_pca_eval, b->d_counts, b->d_out, b->d_desc, b->d_kxy};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int sfmloc_bof_dim(const sfmloc_bof *bof) {
+  const BofModel *b = reinterpret_cast<const BofModel *>(bof);
+  return b ? b->K * b->cells : 0;
+}
+
+int sfmloc_bof_compute(sfmloc_bof *bof, const float *desc, const float *kpt_xy, uint32_t n, double *out_bow) {
+  SFM_CHECK(bof && out_bow && (n == 0 || (desc && kpt_xy)), SFMLOC_EINVAL, "sfmloc_bof_compute: null argument");
+  BofModel *b = reinterpret_cast<BofModel *>(bof);
+  SFM_HIP(hipSetDevice(b->device));
+  if ((int)n > b->cap_n) {
+    if (b->d_desc) hipFree(b->d_desc);
+    if (b->d_kxy) hipFree(b->d_kxy);
+    b->d_desc = nullptr;
+    b->d_kxy = nullptr;
+    SFM_HIP(hipMalloc((void **)&b->d_desc, (size_t)n * b->in_dim * sizeof(float)));
+    SFM_HIP(hipMalloc((void **)&b->d_kxy, (size_t)n * 2 * sizeof(float)));
+    b->cap_n = (int)n;
+  }
+  if (n) {
+    SFM_HIP(hipMemcpyAsync(b->d_desc, desc, (size_t)n * b->in_dim * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    SFM_HIP(hipMemcpyAsync(b->d_kxy, kpt_xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  }
+  int rc = launch_bof(b, b->stream, b->d_desc, b->d_kxy, (int)n, b->d_counts, b->d_out, nullptr);
+  if (rc) return rc;
+  SFM_HIP(hipMemcpyAsync(out_bow, b->d_out, (size_t)b->K * b->cells * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  SFM_HIP(hipStreamSynchronize(b->stream));
+  return SFMLOC_OK;
 }
 
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride) {

@@ -162,6 +162,10 @@ struct Ctx {
   P3pState *d_p3p_state = nullptr;
   Pose *d_pose = nullptr;
   uint32_t *d_view_stats = nullptr;  // [2] views with >= min_putative matches, views passing the F filter
+  float *d_bow_query = nullptr;      // [bow_dim]
+  uint32_t *d_bow_dist = nullptr;    // [n_views]
+  uint32_t *d_bow_cand = nullptr;    // [n_views]
+  uint32_t *d_bow_sel = nullptr;     // [n_views]
   void *h_result = nullptr;  // pinned: what a finished query copies back in one go (capi.hip HostResult)
   hipEvent_t pinned_busy = nullptr;  // recorded after the last upload out of h_pinned
 
@@ -197,6 +201,23 @@ int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use
 int launch_merge_ratio_compact(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, uint32_t split,
                                uint32_t n_work_blocks);
 
+
+// bow.hip
+struct BofModel {
+  int device = 0;
+  int K = 0, cdim = 0, in_dim = 0, n_pca = 0, resized = 300, levels = 2, norm_type = 2, cells = 5;
+  float *d_centers = nullptr, *d_pca_mean = nullptr, *d_pca_evec = nullptr, *d_pca_eval = nullptr;
+  // workspace of one call
+  uint32_t *d_counts = nullptr;
+  double *d_out = nullptr;
+  float *d_desc = nullptr, *d_kxy = nullptr;
+  int cap_n = 0;
+  hipStream_t stream = nullptr;
+};
+int launch_bow_select(Map *m, hipStream_t s, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
+                      uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel);
+int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const float *d_kxy, int n, uint32_t *d_counts,
+               double *d_out, float *d_out_f32);
 
 // acransac.hip
 int launch_fill_log10(double *d_L10, int n, hipStream_t s);

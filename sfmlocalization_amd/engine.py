@@ -63,14 +63,21 @@ class LocalizeEngine:
         return np.nonzero(d2 <= radius)[0].astype(np.uint32)
 
     def localize(self, desc, kpt_xy, width, height, return_keypoints=False, return_time=False, center=None,
-                 radius=-1.0):
-        """-> result (list of 12 doubles or []), extras dict.  LocalizeEngine.cc:288-661 from `endFeat` on."""
+                 radius=-1.0, bow=None):
+        """-> result (list of 12 doubles or []), extras dict.  LocalizeEngine.cc:288-661 from `endFeat` on.
+        bow: the query's BoW vector (calcBoF output, 500 doubles); with bow_knn_num > 0 it shortlists the views
+        (LocalizeEngine.cc:333-361) -- only when more views than knn remain."""
         t0 = time.perf_counter()
         view_sel = None
         if center is not None and len(center) == 3 and radius > 0:
             view_sel = self.local_views(center, radius)
             if len(view_sel) == 0:
                 return [], {}
+        knn = int(self.params.bow_knn)
+        if bow is not None and knn > 0:
+            n_cand = self.map.n_views if view_sel is None else len(view_sel)
+            if n_cand > knn:                         # localization.cpp:346 / LocalizeEngine.cc:342
+                view_sel = self.map.bow_select(np.asarray(bow, np.float64).astype(np.float32), knn, view_sel)
         q = self.map.query(desc, kpt_xy, width, height)
         try:
             pose, pq, pl = self.map.localize(q, view_sel)
@@ -186,7 +193,14 @@ def main(argv=None):
             continue
         w, h = _image_size(img, default_wh)
         center = (o["cenLocX"], o["cenLocY"], o["cenLocZ"]) if o["cenRadius"] > 0 else None
-        res, ex = eng.localize(desc, feat[:, :2], w, h, center=center, radius=o["cenRadius"])
+        bow = None
+        if o["knnbow"] > 0 and o["bowModelFile"]:
+            # the query's BoW vector: <base>.bow next to its features (what TrainBoW's calcBoF writes per view,
+            # TrainBoW.cpp:256-271) until dense AKAZE extraction runs on the GPU
+            bpath = os.path.join(fdir, base + ".bow")
+            if os.path.exists(bpath):
+                bow = fileio.read_mat_bin(bpath).ravel()
+        res, ex = eng.localize(desc, feat[:, :2], w, h, center=center, radius=o["cenRadius"], bow=bow)
         if not res:
             print("Fail to estimate camera matrix" if ex else "Not enough putative matches")
             fileio.write_result_json(out_dir, img, sfm_json, match_dir)

@@ -142,3 +142,30 @@ def test_engine_mirror_return_convention(toy):
     assert none == []                                                        # LocalizeEngine.cc:453,481,579
     e0.close()
     e1.close()
+
+
+def test_bow_shortlist_in_engine(tmp_path_factory):
+    """-k / bowKnnNum: views are shortlisted by their .bow vectors before matching (localization.cpp:346-368)."""
+    root = tmp_path_factory.mktemp("bowmap")
+    m = synth.make_map(3, n_views=60, desc_per_view=300, views_per_place=10, landmarks_per_place=250, obs_per_view=110)
+    rng = np.random.Generator(np.random.PCG64(8))
+    proto = np.sqrt(rng.random((6, 500)))                      # one BoW prototype per place
+    bow = np.clip(proto[m.view_place] + rng.normal(0, 0.02, (60, 500)), 0, None)
+    synth.write_map_to_disk(m, str(root / "sfm"), str(root / "matches"), with_bow=bow)
+    q = synth.make_query(m, 77, n_feat=450, n_copies=160, outlier_frac=0.2, place=2)
+    kp = synth.round6(q.kpt_xy)
+    e_all = engine.LocalizeEngine(str(root / "sfm"), str(root / "matches"), None, 0.6, 25, 4.0, False, 0, 0)
+    e_bow = engine.LocalizeEngine(str(root / "sfm"), str(root / "matches"), None, 0.6, 25, 4.0, False, 0, 10)
+    r_all, x_all = e_all.localize(q.desc, kp, 640, 480)
+    qbow = proto[2] + rng.normal(0, 0.02, 500)
+    sel = e_bow.map.bow_select(qbow.astype(np.float32), 10)
+    assert set(sel) == set(np.nonzero(m.view_place == 2)[0])   # the 10 views of the query's place
+    r_bow, x_bow = e_bow.localize(q.desc, kp, 640, 480, bow=qbow)
+    assert len(r_all) == 12 and len(r_bow) == 12
+    # every surviving view was in the shortlist anyway -> identical answer, an order of magnitude less matching
+    assert r_all == r_bow and x_all["pairs"] == x_bow["pairs"]
+    assert x_bow["pose"].n_putative_views == x_all["pose"].n_putative_views
+    r_none, _ = e_bow.localize(q.desc, kp, 640, 480, bow=proto[5])        # wrong place shortlisted -> fails
+    assert r_none == []
+    e_all.close()
+    e_bow.close()
