@@ -40,6 +40,7 @@ def lib():
         _lib.orc_p3p_localize.restype = C.c_int
         _lib.orc_match_set.restype = C.c_int
         _lib.orc_bow_dist.restype = C.c_float
+        _lib.orc_refine_pose.restype = C.c_double
         _lib.orc_bof_cells.restype = C.c_int
     return _lib
 
@@ -248,3 +249,20 @@ def bof(desc, kxy, centers, resized=300, levels=2, norm_type=2, pca_mean=None, p
                   _p(pm, C.c_float), _p(pe, C.c_float), _p(pv, C.c_float), C.c_int(n_pca), _p(centers, C.c_float),
                   C.c_int(centers.shape[0]), C.c_int(resized), C.c_int(levels), C.c_int(norm_type), _p(out, C.c_double))
     return out
+
+
+def refine_pose(pt2d, pt3d, inliers, focal, ppx, ppy, R, t, max_iter=20):
+    """A13 extension: LM refinement on the inliers; -> dict(R, t, center, cost0, cost, iters)."""
+    pt2d = np.ascontiguousarray(pt2d, np.float64).reshape(-1, 2)
+    pt3d = np.ascontiguousarray(pt3d, np.float64).reshape(-1, 3)
+    inl = np.ascontiguousarray(inliers, np.int32)
+    R = np.ascontiguousarray(R, np.float64).reshape(9).copy()
+    t = np.ascontiguousarray(t, np.float64).reshape(3).copy()
+    it = C.c_int()
+    c0 = C.c_double()
+    cost = lib().orc_refine_pose(_p(pt2d, C.c_double), _p(pt3d, C.c_double), _p(inl, C.c_int32), C.c_int(len(inl)),
+                                 C.c_double(focal), C.c_double(ppx), C.c_double(ppy), _p(R, C.c_double),
+                                 _p(t, C.c_double), C.c_int(max_iter), C.byref(it), C.byref(c0))
+    c = np.zeros(3)
+    lib().orc_center_from_rt(_p(R, C.c_double), _p(t, C.c_double), _p(c, C.c_double))
+    return {"R": R.reshape(3, 3), "t": t, "center": c, "cost0": c0.value, "cost": float(cost), "iters": it.value}

@@ -976,3 +976,135 @@ int orc_match_set(const uint32_t *geo_view, const uint32_t *geo_i, const uint32_
   free(best_d);
   return n;
 }
+
+/*
+ * A13 (north-star extension; NOT in the reference, whose localiser never calls RefinePose -- SURVEY.md F4):
+ * Levenberg-Marquardt refinement of [R|t] on the inliers, intrinsics fixed, squared reprojection error, left
+ * rotation increment Exp(w) R.  Same algorithm and schedule as the HIP kernel (acransac.hip refine_pose_block);
+ * parity unpinned by definition, compared to the kernel within a tolerance (the kernel accumulates the normal
+ * equations with fused multiply-adds on the matrix cores).  Returns the final cost.
+ */
+static void normal_equations(const double *pt2d, const double *pt3d, const int32_t *inl, int n, double f, double ppx,
+                             double ppy, const double *R, const double *t, double H[7][7]) {
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) H[i][j] = 0.0;
+  for (int row = 0; row < 2 * n; ++row) {
+    const int p = inl[row >> 1];
+    const double X = pt3d[3 * p], Y = pt3d[3 * p + 1], Z = pt3d[3 * p + 2];
+    const double rx = (R[0] * X + R[1] * Y) + R[2] * Z;
+    const double ry = (R[3] * X + R[4] * Y) + R[5] * Z;
+    const double rz = (R[6] * X + R[7] * Y) + R[8] * Z;
+    const double xc = rx + t[0], yc = ry + t[1], zc = rz + t[2];
+    const double iz = 1.0 / zc;
+    double g0, g1, g2, res;
+    if ((row & 1) == 0) {
+      g0 = f * iz;
+      g1 = 0.0;
+      g2 = -f * xc * iz * iz;
+      res = (f * xc * iz + ppx) - pt2d[2 * p];
+    } else {
+      g0 = 0.0;
+      g1 = f * iz;
+      g2 = -f * yc * iz * iz;
+      res = (f * yc * iz + ppy) - pt2d[2 * p + 1];
+    }
+    const double m[7] = {ry * g2 - rz * g1, rz * g0 - rx * g2, rx * g1 - ry * g0, g0, g1, g2, res};
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) H[i][j] += m[i] * m[j];
+  }
+}
+
+static void rotate_left(const double *w, const double *R, double *out) {
+  const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+  const double th = sqrt(th2);
+  double a, b;
+  if (th < 1e-8) {
+    a = 1.0 - th2 / 6.0;
+    b = 0.5 - th2 / 24.0;
+  } else {
+    a = sin(th) / th;
+    b = (1.0 - cos(th)) / th2;
+  }
+  const double W[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
+  double W2[9], E[9];
+  matmul3(W, W, W2);
+  for (int i = 0; i < 9; ++i) E[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * W[i] + b * W2[i];
+  matmul3(E, R, out);
+}
+
+double orc_refine_pose(const double *pt2d, const double *pt3d, const int32_t *inl, int n, double f, double ppx,
+                       double ppy, double *R, double *t, int max_iter, int *iters_out, double *cost0_out) {
+  double S[7][7];
+  normal_equations(pt2d, pt3d, inl, n, f, ppx, ppy, R, t, S);
+  double H[6][6], g[6], cost = S[6][6];
+  if (cost0_out) *cost0_out = cost;
+  for (int i = 0; i < 6; ++i) {
+    g[i] = S[i][6];
+    for (int j = 0; j < 6; ++j) H[i][j] = S[i][j];
+  }
+  double lambda = 1e-4;
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    double A[6][7];
+    for (int i = 0; i < 6; ++i) {
+      for (int j = 0; j < 6; ++j) A[i][j] = H[i][j];
+      A[i][i] = H[i][i] * (1.0 + lambda);
+      A[i][6] = -g[i];
+    }
+    int singular = 0;
+    for (int c = 0; c < 6; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < 6; ++r)
+        if (dabs(A[r][c]) > dabs(A[piv][c])) piv = r;
+      if (!(dabs(A[piv][c]) > 0.0)) {
+        singular = 1;
+        break;
+      }
+      if (piv != c)
+        for (int j = c; j < 7; ++j) {
+          const double tt = A[c][j];
+          A[c][j] = A[piv][j];
+          A[piv][j] = tt;
+        }
+      for (int r = c + 1; r < 6; ++r) {
+        const double fct = A[r][c] / A[c][c];
+        for (int j = c; j < 7; ++j) A[r][j] = A[r][j] - fct * A[c][j];
+      }
+    }
+    if (singular) break;
+    double d[6];
+    for (int i = 5; i >= 0; --i) {
+      double acc = A[i][6];
+      for (int j = i + 1; j < 6; ++j) acc = acc - A[i][j] * d[j];
+      d[i] = acc / A[i][i];
+    }
+    double Rn[9], tn[3];
+    rotate_left(d, R, Rn);
+    tn[0] = t[0] + d[3];
+    tn[1] = t[1] + d[4];
+    tn[2] = t[2] + d[5];
+    normal_equations(pt2d, pt3d, inl, n, f, ppx, ppy, Rn, tn, S);
+    const double c_new = S[6][6];
+    if (c_new < cost) {
+      const double rel = (cost - c_new) / cost;
+      memcpy(R, Rn, sizeof(Rn));
+      memcpy(t, tn, sizeof(tn));
+      cost = c_new;
+      for (int i = 0; i < 6; ++i) {
+        g[i] = S[i][6];
+        for (int j = 0; j < 6; ++j) H[i][j] = S[i][j];
+      }
+      lambda = lambda * 0.1;
+      if (lambda < 1e-12) lambda = 1e-12;
+      if (rel < 1e-10) {
+        ++it;
+        break;
+      }
+    } else {
+      lambda = lambda * 10.0;
+      if (lambda > 1e10) break;
+    }
+  }
+  if (iters_out) *iters_out = it;
+  return cost;
+}

@@ -576,6 +576,175 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K6 (north-star extension A13; absent from the reference, which never calls RefinePose): non-linear refinement
+// of [R|t] on the inliers, intrinsics fixed -- Levenberg-Marquardt on the squared reprojection error with a left
+// rotation increment.  The normal equations [J r]^T [J r] (7x7: J^T J, J^T r, r^T r) are accumulated on the
+// matrix cores: v_mfma_f64_16x16x4_f64 takes four rows of M = [J | r] (padded to 16 columns) per instruction,
+// and because A[i][k] = M[4s+k][i] and B[k][j] = M[4s+k][j] sit in the same lane (i = j = lane & 15, k = lane >> 4)
+// one f64 per lane feeds both operands.  Executed by the whole workgroup (barriers), arithmetic by wave 0.
+// ---------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct RefineShared {
+  double H[7][8];
+  double delta[6];
+};
+
+__device__ void normal_equations_wave0(const double *pt2d, const double *pt3d, const int32_t *inl, int n, double f,
+                                       double ppx, double ppy, const double *Rm, const double *tv,
+                                       RefineShared &S) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const int k = tid >> 4, col = tid & 15;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int rows = 2 * n;
+    for (int s4 = 0; s4 < rows; s4 += 4) {
+      const int row = s4 + k;
+      double m = 0.0;
+      if (row < rows && col < 7) {
+        const int p = inl[row >> 1];
+        const double X = pt3d[3 * p], Y = pt3d[3 * p + 1], Z = pt3d[3 * p + 2];
+        const double rx = (Rm[0] * X + Rm[1] * Y) + Rm[2] * Z;  // R X
+        const double ry = (Rm[3] * X + Rm[4] * Y) + Rm[5] * Z;
+        const double rz = (Rm[6] * X + Rm[7] * Y) + Rm[8] * Z;
+        const double xc = rx + tv[0], yc = ry + tv[1], zc = rz + tv[2];
+        const double iz = 1.0 / zc;
+        // d(u or v)/d(Xc)
+        double g0, g1, g2, res;
+        if ((row & 1) == 0) {
+          g0 = f * iz;
+          g1 = 0.0;
+          g2 = -f * xc * iz * iz;
+          res = (f * xc * iz + ppx) - pt2d[2 * p];
+        } else {
+          g0 = 0.0;
+          g1 = f * iz;
+          g2 = -f * yc * iz * iz;
+          res = (f * yc * iz + ppy) - pt2d[2 * p + 1];
+        }
+        // d(Exp(w) R X)/dw = -[R X]_x  ->  g^T (-[RX]_x) = ( RX x g )
+        switch (col) {
+          case 0: m = ry * g2 - rz * g1; break;
+          case 1: m = rz * g0 - rx * g2; break;
+          case 2: m = rx * g1 - ry * g0; break;
+          case 3: m = g0; break;
+          case 4: m = g1; break;
+          case 5: m = g2; break;
+          default: m = res; break;
+        }
+      }
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m, m, acc, 0, 0, 0);
+    }
+    // D[row = (lane>>4) + 4*reg][col = lane&15]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int drow = k + 4 * r;
+      if (drow < 7 && col < 7) S.H[drow][col] = acc[r];
+    }
+  }
+  __syncthreads();
+}
+
+// Exp(w) * R by Rodrigues' formula
+__device__ void rotate_left(const double *w, const double *Rm, double *out) {
+  const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+  const double th = sqrt(th2);
+  double a, b;  // Exp(w) = I + a [w]x + b [w]x^2
+  if (th < 1e-8) {
+    a = 1.0 - th2 / 6.0;
+    b = 0.5 - th2 / 24.0;
+  } else {
+    a = sin(th) / th;
+    b = (1.0 - cos(th)) / th2;
+  }
+  const double W[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
+  double W2[9], E[9];
+  matmul3(W, W, W2);
+  for (int i = 0; i < 9; ++i) E[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * W[i] + b * W2[i];
+  matmul3(E, Rm, out);
+}
+
+// returns the final cost; Rm/tv are updated in place (identically in every thread)
+__device__ double refine_pose_block(const double *pt2d, const double *pt3d, const int32_t *inl, int n, double f,
+                                    double ppx, double ppy, double *Rm, double *tv, int max_iter, int *iters_out) {
+  __shared__ RefineShared S;
+  normal_equations_wave0(pt2d, pt3d, inl, n, f, ppx, ppy, Rm, tv, S);
+  double H[6][6], g[6], cost = S.H[6][6];
+  for (int i = 0; i < 6; ++i) {
+    g[i] = S.H[i][6];
+    for (int j = 0; j < 6; ++j) H[i][j] = S.H[i][j];
+  }
+  double lambda = 1e-4;
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    // (H + lambda diag(H)) d = -g   -- every thread solves the same 6x6 system (Gaussian elimination, partial pivoting)
+    double A[6][7];
+    for (int i = 0; i < 6; ++i) {
+      for (int j = 0; j < 6; ++j) A[i][j] = H[i][j];
+      A[i][i] = H[i][i] * (1.0 + lambda);
+      A[i][6] = -g[i];
+    }
+    bool singular = false;
+    for (int c = 0; c < 6; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < 6; ++r)
+        if (dabs(A[r][c]) > dabs(A[piv][c])) piv = r;
+      if (!(dabs(A[piv][c]) > 0.0)) {
+        singular = true;
+        break;
+      }
+      if (piv != c)
+        for (int j = c; j < 7; ++j) {
+          const double t = A[c][j];
+          A[c][j] = A[piv][j];
+          A[piv][j] = t;
+        }
+      for (int r = c + 1; r < 6; ++r) {
+        const double fct = A[r][c] / A[c][c];
+        for (int j = c; j < 7; ++j) A[r][j] = A[r][j] - fct * A[c][j];
+      }
+    }
+    if (singular) break;
+    double d[6];
+    for (int i = 5; i >= 0; --i) {
+      double acc = A[i][6];
+      for (int j = i + 1; j < 6; ++j) acc = acc - A[i][j] * d[j];
+      d[i] = acc / A[i][i];
+    }
+    double Rn[9], tn[3];
+    rotate_left(d, Rm, Rn);
+    tn[0] = tv[0] + d[3];
+    tn[1] = tv[1] + d[4];
+    tn[2] = tv[2] + d[5];
+    __syncthreads();  // S.H of the previous pass has been read by every thread
+    normal_equations_wave0(pt2d, pt3d, inl, n, f, ppx, ppy, Rn, tn, S);
+    const double c_new = S.H[6][6];
+    if (c_new < cost) {
+      const double rel = (cost - c_new) / cost;
+      for (int i = 0; i < 9; ++i) Rm[i] = Rn[i];
+      for (int i = 0; i < 3; ++i) tv[i] = tn[i];
+      cost = c_new;
+      for (int i = 0; i < 6; ++i) {
+        g[i] = S.H[i][6];
+        for (int j = 0; j < 6; ++j) H[i][j] = S.H[i][j];
+      }
+      lambda = lambda * 0.1;
+      if (lambda < 1e-12) lambda = 1e-12;
+      if (rel < 1e-10) {
+        ++it;
+        break;
+      }
+    } else {
+      lambda = lambda * 10.0;
+      if (lambda > 1e10) break;
+    }
+  }
+  __syncthreads();
+  *iters_out = it;
+  return cost;
+}
+
 __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
   P3pState &st = *A.state;
   if (st.done) return;
@@ -660,6 +829,38 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
       A.pair_landmark[p] = A.ms_landmark[c];
       A.inlier_idx[p] = c;
     }
+  // every thread computes the (tiny) pose epilogue redundantly so that the refinement can use block barriers
+  const double inv_f = 1.0 / A.focal;
+  double Pm[12];
+  for (int j = 0; j < 4; ++j) {  // P = K * [R|t]
+    Pm[j] = A.focal * Msh[j] + A.ppx * Msh[8 + j];
+    Pm[4 + j] = A.focal * Msh[4 + j] + A.ppy * Msh[8 + j];
+    Pm[8 + j] = Msh[8 + j];
+  }
+  if (n_final == 0)
+    for (int j = 0; j < 12; ++j) Pm[j] = 0.0;
+  double Kq[9], Rq[9], tq[3], cq[3];
+  double refine_cost = 0.0;
+  int refine_iters = 0;
+  if (ok) {
+    krt_from_p(Pm, Kq, Rq, tq);
+    if (A.refine_pose) {
+      __syncthreads();  // inlier_idx written above by all threads
+      refine_cost = refine_pose_block(A.pt2d, A.pt3d, A.best_inl, n_final, A.focal, A.ppx, A.ppy, Rq, tq, 20,
+                                      &refine_iters);
+      for (int r = 0; r < 3; ++r) {  // P = K [R|t] of the refined pose
+        for (int j = 0; j < 3; ++j) {
+          Pm[4 * r + j] = (r == 0) ? A.focal * Rq[j] + A.ppx * Rq[6 + j]
+                        : (r == 1) ? A.focal * Rq[3 + j] + A.ppy * Rq[6 + j]
+                                   : Rq[6 + j];
+        }
+        Pm[4 * r + 3] = (r == 0) ? A.focal * tq[0] + A.ppx * tq[2] : (r == 1) ? A.focal * tq[1] + A.ppy * tq[2] : tq[2];
+      }
+      Kq[0] = A.focal; Kq[1] = 0.0; Kq[2] = A.ppx; Kq[3] = 0.0; Kq[4] = A.focal; Kq[5] = A.ppy;
+      Kq[6] = 0.0; Kq[7] = 0.0; Kq[8] = 1.0;
+    }
+    center_from_rt(Rq, tq, cq);
+  }
   if (tid == 0) {
     R.ok = ok ? 1 : 0;
     R.n_inliers = n_final;
@@ -667,21 +868,10 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
     R.iterations = (int)(iter0 + processed);
     R.nfa = min_nfa;
     R.status = st.status;
-    const double inv_f = 1.0 / A.focal;
+    R.reserved = refine_iters;
     R.error_max = (n_final > 0) ? sqrt(errmax) / inv_f : errmax;
-    double Pm[12];
-    for (int j = 0; j < 4; ++j) {  // P = K * [R|t]
-      Pm[j] = A.focal * Msh[j] + A.ppx * Msh[8 + j];
-      Pm[4 + j] = A.focal * Msh[4 + j] + A.ppy * Msh[8 + j];
-      Pm[8 + j] = Msh[8 + j];
-    }
-    if (n_final == 0)
-      for (int j = 0; j < 12; ++j) Pm[j] = 0.0;
     for (int j = 0; j < 12; ++j) R.P[j] = Pm[j];
     if (ok) {
-      double Kq[9], Rq[9], tq[3], cq[3];
-      krt_from_p(Pm, Kq, Rq, tq);
-      center_from_rt(Rq, tq, cq);
       for (int j = 0; j < 9; ++j) {
         R.K[j] = Kq[j];
         R.R[j] = Rq[j];
@@ -690,6 +880,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
         R.t[j] = tq[j];
         R.center[j] = cq[j];
       }
+      if (A.refine_pose) R.stage_seconds[0] = refine_cost;  // overwritten by the host; kept for sfmloc_pose_read
     }
   }
 }
@@ -865,6 +1056,7 @@ static P3pArgs make_p3p_args(Ctx *c) {
   A.min_resection_points = m->params.min_resection_points;
   A.min_inliers = m->params.min_inliers;
   A.max_n = kP3pMaxN;
+  A.refine_pose = m->params.refine_pose;
   A.seed = m->params.seed;
   A.stream = 0;
   return A;

@@ -81,7 +81,7 @@ struct P3pArgs {
   int32_t *hyp_inl;
   uint32_t *pair_qfeat, *pair_landmark, *inlier_idx;
   double focal, ppx, ppy;
-  int max_iteration, min_resection_points, min_inliers, max_n;
+  int max_iteration, min_resection_points, min_inliers, max_n, refine_pose;
   uint64_t seed;
   uint32_t stream;
 };

@@ -322,3 +322,45 @@ def test_sharded_map_equals_unsharded(oracle_c):
     for sm in shards:
         sm.close()
     full.close()
+
+
+def test_pose_refinement_extension(oracle_c):
+    """refine_pose = 1 (A13, north-star extension with no reference counterpart -> parity unpinned): the kernel's
+    LM (normal equations on f64 MFMA) against the oracle's plain-loop LM within 1e-7, cost never worse, inlier set
+    untouched; refine_pose = 0 stays the reference-equivalent output."""
+    m = make_scene(27)
+    base = dev_map(m)
+    ref = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, refine_pose=1),
+                view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+                landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    f, ppx, ppy = m.intrinsic
+    err0, err1 = [], []
+    for k in range(5):
+        q = synth.make_query(m, 900 + k, n_feat=600, n_copies=220, outlier_frac=0.25)
+        exp = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height))
+        q0 = base.query(q.desc, q.kpt_xy, q.width, q.height)
+        q1 = ref.query(q.desc, q.kpt_xy, q.width, q.height)
+        p0, pq0, pl0 = base.localize(q0)
+        p1, pq1, pl1 = ref.localize(q1)
+        assert bool(p0.ok) == bool(p1.ok) == exp["ok"]
+        if not exp["ok"]:
+            continue
+        np.testing.assert_array_equal(pq0, pq1)
+        np.testing.assert_array_equal(pl0, pl1)
+        np.testing.assert_array_equal(bits(np.array(p0.P)), bits(exp["P"].ravel()))       # unrefined = oracle, bit for bit
+        o = oracle_c.refine_pose(exp["pt2d"], exp["pt3d"], exp["inlier_idx"], f, ppx, ppy, exp["R"], exp["t"])
+        R1, c1 = np.array(p1.R).reshape(3, 3), np.array(p1.center)
+        assert np.abs(R1 - o["R"]).max() < 1e-7 and np.abs(c1 - o["center"]).max() < 1e-7
+        assert 1 <= p1.reserved <= 20      # LM iterations (the last accept/reject steps are decided by rounding noise,
+                                           # fused on the MFMA path, so the count is not compared)
+        np.testing.assert_allclose(np.array(p1.K).reshape(3, 3), [[f, 0, ppx], [0, f, ppy], [0, 0, 1]])
+        P1 = np.array(p1.P).reshape(3, 4)
+        np.testing.assert_allclose(P1, np.array(p1.K).reshape(3, 3) @ np.c_[R1, np.array(p1.t)], rtol=1e-12, atol=1e-9)
+        assert o["cost"] <= o["cost0"]
+        err0.append(np.abs(np.array(p0.center) - q.C_true).max())
+        err1.append(np.abs(c1 - q.C_true).max())
+        q0.close()
+        q1.close()
+    assert len(err0) >= 4 and np.mean(err1) <= np.mean(err0) * 1.05      # refinement does not hurt, usually helps
+    base.close()
+    ref.close()

@@ -224,3 +224,23 @@ def test_match_set_semantics(oracle_c):
     put_d2[4] = 11
     q, lm = oracle_c.match_set(gv, gi, gj, view_off, put_count, put_i, put_j, put_d2, row_landmark, 12)
     assert list(lm) == [200, 101, 202]
+
+
+def test_refine_pose_extension(oracle_c):
+    """A13 (north-star extension, absent from the reference): LM on the inliers lowers the reprojection cost and
+    moves a perturbed pose back to the truth."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    X, _, x2, (R2, C2, f, ppx, ppy) = _two_views(rng, 150)
+    x2n = x2 + rng.normal(0, 0.5, x2.shape)
+    ang = 0.01
+    dR = np.array([[1, -ang, 0], [ang, 1, 0], [0, 0, 1.0]])
+    U, _, Vt = np.linalg.svd(dR @ R2)
+    R0 = U @ Vt
+    t0 = -R0 @ (C2 + np.array([0.05, -0.03, 0.04]))
+    r = oracle_c.refine_pose(x2n, X, np.arange(150), f, ppx, ppy, R0, t0)
+    assert r["cost"] < 0.05 * r["cost0"] and 1 <= r["iters"] <= 20
+    assert np.abs(r["R"] - R2).max() < 2e-3 and np.abs(r["center"] - C2).max() < 2e-2
+    np.testing.assert_allclose(r["R"] @ r["R"].T, np.eye(3), atol=1e-12)
+    # already optimal (noise-free): stays put
+    r2 = oracle_c.refine_pose(x2, X, np.arange(150), f, ppx, ppy, R2, -R2 @ C2)
+    assert np.abs(r2["R"] - R2).max() < 1e-9 and r2["cost"] <= r2["cost0"]
