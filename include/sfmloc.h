@@ -302,6 +302,29 @@ int sfmloc_bof_dim(const sfmloc_bof *bof); /* K x pyramid cells (500) */
 /* desc [n x in_dim] f32, kpt_xy [n x 2] in the resized image; out_bow [sfmloc_bof_dim] f64.  Synchronises. */
 int sfmloc_bof_compute(sfmloc_bof *bof, const float *desc, const float *kpt_xy, uint32_t n, double *out_bow);
 
+/* ------------------------------------------------------------------------- */
+/* Stage A2 / A5a: AKAZE detection and full 486-bit M-LDB description.            */
+/* sfmloc_akaze_detect_and_compute replaces                                        */
+/*   cv::AKAZE::create(DESCRIPTOR_MLDB, 0, 3, thres, nOct, nOctLay)->detectAndCompute(gray, noArray(), kpts, desc) */
+/* (AKAZEOpenCV.cpp:44-46,67); sfmloc_akaze_compute replaces extractor->compute(gray, keypoints, desc) on given  */
+/* keypoints (DenseLocalFeatureWrapper.cpp:146; class_id = evolution level, octave 0).                           */
+/* An extractor is bound to one image size (it owns the scale-space buffers).                                    */
+/*   kpts [cap*6]: x, y, size (diameter), angle (radians), response, class_id                                    */
+/*   desc64 [cap*64]: rows exactly as saveAKAZEBin stores them (61 M-LDB bytes + 3 zero bytes, FileUtils.cpp:77-92) */
+/* ------------------------------------------------------------------------- */
+typedef struct sfmloc_akaze sfmloc_akaze;
+int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_sublevels, float threshold,
+                        sfmloc_akaze **out);
+void sfmloc_akaze_destroy(sfmloc_akaze *ak);
+int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float *kpts, uint8_t *desc64, uint32_t cap,
+                                    uint32_t *n_out);
+/* kin [n*4]: x, y, size, class_id */
+int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin, uint32_t n, uint8_t *desc64,
+                         float *angle_out);
+/* scale-space introspection for parity tests: level sizes, and the stacked Ldet / Lt images of the last call */
+int sfmloc_akaze_levels(const sfmloc_akaze *ak, int *n_levels, int *wh);
+int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt);
+
 /* Parity probe: runs one of the f64 device building blocks over n items (tests compare with the oracle).
  * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample */
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride);

@@ -14,7 +14,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle.c", "sfm_oracle_geom.c", "sfm_oracle_bow.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle.c", "sfm_oracle_geom.c", "sfm_oracle_bow.c", "sfm_oracle_akaze.c", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs if os.path.exists(f)):
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
     return _SO
@@ -266,3 +266,52 @@ def refine_pose(pt2d, pt3d, inliers, focal, ppx, ppy, R, t, max_iter=20):
     c = np.zeros(3)
     lib().orc_center_from_rt(_p(R, C.c_double), _p(t, C.c_double), _p(c, C.c_double))
     return {"R": R.reshape(3, 3), "t": t, "center": c, "cost0": c0.value, "cost": float(cost), "iters": it.value}
+
+
+# ---------------------------------------------------------------------------------------------------
+# AKAZE (sfm_oracle_akaze.c)
+# ---------------------------------------------------------------------------------------------------
+def akaze_levels(w, h, omax=4, nsub=4):
+    wh = np.zeros(64, np.int32)
+    n = lib().orc_akaze_levels(C.c_int(w), C.c_int(h), C.c_int(omax), C.c_int(nsub), _p(wh, C.c_int32))
+    return wh[:2 * n].reshape(n, 2)
+
+
+def akaze_detect_and_compute(gray, thres=0.001, omax=4, nsub=4, cap=20000, want_levels=False):
+    """-> kpts [n x 6] (x, y, size, angle[rad], response, class_id), desc [n x 61] (+ Ldet, Lt of all levels)."""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    kp = np.zeros((cap, 6), np.float32)
+    desc = np.zeros((cap, 61), np.uint8)
+    ldet = lt = None
+    if want_levels:
+        tot = int(sum(int(a) * int(b) for a, b in akaze_levels(w, h, omax, nsub)))
+        ldet = np.zeros(tot, np.float32)
+        lt = np.zeros(tot, np.float32)
+    lib().orc_akaze_detect_and_compute.restype = C.c_int
+    n = lib().orc_akaze_detect_and_compute(_p(gray, C.c_uint8), C.c_int(w), C.c_int(h), C.c_int(omax), C.c_int(nsub),
+                                           C.c_float(thres), _p(kp, C.c_float), _p(desc, C.c_uint8), C.c_int(cap),
+                                           _p(ldet, C.c_float), _p(lt, C.c_float))
+    if n < 0:
+        raise OverflowError(f"{-n} keypoints > cap {cap}")
+    if want_levels:
+        return kp[:n].copy(), desc[:n].copy(), ldet, lt
+    return kp[:n].copy(), desc[:n].copy()
+
+
+def akaze_compute(gray, kin, omax=4, nsub=4):
+    """compute() on given keypoints [n x 4] (x, y, size, class_id) -> desc [n x 61], angle [n]."""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    kin = np.ascontiguousarray(kin, np.float32).reshape(-1, 4)
+    desc = np.zeros((kin.shape[0], 61), np.uint8)
+    ang = np.zeros(kin.shape[0], np.float32)
+    lib().orc_akaze_compute(_p(gray, C.c_uint8), C.c_int(w), C.c_int(h), C.c_int(omax), C.c_int(nsub),
+                            _p(kin, C.c_float), C.c_int(kin.shape[0]), _p(desc, C.c_uint8), _p(ang, C.c_float))
+    return desc, ang
+
+
+def akaze_math(x, y):
+    out = np.zeros(3, np.float32)
+    lib().orc_akaze_math(C.c_float(x), C.c_float(y), _p(out, C.c_float))
+    return out

@@ -102,7 +102,8 @@ SYMBOLS = [
     "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
     "sfmloc_localize_batch", "sfmloc_part_bytes", "sfmloc_shard_begin", "sfmloc_shard_export",
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
-    "sfmloc_bof_dim", "sfmloc_bof_compute",
+    "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
+    "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
     "sfmloc_stats_read", "sfmloc_stats_reset",
 ]
 
@@ -161,6 +162,15 @@ def _L():
         L.sfmloc_bof_destroy.argtypes = [C.c_void_p]
         L.sfmloc_bof_dim.argtypes = [C.c_void_p]
         L.sfmloc_bof_compute.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, F64P]
+        L.sfmloc_akaze_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_void_p)]
+        L.sfmloc_akaze_destroy.restype = None
+        L.sfmloc_akaze_destroy.argtypes = [C.c_void_p]
+        L.sfmloc_akaze_detect_and_compute.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float),
+                                                      C.POINTER(C.c_uint8), C.c_uint32, U32P]
+        L.sfmloc_akaze_compute.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_uint32,
+                                           C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
+        L.sfmloc_akaze_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.sfmloc_akaze_read_levels.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.sfmloc_localize_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32,
                                             C.POINTER(Pose), U32P, U32P, C.c_uint32]
         L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
@@ -485,6 +495,60 @@ class BofModel:
     def close(self):
         if self._h is not None:
             _L().sfmloc_bof_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Akaze:
+    """sfmloc_akaze: AKAZE + M-LDB extractor for one image size (extractAKAZESingleImg's compute part,
+    AKAZEOpenCV.cpp:44-46,67; defaults AKAZEOption.h:31-34)."""
+
+    def __init__(self, width, height, n_octaves=4, n_sublevels=4, threshold=0.001, device=0):
+        self._h = None
+        self.width, self.height = int(width), int(height)
+        h = C.c_void_p()
+        _check(_L().sfmloc_akaze_create(device, self.width, self.height, n_octaves, n_sublevels, threshold, C.byref(h)))
+        self._h = h
+        n = C.c_int()
+        wh = (C.c_int * 64)()
+        _check(_L().sfmloc_akaze_levels(h, C.byref(n), wh))
+        self.levels = [(wh[2 * i], wh[2 * i + 1]) for i in range(n.value)]
+
+    def detect_and_compute(self, gray, cap=65536):
+        """-> kpts [n x 6] (x, y, size, angle, response, class_id), desc [n x 64] (.desc rows)."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        assert gray.shape == (self.height, self.width)
+        kp = np.zeros((cap, 6), np.float32)
+        desc = np.zeros((cap, 64), np.uint8)
+        n = C.c_uint32()
+        _check(_L().sfmloc_akaze_detect_and_compute(self._h, _ptr(gray, C.c_uint8), _ptr(kp, C.c_float),
+                                                    _ptr(desc, C.c_uint8), cap, C.byref(n)))
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def compute(self, gray, kin):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        kin = np.ascontiguousarray(kin, np.float32).reshape(-1, 4)
+        desc = np.zeros((kin.shape[0], 64), np.uint8)
+        ang = np.zeros(kin.shape[0], np.float32)
+        _check(_L().sfmloc_akaze_compute(self._h, _ptr(gray, C.c_uint8), _ptr(kin, C.c_float), kin.shape[0],
+                                         _ptr(desc, C.c_uint8), _ptr(ang, C.c_float)))
+        return desc, ang
+
+    def read_levels(self):
+        tot = sum(w * h for w, h in self.levels)
+        ldet = np.zeros(tot, np.float32)
+        lt = np.zeros(tot, np.float32)
+        _check(_L().sfmloc_akaze_read_levels(self._h, _ptr(ldet, C.c_float), _ptr(lt, C.c_float)))
+        return ldet, lt
+
+    def close(self):
+        if self._h is not None:
+            _L().sfmloc_akaze_destroy(self._h)
             self._h = None
 
     def __del__(self):

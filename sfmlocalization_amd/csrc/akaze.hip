@@ -1,0 +1,922 @@
+// K9: AKAZE detection + full 486-bit M-LDB description for gfx950.
+//   replaces cv::AKAZE::create(DESCRIPTOR_MLDB, 0, 3, thres, nOct, nOctLay)->detectAndCompute(gray)
+//   (VisionLocalizeCommon/src/AKAZEOpenCV.cpp:44-46,67) and cv::AKAZE::create()->compute(gray, keypoints)
+//   (BoWCommon/src/DenseLocalFeatureWrapper.cpp:42,146).
+// Algorithm: Alcantarilla, Nuevo, Bartoli, BMVC 2013 -- nonlinear (Perona-Malik g2) scale space by Fast Explicit
+// Diffusion, determinant-of-Hessian extrema with Scharr derivatives, sub-pixel refinement, dominant orientation,
+// rotated 2x2 / 3x3 / 4x4 grid comparisons of intensity and gradients (M-LDB).  OpenCV 3.0 is not in the image:
+// parity is against the build's own CPU restatement, operation order for operation order (float32, no FMA fusion).
+//
+// Every pixel-wise stage is a plain memory-bound kernel over one pyramid level (<= 1.2 MB at VGA, L2-resident);
+// the only sequential step -- OpenCV's order-dependent duplicate suppression over a few thousand candidates -- runs on
+// the host between two kernels (candidates carry their 3x3 Hessian-response patch, so sub-pixel refinement needs no
+// second trip).  Orientation and description use one 64-lane wave per keypoint with the per-cell / per-window sums
+// kept sequential inside a lane so that they round exactly like the restatement.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "sfmloc_internal.h"
+
+namespace sfmloc {
+namespace {
+
+constexpr int kMaxLevels = 32;
+constexpr float kPiF = 3.14159265358979323846f;
+
+struct AkLevel {
+  int w, h, octave, sublevel, sigma_size, nsteps;
+  float esigma, etime;
+  float tsteps[64];
+  size_t off;  // offset (floats) of this level inside each per-level image stack
+};
+
+struct AkPlan {
+  int nlev = 0;
+  AkLevel lev[kMaxLevels];
+  float g16[9], g10[5];
+  float gauss25[49];
+  float win_ang1[64];
+  int n_win = 0;
+  uint16_t pair_tab[486 * 2];
+  size_t total = 0;
+};
+
+int fround_h(float f) { return (int)(f + 0.5f); }
+
+bool is_prime(int n) {
+  if (n <= 3) return n > 1;
+  if (n % 2 == 0 || n % 3 == 0) return false;
+  for (int i = 5; i * i <= n; i += 6)
+    if (n % i == 0 || n % (i + 2) == 0) return false;
+  return true;
+}
+
+// fed_tau_by_process_time(T, 1, 0.25, reordering = true) of OpenCV's fed.cpp
+int fed_tau(float T, float tau_max, float *tau) {
+  const int n = (int)(ceilf(sqrtf(3.0f * T / tau_max + 0.25f) - 0.5f - 1.0e-8f) + 0.5f);
+  if (n <= 0) return 0;
+  const float scale = 3.0f * T / (tau_max * (float)(n * (n + 1)));
+  float tauh[64];
+  const float c = 1.0f / (4.0f * (float)n + 2.0f);
+  const float d = scale * tau_max / 2.0f;
+  for (int k = 0; k < n; ++k) {
+    const float hh = cosf(kPiF * (2.0f * (float)k + 1.0f) * c);
+    tauh[k] = d / (hh * hh);
+  }
+  const int kappa = n / 2;
+  int prime = n + 1;
+  while (!is_prime(prime)) prime++;
+  for (int k = 0, l = 0; l < n; ++k, ++l) {
+    int index;
+    while ((index = ((k + 1) * kappa) % prime - 1) >= n) k++;
+    tau[l] = tauh[index];
+  }
+  return n;
+}
+
+void gaussian_kernel(int ksize, float sigma, float *cf) {  // cv::getGaussianKernel(ksize, sigma, CV_32F)
+  const double scale2x = -0.5 / ((double)sigma * sigma);
+  double sum = 0;
+  for (int i = 0; i < ksize; ++i) {
+    const double x = i - (ksize - 1) * 0.5;
+    cf[i] = (float)exp(scale2x * x * x);
+    sum += cf[i];
+  }
+  sum = 1.0 / sum;
+  for (int i = 0; i < ksize; ++i) cf[i] = (float)(cf[i] * sum);
+}
+
+// Allocate_Memory_Evolution + FED schedule + constant tables
+void make_plan(int w, int h, int omax, int nsub, AkPlan &P) {
+  const float soffset = 1.6f, derivative_factor = 1.5f;
+  P.nlev = 0;
+  P.total = 0;
+  for (int i = 0; i < omax; ++i) {
+    const float rfactor = 1.0f / powf(2.0f, (float)i);
+    const int lh = (int)(h * rfactor), lw = (int)(w * rfactor);
+    if ((lw < 80 || lh < 40) && i != 0) break;
+    for (int j = 0; j < nsub && P.nlev < kMaxLevels; ++j) {
+      AkLevel &L = P.lev[P.nlev++];
+      memset(&L, 0, sizeof(L));
+      L.w = lw;
+      L.h = lh;
+      L.esigma = soffset * powf(2.0f, (float)j / (float)nsub + (float)i);
+      L.sigma_size = fround_h(L.esigma * derivative_factor / powf(2.0f, (float)i));
+      L.etime = 0.5f * (L.esigma * L.esigma);
+      L.octave = i;
+      L.sublevel = j;
+      L.off = P.total;
+      P.total += (size_t)lw * lh;
+    }
+  }
+  for (int i = 1; i < P.nlev; ++i)
+    P.lev[i].nsteps = fed_tau(P.lev[i].etime - P.lev[i - 1].etime, 0.25f, P.lev[i].tsteps);
+  gaussian_kernel(9, 1.6f, P.g16);
+  gaussian_kernel(5, 1.0f, P.g10);
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j)
+      P.gauss25[7 * i + j] = (float)(exp(-(double)(i * i + j * j) / 12.5) / (2.0 * 3.14159265358979323846 * 6.25));
+  P.n_win = 0;
+  for (float a = 0.0f; a < 2.0f * kPiF; a += 0.15f) P.win_ang1[P.n_win++] = a;
+  // M-LDB comparison pairs: bit dpos compares values[a] > values[b]; values are laid out [cell][channel] with the
+  // cells of the three grids back to back (4 + 9 + 16)
+  int dpos = 0, cell0 = 0;
+  const int counts[3] = {4, 9, 16};
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    for (int pos = 0; pos < 3; ++pos)
+      for (int a = 0; a < counts[lvl]; ++a)
+        for (int b = a + 1; b < counts[lvl]; ++b) {
+          P.pair_tab[2 * dpos] = (uint16_t)((cell0 + a) * 3 + pos);
+          P.pair_tab[2 * dpos + 1] = (uint16_t)((cell0 + b) * 3 + pos);
+          ++dpos;
+        }
+    cell0 += counts[lvl];
+  }
+}
+
+// ---- fixed-order float math shared with the restatement -------------------------------------------------------
+__device__ __forceinline__ int fround_d(float f) { return (int)(f + 0.5f); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int reflect101(int v, int n) {
+  if (n == 1) return 0;
+  while (v < 0 || v >= n) v = v < 0 ? -v : 2 * (n - 1) - v;
+  return v;
+}
+
+__device__ float det_atanf(float x) {
+  float y;
+  if (x > 2.414213562373095f) {
+    y = 1.5707963267948966f;
+    x = -(1.0f / x);
+  } else if (x > 0.4142135623730950f) {
+    y = 0.7853981633974483f;
+    x = (x - 1.0f) / (x + 1.0f);
+  } else {
+    y = 0.0f;
+  }
+  const float z = x * x;
+  float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
+  p = p * z + 1.99777106478e-1f;
+  p = p * z - 3.33329491539e-1f;
+  p = p * z;
+  p = p * x + x;
+  return y + p;
+}
+
+__device__ float get_angle(float x, float y) {
+  if (x == 0.0f && y == 0.0f) return 0.0f;
+  if (x >= 0 && y >= 0) return (x == 0.0f) ? 1.5707963267948966f : det_atanf(y / x);
+  if (x < 0 && y >= 0) return kPiF - det_atanf(-y / x);
+  if (x < 0 && y < 0) return kPiF + det_atanf(y / x);
+  return (x == 0.0f) ? (2.0f * kPiF - 1.5707963267948966f) : 2.0f * kPiF - det_atanf(-y / x);
+}
+
+__device__ void det_sincosf(float a, float *s, float *c) {
+  const int k = (int)(a * 0.6366197723675814f + 0.5f);
+  const float kf = (float)k;
+  float r = a - kf * 1.5707963705062866f;
+  r = r + kf * 4.371139000186241e-08f;
+  const float z = r * r;
+  float sp = -1.9515295891e-4f * z + 8.3321608736e-3f;
+  sp = sp * z - 1.6666654611e-1f;
+  sp = sp * z;
+  sp = sp * r + r;
+  float cp = 2.443315711809948e-5f * z - 1.388731625493765e-3f;
+  cp = cp * z + 4.166664568298827e-2f;
+  cp = cp * z;
+  cp = cp * z;
+  cp = cp - 0.5f * z;
+  cp = cp + 1.0f;
+  switch (k & 3) {
+    case 0: *s = sp; *c = cp; break;
+    case 1: *s = cp; *c = -sp; break;
+    case 2: *s = -sp; *c = -cp; break;
+    default: *s = -cp; *c = sp; break;
+  }
+}
+
+// ---- pixel kernels -----------------------------------------------------------------------------------------------
+struct Taps {
+  float k[9];
+};
+
+__global__ void k_u8_to_f32(const uint8_t *__restrict__ src, float *__restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i] / 255.0f;
+}
+
+// one pass of the separable Gaussian, BORDER_REPLICATE; horizontal = 1: along x
+__global__ void k_gauss_pass(const float *__restrict__ src, float *__restrict__ dst, int w, int h, Taps t, int ksize,
+                             int horizontal) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const int r = ksize / 2;
+  float acc = 0.0f;
+  for (int i = 0; i < ksize; ++i) {
+    const float v = horizontal ? src[(size_t)y * w + clampi(x + i - r, 0, w - 1)]
+                               : src[(size_t)clampi(y + i - r, 0, h - 1) * w + x];
+    acc = acc + t.k[i] * v;
+  }
+  dst[(size_t)y * w + x] = acc;
+}
+
+__global__ void k_scharr(const float *__restrict__ src, float *__restrict__ dst, int w, int h, int xorder, int scale,
+                         float ws, float wm) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const int xm = reflect101(x - scale, w), xp = reflect101(x + scale, w);
+  const int ym = reflect101(y - scale, h), yp = reflect101(y + scale, h);
+  float d;
+  if (xorder) {
+    const float r0 = src[(size_t)y * w + xp] - src[(size_t)y * w + xm];
+    const float rm = src[(size_t)ym * w + xp] - src[(size_t)ym * w + xm];
+    const float rp = src[(size_t)yp * w + xp] - src[(size_t)yp * w + xm];
+    d = wm * r0 + ws * (rm + rp);
+  } else {
+    const float r0 = src[(size_t)yp * w + x] - src[(size_t)ym * w + x];
+    const float rm = src[(size_t)yp * w + xm] - src[(size_t)ym * w + xm];
+    const float rp = src[(size_t)yp * w + xp] - src[(size_t)ym * w + xp];
+    d = wm * r0 + ws * (rm + rp);
+  }
+  dst[(size_t)y * w + x] = d;
+}
+
+__global__ void k_halfsample(const float *__restrict__ src, int sw, int sh, float *__restrict__ dst, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= dw) return;
+  const double sx = (double)sw / dw, sy = (double)sh / dh;
+  const double fx0 = x * sx, fx1 = (x + 1) * sx, fy0 = y * sy, fy1 = (y + 1) * sy;
+  const int ix0 = (int)floor(fx0), iy0 = (int)floor(fy0);
+  const int ix1 = (int)ceil(fx1), iy1 = (int)ceil(fy1);
+  float acc = 0.0f;
+  for (int yy = iy0; yy < iy1 && yy < sh; ++yy) {
+    const double wy = fmin(fy1, yy + 1.0) - fmax(fy0, (double)yy);
+    for (int xx = ix0; xx < ix1 && xx < sw; ++xx) {
+      const double wx = fmin(fx1, xx + 1.0) - fmax(fx0, (double)xx);
+      const float wgt = (float)(wx * wy / (sx * sy));
+      acc = acc + wgt * src[(size_t)yy * sw + xx];
+    }
+  }
+  dst[(size_t)y * dw + x] = acc;
+}
+
+// compute_k_percentile: maximum gradient magnitude over the interior, then its 300-bin histogram
+__global__ void k_grad_max(const float *__restrict__ lx, const float *__restrict__ ly, int w, int h,
+                           unsigned int *hmax_bits) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+  const float a = lx[(size_t)y * w + x], b = ly[(size_t)y * w + x];
+  const float m = sqrtf(a * a + b * b);
+  atomicMax(hmax_bits, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+__global__ void k_grad_hist(const float *__restrict__ lx, const float *__restrict__ ly, int w, int h,
+                            const unsigned int *hmax_bits, unsigned int *hist /*[301]: 300 bins + npoints*/) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+  const float hmax = __uint_as_float(*hmax_bits);
+  const float a = lx[(size_t)y * w + x], b = ly[(size_t)y * w + x];
+  const float m = sqrtf(a * a + b * b);
+  if (m != 0.0f) {
+    int nbin = (int)floorf(300.0f * (m / hmax));
+    if (nbin == 300) nbin--;
+    atomicAdd(&hist[nbin], 1u);
+    atomicAdd(&hist[300], 1u);
+  }
+}
+
+__global__ void k_kcontrast(const unsigned int *hmax_bits, const unsigned int *hist, float *kcontrast) {
+  const float hmax = __uint_as_float(*hmax_bits);
+  const int npoints = (int)hist[300];
+  const int nthreshold = (int)((float)npoints * 0.7f);
+  int nelements = 0, k = 0;
+  for (k = 0; nelements < nthreshold && k < 300; k++) nelements += (int)hist[k];
+  *kcontrast = (nelements < nthreshold) ? 0.03f : hmax * ((float)k / 300.0f);
+}
+
+// pm_g2 with the contrast factor of this octave (kcontrast * 0.75 per octave change)
+__global__ void k_pm_g2(const float *__restrict__ lx, const float *__restrict__ ly, float *__restrict__ dst, size_t n,
+                        const float *kcontrast, int octave) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float kc = *kcontrast;
+  for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
+  const float inv_k = 1.0f / (kc * kc);
+  dst[i] = 1.0f / (1.0f + inv_k * (lx[i] * lx[i] + ly[i] * ly[i]));
+}
+
+// nld_step_scalar: flux into `step_out`, zero flux across the image border
+__global__ void k_nld_flux(const float *__restrict__ Ld, const float *__restrict__ c, float *__restrict__ step_out,
+                           int w, int h, float half_step) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const size_t p = (size_t)y * w + x;
+  const float cc = c[p], v = Ld[p];
+  float xpos = 0.0f, xneg = 0.0f, ypos = 0.0f, yneg = 0.0f;
+  if (x + 1 < w) xpos = (cc + c[p + 1]) * (Ld[p + 1] - v);
+  if (x > 0) xneg = (c[p - 1] + cc) * (v - Ld[p - 1]);
+  if (y + 1 < h) ypos = (cc + c[p + w]) * (Ld[p + w] - v);
+  if (y > 0) yneg = (c[p - w] + cc) * (v - Ld[p - w]);
+  step_out[p] = half_step * (((xpos - xneg) + ypos) - yneg);
+}
+
+__global__ void k_add(float *__restrict__ a, const float *__restrict__ b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = a[i] + b[i];
+}
+
+__global__ void k_scale_det(float *lx, float *ly, float *lxx, float *lxy, float *lyy, float *ldet, size_t n, float sf,
+                            float sf2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  lx[i] = lx[i] * sf;
+  ly[i] = ly[i] * sf;
+  const float a = lxx[i] * sf2, b = lxy[i] * sf2, c = lyy[i] * sf2;
+  lxx[i] = a;
+  lxy[i] = b;
+  lyy[i] = c;
+  ldet[i] = a * c - b * b;
+}
+
+struct Candidate9 {
+  int level, x, y, pad;
+  float patch[9];  // Ldet(y-1..y+1, x-1..x+1), row major
+  float pad2[3];
+};
+
+// Find_Scale_Space_Extrema, the order-independent part: 3x3 strict maxima above the threshold that also pass the
+// descriptor-support border test (candidates failing it never change OpenCV's keypoint list)
+__global__ void k_extrema(const float *__restrict__ ldet, int w, int h, int level, int sigma_size_, float dthreshold,
+                          Candidate9 *out, unsigned int cap, unsigned int *n_out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+  const float *D = ldet;
+  const float v = D[(size_t)y * w + x];
+  if (!(v > dthreshold && v >= 0.00001f)) return;
+  float p[9];
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) p[(dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
+  if (!(v > p[3] && v > p[5] && v > p[0] && v > p[1] && v > p[2] && v > p[6] && v > p[7] && v > p[8])) return;
+  const float smax = 10.0f * sqrtf(2.0f);
+  const int left_x = fround_d((float)x - smax * sigma_size_) - 1, right_x = fround_d((float)x + smax * sigma_size_) + 1;
+  const int up_y = fround_d((float)y - smax * sigma_size_) - 1, down_y = fround_d((float)y + smax * sigma_size_) + 1;
+  if (left_x < 0 || right_x >= w || up_y < 0 || down_y >= h) return;
+  const unsigned int slot = atomicAdd(n_out, 1u);
+  if (slot >= cap) return;
+  Candidate9 c;
+  c.level = level;
+  c.x = x;
+  c.y = y;
+  c.pad = 0;
+  for (int i = 0; i < 9; ++i) c.patch[i] = p[i];
+  c.pad2[0] = c.pad2[1] = c.pad2[2] = 0.0f;
+  out[slot] = c;
+}
+
+struct DevLevel {
+  const float *Lt, *Lx, *Ly;
+  int w, h, octave;
+};
+struct DevLevels {
+  DevLevel l[kMaxLevels];
+};
+
+__device__ __forceinline__ float at_clamped(const float *img, int w, int h, int y, int x) {
+  return img[(size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)];
+}
+
+// Compute_Main_Orientation + Get_MLDB_Full_Descriptor: one wave per keypoint
+// kp [n x 4] = x, y, size (diameter), class_id ; angle_out [n] ; desc [n x 64] (61 bytes + 3 zero bytes = .desc row)
+__global__ __launch_bounds__(64) void k_orient_describe(DevLevels LV, const float *__restrict__ kp, int n,
+                                                        const float *__restrict__ gauss25,
+                                                        const float *__restrict__ win_ang1, int n_win,
+                                                        const uint16_t *__restrict__ pair_tab,
+                                                        float *__restrict__ angle_out, uint8_t *__restrict__ desc) {
+  __shared__ float resX[109], resY[109], Ang[109];
+  __shared__ float vals[29 * 3];
+  const int kidx = blockIdx.x;
+  if (kidx >= n) return;
+  const int lane = threadIdx.x;
+  const float kx = kp[4 * kidx], ky = kp[4 * kidx + 1], ksize = kp[4 * kidx + 2];
+  const int level = (int)kp[4 * kidx + 3];
+  const DevLevel L = LV.l[level];
+  const float ratio = (float)(1 << L.octave);
+  const int s = fround_d(0.5f * ksize / ratio);
+  const float xf = kx / ratio, yf = ky / ratio;
+  // --- orientation: 109 samples of the disc of radius 6 s ---
+  for (int q = lane; q < 109; q += 64) {
+    // q-th (i, j) of the double loop i = -6..6, j = -6..6 with i*i + j*j < 36
+    int cnt = 0, ii = 0, jj = 0;
+    for (int i = -6; i <= 6; ++i)
+      for (int j = -6; j <= 6; ++j)
+        if (i * i + j * j < 36) {
+          if (cnt == q) {
+            ii = i;
+            jj = j;
+          }
+          ++cnt;
+        }
+    const int iy = fround_d(yf + (float)(jj * s)), ix = fround_d(xf + (float)(ii * s));
+    const int a = ii < 0 ? -ii : ii, b = jj < 0 ? -jj : jj;  // id[] = |.| mirrored table index
+    const float g = gauss25[7 * a + b];
+    const float rx = g * at_clamped(L.Lx, L.w, L.h, iy, ix);
+    const float ry = g * at_clamped(L.Ly, L.w, L.h, iy, ix);
+    resX[q] = rx;
+    resY[q] = ry;
+    Ang[q] = get_angle(rx, ry);
+  }
+  __syncthreads();
+  const float two_pi = 2.0f * kPiF;
+  float mag = -1.0f, sumX = 0.0f, sumY = 0.0f;
+  if (lane < n_win) {
+    const float ang1 = win_ang1[lane];
+    const float ang2 = (ang1 + kPiF / 3.0f > two_pi) ? ang1 - 5.0f * kPiF / 3.0f : ang1 + kPiF / 3.0f;
+    for (int q = 0; q < 109; ++q) {
+      const float ang = Ang[q];
+      if (ang1 < ang2 && ang1 < ang && ang < ang2) {
+        sumX += resX[q];
+        sumY += resY[q];
+      } else if (ang2 < ang1 && ((ang > 0 && ang < ang2) || (ang > ang1 && ang < two_pi))) {
+        sumX += resX[q];
+        sumY += resY[q];
+      }
+    }
+    mag = sumX * sumX + sumY * sumY;
+  }
+  // first window (in sweep order) with the strictly largest magnitude; "max" starts at 0, so an all-zero sweep keeps angle 0
+  float best = mag;
+  int best_lane = lane;
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64);
+    const int ol = __shfl_xor(best_lane, off, 64);
+    if (ob > best || (ob == best && ol < best_lane)) {
+      best = ob;
+      best_lane = ol;
+    }
+  }
+  const float wx = __shfl(sumX, best_lane, 64), wy = __shfl(sumY, best_lane, 64);
+  const float angle = (best > 0.0f) ? get_angle(wx, wy) : 0.0f;
+  if (lane == 0) angle_out[kidx] = angle;
+  // --- M-LDB: 4 + 9 + 16 grid cells, one lane per cell, samples summed in (k, l) order ---
+  float si, co;
+  det_sincosf(angle, &si, &co);
+  const int scale = s;
+  if (lane < 29) {
+    int lvl, cell;
+    if (lane < 4) {
+      lvl = 0;
+      cell = lane;
+    } else if (lane < 13) {
+      lvl = 1;
+      cell = lane - 4;
+    } else {
+      lvl = 2;
+      cell = lane - 13;
+    }
+    const int pattern = 10;
+    const int step = lvl == 0 ? 10 : (lvl == 1 ? 7 : 5);
+    const int per = lvl + 2;               // cells per side
+    const int i0 = -pattern + (cell / per) * step, j0 = -pattern + (cell % per) * step;
+    float di = 0.0f, dx = 0.0f, dy = 0.0f;
+    int ns = 0;
+    for (int kk = i0; kk < i0 + step; ++kk)
+      for (int l = j0; l < j0 + step; ++l) {
+        const float sample_y = yf + ((float)l * co * (float)scale + (float)kk * si * (float)scale);
+        const float sample_x = xf + (-(float)l * si * (float)scale + (float)kk * co * (float)scale);
+        const int y1 = fround_d(sample_y), x1 = fround_d(sample_x);
+        const float ri = at_clamped(L.Lt, L.w, L.h, y1, x1);
+        const float rx = at_clamped(L.Lx, L.w, L.h, y1, x1);
+        const float ry = at_clamped(L.Ly, L.w, L.h, y1, x1);
+        di += ri;
+        const float rry = rx * co + ry * si;
+        const float rrx = -rx * si + ry * co;
+        dx += rrx;
+        dy += rry;
+        ns++;
+      }
+    vals[lane * 3 + 0] = di / (float)ns;
+    vals[lane * 3 + 1] = dx / (float)ns;
+    vals[lane * 3 + 2] = dy / (float)ns;
+  }
+  __syncthreads();
+  {
+    uint8_t byte = 0;
+    if (lane < 61) {
+      for (int b = 0; b < 8; ++b) {
+        const int dpos = 8 * lane + b;
+        if (dpos < 486 && vals[pair_tab[2 * dpos]] > vals[pair_tab[2 * dpos + 1]]) byte |= (uint8_t)(1 << b);
+      }
+    }
+    desc[(size_t)kidx * 64 + lane] = byte;  // lanes 61..63 write the zero padding of the .desc row
+  }
+}
+
+}  // namespace
+
+struct Akaze {
+  int device = 0;
+  int w = 0, h = 0, omax = 4, nsub = 4;
+  float thres = 0.001f;
+  AkPlan plan;
+  hipStream_t stream = nullptr;
+  uint8_t *d_gray = nullptr;
+  float *d_img = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr;
+  float *d_Lt = nullptr, *d_Lsmooth = nullptr, *d_Lx = nullptr, *d_Ly = nullptr, *d_Lxx = nullptr, *d_Lxy = nullptr,
+        *d_Lyy = nullptr, *d_Ldet = nullptr;  // per-level stacks
+  unsigned int *d_hist = nullptr;             // [0] hmax bits, [1..301] histogram + npoints
+  float *d_kcontrast = nullptr;
+  Candidate9 *d_cand = nullptr;
+  unsigned int *d_ncand = nullptr;
+  unsigned int cand_cap = 1u << 16;
+  float *d_gauss25 = nullptr, *d_win = nullptr;
+  uint16_t *d_pair = nullptr;
+  float *d_kp = nullptr, *d_angle = nullptr;
+  uint8_t *d_desc = nullptr;
+  unsigned int kp_cap = 0;
+};
+
+namespace {
+
+#define AK_HIP(x)                                                              \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      return e_ == hipErrorOutOfMemory ? SFMLOC_ENOMEM : SFMLOC_EHIP;          \
+    }                                                                          \
+  } while (0)
+
+dim3 grid2(int w, int h) { return dim3((w + 127) / 128, h); }
+
+int gauss(Akaze *a, const float *src, float *dst, float *tmp, int w, int h, const float *k, int ksize) {
+  Taps t;
+  for (int i = 0; i < 9; ++i) t.k[i] = i < ksize ? k[i] : 0.0f;
+  hipLaunchKernelGGL(k_gauss_pass, grid2(w, h), dim3(128), 0, a->stream, src, tmp, w, h, t, ksize, 1);
+  hipLaunchKernelGGL(k_gauss_pass, grid2(w, h), dim3(128), 0, a->stream, tmp, dst, w, h, t, ksize, 0);
+  AK_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int scharr(Akaze *a, const float *src, float *dst, int w, int h, int xorder, int scale, float ws, float wm) {
+  hipLaunchKernelGGL(k_scharr, grid2(w, h), dim3(128), 0, a->stream, src, dst, w, h, xorder, scale, ws, wm);
+  AK_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+// Create_Nonlinear_Scale_Space + Compute_Multiscale_Derivatives + Compute_Determinant_Hessian_Response
+int build_scale_space(Akaze *a, const uint8_t *gray) {
+  const AkPlan &P = a->plan;
+  const int w = a->w, h = a->h;
+  const size_t n0 = (size_t)w * h;
+  hipStream_t s = a->stream;
+  AK_HIP(hipMemcpyAsync(a->d_gray, gray, n0, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_u8_to_f32, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, a->d_gray, a->d_img, n0);
+  int rc = gauss(a, a->d_img, a->d_Lt, a->d_t3, w, h, P.g16, 9);
+  if (rc) return rc;
+  AK_HIP(hipMemcpyAsync(a->d_Lsmooth, a->d_Lt, n0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // contrast factor
+  rc = gauss(a, a->d_img, a->d_t0, a->d_t3, w, h, P.g10, 5);
+  if (!rc) rc = scharr(a, a->d_t0, a->d_t1, w, h, 1, 1, 3.0f, 10.0f);
+  if (!rc) rc = scharr(a, a->d_t0, a->d_t2, w, h, 0, 1, 3.0f, 10.0f);
+  if (rc) return rc;
+  AK_HIP(hipMemsetAsync(a->d_hist, 0, 302 * sizeof(unsigned int), s));
+  hipLaunchKernelGGL(k_grad_max, grid2(w, h), dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist);
+  hipLaunchKernelGGL(k_grad_hist, grid2(w, h), dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist, a->d_hist + 1);
+  hipLaunchKernelGGL(k_kcontrast, dim3(1), dim3(1), 0, s, a->d_hist, a->d_hist + 1, a->d_kcontrast);
+  AK_HIP(hipGetLastError());
+  for (int i = 1; i < P.nlev; ++i) {
+    const AkLevel &L = P.lev[i], &Lp = P.lev[i - 1];
+    const size_t n = (size_t)L.w * L.h;
+    float *Lt = a->d_Lt + L.off;
+    if (L.octave > Lp.octave) {
+      hipLaunchKernelGGL(k_halfsample, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lt + Lp.off, Lp.w, Lp.h, Lt, L.w, L.h);
+    } else {
+      AK_HIP(hipMemcpyAsync(Lt, a->d_Lt + Lp.off, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    rc = gauss(a, Lt, a->d_Lsmooth + L.off, a->d_t3, L.w, L.h, P.g10, 5);
+    if (!rc) rc = scharr(a, a->d_Lsmooth + L.off, a->d_t0, L.w, L.h, 1, 1, 3.0f, 10.0f);
+    if (!rc) rc = scharr(a, a->d_Lsmooth + L.off, a->d_t1, L.w, L.h, 0, 1, 3.0f, 10.0f);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pm_g2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a->d_t0, a->d_t1, a->d_t2, n,
+                       a->d_kcontrast, L.octave);
+    for (int st = 0; st < L.nsteps; ++st) {
+      hipLaunchKernelGGL(k_nld_flux, grid2(L.w, L.h), dim3(128), 0, s, Lt, a->d_t2, a->d_t3, L.w, L.h,
+                         0.5f * L.tsteps[st]);
+      hipLaunchKernelGGL(k_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Lt, a->d_t3, n);
+    }
+    AK_HIP(hipGetLastError());
+  }
+  for (int i = 0; i < P.nlev; ++i) {
+    const AkLevel &L = P.lev[i];
+    const size_t n = (size_t)L.w * L.h;
+    const int sc = L.sigma_size;
+    const float wgt = 10.0f / 3.0f;
+    const float norm = 1.0f / (2.0f * (float)sc * (wgt + 2.0f));
+    const float ws = norm, wm = wgt * norm;
+    float *Ls = a->d_Lsmooth + L.off, *Lx = a->d_Lx + L.off, *Ly = a->d_Ly + L.off;
+    rc = scharr(a, Ls, Lx, L.w, L.h, 1, sc, ws, wm);
+    if (!rc) rc = scharr(a, Ls, Ly, L.w, L.h, 0, sc, ws, wm);
+    if (!rc) rc = scharr(a, Lx, a->d_Lxx + L.off, L.w, L.h, 1, sc, ws, wm);
+    if (!rc) rc = scharr(a, Ly, a->d_Lyy + L.off, L.w, L.h, 0, sc, ws, wm);
+    if (!rc) rc = scharr(a, Lx, a->d_Lxy + L.off, L.w, L.h, 0, sc, ws, wm);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scale_det, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Lx, Ly, a->d_Lxx + L.off,
+                       a->d_Lxy + L.off, a->d_Lyy + L.off, a->d_Ldet + L.off, n, (float)sc, (float)(sc * sc));
+    AK_HIP(hipGetLastError());
+  }
+  return SFMLOC_OK;
+}
+
+struct HostKpt {
+  float x, y, size, angle, response;
+  int octave, class_id;
+  float patch[9];
+};
+
+int ensure_kp_cap(Akaze *a, unsigned int n) {
+  if (n <= a->kp_cap) return SFMLOC_OK;
+  if (a->d_kp) hipFree(a->d_kp);
+  if (a->d_angle) hipFree(a->d_angle);
+  if (a->d_desc) hipFree(a->d_desc);
+  a->d_kp = a->d_angle = nullptr;
+  a->d_desc = nullptr;
+  const unsigned int cap = std::max(n, 4096u);
+  AK_HIP(hipMalloc((void **)&a->d_kp, (size_t)cap * 4 * sizeof(float)));
+  AK_HIP(hipMalloc((void **)&a->d_angle, (size_t)cap * sizeof(float)));
+  AK_HIP(hipMalloc((void **)&a->d_desc, (size_t)cap * 64));
+  a->kp_cap = cap;
+  return SFMLOC_OK;
+}
+
+int orient_describe(Akaze *a, const std::vector<float> &kin, unsigned int n, float *angle_out, uint8_t *desc64) {
+  if (n == 0) return SFMLOC_OK;
+  int rc = ensure_kp_cap(a, n);
+  if (rc) return rc;
+  DevLevels LV;
+  memset(&LV, 0, sizeof(LV));
+  for (int i = 0; i < a->plan.nlev; ++i) {
+    const AkLevel &L = a->plan.lev[i];
+    LV.l[i].Lt = a->d_Lt + L.off;
+    LV.l[i].Lx = a->d_Lx + L.off;
+    LV.l[i].Ly = a->d_Ly + L.off;
+    LV.l[i].w = L.w;
+    LV.l[i].h = L.h;
+    LV.l[i].octave = L.octave;
+  }
+  AK_HIP(hipMemcpyAsync(a->d_kp, kin.data(), (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, a->stream));
+  hipLaunchKernelGGL(k_orient_describe, dim3(n), dim3(64), 0, a->stream, LV, a->d_kp, (int)n, a->d_gauss25, a->d_win,
+                     a->plan.n_win, a->d_pair, a->d_angle, a->d_desc);
+  AK_HIP(hipGetLastError());
+  if (angle_out) AK_HIP(hipMemcpyAsync(angle_out, a->d_angle, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, a->stream));
+  if (desc64) AK_HIP(hipMemcpyAsync(desc64, a->d_desc, (size_t)n * 64, hipMemcpyDeviceToHost, a->stream));
+  AK_HIP(hipStreamSynchronize(a->stream));
+  return SFMLOC_OK;
+}
+
+}  // namespace
+}  // namespace sfmloc
+
+using namespace sfmloc;
+
+extern "C" {
+
+void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
+  Akaze *a = reinterpret_cast<Akaze *>(ak);
+  if (!a) return;
+  hipSetDevice(a->device);
+  if (a->stream) hipStreamSynchronize(a->stream);
+  void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
+                  a->d_Lxx, a->d_Lxy, a->d_Lyy, a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_cand, a->d_ncand,
+                  a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  if (a->stream) hipStreamDestroy(a->stream);
+  delete a;
+}
+
+int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_sublevels, float threshold,
+                        sfmloc_akaze **out) {
+  SFM_CHECK(out, SFMLOC_EINVAL, "sfmloc_akaze_create: null argument");
+  *out = nullptr;
+  SFM_CHECK(width >= 16 && height >= 16 && width <= 16384 && height <= 16384, SFMLOC_EINVAL,
+            "sfmloc_akaze_create: image size %dx%d", width, height);
+  SFM_CHECK(n_octaves >= 1 && n_octaves <= 8 && n_sublevels >= 1 && n_octaves * n_sublevels <= kMaxLevels,
+            SFMLOC_EINVAL, "sfmloc_akaze_create: nOct %d nOctLay %d", n_octaves, n_sublevels);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  SFM_CHECK(e == hipSuccess && ndev > 0, SFMLOC_ENODEV, "no HIP device visible; this library has no CPU fallback");
+  SFM_HIP(hipSetDevice(device));
+  Akaze *a = new (std::nothrow) Akaze();
+  SFM_CHECK(a, SFMLOC_ENOMEM, "out of host memory");
+  a->device = device;
+  a->w = width;
+  a->h = height;
+  a->omax = n_octaves;
+  a->nsub = n_sublevels;
+  a->thres = threshold;
+  make_plan(width, height, n_octaves, n_sublevels, a->plan);
+  const size_t n0 = (size_t)width * height, tot = a->plan.total;
+  hipError_t he = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+  auto A = [&](void **p, size_t bytes) {
+    if (he == hipSuccess) he = hipMalloc(p, bytes);
+  };
+  A((void **)&a->d_gray, n0);
+  A((void **)&a->d_img, n0 * 4);
+  A((void **)&a->d_t0, n0 * 4);
+  A((void **)&a->d_t1, n0 * 4);
+  A((void **)&a->d_t2, n0 * 4);
+  A((void **)&a->d_t3, n0 * 4);
+  float **stacks[] = {&a->d_Lt, &a->d_Lsmooth, &a->d_Lx, &a->d_Ly, &a->d_Lxx, &a->d_Lxy, &a->d_Lyy, &a->d_Ldet};
+  for (float **sp : stacks) A((void **)sp, tot * 4);
+  A((void **)&a->d_hist, 302 * 4);
+  A((void **)&a->d_kcontrast, 4);
+  A((void **)&a->d_cand, (size_t)a->cand_cap * sizeof(Candidate9));
+  A((void **)&a->d_ncand, 4);
+  A((void **)&a->d_gauss25, 49 * 4);
+  A((void **)&a->d_win, 64 * 4);
+  A((void **)&a->d_pair, 486 * 2 * 2);
+  if (he == hipSuccess) he = hipMemcpy(a->d_gauss25, a->plan.gauss25, 49 * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(a->d_win, a->plan.win_ang1, 64 * 4, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(a->d_pair, a->plan.pair_tab, 486 * 2 * 2, hipMemcpyHostToDevice);
+  if (he != hipSuccess) {
+    set_error("sfmloc_akaze_create: %s", hipGetErrorString(he));
+    sfmloc_akaze_destroy(reinterpret_cast<sfmloc_akaze *>(a));
+    return he == hipErrorOutOfMemory ? SFMLOC_ENOMEM : SFMLOC_EHIP;
+  }
+  *out = reinterpret_cast<sfmloc_akaze *>(a);
+  return SFMLOC_OK;
+}
+
+int sfmloc_akaze_levels(const sfmloc_akaze *ak, int *n_levels, int *wh /*[32*2]*/) {
+  SFM_CHECK(ak && n_levels, SFMLOC_EINVAL, "sfmloc_akaze_levels: null argument");
+  const Akaze *a = reinterpret_cast<const Akaze *>(ak);
+  *n_levels = a->plan.nlev;
+  if (wh)
+    for (int i = 0; i < a->plan.nlev; ++i) {
+      wh[2 * i] = a->plan.lev[i].w;
+      wh[2 * i + 1] = a->plan.lev[i].h;
+    }
+  return SFMLOC_OK;
+}
+
+int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt) {
+  SFM_CHECK(ak, SFMLOC_EINVAL, "sfmloc_akaze_read_levels: null argument");
+  Akaze *a = reinterpret_cast<Akaze *>(ak);
+  SFM_HIP(hipSetDevice(a->device));
+  SFM_HIP(hipStreamSynchronize(a->stream));
+  if (ldet) SFM_HIP(hipMemcpy(ldet, a->d_Ldet, a->plan.total * sizeof(float), hipMemcpyDeviceToHost));
+  if (lt) SFM_HIP(hipMemcpy(lt, a->d_Lt, a->plan.total * sizeof(float), hipMemcpyDeviceToHost));
+  return SFMLOC_OK;
+}
+
+int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float *kpts /*[cap*6]*/,
+                                    uint8_t *desc64 /*[cap*64]*/, uint32_t cap, uint32_t *n_out) {
+  SFM_CHECK(ak && gray && n_out, SFMLOC_EINVAL, "sfmloc_akaze_detect_and_compute: null argument");
+  Akaze *a = reinterpret_cast<Akaze *>(ak);
+  const AkPlan &P = a->plan;
+  SFM_HIP(hipSetDevice(a->device));
+  int rc = build_scale_space(a, gray);
+  if (rc) return rc;
+  // candidates of every level
+  SFM_HIP(hipMemsetAsync(a->d_ncand, 0, sizeof(unsigned int), a->stream));
+  for (int i = 0; i < P.nlev; ++i) {
+    const AkLevel &L = P.lev[i];
+    const float ratio = (float)(1 << L.octave);
+    const int sigma_size_ = fround_h(L.esigma * 1.5f / ratio);
+    hipLaunchKernelGGL(k_extrema, grid2(L.w, L.h), dim3(128), 0, a->stream, a->d_Ldet + L.off, L.w, L.h, i, sigma_size_,
+                       a->thres, a->d_cand, a->cand_cap, a->d_ncand);
+  }
+  SFM_HIP(hipGetLastError());
+  unsigned int nc = 0;
+  SFM_HIP(hipMemcpyAsync(&nc, a->d_ncand, sizeof(nc), hipMemcpyDeviceToHost, a->stream));
+  SFM_HIP(hipStreamSynchronize(a->stream));
+  SFM_CHECK(nc <= a->cand_cap, SFMLOC_ECAP, "AKAZE: %u extrema candidates exceed the workspace (%u)", nc, a->cand_cap);
+  std::vector<Candidate9> cand(nc);
+  if (nc) SFM_HIP(hipMemcpy(cand.data(), a->d_cand, (size_t)nc * sizeof(Candidate9), hipMemcpyDeviceToHost));
+  std::sort(cand.begin(), cand.end(), [](const Candidate9 &p, const Candidate9 &q) {
+    if (p.level != q.level) return p.level < q.level;
+    if (p.y != q.y) return p.y < q.y;
+    return p.x < q.x;
+  });
+  // OpenCV's sequential duplicate suppression (same / previous level while scanning, then against the upper level)
+  std::vector<HostKpt> aux;
+  aux.reserve(nc);
+  for (const Candidate9 &c : cand) {
+    const AkLevel &L = P.lev[c.level];
+    HostKpt pt;
+    pt.response = fabsf(c.patch[4]);
+    pt.size = L.esigma * 1.5f;
+    pt.octave = L.octave;
+    pt.class_id = c.level;
+    pt.angle = 0.0f;
+    memcpy(pt.patch, c.patch, sizeof(pt.patch));
+    const float ratio = (float)(1 << L.octave);
+    pt.x = (float)c.x;
+    pt.y = (float)c.y;
+    bool is_extremum = true, is_repeated = false;
+    size_t id_repeated = 0;
+    for (size_t ik = 0; ik < aux.size(); ++ik) {
+      if (pt.class_id - 1 == aux[ik].class_id || pt.class_id == aux[ik].class_id) {
+        const float dx = pt.x * ratio - aux[ik].x, dy = pt.y * ratio - aux[ik].y;
+        const float dist = dx * dx + dy * dy;
+        if (dist <= pt.size * pt.size) {
+          if (pt.response > aux[ik].response) {
+            id_repeated = ik;
+            is_repeated = true;
+          } else {
+            is_extremum = false;
+          }
+          break;
+        }
+      }
+    }
+    if (!is_extremum) continue;
+    pt.x = pt.x * ratio;
+    pt.y = pt.y * ratio;
+    if (!is_repeated)
+      aux.push_back(pt);
+    else
+      aux[id_repeated] = pt;
+  }
+  std::vector<HostKpt> kept;
+  kept.reserve(aux.size());
+  for (size_t i = 0; i < aux.size(); ++i) {
+    bool rep = false;
+    for (size_t j = i + 1; j < aux.size(); ++j)
+      if (aux[i].class_id + 1 == aux[j].class_id) {
+        const float dx = aux[i].x - aux[j].x, dy = aux[i].y - aux[j].y;
+        if (dx * dx + dy * dy <= aux[i].size * aux[i].size && aux[i].response < aux[j].response) {
+          rep = true;
+          break;
+        }
+      }
+    if (!rep) kept.push_back(aux[i]);
+  }
+  // Do_Subpixel_Refinement on the carried 3x3 patch
+  std::vector<HostKpt> fin;
+  fin.reserve(kept.size());
+  for (HostKpt k : kept) {
+    const float ratio = (float)(1 << k.octave);
+    const int x = fround_h(k.x / ratio), y = fround_h(k.y / ratio);
+    const float *p = k.patch;  // p[(dy+1)*3 + dx+1]
+    const float Dx = 0.5f * (p[5] - p[3]);
+    const float Dy = 0.5f * (p[7] - p[1]);
+    const float Dxx = (p[5] + p[3]) - 2.0f * p[4];
+    const float Dyy = (p[7] + p[1]) - 2.0f * p[4];
+    const float Dxy = 0.25f * (p[8] + p[0]) - 0.25f * (p[2] + p[6]);
+    const float det = Dxx * Dyy - Dxy * Dxy;
+    if (det == 0.0f) continue;
+    const float d0 = (-Dx * Dyy + Dy * Dxy) / det;
+    const float d1 = (-Dy * Dxx + Dx * Dxy) / det;
+    if (fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f) {
+      k.x = ((float)x + d0) * ratio;
+      k.y = ((float)y + d1) * ratio;
+      k.size = k.size * 2.0f;
+      fin.push_back(k);
+    }
+  }
+  const uint32_t n = (uint32_t)fin.size();
+  *n_out = n;
+  SFM_CHECK(n <= cap, SFMLOC_ECAP, "AKAZE: %u keypoints, caller buffers hold %u", n, cap);
+  std::vector<float> kin((size_t)n * 4), ang(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    kin[4 * i] = fin[i].x;
+    kin[4 * i + 1] = fin[i].y;
+    kin[4 * i + 2] = fin[i].size;
+    kin[4 * i + 3] = (float)fin[i].class_id;
+  }
+  rc = orient_describe(a, kin, n, ang.data(), desc64);
+  if (rc) return rc;
+  if (kpts)
+    for (uint32_t i = 0; i < n; ++i) {
+      kpts[6 * i] = fin[i].x;
+      kpts[6 * i + 1] = fin[i].y;
+      kpts[6 * i + 2] = fin[i].size;
+      kpts[6 * i + 3] = ang[i];
+      kpts[6 * i + 4] = fin[i].response;
+      kpts[6 * i + 5] = (float)fin[i].class_id;
+    }
+  return SFMLOC_OK;
+}
+
+int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin, uint32_t n, uint8_t *desc64,
+                         float *angle_out) {
+  SFM_CHECK(ak && gray && (n == 0 || (kin && desc64)), SFMLOC_EINVAL, "sfmloc_akaze_compute: null argument");
+  Akaze *a = reinterpret_cast<Akaze *>(ak);
+  SFM_HIP(hipSetDevice(a->device));
+  int rc = build_scale_space(a, gray);
+  if (rc) return rc;
+  std::vector<float> k(kin, kin + (size_t)n * 4);
+  for (uint32_t i = 0; i < n; ++i) {
+    int lvl = (int)k[4 * i + 3];
+    lvl = lvl < 0 ? 0 : (lvl >= a->plan.nlev ? a->plan.nlev - 1 : lvl);
+    k[4 * i + 3] = (float)lvl;
+  }
+  return orient_describe(a, k, n, angle_out, desc64);
+}
+
+}  // extern "C"

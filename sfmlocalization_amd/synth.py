@@ -289,3 +289,23 @@ def write_map_to_disk(m: SynthMap, sfm_dir, match_dir, unposed_views=(), with_bo
         if with_bow is not None:
             fileio.write_mat_bin(os.path.join(match_dir, n + ".bow"), np.asarray(with_bow[k], np.float64).reshape(-1, 1))
     return names
+
+
+def texture_image(seed, height=480, width=640, n_blobs=400, n_rects=60):
+    """A grey test image with structure at several scales (blobs + rectangles), uint8."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = np.zeros((height, width), np.float64)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for _ in range(n_blobs):
+        cx, cy = rng.uniform(0, width), rng.uniform(0, height)
+        s, a = rng.uniform(2, 18), rng.uniform(-1, 1)
+        r = int(4 * s) + 1
+        x0, x1 = max(0, int(cx) - r), min(width, int(cx) + r + 1)
+        y0, y1 = max(0, int(cy) - r), min(height, int(cy) + r + 1)
+        img[y0:y1, x0:x1] += a * np.exp(-((xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2) / (2 * s * s))
+    for _ in range(n_rects):
+        x0, y0 = int(rng.uniform(0, width - 40)), int(rng.uniform(0, height - 40))
+        ww, hh = int(rng.uniform(8, 60)), int(rng.uniform(8, 60))
+        img[y0:y0 + hh, x0:x0 + ww] += rng.uniform(-0.8, 0.8)
+    img = (img - img.min()) / (img.max() - img.min())
+    return (img * 255).astype(np.uint8)

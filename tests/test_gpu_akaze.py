@@ -1,0 +1,63 @@
+"""GPU: K9 AKAZE + M-LDB against the CPU restatement -- scale space, keypoints and descriptor bits exact."""
+import numpy as np
+import pytest
+
+import sfmlocalization_amd as S
+from sfmlocalization_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits32(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("shape,seed", [((480, 640), 1), ((300, 300), 2), ((270, 481), 3)])
+def test_detect_and_compute_matches_oracle(oracle_c, shape, seed):
+    g = synth.texture_image(seed, *shape)
+    ekp, edesc, eldet, elt = oracle_c.akaze_detect_and_compute(g, want_levels=True)
+    ak = S.Akaze(shape[1], shape[0])
+    assert [tuple(x) for x in oracle_c.akaze_levels(shape[1], shape[0])] == ak.levels
+    kp, desc = ak.detect_and_compute(g)
+    ldet, lt = ak.read_levels()
+    np.testing.assert_array_equal(bits32(lt), bits32(elt), err_msg="nonlinear scale space Lt")
+    np.testing.assert_array_equal(bits32(ldet), bits32(eldet), err_msg="Hessian determinant response")
+    assert len(kp) == len(ekp) and len(kp) > 10
+    np.testing.assert_array_equal(bits32(kp), bits32(ekp), err_msg="keypoints (x, y, size, angle, response, level)")
+    np.testing.assert_array_equal(desc[:, :61], edesc)
+    assert (desc[:, 61:] == 0).all()
+    ak.close()
+
+
+def test_dense_compute_matches_oracle(oracle_c):
+    g = synth.texture_image(4, 300, 300)
+    xs = np.arange(0, 300, 6, dtype=np.float32)
+    kin, size = [], 4.0
+    for s in range(4):
+        kin += [(x, y, size, s) for y in xs for x in xs]
+        size *= 1.5
+    kin = np.array(kin, np.float32)
+    ak = S.Akaze(300, 300)
+    desc, ang = ak.compute(g, kin)
+    edesc, eang = oracle_c.akaze_compute(g, kin)
+    np.testing.assert_array_equal(bits32(ang), bits32(eang))
+    np.testing.assert_array_equal(desc[:, :61], edesc)
+    ak.close()
+
+
+def test_extracted_query_localises(oracle_c):
+    """Descriptors extracted by the GPU from an image feed the matcher: an image and its shifted copy match."""
+    g = synth.texture_image(5)
+    ak = S.Akaze(640, 480)
+    kp, desc = ak.detect_and_compute(g)
+    kp2, desc2 = ak.detect_and_compute(np.roll(np.roll(g, 6, axis=0), 10, axis=1))
+    view_off = np.array([0, len(desc)], np.uint32)
+    with S.Map([0], view_off, desc) as m:
+        q = m.query(desc2)
+        m.match_putative(q)
+        cnt, mi, mj, md = m.putative_read()
+        n = int(cnt[0])
+        assert n > 0.7 * len(kp)
+        shift = kp2[mj[:n], :2] - kp[mi[:n], :2]
+        assert np.abs(np.median(shift, axis=0) - [10, 6]).max() < 0.05
+    ak.close()
