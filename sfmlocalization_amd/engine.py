@@ -30,6 +30,21 @@ def _image_size(path, default):
         return default
 
 
+def _load_gray(path):
+    """imread(filename, IMREAD_GRAYSCALE) (AKAZEOpenCV.cpp:61) through PIL."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            return np.asarray(im.convert("L"), dtype=np.uint8)
+    except Exception:
+        return None
+
+
+def synth_round6(a):
+    a = np.asarray(a, dtype=np.float32)
+    return np.array([np.float32(float("%.6g" % float(v))) for v in a.ravel()], dtype=np.float32).reshape(a.shape)
+
+
 class LocalizeEngine:
     """LocalizeEngine(sfmDataDir, matchDir, AmatFile, secondTestRatio, ransacRound, ransacPrecision,
     guidedMatching, beaconKnnNum=0, bowKnnNum=0)   -- LocalizeEngine.h:75-77."""
@@ -51,7 +66,34 @@ class LocalizeEngine:
             self.A = np.asarray(y["A"], dtype=np.float64).reshape(3, 4)
 
     def close(self):
+        for ak in getattr(self, "_akaze", {}).values():
+            ak.close()
         self.map.close()
+
+    def extract(self, gray):
+        """extractAKAZESingleImg's compute part (AKAZEOpenCV.cpp:44-46,67) on the GPU, with the map's
+        image_describer.txt options (AKAZEOption.cpp:44-55): -> desc [n x 64], kpts [n x 4] (x, y, size, angle)."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        if not hasattr(self, "_akaze"):
+            self._akaze = {}
+            self._akaze_opt = fileio.read_image_describer(os.path.join(self.match_dir, "image_describer.txt"))
+            if int(self._akaze_opt["desc_ch"]) != 3:
+                raise NotImplementedError("only the 3-channel M-LDB descriptor the reference uses is implemented")
+        if (w, h) not in self._akaze:
+            o = self._akaze_opt
+            self._akaze[(w, h)] = capi.Akaze(w, h, int(o["nOct"]), int(o["nOctLay"]), float(o["thres"]),
+                                             device=int(self.params.device))
+        kp, desc = self._akaze[(w, h)].detect_and_compute(gray)
+        return desc, kp[:, :4]
+
+    def localize_image(self, gray, **kw):
+        """LocalizeEngine::localize on an image (LocalizeEngine.cc:288-661): extract, then localize()."""
+        desc, kp = self.extract(gray)
+        h, w = np.asarray(gray).shape
+        res, ex = self.localize(desc, kp[:, :2], w, h, **kw)
+        ex["n_features"] = len(desc)
+        return res, ex
 
     # getLocalViews (SfMDataUtils.cpp:210-227 / LocalizeEngine.cc:200-): NOTE the reference compares the SQUARED
     # distance with the un-squared radius; reproduced.
@@ -184,14 +226,20 @@ def main(argv=None):
             match_next -= 1
         base = os.path.splitext(os.path.basename(img))[0]
         fdir = o["featdir"] or os.path.dirname(img)
+        w, h = _image_size(img, default_wh)
         try:
             desc = fileio.read_desc(os.path.join(fdir, base + ".desc"))
             feat = fileio.read_feat(os.path.join(fdir, base + ".feat"))
         except (IOError, OSError) as e:
-            print(f"cannot read precomputed features of {img}: {e}", file=sys.stderr)
-            fileio.write_result_json(out_dir, img, sfm_json, match_dir)
-            continue
-        w, h = _image_size(img, default_wh)
+            gray = _load_gray(img)
+            if gray is None:
+                print(f"cannot read {img} nor precomputed features for it: {e}", file=sys.stderr)
+                fileio.write_result_json(out_dir, img, sfm_json, match_dir)
+                continue
+            print("Extract features from query image")          # localization.cpp:313
+            desc, feat = eng.extract(gray)
+            feat = synth_round6(feat)                            # what the reference reads back from its .feat
+            h, w = gray.shape
         center = (o["cenLocX"], o["cenLocY"], o["cenLocZ"]) if o["cenRadius"] > 0 else None
         bow = None
         if o["knnbow"] > 0 and o["bowModelFile"]:

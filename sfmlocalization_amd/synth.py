@@ -309,3 +309,42 @@ def texture_image(seed, height=480, width=640, n_blobs=400, n_rects=60):
         img[y0:y0 + hh, x0:x0 + ww] += rng.uniform(-0.8, 0.8)
     img = (img - img.min()) / (img.max() - img.min())
     return (img * 255).astype(np.uint8)
+
+
+def render_plane_view(texture, px_per_m, R, C, focal, width, height):
+    """Pinhole image of the textured plane z = 0 (texture pixel (i, j) covers x = j/px_per_m, y = i/px_per_m)
+    seen from a camera with world->camera rotation R and centre C.  Bilinear sampling, border replicated."""
+    from scipy import ndimage
+    ppx, ppy = width / 2.0, height / 2.0
+    u, v = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
+    rays_c = np.stack([(u - ppx) / focal, (v - ppy) / focal, np.ones_like(u)], -1)
+    rays_w = rays_c @ R                       # R^T applied to each ray (rows of R are camera axes)
+    t = -C[2] / rays_w[..., 2]
+    X = C[0] + t * rays_w[..., 0]
+    Y = C[1] + t * rays_w[..., 1]
+    img = ndimage.map_coordinates(texture.astype(np.float64), [Y * px_per_m, X * px_per_m], order=1, mode="nearest")
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def backproject_to_plane(kpt_xy, R, C, focal, width, height):
+    """3-D points (z = 0) seen at the given pixels."""
+    ppx, ppy = width / 2.0, height / 2.0
+    rays_c = np.stack([(kpt_xy[:, 0] - ppx) / focal, (kpt_xy[:, 1] - ppy) / focal, np.ones(len(kpt_xy))], -1)
+    rays_w = rays_c @ R
+    t = -C[2] / rays_w[:, 2]
+    return np.stack([C[0] + t * rays_w[:, 0], C[1] + t * rays_w[:, 1], np.zeros(len(kpt_xy))], -1)
+
+
+def plane_camera(rng, center_xy, height_m, tilt=0.25):
+    """A camera above the plane looking down with a random tilt and roll: (R world->camera, C)."""
+    C = np.array([center_xy[0], center_xy[1], height_m])
+    target = np.array([center_xy[0] + rng.uniform(-tilt, tilt) * height_m,
+                       center_xy[1] + rng.uniform(-tilt, tilt) * height_m, 0.0])
+    z = target - C
+    z /= np.linalg.norm(z)
+    roll = rng.uniform(0, 2 * np.pi)
+    up = np.array([np.cos(roll), np.sin(roll), 0.0])
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    return np.stack([x, y, z]), C
