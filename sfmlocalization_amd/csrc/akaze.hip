@@ -200,6 +200,8 @@ __device__ void det_sincosf(float a, float *s, float *c) {
 }
 
 // ---- pixel kernels -----------------------------------------------------------------------------------------------
+constexpr int kGradRows = 16;  // image rows one block of the contrast-factor kernels walks
+
 struct Taps {
   float k[9];
 };
@@ -264,29 +266,46 @@ __global__ void k_halfsample(const float *__restrict__ src, int sw, int sh, floa
   dst[(size_t)y * dw + x] = acc;
 }
 
-// compute_k_percentile: maximum gradient magnitude over the interior, then its 300-bin histogram
-__global__ void k_grad_max(const float *__restrict__ lx, const float *__restrict__ ly, int w, int h,
-                           unsigned int *hmax_bits) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
-  const float a = lx[(size_t)y * w + x], b = ly[(size_t)y * w + x];
-  const float m = sqrtf(a * a + b * b);
-  atomicMax(hmax_bits, __float_as_uint(m));  // non-negative floats order like their bit patterns
+// compute_k_percentile: maximum gradient magnitude over the interior, then its 300-bin histogram.
+// One atomic per wave (max) / per block and bin (histogram): a single global word hit by every pixel serialises.
+__global__ __launch_bounds__(128) void k_grad_max(const float *__restrict__ lx, const float *__restrict__ ly, int w,
+                                                  int h, unsigned int *hmax_bits) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.0f;
+  for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y)
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+      const float a = lx[(size_t)y * w + x], b = ly[(size_t)y * w + x];
+      m = fmaxf(m, sqrtf(a * a + b * b));
+    }
+  unsigned int bits = __float_as_uint(m);  // non-negative floats order like their bit patterns
+  for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off, 64));
+  if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(hmax_bits, bits);
 }
 
-__global__ void k_grad_hist(const float *__restrict__ lx, const float *__restrict__ ly, int w, int h,
-                            const unsigned int *hmax_bits, unsigned int *hist /*[301]: 300 bins + npoints*/) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+__global__ __launch_bounds__(128) void k_grad_hist(const float *__restrict__ lx, const float *__restrict__ ly, int w,
+                                                   int h, const unsigned int *hmax_bits,
+                                                   unsigned int *hist /*[301]: 300 bins + npoints*/) {
+  __shared__ unsigned int lh[301];
+  for (int i = threadIdx.x; i < 301; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const float hmax = __uint_as_float(*hmax_bits);
-  const float a = lx[(size_t)y * w + x], b = ly[(size_t)y * w + x];
-  const float m = sqrtf(a * a + b * b);
-  if (m != 0.0f) {
-    int nbin = (int)floorf(300.0f * (m / hmax));
-    if (nbin == 300) nbin--;
-    atomicAdd(&hist[nbin], 1u);
-    atomicAdd(&hist[300], 1u);
-  }
+  unsigned int mine = 0;
+  for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y)
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+      const float a = lx[(size_t)y * w + x], b = ly[(size_t)y * w + x];
+      const float m = sqrtf(a * a + b * b);
+      if (m != 0.0f) {
+        int nbin = (int)floorf(300.0f * (m / hmax));
+        if (nbin == 300) nbin--;
+        atomicAdd(&lh[nbin], 1u);
+        ++mine;
+      }
+    }
+  if (mine) atomicAdd(&lh[300], mine);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 301; i += blockDim.x)
+    if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
 __global__ void k_kcontrast(const unsigned int *hmax_bits, const unsigned int *hist, float *kcontrast) {
@@ -309,8 +328,8 @@ __global__ void k_pm_g2(const float *__restrict__ lx, const float *__restrict__ 
   dst[i] = 1.0f / (1.0f + inv_k * (lx[i] * lx[i] + ly[i] * ly[i]));
 }
 
-// nld_step_scalar: flux into `step_out`, zero flux across the image border
-__global__ void k_nld_flux(const float *__restrict__ Ld, const float *__restrict__ c, float *__restrict__ step_out,
+// nld_step_scalar: Ld_out = Ld + half_step * flux, zero flux across the image border (ping-pong buffers)
+__global__ void k_nld_step(const float *__restrict__ Ld, const float *__restrict__ c, float *__restrict__ Ld_out,
                            int w, int h, float half_step) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= w) return;
@@ -321,7 +340,8 @@ __global__ void k_nld_flux(const float *__restrict__ Ld, const float *__restrict
   if (x > 0) xneg = (c[p - 1] + cc) * (v - Ld[p - 1]);
   if (y + 1 < h) ypos = (cc + c[p + w]) * (Ld[p + w] - v);
   if (y > 0) yneg = (c[p - w] + cc) * (v - Ld[p - w]);
-  step_out[p] = half_step * (((xpos - xneg) + ypos) - yneg);
+  const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
+  Ld_out[p] = v + stp;
 }
 
 __global__ void k_add(float *__restrict__ a, const float *__restrict__ b, size_t n) {
@@ -584,8 +604,9 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
   if (!rc) rc = scharr(a, a->d_t0, a->d_t2, w, h, 0, 1, 3.0f, 10.0f);
   if (rc) return rc;
   AK_HIP(hipMemsetAsync(a->d_hist, 0, 302 * sizeof(unsigned int), s));
-  hipLaunchKernelGGL(k_grad_max, grid2(w, h), dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist);
-  hipLaunchKernelGGL(k_grad_hist, grid2(w, h), dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist, a->d_hist + 1);
+  const dim3 ggrid((w + 127) / 128, (h + kGradRows - 1) / kGradRows);
+  hipLaunchKernelGGL(k_grad_max, ggrid, dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist);
+  hipLaunchKernelGGL(k_grad_hist, ggrid, dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist, a->d_hist + 1);
   hipLaunchKernelGGL(k_kcontrast, dim3(1), dim3(1), 0, s, a->d_hist, a->d_hist + 1, a->d_kcontrast);
   AK_HIP(hipGetLastError());
   for (int i = 1; i < P.nlev; ++i) {
@@ -603,12 +624,14 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_pm_g2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a->d_t0, a->d_t1, a->d_t2, n,
                        a->d_kcontrast, L.octave);
+    float *cur = Lt, *nxt = a->d_t3;
     for (int st = 0; st < L.nsteps; ++st) {
-      hipLaunchKernelGGL(k_nld_flux, grid2(L.w, L.h), dim3(128), 0, s, Lt, a->d_t2, a->d_t3, L.w, L.h,
+      hipLaunchKernelGGL(k_nld_step, grid2(L.w, L.h), dim3(128), 0, s, cur, a->d_t2, nxt, L.w, L.h,
                          0.5f * L.tsteps[st]);
-      hipLaunchKernelGGL(k_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Lt, a->d_t3, n);
+      std::swap(cur, nxt);
     }
     AK_HIP(hipGetLastError());
+    if (cur != Lt) AK_HIP(hipMemcpyAsync(Lt, cur, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   for (int i = 0; i < P.nlev; ++i) {
     const AkLevel &L = P.lev[i];
