@@ -57,6 +57,33 @@ __device__ void bitonic_sort(uint64_t *key, uint32_t *idx, int P) {
   }
 }
 
+// the same sort run by every wave of the block on its own segment (segment w starts at w*seg): the loop
+// structure depends only on P, so block-wide barriers serve all waves at once
+__device__ void bitonic_sort_per_wave(uint64_t *key, uint32_t *idx, int P, int seg) {
+  const int lane = threadIdx.x & 63;
+  uint64_t *kw = key + (size_t)(threadIdx.x >> 6) * seg;
+  uint32_t *iw = idx + (size_t)(threadIdx.x >> 6) * seg;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (P >> 1); t += 64) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i + j;
+        const bool up = (i & k) == 0;
+        const uint64_t ka = kw[i], kb = kw[l];
+        const uint32_t ia = iw[i], ib = iw[l];
+        const bool a_gt_b = pair_less(kb, ib, ka, ia);
+        if (a_gt_b == up) {
+          kw[i] = kb;
+          kw[l] = ka;
+          iw[i] = ib;
+          iw[l] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 struct NfaBest {
   double nfa;
   int k;
@@ -103,6 +130,33 @@ __device__ NfaBest best_nfa_block(const uint64_t *key, int n, int s, double max_
     }
   }
   return r;
+}
+
+// bestNFA over one wave's sorted segment; every lane of the wave returns the result
+__device__ NfaBest best_nfa_wave(const uint64_t *key, int n, int s, double max_thr, double logalpha0, double mult,
+                                 double loge0, const float *logc_n, const float *logc_k) {
+  double lb = pos_inf();
+  int lk = 0x7FFFFFFF;
+  for (int kk = s + 1 + (int)(threadIdx.x & 63); kk <= n; kk += 64) {
+    const double ek = u2d(key[kk - 1]);
+    if (ek <= max_thr) {
+      const double logalpha = logalpha0 + mult * det_log10(ek + (double)FLT_EPSILON);
+      const double nfa = loge0 + logalpha * (double)(kk - s) + (double)logc_n[kk] + (double)logc_k[kk];
+      if (nfa < lb) {
+        lb = nfa;
+        lk = kk;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ob = __shfl_xor(lb, off, 64);
+    const int ok = __shfl_xor(lk, off, 64);
+    if (ob < lb || (ob == lb && ok < lk)) {
+      lb = ob;
+      lk = ok;
+    }
+  }
+  return NfaBest{lb, lk};
 }
 
 // logcombi tables of OpenMVG (float): logc_n[k] = log10 C(n,k), logc_k[m] = log10 C(m,s); L10[i] = log10(i).
@@ -499,6 +553,8 @@ __global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
   logcombi_tables_block(3, n, A.L10, A.logc_n, A.logc_k);
 }
 
+constexpr int kP3pWaveSeg = kP3pMaxN / 4;  // elements one wave sorts when the four models run side by side
+
 struct P3pShared {
   uint64_t key[kP3pMaxN];
   uint32_t idx[kP3pMaxN];
@@ -543,6 +599,42 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
   double best = pos_inf();
   int best_k = 0, best_m = -1;
   double best_err = pos_inf();
+  if (P <= kP3pWaveSeg) {
+    // fast path: the (up to 4) models of the hypothesis are evaluated side by side, one wave each
+    const int wv = tid >> 6, lane = tid & 63;
+    uint64_t *kw = S.key + (size_t)wv * kP3pWaveSeg;
+    uint32_t *iw = S.idx + (size_t)wv * kP3pWaveSeg;
+    double M[12];
+    for (int q = 0; q < 12; ++q) M[q] = (wv < nm) ? S.models[12 * wv + q] : 0.0;
+    for (int p = lane; p < P; p += 64) {
+      uint64_t kv = ~0ull;
+      if (p < n && wv < nm)
+        kv = d2u(err_resection(M, A.pt3d[3 * p], A.pt3d[3 * p + 1], A.pt3d[3 * p + 2], A.xn[2 * p], A.xn[2 * p + 1]));
+      kw[p] = kv;
+      iw[p] = (uint32_t)p;
+    }
+    __syncthreads();
+    bitonic_sort_per_wave(S.key, S.idx, P, kP3pWaveSeg);
+    NfaBest r{pos_inf(), 0x7FFFFFFF};
+    if (wv < nm) r = best_nfa_wave(kw, n, s, pos_inf(), logalpha0, 1.0, loge0, A.logc_n, A.logc_k);
+    if (lane == 0) {
+      S.red_nfa[wv] = r.nfa;
+      S.red_k[wv] = r.k;
+    }
+    __syncthreads();
+    for (int k = 0; k < nm; ++k)
+      if (S.red_nfa[k] < best) {  // strict: the first model of the hypothesis wins ties, as the sequential loop does
+        best = S.red_nfa[k];
+        best_k = S.red_k[k];
+        best_m = k;
+      }
+    if (best_m >= 0) {
+      best_err = u2d(S.key[(size_t)best_m * kP3pWaveSeg + best_k - 1]);
+      int32_t *dst = A.hyp_inl + (size_t)b * A.max_n;
+      const uint32_t *src = S.idx + (size_t)best_m * kP3pWaveSeg;
+      for (int p = tid; p < best_k; p += kThreads) dst[p] = (int32_t)src[p];
+    }
+  } else
   for (int k = 0; k < nm; ++k) {
     double M[12];
     for (int q = 0; q < 12; ++q) M[q] = S.models[12 * k + q];

@@ -196,6 +196,7 @@ GDN int solve_cubic(double a3, double a2, double a1, double a0, double r[3]) {
 }
 
 GD double quartic_polish(const double a[5], double x) {
+  #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const double f = (((a[0] * x + a[1]) * x + a[2]) * x + a[3]) * x + a[4];
     const double df = ((4.0 * a[0] * x + 3.0 * a[1]) * x + 2.0 * a[2]) * x + a[3];
@@ -207,7 +208,7 @@ GD double quartic_polish(const double a[5], double x) {
   return x;
 }
 
-GDN void solve_quartic_real(const double a[5], double out[4]) {
+GD void solve_quartic_real(const double a[5], double out[4]) {
   const double b = a[1] / a[0], c = a[2] / a[0], d = a[3] / a[0], e = a[4] / a[0];
   const double b2 = b * b;
   const double p = c - 0.375 * b2;
@@ -217,6 +218,7 @@ GDN void solve_quartic_real(const double a[5], double out[4]) {
   double y[4];
   int real[4] = {0, 0, 0, 0};
   if (is_nan(p) || is_nan(q) || is_nan(r) || is_inf(p) || is_inf(q) || is_inf(r)) {
+    #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = q_nan();
     return;
   }
@@ -279,6 +281,7 @@ GDN void solve_quartic_real(const double a[5], double out[4]) {
     const double g = q / (2.0 * s);
     const double beta[2] = {-s, s};
     const double gamma[2] = {h + g, h - g};
+    #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const double disc = beta[k] * beta[k] - 4.0 * gamma[k];
       if (disc >= 0.0) {
@@ -292,6 +295,7 @@ GDN void solve_quartic_real(const double a[5], double out[4]) {
       }
     }
   }
+  #pragma unroll
   for (int i = 0; i < 4; ++i) {
     double x = y[i] + shift;
     if (real[i]) x = quartic_polish(a, x);
@@ -399,16 +403,20 @@ GD void matvec3(const double M[9], const double v[3], double o[3]) {
   o[2] = (M[6] * v[0] + M[7] * v[1]) + M[8] * v[2];
 }
 GD void matmul3(const double A[9], const double B[9], double C[9]) {
+  #pragma unroll
   for (int i = 0; i < 3; ++i)
+    #pragma unroll
     for (int j = 0; j < 3; ++j) C[3 * i + j] = (A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j]) + A[3 * i + 2] * B[6 + j];
 }
 GD void transpose3(const double A[9], double T[9]) {
+  #pragma unroll
   for (int i = 0; i < 3; ++i)
+    #pragma unroll
     for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * j + i];
 }
 
 // x2d: 3 x 2 normalised image points, X: 3 x 3 world points (row = point); models: 4 x 12 [R|t] row-major.
-GDN int p3p_kneip(const double *x2d, const double *X, double *models) {
+GD int p3p_kneip(const double *x2d, const double *X, double *models) {
   double P1[3] = {X[0], X[1], X[2]}, P2[3] = {X[3], X[4], X[5]}, P3[3] = {X[6], X[7], X[8]};
   double f1[3] = {x2d[0], x2d[1], 1.0}, f2[3] = {x2d[2], x2d[3], 1.0}, f3[3] = {x2d[4], x2d[5], 1.0};
   normalize3(f1);
@@ -421,6 +429,7 @@ GDN int p3p_kneip(const double *x2d, const double *X, double *models) {
   if (norm3(cr) == 0.0) return 0;
 
   double e1[3], e2[3], e3[3], T[9], f3t[3];
+  #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     e1[0] = f1[0];
     e1[1] = f1[1];
@@ -428,6 +437,7 @@ GDN int p3p_kneip(const double *x2d, const double *X, double *models) {
     cross3(f1, f2, e3);
     normalize3(e3);
     cross3(e3, e1, e2);
+    #pragma unroll
     for (int k = 0; k < 3; ++k) {
       T[k] = e1[k];
       T[3 + k] = e2[k];
@@ -435,6 +445,7 @@ GDN int p3p_kneip(const double *x2d, const double *X, double *models) {
     }
     matvec3(T, f3, f3t);
     if (pass == 0 && f3t[2] > 0.0) {
+      #pragma unroll
       for (int k = 0; k < 3; ++k) {
         double t = f1[k];
         f1[k] = f2[k];
@@ -455,6 +466,7 @@ GDN int p3p_kneip(const double *x2d, const double *X, double *models) {
   cross3(n1, p31, n3);
   normalize3(n3);
   cross3(n3, n1, n2);
+  #pragma unroll
   for (int k = 0; k < 3; ++k) {
     N[k] = n1[k];
     N[3 + k] = n2[k];
@@ -493,6 +505,7 @@ GDN int p3p_kneip(const double *x2d, const double *X, double *models) {
 
   double NT[9];
   transpose3(N, NT);
+  #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const double cos_theta = roots[i];
     const double cot_alpha =
@@ -517,6 +530,7 @@ GDN int p3p_kneip(const double *x2d, const double *X, double *models) {
     matmul3(TT, QN, R);
     matvec3(R, C, t);
     double *M = models + 12 * i;
+    #pragma unroll
     for (int r = 0; r < 3; ++r) {
       M[4 * r + 0] = R[3 * r + 0];
       M[4 * r + 1] = R[3 * r + 1];
@@ -551,7 +565,7 @@ GD double err_resection(const double *M, double X, double Y, double Z, double x,
 }
 
 // OpenMVG KRt_From_P (RQ by Givens), all row-major
-GDN void krt_from_p(const double *P, double *Kout, double *Rout, double *tout) {
+GD void krt_from_p(const double *P, double *Kout, double *Rout, double *tout) {
   double K[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
   double Q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double T1[9], T2[9], G[9], GT[9];
@@ -562,9 +576,11 @@ GDN void krt_from_p(const double *P, double *Kout, double *Rout, double *tout) {
     s = s / l;
     G[0] = 1; G[1] = 0; G[2] = 0; G[3] = 0; G[4] = c; G[5] = -s; G[6] = 0; G[7] = s; G[8] = c;
     matmul3(K, G, T1);
+    #pragma unroll
     for (int i = 0; i < 9; ++i) K[i] = T1[i];
     transpose3(G, GT);
     matmul3(GT, Q, T2);
+    #pragma unroll
     for (int i = 0; i < 9; ++i) Q[i] = T2[i];
   }
   if (K[6] != 0.0) {
@@ -574,9 +590,11 @@ GDN void krt_from_p(const double *P, double *Kout, double *Rout, double *tout) {
     s = s / l;
     G[0] = c; G[1] = 0; G[2] = s; G[3] = 0; G[4] = 1; G[5] = 0; G[6] = -s; G[7] = 0; G[8] = c;
     matmul3(K, G, T1);
+    #pragma unroll
     for (int i = 0; i < 9; ++i) K[i] = T1[i];
     transpose3(G, GT);
     matmul3(GT, Q, T2);
+    #pragma unroll
     for (int i = 0; i < 9; ++i) Q[i] = T2[i];
   }
   if (K[3] != 0.0) {
@@ -586,24 +604,32 @@ GDN void krt_from_p(const double *P, double *Kout, double *Rout, double *tout) {
     s = s / l;
     G[0] = c; G[1] = -s; G[2] = 0; G[3] = s; G[4] = c; G[5] = 0; G[6] = 0; G[7] = 0; G[8] = 1;
     matmul3(K, G, T1);
+    #pragma unroll
     for (int i = 0; i < 9; ++i) K[i] = T1[i];
     transpose3(G, GT);
     matmul3(GT, Q, T2);
+    #pragma unroll
     for (int i = 0; i < 9; ++i) Q[i] = T2[i];
   }
   double R[9];
+  #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = Q[i];
   if (K[8] < 0.0)
+    #pragma unroll
     for (int i = 0; i < 9; ++i) {
       K[i] = -K[i];
       R[i] = -R[i];
     }
   if (K[4] < 0.0) {
+    #pragma unroll
     for (int i = 0; i < 3; ++i) K[3 * i + 1] = -K[3 * i + 1];
+    #pragma unroll
     for (int j = 0; j < 3; ++j) R[3 + j] = -R[3 + j];
   }
   if (K[0] < 0.0) {
+    #pragma unroll
     for (int i = 0; i < 3; ++i) K[3 * i] = -K[3 * i];
+    #pragma unroll
     for (int j = 0; j < 3; ++j) R[j] = -R[j];
   }
   double t[3];
@@ -613,16 +639,22 @@ GDN void krt_from_p(const double *P, double *Kout, double *Rout, double *tout) {
   const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
                      R[2] * (R[3] * R[7] - R[4] * R[6]);
   if (det < 0.0) {
+    #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = -R[i];
+    #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = -t[i];
   }
   const double k22 = K[8];
+  #pragma unroll
   for (int i = 0; i < 9; ++i) Kout[i] = K[i] / k22;
+  #pragma unroll
   for (int i = 0; i < 9; ++i) Rout[i] = R[i];
+  #pragma unroll
   for (int i = 0; i < 3; ++i) tout[i] = t[i];
 }
 
 GD void center_from_rt(const double *R, const double *t, double *c) {
+  #pragma unroll
   for (int i = 0; i < 3; ++i) c[i] = -((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]);
 }
 
