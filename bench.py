@@ -15,7 +15,9 @@ import os
 import sys
 import time
 
-import numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one HW queue per in-flight context (sfmlocalization_amd/_lib.py)
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -23,6 +25,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 VALU_PEAK_TOPS = 39.1  # measured ceiling of the xor+bcnt instruction mix at 8 waves/SIMD (profiles/r01_valu_rates.jsonl)
 OPS_PER_PAIR = 35  # 16 xor + 16 bcnt + lshl_or + med3 + min (hamming.hip)
+
+
+# HBM bytes per K1 launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs of this same
+# command, corrected as MI355X_MICROARCH.md prescribes; tools/run_profile_r01c.sh + tools/pmc_summary.py)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary_screen.json")
+
+
+def pmc_traffic(default_workload):
+    """HBM bytes per launch of the dominant kernel, or None when no PMC pass exists for this workload."""
+    if not default_workload or not os.path.exists(PMC_SUMMARY):
+        return None, None
+    with open(PMC_SUMMARY) as fh:
+        d = json.load(fh)
+    tot = 0.0
+    for k in ("k_hamming_screen", "k_hamming_rows"):
+        if k not in d or "hbm_bytes_per_dispatch" not in d[k]:
+            return None, None
+        tot += d[k]["hbm_bytes_per_dispatch"]["total"]
+    return tot, os.path.relpath(PMC_SUMMARY, ROOT)
 
 
 def parse():
@@ -34,7 +55,7 @@ def parse():
     ap.add_argument("--desc-per-view", type=int, default=2000)
     ap.add_argument("--nq", type=int, default=2000)
     ap.add_argument("--queries", type=int, default=8, help="distinct synthetic queries cycled through")
-    ap.add_argument("--in-flight", type=int, default=3, help="queries in flight (contexts); 1 = latency mode")
+    ap.add_argument("--in-flight", type=int, default=4, help="queries in flight (contexts); 1 = latency mode")
     ap.add_argument("--batch", type=int, default=16, help="queries per all-gather when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -182,8 +203,12 @@ def main():
     alg_bytes = 64 * rows_rank + 64 * a.nq + 12 * n_match
     achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
     pairs = rows_rank * a.nq
-    valu = pairs * OPS_PER_PAIR / (k1_ms * 1e-3) / 1e12
+    # VALU lane-instructions K1 actually issued (counted by the library: the screening kernel rejects most pairs on
+    # a 10-dword prefix distance, so this is below 35 per pair)
+    lane_ops = st.hamming_lane_ops / max(1, st.launches[0])
+    valu = lane_ops / (k1_ms * 1e-3) / 1e12
 
+    traffic, traffic_src = pmc_traffic(world == 1 and (a.views, a.desc_per_view, a.nq) == (1000, 2000, 2000))
     if rank == 0:
         out = {
             "metric": "query images localized/sec",
@@ -211,11 +236,17 @@ def main():
                          "geoMatch(K3)": st.total_ms[2] / a.steps, "matchSet(K4)": st.total_ms[3] / a.steps,
                          "PnP(K5)": st.total_ms[4] / a.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_hamming_top2", "kernel_ms": k1_ms, "algorithmic_bytes": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (PMC FETCH_SIZE*2+WRITE_SIZE)", "traffic_source": traffic_src,
+                         "kernel": "k_hamming_screen (+k_hamming_rows)", "kernel_ms": k1_ms,
+                         "algorithmic_bytes": alg_bytes,
                          "note": "SURVEY F7: at N_q=2000 the kernel is VALU-bound (intensity N_q/2 lane-ops/byte)",
                          "valu": {"achieved": valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
-                                  "frac": valu / VALU_PEAK_TOPS, "ops_per_pair": OPS_PER_PAIR}},
+                                  "frac": valu / VALU_PEAK_TOPS, "ops_per_pair_exact": OPS_PER_PAIR,
+                                  "ops_per_pair_issued": lane_ops / max(1, pairs),
+                                  "pairs_per_s": pairs / (k1_ms * 1e-3),
+                                  "pairs_finished_frac": st.hamming_pairs_finished / max(1, st.hamming_pairs),
+                                  "rows_flagged_per_query": st.hamming_rows_flagged / max(1, st.launches[0])}},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, queries, a.cpu_seconds)

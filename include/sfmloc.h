@@ -69,6 +69,8 @@ typedef struct sfmloc_params {
   int refine_pose;          /* north-star extension A13; 0 = reference-equivalent output */
   int device;               /* HIP device ordinal */
   int profile;              /* 1 = bracket each kernel with HIP events on the handle's stream */
+  int exact_rows;           /* 1 = keep the exact (nearest, second) pair of EVERY bank row (sfmloc_putative_read_rows);
+                               0 = rows the screening kernel proves rejected are not finished (same matches) */
 } sfmloc_params;
 
 void sfmloc_default_params(sfmloc_params *p);
@@ -347,6 +349,10 @@ typedef struct sfmloc_kernel_stats {
   uint64_t launches[SFMLOC_K_COUNT];
   uint64_t hamming_pairs;      /* bank rows x query rows compared since reset */
   uint64_t hamming_alg_bytes;  /* 64*rows + 64*Nq + 12*matches is finalised by the caller */
+  uint64_t hamming_lane_ops;       /* VALU lane-instructions K1 issued for those pairs (35 per exact pair; fewer when
+                                      the screening kernel rejects a pair on its prefix distance) */
+  uint64_t hamming_pairs_finished; /* screened pairs whose full distance had to be computed */
+  uint64_t hamming_rows_flagged;   /* bank rows the screening kernel handed to the exact kernel */
 } sfmloc_kernel_stats;
 int sfmloc_stats_read(sfmloc_map *map, sfmloc_kernel_stats *out); /* synchronises */
 int sfmloc_stats_reset(sfmloc_map *map);

@@ -33,6 +33,7 @@ class Params(C.Structure):
         ("refine_pose", C.c_int),
         ("device", C.c_int),
         ("profile", C.c_int),
+        ("exact_rows", C.c_int),
     ]
 
 
@@ -87,7 +88,9 @@ class ScanInfo(C.Structure):
 
 class KernelStats(C.Structure):
     _fields_ = [("total_ms", C.c_double * K_COUNT), ("launches", C.c_uint64 * K_COUNT),
-                ("hamming_pairs", C.c_uint64), ("hamming_alg_bytes", C.c_uint64)]
+                ("hamming_pairs", C.c_uint64), ("hamming_alg_bytes", C.c_uint64),
+                ("hamming_lane_ops", C.c_uint64), ("hamming_pairs_finished", C.c_uint64),
+                ("hamming_rows_flagged", C.c_uint64)]
 
 
 # every symbol include/sfmloc.h declares (tests check the library exports each one)

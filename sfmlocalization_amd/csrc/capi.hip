@@ -130,7 +130,7 @@ void free_ctx(Ctx *c) {
                   c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
                   c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,    c->d_pair_qfeat,
                   c->d_pair_landmark, c->d_inlier_idx, c->d_p3p_state, c->d_pose,   c->d_view_stats,
-                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel};
+                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters};
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -173,6 +173,10 @@ int make_ctx(Map *m, Ctx **out) {
   CTX_TRY(dev_alloc(acct, &c->d_view_count, (size_t)m->n_views));
   CTX_TRY(dev_alloc(acct, &c->d_match_i, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_match_key, (size_t)m->n_rows));
+  CTX_TRY(dev_alloc(acct, &c->d_flagged, (size_t)n_pad));
+  CTX_TRY(dev_alloc(acct, &c->d_n_flagged, (size_t)1));
+  CTX_TRY(dev_alloc(acct, &c->d_k1_counters, (size_t)2));
+  CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
   CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views));
   CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_status, (size_t)1));
@@ -458,6 +462,7 @@ void sfmloc_default_params(sfmloc_params *p) {
   p->refine_pose = 0;
   p->device = 0;
   p->profile = 0;
+  p->exact_rows = 0;
 }
 
 int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfmloc_map **out) {
@@ -1220,6 +1225,11 @@ int sfmloc_stats_read(sfmloc_map *map, sfmloc_kernel_stats *out) {
     }
     out->hamming_pairs += c->stats.hamming_pairs;
     out->hamming_alg_bytes += c->stats.hamming_alg_bytes;
+    unsigned long long k1c[2] = {0, 0};
+    SFM_HIP(hipMemcpy(k1c, c->d_k1_counters, sizeof(k1c), hipMemcpyDeviceToHost));
+    out->hamming_lane_ops += c->stats.hamming_lane_ops + 64ull * k1c[0] * (uint64_t)c->k1_finish_ops;
+    out->hamming_pairs_finished += 64ull * k1c[0];
+    out->hamming_rows_flagged += k1c[1];
   }
   return SFMLOC_OK;
 }
@@ -1235,6 +1245,7 @@ int sfmloc_stats_reset(sfmloc_map *map) {
     int rc = drain_events(c);
     if (rc) return rc;
     memset(&c->stats, 0, sizeof(c->stats));
+    SFM_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
   }
   return SFMLOC_OK;
 }

@@ -115,6 +115,168 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Exact screening (large N_q, one split).  A bank row can only pass the ratio test if its nearest query
+// descriptor is closer than T = ratio_cnt[d1], and ratio_cnt is non-decreasing, so ANY upper bound s1 >= d1 gives
+// a valid (larger) threshold.  The kernel therefore (a) scans the first kScreenHead query rows exactly to get s1,
+// (b) for the remaining rows computes the distance over the first NW dwords only -- a lower bound -- and
+// finishes the pair only when some lane of the wave is still below its threshold, (c) flags rows that ever see
+// a distance below T.  Unflagged rows are provably rejected; flagged rows (the true matches, a fraction of a
+// percent) are redone exactly by k_hamming_rows.  Results are bit-identical to k_hamming_top2 + K2; per pair
+// the loop issues 2*NW + 1 VALU instructions instead of 35.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kScreenHead = 64;  // measured: 64 and 128 within 1 %, 256+ slower (profiles/r01_k1_screen_sweep.txt)
+
+template <int WAVES, int NW>
+__global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
+    const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
+    const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t lds_rows, const uint16_t *__restrict__ ratio_cnt,
+    uint2 *__restrict__ part, uint2 *__restrict__ flagged /*{part index, bank row}*/, uint32_t *__restrict__ n_flagged,
+    unsigned long long *__restrict__ counters /*[0] finished wave-pairs, [1] flagged rows*/, uint32_t head) {
+  extern __shared__ uint4 qs[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t w0 = blockIdx.x * WAVES + wave;
+  const bool valid = w0 < n_work_blocks;
+  const uint32_t blk = valid ? (block_list ? block_list[w0] : w0) : 0u;
+  uint32_t b[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid) v = bank[((uint64_t)blk * 4 + c) * 64 + lane];
+    b[4 * c + 0] = v.x;
+    b[4 * c + 1] = v.y;
+    b[4 * c + 2] = v.z;
+    b[4 * c + 3] = v.w;
+  }
+  __shared__ uint16_t cnt_s[520];
+  for (uint32_t i = threadIdx.x; i < 513; i += WAVES * 64) cnt_s[i] = ratio_cnt[i];
+  uint32_t best0 = SFMLOC_NOMATCH, best1 = SFMLOC_NOMATCH;  // exact top-2 over the pairs finished so far
+  uint32_t T = 0;                                            // accept needs (nearest distance) < T
+  bool flag = false;
+  uint32_t n_finished = 0;
+  for (uint32_t j0 = 0; j0 < nq; j0 += lds_rows) {
+    const uint32_t cnt = min(lds_rows, nq - j0);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
+    __syncthreads();
+    if (!valid) continue;
+    uint32_t jj = 0;
+    // (a) exact head
+    for (; jj < cnt && j0 + jj < head; ++jj) {
+      const uint4 q0 = qs[jj * 4 + 0], q1 = qs[jj * 4 + 1], q2 = qs[jj * 4 + 2], q3 = qs[jj * 4 + 3];
+      const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                              q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
+      top2_push(best0, best1, (acc << 16) | (j0 + jj));
+      if (j0 + jj + 1 == head || j0 + jj + 1 == nq) {
+        T = (best1 != SFMLOC_NOMATCH) ? (uint32_t)cnt_s[best1 >> 16] : 0u;
+        flag = (best0 >> 16) < T;
+      }
+    }
+    // (b) screened tail.  A finished pair is exact, so it also tightens (best0, best1) and with them T: the
+    // threshold only ever shrinks towards ratio_cnt[d1], which keeps every earlier decision valid.
+#pragma unroll 2
+    for (; jj < cnt; ++jj) {
+      uint32_t q[16];
+#pragma unroll
+      for (int c = 0; c < (NW + 3) / 4; ++c) {
+        const uint4 v = qs[jj * 4 + c];
+        q[4 * c + 0] = v.x, q[4 * c + 1] = v.y, q[4 * c + 2] = v.z, q[4 * c + 3] = v.w;
+      }
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
+      if (__any(acc < T)) {
+        ++n_finished;
+#pragma unroll
+        for (int c = (NW + 3) / 4; c < 4; ++c) {
+          const uint4 v = qs[jj * 4 + c];
+          q[4 * c + 0] = v.x, q[4 * c + 1] = v.y, q[4 * c + 2] = v.z, q[4 * c + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = NW; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
+        flag = flag || (acc < T);
+        top2_push(best0, best1, (acc << 16) | (j0 + jj));
+        T = (uint32_t)cnt_s[best1 >> 16];
+      }
+    }
+  }
+  if (!valid) return;
+  const uint32_t pidx = w0 * 64 + lane;
+  part[pidx] = make_uint2(SFMLOC_NOMATCH, SFMLOC_NOMATCH);  // "rejected" unless k_hamming_rows overwrites it
+  const unsigned long long mask = __ballot(flag);
+  if (lane == 0) {
+    atomicAdd(&counters[0], (unsigned long long)n_finished);
+    if (mask) atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
+  }
+  if (mask) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(n_flagged, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (flag) flagged[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(pidx, blk * 64 + lane);
+  }
+}
+
+// Exact top-2 of the flagged rows: one workgroup per 64 flagged rows, its 8 waves interleave the query rows and
+// merge their partial top-2 through LDS (the packed key makes the merge order-independent).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__restrict__ bank,
+                                                             const uint4 *__restrict__ qdesc, uint32_t nq,
+                                                             uint32_t lds_rows, const uint2 *__restrict__ flagged,
+                                                             const uint32_t *__restrict__ n_flagged,
+                                                             uint2 *__restrict__ part) {
+  extern __shared__ uint4 qs[];
+  __shared__ uint2 merge[WAVES][64];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n = *n_flagged;
+  for (uint32_t chunk = blockIdx.x; chunk * 64 < n; chunk += gridDim.x) {
+    const uint32_t e = chunk * 64 + lane;
+    const bool valid = e < n;
+    const uint2 ent = valid ? flagged[e] : make_uint2(0, 0);
+    uint32_t b[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (valid) v = bank[((uint64_t)(ent.y >> 6) * 4 + c) * 64 + (ent.y & 63u)];
+      b[4 * c + 0] = v.x;
+      b[4 * c + 1] = v.y;
+      b[4 * c + 2] = v.z;
+      b[4 * c + 3] = v.w;
+    }
+    uint32_t best0 = SFMLOC_NOMATCH, best1 = SFMLOC_NOMATCH;
+    for (uint32_t j0 = 0; j0 < nq; j0 += lds_rows) {
+      const uint32_t cnt = min(lds_rows, nq - j0);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
+      __syncthreads();
+      for (uint32_t jj = wave; jj < cnt; jj += WAVES) {
+        const uint4 q0 = qs[jj * 4 + 0], q1 = qs[jj * 4 + 1], q2 = qs[jj * 4 + 2], q3 = qs[jj * 4 + 3];
+        const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
+        top2_push(best0, best1, (acc << 16) | (j0 + jj));
+      }
+    }
+    merge[wave][lane] = make_uint2(best0, best1);
+    __syncthreads();
+    if (wave == 0 && valid) {
+      uint32_t m0 = SFMLOC_NOMATCH, m1 = SFMLOC_NOMATCH;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        top2_push(m0, m1, merge[w][lane].x);
+        top2_push(m0, m1, merge[w][lane].y);
+      }
+      part[ent.x] = make_uint2(m0, m1);
+    }
+  }
+}
+
 // One wave per selected view.  Merges the per-split partial top-2, applies the ratio test through a
 // 513-entry table (ratio_cnt[d1] = number of d0 values for which the reference's float expression
 // (0.0f + d0) / d1 < ratio holds; the accepted d0 are exactly 0..cnt-1 because IEEE division is
@@ -205,10 +367,55 @@ int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, 
   return SFMLOC_OK;
 }
 
+static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list) {
+  Map *m = c->map;
+  constexpr int WAVES = 8;
+  // Prefix length of the lower bound, in dwords.  With 10 of 16 the "some lane still below its threshold" vote
+  // fires for ~3 % of the pairs on the bench data at ratio 0.6 (9 is past the cliff: half the lanes pass);
+  // SFMLOC_K1_SCREEN_NW={8..13} / SFMLOC_K1_SCREEN_HEAD override the two knobs for tuning.
+  static const int nw = [] {
+    const char *e = getenv("SFMLOC_K1_SCREEN_NW");
+    const int v = e ? atoi(e) : 10;
+    return (v >= 8 && v <= 13) ? v : 10;
+  }();
+  static const uint32_t head = [] {
+    const char *e = getenv("SFMLOC_K1_SCREEN_HEAD");
+    const int v = e ? atoi(e) : (int)kScreenHead;
+    return (uint32_t)((v >= 2 && v <= 4 * (int)kScreenHead) ? v : (int)kScreenHead);
+  }();
+  const uint32_t lds_rows = 512;
+  const size_t lds_bytes = (size_t)lds_rows * 64;
+  SFM_HIP(hipMemsetAsync(c->d_n_flagged, 0, sizeof(uint32_t), c->stream));
+#define K1_SCREEN(NW)                                                                                              \
+  case NW:                                                                                                        \
+    hipLaunchKernelGGL((k_hamming_screen<WAVES, NW>), dim3((n_work_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64), \
+                       lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks,       \
+                       q->d_desc, q->n, lds_rows, m->d_ratio_cnt, c->d_part, c->d_flagged, c->d_n_flagged,        \
+                       c->d_k1_counters, head);                                                                   \
+    break;
+  switch (nw) {
+    K1_SCREEN(8) K1_SCREEN(9) K1_SCREEN(10) K1_SCREEN(11) K1_SCREEN(12) K1_SCREEN(13)
+  }
+#undef K1_SCREEN
+  // executed VALU lane-ops, deterministic part (the finished pairs are counted on the device): exact head 35 per
+  // pair, screened tail 2*nw+1, plus (sfmloc_stats_read) 2*(16-nw)+5 per finished pair
+  const uint64_t rows = (uint64_t)n_work_blocks * kBlockRows;
+  c->stats.hamming_lane_ops += rows * head * 35 + rows * (q->n - head) * (uint64_t)(2 * nw + 1);
+  c->k1_finish_ops = 2 * (16 - nw) + 5;
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL((k_hamming_rows<WAVES>), dim3(512), dim3(WAVES * 64), lds_bytes, c->stream, m->d_bank, q->d_desc,
+                     q->n, lds_rows, c->d_flagged, c->d_n_flagged, c->d_part);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
 int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
   Map *m = c->map;
   if (n_work_blocks == 0 || q->n == 0) return SFMLOC_OK;
+  if (split == 1 && m->params.exact_rows == 0 && q->n >= 4 * kScreenHead && !k1_override().r)
+    return launch_hamming_screened(c, q, n_work_blocks, use_list);
   int R, W, L;
+  c->stats.hamming_lane_ops += (uint64_t)n_work_blocks * kBlockRows * q->n * 35;
   const K1Geom &o = k1_override();
   if (o.r) {
     R = o.r;

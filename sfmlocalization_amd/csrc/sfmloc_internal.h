@@ -90,6 +90,7 @@ struct Ctx;
 
 // Static, read-only after creation: the map as it sits in HBM.
 struct Map {
+
   int device = 0;
   int n_cu = 256;
   sfmloc_params params{};
@@ -141,6 +142,10 @@ struct Ctx {
   uint32_t *d_view_count = nullptr; // [n_views]
   uint32_t *d_match_i = nullptr;    // [n_rows]
   uint32_t *d_match_key = nullptr;  // [n_rows]  (d0<<16)|j0
+  uint2 *d_flagged = nullptr;       // [n_blocks*64] rows the screening kernel could not reject {part index, bank row}
+  uint32_t *d_n_flagged = nullptr;
+  unsigned long long *d_k1_counters = nullptr;  // [2] finished wave-pairs, flagged rows (since stats reset)
+  int k1_finish_ops = 0;
 
   // --- geometric stages ---
   uint32_t *d_geo_count = nullptr;  // [n_views]

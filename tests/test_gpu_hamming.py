@@ -21,13 +21,22 @@ def keys_from_oracle(j, d):
 
 def check_against_oracle(oracle_c, q, bank, view_off, view_sel, ratio=0.6):
     nv = len(view_off) - 1
-    params = S.default_params(dist_ratio=ratio)
+    # default path (rows the screening kernel proves rejected are not finished) ...
+    with S.Map(np.arange(nv, dtype=np.uint32) * 2 + 1, view_off, bank, params=S.default_params(dist_ratio=ratio)) as m:
+        qq = m.query(q)
+        m.match_putative(qq, view_sel)
+        got_screened = m.putative_read()
+        qq.close()
+    # ... and the exact-rows path, whose per-row (nearest, second) keys are compared too
+    params = S.default_params(dist_ratio=ratio, exact_rows=1)
     with S.Map(np.arange(nv, dtype=np.uint32) * 2 + 1, view_off, bank, params=params) as m:
         qq = m.query(q)
         m.match_putative(qq, view_sel)
         got = m.putative_read()
         b0, b1 = m.putative_read_rows()
         qq.close()
+    for name, a, b in zip(("view_count", "match_i", "match_j", "match_d"), got_screened, got):
+        np.testing.assert_array_equal(a, b, err_msg="screened vs exact-rows: " + name)
     exp = oracle_c.match_to_query(q, bank, view_off, view_sel, ratio, threads=4)
     for name, a, b in zip(("view_count", "match_i", "match_j", "match_d"), got, exp):
         np.testing.assert_array_equal(a, b, err_msg=name)
