@@ -1,6 +1,8 @@
 """Locates and loads libsfmloc_hip.so.  Fails loudly: there is no fallback implementation."""
 import ctypes
+import importlib.util
 import os
+import sys
 
 # One hardware queue per in-flight query context: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES
 # hardware queues (4 by default), and two contexts that share one serialise their kernels behind each other's
@@ -18,6 +20,27 @@ class LibraryMissing(ImportError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes in one
+    process do not work: whichever initialises second finds no device.  torch.distributed is this package's
+    multi-GPU plumbing, so when torch is installed its copy is loaded first (by path, without importing torch) and
+    libsfmloc_hip.so binds to it through the SONAME; SFMLOC_HIP_RUNTIME=system keeps the system runtime."""
+    if os.environ.get("SFMLOC_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     global _handle
     if _handle is None:
@@ -25,5 +48,6 @@ def load():
             raise LibraryMissing(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C sfmlocalization_amd/csrc`). The HIP library is the only compute path.")
+        _share_torch_hip_runtime()
         _handle = ctypes.CDLL(LIB_PATH)
     return _handle

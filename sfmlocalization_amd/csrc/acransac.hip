@@ -215,6 +215,7 @@ struct FFilterArgs {
   const double *L10;
   uint32_t *geo_count, *geo_idx;
   int *status;
+  int skip_le;  // k_fmatrix_filter leaves views with at most this many putative matches to k_fmatrix_fast
 };
 
 struct FShared {
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
   const int m = (int)A.put_count[v];
   const uint32_t off = A.view_off[v];
   constexpr int s = 7;
+  if (m <= A.skip_le) return;
   if (m < A.min_putative || m <= s) {  // localization.cpp:408-415 ; ACRANSAC: nData <= sizeSample
     if (tid == 0) A.geo_count[v] = 0;
     return;
@@ -371,6 +373,321 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
   if (min_nfa >= 0.0) n_in = 0;
   if ((double)n_in > 7 * 2.5) {
     for (int p = tid; p < n_in; p += kThreads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
+    if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
+  } else if (tid == 0) {
+    A.geo_count[v] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3, fast form (views with at most kF2MaxM putative matches -- in practice all of them): the same AC-RANSAC,
+// restructured so that nothing waits on a single lane.
+//   * the 7-point solver runs wave-wide (wave_seven_point), 8 hypotheses at a time, one per wave;
+//   * while sampling is still uniform the iterations are independent, so a batch of them is solved and their
+//     models are evaluated speculatively, one MODEL per wave (residuals -> per-wave bitonic sort -> bestNFA), eight
+//     side by side; the sequential acceptance rule of ACRANSAC is then replayed over the results in iteration
+//     order, and the winner's inlier list is rebuilt by evaluating that one model again;
+//   * after the switch to inlier sampling each iteration depends on the previous one: wave 0 solves, waves 0..2
+//     evaluate the (up to 3) models side by side.
+// Results are bit-identical to k_fmatrix_filter (same samples, same arithmetic per value, same tie rules).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kF2Waves = 8;
+constexpr int kF2Threads = kF2Waves * 64;
+constexpr int kF2MaxM = 512;   // putative matches per view (one wave sorts one model's residuals)
+constexpr int kF2Batch = 32;   // uniform iterations solved speculatively per batch
+
+struct F2Shared {
+  uint64_t key[kF2Waves][kF2MaxM];
+  uint32_t idx[kF2Waves][kF2MaxM];
+  double pts[kF2MaxM][4];  // normalised (x, y) of the map keypoint, (u, w) of the query keypoint
+  int32_t vec_index[kF2MaxM];
+  int32_t best_inl[kF2MaxM];
+  float logc_n[kF2MaxM + 1];
+  float logc_k[kF2MaxM + 1];
+  double pre_models[kF2Batch][27];
+  int pre_nm[kF2Batch];
+  double res_nfa[kF2Batch][3];
+  int res_k[kF2Batch][3];
+  double best_model[9];
+  int iter_end[kF2Batch];  // flattened index one past the last model of each iteration of the batch
+  uint8_t flat_b[kF2Batch * 3], flat_k[kF2Batch * 3];
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ascending bitonic sort of one wave's own (key, idx) segment; no workgroup barrier involved
+__device__ void bitonic_sort_wave(uint64_t *kw, uint32_t *iw, int P) {
+  const int lane = threadIdx.x & 63;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (P >> 1); t += 64) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i + j;
+        const bool up = (i & k) == 0;
+        const uint64_t ka = kw[i], kb = kw[l];
+        const uint32_t ia = iw[i], ib = iw[l];
+        const bool a_gt_b = pair_less(kb, ib, ka, ia);
+        if (a_gt_b == up) {
+          kw[i] = kb;
+          kw[l] = ka;
+          iw[i] = ib;
+          iw[l] = ia;
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+}
+
+__global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
+  extern __shared__ unsigned char smem_raw[];
+  F2Shared &S = *reinterpret_cast<F2Shared *>(smem_raw);
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63;
+  const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
+  const int m = (int)A.put_count[v];
+  const uint32_t off = A.view_off[v];
+  constexpr int s = 7;
+  if (m > kF2MaxM) return;  // k_fmatrix_filter handles this view
+  if (m < A.min_putative || m <= s) {  // localization.cpp:408-415 ; ACRANSAC: nData <= sizeSample
+    if (tid == 0) A.geo_count[v] = 0;
+    return;
+  }
+  // NormalizePoints(x, w, h) for both images
+  const int w1 = (int)A.view_wh[2 * v], h1 = (int)A.view_wh[2 * v + 1];
+  const int w2 = (int)A.qw, h2 = (int)A.qh;
+  const double s1 = 1.0 / sqrt((double)(w1 * h1)), s2 = 1.0 / sqrt((double)(w2 * h2));
+  const double t1x = -0.5 * (double)w1 * s1, t1y = -0.5 * (double)h1 * s1;
+  const double t2x = -0.5 * (double)w2 * s2, t2y = -0.5 * (double)h2 * s2;
+  const double Dg = sqrt((double)w2 * (double)w2 + (double)h2 * (double)h2);
+  const double Ar = (double)w2 * (double)h2;
+  const double logalpha0 = det_log10(2.0 * Dg / Ar / s2);
+  const double max_thr = (A.precision * A.precision) * s2 * s2;
+  const double loge0 = det_log10(3.0 * (double)(m - s));
+  const uint32_t stream = A.view_id[v];
+  const int P = next_pow2(m);
+
+  for (int p = tid; p < m; p += kF2Threads) {
+    const uint32_t i = A.match_i[off + p];
+    const uint32_t j = A.match_key[off + p] & 0xFFFFu;
+    const float2 a = A.map_kpt[off + i];
+    const float2 b = A.q_kpt6[j];
+    S.pts[p][0] = s1 * (double)a.x + t1x;
+    S.pts[p][1] = s1 * (double)a.y + t1y;
+    S.pts[p][2] = s2 * (double)b.x + t2x;
+    S.pts[p][3] = s2 * (double)b.y + t2y;
+  }
+  // logcombi tables (logcombi_tables_block is written for 256 threads)
+  if (tid == 0) {
+    double r = 0.0;
+    S.logc_n[0] = 0.0f;
+    S.logc_n[m] = 0.0f;
+    for (int k = 1; 2 * k <= m; ++k) {
+      if (k < m) {
+        r += A.L10[m - k + 1] - A.L10[k];
+        S.logc_n[k] = (float)r;
+        S.logc_n[m - k] = (float)r;
+      }
+    }
+  }
+  for (int q = tid; q <= m; q += kF2Threads) {
+    float val = 0.0f;
+    if (s < q) {
+      int k = s;
+      if (q - k < k) k = q - k;
+      double r = 0.0;
+      for (int i = 1; i <= k; ++i) r += A.L10[q - i + 1] - A.L10[i];
+      val = (float)r;
+    }
+    S.logc_k[q] = val;
+  }
+  __syncthreads();
+
+  // this wave: sample iteration `it`, solve, store the models at `models` / the count at *nm_out
+  auto wave_solve = [&](const int32_t *vec_index, int n_index, long it, double *models, int *nm_out) {
+    int32_t smp[7];
+    ac_sample<7>(vec_index, n_index, A.seed, STAGE_FMATRIX, stream, (uint32_t)it, smp);
+    const int r = lane / 9;
+    int pidx = smp[0];
+#pragma unroll
+    for (int q = 1; q < 7; ++q)
+      if (r == q) pidx = smp[q];
+    double f = 0.0;
+    const int nm = wave_seven_point(S.pts[pidx][0], S.pts[pidx][1], S.pts[pidx][2], S.pts[pidx][3], &f);
+    if (lane < 9 * nm) models[lane] = f;
+    if (lane == 0) *nm_out = nm;
+  };
+  // this wave: residuals of model M over all matches -> sorted (key, idx) in the wave's segment -> bestNFA
+  auto wave_eval = [&](const double *Mp) -> NfaBest {
+    double M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = Mp[q];
+    uint64_t *kw = S.key[wv];
+    uint32_t *iw = S.idx[wv];
+    for (int p = lane; p < P; p += 64) {
+      uint64_t kv = ~0ull;
+      if (p < m) kv = d2u(err_fmatrix(M, S.pts[p][0], S.pts[p][1], S.pts[p][2], S.pts[p][3]));
+      kw[p] = kv;
+      iw[p] = (uint32_t)p;
+    }
+    wave_lds_sync();
+    bitonic_sort_wave(kw, iw, P);
+    return best_nfa_wave(kw, m, s, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k);
+  };
+
+  // replicated scalar state (every thread holds the same values)
+  double min_nfa = pos_inf();
+  int n_in = 0;
+  long n_iter = A.n_iter;
+  long n_reserve = n_iter / 10;
+  n_iter -= n_reserve;
+  bool identity = true;
+  bool inl_valid = true;  // S.best_inl holds the inliers of the best model (vacuously: n_in == 0)
+  int n_index = m;
+  long iter = 0;
+
+  // wave 0 rebuilds the inlier list of S.best_model into best_inl (and vec_index when `to_index`)
+  auto rebuild_inliers = [&](bool to_index) {
+    __syncthreads();
+    if (wv == 0) {
+      (void)wave_eval(S.best_model);
+      for (int p = lane; p < n_in; p += 64) {
+        const int32_t q = (int32_t)S.idx[0][p];
+        S.best_inl[p] = q;
+        if (to_index) S.vec_index[p] = q;
+      }
+    }
+    __syncthreads();
+  };
+
+  while (iter < n_iter) {
+    if (identity) {
+      const int B = (int)((n_iter - iter < (long)kF2Batch) ? (n_iter - iter) : (long)kF2Batch);
+      __syncthreads();  // pre_* / res_* of the previous batch are no longer read
+      for (int b = wv; b < B; b += kF2Waves) wave_solve(nullptr, m, iter + b, S.pre_models[b], &S.pre_nm[b]);
+      __syncthreads();
+      // flattened model list in iteration order
+      if (tid == 0) {
+        int n = 0;
+        for (int b = 0; b < B; ++b) {
+          for (int k = 0; k < S.pre_nm[b]; ++k) {
+            S.flat_b[n] = (uint8_t)b;
+            S.flat_k[n] = (uint8_t)k;
+            ++n;
+          }
+          S.iter_end[b] = n;
+        }
+      }
+      __syncthreads();
+      const int total = S.iter_end[B - 1];
+      // evaluate the models eight per round; before each round replay the iterations whose models are all done,
+      // and stop as soon as one of them ends the uniform phase
+      int done = 0;    // models evaluated so far
+      int b_done = 0;  // iterations replayed so far
+      bool stop = false;
+      for (;;) {
+        while (b_done < B && S.iter_end[b_done] <= done) {
+          const int b = b_done;
+          bool better = false;
+          int bk = -1;
+          for (int k = 0; k < S.pre_nm[b]; ++k)
+            if (S.res_nfa[b][k] < min_nfa) {
+              better = true;
+              min_nfa = S.res_nfa[b][k];
+              n_in = S.res_k[b][k];
+              bk = k;
+            }
+          if (better) {
+            inl_valid = false;
+            if (tid < 9) S.best_model[tid] = S.pre_models[b][9 * bk + tid];
+          }
+          ++b_done;
+          const long it = iter + b;
+          if ((better && min_nfa < 0.0) || (it + 1 == n_iter && n_reserve)) {
+            if (n_in == 0) {
+              n_iter++;
+              n_reserve--;  // the iteration budget moved: close this batch here
+            } else {
+              rebuild_inliers(true);
+              inl_valid = true;
+              n_index = n_in;
+              identity = false;
+              if (n_reserve) {
+                n_iter = it + 1 + n_reserve;
+                n_reserve = 0;
+              }
+            }
+            stop = true;
+            break;
+          }
+        }
+        if (stop || b_done >= B) break;
+        const int mi = done + wv;
+        if (mi < total) {
+          const int bb = S.flat_b[mi], kk = S.flat_k[mi];
+          const NfaBest r = wave_eval(&S.pre_models[bb][9 * kk]);
+          if (lane == 0) {
+            S.res_nfa[bb][kk] = r.nfa;
+            S.res_k[bb][kk] = r.k;
+          }
+        }
+        __syncthreads();
+        done = (done + kF2Waves < total) ? done + kF2Waves : total;
+      }
+      iter += b_done;
+    } else {
+      __syncthreads();
+      if (wv == 0) wave_solve(S.vec_index, n_index, iter, S.pre_models[0], &S.pre_nm[0]);
+      __syncthreads();
+      const int nm = S.pre_nm[0];
+      if (wv < nm) {
+        const NfaBest r = wave_eval(&S.pre_models[0][9 * wv]);
+        if (lane == 0) {
+          S.res_nfa[0][wv] = r.nfa;
+          S.res_k[0][wv] = r.k;
+        }
+      }
+      __syncthreads();
+      bool better = false;
+      int bk = -1;
+      for (int k = 0; k < nm; ++k)
+        if (S.res_nfa[0][k] < min_nfa) {
+          better = true;
+          min_nfa = S.res_nfa[0][k];
+          n_in = S.res_k[0][k];
+          bk = k;
+        }
+      if (better) {
+        for (int p = tid; p < n_in; p += kF2Threads) S.best_inl[p] = (int32_t)S.idx[bk][p];
+        inl_valid = true;
+      }
+      if ((better && min_nfa < 0.0) || (iter + 1 == n_iter && n_reserve)) {
+        if (n_in == 0) {
+          n_iter++;
+          n_reserve--;
+        } else {
+          __syncthreads();
+          for (int p = tid; p < n_in; p += kF2Threads) S.vec_index[p] = S.best_inl[p];
+          n_index = n_in;
+          identity = false;
+          if (n_reserve) {
+            n_iter = iter + 1 + n_reserve;
+            n_reserve = 0;
+          }
+        }
+      }
+      ++iter;
+    }
+  }
+  __syncthreads();
+  if (min_nfa >= 0.0) n_in = 0;
+  if ((double)n_in > 7 * 2.5) {
+    if (!inl_valid) rebuild_inliers(false);
+    for (int p = tid; p < n_in; p += kF2Threads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
     if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
   } else if (tid == 0) {
     A.geo_count[v] = 0;
@@ -1068,6 +1385,24 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
   A.geo_count = c->d_geo_count;
   A.geo_idx = c->d_geo_idx;
   A.status = c->d_status;
+  // views with <= kF2MaxM putative matches take the wave-parallel kernel, the rest (if any: the second launch
+  // returns at once for the others) the block-wide one; SFMLOC_K3_FAST=0 sends every view to the latter
+  static const bool fast = [] {
+    const char *e = getenv("SFMLOC_K3_FAST");
+    return !(e && atoi(e) == 0);
+  }();
+  A.skip_le = fast ? kF2MaxM : -1;
+  if (fast) {
+    const size_t lds2 = sizeof(F2Shared);
+    static bool attr2 = false;
+    if (!attr2) {
+      SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(k_fmatrix_fast, dim3(n_sel), dim3(kF2Threads), lds2, c->stream, A);
+    SFM_HIP(hipGetLastError());
+  }
   const size_t lds = sizeof(FShared);
   SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_filter),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -384,6 +384,85 @@ GDN int seven_point(const double *x1, const double *x2, double *F) {
   return n;
 }
 
+// The same solver spread over one wave: lane l < 63 owns A[l / 9][l % 9] in a register, the pivot search is a
+// butterfly reduction, row/column swaps, the pivot-row broadcast and the elimination factors are shuffles.  Every
+// value goes through exactly the operations seven_point applies to it, in the same order, so the results are
+// bit-identical; what changes is that nothing is dynamically indexed (no scratch) and the 7x9 eliminations run
+// 63-wide.  (ax, ay, bx, by): the coordinates of point l / 9 (any value in lane 63).  All lanes return the
+// number of solutions; lane l < 9 * n returns F[l] (solution l / 9, entry l % 9) in *f_out.
+__device__ __forceinline__ int wave_seven_point(double ax, double ay, double bx, double by, double *f_out) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int row = lane / 9, col = lane - 9 * row;  // lane 63: row 7 (inactive)
+  const bool live = lane < 63;
+  const double pa = (col < 3) ? bx : (col < 6) ? by : 1.0;
+  const int c3 = col % 3;
+  const double pb = (c3 == 0) ? ax : (c3 == 1) ? ay : 1.0;
+  double a = (col < 6) ? ((c3 == 2) ? pa : pa * pb) : pb;  // bx*ax bx*ay bx by*ax by*ay by ax ay 1
+  uint64_t perm = 0x876543210ull;  // nibble j = perm[j]
+  for (int k = 0; k < 7; ++k) {
+    // complete pivoting: largest |A[i][j]|, i >= k, j >= k; first in row-major order on ties
+    const double aa = dabs(a);
+    double bv = (live && row >= k && col >= k && aa == aa) ? aa : -1.0;
+    int bi = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (!(bv > 0.0)) return 0;
+    const int pi = bi / 9, pj = bi - 9 * pi;
+    const int sr = (row == k) ? pi : (row == pi) ? k : row;
+    const int sc = (col == k) ? pj : (col == pj) ? k : col;
+    a = __shfl(a, live ? sr * 9 + sc : lane, 64);
+    if (pj != k) {
+      const uint64_t nk = (perm >> (4 * k)) & 0xFull, nj = (perm >> (4 * pj)) & 0xFull;
+      perm &= ~((0xFull << (4 * k)) | (0xFull << (4 * pj)));
+      perm |= (nj << (4 * k)) | (nk << (4 * pj));
+    }
+    const double piv = __shfl(a, k * 9 + k, 64);
+    if (live && row == k && col >= k) a = a / piv;
+    const double rk = __shfl(a, live ? k * 9 + col : lane, 64);   // normalised pivot row at my column
+    const double fct = __shfl(a, live ? row * 9 + k : lane, 64);  // my row's entry in the pivot column
+    if (live && row != k && col >= k && fct != 0.0) a = a - fct * rk;
+  }
+  // null-space basis: f1[perm[i]] = -A[i][7], f2[perm[i]] = -A[i][8] (i < 7); unit entries at perm[7], perm[8]
+  double f1[9], f2[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    int pos = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+      if ((int)((perm >> (4 * q)) & 0xFull) == c) pos = q;
+    const double v1 = __shfl(a, pos < 7 ? pos * 9 + 7 : 0, 64);
+    const double v2 = __shfl(a, pos < 7 ? pos * 9 + 8 : 0, 64);
+    f1[c] = (pos < 7) ? -v1 : (pos == 7 ? 1.0 : 0.0);
+    f2[c] = (pos < 7) ? -v2 : (pos == 8 ? 1.0 : 0.0);
+  }
+  double a0[3] = {f1[0], f1[3], f1[6]}, a1[3] = {f1[1], f1[4], f1[7]}, a2[3] = {f1[2], f1[5], f1[8]};
+  double b0[3] = {f2[0], f2[3], f2[6]}, b1[3] = {f2[1], f2[4], f2[7]}, b2[3] = {f2[2], f2[5], f2[8]};
+  const double c0 = det3c(a0, a1, a2);
+  const double c1 = (det3c(b0, a1, a2) + det3c(a0, b1, a2)) + det3c(a0, a1, b2);
+  const double c2 = (det3c(a0, b1, b2) + det3c(b0, a1, b2)) + det3c(b0, b1, a2);
+  const double c3c = det3c(b0, b1, b2);
+  double roots[3] = {0.0, 0.0, 0.0};
+  const int n = solve_cubic(c3c, c2, c1, c0, roots);
+  const int sol = lane / 9, ent = lane - 9 * sol;
+  double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c)
+    if (ent == c) {
+      g1 = f1[c];
+      g2 = f2[c];
+    }
+  const double rt = (sol == 0) ? roots[0] : (sol == 1) ? roots[1] : roots[2];
+  *f_out = g1 + rt * g2;
+  return n;
+}
+
 GD void cross3(const double a[3], const double b[3], double o[3]) {
   o[0] = a[1] * b[2] - a[2] * b[1];
   o[1] = a[2] * b[0] - a[0] * b[2];

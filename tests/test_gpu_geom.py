@@ -194,6 +194,36 @@ def test_pipeline_more_ransac_rounds(oracle_c):
     mm.close()
 
 
+def _map_with(m, **p):
+    return S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(**p), view_wh=m.view_wh, kpt_xy=m.kpt_xy,
+                 row_landmark=m.row_landmark, landmark_id=m.landmark_id, landmark_X=m.landmark_X,
+                 intrinsic=m.intrinsic)
+
+
+@pytest.mark.parametrize("rounds", [5, 9, 10, 33, 70, 400])
+def test_fmatrix_filter_round_budgets(oracle_c, rounds):
+    """The speculative (batched) uniform phase and the sequential tail must replay ACRANSAC's budget rules exactly:
+    no reserve (< 10 rounds), end-of-uniform switch without a meaningful model, several batches, long tails."""
+    m = make_scene(31)
+    with _map_with(m, ransac_round=rounds) as dm:
+        for seed, frac in ((7, 0.2), (8, 0.55), (9, 0.75)):
+            q = synth.make_query(m, seed, n_feat=600, n_copies=220, outlier_frac=frac)
+            compare_stages(m, q, dm, ransac_round=rounds)
+
+
+def test_fmatrix_filter_large_views(oracle_c):
+    """Views with more than 512 putative matches take the block-wide kernel; smaller ones the wave-parallel one."""
+    m = make_scene(32, n_views=20, desc_per_view=1500, landmarks_per_place=1200, obs_per_view=1100)
+    with _map_with(m, ransac_round=25) as dm:
+        q = synth.make_query(m, 3, n_feat=1800, n_copies=1100, outlier_frac=0.3)
+        exp, _ = compare_stages(m, q, dm, ransac_round=25)
+        assert exp["put_count"].max() > 512
+        q = synth.make_query(m, 4, n_feat=1800, n_copies=500, outlier_frac=0.3)
+        exp, _ = compare_stages(m, q, dm, ransac_round=25)
+        big = exp["put_count"][exp["put_count"] >= 16]
+        assert len(big) and big.max() <= 512
+
+
 def test_localize_one_call(oracle_c):
     m = make_scene(24)
     with dev_map(m) as dm:
