@@ -328,7 +328,8 @@ int sfmloc_akaze_levels(const sfmloc_akaze *ak, int *n_levels, int *wh);
 int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt);
 
 /* Parity probe: runs one of the f64 device building blocks over n items (tests compare with the oracle).
- * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample */
+ * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample,
+ *     8 seven-point, wave-parallel form (K3's fast kernel; layout of op 4) */
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride);
 
 /* ------------------------------------------------------------------------- */

@@ -17,6 +17,8 @@
 // which round evaluates it.  All arithmetic is f64, in the operation order of geom_device.h.
 #include <float.h>
 
+#include <type_traits>
+
 #include "geom_device.h"
 #include "sfmloc_internal.h"
 
@@ -50,33 +52,6 @@ __device__ void bitonic_sort(uint64_t *key, uint32_t *idx, int P) {
           key[l] = ka;
           idx[i] = ib;
           idx[l] = ia;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// the same sort run by every wave of the block on its own segment (segment w starts at w*seg): the loop
-// structure depends only on P, so block-wide barriers serve all waves at once
-__device__ void bitonic_sort_per_wave(uint64_t *key, uint32_t *idx, int P, int seg) {
-  const int lane = threadIdx.x & 63;
-  uint64_t *kw = key + (size_t)(threadIdx.x >> 6) * seg;
-  uint32_t *iw = idx + (size_t)(threadIdx.x >> 6) * seg;
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = lane; t < (P >> 1); t += 64) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i + j;
-        const bool up = (i & k) == 0;
-        const uint64_t ka = kw[i], kb = kw[l];
-        const uint32_t ia = iw[i], ib = iw[l];
-        const bool a_gt_b = pair_less(kb, ib, ka, ia);
-        if (a_gt_b == up) {
-          kw[i] = kb;
-          kw[l] = ka;
-          iw[i] = ib;
-          iw[l] = ia;
         }
       }
       __syncthreads();
@@ -157,6 +132,99 @@ __device__ NfaBest best_nfa_wave(const uint64_t *key, int n, int s, double max_t
     }
   }
   return NfaBest{lb, lk};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// register-resident wave sort: 64*E (key, idx) pairs, element e = r*64 + lane in register r.  The same bitonic
+// network as bitonic_sort: strides >= 64 are compare-exchanges between two registers of one lane, strides < 64
+// exchange with lane ^ j through ds_bpermute.  The order by (key, idx) is total, so any correct sort gives the
+// same array.
+// ---------------------------------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void wave_sort_regs(uint64_t (&key)[E], uint32_t (&idx)[E]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int jr = j >> 6;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          if ((r & jr) == 0) {
+            const int r2 = r | jr;
+            const bool up = ((r << 6) & k) == 0;  // k >= 128: only the register index decides the direction
+            const bool a_gt_b = pair_less(key[r2], idx[r2], key[r], idx[r]);
+            if (a_gt_b == up) {
+              const uint64_t tk = key[r];
+              key[r] = key[r2];
+              key[r2] = tk;
+              const uint32_t ti = idx[r];
+              idx[r] = idx[r2];
+              idx[r2] = ti;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const uint64_t ok = __shfl_xor(key[r], j, 64);
+          const uint32_t oi = __shfl_xor(idx[r], j, 64);
+          const bool up = ((((r << 6) | lane) & k) == 0);
+          const bool want_min = (((lane & j) == 0) == up);  // lower position of an ascending pair, or upper of a descending one
+          if (pair_less(ok, oi, key[r], idx[r]) == want_min) {
+            key[r] = ok;
+            idx[r] = oi;
+          }
+        }
+      }
+    }
+  }
+}
+
+// bestNFA over the sorted registers of wave_sort_regs (position r*64 + lane holds e_{position+1}); same
+// candidates, same per-lane visiting order and same reduction as best_nfa_wave
+template <int E>
+__device__ __forceinline__ NfaBest best_nfa_regs(const uint64_t (&key)[E], int n, int s, double max_thr,
+                                                 double logalpha0, double mult, double loge0, const float *logc_n,
+                                                 const float *logc_k) {
+  const int lane = threadIdx.x & 63;
+  double lb = pos_inf();
+  int lk = 0x7FFFFFFF;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int kk = (r << 6) + lane + 1;
+    if (kk > s && kk <= n) {
+      const double ek = u2d(key[r]);
+      if (ek <= max_thr) {
+        const double logalpha = logalpha0 + mult * det_log10(ek + (double)FLT_EPSILON);
+        const double nfa = loge0 + logalpha * (double)(kk - s) + (double)logc_n[kk] + (double)logc_k[kk];
+        if (nfa < lb) {
+          lb = nfa;
+          lk = kk;
+        }
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ob = __shfl_xor(lb, off, 64);
+    const int ok = __shfl_xor(lk, off, 64);
+    if (ob < lb || (ob == lb && ok < lk)) {
+      lb = ob;
+      lk = ok;
+    }
+  }
+  return NfaBest{lb, lk};
+}
+
+// the key at sorted position pos (every lane returns it)
+template <int E>
+__device__ __forceinline__ uint64_t sorted_key_at(const uint64_t (&key)[E], int pos) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int r = 0; r < E; ++r)
+    if ((pos >> 6) == r) v = key[r];
+  return __shfl(v, pos & 63, 64);
 }
 
 // logcombi tables of OpenMVG (float): logc_n[k] = log10 C(n,k), logc_k[m] = log10 C(m,s); L10[i] = log10(i).
@@ -397,8 +465,7 @@ constexpr int kF2MaxM = 512;   // putative matches per view (one wave sorts one 
 constexpr int kF2Batch = 32;   // uniform iterations solved speculatively per batch
 
 struct F2Shared {
-  uint64_t key[kF2Waves][kF2MaxM];
-  uint32_t idx[kF2Waves][kF2MaxM];
+  uint32_t idx[kF2Waves][kF2MaxM];  // sorted match indices of the model each wave evaluated last
   double pts[kF2MaxM][4];  // normalised (x, y) of the map keypoint, (u, w) of the query keypoint
   int32_t vec_index[kF2MaxM];
   int32_t best_inl[kF2MaxM];
@@ -507,10 +574,15 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
   }
   __syncthreads();
 
+  // (the lambdas below must not capture the kernel-argument struct: that would put all of it on the stack)
+  const uint64_t seed = A.seed;
+  F2Shared *const Sp = &S;
   // this wave: sample iteration `it`, solve, store the models at `models` / the count at *nm_out
-  auto wave_solve = [&](const int32_t *vec_index, int n_index, long it, double *models, int *nm_out) {
+  auto wave_solve = [Sp, seed, stream, lane](const int32_t *vec_index, int n_index, long it, double *models,
+                                             int *nm_out) {
+    F2Shared &S = *Sp;
     int32_t smp[7];
-    ac_sample<7>(vec_index, n_index, A.seed, STAGE_FMATRIX, stream, (uint32_t)it, smp);
+    ac_sample<7>(vec_index, n_index, seed, STAGE_FMATRIX, stream, (uint32_t)it, smp);
     const int r = lane / 9;
     int pidx = smp[0];
 #pragma unroll
@@ -521,22 +593,37 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
     if (lane < 9 * nm) models[lane] = f;
     if (lane == 0) *nm_out = nm;
   };
-  // this wave: residuals of model M over all matches -> sorted (key, idx) in the wave's segment -> bestNFA
-  auto wave_eval = [&](const double *Mp) -> NfaBest {
+  // this wave: residuals of model M over all matches, sorted in registers, bestNFA; the sorted match indices go
+  // to the wave's LDS segment (S.idx[wv]) for whoever needs the inlier list afterwards
+  auto eval_e = [Sp, lane, wv, m, max_thr, logalpha0, loge0](const double *Mp, auto e_tag) -> NfaBest {
+    constexpr int E = decltype(e_tag)::value;
+    F2Shared &S = *Sp;
     double M[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) M[q] = Mp[q];
-    uint64_t *kw = S.key[wv];
-    uint32_t *iw = S.idx[wv];
-    for (int p = lane; p < P; p += 64) {
+    uint64_t key[E];
+    uint32_t idx[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int p = (r << 6) + lane;
       uint64_t kv = ~0ull;
       if (p < m) kv = d2u(err_fmatrix(M, S.pts[p][0], S.pts[p][1], S.pts[p][2], S.pts[p][3]));
-      kw[p] = kv;
-      iw[p] = (uint32_t)p;
+      key[r] = kv;
+      idx[r] = (uint32_t)p;
     }
-    wave_lds_sync();
-    bitonic_sort_wave(kw, iw, P);
-    return best_nfa_wave(kw, m, s, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k);
+    wave_sort_regs<E>(key, idx);
+    uint32_t *iw = S.idx[wv];
+#pragma unroll
+    for (int r = 0; r < E; ++r) iw[(r << 6) + lane] = idx[r];
+    return best_nfa_regs<E>(key, m, 7, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k);
+  };
+  auto wave_eval = [&eval_e, P](const double *Mp) -> NfaBest {
+    switch (P >> 6) {
+      case 1: return eval_e(Mp, std::integral_constant<int, 1>{});
+      case 2: return eval_e(Mp, std::integral_constant<int, 2>{});
+      case 4: return eval_e(Mp, std::integral_constant<int, 4>{});
+      default: return eval_e(Mp, std::integral_constant<int, 8>{});
+    }
   };
 
   // replicated scalar state (every thread holds the same values)
@@ -551,10 +638,12 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
   long iter = 0;
 
   // wave 0 rebuilds the inlier list of S.best_model into best_inl (and vec_index when `to_index`)
-  auto rebuild_inliers = [&](bool to_index) {
+  auto rebuild_inliers = [&wave_eval, Sp, wv, lane, &n_in](bool to_index) {
+    F2Shared &S = *Sp;
     __syncthreads();
     if (wv == 0) {
       (void)wave_eval(S.best_model);
+      wave_lds_sync();
       for (int p = lane; p < n_in; p += 64) {
         const int32_t q = (int32_t)S.idx[0][p];
         S.best_inl[p] = q;
@@ -879,6 +968,7 @@ struct P3pShared {
   int nm;
   double red_nfa[kThreads / 64];
   int red_k[kThreads / 64];
+  double red_err[kThreads / 64];
 };
 
 __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
@@ -917,26 +1007,50 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
   int best_k = 0, best_m = -1;
   double best_err = pos_inf();
   if (P <= kP3pWaveSeg) {
-    // fast path: the (up to 4) models of the hypothesis are evaluated side by side, one wave each
+    // fast path: the (up to 4) models of the hypothesis are evaluated side by side, one wave each, residuals
+    // sorted in registers
     const int wv = tid >> 6, lane = tid & 63;
-    uint64_t *kw = S.key + (size_t)wv * kP3pWaveSeg;
     uint32_t *iw = S.idx + (size_t)wv * kP3pWaveSeg;
-    double M[12];
-    for (int q = 0; q < 12; ++q) M[q] = (wv < nm) ? S.models[12 * wv + q] : 0.0;
-    for (int p = lane; p < P; p += 64) {
-      uint64_t kv = ~0ull;
-      if (p < n && wv < nm)
-        kv = d2u(err_resection(M, A.pt3d[3 * p], A.pt3d[3 * p + 1], A.pt3d[3 * p + 2], A.xn[2 * p], A.xn[2 * p + 1]));
-      kw[p] = kv;
-      iw[p] = (uint32_t)p;
-    }
-    __syncthreads();
-    bitonic_sort_per_wave(S.key, S.idx, P, kP3pWaveSeg);
     NfaBest r{pos_inf(), 0x7FFFFFFF};
-    if (wv < nm) r = best_nfa_wave(kw, n, s, pos_inf(), logalpha0, 1.0, loge0, A.logc_n, A.logc_k);
+    double r_err = pos_inf();
+    if (wv < nm) {
+      double M[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) M[q] = S.models[12 * wv + q];
+      // (the lambda must not capture the kernel-argument struct: that would put all of it on the stack)
+      const double *pt3d = A.pt3d, *xn = A.xn;
+      const float *logc_n = A.logc_n, *logc_k = A.logc_k;
+      auto run = [&M, &r, &r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0](auto e_tag) {
+        constexpr int E = decltype(e_tag)::value;
+        uint64_t key[E];
+        uint32_t idx[E];
+#pragma unroll
+        for (int rr = 0; rr < E; ++rr) {
+          const int p = (rr << 6) + lane;
+          uint64_t kv = ~0ull;
+          if (p < n)
+            kv = d2u(err_resection(M, pt3d[3 * p], pt3d[3 * p + 1], pt3d[3 * p + 2], xn[2 * p], xn[2 * p + 1]));
+          key[rr] = kv;
+          idx[rr] = (uint32_t)p;
+        }
+        wave_sort_regs<E>(key, idx);
+#pragma unroll
+        for (int rr = 0; rr < E; ++rr) iw[(rr << 6) + lane] = idx[rr];
+        r = best_nfa_regs<E>(key, n, 3, pos_inf(), logalpha0, 1.0, loge0, logc_n, logc_k);
+        if (r.k != 0x7FFFFFFF) r_err = u2d(sorted_key_at<E>(key, r.k - 1));
+      };
+      switch (P >> 6) {
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 8: run(std::integral_constant<int, 8>{}); break;
+        default: run(std::integral_constant<int, 16>{}); break;
+      }
+    }
     if (lane == 0) {
       S.red_nfa[wv] = r.nfa;
       S.red_k[wv] = r.k;
+      S.red_err[wv] = r_err;
     }
     __syncthreads();
     for (int k = 0; k < nm; ++k)
@@ -946,7 +1060,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
         best_m = k;
       }
     if (best_m >= 0) {
-      best_err = u2d(S.key[(size_t)best_m * kP3pWaveSeg + best_k - 1]);
+      best_err = S.red_err[best_m];
       int32_t *dst = A.hyp_inl + (size_t)b * A.max_n;
       const uint32_t *src = S.idx + (size_t)best_m * kP3pWaveSeg;
       for (int p = tid; p < best_k; p += kThreads) dst[p] = (int32_t)src[p];
@@ -1343,6 +1457,21 @@ __global__ void k_debug_math(int op, const double *in, int n, int in_stride, dou
   }
 }
 
+// op 8: wave_seven_point, one wave per row (same input/output layout as op 4)
+__global__ __launch_bounds__(64) void k_debug_wave7(const double *in, int n, int in_stride, double *out, int out_stride) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const double *x = in + (size_t)i * in_stride;
+  double *o = out + (size_t)i * out_stride;
+  const int lane = threadIdx.x & 63;
+  int r = lane / 9;
+  if (r > 6) r = 6;
+  double f = 0.0;
+  const int nm = wave_seven_point(x[2 * r], x[2 * r + 1], x[14 + 2 * r], x[14 + 2 * r + 1], &f);
+  if (lane == 0) o[0] = (double)nm;
+  if (lane < 27) o[1 + lane] = (lane < 9 * nm) ? f : 0.0;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -1356,7 +1485,10 @@ int launch_fill_log10(double *d_L10, int n, hipStream_t s) {
 
 int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *d_out, int out_stride,
                       hipStream_t s) {
-  hipLaunchKernelGGL(k_debug_math, dim3((n + 63) / 64), dim3(64), 0, s, op, d_in, n, in_stride, d_out, out_stride);
+  if (op == 8)
+    hipLaunchKernelGGL(k_debug_wave7, dim3(n), dim3(64), 0, s, d_in, n, in_stride, d_out, out_stride);
+  else
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 63) / 64), dim3(64), 0, s, op, d_in, n, in_stride, d_out, out_stride);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -66,15 +66,6 @@ void build_ratio_table(float ratio, uint16_t *cnt) {
   }
 }
 
-// what a finished query copies back in one asynchronous transfer
-struct HostResult {
-  P3pState state;
-  Pose pose;
-  int status;
-  uint32_t view_stats[2];
-  uint32_t pair_qfeat[kP3pMaxN];
-  uint32_t pair_landmark[kP3pMaxN];
-};
 
 struct EventScope {
   Ctx *c;
@@ -125,11 +116,11 @@ void free_ctx(Ctx *c) {
     hipEventDestroy(e.second);
   }
   void *ptrs[] = {c->d_part,      c->d_view_sel,  c->d_view_widx0, c->d_block_list, c->d_view_count, c->d_match_i,
-                  c->d_match_key, c->d_geo_count, c->d_geo_idx,    c->d_status,     c->d_cand_part,
+                  c->d_match_key, c->d_geo_count, c->d_geo_idx,    c->d_result,     c->d_cand_part,
                   c->d_best64,    c->d_winner,    c->d_ms_n,       c->d_ms_qfeat,   c->d_ms_landmark, c->d_pt2d,
                   c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
-                  c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,    c->d_pair_qfeat,
-                  c->d_pair_landmark, c->d_inlier_idx, c->d_p3p_state, c->d_pose,   c->d_view_stats,
+                  c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,
+                  c->d_inlier_idx,
                   c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -179,7 +170,17 @@ int make_ctx(Map *m, Ctx **out) {
   CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
   CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views));
   CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
-  CTX_TRY(dev_alloc(acct, &c->d_status, (size_t)1));
+  // everything a finished query reports lives in ONE device record laid out as HostResult: one D2H copy per query
+  CTX_TRY(dev_alloc(acct, &c->d_result, sizeof(HostResult)));
+  {
+    HostResult *r = reinterpret_cast<HostResult *>(c->d_result);
+    c->d_p3p_state = &r->state;
+    c->d_pose = &r->pose;
+    c->d_status = &r->status;
+    c->d_view_stats = r->view_stats;
+    c->d_pair_qfeat = r->pair_qfeat;
+    c->d_pair_landmark = r->pair_landmark;
+  }
   CTX_TRY(dev_alloc(acct, &c->d_cand_part, (size_t)kPartHeaderBytes + (size_t)c->cand_cap * sizeof(Candidate)));
   CTX_TRY(dev_alloc(acct, &c->d_best64, (size_t)65536));
   CTX_TRY(dev_alloc(acct, &c->d_winner, (size_t)65536));
@@ -198,12 +199,7 @@ int make_ctx(Map *m, Ctx **out) {
   CTX_TRY(dev_alloc(acct, &c->d_hyp_model, (size_t)kP3pBatchMax * 12));
   CTX_TRY(dev_alloc(acct, &c->d_hyp_k, (size_t)kP3pBatchMax));
   CTX_TRY(dev_alloc(acct, &c->d_hyp_inl, (size_t)kP3pBatchMax * kP3pMaxN));
-  CTX_TRY(dev_alloc(acct, &c->d_pair_qfeat, (size_t)kP3pMaxN));
-  CTX_TRY(dev_alloc(acct, &c->d_pair_landmark, (size_t)kP3pMaxN));
   CTX_TRY(dev_alloc(acct, &c->d_inlier_idx, (size_t)kP3pMaxN));
-  CTX_TRY(dev_alloc(acct, &c->d_p3p_state, (size_t)1));
-  CTX_TRY(dev_alloc(acct, &c->d_pose, (size_t)1));
-  CTX_TRY(dev_alloc(acct, &c->d_view_stats, (size_t)2));
   if (m->bow_dim) {
     CTX_TRY(dev_alloc(acct, &c->d_bow_query, (size_t)m->bow_dim));
     CTX_TRY(dev_alloc(acct, &c->d_bow_dist, (size_t)m->n_views));
@@ -355,19 +351,17 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
     rc = launch_p3p_init(c);
     if (rc) return rc;
   }
-  for (int r = 0; r < 12 && rc == SFMLOC_OK; ++r) rc = launch_p3p_round(c, (first_call && r == 0) ? 64 : kP3pBatchMax);
+  // typically 6-8 rounds end the stage (one per improvement of the model); rounds enqueued past the end return at
+  // once but still cost two launches each, so the first call queues 9 and ctx_resection_wait adds more if needed
+  const int rounds = first_call ? 9 : 6;
+  for (int r = 0; r < rounds && rc == SFMLOC_OK; ++r)
+    rc = launch_p3p_round(c, (first_call && r == 0) ? 64 : kP3pBatchMax);
   return rc;
 }
 
 int ctx_fetch_result(Ctx *c) {
   HostResult *h = reinterpret_cast<HostResult *>(c->h_result);
-  SFM_HIP(hipMemcpyAsync(&h->state, c->d_p3p_state, sizeof(P3pState), hipMemcpyDeviceToHost, c->stream));
-  SFM_HIP(hipMemcpyAsync(&h->pose, c->d_pose, sizeof(Pose), hipMemcpyDeviceToHost, c->stream));
-  SFM_HIP(hipMemcpyAsync(&h->status, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  SFM_HIP(hipMemcpyAsync(h->view_stats, c->d_view_stats, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  SFM_HIP(hipMemcpyAsync(h->pair_qfeat, c->d_pair_qfeat, sizeof(h->pair_qfeat), hipMemcpyDeviceToHost, c->stream));
-  SFM_HIP(hipMemcpyAsync(h->pair_landmark, c->d_pair_landmark, sizeof(h->pair_landmark), hipMemcpyDeviceToHost,
-                         c->stream));
+  SFM_HIP(hipMemcpyAsync(h, c->d_result, sizeof(HostResult), hipMemcpyDeviceToHost, c->stream));
   return SFMLOC_OK;
 }
 

@@ -122,7 +122,9 @@ GDN double cubic_one_root(double b, double c, double d) {
       dxold = dx;
       dx = 0.5 * (xh - xl);
       x = xl + dx;
-      if (xl == x) return x;
+      // a bracket one ulp wide cannot shrink: its midpoint rounds to either end (to xh on a round-to-even tie,
+      // which the classic `xl == x` test alone misses and then spins to the iteration cap on the same x)
+      if (xl == x || xh == x) return x;
     } else {
       dxold = dx;
       dx = f / df;

@@ -86,6 +86,16 @@ struct P3pArgs {
   uint32_t stream;
 };
 
+// what a finished query copies back in one asynchronous transfer
+struct HostResult {
+  P3pState state;
+  Pose pose;
+  int status;
+  uint32_t view_stats[2];
+  uint32_t pair_qfeat[kP3pMaxN];
+  uint32_t pair_landmark[kP3pMaxN];
+};
+
 struct Ctx;
 
 // Static, read-only after creation: the map as it sits in HBM.
@@ -166,6 +176,7 @@ struct Ctx {
   uint32_t *d_pair_qfeat = nullptr, *d_pair_landmark = nullptr, *d_inlier_idx = nullptr;  // [kP3pMaxN]
   P3pState *d_p3p_state = nullptr;
   Pose *d_pose = nullptr;
+  unsigned char *d_result = nullptr;  // one HostResult record; the six pointers below alias into it
   uint32_t *d_view_stats = nullptr;  // [2] views with >= min_putative matches, views passing the F filter
   float *d_bow_query = nullptr;      // [bow_dim]
   uint32_t *d_bow_dist = nullptr;    // [n_views]

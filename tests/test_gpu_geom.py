@@ -60,10 +60,28 @@ def test_minimal_solvers_bit_exact(oracle_c):
     x1 = rng.uniform(-0.5, 0.5, (n, 7, 2))
     x2 = x1 + rng.normal(0, 0.05, (n, 7, 2))
     got = S.debug_math(4, np.concatenate([x1.reshape(n, 14), x2.reshape(n, 14)], 1), 28)
+    got_w = S.debug_math(8, np.concatenate([x1.reshape(n, 14), x2.reshape(n, 14)], 1), 28)  # wave-parallel form
     for i in range(n):
         F = oracle_c.seven_point(x1[i], x2[i])
-        assert int(got[i, 0]) == len(F)
+        assert int(got[i, 0]) == len(F) and int(got_w[i, 0]) == len(F)
         np.testing.assert_array_equal(bits(got[i, 1:1 + 9 * len(F)]), bits(F.ravel()))
+        np.testing.assert_array_equal(bits(got_w[i, 1:1 + 9 * len(F)]), bits(F.ravel()))
+    # degenerate samples (repeated points, collinear, zeros): both forms must agree with the oracle bit for bit
+    xd1 = x1[:40].copy()
+    xd2 = x2[:40].copy()
+    xd1[:10, 3] = xd1[:10, 2]
+    xd2[:10, 3] = xd2[:10, 2]
+    xd1[10:20, :, 1] = 0.0
+    xd2[20:30] = 0.0
+    xd1[30:40] = 0.0
+    xd2[30:40] = 0.0
+    din = np.concatenate([xd1.reshape(40, 14), xd2.reshape(40, 14)], 1)
+    for op in (4, 8):
+        gd = S.debug_math(op, din, 28)
+        for i in range(40):
+            F = oracle_c.seven_point(xd1[i], xd2[i])
+            assert int(gd[i, 0]) == len(F), (op, i)
+            np.testing.assert_array_equal(bits(gd[i, 1:1 + 9 * len(F)]), bits(F.ravel()))
     x = rng.uniform(-0.4, 0.4, (n, 3, 2))
     X = rng.uniform(-3, 3, (n, 3, 3)) + np.array([0, 0, 9.0])
     got = S.debug_math(5, np.concatenate([x.reshape(n, 6), X.reshape(n, 9)], 1), 49)

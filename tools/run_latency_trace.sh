@@ -6,8 +6,8 @@ import csv,glob,re
 f=glob.glob("gpurun_out/prof_lat/*/*kernel_trace.csv")[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-# last query: find last k_hamming_top2
-idx=[i for i,r in enumerate(rows) if "k_hamming_top2" in r["Kernel_Name"]]
+# last query: find last k_hamming_screen
+idx=[i for i,r in enumerate(rows) if "k_hamming_screen" in r["Kernel_Name"]]
 start=idx[-2]
 t0=int(rows[start]["Start_Timestamp"])
 prev_end=t0
