@@ -264,7 +264,7 @@ GD void solve_quartic_real(const double a[5], double out[4]) {
         dxold = dx;
         dx = 0.5 * (xh - xl);
         m = xl + dx;
-        if (xl == m) break;
+        if (xl == m || xh == m) break;  // one-ulp bracket (see cubic_one_root)
       } else {
         dxold = dx;
         dx = f / df;
