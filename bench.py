@@ -94,7 +94,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    forced = os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or (forced and "RANK" in os.environ):
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -118,13 +119,14 @@ def main():
     n_ok = [0]
     nctx = max(1, a.in_flight)
     sharded = None
-    if world > 1:
+    # SFMLOC_BENCH_FORCE_SHARDED=1: rehearse the N>1 code path (parts, collective, merge) on a single rank
+    if world > 1 or forced:
         # bank sharded by view; per batch: stage 1 on every shard, ONE all-gather of candidate parts over RCCL,
         # stage 2 of each query on its owner rank (sfmlocalization_amd/dist.py)
         from sfmlocalization_amd import dist as D
         cap = 4096
         comp = D.HipShardCompute(dev_map, cap, n_contexts=nctx, device=torch.device("cuda", local_rank))
-        sharded = D.ShardedLocalizer(comp, cap, rank=rank, world=world)
+        sharded = D.ShardedLocalizer(comp, cap, rank=rank, world=world, always_gather=forced and dist is not None)
     ctxs = [dev_map.context() for _ in range(nctx)] if sharded is None else []
     t_begin = [0.0] * nctx
     busy = [False] * nctx
@@ -135,24 +137,21 @@ def main():
         n_ok[0] += int(pose.ok)
         busy[k] = False
 
-    batch = []
-
-    def flush():
-        if batch:
-            tb = time.perf_counter()
-            res = sharded.localize_batch([dqs[i % len(dqs)] for i in batch], gather_results=False)
-            dtb = time.perf_counter() - tb
-            lat.extend([dtb] * len(batch))          # a query's latency in batch mode = its batch's wall time
+    def run_sharded(first, count):
+        """`count` steps starting at step `first`, in batches of a.batch through the two-slot pipeline: stage 1 of
+        batch b+1 is queued before batch b's all-gather and P3P stage."""
+        idx = list(range(first, first + count))
+        batches = [idx[k:k + a.batch] for k in range(0, len(idx), a.batch)]
+        t_mark = [time.perf_counter(), time.perf_counter()]   # batch b was enqueued when batch b-2 was yielded
+        stream = sharded.localize_stream([[dqs[i % len(dqs)] for i in b] for b in batches], gather_results=False)
+        for b, res in zip(batches, stream):
+            now = time.perf_counter()
+            lat.extend([now - t_mark[0]] * len(b))          # a query's latency in batch mode = its batch's wall time
+            t_mark = [t_mark[1], now]
             n_ok[0] += sum(int(r["ok"]) for r in res.values())
-            batch.clear()
 
     def step(i):
         # one step = one query through the whole path; up to `nctx` steps overlap on the GPU
-        if sharded is not None:
-            batch.append(i)
-            if len(batch) >= a.batch:
-                flush()
-            return
         k = i % nctx
         if busy[k]:
             finish(k)
@@ -160,12 +159,16 @@ def main():
         ctxs[k].begin(dqs[i % len(dqs)])
         busy[k] = True
 
-    def drain():
+    def run(first, count):
         if sharded is not None:
-            flush()
-            return
+            run_sharded(first, count)
+        else:
+            for i in range(first, first + count):
+                step(i)
+
+    def drain():
         for k in range(nctx):
-            if busy[k]:
+            if sharded is None and busy[k]:
                 finish(k)
 
     def fence():
@@ -175,16 +178,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for i in range(a.warmup):
-        step(i)
+    run(0, a.warmup)
     fence()
     dev_map.stats_reset()
     lat.clear()
     n_ok[0] = 0
     fence()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
+    run(0, a.steps)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -59,35 +59,50 @@ def shard_views(view_off, world):
 
 
 class ShardedLocalizer:
-    """compute.stage1(queries) -> torch.uint8 [B, part_bytes] on compute.device (this shard's parts);
-    compute.stage2(indices, gathered[world, B, part_bytes]) -> {index: result} for the queries this rank owns."""
+    """compute.stage1(queries[, slot]) -> torch.uint8 [B, part_bytes] on compute.device (this shard's parts, possibly
+    still being written: compute.stage1_wait(slot) blocks until they are final);
+    compute.stage2(indices, gathered[world, B, part_bytes][, slot]) -> {index: result} for the queries this rank owns.
+    A compute object with `n_slots >= 2` lets two batches overlap (localize_stream)."""
 
-    def __init__(self, compute, cap, rank=None, world=None, group=None):
+    def __init__(self, compute, cap, rank=None, world=None, group=None, always_gather=False):
         import torch.distributed as dist
         self.dist = dist
+        self.always_gather = always_gather   # run the collective even on one rank (rehearsal of the N>1 path)
         self.compute = compute
         self.cap = cap
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
+        self.n_slots = int(getattr(compute, "n_slots", 1))
 
     def owner(self, i):
         return i % self.world
 
-    def localize_batch(self, queries, gather_results=True):
+    def _stage1(self, queries, slot):
+        if self.n_slots > 1:
+            return self.compute.stage1(queries, slot)
+        return self.compute.stage1(queries)
+
+    def _finish(self, queries, parts, slot, gather_results):
         import torch
         B = len(queries)
-        parts = self.compute.stage1(queries)
         assert parts.dtype == torch.uint8 and tuple(parts.shape) == (B, part_bytes(self.cap))
+        if hasattr(self.compute, "stage1_wait"):
+            self.compute.stage1_wait(slot)     # the parts are written on the compute object's own streams
         # concatenated along dim 0 (the layout every backend accepts), viewed as [world, B, part_bytes]
         flat = torch.empty((self.world * B, parts.shape[1]), dtype=torch.uint8, device=parts.device)
-        if self.world > 1:
+        if self.world > 1 or self.always_gather:
             self.dist.all_gather_into_tensor(flat, parts.contiguous(), group=self.group)
         else:
             flat.copy_(parts)
+        if flat.is_cuda:
+            torch.cuda.current_stream(flat.device).synchronize()   # stage 2 reads `flat` on other streams
         gathered = flat.view(self.world, B, parts.shape[1])
         mine = [i for i in range(B) if self.owner(i) == self.rank]
-        local = self.compute.stage2(mine, gathered)
+        if self.n_slots > 1:
+            local = self.compute.stage2(mine, gathered, slot)
+        else:
+            local = self.compute.stage2(mine, gathered)
         if not gather_results or self.world == 1:
             return local
         allres = [None] * self.world
@@ -97,50 +112,89 @@ class ShardedLocalizer:
             out.update(d)
         return out
 
+    def localize_batch(self, queries, gather_results=True):
+        return self._finish(queries, self._stage1(queries, 0), 0, gather_results)
+
+    def localize_stream(self, batches, gather_results=False):
+        """Generator over batches (lists of queries), yielding each batch's {index: result} in order.  With a
+        two-slot compute object the shard-local stage of batch i+1 is already queued on the GPU while batch i goes
+        through the collective and its P3P stage, so the exchange and the latency-bound tail hide under the next
+        batch's Hamming scans.  Every rank must iterate the same batches."""
+        prev = None
+        slot = 0
+        for batch in batches:
+            if self.n_slots < 2:
+                yield self.localize_batch(batch, gather_results)
+                continue
+            cur = (batch, self._stage1(batch, slot), slot)
+            if prev is not None:
+                yield self._finish(*prev, gather_results)
+            prev = cur
+            slot ^= 1
+        if prev is not None:
+            yield self._finish(*prev, gather_results)
+
 
 class HipShardCompute:
     """Stage 1 / stage 2 on one MI355X through the C ABI.  `shard_map` is a capi.Map holding this rank's views
-    (with the FULL landmark table); queries are capi.Query objects created on it."""
+    (with the FULL landmark table); queries are capi.Query objects created on it.  Two slots of `n_contexts`
+    contexts each, so that ShardedLocalizer.localize_stream can overlap consecutive batches."""
+
+    n_slots = 2
 
     def __init__(self, shard_map, cap, n_contexts=4, device=None):
         import torch
         self.map = shard_map
         self.cap = cap
         self.device = torch.device("cuda", shard_map.params.device) if device is None else device
-        self.ctxs = [shard_map.context() for _ in range(n_contexts)]
+        self.ctxs = [[shard_map.context() for _ in range(n_contexts)] for _ in range(self.n_slots)]
+        self._parts = [None] * self.n_slots
+        self._queries = [None] * self.n_slots
 
     def close(self):
-        for c in self.ctxs:
-            c.close()
+        for cs in self.ctxs:
+            for c in cs:
+                c.close()
 
-    def stage1(self, queries):
+    def stage1(self, queries, slot=0):
         import torch
         B = len(queries)
         pb = part_bytes(self.cap)
-        parts = torch.zeros((B, pb), dtype=torch.uint8, device=self.device)
+        parts = self._parts[slot]
+        if parts is None or parts.shape[0] != B:
+            # persistent per slot; sfmloc_shard_export writes every byte of a part, so no clearing is needed (and a
+            # fill on torch's stream would race with the exports on the contexts' streams)
+            parts = torch.empty((B, pb), dtype=torch.uint8, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()
+            self._parts[slot] = parts
         base = parts.data_ptr()
+        cs = self.ctxs[slot]
         for i, q in enumerate(queries):
-            c = self.ctxs[i % len(self.ctxs)]
+            c = cs[i % len(cs)]
             c.shard_begin(q)                       # K1..K3 + candidate emission, asynchronous
             c.shard_export(base + i * pb, self.cap)  # device-to-device copy on the same stream
-        for c in self.ctxs:
-            c.sync()                               # the collective runs on torch's stream
-        self._queries = queries
+        self._queries[slot] = queries
         return parts
 
-    def stage2(self, indices, gathered):
+    def stage1_wait(self, slot=0):
+        for c in self.ctxs[slot]:
+            c.sync()                               # the collective runs on torch's stream
+
+    def stage2(self, indices, gathered, slot=0):
         world, B, pb = gathered.shape
         base = gathered.data_ptr()
         out = {}
-        n = len(self.ctxs)
+        cs = self.ctxs[slot]
+        n = len(cs)
+        queries = self._queries[slot]
         pending = []
         for k, i in enumerate(indices):
-            c = self.ctxs[k % n]
+            c = cs[k % n]
             if k >= n:
                 j, cj = pending.pop(0)
                 out[j] = _pose_tuple(cj.end())
             # query i's parts: gathered[r, i, :] for r in range(world) -> stride B*pb
-            c.merge_begin(self._queries[i], base + i * pb, world, self.cap, part_stride=B * pb)
+            c.merge_begin(queries[i], base + i * pb, world, self.cap, part_stride=B * pb)
             pending.append((i, c))
         for j, cj in pending:
             out[j] = _pose_tuple(cj.end())

@@ -45,20 +45,24 @@ class OracleShardCompute:
         self.m, self.v0, self.v1, self.cap = m, v0, v1, cap
         self.device = torch.device("cpu")
 
-    def stage1(self, queries):
+    n_slots = 2      # so that ShardedLocalizer.localize_stream takes its pipelined branch
+
+    def stage1(self, queries, slot=0):
         from oracle import pipeline as opipe
-        self.queries = queries
+        if not hasattr(self, "queries"):
+            self.queries = {}
+        self.queries[slot] = queries
         rows = [D.pack_part(opipe.shard_candidates(self.m, q.desc, q.kpt_xy, (q.width, q.height), self.v0, self.v1),
                             self.cap) for q in queries]
         return torch.from_numpy(np.stack(rows))
 
-    def stage2(self, indices, gathered):
+    def stage2(self, indices, gathered, slot=0):
         from oracle import pipeline as opipe
         g = gathered.numpy()
         out = {}
         for i in indices:
             parts = [D.unpack_part(g[r, i], self.cap) for r in range(g.shape[0])]
-            out[i] = opipe.merge_candidates(parts, self.queries[i].kpt_xy, self.m.intrinsic)
+            out[i] = opipe.merge_candidates(parts, self.queries[slot][i].kpt_xy, self.m.intrinsic)
         return out
 
 
@@ -75,6 +79,15 @@ def _worker(rank, world, port, q):
         v0, v1 = D.shard_views(m.view_off, world)[rank]
         loc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), cap=2048)
         res = loc.localize_batch(queries)
+        # the pipelined form over three uneven batches must give the same per-query results
+        batches = [[queries[0], queries[1]], [queries[2]], [queries[2], queries[0]]]
+        for b, out in zip(batches, loc.localize_stream(batches, gather_results=True)):
+            for i, qq in enumerate(b):
+                k = [id(x) for x in queries].index(id(qq))
+                assert out[i]["ok"] == res[k]["ok"], "stream vs batch: ok"
+                if out[i]["ok"]:
+                    assert np.array_equal(np.asarray(out[i]["pair_qfeat"]), np.asarray(res[k]["pair_qfeat"]))
+                    assert np.array_equal(np.asarray(out[i]["P"]), np.asarray(res[k]["P"]))
         if rank == 0:
             q.put({i: {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for i, r in res.items()})
     except Exception as e:  # surface the failure instead of letting the parent time out

@@ -364,6 +364,16 @@ def test_sharded_map_equals_unsharded(oracle_c):
         assert res[i]["ok"] == bool(ref[0].ok)
         np.testing.assert_array_equal(res[i]["pair_qfeat"], ref[1])
         np.testing.assert_array_equal(bits(res[i]["P"].ravel()), bits(np.array(ref[0].P)))
+    # the two-slot pipeline (stage 1 of batch b+1 queued before batch b's exchange and P3P stage): same results
+    batches = [[dqs[0], dqs[1]], [dqs[2]], [dqs[1], dqs[0], dqs[2]]]
+    outs = list(loc.localize_stream(batches))
+    assert len(outs) == 3
+    for b, out in zip(batches, outs):
+        for i, dq in enumerate(b):
+            k = dqs.index(dq)
+            assert out[i]["ok"] == res[k]["ok"]
+            np.testing.assert_array_equal(out[i]["pair_qfeat"], res[k]["pair_qfeat"])
+            np.testing.assert_array_equal(bits(out[i]["P"].ravel()), bits(res[k]["P"].ravel()))
     comp.close()
     for dq in dqs:
         dq.close()
