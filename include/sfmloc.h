@@ -327,6 +327,37 @@ int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin
 int sfmloc_akaze_levels(const sfmloc_akaze *ak, int *n_levels, int *wh);
 int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt);
 
+/* ------------------------------------------------------------------------- */
+/* Map-side matching: the reference's matchAKAZE /         */
+/* trackAKAZE on the same kernels.  Views are addressed by their index in the  */
+/* map's view table (ascending view id).                                       */
+/* ------------------------------------------------------------------------- */
+typedef struct sfmloc_matches sfmloc_matches; /* PairWiseMatches: std::map<Pair, vector<IndMatch>> flattened */
+
+/* The descriptors (and keypoints) of one map image as a query object, rebuilt on the device from the bank: what
+ * the reference obtains by re-reading <base>.desc for the second image of a pair (MatchUtils.cpp:85-96). */
+int sfmloc_query_from_view(sfmloc_map *map, uint32_t view_index, sfmloc_query **out);
+
+/* matchAKAZE's per-pair body (MatchUtils.cpp:99-150) for first = each selected view, second = the query:
+ * 2-NN + ratio of every row of `first` among the query's rows (sfmloc_match_putative), then the one-to-one filter
+ * (a query row hit twice or more loses all its hits, :125-143) and the emit loop that never emits the last row of
+ * `first` (:146).  Results are read with sfmloc_putative_read. */
+int sfmloc_match_one_to_one(sfmloc_map *map, sfmloc_query *query, const uint32_t *view_sel, uint32_t n_sel);
+
+/* hulo::matchAKAZE (MatchUtils.cpp:73-152): pairs[2k], pairs[2k+1] = (first, second) view indices; images with
+ * fewer than 2 descriptors are skipped (:101-103); pairs without matches get no entry. */
+int sfmloc_match_pairs(sfmloc_map *map, const uint32_t *pairs, uint32_t n_pairs, sfmloc_matches **out);
+
+/* hulo::trackAKAZE (MatchUtils.cpp:156-277) over the map's views in table order: consecutive-frame matches as
+ * above, then chained up to max_frame_dist frames apart (:240-276).  Every consecutive pair has an entry (possibly
+ * empty), longer-range pairs only when non-empty, as the reference's std::map ends up. */
+int sfmloc_track(sfmloc_map *map, uint32_t max_frame_dist, sfmloc_matches **out);
+
+uint32_t sfmloc_matches_pairs(const sfmloc_matches *m); /* number of (I, J) entries, ascending (I, J) */
+int sfmloc_matches_pair(const sfmloc_matches *m, uint32_t k, uint32_t *view_i, uint32_t *view_j, uint32_t *n);
+int sfmloc_matches_read(const sfmloc_matches *m, uint32_t k, uint32_t *i, uint32_t *j, uint32_t cap);
+void sfmloc_matches_destroy(sfmloc_matches *m);
+
 /* Parity probe: runs one of the f64 device building blocks over n items (tests compare with the oracle).
  * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample,
  *     8 seven-point, wave-parallel form (K3's fast kernel; layout of op 4) */

@@ -124,3 +124,68 @@ def merge_candidates(parts, q_kpt, intrinsic, min_resection_points=8, min_inlier
             res.update(ok=True, K=K, R=R, center=c, P=r["P"], pair_qfeat=qf[r["inliers"]],
                        pair_landmark=lm_id[r["inliers"]])
     return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# map-side twins: literal restatements of hulo::matchAKAZE / trackAKAZE with the exact matcher
+# ---------------------------------------------------------------------------------------------------
+def match_akaze_pair(desc1, desc2, ratio=0.6):
+    """MatchUtils.cpp:99-150 for one pair: rows of desc1 (first) matched among desc2 (second), one-to-one filter,
+    the emit loop that stops before the last row.  -> (i[], j[])"""
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 64)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 64)
+    n1 = len(desc1)
+    if n1 < 2 or len(desc2) < 2:
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+    cnt, mi, mj, _ = oracle_c.match_to_query(desc2, desc1, np.array([0, n1], np.uint32), None, ratio)
+    ind = np.full(n1, -1, np.int64)                     # matchesInd
+    ind[mi[:cnt[0]].astype(np.int64)] = mj[:cnt[0]].astype(np.int64)
+    for i in range(n1 - 1):                             # :125-143
+        if ind[i] == -1:
+            continue
+        dup = False
+        for j in range(i + 1, n1):
+            if ind[i] == ind[j]:
+                ind[j] = -1
+                dup = True
+        if dup:
+            ind[i] = -1
+    keep = [i for i in range(n1 - 1) if ind[i] != -1]   # :146-149
+    return np.array(keep, np.uint32), ind[keep].astype(np.uint32)
+
+
+def match_akaze(descs, pairs, ratio=0.6):
+    """hulo::matchAKAZE (MatchUtils.cpp:73-152): {(first, second): (i[], j[])}, no entry for an empty list."""
+    out = {}
+    for a, b in pairs:
+        mi, mj = match_akaze_pair(descs[a], descs[b], ratio)
+        if len(mi):
+            out[(int(a), int(b))] = (mi, mj)
+    return dict(sorted(out.items()))
+
+
+def track_akaze(descs, max_frame_dist, ratio=0.6):
+    """hulo::trackAKAZE (MatchUtils.cpp:156-277) over frames 0..N-1."""
+    N = len(descs)
+    matches = {}
+    for f in range(N - 1):
+        mi, mj = match_akaze_pair(descs[f], descs[f + 1], ratio)
+        matches[(f, f + 1)] = (list(mi), list(mj))      # operator[] at :228 creates the entry even when empty
+    tp = []
+    for f in range(N - 1):
+        t = np.full(len(descs[f]), -1, np.int64)
+        mi, mj = matches[(f, f + 1)]
+        t[np.array(mi, np.int64)] = np.array(mj, np.int64)
+        tp.append(t)
+    for f in range(N - 1):
+        for to in range(f + 2, min(f + max_frame_dist, N)):
+            for i in range(len(tp[f])):
+                t = tp[f][i]
+                if t != -1:
+                    nxt = tp[to - 1][t]
+                    tp[f][i] = nxt
+                    if nxt != -1:
+                        e = matches.setdefault((f, to), ([], []))
+                        e[0].append(i)
+                        e[1].append(int(nxt))
+    return {k: (np.array(v[0], np.uint32), np.array(v[1], np.uint32)) for k, v in sorted(matches.items())}

@@ -103,6 +103,8 @@ SYMBOLS = [
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
     "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
     "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
+    "sfmloc_query_from_view", "sfmloc_match_one_to_one", "sfmloc_match_pairs", "sfmloc_track",
+    "sfmloc_matches_pairs", "sfmloc_matches_pair", "sfmloc_matches_read", "sfmloc_matches_destroy",
     "sfmloc_localize_batch", "sfmloc_part_bytes", "sfmloc_shard_begin", "sfmloc_shard_export",
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
@@ -137,6 +139,17 @@ def _L():
         L.sfmloc_match_putative.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
         L.sfmloc_putative_read.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4 + [C.c_uint64]
         L.sfmloc_putative_read_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.sfmloc_query_from_view.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sfmloc_match_one_to_one.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        L.sfmloc_match_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sfmloc_track.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sfmloc_matches_pairs.argtypes = [C.c_void_p]
+        L.sfmloc_matches_pairs.restype = C.c_uint32
+        L.sfmloc_matches_pair.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint32)]
+        L.sfmloc_matches_read.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]
+        L.sfmloc_matches_destroy.argtypes = [C.c_void_p]
+        L.sfmloc_matches_destroy.restype = None
         L.sfmloc_sync.argtypes = [C.c_void_p]
         U32P, F64P = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
         L.sfmloc_geometric_filter.argtypes = [C.c_void_p, C.c_void_p]
@@ -357,6 +370,48 @@ class Map:
 
     def sync(self):
         _check(_L().sfmloc_sync(self._h))
+
+    # ----- map-side matching (matchAKAZE / trackAKAZE, MatchUtils.cpp:73-277) -----
+    def query_from_view(self, view_index):
+        """sfmloc_query_from_view: one map image's descriptors as a Query (rebuilt from the bank on the device)."""
+        return Query._from_view(self, int(view_index))
+
+    def match_one_to_one(self, q, view_sel=None):
+        """sfmloc_match_one_to_one: putative matching + matchAKAZE's one-to-one filter; read with putative_read()."""
+        if view_sel is None:
+            _check(_L().sfmloc_match_one_to_one(self._h, q._h, None, 0))
+        else:
+            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
+            _check(_L().sfmloc_match_one_to_one(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+
+    @staticmethod
+    def _take_matches(h):
+        out = {}
+        try:
+            for k in range(_L().sfmloc_matches_pairs(h)):
+                vi, vj, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+                _check(_L().sfmloc_matches_pair(h, k, C.byref(vi), C.byref(vj), C.byref(n)))
+                mi = np.zeros(n.value, np.uint32)
+                mj = np.zeros(n.value, np.uint32)
+                _check(_L().sfmloc_matches_read(h, k, _ptr(mi, C.c_uint32), _ptr(mj, C.c_uint32), n.value))
+                out[(vi.value, vj.value)] = (mi, mj)
+        finally:
+            _L().sfmloc_matches_destroy(h)
+        return out
+
+    def match_pairs(self, pairs):
+        """sfmloc_match_pairs (hulo::matchAKAZE): pairs = [(first, second) view indices] ->
+        {(first, second): (i[], j[])} in std::map order."""
+        arr = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        h = C.c_void_p()
+        _check(_L().sfmloc_match_pairs(self._h, _ptr(arr, C.c_uint32), arr.shape[0], C.byref(h)))
+        return self._take_matches(h)
+
+    def track(self, max_frame_dist):
+        """sfmloc_track (hulo::trackAKAZE) over the views in table order."""
+        h = C.c_void_p()
+        _check(_L().sfmloc_track(self._h, int(max_frame_dist), C.byref(h)))
+        return self._take_matches(h)
 
     def geometric_filter(self, q):
         _check(_L().sfmloc_geometric_filter(self._h, q._h))
@@ -633,6 +688,18 @@ class Query:
                                         int(width), int(height), C.byref(h)))
         self._h = h
         m._children.add(self)
+
+    @classmethod
+    def _from_view(cls, m, view_index):
+        self = cls.__new__(cls)
+        self._h = None
+        self.map = m
+        self.n = int(m.view_off[view_index + 1] - m.view_off[view_index])
+        h = C.c_void_p()
+        _check(_L().sfmloc_query_from_view(m._h, view_index, C.byref(h)))
+        self._h = h
+        m._children.add(self)
+        return self
 
     def close(self):
         if self._h is not None and self.map._h is not None:

@@ -426,6 +426,10 @@ int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *p
 }
 
 }  // namespace
+
+int match_putative_on(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel) {
+  return ctx_match_putative(c, q, view_sel, n_sel);
+}
 }  // namespace sfmloc
 
 using namespace sfmloc;

@@ -211,6 +211,9 @@ struct Query {
   std::vector<float> h_kpt;
 };
 
+// capi.hip: K1 + K2 of the selected views against q on context c (sfmloc_match_putative's body)
+int match_putative_on(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel);
+
 // hamming.hip
 int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, uint4 *d_bank, hipStream_t s);
 int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split);

@@ -91,3 +91,21 @@ def test_match_to_query_views(oracle_c):
         lst = a[1][off:off + int(cnt[v])]
         assert (np.diff(lst.astype(np.int64)) > 0).all()
     del rng
+
+
+def test_match_akaze_pair_one_to_one_and_last_row():
+    """Literal restatement of MatchUtils.cpp:99-150 on a handcrafted pair: rows 1 and 2 hit the same train row
+    (both dropped), the last row has a perfect match but is never emitted."""
+    from oracle import oracle_c, pipeline as opipe
+    oracle_c.build()
+    rng = np.random.Generator(np.random.PCG64(3))
+    d2 = rng.integers(0, 256, (6, 64), dtype=np.uint8)
+    d2[:, 61:] = 0
+    d1 = np.stack([d2[0], d2[1], d2[1], d2[3], rng.integers(0, 256, 64, dtype=np.uint8), d2[5]])
+    d1[:, 61:] = 0
+    mi, mj = opipe.match_akaze_pair(d1, d2)
+    assert mi.tolist() == [0, 3] and mj.tolist() == [0, 3]
+    assert opipe.match_akaze_pair(d1[:1], d2)[0].size == 0          # fewer than 2 rows: skipped (:101-103)
+    tr = opipe.track_akaze([d1, d2, d2], 3)
+    assert list(tr) == [(0, 1), (0, 2), (1, 2)]
+    assert tr[(1, 2)][0].tolist() == [0, 1, 2, 3, 4] and tr[(0, 2)][0].tolist() == [0, 3]
