@@ -327,6 +327,13 @@ int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin
 int sfmloc_akaze_levels(const sfmloc_akaze *ak, int *n_levels, int *wh);
 int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt);
 
+/* Dense-BoW front end (DenseLocalFeatureWrapper.cpp:89-99): colour image (BGR, 8-bit,
+ * row-major h x w x 3) -> cv::resize(size x size, INTER_CUBIC) -> BGR2GRAY -> normalize(0, 255, NORM_MINMAX);
+ * gray_out [size*size].  The grid keypoints (DenseFeatureDetector.cpp:44-69) and the chaining into
+ * sfmloc_akaze_compute / sfmloc_bof_compute are host glue (sfmlocalization_amd/engine.py::dense_bow). */
+int sfmloc_dense_gray(int device, const uint8_t *bgr, uint32_t width, uint32_t height, uint32_t size,
+                      uint8_t *gray_out);
+
 /* ------------------------------------------------------------------------- */
 /* Map-side matching: the reference's matchAKAZE /         */
 /* trackAKAZE on the same kernels.  Views are addressed by their index in the  */

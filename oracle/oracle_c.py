@@ -315,3 +315,13 @@ def akaze_math(x, y):
     out = np.zeros(3, np.float32)
     lib().orc_akaze_math(C.c_float(x), C.c_float(y), _p(out, C.c_float))
     return out
+
+
+def dense_gray(bgr, size=300):
+    """orc_dense_gray: resize(INTER_CUBIC) -> BGR2GRAY -> normalize(MINMAX) restatement (sfm_oracle_bow.c)."""
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w, c = bgr.shape
+    assert c == 3
+    out = np.zeros((size, size), np.uint8)
+    lib().orc_dense_gray(_p(bgr, C.c_uint8), C.c_int(w), C.c_int(h), C.c_int(size), _p(out, C.c_uint8))
+    return out

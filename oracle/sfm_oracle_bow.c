@@ -166,3 +166,87 @@ void orc_bof(const float *desc, const float *kxy, int n, int in_dim, const float
     }
   }
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Dense-BoW front end (DenseLocalFeatureWrapper.cpp:89-99): restatement of OpenCV 3.0's 8-bit
+ * cv::resize(INTER_CUBIC) as its two passes (rows to an int buffer, then columns), BGR2GRAY and
+ * normalize(0, 255, NORM_MINMAX).  OpenCV is not available here: parity with it is unpinned.
+ * ------------------------------------------------------------------------------------------------------- */
+static void orc_cubic_coeffs(float x, float *c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+static short orc_sat_short(float v) {
+  const float r = nearbyintf(v);
+  return (short)(r > 32767.f ? 32767.f : (r < -32768.f ? -32768.f : r));
+}
+
+static int orc_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void orc_dense_gray(const uint8_t *bgr, int w, int h, int size, uint8_t *gray) {
+  int *xofs = (int *)malloc(sizeof(int) * size), *yofs = (int *)malloc(sizeof(int) * size);
+  short *xa = (short *)malloc(sizeof(short) * 4 * size), *ya = (short *)malloc(sizeof(short) * 4 * size);
+  const double scale_x = 1.0 / ((double)size / (double)w), scale_y = 1.0 / ((double)size / (double)h);
+  for (int d = 0; d < size; ++d) {
+    float c[4];
+    float fx = (float)((d + 0.5) * scale_x - 0.5);
+    int s = (int)floorf(fx);
+    fx -= (float)s;
+    orc_cubic_coeffs(fx, c);
+    xofs[d] = s;
+    for (int k = 0; k < 4; ++k) xa[4 * d + k] = orc_sat_short(c[k] * 2048.f);
+    float fy = (float)((d + 0.5) * scale_y - 0.5);
+    s = (int)floorf(fy);
+    fy -= (float)s;
+    orc_cubic_coeffs(fy, c);
+    yofs[d] = s;
+    for (int k = 0; k < 4; ++k) ya[4 * d + k] = orc_sat_short(c[k] * 2048.f);
+  }
+  /* pass 1: every source row resampled horizontally (int, unshifted) */
+  int *rows = (int *)malloc(sizeof(int) * (size_t)h * size * 3);
+  for (int y = 0; y < h; ++y)
+    for (int d = 0; d < size; ++d)
+      for (int c = 0; c < 3; ++c) {
+        int acc = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int x = orc_clampi(xofs[d] - 1 + k, 0, w - 1);
+          acc += (int)bgr[((size_t)y * w + x) * 3 + c] * (int)xa[4 * d + k];
+        }
+        rows[((size_t)y * size + d) * 3 + c] = acc;
+      }
+  /* pass 2: columns, rounding shift by 22, saturate; then gray */
+  int gmin = 255, gmax = 0;
+  for (int dy = 0; dy < size; ++dy)
+    for (int dx = 0; dx < size; ++dx) {
+      int ch[3];
+      for (int c = 0; c < 3; ++c) {
+        int acc = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int y = orc_clampi(yofs[dy] - 1 + k, 0, h - 1);
+          acc += rows[((size_t)y * size + dx) * 3 + c] * (int)ya[4 * dy + k];
+        }
+        ch[c] = orc_clampi((acc + (1 << 21)) >> 22, 0, 255);
+      }
+      const int g = (ch[0] * 1868 + ch[1] * 9617 + ch[2] * 4899 + 8192) >> 14;
+      gray[(size_t)dy * size + dx] = (uint8_t)g;
+      if (g < gmin) gmin = g;
+      if (g > gmax) gmax = g;
+    }
+  const double smin = gmin, smax = gmax;
+  const double scale_d = 255.0 * ((smax - smin > 2.220446049250313e-16) ? 1.0 / (smax - smin) : 0.0);
+  const float scale = (float)scale_d, shift = (float)(0.0 - smin * scale_d);
+  for (size_t i = 0; i < (size_t)size * size; ++i) {
+    const float v = (float)gray[i] * scale + shift;
+    const float r = nearbyintf(v);
+    gray[i] = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+  }
+  free(rows);
+  free(xofs);
+  free(yofs);
+  free(xa);
+  free(ya);
+}

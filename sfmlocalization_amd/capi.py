@@ -103,7 +103,7 @@ SYMBOLS = [
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
     "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
     "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
-    "sfmloc_query_from_view", "sfmloc_match_one_to_one", "sfmloc_match_pairs", "sfmloc_track",
+    "sfmloc_dense_gray", "sfmloc_query_from_view", "sfmloc_match_one_to_one", "sfmloc_match_pairs", "sfmloc_track",
     "sfmloc_matches_pairs", "sfmloc_matches_pair", "sfmloc_matches_read", "sfmloc_matches_destroy",
     "sfmloc_localize_batch", "sfmloc_part_bytes", "sfmloc_shard_begin", "sfmloc_shard_export",
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
@@ -139,6 +139,8 @@ def _L():
         L.sfmloc_match_putative.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
         L.sfmloc_putative_read.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4 + [C.c_uint64]
         L.sfmloc_putative_read_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.sfmloc_dense_gray.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.POINTER(C.c_uint8)]
         L.sfmloc_query_from_view.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         L.sfmloc_match_one_to_one.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
         L.sfmloc_match_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_void_p)]
@@ -227,6 +229,18 @@ def default_params(**overrides):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def dense_gray(bgr, size=300, device=0):
+    """sfmloc_dense_gray: BGR u8 [h, w, 3] -> the size x size gray image the dense AKAZE describes
+    (DenseLocalFeatureWrapper.cpp:89-99)."""
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w, c = bgr.shape
+    if c != 3:
+        raise ValueError("dense_gray: expected an h x w x 3 BGR image")
+    out = np.zeros((size, size), np.uint8)
+    _check(_L().sfmloc_dense_gray(device, _ptr(bgr, C.c_uint8), w, h, size, _ptr(out, C.c_uint8)))
+    return out
 
 
 def debug_math(op, x, out_stride, device=0):
@@ -529,6 +543,7 @@ class BofModel:
         _check(_L().sfmloc_bof_create(C.byref(d), device, C.byref(h)))
         self._h = h
         self.dim = int(_L().sfmloc_bof_dim(h))
+        self.resized = int(resized)
 
     @classmethod
     def from_files(cls, bow_file, pca_file=None, in_dim=61, device=0):

@@ -40,6 +40,16 @@ def _load_gray(path):
         return None
 
 
+def _load_bgr(path):
+    """imread(filename, IMREAD_COLOR) (DenseLocalFeatureWrapper.cpp:85) through PIL: h x w x 3, B G R order."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8)[:, :, ::-1])
+    except Exception:
+        return None
+
+
 def synth_round6(a):
     a = np.asarray(a, dtype=np.float32)
     return np.array([np.float32(float("%.6g" % float(v))) for v in a.ravel()], dtype=np.float32).reshape(a.shape)
@@ -141,6 +151,47 @@ class LocalizeEngine:
         return list(c) + list(R.ravel()), extras
 
 
+def dense_grid_keypoints(size=300, step=6, levels=4, init_scale=4.0, scale_mul=1.5, bound=0):
+    """DenseFeatureDetector::detectImpl (BoWCommon/src/DenseFeatureDetector.cpp:44-69) with the constants of
+    DenseLocalFeatureWrapper.h:32-38: per scale level s a regular grid (x fastest), size = init_scale * mul^s,
+    class_id = s (which cv::AKAZE::compute then reads as the evolution level).  -> [n, 4] f32 (x, y, size, class_id)"""
+    out = []
+    fs = np.float32(init_scale)
+    for s in range(levels):
+        for y in range(bound, size - bound, step):
+            for x in range(bound, size - bound, step):
+                out.append((x, y, fs, s))
+        fs = np.float32(fs * np.float32(scale_mul))
+    return np.array(out, np.float32).reshape(-1, 4)
+
+
+class DenseBow:
+    """The query-side BoW vector of the reference (DenseLocalFeatureWrapper::calcDenseLocalFeature ->
+    PcaWrapper::calcPcaProject -> BoFSpatialPyramids::calcBoF; LocalizeEngine.cc:205-232): colour image ->
+    300x300 gray (sfmloc_dense_gray) -> dense-grid AKAZE descriptors (sfmloc_akaze_compute, cv::AKAZE defaults) as
+    float32 -> PCA + BoF (sfmloc_bof_compute)."""
+
+    def __init__(self, bow_file, pca_file=None, device=0):
+        self.bof = capi.BofModel.from_files(bow_file, pca_file, in_dim=61, device=device)
+        self.size = int(self.bof.resized) if hasattr(self.bof, "resized") else 300
+        self.device = device
+        self.akaze = capi.Akaze(self.size, self.size, 4, 4, 0.001, device=device)   # cv::AKAZE::create() defaults
+        self.grid = dense_grid_keypoints(self.size)
+
+    def local_features(self, bgr):
+        gray = capi.dense_gray(bgr, self.size, device=self.device)
+        desc, _ = self.akaze.compute(gray, self.grid)
+        return desc[:, :61].astype(np.float32), self.grid[:, :2].copy(), gray      # convertTo(CV_32FC1)
+
+    def compute(self, bgr):
+        feats, kxy, _ = self.local_features(bgr)
+        return self.bof.compute(feats, kxy)
+
+    def close(self):
+        self.akaze.close()
+        self.bof.close()
+
+
 def parse_cv_args(argv, spec):
     """cv::CommandLineParser syntax: positional arguments and -k=v / --key=v / bare flags."""
     pos, opts = [], {}
@@ -216,6 +267,7 @@ def main(argv=None):
     every = o["locEvryNFrame"] if o["locEvryNFrame"] > 0 else 1
     os.makedirs(out_dir, exist_ok=True)
     n_img, match_next = 0, 0
+    dense = None
     for img in images:
         n_img += 1
         if n_img % every == 0:      # localization.cpp:289-298
@@ -243,11 +295,18 @@ def main(argv=None):
         center = (o["cenLocX"], o["cenLocY"], o["cenLocZ"]) if o["cenRadius"] > 0 else None
         bow = None
         if o["knnbow"] > 0 and o["bowModelFile"]:
-            # the query's BoW vector: <base>.bow next to its features (what TrainBoW's calcBoF writes per view,
-            # TrainBoW.cpp:256-271) until dense AKAZE extraction runs on the GPU
+            # the query's BoW vector (localization.cpp:346-361): a precomputed <base>.bow next to its features if
+            # there is one (what TrainBoW's calcBoF writes per view, TrainBoW.cpp:256-271), else computed from the
+            # colour image as the reference does (DenseLocalFeatureWrapper -> PcaWrapper -> BoFSpatialPyramids)
             bpath = os.path.join(fdir, base + ".bow")
             if os.path.exists(bpath):
                 bow = fileio.read_mat_bin(bpath).ravel()
+            else:
+                bgr = _load_bgr(img)
+                if bgr is not None:
+                    if dense is None:
+                        dense = DenseBow(o["bowModelFile"], o["pcaModelFile"] or None, device=o["device"])
+                    bow = dense.compute(bgr)
         res, ex = eng.localize(desc, feat[:, :2], w, h, center=center, radius=o["cenRadius"], bow=bow)
         if not res:
             print("Fail to estimate camera matrix" if ex else "Not enough putative matches")
@@ -260,6 +319,8 @@ def main(argv=None):
         match_next = every - 1
         print("complete")
     eng.close()
+    if dense is not None:
+        dense.close()
     return 0
 
 

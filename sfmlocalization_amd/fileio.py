@@ -257,3 +257,31 @@ def write_result_json(out_dir, query_path, sfm_data_path, matches_dir, **kw):
     with open(path, "w") as f:
         f.write(format_result_json(query_path, sfm_data_path, matches_dir, **kw))
     return path
+
+
+# ---------------------------------------------------------------------------------------------------------
+# PairWiseMatches text files (matches.putative.txt / matches.f.txt): "I J\nN\ni j\n..." per pair, pairs in
+# std::map order -- hulo::exportMatch (FileUtils.cpp:123-148) and OpenMVG's matching::Save(".txt") share the layout
+# ---------------------------------------------------------------------------------------------------------
+def write_matches_txt(path, matches):
+    """matches: {(I, J): (i[], j[])} as Map.match_pairs / Map.track return (view ids as keys)."""
+    with open(path, "w") as fh:
+        for (a, b) in sorted(matches):
+            mi, mj = matches[(a, b)]
+            fh.write(f"{int(a)} {int(b)}\n{len(mi)}\n")
+            for x, y in zip(mi, mj):
+                fh.write(f"{int(x)} {int(y)}\n")
+
+
+def read_matches_txt(path):
+    out = {}
+    with open(path) as fh:
+        tok = fh.read().split()
+    p = 0
+    while p < len(tok):
+        a, b, n = int(tok[p]), int(tok[p + 1]), int(tok[p + 2])
+        p += 3
+        arr = np.array(tok[p:p + 2 * n], dtype=np.int64).reshape(n, 2) if n else np.zeros((0, 2), np.int64)
+        p += 2 * n
+        out[(a, b)] = (arr[:, 0].astype(np.uint32), arr[:, 1].astype(np.uint32))
+    return out

@@ -127,3 +127,17 @@ def test_cli_argument_syntax():
     assert o["cenRadius"] == -1.0 and o["cenLocX"] == -3.5 and o["geomLimit"] == 4.0 and o["locEvryNFrame"] == 1
     _, d = engine.parse_cv_args(["a", "b", "c", "d"], engine.KEYS)               # defaults: localization.cpp:70-82
     assert (d["fDistRatio"], d["ransacRound"], d["knnbow"], d["geomLimit"]) == (0.6, 200, 0, 4.0)
+
+
+def test_matches_txt_roundtrip(tmp_path):
+    from sfmlocalization_amd import fileio
+    m = {(0, 1): (np.array([0, 5, 9], np.uint32), np.array([3, 2, 7], np.uint32)),
+         (0, 2): (np.zeros(0, np.uint32), np.zeros(0, np.uint32)),
+         (3, 10): (np.array([1], np.uint32), np.array([1], np.uint32))}
+    p = tmp_path / "matches.putative.txt"
+    fileio.write_matches_txt(p, m)
+    assert p.read_text() == "0 1\n3\n0 3\n5 2\n9 7\n0 2\n0\n3 10\n1\n1 1\n"   # FileUtils.cpp:123-148 layout
+    back = fileio.read_matches_txt(p)
+    assert list(back) == sorted(m)
+    for k in m:
+        assert back[k][0].tolist() == m[k][0].tolist() and back[k][1].tolist() == m[k][1].tolist()

@@ -1,0 +1,66 @@
+"""Dense-BoW front end through the C ABI: sfmloc_dense_gray against the CPU restatement of
+resize(INTER_CUBIC) -> BGR2GRAY -> normalize(MINMAX), the grid of DenseFeatureDetector, and the chain
+image -> dense AKAZE -> PCA -> BoF against the same chain built from the oracle's stages.  Bit-exact."""
+import numpy as np
+import pytest
+
+import sfmlocalization_amd as S
+from sfmlocalization_amd import engine, fileio, synth
+from oracle import oracle_c
+
+pytestmark = pytest.mark.gpu
+
+
+def colour_image(seed, w, h):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = synth.texture_image(seed, h, w).astype(np.float32)
+    img = np.stack([np.clip(g * a + b + rng.normal(0, 3, g.shape), 0, 255) for a, b in ((1.0, 0), (0.8, 20), (0.6, 40))],
+                   axis=2)
+    return img.astype(np.uint8)
+
+
+@pytest.mark.parametrize("wh", [(640, 480), (300, 300), (1920, 1080), (211, 157), (40, 700)])
+def test_dense_gray_bit_exact(oracle_c, wh):
+    w, h = wh
+    img = colour_image(w + h, w, h)
+    got = S.dense_gray(img, 300)
+    exp = oracle_c.dense_gray(img, 300)
+    np.testing.assert_array_equal(got, exp)
+    assert got.min() == 0 and got.max() == 255            # NORM_MINMAX stretched it
+    flat = np.full((50, 60, 3), 77, np.uint8)               # max == min -> scale 0 -> all zeros
+    np.testing.assert_array_equal(S.dense_gray(flat, 64), oracle_c.dense_gray(flat, 64))
+    assert S.dense_gray(flat, 64).max() == 0
+
+
+def test_grid_keypoints():
+    g = engine.dense_grid_keypoints()
+    assert g.shape == (10000, 4)                            # 50 x 50 x 4
+    assert g[0].tolist() == [0, 0, 4, 0] and g[1].tolist() == [6, 0, 4, 0] and g[50].tolist() == [0, 6, 4, 0]
+    assert g[2500].tolist() == [0, 0, 6, 1] and g[-1].tolist() == [294, 294, 13.5, 3]
+
+
+def test_dense_bow_chain(oracle_c, tmp_path):
+    """image -> BoW vector end to end; every stage also against the oracle's stage on the same intermediate."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    K, npca = 20, 16
+    pca = {"DimPCA": npca, "EigenVectorsPCA": rng.normal(size=(61, 61)).astype(np.float32),
+           "EigenValuesPCA": rng.uniform(0.5, 4.0, (61, 1)).astype(np.float32),
+           "MeanPCA": rng.uniform(0, 255, (1, 61)).astype(np.float32)}
+    bow = {"ResizedImageSize": 300, "UseSpatialPyramid": 1, "PyramidLevel": 2, "NormBofFeatureType": "L1",
+           "Centers": rng.normal(size=(K, npca)).astype(np.float32) * 30}
+    fileio.write_cv_yaml(tmp_path / "PCAfile.yml", pca)
+    fileio.write_cv_yaml(tmp_path / "BOWfile.yml", bow)
+    db = engine.DenseBow(str(tmp_path / "BOWfile.yml"), str(tmp_path / "PCAfile.yml"))
+    img = colour_image(5, 640, 480)
+    feats, kxy, gray = db.local_features(img)
+    np.testing.assert_array_equal(gray, oracle_c.dense_gray(img, 300))
+    assert feats.shape == (10000, 61) and feats.dtype == np.float32
+    e_desc, _ = oracle_c.akaze_compute(gray, db.grid)          # CPU restatement of cv::AKAZE::compute
+    np.testing.assert_array_equal(feats, e_desc[:, :61].astype(np.float32))
+    assert len(np.unique(e_desc, axis=0)) > 1000                # the descriptors carry information
+    vec = db.compute(img)
+    exp = oracle_c.bof(feats, kxy, bow["Centers"], 300, 2, 2, pca_mean=pca["MeanPCA"], pca_eigvec=pca["EigenVectorsPCA"],
+                       pca_eigval=pca["EigenValuesPCA"], n_pca=npca)
+    np.testing.assert_array_equal(vec, exp)
+    assert vec.shape == (K * 5,) and abs(float((vec[:K] ** 2).sum()) - 1.0) < 1e-6   # L1-sqrt: each cell sums to 1
+    db.close()
