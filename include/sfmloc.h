@@ -98,6 +98,10 @@ typedef struct sfmloc_map_desc {
   double focal, ppx, ppy, k1, k2, k3;
   uint32_t bow_dim;             /* 0 = no BoW */
   const float *bow;             /* [n_views*bow_dim] .bow vectors as f32 (BoFUtils.cpp:43-45) or NULL */
+  /* 0 = pinhole: pt2D = the query keypoint (get_ud_pixel is the identity); 3 = pinhole_radial_k3: pt2D =
+   * cam2ima(remove_disto(ima2cam(p))) with (k1, k2, k3) (localization.cpp:484-487).  A radial camera with zero
+   * coefficients still goes through remove_disto's bisection, so the type is explicit. */
+  uint32_t intrinsic_type;
 } sfmloc_map_desc;
 
 typedef struct sfmloc_map sfmloc_map;

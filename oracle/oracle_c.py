@@ -325,3 +325,12 @@ def dense_gray(bgr, size=300):
     out = np.zeros((size, size), np.uint8)
     lib().orc_dense_gray(_p(bgr, C.c_uint8), C.c_int(w), C.c_int(h), C.c_int(size), _p(out, C.c_uint8))
     return out
+
+
+def ud_pixel_k3(xy, f, ppx, ppy, k1, k2, k3):
+    """orc_ud_pixel_k3: Pinhole_Intrinsic_Radial_K3::get_ud_pixel on [n, 2] pixels."""
+    xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    lib().orc_ud_pixel_k3(C.c_double(f), C.c_double(ppx), C.c_double(ppy), C.c_double(k1), C.c_double(k2), C.c_double(k3),
+                          _p(xy, C.c_double), C.c_int(xy.shape[0]), _p(out, C.c_double))
+    return out

@@ -56,6 +56,8 @@ def localize(m, q_desc, q_kpt, q_wh, view_sel=None, ratio=0.6, ransac_round=25, 
     out["ms_qfeat"] = qf
     out["ms_landmark"] = m.landmark_id[lm_slot] if len(lm_slot) else np.zeros(0, np.uint32)
     pt2d = q_kpt[qf].astype(np.float64) if len(qf) else np.zeros((0, 2))
+    if len(m.intrinsic) >= 6 and len(qf):      # pinhole_radial_k3: cam_I->get_ud_pixel (localization.cpp:484-487)
+        pt2d = oracle_c.ud_pixel_k3(pt2d, *m.intrinsic[:6])
     pt3d = m.landmark_X[lm_slot] if len(lm_slot) else np.zeros((0, 3))
     out["pt2d"], out["pt3d"] = pt2d, pt3d
     out["ok"] = False
@@ -114,6 +116,8 @@ def merge_candidates(parts, q_kpt, intrinsic, min_resection_points=8, min_inlier
     lm_id = np.array([best[int(j)]["landmark_id"] for j in qf], dtype=np.uint32)
     pt3d = np.array([best[int(j)]["X"] for j in qf], dtype=np.float64).reshape(-1, 3)
     pt2d = np.asarray(q_kpt)[qf].astype(np.float64)
+    if len(intrinsic) >= 6 and len(qf):
+        pt2d = oracle_c.ud_pixel_k3(pt2d, *intrinsic[:6])
     res.update(ms_qfeat=qf, ms_landmark=lm_id)
     if len(qf) > min_resection_points:
         f, ppx, ppy = intrinsic[:3]

@@ -1110,3 +1110,37 @@ double orc_refine_pose(const double *pt2d, const double *pt3d, const int32_t *in
   if (iters_out) *iters_out = it;
   return cost;
 }
+
+
+/* Pinhole_Intrinsic_Radial_K3::get_ud_pixel (OpenMVG 1.1, restated from its published source; parity unpinned):
+ * cam2ima(remove_disto(ima2cam(p))), remove_disto = p * sqrt(bisection_Radius_Solve(r2) / r2) with
+ * distoFunctor(r2) = r2 (1 + r2 (k1 + r2 (k2 + r2 k3)))^2 inverted by bisection to 1e-8 (A10, localization.cpp:484-487).
+ * Loop caps as on the device. */
+static double orc_disto_k3(double k1, double k2, double k3, double r2) {
+  const double t = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+  return r2 * (t * t);
+}
+
+void orc_ud_pixel_k3(double f, double ppx, double ppy, double k1, double k2, double k3, const double *xy, int n,
+                     double *out) {
+  for (int i = 0; i < n; ++i) {
+    const double px = (xy[2 * i] - ppx) / f, py = (xy[2 * i + 1] - ppy) / f;
+    const double r2 = px * px + py * py;
+    double radius = 1.0;
+    if (r2 != 0.0) {
+      double lo = r2, up = r2;
+      for (int it = 0; it < 4096 && orc_disto_k3(k1, k2, k3, lo) > r2; ++it) lo = lo / 1.05;
+      for (int it = 0; it < 4096 && orc_disto_k3(k1, k2, k3, up) < r2; ++it) up = up * 1.05;
+      for (int it = 0; it < 4096 && 1e-8 < up - lo; ++it) {
+        const double mid = 0.5 * (lo + up);
+        if (orc_disto_k3(k1, k2, k3, mid) > r2)
+          up = mid;
+        else
+          lo = mid;
+      }
+      radius = sqrt((0.5 * (lo + up)) / r2);
+    }
+    out[2 * i] = f * (radius * px) + ppx;
+    out[2 * i + 1] = f * (radius * py) + ppy;
+  }
+}

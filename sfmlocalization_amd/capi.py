@@ -54,6 +54,7 @@ class MapDesc(C.Structure):
         ("k1", C.c_double), ("k2", C.c_double), ("k3", C.c_double),
         ("bow_dim", C.c_uint32),
         ("bow", C.POINTER(C.c_float)),
+        ("intrinsic_type", C.c_uint32),
     ]
 
 
@@ -293,8 +294,9 @@ class Map:
             d.landmark_X = _ptr(landmark_X, C.c_double)
         if intrinsic is not None:
             d.focal, d.ppx, d.ppy = intrinsic[:3]
-            if len(intrinsic) >= 6:
+            if len(intrinsic) >= 6:           # (f, ppx, ppy, k1, k2, k3) = pinhole_radial_k3
                 d.k1, d.k2, d.k3 = intrinsic[3:6]
+                d.intrinsic_type = 3
         if bow is not None:
             bow = np.ascontiguousarray(bow, dtype=np.float32).reshape(self.n_views, -1)
             keep.append(bow)

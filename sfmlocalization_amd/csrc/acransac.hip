@@ -883,7 +883,8 @@ __global__ __launch_bounds__(64) void k_match_set_finish(const unsigned char *pa
                                                          uint32_t cap, const unsigned long long *best,
                                                          const uint32_t *winner, uint32_t nq, const float2 *q_kpt,
                                                          uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
-                                                         double *pt2d, double *pt3d) {
+                                                         double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
+                                                         double ppy, double k1, double k2, double k3) {
   const uint32_t lane = threadIdx.x;
   uint32_t base = 0;
   for (uint32_t j0 = 0; j0 < nq; j0 += 64) {
@@ -897,8 +898,10 @@ __global__ __launch_bounds__(64) void k_match_set_finish(const unsigned char *pa
       ms_qfeat[pos] = j;
       ms_landmark[pos] = c.landmark_id;
       const float2 kp = q_kpt[j];
-      pt2d[2 * pos] = (double)kp.x;
-      pt2d[2 * pos + 1] = (double)kp.y;
+      double ux = (double)kp.x, uy = (double)kp.y;  // cam_I->get_ud_pixel(qFeatLoc[j])   localization.cpp:484-487
+      if (radial_k3) ud_pixel_k3(f, ppx, ppy, k1, k2, k3, ux, uy, &ux, &uy);
+      pt2d[2 * pos] = ux;
+      pt2d[2 * pos + 1] = uy;
       pt3d[3 * pos] = c.X[0];
       pt3d[3 * pos + 1] = c.X[1];
       pt3d[3 * pos + 2] = c.X[2];
@@ -1572,7 +1575,9 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
                      c->d_best64, c->d_winner);
   SFM_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(64), 0, c->stream, parts, part_bytes, cap, c->d_best64,
-                     c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d);
+                     c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d,
+                     c->map->intrinsic_type == 3 ? 1 : 0, c->map->focal, c->map->ppx, c->map->ppy, c->map->k1, c->map->k2,
+                     c->map->k3);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

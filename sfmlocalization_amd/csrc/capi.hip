@@ -540,6 +540,9 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
   m->k1 = d->k1;
   m->k2 = d->k2;
   m->k3 = d->k3;
+  SFM_CHECK(d->intrinsic_type == 0 || d->intrinsic_type == 3, SFMLOC_EINVAL,
+            "sfmloc_map_create: intrinsic_type %u (0 = pinhole, 3 = pinhole_radial_k3)", d->intrinsic_type);
+  m->intrinsic_type = d->intrinsic_type;
   uint64_t *acct = &m->hbm_bytes;
 
   // bank: upload row-major chunks and re-tile on the device

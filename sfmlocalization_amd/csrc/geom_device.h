@@ -622,6 +622,36 @@ GD int p3p_kneip(const double *x2d, const double *X, double *models) {
   return 4;
 }
 
+// Pinhole_Intrinsic_Radial_K3::get_ud_pixel (OpenMVG 1.1, restated): cam2ima(remove_disto(ima2cam(p))) where
+// remove_disto scales p by sqrt(bisection_Radius_Solve(r2) / r2), the bisection inverting
+// distoFunctor(r2) = r2 * (1 + r2 (k1 + r2 (k2 + r2 k3)))^2 to 1e-8.  The bound-search loops are capped so that
+// meaningless coefficients cannot hang a kernel (the oracle carries the same cap).
+GD double disto_functor_k3(double k1, double k2, double k3, double r2) {
+  const double t = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+  return r2 * (t * t);
+}
+GD void ud_pixel_k3(double f, double ppx, double ppy, double k1, double k2, double k3, double x, double y, double *ox,
+                    double *oy) {
+  const double px = (x - ppx) / f, py = (y - ppy) / f;
+  const double r2 = px * px + py * py;
+  double radius = 1.0;
+  if (r2 != 0.0) {
+    double lo = r2, up = r2;
+    for (int it = 0; it < 4096 && disto_functor_k3(k1, k2, k3, lo) > r2; ++it) lo = lo / 1.05;
+    for (int it = 0; it < 4096 && disto_functor_k3(k1, k2, k3, up) < r2; ++it) up = up * 1.05;
+    for (int it = 0; it < 4096 && 1e-8 < up - lo; ++it) {
+      const double mid = 0.5 * (lo + up);
+      if (disto_functor_k3(k1, k2, k3, mid) > r2)
+        up = mid;
+      else
+        lo = mid;
+    }
+    radius = sqrt((0.5 * (lo + up)) / r2);
+  }
+  *ox = f * (radius * px) + ppx;
+  *oy = f * (radius * py) + ppy;
+}
+
 // EpipolarDistanceError: squared distance of x2 = (u,v) to the line F (x,y,1)
 GD double err_fmatrix(const double *M, double x, double y, double u, double v) {
   const double l0 = (M[0] * x + M[1] * y) + M[2];

@@ -207,6 +207,7 @@ struct Scene {
   std::vector<double> landmark_X;
   std::vector<double> view_center;  // [n_views*3] camera centres (getLocalViews, SfMDataUtils.cpp:210-227)
   double focal = 0, ppx = 0, ppy = 0, k1 = 0, k2 = 0, k3 = 0;
+  uint32_t intrinsic_type = 0;  // 0 pinhole, 3 pinhole_radial_k3
   uint32_t bow_dim = 0;
   std::vector<float> bow;
   uint32_t n_views_total = 0, n_landmarks_total = 0, n_obs_used = 0;
@@ -271,6 +272,7 @@ int load_scene(const char *sfm_dir, const char *match_dir, Scene &S) {
                 }
                 const JVal *dk = d->get("disto_k3");
                 if (dk && dk->arr.size() == 3) {
+                  S.intrinsic_type = 3;
                   S.k1 = dk->arr[0].num;
                   S.k2 = dk->arr[1].num;
                   S.k3 = dk->arr[2].num;
@@ -511,6 +513,7 @@ int sfmloc_open(const char *sfm_dir, const char *match_dir, const sfmloc_params 
   d.k1 = S.k1;
   d.k2 = S.k2;
   d.k3 = S.k3;
+  d.intrinsic_type = S.intrinsic_type;
   d.bow_dim = S.bow_dim;
   d.bow = S.bow.empty() ? nullptr : S.bow.data();
   rc = sfmloc_map_create(&d, params, out);

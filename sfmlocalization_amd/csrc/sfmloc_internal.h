@@ -121,6 +121,7 @@ struct Map {
   uint32_t *d_landmark_id = nullptr;
   double *d_landmark_X = nullptr;
   double focal = 0, ppx = 0, ppy = 0, k1 = 0, k2 = 0, k3 = 0;
+  uint32_t intrinsic_type = 0;  // 0 pinhole, 3 pinhole_radial_k3
   uint32_t bow_dim = 0;
   float *d_bow = nullptr;
   double *d_L10 = nullptr;          // [65538] log10(i)

@@ -181,7 +181,7 @@ class SynthQuery:
 def make_query(m: SynthMap, seed, n_feat=2000, n_copies=300, outlier_frac=0.3, query_flips=40,
                noise_px=1.0, place=None):
     rng = np.random.Generator(np.random.PCG64(seed))
-    f, ppx, ppy = m.intrinsic
+    f, ppx, ppy = m.intrinsic[:3]
     n_places = len(m.place_center)
     p = int(rng.integers(0, n_places)) if place is None else int(place)
     az, el, dist = rng.uniform(0, 2 * np.pi), rng.uniform(-0.2, 0.5), rng.uniform(12.0, 16.0)
@@ -263,7 +263,7 @@ def write_map_to_disk(m: SynthMap, sfm_dir, match_dir, unposed_views=(), with_bo
     os.makedirs(sfm_dir, exist_ok=True)
     os.makedirs(match_dir, exist_ok=True)
     names = [f"img{int(v):06d}" for v in m.view_id]
-    f, ppx, ppy = m.intrinsic
+    f, ppx, ppy = m.intrinsic[:3]
     poses = {int(v): (m.view_R[k], m.view_C[k]) for k, v in enumerate(m.view_id) if int(v) not in set(unposed_views)}
     slot_view = np.searchsorted(m.view_off, np.arange(m.n_rows), side="right") - 1
     obs_rows = np.nonzero(m.row_landmark >= 0)[0]
@@ -277,8 +277,11 @@ def write_map_to_disk(m: SynthMap, sfm_dir, match_dir, unposed_views=(), with_bo
     seen = set(per_lm)
     structure += [(int(m.landmark_id[s]), m.landmark_X[s], []) for s in range(len(m.landmark_id)) if s not in seen]
     structure.sort(key=lambda t: t[0])
+    radial = len(m.intrinsic) >= 6   # (f, ppx, ppy, k1, k2, k3) -> a pinhole_radial_k3 intrinsic
     sd = fileio.make_sfm_data([int(v) for v in m.view_id], [n + ".jpg" for n in names], m.width, m.height, f, ppx,
-                              ppy, poses=poses, structure=structure, root_path=os.path.abspath(sfm_dir))
+                              ppy, poses=poses, structure=structure, root_path=os.path.abspath(sfm_dir),
+                              intrinsic_type="pinhole_radial_k3" if radial else "pinhole",
+                              disto_k3=tuple(m.intrinsic[3:6]) if radial else None)
     fileio.write_sfm_data(os.path.join(sfm_dir, "sfm_data.json"), sd)
     fileio.write_image_describer(os.path.join(match_dir, "image_describer.txt"))
     for k, n in enumerate(names):

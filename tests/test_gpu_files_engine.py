@@ -169,3 +169,24 @@ def test_bow_shortlist_in_engine(tmp_path_factory):
     assert r_none == []
     e_all.close()
     e_bow.close()
+
+
+def test_open_radial_k3_map(tmp_path, oracle_c):
+    """sfm_data.json with a pinhole_radial_k3 intrinsic (cereal nests the pinhole base as value0): the loader picks
+    up disto_k3 and the 2D points of the resection are undistorted, exactly as the in-memory map does."""
+    m = synth.make_map(3, n_views=20, desc_per_view=300, views_per_place=10, landmarks_per_place=250, obs_per_view=120)
+    m.intrinsic = tuple(m.intrinsic[:3]) + (-0.1, 0.02, 0.0)
+    names = synth.write_map_to_disk(m, str(tmp_path / "sfm"), str(tmp_path / "matches"))
+    info = capi.scan(str(tmp_path / "sfm"), str(tmp_path / "matches"))
+    assert (info["k1"], info["k2"], info["k3"]) == (-0.1, 0.02, 0.0)
+    m.kpt_xy = np.concatenate([fileio.read_feat(tmp_path / "matches" / (n + ".feat"))[:, :2] for n in names])
+    q = synth.make_query(m, 77, n_feat=500, n_copies=200, outlier_frac=0.2)
+    p = S.default_params(ransac_round=25)
+    with capi.Map.open(str(tmp_path / "sfm"), str(tmp_path / "matches"), p) as dm:
+        dq = dm.query(q.desc, q.kpt_xy, 640, 480)
+        pose, pq, pl = dm.localize(dq)
+        dq.close()
+    exp = opipe.localize(m, q.desc, q.kpt_xy, (640, 480))
+    assert bool(pose.ok) == exp["ok"] and exp["ok"]
+    np.testing.assert_array_equal(pq, exp["pair_qfeat"])
+    np.testing.assert_array_equal(np.array(pose.P), exp["P"].ravel())

@@ -242,6 +242,39 @@ def test_fmatrix_filter_large_views(oracle_c):
         assert len(big) and big.max() <= 512
 
 
+def _distort_k3(xy, f, ppx, ppy, k1, k2, k3):
+    """forward radial model of OpenMVG's pinhole_radial_k3: p_d = p_u (1 + k1 r^2 + k2 r^4 + k3 r^6)"""
+    p = (np.asarray(xy, np.float64) - [ppx, ppy]) / f
+    r2 = (p ** 2).sum(1, keepdims=True)
+    return (p * (1 + r2 * (k1 + r2 * (k2 + r2 * k3))) * f + [ppx, ppy]).astype(np.float32)
+
+
+@pytest.mark.parametrize("disto", [(-0.12, 0.03, -0.002), (0.0, 0.0, 0.0), (0.25, -0.4, 0.1)])
+def test_radial_k3_intrinsic(oracle_c, disto):
+    """A10 with a pinhole_radial_k3 camera: pt2D = get_ud_pixel(query keypoint) (localization.cpp:484-487).  The
+    query image is distorted with the forward model, so undistortion must bring the pose back to the truth; every
+    stage is compared with the oracle bit for bit (zero coefficients still run remove_disto's bisection)."""
+    m = make_scene(27)
+    f, ppx, ppy = m.intrinsic[:3]
+    m.intrinsic = (f, ppx, ppy) + tuple(disto)
+    with dev_map(m) as dm:
+        n_ok = 0
+        for k in range(3):
+            q = synth.make_query(m, 300 + k, n_feat=600, n_copies=220, outlier_frac=0.2)
+            q.kpt_xy = _distort_k3(q.kpt_xy, f, ppx, ppy, *disto)
+            exp, pose = compare_stages(m, q, dm)
+            if exp["ok"]:
+                n_ok += 1
+                assert np.abs(np.array(pose.R).reshape(3, 3) - q.R_true).max() < 2e-2
+                assert np.abs(np.array(pose.center) - q.C_true).max() < 0.25
+            if len(exp["pt2d"]):
+                und = oracle_c.ud_pixel_k3(q.kpt_xy[exp["ms_qfeat"]].astype(np.float64), f, ppx, ppy, *disto)
+                np.testing.assert_array_equal(bits(exp["pt2d"]), bits(und))
+                if any(disto):
+                    assert np.abs(exp["pt2d"] - q.kpt_xy[exp["ms_qfeat"]]).max() > 0.05   # it really moved points
+        assert n_ok >= 2
+
+
 def test_localize_one_call(oracle_c):
     m = make_scene(24)
     with dev_map(m) as dm:

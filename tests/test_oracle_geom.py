@@ -244,3 +244,22 @@ def test_refine_pose_extension(oracle_c):
     # already optimal (noise-free): stays put
     r2 = oracle_c.refine_pose(x2, X, np.arange(150), f, ppx, ppy, R2, -R2 @ C2)
     assert np.abs(r2["R"] - R2).max() < 1e-9 and r2["cost"] <= r2["cost0"]
+
+
+def test_ud_pixel_k3_inverts_the_radial_model():
+    """Pinhole_Intrinsic_Radial_K3::get_ud_pixel restatement: undistort(distort(p)) = p to the bisection's 1e-8 (in
+    squared normalised radius), identity at the principal point, and exactly reproducible."""
+    from oracle import oracle_c
+    oracle_c.build()
+    rng = np.random.Generator(np.random.PCG64(4))
+    f, ppx, ppy = 800.0, 320.0, 240.0
+    for k1, k2, k3 in ((-0.12, 0.03, -0.002), (0.25, -0.4, 0.1), (0.0, 0.0, 0.0)):
+        pu = np.stack([rng.uniform(0, 640, 300), rng.uniform(0, 480, 300)], 1)
+        pn = (pu - [ppx, ppy]) / f
+        r2 = (pn ** 2).sum(1, keepdims=True)
+        pd = pn * (1 + r2 * (k1 + r2 * (k2 + r2 * k3))) * f + [ppx, ppy]
+        back = oracle_c.ud_pixel_k3(pd, f, ppx, ppy, k1, k2, k3)
+        assert np.abs(back - pu).max() < 5e-3      # the bisection stops at 1e-8 ABSOLUTE in r^2: coarse near the centre
+        assert np.array_equal(back, oracle_c.ud_pixel_k3(pd, f, ppx, ppy, k1, k2, k3))
+    c = oracle_c.ud_pixel_k3(np.array([[ppx, ppy]]), f, ppx, ppy, -0.1, 0.01, 0.0)
+    assert c.tolist() == [[ppx, ppy]]
