@@ -97,6 +97,28 @@ def test_large_bank_geometry_paths(oracle_c):
     check_against_oracle(oracle_c, q, bank, view_off, None)
 
 
+@pytest.mark.parametrize("ratio", [0.3, 0.6, 0.95, 1.5])
+def test_screening_on_structured_descriptors(oracle_c, ratio):
+    """The screening kernel's threshold logic away from uniform random bits: sparse descriptors (small distances,
+    large thresholds, the wave vote fires all the time), clusters of near-duplicates in the query (d1 = 0 and tiny
+    second distances), ratios from strict to > 1 (everything with a finite ratio is accepted)."""
+    rng = np.random.Generator(np.random.PCG64(int(ratio * 100)))
+    nq, n_rows = 1500, 6000
+    dense = synth.random_descriptors(rng, nq + n_rows)
+    sparse = dense & synth.random_descriptors(rng, nq + n_rows) & synth.random_descriptors(rng, nq + n_rows)  # ~1/8 ones
+    for src in (dense, sparse):
+        q, bank = src[:nq].copy(), src[nq:].copy()
+        q[100:140] = q[100]                                   # 40 identical query rows
+        q[200:260] = synth.flip_bits(rng, np.repeat(q[200:201], 60, 0), 3)
+        pick = rng.integers(0, nq, 1500)
+        bank[:1500] = synth.flip_bits(rng, q[pick], 30)
+        bank[1500:1600] = q[rng.integers(0, nq, 100)]        # exact copies: d0 = 0
+        view_off = np.array([0, 1000, 1000, 2500, 6000], np.uint32)
+        got = check_against_oracle(oracle_c, q, bank, view_off, None, ratio=ratio)
+        if ratio >= 0.6 and src is dense:
+            assert got[0].sum() > 500
+
+
 def test_argument_errors():
     bank = np.zeros((10, 64), np.uint8)
     with pytest.raises(S.SfmlocError):
