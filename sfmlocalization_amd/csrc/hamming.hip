@@ -412,7 +412,9 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
 int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split) {
   Map *m = c->map;
   if (n_work_blocks == 0 || q->n == 0) return SFMLOC_OK;
-  if (split == 1 && m->params.exact_rows == 0 && q->n >= 4 * kScreenHead && !k1_override().r)
+  // (below ~12 heads' worth of query rows the exact head and the second launch eat the saving:
+  // profiles/r01_k1_screen_on_akaze_descriptors.json)
+  if (split == 1 && m->params.exact_rows == 0 && q->n >= 12 * kScreenHead && !k1_override().r)
     return launch_hamming_screened(c, q, n_work_blocks, use_list);
   int R, W, L;
   c->stats.hamming_lane_ops += (uint64_t)n_work_blocks * kBlockRows * q->n * 35;

@@ -61,7 +61,7 @@ def test_golden_planted(oracle_c):
     np.testing.assert_array_equal(got[3], g["match_d"])
 
 
-@pytest.mark.parametrize("nq", [0, 1, 2, 63, 64, 65, 257, 2000, 2049, 2400])
+@pytest.mark.parametrize("nq", [0, 1, 2, 63, 64, 65, 257, 767, 768, 769, 2000, 2049, 2400])
 def test_query_sizes(oracle_c, nq):
     rng = np.random.Generator(np.random.PCG64(nq + 5))
     bank = synth.random_descriptors(rng, 700)
