@@ -15,7 +15,9 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one HW queue per in-flight context (sfmlocalization_amd/_lib.py)
+# one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or
+                                                    os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1") else "8")
 
 import numpy as np  # noqa: E402
 
