@@ -364,6 +364,14 @@ int sfmloc_match_pairs(sfmloc_map *map, const uint32_t *pairs, uint32_t n_pairs,
  * empty), longer-range pairs only when non-empty, as the reference's std::map ends up. */
 int sfmloc_track(sfmloc_map *map, uint32_t max_frame_dist, sfmloc_matches **out);
 
+/* hulo::geometricMatch (MatchUtils.cpp:372-420) for map image pairs: F-matrix AC-RANSAC (params.ransac_round,
+ * params.geom_precision) on the given putative lists -- pair k = (pairs[2k], pairs[2k+1]) owns
+ * match_i/j[offsets[k] .. offsets[k+1]) -- keeping a pair iff it has more than 2.5*7 inliers; the surviving matches
+ * come in AC-RANSAC's inlier order.  No minimum list length is applied here (the caller applies ExtFeatAndMatch's
+ * minMatch, computeFeaturesAndMatches.cpp:211-221). */
+int sfmloc_geometric_pairs(sfmloc_map *map, const uint32_t *pairs, uint32_t n_pairs, const uint64_t *offsets,
+                           const uint32_t *match_i, const uint32_t *match_j, sfmloc_matches **out);
+
 uint32_t sfmloc_matches_pairs(const sfmloc_matches *m); /* number of (I, J) entries, ascending (I, J) */
 int sfmloc_matches_pair(const sfmloc_matches *m, uint32_t k, uint32_t *view_i, uint32_t *view_j, uint32_t *n);
 int sfmloc_matches_read(const sfmloc_matches *m, uint32_t k, uint32_t *i, uint32_t *j, uint32_t cap);

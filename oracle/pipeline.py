@@ -193,3 +193,20 @@ def track_akaze(descs, max_frame_dist, ratio=0.6):
                         e[0].append(i)
                         e[1].append(int(nxt))
     return {k: (np.array(v[0], np.uint32), np.array(v[1], np.uint32)) for k, v in sorted(matches.items())}
+
+
+def geometric_match(kpts, whs, view_ids, matches, ransac_round=4096, geom_precision=4.0, seed=0x5f3759df12345678):
+    """hulo::geometricMatch (MatchUtils.cpp:372-420) for map image pairs: F-matrix AC-RANSAC on every putative list,
+    pairs with more than 2.5*7 inliers kept, matches in AC-RANSAC's inlier order.  kpts[v]: [n_v, 2] .feat x, y;
+    whs[v]: (w, h); matches: {(I, J): (i[], j[])} over view indices."""
+    out = {}
+    for (a, b), (mi, mj) in sorted(matches.items()):
+        if len(mi) == 0:
+            continue
+        x1 = np.asarray(kpts[a], np.float64)[np.asarray(mi, np.int64)]
+        x2 = np.asarray(kpts[b], np.float64)[np.asarray(mj, np.int64)]
+        r = oracle_c.fmatrix_filter(x1, tuple(int(t) for t in whs[a]), x2, tuple(int(t) for t in whs[b]), geom_precision,
+                                    ransac_round, seed, stream=int(view_ids[a]))
+        if r["n"] > 0:
+            out[(a, b)] = (np.asarray(mi, np.uint32)[r["inliers"]], np.asarray(mj, np.uint32)[r["inliers"]])
+    return out

@@ -104,7 +104,7 @@ SYMBOLS = [
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
     "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
     "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
-    "sfmloc_dense_gray", "sfmloc_query_from_view", "sfmloc_match_one_to_one", "sfmloc_match_pairs", "sfmloc_track",
+    "sfmloc_dense_gray", "sfmloc_query_from_view", "sfmloc_match_one_to_one", "sfmloc_match_pairs", "sfmloc_track", "sfmloc_geometric_pairs",
     "sfmloc_matches_pairs", "sfmloc_matches_pair", "sfmloc_matches_read", "sfmloc_matches_destroy",
     "sfmloc_localize_batch", "sfmloc_part_bytes", "sfmloc_shard_begin", "sfmloc_shard_export",
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
@@ -146,6 +146,8 @@ def _L():
         L.sfmloc_match_one_to_one.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
         L.sfmloc_match_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_void_p)]
         L.sfmloc_track.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sfmloc_geometric_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]
         L.sfmloc_matches_pairs.argtypes = [C.c_void_p]
         L.sfmloc_matches_pairs.restype = C.c_uint32
         L.sfmloc_matches_pair.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
@@ -427,6 +429,21 @@ class Map:
         """sfmloc_track (hulo::trackAKAZE) over the views in table order."""
         h = C.c_void_p()
         _check(_L().sfmloc_track(self._h, int(max_frame_dist), C.byref(h)))
+        return self._take_matches(h)
+
+    def geometric_pairs(self, matches):
+        """sfmloc_geometric_pairs (hulo::geometricMatch): {(I, J): (i[], j[])} -> the same for the pairs that pass the
+        F-matrix AC-RANSAC, matches in its inlier order."""
+        keys = sorted(matches)
+        pairs = np.array(keys, np.uint32).reshape(-1, 2)
+        off = np.zeros(len(keys) + 1, np.uint64)
+        off[1:] = np.cumsum([len(matches[k][0]) for k in keys])
+        mi = np.concatenate([np.asarray(matches[k][0], np.uint32) for k in keys]) if keys else np.zeros(0, np.uint32)
+        mj = np.concatenate([np.asarray(matches[k][1], np.uint32) for k in keys]) if keys else np.zeros(0, np.uint32)
+        mi, mj = np.ascontiguousarray(mi, np.uint32), np.ascontiguousarray(mj, np.uint32)
+        h = C.c_void_p()
+        _check(_L().sfmloc_geometric_pairs(self._h, _ptr(pairs, C.c_uint32), len(keys), _ptr(off, C.c_uint64),
+                                           _ptr(mi, C.c_uint32), _ptr(mj, C.c_uint32), C.byref(h)))
         return self._take_matches(h)
 
     def geometric_filter(self, q):

@@ -1496,7 +1496,7 @@ int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *
   return SFMLOC_OK;
 }
 
-int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views) {
+int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, int min_putative) {
   Map *m = c->map;
   if (n_sel == 0) return SFMLOC_OK;
   FFilterArgs A;
@@ -1515,7 +1515,7 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
   A.precision = m->params.geom_precision;
   A.n_iter = m->params.ransac_round;
   A.seed = m->params.seed;
-  A.min_putative = m->params.min_putative;
+  A.min_putative = min_putative >= 0 ? min_putative : m->params.min_putative;
   A.L10 = m->d_L10;
   A.geo_count = c->d_geo_count;
   A.geo_idx = c->d_geo_idx;

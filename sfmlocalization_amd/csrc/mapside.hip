@@ -326,6 +326,94 @@ int sfmloc_track(sfmloc_map *map, uint32_t max_frame_dist, sfmloc_matches **out)
   return SFMLOC_OK;
 }
 
+int sfmloc_geometric_pairs(sfmloc_map *map, const uint32_t *pairs, uint32_t n_pairs, const uint64_t *offsets,
+                           const uint32_t *match_i, const uint32_t *match_j, sfmloc_matches **out) {
+  SFM_CHECK(map && out && (n_pairs == 0 || (pairs && offsets)), SFMLOC_EINVAL, "sfmloc_geometric_pairs: null argument");
+  *out = nullptr;
+  Map *m = reinterpret_cast<Map *>(map);
+  SFM_CHECK(m->d_kpt && !m->h_view_wh.empty(), SFMLOC_EINVAL,
+            "sfmloc_geometric_pairs: the map was created without keypoints / view sizes");
+  SFM_HIP(hipSetDevice(m->device));
+  Ctx *c = m->ctx0;
+  // group by the second image (the query side of K3); within a group the firsts are distinct views
+  std::map<uint32_t, std::vector<uint32_t>> by_second;  // second -> pair indices
+  for (uint32_t k = 0; k < n_pairs; ++k) {
+    const uint32_t a = pairs[2 * k], b = pairs[2 * k + 1];
+    SFM_CHECK(a < m->n_views && b < m->n_views, SFMLOC_EINVAL, "sfmloc_geometric_pairs: pair %u = (%u, %u) out of range",
+              k, a, b);
+    const uint64_t n = offsets[k + 1] - offsets[k];
+    SFM_CHECK(offsets[k + 1] >= offsets[k] && n <= m->h_view_off[a + 1] - m->h_view_off[a], SFMLOC_EINVAL,
+              "sfmloc_geometric_pairs: pair %u has %llu matches for a %u-row image", k, (unsigned long long)n,
+              m->h_view_off[a + 1] - m->h_view_off[a]);
+    SFM_CHECK(n == 0 || (match_i && match_j), SFMLOC_EINVAL, "sfmloc_geometric_pairs: match arrays missing");
+    by_second[b].push_back(k);
+  }
+  PairMap pm;
+  for (auto &kv : by_second) {
+    const uint32_t b = kv.first;
+    std::map<uint32_t, uint32_t> first_to_pair;  // ascending firsts; a repeated (a, b) keeps its last list
+    for (uint32_t k : kv.second) first_to_pair[pairs[2 * k]] = k;
+    Query *q = nullptr;
+    int rc = query_from_view(m, b, &q);
+    if (rc) return rc;
+    std::vector<uint32_t> sel;
+    std::vector<uint32_t> zero(1, 0);
+    rc = SFMLOC_OK;
+    for (auto &fp : first_to_pair) {
+      const uint32_t a = fp.first, k = fp.second;
+      const uint32_t n = (uint32_t)(offsets[k + 1] - offsets[k]);
+      const uint32_t off = m->h_view_off[a];
+      for (uint32_t t = 0; t < n && rc == SFMLOC_OK; ++t)
+        if (match_i[offsets[k] + t] >= m->h_view_off[a + 1] - off || match_j[offsets[k] + t] >= q->n) {
+          set_error("sfmloc_geometric_pairs: pair (%u, %u) match %u out of range", a, b, t);
+          rc = SFMLOC_EINVAL;
+        }
+      if (rc) break;
+      sel.push_back(a);
+      if (n) {
+        hipMemcpyAsync(c->d_match_i + off, match_i + offsets[k], n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+        hipMemcpyAsync(c->d_match_key + off, match_j + offsets[k], n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+      }
+      hipMemcpyAsync(c->d_view_count + a, &n, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+      hipStreamSynchronize(c->stream);  // `n` and the caller's arrays are pageable host memory
+    }
+    if (rc == SFMLOC_OK) {
+      hipMemcpyAsync(c->d_view_sel, sel.data(), sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+      hipStreamSynchronize(c->stream);
+      for (uint32_t a : sel) hipMemsetAsync(c->d_geo_count + a, 0, sizeof(uint32_t), c->stream);
+      hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream);
+      // no >=16 rule here: OpenMVG's Robust_model_estimation takes every pair it is given (the caller has applied
+      // ExtFeatAndMatch's minMatch, computeFeaturesAndMatches.cpp:211-221)
+      rc = launch_fmatrix_filter(c, q, (uint32_t)sel.size(), false, 0);
+    }
+    for (size_t t = 0; rc == SFMLOC_OK && t < sel.size(); ++t) {
+      const uint32_t a = sel[t], k = first_to_pair[a];
+      uint32_t ng = 0;
+      hipMemcpyAsync(&ng, c->d_geo_count + a, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+      hipStreamSynchronize(c->stream);
+      if (ng == 0) continue;  // pairs that fail the filter get no entry
+      std::vector<uint32_t> gi(ng);
+      hipMemcpyAsync(gi.data(), c->d_geo_idx + m->h_view_off[a], ng * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+      hipStreamSynchronize(c->stream);
+      auto &pr = pm[{a, b}];
+      for (uint32_t g : gi) {  // AC-RANSAC's inlier order, indices into the putative list
+        pr.first.push_back(match_i[offsets[k] + g]);
+        pr.second.push_back(match_j[offsets[k] + g]);
+      }
+    }
+    int status = 0;
+    hipMemcpy(&status, c->d_status, sizeof(int), hipMemcpyDeviceToHost);
+    if (c->last_query == q) c->last_query = nullptr;
+    free_query(q);
+    if (rc) return rc;
+    SFM_CHECK((status & 1) == 0, SFMLOC_ECAP, "a pair has more than 2048 putative matches (F-matrix workspace)");
+  }
+  Matches *M = flatten(pm);
+  SFM_CHECK(M, SFMLOC_ENOMEM, "out of host memory");
+  *out = reinterpret_cast<sfmloc_matches *>(M);
+  return SFMLOC_OK;
+}
+
 uint32_t sfmloc_matches_pairs(const sfmloc_matches *mm) {
   const Matches *M = reinterpret_cast<const Matches *>(mm);
   return M ? (uint32_t)M->I.size() : 0;

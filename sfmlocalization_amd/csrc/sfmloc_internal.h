@@ -242,7 +242,8 @@ int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const floa
 // acransac.hip
 int launch_fill_log10(double *d_L10, int n, hipStream_t s);
 int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *d_out, int out_stride, hipStream_t s);
-int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
+// min_putative < 0: the map's params.min_putative (the query path's >=16 rule, localization.cpp:408-415)
+int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, int min_putative = -1);
 int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
 int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,

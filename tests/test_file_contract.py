@@ -141,3 +141,13 @@ def test_matches_txt_roundtrip(tmp_path):
     assert list(back) == sorted(m)
     for k in m:
         assert back[k][0].tolist() == m[k][0].tolist() and back[k][1].tolist() == m[k][1].tolist()
+
+
+def test_pair_generators_literal():
+    from sfmlocalization_amd import extfeat
+    ids = [0, 2, 4, 6]
+    assert extfeat.generate_all_pairs(ids) == [(0, 2), (0, 4), (0, 6), (2, 4), (2, 6), (4, 6)]
+    assert extfeat.generate_video_match_pairs(ids, 2) == [(0, 2), (0, 4), (2, 4), (2, 6), (4, 6)]
+    # removeDupPairs (SfMDataUtils.cpp:168-187): a later duplicate (either orientation) goes, earlier entries end up ordered
+    assert extfeat.remove_dup_pairs([(3, 1), (1, 3), (2, 5), (5, 2), (1, 3)]) == [(1, 3), (2, 5)]
+    assert extfeat.remove_dup_pairs([(0, 1)]) == [(0, 1)]

@@ -70,3 +70,22 @@ def test_pair_list_equals_reference_restatement(oracle_c):
         exp = opipe.match_akaze(descs, sorted(set(pairs)), 0.6)
         assert_same(got, exp)
         assert (2, 2) in got and len(got[(2, 2)][0]) > 0
+
+
+def test_geometric_match_of_map_pairs(oracle_c):
+    """sfmloc_geometric_pairs = hulo::geometricMatch on tracked pairs (incl. chained ones and the minMatch filter
+    applied by the caller), against the oracle's F-matrix AC-RANSAC on the same lists."""
+    m, desc, descs = video(43, n_views=8)
+    off = m.view_off.astype(np.int64)
+    kp = synth.round6(m.kpt_xy)
+    for rounds in (25, 300):
+        p = S.default_params(ransac_round=rounds, geom_precision=4.0)
+        with S.Map(m.view_id, m.view_off, desc, params=p, view_wh=m.view_wh, kpt_xy=kp) as dm:
+            put = dm.track(3)
+            put = {k: v for k, v in put.items() if len(v[0]) >= 20}         # minMatch
+            assert len(put) >= 8 and any(b - a == 2 for a, b in put)
+            got = dm.geometric_pairs(put)
+        exp = opipe.geometric_match([kp[off[v]:off[v + 1]] for v in range(8)], m.view_wh, m.view_id, put,
+                                    ransac_round=rounds)
+        assert_same(got, exp)
+        assert len(exp) >= 6 and all(len(v[0]) > 17 for v in exp.values())
