@@ -879,20 +879,28 @@ __global__ __launch_bounds__(256) void k_candidates_win(const unsigned char *par
 
 // single wave: compact the winners in ascending query-feature order (SfMDataUtils.cpp:121-124) and assemble
 // pt2D / pt3D (localization.cpp:479-501; pinhole get_ud_pixel is the identity)
-__global__ __launch_bounds__(64) void k_match_set_finish(const unsigned char *parts, uint64_t part_bytes,
-                                                         uint32_t cap, const unsigned long long *best,
-                                                         const uint32_t *winner, uint32_t nq, const float2 *q_kpt,
-                                                         uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
-                                                         double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
-                                                         double ppy, double k1, double k2, double k3) {
-  const uint32_t lane = threadIdx.x;
-  uint32_t base = 0;
-  for (uint32_t j0 = 0; j0 < nq; j0 += 64) {
-    const uint32_t j = j0 + lane;
+__global__ __launch_bounds__(256) void k_match_set_finish(const unsigned char *parts, uint64_t part_bytes,
+                                                          uint32_t cap, const unsigned long long *best,
+                                                          const uint32_t *winner, uint32_t nq, const float2 *q_kpt,
+                                                          uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
+                                                          double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
+                                                          double ppy, double k1, double k2, double k3) {
+  // one workgroup; winners are compacted in query-feature order, 256 features per pass
+  __shared__ uint32_t wave_cnt[4];
+  __shared__ uint32_t base_s;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (uint32_t j0 = 0; j0 < nq; j0 += 256) {
+    const uint32_t j = j0 + threadIdx.x;
     const bool has = j < nq && best[j] != ~0ull;
     const unsigned long long mask = __ballot(has);
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t pre = base_s;
+    for (uint32_t w = 0; w < wave; ++w) pre += wave_cnt[w];
     if (has) {
-      const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      const uint32_t pos = pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       const uint32_t w = winner[j];
       const Candidate c = part_cands(parts, part_bytes, w / cap)[w % cap];
       ms_qfeat[pos] = j;
@@ -906,9 +914,11 @@ __global__ __launch_bounds__(64) void k_match_set_finish(const unsigned char *pa
       pt3d[3 * pos + 1] = c.X[1];
       pt3d[3 * pos + 2] = c.X[2];
     }
-    base += (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
   }
-  if (lane == 0) *ms_n = base;
+  if (threadIdx.x == 0) *ms_n = base_s;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1283,16 +1293,27 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
   int best_b = -1;  // hypothesis of this batch that currently holds the best model
   long processed = 0;
   bool index_changed = false;
+  // the replay is a dependent chain over up to 512 hypotheses: read their results from LDS, not from L2
+  __shared__ double s_nfa[kP3pBatchMax];
+  __shared__ double s_err[kP3pBatchMax];
+  __shared__ int s_k[kP3pBatchMax];
+  for (int b = tid; b < batch && b < kP3pBatchMax; b += kThreads) {
+    const bool live = iter0 + b < n_iter;
+    s_nfa[b] = live ? A.hyp_nfa[b] : pos_inf();
+    s_err[b] = live ? A.hyp_err[b] : 0.0;
+    s_k[b] = live ? A.hyp_k[b] : 0;
+  }
+  __syncthreads();
   for (int b = 0; b < batch; ++b) {
     const long it = iter0 + b;
     if (it >= n_iter || it >= n_iter_evaluated) break;
-    const double nfa = A.hyp_nfa[b];
+    const double nfa = s_nfa[b];
     bool better = false;
     if (nfa < min_nfa) {
       better = true;
       min_nfa = nfa;
-      n_in = A.hyp_k[b];
-      errmax = A.hyp_err[b];
+      n_in = s_k[b];
+      errmax = s_err[b];
       best_b = b;
     }
     processed = b + 1;
@@ -1548,8 +1569,10 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
 
 int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_views) {
   Map *m = c->map;
-  SFM_HIP(hipMemsetAsync(c->d_cand_part, 0, kPartHeaderBytes, c->stream));
-  SFM_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
+  if (!c->cleared) {
+    SFM_HIP(hipMemsetAsync(c->d_cand_part, 0, kPartHeaderBytes, c->stream));
+    SFM_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
+  }
   if (n_sel == 0 || q->n == 0) return SFMLOC_OK;
   hipLaunchKernelGGL(k_emit_candidates, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream,
                      all_views ? nullptr : c->d_view_sel, n_sel, m->d_view_off, m->d_view_id, c->d_view_count,
@@ -1564,8 +1587,10 @@ int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_view
 
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
                              uint64_t part_bytes, uint32_t cap) {
-  SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
-  SFM_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
+  if (!c->cleared) {
+    SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
+    SFM_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
+  }
   if (q->n == 0 || n_parts == 0) return SFMLOC_OK;
   const dim3 grid(16, n_parts < 64 ? n_parts : 64);
   hipLaunchKernelGGL(k_candidates_min, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
@@ -1574,7 +1599,7 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
   hipLaunchKernelGGL(k_candidates_win, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
                      c->d_best64, c->d_winner);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(64), 0, c->stream, parts, part_bytes, cap, c->d_best64,
+  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(256), 0, c->stream, parts, part_bytes, cap, c->d_best64,
                      c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d,
                      c->map->intrinsic_type == 3 ? 1 : 0, c->map->focal, c->map->ppx, c->map->ppy, c->map->k1, c->map->k2,
                      c->map->k3);

@@ -385,7 +385,7 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   }();
   const uint32_t lds_rows = 512;
   const size_t lds_bytes = (size_t)lds_rows * 64;
-  SFM_HIP(hipMemsetAsync(c->d_n_flagged, 0, sizeof(uint32_t), c->stream));
+  if (!c->cleared) SFM_HIP(hipMemsetAsync(c->d_n_flagged, 0, sizeof(uint32_t), c->stream));
 #define K1_SCREEN(NW)                                                                                              \
   case NW:                                                                                                        \
     hipLaunchKernelGGL((k_hamming_screen<WAVES, NW>), dim3((n_work_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64), \

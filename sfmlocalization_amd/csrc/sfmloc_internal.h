@@ -193,6 +193,7 @@ struct Ctx {
   bool last_all_views = false;
   uint32_t last_n_work_blocks = 0;
   std::vector<uint32_t> last_blocks;  // host copy of the block list (empty = all)
+  bool cleared = false;  // k_query_reset already cleared this query's counters: the stages skip their own memsets
   struct Query *last_query = nullptr;  // query of the last putative call
   struct Query *in_flight = nullptr;   // query of a begun, not yet ended, localisation
   double t_begin = 0.0;
