@@ -1550,12 +1550,9 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
   A.skip_le = fast ? kF2MaxM : -1;
   if (fast) {
     const size_t lds2 = sizeof(F2Shared);
-    static bool attr2 = false;
-    if (!attr2) {
-      SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      attr2 = true;
-    }
+    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(F2Shared));
+    SFM_HIP(attr2);
     hipLaunchKernelGGL(k_fmatrix_fast, dim3(n_sel), dim3(kF2Threads), lds2, c->stream, A);
     SFM_HIP(hipGetLastError());
   }

@@ -345,11 +345,6 @@ __global__ void k_nld_step(const float *__restrict__ Ld, const float *__restrict
   Ld_out[p] = v + stp;
 }
 
-__global__ void k_add(float *__restrict__ a, const float *__restrict__ b, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] = a[i] + b[i];
-}
-
 __global__ void k_scale_det(float *lx, float *ly, float *lxx, float *lxy, float *lyy, float *ldet, size_t n, float sf,
                             float sf2) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

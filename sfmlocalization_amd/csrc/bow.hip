@@ -40,7 +40,7 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
                                                    uint32_t *__restrict__ out_sel) {
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t scan[1024];
-  __shared__ uint32_t sh_prefix, sh_rank, sh_less;
+  __shared__ uint32_t sh_prefix, sh_rank;
   const uint32_t tid = threadIdx.x;
   if (k > n) k = n;
   if (k == 0) return;
@@ -112,7 +112,6 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
       scan[t] = acc;
       acc += v;
     }
-    sh_less = acc;
   }
   __syncthreads();
   uint32_t pos = scan[tid];

@@ -121,7 +121,7 @@ void free_ctx(Ctx *c) {
                   c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
                   c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,
                   c->d_inlier_idx,
-                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters};
+                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters, c->d_flagmask};
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -166,6 +166,7 @@ int make_ctx(Map *m, Ctx **out) {
   CTX_TRY(dev_alloc(acct, &c->d_match_key, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_flagged, (size_t)n_pad));
   CTX_TRY(dev_alloc(acct, &c->d_n_flagged, (size_t)1));
+  CTX_TRY(dev_alloc(acct, &c->d_flagmask, (size_t)m->n_blocks + 1));
   CTX_TRY(dev_alloc(acct, &c->d_k1_counters, (size_t)2));
   CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
   CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views));
@@ -816,6 +817,11 @@ int sfmloc_putative_read_rows(sfmloc_map *map, uint32_t *best0, uint32_t *best1)
   const uint64_t nwb = c->last_n_work_blocks;
   std::vector<uint2> part((size_t)c->last_split * nwb * 64);
   SFM_HIP(hipMemcpy(part.data(), c->d_part, part.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> mask;
+  if (c->last_screened) {  // only the rows the screening scan could not reject have a pair; the others stay NOMATCH
+    mask.resize(nwb);
+    SFM_HIP(hipMemcpy(mask.data(), c->d_flagmask, nwb * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
   auto push = [](uint32_t &b0, uint32_t &b1, uint32_t k) {
     if (k < b0) {
       b1 = b0;
@@ -829,6 +835,7 @@ int sfmloc_putative_read_rows(sfmloc_map *map, uint32_t *best0, uint32_t *best1)
     for (uint32_t l = 0; l < kBlockRows; ++l) {
       const uint64_t r = (uint64_t)blk * kBlockRows + l;
       if (r >= m->n_rows) break;
+      if (c->last_screened && !((mask[w] >> l) & 1ull)) continue;
       uint32_t b0 = SFMLOC_NOMATCH, b1 = SFMLOC_NOMATCH;
       for (uint32_t s = 0; s < c->last_split; ++s) {
         const uint2 p = part[((size_t)s * nwb + w) * 64 + l];

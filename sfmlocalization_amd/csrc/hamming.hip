@@ -131,7 +131,8 @@ template <int WAVES, int NW>
 __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
     const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
     const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t lds_rows, const uint16_t *__restrict__ ratio_cnt,
-    uint2 *__restrict__ part, uint2 *__restrict__ flagged /*{part index, bank row}*/, uint32_t *__restrict__ n_flagged,
+    unsigned long long *__restrict__ flagmask /*[work block]: rows handed to k_hamming_rows*/,
+    uint2 *__restrict__ flagged /*{part index, bank row}*/, uint32_t *__restrict__ n_flagged,
     unsigned long long *__restrict__ counters /*[0] finished wave-pairs, [1] flagged rows*/, uint32_t head) {
   extern __shared__ uint4 qs[];
   const uint32_t lane = threadIdx.x & 63u;
@@ -206,8 +207,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
   }
   if (!valid) return;
   const uint32_t pidx = w0 * 64 + lane;
-  part[pidx] = make_uint2(SFMLOC_NOMATCH, SFMLOC_NOMATCH);  // "rejected" unless k_hamming_rows overwrites it
+  // unflagged rows are rejected: K2 reads the mask and never touches their (stale) partial-result slots, so the
+  // only per-row bytes this kernel writes are 8 per 64 rows
   const unsigned long long mask = __ballot(flag);
+  if (lane == 0) flagmask[w0] = mask;
   if (lane == 0) {
     atomicAdd(&counters[0], (unsigned long long)n_finished);
     if (mask) atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
@@ -282,7 +285,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__rest
 // (0.0f + d0) / d1 < ratio holds; the accepted d0 are exactly 0..cnt-1 because IEEE division is
 // monotone), and compacts accepted rows in ascending row order.
 __global__ __launch_bounds__(256) void k_merge_ratio_compact(
-    const uint2 *__restrict__ part, uint32_t n_work_blocks, uint32_t split, const uint32_t *__restrict__ view_sel,
+    const uint2 *__restrict__ part, const unsigned long long *__restrict__ flagmask /*or null: every slot is valid*/,
+    uint32_t n_work_blocks, uint32_t split, const uint32_t *__restrict__ view_sel,
     const uint32_t *__restrict__ view_widx0, uint32_t n_sel, const uint32_t *__restrict__ view_off,
     const uint16_t *__restrict__ ratio_cnt, uint32_t *__restrict__ view_count, uint32_t *__restrict__ match_i,
     uint32_t *__restrict__ match_key) {
@@ -300,9 +304,10 @@ __global__ __launch_bounds__(256) void k_merge_ratio_compact(
     const uint32_t r = r0 + lane;
     const bool valid = r < end;
     uint32_t b0 = SFMLOC_NOMATCH, b1 = SFMLOC_NOMATCH;
-    if (valid) {
+    const uint32_t widx = widx0 + ((r >> 6) - blk0);
+    if (valid && (!flagmask || ((flagmask[widx] >> (r & 63u)) & 1ull))) {
       for (uint32_t s = 0; s < split; ++s) {
-        const uint2 p = part[((uint64_t)s * n_work_blocks + (widx0 + ((r >> 6) - blk0))) * 64 + (r & 63u)];
+        const uint2 p = part[((uint64_t)s * n_work_blocks + widx) * 64 + (r & 63u)];
         top2_push(b0, b1, p.x);
         top2_push(b0, b1, p.y);
       }
@@ -390,7 +395,7 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   case NW:                                                                                                        \
     hipLaunchKernelGGL((k_hamming_screen<WAVES, NW>), dim3((n_work_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64), \
                        lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks,       \
-                       q->d_desc, q->n, lds_rows, m->d_ratio_cnt, c->d_part, c->d_flagged, c->d_n_flagged,        \
+                       q->d_desc, q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged,    \
                        c->d_k1_counters, head);                                                                   \
     break;
   switch (nw) {
@@ -414,8 +419,11 @@ int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use
   if (n_work_blocks == 0 || q->n == 0) return SFMLOC_OK;
   // (below ~12 heads' worth of query rows the exact head and the second launch eat the saving:
   // profiles/r01_k1_screen_on_akaze_descriptors.json)
-  if (split == 1 && m->params.exact_rows == 0 && q->n >= 12 * kScreenHead && !k1_override().r)
+  c->last_screened = false;
+  if (split == 1 && m->params.exact_rows == 0 && q->n >= 12 * kScreenHead && !k1_override().r) {
+    c->last_screened = true;
     return launch_hamming_screened(c, q, n_work_blocks, use_list);
+  }
   int R, W, L;
   c->stats.hamming_lane_ops += (uint64_t)n_work_blocks * kBlockRows * q->n * 35;
   const K1Geom &o = k1_override();
@@ -458,7 +466,7 @@ int launch_merge_ratio_compact(Ctx *c, const Query *q, uint32_t n_sel, bool all_
   Map *m = c->map;
   if (n_sel == 0) return SFMLOC_OK;
   hipLaunchKernelGGL(k_merge_ratio_compact, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream, c->d_part,
-                     n_work_blocks, split, all_views ? nullptr : c->d_view_sel,
+                     c->last_screened ? c->d_flagmask : nullptr, n_work_blocks, split, all_views ? nullptr : c->d_view_sel,
                      all_views ? nullptr : c->d_view_widx0, n_sel, m->d_view_off, m->d_ratio_cnt, c->d_view_count,
                      c->d_match_i, c->d_match_key);
   SFM_HIP(hipGetLastError());

@@ -155,6 +155,8 @@ struct Ctx {
   uint32_t *d_match_key = nullptr;  // [n_rows]  (d0<<16)|j0
   uint2 *d_flagged = nullptr;       // [n_blocks*64] rows the screening kernel could not reject {part index, bank row}
   uint32_t *d_n_flagged = nullptr;
+  unsigned long long *d_flagmask = nullptr;  // [n_blocks] per work block: rows whose d_part slot is valid (screened scan)
+  bool last_screened = false;
   unsigned long long *d_k1_counters = nullptr;  // [2] finished wave-pairs, flagged rows (since stats reset)
   int k1_finish_ops = 0;
 

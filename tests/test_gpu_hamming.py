@@ -26,6 +26,19 @@ def check_against_oracle(oracle_c, q, bank, view_off, view_sel, ratio=0.6):
         qq = m.query(q)
         m.match_putative(qq, view_sel)
         got_screened = m.putative_read()
+        s0, s1 = m.putative_read_rows()      # pairs exist only for the rows the screening scan could not reject
+        # run a second, different query on the same map first: stale partial-result slots must not leak through
+        if len(q) > 1:
+            q2 = m.query(q[::-1].copy())
+            m.match_putative(q2, view_sel)
+            m.match_putative(qq, view_sel)
+            again = m.putative_read()
+            for a, b in zip(got_screened, again):
+                np.testing.assert_array_equal(a, b, err_msg="same query after another one on the same context")
+            s0b, s1b = m.putative_read_rows()
+            np.testing.assert_array_equal(s0, s0b)
+            np.testing.assert_array_equal(s1, s1b)
+            q2.close()
         qq.close()
     # ... and the exact-rows path, whose per-row (nearest, second) keys are compared too
     params = S.default_params(dist_ratio=ratio, exact_rows=1)
@@ -49,6 +62,15 @@ def check_against_oracle(oracle_c, q, bank, view_off, view_sel, ratio=0.6):
     if len(q) > 0:
         np.testing.assert_array_equal(b0[searched], keys_from_oracle(j0, d0)[searched])
         np.testing.assert_array_equal(b1[searched], keys_from_oracle(j1, d1)[searched])
+        # default path: a row either carries its exact pair or is marked "proved rejected"; accepted rows carry it
+        have = s0 != S.NOMATCH
+        np.testing.assert_array_equal(s0[have], b0[have])
+        np.testing.assert_array_equal(s1[have], b1[have])
+        acc = np.zeros(len(bank), bool)
+        for v in views:
+            o = int(view_off[v])
+            acc[o + got[1][o:o + int(got[0][v])].astype(np.int64)] = True
+        assert have[acc].all()
     return got
 
 
