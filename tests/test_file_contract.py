@@ -151,3 +151,38 @@ def test_pair_generators_literal():
     # removeDupPairs (SfMDataUtils.cpp:168-187): a later duplicate (either orientation) goes, earlier entries end up ordered
     assert extfeat.remove_dup_pairs([(3, 1), (1, 3), (2, 5), (5, 2), (1, 3)]) == [(1, 3), (2, 5)]
     assert extfeat.remove_dup_pairs([(0, 1)]) == [(0, 1)]
+
+
+GOLD_FILES = os.path.join(os.path.dirname(__file__), "golden", "files")
+
+
+def test_golden_file_samples(tmp_path):
+    """Hand-built byte-level samples of the on-disk contract (tests/golden/files, written by make_golden.py WITHOUT
+    fileio): the codecs read them to the known values and write the same bytes back."""
+    d = fileio.read_desc(os.path.join(GOLD_FILES, "img000.desc"))
+    assert d.shape == (3, 64) and d[1, 0] == 64 and d[2, 60] == (188 & 0x3F) and (d[:, 61:] == 0).all()
+    fileio.write_desc(tmp_path / "a.desc", d)
+    assert (tmp_path / "a.desc").read_bytes() == open(os.path.join(GOLD_FILES, "img000.desc"), "rb").read()
+    k = fileio.read_feat(os.path.join(GOLD_FILES, "img000.feat"))
+    np.testing.assert_array_equal(k, np.array([[12.5, 7.25, 4.8, 90], [123.457, 0.000123457, 9.6, 359.5],
+                                               [639, 479, 19.2, 0]], np.float32))
+    fileio.write_feat(tmp_path / "a.feat", k)
+    assert (tmp_path / "a.feat").read_text() == open(os.path.join(GOLD_FILES, "img000.feat")).read()
+    b = fileio.read_mat_bin(os.path.join(GOLD_FILES, "img000.bow"))
+    assert b.shape == (4, 1) and b.ravel().tolist() == [0.0, 0.25, 0.5, 1.0]
+    fileio.write_mat_bin(tmp_path / "a.bow", b)
+    assert (tmp_path / "a.bow").read_bytes() == open(os.path.join(GOLD_FILES, "img000.bow"), "rb").read()
+    o = fileio.read_image_describer(os.path.join(GOLD_FILES, "image_describer.txt"))
+    assert o["desc_ch"] == 3 and o["nOct"] == 4 and o["nOctLay"] == 4 and abs(o["thres"] - 0.001) < 1e-9
+    sd = fileio.read_sfm_data(os.path.join(GOLD_FILES, "sfm_data.json"))
+    assert [v["key"] for v in sd["views"]] == [0, 1] and sd["structure"][0]["key"] == 5
+
+
+def test_native_loader_reads_golden_files():
+    """sfmloc_scan (host-only half of sfmloc_open) on the hand-built samples: one posed view of two, three rows, the
+    landmark observed by feature 1."""
+    info = capi.scan(GOLD_FILES, GOLD_FILES)
+    assert info["n_views_total"] == 2 and info["n_views_posed"] == 1 and info["n_rows"] == 3
+    assert info["n_landmarks"] == 1 and info["n_observations"] == 1 and info["bow_dim"] == 4
+    assert info["row_landmark_sum"] == -1 + 0 + -1          # rows 0 and 2 unobserved, feature 1 -> landmark slot 0
+    assert (info["focal"], info["ppx"], info["ppy"]) == (800.0, 320.0, 240.0)

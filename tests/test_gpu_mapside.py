@@ -89,3 +89,24 @@ def test_geometric_match_of_map_pairs(oracle_c):
                                     ransac_round=rounds)
         assert_same(got, exp)
         assert len(exp) >= 6 and all(len(v[0]) > 17 for v in exp.values())
+
+
+def test_fmatrix_golden_scene_on_device():
+    """The committed fundamental-matrix scene (tests/golden/geometry_scenes.npz) through sfmloc_geometric_pairs: the
+    device reproduces the minted inlier list exactly."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "geometry_scenes.npz"))
+    x1, x2 = g["f_x1"].astype(np.float32), g["f_x2"].astype(np.float32)
+    assert np.array_equal(x1.astype(np.float64), g["f_x1"])          # the scene is float32-exact by construction
+    n = len(x1)
+    rng = np.random.Generator(np.random.PCG64(2))
+    desc = synth.random_descriptors(rng, 2 * n)
+    w, h = (int(v) for v in g["wh"])
+    p = S.default_params(ransac_round=200, geom_precision=4.0)
+    with S.Map(np.array([7, 9], np.uint32), np.array([0, n, 2 * n], np.uint32), desc, params=p,
+               view_wh=np.array([[w, h], [w, h]], np.uint32), kpt_xy=np.concatenate([x1, x2])) as dm:
+        ident = np.arange(n, dtype=np.uint32)
+        got = dm.geometric_pairs({(0, 1): (ident, ident)})
+    assert list(got) == [(0, 1)]
+    np.testing.assert_array_equal(got[(0, 1)][0], g["f_inliers"])
+    np.testing.assert_array_equal(got[(0, 1)][1], g["f_inliers"])

@@ -263,3 +263,30 @@ def test_ud_pixel_k3_inverts_the_radial_model():
         assert np.array_equal(back, oracle_c.ud_pixel_k3(pd, f, ppx, ppy, k1, k2, k3))
     c = oracle_c.ud_pixel_k3(np.array([[ppx, ppy]]), f, ppx, ppy, -0.1, 0.01, 0.0)
     assert c.tolist() == [[ppx, ppy]]
+
+
+def test_golden_geometry_scenes():
+    """tests/golden/geometry_scenes.npz (make_golden.py): planted scenes with the analytic answer and the oracle's exact
+    output at minting time.  Pins the C restatement against regressions (sampling, solvers, NFA, budget rules) and
+    checks it against the truth it was planted with."""
+    import os
+    from oracle import oracle_c
+    oracle_c.build()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "geometry_scenes.npz"))
+    f, ppx, ppy = g["intrinsic"]
+    r = oracle_c.p3p_localize(g["pt2d"], g["pt3d"], f, ppx, ppy, 4096, 0x5f3759df12345678, stream=0)
+    assert r["n"] == int(g["p3p_n"]) and r["iters"] == int(g["p3p_iters"])
+    np.testing.assert_array_equal(r["inliers"], g["p3p_inliers"])
+    np.testing.assert_array_equal(r["P"].view(np.uint64), g["p3p_P"].view(np.uint64))
+    assert r["nfa"] == float(g["p3p_nfa"]) and r["errmax"] == float(g["p3p_errmax"])
+    truth_in = ~g["is_outlier"]
+    assert truth_in[r["inliers"]].mean() > 0.98 and r["n"] >= 0.95 * truth_in.sum()
+    K, R, t, c = oracle_c.krt_from_p(r["P"])
+    assert np.abs(c - g["C_true"]).max() < 0.05 and np.abs(R - g["R_true"]).max() < 5e-3
+    w, h = (int(v) for v in g["wh"])
+    fr = oracle_c.fmatrix_filter(g["f_x1"], (w, h), g["f_x2"], (w, h), 4.0, 200, 0x5f3759df12345678, stream=7)
+    assert fr["n"] == int(g["f_n"]) and fr["iters"] == int(g["f_iters"]) and fr["nfa"] == float(g["f_nfa"])
+    np.testing.assert_array_equal(fr["inliers"], g["f_inliers"])
+    np.testing.assert_array_equal(fr["F"].view(np.uint64), g["f_F"].view(np.uint64))
+    f_truth = ~g["f_is_outlier"]
+    assert f_truth[fr["inliers"]].mean() > 0.95 and fr["n"] >= 0.9 * f_truth.sum()
