@@ -284,6 +284,11 @@ int sfmloc_merge_begin(sfmloc_context *ctx, sfmloc_query *q, const void *parts_d
 /* ------------------------------------------------------------------------- */
 int sfmloc_bow_select(sfmloc_map *map, const float *query_bow, const uint32_t *cand_views, uint32_t n_cand,
                       uint32_t k, uint32_t *out_sel, uint32_t *n_out);
+/* The distances sfmloc_bow_select ranks by: out_dist[v] = the float32 L2 distance of view v's .bow vector to the
+ * query's (same kernel, same summation order).  For the sharded shortlist: every rank ranks its own
+ * views, the ranks exchange their k best (distance, view id) pairs and keep the global k best; ties go to the lower
+ * view id, as in the unsharded selection. */
+int sfmloc_bow_distances(sfmloc_map *map, const float *query_bow, float *out_dist /*[n_views]*/);
 
 /* The query's BoW vector from its dense local features: PcaWrapper::calcPcaProject (PcaWrapper.cpp:67-89) +
  * BoFSpatialPyramids::calcBoF (BoFSpatialPyramids.cpp:108-302) with an exact nearest-centre search.

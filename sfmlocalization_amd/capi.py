@@ -104,7 +104,7 @@ SYMBOLS = [
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
     "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
     "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
-    "sfmloc_dense_gray", "sfmloc_query_from_view", "sfmloc_match_one_to_one", "sfmloc_match_pairs", "sfmloc_track", "sfmloc_geometric_pairs",
+    "sfmloc_dense_gray", "sfmloc_bow_distances", "sfmloc_query_from_view", "sfmloc_match_one_to_one", "sfmloc_match_pairs", "sfmloc_track", "sfmloc_geometric_pairs",
     "sfmloc_matches_pairs", "sfmloc_matches_pair", "sfmloc_matches_read", "sfmloc_matches_destroy",
     "sfmloc_localize_batch", "sfmloc_part_bytes", "sfmloc_shard_begin", "sfmloc_shard_export",
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
@@ -140,6 +140,7 @@ def _L():
         L.sfmloc_match_putative.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
         L.sfmloc_putative_read.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4 + [C.c_uint64]
         L.sfmloc_putative_read_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.sfmloc_bow_distances.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.sfmloc_dense_gray.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_uint8)]
         L.sfmloc_query_from_view.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -207,6 +208,14 @@ def _check(rc):
 
 def _ptr(a, ctype):
     return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _sel(view_sel):
+    """view selection -> (pointer, count, keep-alive).  An EMPTY selection must stay a non-null pointer with count 0
+    (NULL means "all views" in the C ABI), so it is backed by a one-element dummy."""
+    sel = np.ascontiguousarray(view_sel, dtype=np.uint32).ravel()
+    back = sel if sel.shape[0] else np.zeros(1, np.uint32)
+    return _ptr(back, C.c_uint32), int(sel.shape[0]), back
 
 
 def device_count():
@@ -367,8 +376,8 @@ class Map:
         if view_sel is None:
             _check(_L().sfmloc_match_putative(self._h, q._h, None, 0))
         else:
-            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
-            _check(_L().sfmloc_match_putative(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+            p, n, keep = _sel(view_sel)
+            _check(_L().sfmloc_match_putative(self._h, q._h, p, n))
 
     def putative_read(self):
         """-> view_count[V], match_i, match_j, match_d (each [n_rows]; view v's list at view_off[v])."""
@@ -399,8 +408,8 @@ class Map:
         if view_sel is None:
             _check(_L().sfmloc_match_one_to_one(self._h, q._h, None, 0))
         else:
-            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
-            _check(_L().sfmloc_match_one_to_one(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+            p, n, keep = _sel(view_sel)
+            _check(_L().sfmloc_match_one_to_one(self._h, q._h, p, n))
 
     @staticmethod
     def _take_matches(h):
@@ -491,8 +500,7 @@ class Map:
         if view_sel is None:
             sel_p, n_sel = None, 0
         else:
-            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
-            sel_p, n_sel = _ptr(sel, C.c_uint32), sel.shape[0]
+            sel_p, n_sel, keep = _sel(view_sel)
         _check(_L().sfmloc_localize(self._h, q._h, sel_p, n_sel, C.byref(pose), _ptr(pq, C.c_uint32),
                                     _ptr(pl, C.c_uint32), cap))
         k = pose.n_inliers if pose.ok else 0
@@ -513,6 +521,13 @@ class Map:
             cp, nc = _ptr(cv, C.c_uint32), cv.shape[0]
         _check(_L().sfmloc_bow_select(self._h, _ptr(qb, C.c_float), cp, nc, k, _ptr(out, C.c_uint32), C.byref(n)))
         return out[:n.value].copy()
+
+    def bow_distances(self, query_bow):
+        """sfmloc_bow_distances: float32 L2 distance of every view's .bow vector to the query's (what bow_select ranks)."""
+        qb = np.ascontiguousarray(query_bow, dtype=np.float32).ravel()
+        out = np.zeros(self.n_views, np.float32)
+        _check(_L().sfmloc_bow_distances(self._h, _ptr(qb, C.c_float), _ptr(out, C.c_float)))
+        return out
 
     def localize_batch(self, queries, n_contexts=4, cap=0):
         """sfmloc_localize_batch: queries pipelined over n_contexts streams; -> list of Pose (+ pairs if cap)."""
@@ -665,16 +680,16 @@ class Context:
         if view_sel is None:
             _check(_L().sfmloc_localize_begin(self._h, q._h, None, 0))
         else:
-            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
-            _check(_L().sfmloc_localize_begin(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+            p, n, keep = _sel(view_sel)
+            _check(_L().sfmloc_localize_begin(self._h, q._h, p, n))
 
     def shard_begin(self, q, view_sel=None):
         """K1..K3 + candidate emission on this shard (asynchronous)."""
         if view_sel is None:
             _check(_L().sfmloc_shard_begin(self._h, q._h, None, 0))
         else:
-            sel = np.ascontiguousarray(view_sel, dtype=np.uint32)
-            _check(_L().sfmloc_shard_begin(self._h, q._h, _ptr(sel, C.c_uint32), sel.shape[0]))
+            p, n, keep = _sel(view_sel)
+            _check(_L().sfmloc_shard_begin(self._h, q._h, p, n))
 
     def shard_export(self, dst_dev_ptr, cap):
         _check(_L().sfmloc_shard_export(self._h, C.c_void_p(dst_dev_ptr), cap))

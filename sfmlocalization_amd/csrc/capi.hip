@@ -1138,6 +1138,26 @@ int sfmloc_bow_select(sfmloc_map *map, const float *query_bow, const uint32_t *c
   return SFMLOC_OK;
 }
 
+int sfmloc_bow_distances(sfmloc_map *map, const float *query_bow, float *out_dist) {
+  SFM_CHECK(map && query_bow && out_dist, SFMLOC_EINVAL, "sfmloc_bow_distances: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  Ctx *c = m->ctx0;
+  SFM_CHECK(m->bow_dim > 0 && m->d_bow, SFMLOC_EINVAL, "sfmloc_bow_distances: the map has no .bow vectors");
+  SFM_HIP(hipSetDevice(m->device));
+  if (m->n_views == 0) return SFMLOC_OK;
+  SFM_HIP(hipMemcpyAsync(c->d_bow_query, query_bow, m->bow_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  int rc;
+  {
+    EventScope ev(c, SFMLOC_K_BOW);
+    rc = launch_bow_select(m, c->stream, c->d_bow_query, nullptr, m->n_views, 1, c->d_bow_dist, c->d_bow_sel);
+  }
+  if (rc) return rc;
+  // the kernel stores the float32 distance's bit pattern (non-negative floats order like their bits)
+  SFM_HIP(hipMemcpyAsync(out_dist, c->d_bow_dist, (size_t)m->n_views * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  SFM_HIP(hipStreamSynchronize(c->stream));
+  return SFMLOC_OK;
+}
+
 int sfmloc_bof_create(const sfmloc_bof_desc *d, int device, sfmloc_bof **out) {
   SFM_CHECK(d && out, SFMLOC_EINVAL, "sfmloc_bof_create: null argument");
   *out = nullptr;

@@ -58,6 +58,24 @@ def shard_views(view_off, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def merge_bow_shortlists(local_dist, local_view_id, k, world, all_gather):
+    """Sharded BoW shortlist: `local_dist[i]` = this rank's distance for its view `local_view_id[i]`
+    (ascending ids).  Every rank contributes its k best (distance, view id) pairs; the global k best -- ties to the
+    lower view id, as sfmloc_bow_select does on one GPU -- are kept, and the function returns the ascending LOCAL
+    indices among them (what sfmloc_shard_begin takes as view_sel).  `all_gather(arr [k, 2] f64) -> [world, k, 2]`."""
+    local_dist = np.asarray(local_dist, np.float32)
+    local_view_id = np.asarray(local_view_id, np.int64)
+    order = np.lexsort((local_view_id, local_dist))[:k]
+    mine = np.full((k, 2), np.inf, np.float64)
+    mine[:len(order), 0] = local_dist[order]
+    mine[:len(order), 1] = local_view_id[order]
+    allp = np.asarray(all_gather(mine)).reshape(world * k, 2)
+    allp = allp[np.isfinite(allp[:, 0])]
+    best = allp[np.lexsort((allp[:, 1], allp[:, 0]))[:k]]
+    chosen = set(int(v) for v in best[:, 1])
+    return np.array([i for i, v in enumerate(local_view_id) if int(v) in chosen], np.uint32)
+
+
 class ShardedLocalizer:
     """compute.stage1(queries[, slot]) -> torch.uint8 [B, part_bytes] on compute.device (this shard's parts, possibly
     still being written: compute.stage1_wait(slot) blocks until they are final);
@@ -78,10 +96,11 @@ class ShardedLocalizer:
     def owner(self, i):
         return i % self.world
 
-    def _stage1(self, queries, slot):
+    def _stage1(self, queries, slot, view_sels=None):
+        kw = {} if view_sels is None else {"view_sels": view_sels}
         if self.n_slots > 1:
-            return self.compute.stage1(queries, slot)
-        return self.compute.stage1(queries)
+            return self.compute.stage1(queries, slot, **kw)
+        return self.compute.stage1(queries, **kw)
 
     def _finish(self, queries, parts, slot, gather_results):
         import torch
@@ -112,8 +131,38 @@ class ShardedLocalizer:
             out.update(d)
         return out
 
-    def localize_batch(self, queries, gather_results=True):
-        return self._finish(queries, self._stage1(queries, 0), 0, gather_results)
+    def bow_shortlists(self, local_map, query_bows, k):
+        """Per query: the LOCAL view indices of the global k-nearest .bow vectors (exact, equal to the unsharded
+        sfmloc_bow_select).  One small all-gather for the whole batch."""
+        import torch
+        ids = np.asarray(local_map.view_id, np.int64)
+        B = len(query_bows)
+        mine = np.full((B, k, 2), np.inf, np.float64)
+        for b, qb in enumerate(query_bows):
+            d = local_map.bow_distances(qb)
+            order = np.lexsort((ids, d))[:k]
+            mine[b, :len(order), 0] = d[order]
+            mine[b, :len(order), 1] = ids[order]
+        if self.world > 1:
+            t = torch.from_numpy(mine)
+            dev = getattr(self.compute, "device", torch.device("cpu"))
+            t = t.to(dev)
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=dev)
+            self.dist.all_gather_into_tensor(out.view(self.world * B, k, 2), t, group=self.group)
+            allp = out.cpu().numpy()
+        else:
+            allp = mine[None]
+        sels = []
+        for b in range(B):
+            p = allp[:, b].reshape(-1, 2)
+            p = p[np.isfinite(p[:, 0])]
+            best = p[np.lexsort((p[:, 1], p[:, 0]))[:k]]
+            chosen = set(int(v) for v in best[:, 1])
+            sels.append(np.array([i for i, v in enumerate(ids) if int(v) in chosen], np.uint32))
+        return sels
+
+    def localize_batch(self, queries, gather_results=True, view_sels=None):
+        return self._finish(queries, self._stage1(queries, 0, view_sels), 0, gather_results)
 
     def localize_stream(self, batches, gather_results=False):
         """Generator over batches (lists of queries), yielding each batch's {index: result} in order.  With a
@@ -156,7 +205,7 @@ class HipShardCompute:
             for c in cs:
                 c.close()
 
-    def stage1(self, queries, slot=0):
+    def stage1(self, queries, slot=0, view_sels=None):
         import torch
         B = len(queries)
         pb = part_bytes(self.cap)
@@ -171,7 +220,8 @@ class HipShardCompute:
         cs = self.ctxs[slot]
         for i, q in enumerate(queries):
             c = cs[i % len(cs)]
-            c.shard_begin(q)                       # K1..K3 + candidate emission, asynchronous
+            # K1..K3 + candidate emission, asynchronous; view_sels[i]: this shard's views to scan (BoW shortlist)
+            c.shard_begin(q, None if view_sels is None else view_sels[i])
             c.shard_export(base + i * pb, self.cap)  # device-to-device copy on the same stream
         self._queries[slot] = queries
         return parts

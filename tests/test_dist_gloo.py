@@ -38,6 +38,33 @@ def test_part_layout_roundtrip():
         D.unpack_part(D.pack_part(c, 2), 2)          # header keeps the true count -> overflow is detected
 
 
+def test_merge_bow_shortlists_equals_global_selection():
+    """Sharded BoW shortlist: per-shard k best (distance, view id) pairs merged to the global k best, ties to the lower
+    view id -- equal to ranking all views at once, for every split of the views into shards."""
+    rng = np.random.Generator(np.random.PCG64(6))
+    V, k = 57, 9
+    dist = rng.integers(0, 12, V).astype(np.float32)            # many exact ties
+    ids = np.arange(V) * 3 + 1
+    glob = set(int(v) for v in ids[np.lexsort((ids, dist))[:k]])
+    for world in (1, 2, 3, 8):
+        cuts = [0] + sorted(rng.choice(np.arange(1, V), world - 1, replace=False).tolist()) + [V] if world > 1 else [0, V]
+        per_rank = []
+        for r in range(world):
+            a, b = cuts[r], cuts[r + 1]
+            order = np.lexsort((ids[a:b], dist[a:b]))[:k]
+            m = np.full((k, 2), np.inf)
+            m[:len(order), 0], m[:len(order), 1] = dist[a:b][order], ids[a:b][order]
+            per_rank.append(m)
+        gathered = np.stack(per_rank)
+        got = set()
+        for r in range(world):
+            a, b = cuts[r], cuts[r + 1]
+            sel = D.merge_bow_shortlists(dist[a:b], ids[a:b], k, world, lambda mine: gathered)
+            assert list(sel) == sorted(sel)
+            got |= set(int(ids[a + i]) for i in sel)
+        assert got == glob
+
+
 class OracleShardCompute:
     """stand-in for HipShardCompute built on the oracle (tests only)"""
 

@@ -54,3 +54,57 @@ def test_bof_vector_matches_oracle(oracle_c):
     np.testing.assert_array_equal(b2.compute(desc, kxy).view(np.uint64),
                                   oracle_c.bof(desc, kxy, desc[:30], levels=1, norm_type=1).view(np.uint64))
     b2.close()
+
+
+def test_sharded_shortlist_equals_unsharded(oracle_c):
+    """sfmloc_bow_distances per shard + the (distance, view id) merge of dist.py = sfmloc_bow_select on the whole map;
+    an empty local selection scans nothing (it must not fall back to "all views")."""
+    from sfmlocalization_amd import dist as D
+    rng = np.random.Generator(np.random.PCG64(14))
+    m = synth.make_map(8, n_views=30, desc_per_view=150, views_per_place=10, landmarks_per_place=120, obs_per_view=60)
+    bow = rng.uniform(0, 1, (30, 40)).astype(np.float32)
+    bow[7] = bow[3]                                                     # exact tie between two views
+    qbow = (bow[3] + rng.normal(0, 0.01, 40)).astype(np.float32)
+    k = 6
+    kw = dict(view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+              landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    with S.Map(m.view_id, m.view_off, m.desc, bow=bow, **kw) as full:
+        ref = full.bow_select(qbow, k)
+        d_all = full.bow_distances(qbow)
+        assert set(np.lexsort((m.view_id, d_all))[:k].tolist()) == set(ref.tolist()) and d_all[7] == d_all[3]
+    cuts = [(0, 11), (11, 12), (12, 30)]
+    shards, dists = [], []
+    for a, b in cuts:
+        r0, r1 = int(m.view_off[a]), int(m.view_off[b])
+        sm = S.Map(m.view_id[a:b], m.view_off[a:b + 1] - m.view_off[a], m.desc[r0:r1], bow=bow[a:b],
+                   view_wh=m.view_wh[a:b], kpt_xy=m.kpt_xy[r0:r1], row_landmark=m.row_landmark[r0:r1],
+                   landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+        shards.append(sm)
+        dists.append(sm.bow_distances(qbow))
+        np.testing.assert_array_equal(dists[-1], d_all[a:b])
+    per_rank = []
+    for (a, b), d in zip(cuts, dists):
+        ids = m.view_id[a:b].astype(np.int64)
+        order = np.lexsort((ids, d))[:k]
+        mm = np.full((k, 2), np.inf)
+        mm[:len(order), 0], mm[:len(order), 1] = d[order], ids[order]
+        per_rank.append(mm)
+    gathered = np.stack(per_rank)
+    got = []
+    q = synth.make_query(m, 5, n_feat=300, n_copies=100)
+    for (a, b), d, sm in zip(cuts, dists, shards):
+        sel = D.merge_bow_shortlists(d, m.view_id[a:b], k, 3, lambda mine: gathered)
+        got += [a + int(i) for i in sel]
+        dq = sm.query(q.desc, q.kpt_xy, q.width, q.height)
+        c = sm.context()
+        c.shard_begin(dq, sel)                                         # possibly an EMPTY selection
+        c.sync()
+        sm.match_putative(dq, sel)
+        cnt = sm.putative_read()[0]
+        assert cnt.sum() == 0 or len(sel) > 0
+        assert (cnt[np.setdiff1d(np.arange(b - a), sel)] == 0).all()
+        c.close()
+        dq.close()
+    assert sorted(got) == ref.tolist()
+    for sm in shards:
+        sm.close()
