@@ -58,7 +58,9 @@ def parse():
     ap.add_argument("--nq", type=int, default=2000)
     ap.add_argument("--queries", type=int, default=8, help="distinct synthetic queries cycled through")
     ap.add_argument("--in-flight", type=int, default=4, help="queries in flight (contexts); 1 = latency mode")
-    ap.add_argument("--batch", type=int, default=16, help="queries per all-gather when --gpus > 1")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="queries per all-gather when --gpus > 1 (a multiple of the world size keeps the P3P stage balanced; "
+                         "small batches keep the two-slot pipeline full over a short timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -100,7 +102,14 @@ def main():
     if world > 1 or (forced and "RANK" in os.environ):
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # SFMLOC_BENCH_BACKEND=gloo: rehearse N ranks on fewer GPUs (ranks share devices, the exchange goes through the
+        # host); the measured configuration is always nccl = RCCL, one rank per GPU
+        backend = os.environ.get("SFMLOC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
 
     import sfmlocalization_amd as S
@@ -191,7 +200,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = dev_map.stats()
@@ -213,7 +222,7 @@ def main():
     dev_map.match_putative(dqs[0])  # outside the timed region: number of emitted matches for the byte count
     n_match = int(dev_map.putative_read()[0].sum())
     if world > 1:
-        ok_t = torch.tensor([n_ok[0]], dtype=torch.int64, device="cuda")
+        ok_t = torch.tensor([n_ok[0]], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ok_t)
         n_ok[0] = int(ok_t.item())
     rows_rank = r1 - r0

@@ -111,7 +111,13 @@ class ShardedLocalizer:
         # concatenated along dim 0 (the layout every backend accepts), viewed as [world, B, part_bytes]
         flat = torch.empty((self.world * B, parts.shape[1]), dtype=torch.uint8, device=parts.device)
         if self.world > 1 or self.always_gather:
-            self.dist.all_gather_into_tensor(flat, parts.contiguous(), group=self.group)
+            if parts.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # rehearsal of the N>1 path without RCCL (e.g. two ranks sharing one GPU): stage through the host
+                host = torch.empty(flat.shape, dtype=torch.uint8)
+                self.dist.all_gather_into_tensor(host, parts.cpu().contiguous(), group=self.group)
+                flat.copy_(host)
+            else:
+                self.dist.all_gather_into_tensor(flat, parts.contiguous(), group=self.group)
         else:
             flat.copy_(parts)
         if flat.is_cuda:
