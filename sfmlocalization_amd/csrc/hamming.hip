@@ -223,20 +223,93 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
   }
 }
 
-// Exact top-2 of the flagged rows: one workgroup per 64 flagged rows, its 8 waves interleave the query rows and
-// merge their partial top-2 through LDS (the packed key makes the merge order-independent).
-template <int WAVES>
+// Exact top-2 of the flagged rows.  64 flagged rows x all query rows is ~130 k pairs: on ONE compute unit that is
+// 25 us of popcounts, on the query's critical path.  So a chunk of 64 rows is spread over SLICES workgroups (one
+// query slice each, the slice in LDS, its waves interleaving the slice's rows); each writes its partial top-2 to a
+// scratch slot, and the workgroup that arrives last at the chunk's counter merges the SLICES partials (the packed
+// key makes the merge order-independent) and resets the counter.  No workgroup ever waits for another.
+template <int WAVES, int SLICES>
 __global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__restrict__ bank,
                                                              const uint4 *__restrict__ qdesc, uint32_t nq,
-                                                             uint32_t lds_rows, const uint2 *__restrict__ flagged,
+                                                             const uint2 *__restrict__ flagged,
                                                              const uint32_t *__restrict__ n_flagged,
+                                                             uint2 *__restrict__ scratch /*[chunk][SLICES][64]*/,
+                                                             uint32_t *__restrict__ arrivals /*[chunk], zero*/,
+                                                             uint32_t chunk_cap, uint32_t lds_rows,
                                                              uint2 *__restrict__ part) {
   extern __shared__ uint4 qs[];
   __shared__ uint2 merge[WAVES][64];
+  __shared__ uint32_t s_last;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t slice = blockIdx.x % SLICES;
   const uint32_t n = *n_flagged;
-  for (uint32_t chunk = blockIdx.x; chunk * 64 < n; chunk += gridDim.x) {
+  const uint32_t per = (nq + SLICES - 1) / SLICES;
+  const uint32_t j_lo = slice * per, j_hi = min(nq, j_lo + per);
+  const uint32_t cnt = j_hi > j_lo ? j_hi - j_lo : 0;
+  // this workgroup's query slice (the same for every chunk it handles); chunk_cap == 0 <=> the slice does not fit
+  if (chunk_cap)
+    for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j_lo * 4 + i];
+  __syncthreads();
+  for (uint32_t chunk = blockIdx.x / SLICES; chunk * 64 < n && chunk < chunk_cap; chunk += gridDim.x / SLICES) {
+    const uint32_t e = chunk * 64 + lane;
+    const bool valid = e < n;
+    const uint2 ent = valid ? flagged[e] : make_uint2(0, 0);
+    uint32_t b[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (valid) v = bank[((uint64_t)(ent.y >> 6) * 4 + c) * 64 + (ent.y & 63u)];
+      b[4 * c + 0] = v.x;
+      b[4 * c + 1] = v.y;
+      b[4 * c + 2] = v.z;
+      b[4 * c + 3] = v.w;
+    }
+    uint32_t best0 = SFMLOC_NOMATCH, best1 = SFMLOC_NOMATCH;
+    for (uint32_t jj = wave; jj < cnt; jj += WAVES) {
+      const uint4 q0 = qs[jj * 4 + 0], q1 = qs[jj * 4 + 1], q2 = qs[jj * 4 + 2], q3 = qs[jj * 4 + 3];
+      const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                              q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
+      top2_push(best0, best1, (acc << 16) | (j_lo + jj));
+    }
+    merge[wave][lane] = make_uint2(best0, best1);
+    __syncthreads();
+    if (wave == 0) {
+      uint32_t m0 = SFMLOC_NOMATCH, m1 = SFMLOC_NOMATCH;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        top2_push(m0, m1, merge[w][lane].x);
+        top2_push(m0, m1, merge[w][lane].y);
+      }
+      scratch[((uint64_t)chunk * SLICES + slice) * 64 + lane] = make_uint2(m0, m1);
+    }
+    // publish the partial, count the arrival; the last of the chunk's SLICES workgroups merges
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const uint32_t prev = atomicAdd(&arrivals[chunk], 1u);
+      s_last = (prev == SLICES - 1) ? 1u : 0u;
+      if (s_last) arrivals[chunk] = 0;  // every arrival of this query is in: ready for the next query
+      __threadfence();
+    }
+    __syncthreads();
+    if (s_last && wave == 0 && valid) {
+      uint32_t m0 = SFMLOC_NOMATCH, m1 = SFMLOC_NOMATCH;
+      for (int sl = 0; sl < SLICES; ++sl) {
+        const uint2 p = scratch[((uint64_t)chunk * SLICES + sl) * 64 + lane];
+        top2_push(m0, m1, p.x);
+        top2_push(m0, m1, p.y);
+      }
+      part[ent.x] = make_uint2(m0, m1);
+    }
+    __syncthreads();  // merge[] and s_last are reused by the next chunk
+  }
+  // more flagged rows than the scratch has chunks for (pathological inputs): one workgroup per remaining chunk walks
+  // all the query slices itself
+  for (uint32_t chunk = chunk_cap + blockIdx.x; chunk * 64 < n; chunk += gridDim.x) {
     const uint32_t e = chunk * 64 + lane;
     const bool valid = e < n;
     const uint2 ent = valid ? flagged[e] : make_uint2(0, 0);
@@ -252,11 +325,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__rest
     }
     uint32_t best0 = SFMLOC_NOMATCH, best1 = SFMLOC_NOMATCH;
     for (uint32_t j0 = 0; j0 < nq; j0 += lds_rows) {
-      const uint32_t cnt = min(lds_rows, nq - j0);
+      const uint32_t c2 = min(lds_rows, nq - j0);
       __syncthreads();
-      for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
+      for (uint32_t i = threadIdx.x; i < c2 * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
       __syncthreads();
-      for (uint32_t jj = wave; jj < cnt; jj += WAVES) {
+      for (uint32_t jj = wave; jj < c2; jj += WAVES) {
         const uint4 q0 = qs[jj * 4 + 0], q1 = qs[jj * 4 + 1], q2 = qs[jj * 4 + 2], q3 = qs[jj * 4 + 3];
         const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                 q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
@@ -266,6 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__rest
         top2_push(best0, best1, (acc << 16) | (j0 + jj));
       }
     }
+    __syncthreads();
     merge[wave][lane] = make_uint2(best0, best1);
     __syncthreads();
     if (wave == 0 && valid) {
@@ -300,12 +374,24 @@ __global__ __launch_bounds__(256) void k_merge_ratio_compact(
   const uint32_t blk0 = off >> 6;
   const uint32_t widx0 = view_sel ? view_widx0[gw] : blk0;
   uint32_t base = 0;
+  // the mask words of the view's blocks, fetched 64 at a time up front instead of one dependent load per iteration
+  const uint32_t n_blk = (end > off) ? (((end - 1) >> 6) - blk0 + 1) : 0;
+  unsigned long long my_mask = ~0ull;
+  uint32_t mask_base = 0;  // block (relative to blk0) held by lane 0
+  if (flagmask && lane < n_blk) my_mask = flagmask[widx0 + lane];
   for (uint32_t r0 = off; r0 < end; r0 += 64) {
     const uint32_t r = r0 + lane;
     const bool valid = r < end;
     uint32_t b0 = SFMLOC_NOMATCH, b1 = SFMLOC_NOMATCH;
-    const uint32_t widx = widx0 + ((r >> 6) - blk0);
-    if (valid && (!flagmask || ((flagmask[widx] >> (r & 63u)) & 1ull))) {
+    const uint32_t rel = (r >> 6) - blk0;
+    const uint32_t widx = widx0 + rel;
+    if (flagmask && ((r0 + 63) >> 6) - blk0 >= mask_base + 64) {  // a view longer than ~4000 rows: slide the window
+      mask_base = (r0 >> 6) - blk0;                                // to the first block this step touches
+      my_mask = (mask_base + lane < n_blk) ? flagmask[widx0 + mask_base + lane] : 0ull;
+    }
+    // a 64-row step of an unaligned view touches two blocks: lanes read the word of their own row's block
+    const unsigned long long mw = flagmask ? __shfl(my_mask, (int)((valid ? rel : mask_base) - mask_base), 64) : ~0ull;
+    if (valid && ((mw >> (r & 63u)) & 1ull)) {
       for (uint32_t s = 0; s < split; ++s) {
         const uint2 p = part[((uint64_t)s * n_work_blocks + widx) * 64 + (r & 63u)];
         top2_push(b0, b1, p.x);
@@ -408,8 +494,14 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   c->stats.hamming_lane_ops += rows * head * 35 + rows * (q->n - head) * (uint64_t)(2 * nw + 1);
   c->k1_finish_ops = 2 * (16 - nw) + 5;
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL((k_hamming_rows<WAVES>), dim3(512), dim3(WAVES * 64), lds_bytes, c->stream, m->d_bank, q->d_desc,
-                     q->n, lds_rows, c->d_flagged, c->d_n_flagged, c->d_part);
+  // the exact pass over the flagged rows: chunks of 64 rows x kRowSlices query slices, see k_hamming_rows
+  constexpr int RW = 4, RS = 8;
+  const uint32_t per = (q->n + RS - 1) / RS;
+  const uint32_t rows_lds = per < 1024 ? per : 1024;  // 64 KiB of LDS at most; a longer slice does not fit ...
+  const uint32_t chunk_cap = per <= 1024 ? c->rows_chunk_cap : 0;  // ... and then every chunk takes the walking path
+  hipLaunchKernelGGL((k_hamming_rows<RW, RS>), dim3(128 * RS), dim3(RW * 64), (size_t)rows_lds * 64, c->stream,
+                     m->d_bank, q->d_desc, q->n, c->d_flagged, c->d_n_flagged, c->d_rows_scratch, c->d_rows_arrivals,
+                     chunk_cap, rows_lds, c->d_part);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -141,6 +141,42 @@ def test_screening_on_structured_descriptors(oracle_c, ratio):
             assert got[0].sum() > 500
 
 
+def test_long_unaligned_views_through_the_screening_path(oracle_c):
+    """Views longer than 64 blocks and not aligned to the 64-row blocks: K2 slides its window of row-mask words."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    nq = 900
+    n_rows = 9000 + 4500 + 70 + 5000
+    q = synth.random_descriptors(rng, nq)
+    bank = synth.random_descriptors(rng, n_rows)
+    idx = rng.choice(n_rows, 2500, replace=False)
+    bank[idx] = synth.flip_bits(rng, q[rng.integers(0, nq, 2500)], 35)
+    view_off = np.array([0, 9000, 13500, 13570, n_rows], np.uint32)       # 9000 rows = 141 blocks, starts at 9000 % 64 != 0
+    got = check_against_oracle(oracle_c, q, bank, view_off, None)
+    assert got[0].min() > 0
+
+
+def test_flagged_row_pass_paths(oracle_c):
+    """The exact pass over flagged rows: the sliced path with its last-arrival merge (many chunks, several rounds per
+    workgroup slot), the walking path when a query slice does not fit LDS (nq > 8192), and partial last chunks."""
+    rng = np.random.Generator(np.random.PCG64(91))
+    # (a) many flagged rows: 20 000 planted matches -> ~313 chunks over 128 chunk slots
+    nq, n_rows = 1200, 40000
+    q = synth.random_descriptors(rng, nq)
+    bank = synth.random_descriptors(rng, n_rows)
+    idx = rng.choice(n_rows, 20000, replace=False)
+    bank[idx] = synth.flip_bits(rng, q[rng.integers(0, nq, 20000)], 30)
+    view_off = np.linspace(0, n_rows, 21).astype(np.uint32)
+    got = check_against_oracle(oracle_c, q, bank, view_off, None)
+    assert got[0].sum() > 15000
+    # (b) a query too long for one LDS slice per workgroup
+    nq, n_rows = 9000, 3000
+    q = synth.random_descriptors(rng, nq)
+    bank = synth.random_descriptors(rng, n_rows)
+    idx = rng.choice(n_rows, 700, replace=False)
+    bank[idx] = synth.flip_bits(rng, q[rng.integers(0, nq, 700)], 30)
+    check_against_oracle(oracle_c, q, bank, np.array([0, 1500, 3000], np.uint32), None)
+
+
 def test_argument_errors():
     bank = np.zeros((10, 64), np.uint8)
     with pytest.raises(S.SfmlocError):
