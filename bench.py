@@ -212,6 +212,7 @@ def main():
     iso = None
     if sharded is None:
         dev_map.stats_reset()
+        dev_map.set_profile(2)   # K1 events only: every bracketed stage costs ~10 us of idle GPU on the critical path
         for i in range(min(a.steps, 32)):
             t1 = time.perf_counter()
             ctxs[0].begin(dqs[i % len(dqs)])

@@ -68,7 +68,7 @@ typedef struct sfmloc_params {
   uint64_t seed;            /* counter-based RNG seed (the reference's RNG is unseeded) */
   int refine_pose;          /* north-star extension A13; 0 = reference-equivalent output */
   int device;               /* HIP device ordinal */
-  int profile;              /* 1 = bracket each kernel with HIP events on the handle's stream */
+  int profile;              /* 1 = bracket each stage with HIP events on the handle's stream, 2 = the Hamming scan only */
   int exact_rows;           /* 1 = keep the exact (nearest, second) pair of EVERY bank row (sfmloc_putative_read_rows);
                                0 = rows the screening kernel proves rejected are not finished (same matches) */
 } sfmloc_params;
@@ -412,6 +412,10 @@ typedef struct sfmloc_kernel_stats {
 } sfmloc_kernel_stats;
 int sfmloc_stats_read(sfmloc_map *map, sfmloc_kernel_stats *out); /* synchronises */
 int sfmloc_stats_reset(sfmloc_map *map);
+/* Changes params.profile of a live map: 0 = no events, 1 = every stage bracketed, 2 = the Hamming scan only.  Each
+ * bracketed stage costs two marker packets on the stream (about 10 us of idle GPU between dependent kernels), so a
+ * latency measurement wants 0 or 2. */
+int sfmloc_set_profile(sfmloc_map *map, int level);
 
 #ifdef __cplusplus
 }

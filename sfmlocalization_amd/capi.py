@@ -110,7 +110,7 @@ SYMBOLS = [
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
-    "sfmloc_stats_read", "sfmloc_stats_reset",
+    "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile",
 ]
 
 _bound = False
@@ -197,6 +197,7 @@ def _L():
                                             C.POINTER(Pose), U32P, U32P, C.c_uint32]
         L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
         L.sfmloc_stats_reset.argtypes = [C.c_void_p]
+        L.sfmloc_set_profile.argtypes = [C.c_void_p, C.c_int]
         _bound = True
     return L
 
@@ -549,6 +550,10 @@ class Map:
 
     def stats_reset(self):
         _check(_L().sfmloc_stats_reset(self._h))
+
+    def set_profile(self, level):
+        """sfmloc_set_profile: 0 off, 1 every stage, 2 the Hamming scan only."""
+        _check(_L().sfmloc_set_profile(self._h, int(level)))
 
 
 NORM_TYPES = {"NONE": 0, "L2": 1, "L1": 2}

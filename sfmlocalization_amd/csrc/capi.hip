@@ -72,7 +72,9 @@ struct EventScope {
   int which;
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
-  EventScope(Ctx *c_, int which_) : c(c_), which(which_), on(c_->map->params.profile != 0) {
+  EventScope(Ctx *c_, int which_)
+      : c(c_), which(which_),
+        on(c_->map->params.profile == 1 || (c_->map->params.profile == 2 && which_ == SFMLOC_K_HAMMING)) {
     if (!on) return;
     if (!c->event_pool.empty()) {
       a = c->event_pool.back().first;
@@ -1310,6 +1312,13 @@ int sfmloc_stats_read(sfmloc_map *map, sfmloc_kernel_stats *out) {
     out->hamming_pairs_finished += 64ull * k1c[0];
     out->hamming_rows_flagged += k1c[1];
   }
+  return SFMLOC_OK;
+}
+
+int sfmloc_set_profile(sfmloc_map *map, int level) {
+  SFM_CHECK(map, SFMLOC_EINVAL, "sfmloc_set_profile: null map");
+  SFM_CHECK(level >= 0 && level <= 2, SFMLOC_EINVAL, "sfmloc_set_profile: level %d (0 off, 1 every stage, 2 K1 only)", level);
+  reinterpret_cast<Map *>(map)->params.profile = level;
   return SFMLOC_OK;
 }
 
