@@ -510,7 +510,7 @@ int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use
   Map *m = c->map;
   if (n_work_blocks == 0 || q->n == 0) return SFMLOC_OK;
   // (below ~12 heads' worth of query rows the exact head and the second launch eat the saving:
-  // profiles/r01_k1_screen_on_akaze_descriptors.json)
+  // profiles/r01_k1_screen_on_akaze_descriptors.jsonl)
   c->last_screened = false;
   if (split == 1 && m->params.exact_rows == 0 && q->n >= 12 * kScreenHead && !k1_override().r) {
     c->last_screened = true;
