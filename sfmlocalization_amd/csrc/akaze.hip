@@ -319,6 +319,10 @@ __global__ void k_kcontrast(const unsigned int *hmax_bits, const unsigned int *h
 }
 
 // pm_g2 with the contrast factor of this octave (kcontrast * 0.75 per octave change)
+// pm_g2 of the Scharr gradient of Lsmooth (scale 1, weights 3/10), the two derivative images never stored
+__global__ void k_flow_g2(const float *__restrict__ ls, float *__restrict__ dst, int w, int h,
+                          const float *kcontrast, int octave);
+
 __global__ void k_pm_g2(const float *__restrict__ lx, const float *__restrict__ ly, float *__restrict__ dst, size_t n,
                         const float *kcontrast, int octave) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,17 +349,56 @@ __global__ void k_nld_step(const float *__restrict__ Ld, const float *__restrict
   Ld_out[p] = v + stp;
 }
 
-__global__ void k_scale_det(float *lx, float *ly, float *lxx, float *lxy, float *lyy, float *ldet, size_t n, float sf,
-                            float sf2) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  lx[i] = lx[i] * sf;
-  ly[i] = ly[i] * sf;
-  const float a = lxx[i] * sf2, b = lxy[i] * sf2, c = lyy[i] * sf2;
-  lxx[i] = a;
-  lxy[i] = b;
-  lyy[i] = c;
-  ldet[i] = a * c - b * b;
+// Compute_Multiscale_Derivatives + Compute_Determinant_Hessian_Response, fused.  The reference runs five Scharr
+// filters per level (Lx, Ly from Lsmooth; Lxx, Lyy, Lxy from those), scales them by sigma / sigma^2 and forms the
+// determinant; here one kernel produces Lx and Ly, a second the determinant straight from them -- the second
+// derivatives never touch memory, and Lx / Ly stay unscaled in memory (their only later reader, the descriptor
+// kernel, applies the level's factor with the same multiplication the reference's in-place scaling does).
+__device__ __forceinline__ float scharr_at(const float *__restrict__ src, int w, int h, int x, int y, int xorder,
+                                           int scale, float ws, float wm) {
+  const int xm = reflect101(x - scale, w), xp = reflect101(x + scale, w);
+  const int ym = reflect101(y - scale, h), yp = reflect101(y + scale, h);
+  if (xorder) {
+    const float r0 = src[(size_t)y * w + xp] - src[(size_t)y * w + xm];
+    const float rm = src[(size_t)ym * w + xp] - src[(size_t)ym * w + xm];
+    const float rp = src[(size_t)yp * w + xp] - src[(size_t)yp * w + xm];
+    return wm * r0 + ws * (rm + rp);
+  }
+  const float r0 = src[(size_t)yp * w + x] - src[(size_t)ym * w + x];
+  const float rm = src[(size_t)yp * w + xm] - src[(size_t)ym * w + xm];
+  const float rp = src[(size_t)yp * w + xp] - src[(size_t)ym * w + xp];
+  return wm * r0 + ws * (rm + rp);
+}
+
+__global__ void k_flow_g2(const float *__restrict__ ls, float *__restrict__ dst, int w, int h,
+                          const float *kcontrast, int octave) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const float lx = scharr_at(ls, w, h, x, y, 1, 1, 3.0f, 10.0f);
+  const float ly = scharr_at(ls, w, h, x, y, 0, 1, 3.0f, 10.0f);
+  float kc = *kcontrast;
+  for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
+  const float inv_k = 1.0f / (kc * kc);
+  dst[(size_t)y * w + x] = 1.0f / (1.0f + inv_k * (lx * lx + ly * ly));
+}
+
+__global__ void k_scharr_xy(const float *__restrict__ src, float *__restrict__ lx, float *__restrict__ ly, int w, int h,
+                            int scale, float ws, float wm) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  lx[(size_t)y * w + x] = scharr_at(src, w, h, x, y, 1, scale, ws, wm);
+  ly[(size_t)y * w + x] = scharr_at(src, w, h, x, y, 0, scale, ws, wm);
+}
+
+__global__ void k_hessian_det(const float *__restrict__ lx, const float *__restrict__ ly, float *__restrict__ ldet,
+                              int w, int h, int scale, float ws, float wm, float sf2) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const float lxx = scharr_at(lx, w, h, x, y, 1, scale, ws, wm);
+  const float lyy = scharr_at(ly, w, h, x, y, 0, scale, ws, wm);
+  const float lxy = scharr_at(lx, w, h, x, y, 0, scale, ws, wm);
+  const float a = lxx * sf2, b = lxy * sf2, c = lyy * sf2;
+  ldet[(size_t)y * w + x] = a * c - b * b;
 }
 
 struct Candidate9 {
@@ -394,8 +437,9 @@ __global__ void k_extrema(const float *__restrict__ ldet, int w, int h, int leve
 }
 
 struct DevLevel {
-  const float *Lt, *Lx, *Ly;
+  const float *Lt, *Lx, *Ly;  // Lx, Ly unscaled: multiply by sf (= sigma_size) on use
   int w, h, octave;
+  float sf;
 };
 struct DevLevels {
   DevLevel l[kMaxLevels];
@@ -439,8 +483,8 @@ __global__ __launch_bounds__(64) void k_orient_describe(DevLevels LV, const floa
     const int iy = fround_d(yf + (float)(jj * s)), ix = fround_d(xf + (float)(ii * s));
     const int a = ii < 0 ? -ii : ii, b = jj < 0 ? -jj : jj;  // id[] = |.| mirrored table index
     const float g = gauss25[7 * a + b];
-    const float rx = g * at_clamped(L.Lx, L.w, L.h, iy, ix);
-    const float ry = g * at_clamped(L.Ly, L.w, L.h, iy, ix);
+    const float rx = g * (at_clamped(L.Lx, L.w, L.h, iy, ix) * L.sf);
+    const float ry = g * (at_clamped(L.Ly, L.w, L.h, iy, ix) * L.sf);
     resX[q] = rx;
     resY[q] = ry;
     Ang[q] = get_angle(rx, ry);
@@ -505,8 +549,8 @@ __global__ __launch_bounds__(64) void k_orient_describe(DevLevels LV, const floa
         const float sample_x = xf + (-(float)l * si * (float)scale + (float)kk * co * (float)scale);
         const int y1 = fround_d(sample_y), x1 = fround_d(sample_x);
         const float ri = at_clamped(L.Lt, L.w, L.h, y1, x1);
-        const float rx = at_clamped(L.Lx, L.w, L.h, y1, x1);
-        const float ry = at_clamped(L.Ly, L.w, L.h, y1, x1);
+        const float rx = at_clamped(L.Lx, L.w, L.h, y1, x1) * L.sf;
+        const float ry = at_clamped(L.Ly, L.w, L.h, y1, x1) * L.sf;
         di += ri;
         const float rry = rx * co + ry * si;
         const float rrx = -rx * si + ry * co;
@@ -547,8 +591,7 @@ struct Akaze {
   hipStream_t stream = nullptr;
   uint8_t *d_gray = nullptr;
   float *d_img = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr;
-  float *d_Lt = nullptr, *d_Lsmooth = nullptr, *d_Lx = nullptr, *d_Ly = nullptr, *d_Lxx = nullptr, *d_Lxy = nullptr,
-        *d_Lyy = nullptr, *d_Ldet = nullptr;  // per-level stacks
+  float *d_Lt = nullptr, *d_Lsmooth = nullptr, *d_Lx = nullptr, *d_Ly = nullptr, *d_Ldet = nullptr;  // per-level stacks
   unsigned int *d_hist = nullptr;             // [0] hmax bits, [1..301] histogram + npoints
   float *d_kcontrast = nullptr;
   Candidate9 *d_cand = nullptr;
@@ -613,44 +656,41 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
   AK_HIP(hipGetLastError());
   for (int i = 1; i < P.nlev; ++i) {
     const AkLevel &L = P.lev[i], &Lp = P.lev[i - 1];
-    const size_t n = (size_t)L.w * L.h;
     float *Lt = a->d_Lt + L.off;
+    // the level starts from the previous level's Lt (half-sampled at an octave change); the FED steps ping-pong
+    // between this level's Lt and a scratch image, arranged so that the last step lands in Lt without a copy
+    const float *start = a->d_Lt + Lp.off;
     if (L.octave > Lp.octave) {
-      hipLaunchKernelGGL(k_halfsample, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lt + Lp.off, Lp.w, Lp.h, Lt, L.w, L.h);
-    } else {
-      AK_HIP(hipMemcpyAsync(Lt, a->d_Lt + Lp.off, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      float *half = (L.nsteps % 2 == 0) ? Lt : a->d_t3;  // even number of steps: start (and end) in Lt
+      hipLaunchKernelGGL(k_halfsample, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lt + Lp.off, Lp.w, Lp.h, half, L.w, L.h);
+      start = half;
     }
-    rc = gauss(a, Lt, a->d_Lsmooth + L.off, a->d_t3, L.w, L.h, P.g10, 5);
-    if (!rc) rc = scharr(a, a->d_Lsmooth + L.off, a->d_t0, L.w, L.h, 1, 1, 3.0f, 10.0f);
-    if (!rc) rc = scharr(a, a->d_Lsmooth + L.off, a->d_t1, L.w, L.h, 0, 1, 3.0f, 10.0f);
+    rc = gauss(a, start, a->d_Lsmooth + L.off, a->d_t0, L.w, L.h, P.g10, 5);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pm_g2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a->d_t0, a->d_t1, a->d_t2, n,
+    hipLaunchKernelGGL(k_flow_g2, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lsmooth + L.off, a->d_t2, L.w, L.h,
                        a->d_kcontrast, L.octave);
-    float *cur = Lt, *nxt = a->d_t3;
+    const float *cur = start;
+    // destination of step st: alternate so that step nsteps-1 writes Lt; `start` is never written
     for (int st = 0; st < L.nsteps; ++st) {
-      hipLaunchKernelGGL(k_nld_step, grid2(L.w, L.h), dim3(128), 0, s, cur, a->d_t2, nxt, L.w, L.h,
-                         0.5f * L.tsteps[st]);
-      std::swap(cur, nxt);
+      float *dst = ((L.nsteps - 1 - st) % 2 == 0) ? Lt : a->d_t3;
+      if (dst == cur) dst = (dst == Lt) ? a->d_t3 : Lt;  // cannot happen by construction; guards an in-place step
+      hipLaunchKernelGGL(k_nld_step, grid2(L.w, L.h), dim3(128), 0, s, cur, a->d_t2, dst, L.w, L.h, 0.5f * L.tsteps[st]);
+      cur = dst;
     }
     AK_HIP(hipGetLastError());
-    if (cur != Lt) AK_HIP(hipMemcpyAsync(Lt, cur, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (L.nsteps == 0 && start != Lt)
+      AK_HIP(hipMemcpyAsync(Lt, start, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   for (int i = 0; i < P.nlev; ++i) {
     const AkLevel &L = P.lev[i];
-    const size_t n = (size_t)L.w * L.h;
     const int sc = L.sigma_size;
     const float wgt = 10.0f / 3.0f;
     const float norm = 1.0f / (2.0f * (float)sc * (wgt + 2.0f));
     const float ws = norm, wm = wgt * norm;
     float *Ls = a->d_Lsmooth + L.off, *Lx = a->d_Lx + L.off, *Ly = a->d_Ly + L.off;
-    rc = scharr(a, Ls, Lx, L.w, L.h, 1, sc, ws, wm);
-    if (!rc) rc = scharr(a, Ls, Ly, L.w, L.h, 0, sc, ws, wm);
-    if (!rc) rc = scharr(a, Lx, a->d_Lxx + L.off, L.w, L.h, 1, sc, ws, wm);
-    if (!rc) rc = scharr(a, Ly, a->d_Lyy + L.off, L.w, L.h, 0, sc, ws, wm);
-    if (!rc) rc = scharr(a, Lx, a->d_Lxy + L.off, L.w, L.h, 0, sc, ws, wm);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_scale_det, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Lx, Ly, a->d_Lxx + L.off,
-                       a->d_Lxy + L.off, a->d_Lyy + L.off, a->d_Ldet + L.off, n, (float)sc, (float)(sc * sc));
+    hipLaunchKernelGGL(k_scharr_xy, grid2(L.w, L.h), dim3(128), 0, s, Ls, Lx, Ly, L.w, L.h, sc, ws, wm);
+    hipLaunchKernelGGL(k_hessian_det, grid2(L.w, L.h), dim3(128), 0, s, Lx, Ly, a->d_Ldet + L.off, L.w, L.h, sc, ws, wm,
+                       (float)(sc * sc));
     AK_HIP(hipGetLastError());
   }
   return SFMLOC_OK;
@@ -691,6 +731,7 @@ int orient_describe(Akaze *a, const std::vector<float> &kin, unsigned int n, flo
     LV.l[i].w = L.w;
     LV.l[i].h = L.h;
     LV.l[i].octave = L.octave;
+    LV.l[i].sf = (float)L.sigma_size;
   }
   AK_HIP(hipMemcpyAsync(a->d_kp, kin.data(), (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, a->stream));
   hipLaunchKernelGGL(k_orient_describe, dim3(n), dim3(64), 0, a->stream, LV, a->d_kp, (int)n, a->d_gauss25, a->d_win,
@@ -715,7 +756,7 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   hipSetDevice(a->device);
   if (a->stream) hipStreamSynchronize(a->stream);
   void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
-                  a->d_Lxx, a->d_Lxy, a->d_Lyy, a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_cand, a->d_ncand,
+                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_cand, a->d_ncand,
                   a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -755,7 +796,7 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   A((void **)&a->d_t1, n0 * 4);
   A((void **)&a->d_t2, n0 * 4);
   A((void **)&a->d_t3, n0 * 4);
-  float **stacks[] = {&a->d_Lt, &a->d_Lsmooth, &a->d_Lx, &a->d_Ly, &a->d_Lxx, &a->d_Lxy, &a->d_Lyy, &a->d_Ldet};
+  float **stacks[] = {&a->d_Lt, &a->d_Lsmooth, &a->d_Lx, &a->d_Ly, &a->d_Ldet};
   for (float **sp : stacks) A((void **)sp, tot * 4);
   A((void **)&a->d_hist, 302 * 4);
   A((void **)&a->d_kcontrast, 4);
