@@ -123,7 +123,7 @@ void free_ctx(Ctx *c) {
                   c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
                   c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,
                   c->d_inlier_idx,
-                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters, c->d_flagmask, c->d_rows_scratch, c->d_rows_arrivals};
+                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters, c->d_flagmask, c->d_rows_scratch, c->d_rows_arrivals, c->d_flagged_desc};
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -172,6 +172,7 @@ int make_ctx(Map *m, Ctx **out) {
   c->rows_chunk_cap = m->n_blocks < 4096 ? (m->n_blocks ? m->n_blocks : 1) : 4096;  // 4096 chunks = 262 k flagged rows, 16 MB
   CTX_TRY(dev_alloc(acct, &c->d_rows_scratch, (size_t)c->rows_chunk_cap * 8 * 64));
   CTX_TRY(dev_alloc(acct, &c->d_rows_arrivals, (size_t)c->rows_chunk_cap));
+  CTX_TRY(dev_alloc(acct, &c->d_flagged_desc, (size_t)c->rows_chunk_cap * 4 * 64));
   CTX_HIP(hipMemset(c->d_rows_arrivals, 0, (size_t)c->rows_chunk_cap * sizeof(uint32_t)));
   CTX_TRY(dev_alloc(acct, &c->d_k1_counters, (size_t)2));
   CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));

@@ -133,7 +133,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
     const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t lds_rows, const uint16_t *__restrict__ ratio_cnt,
     unsigned long long *__restrict__ flagmask /*[work block]: rows handed to k_hamming_rows*/,
     uint2 *__restrict__ flagged /*{part index, bank row}*/, uint32_t *__restrict__ n_flagged,
-    unsigned long long *__restrict__ counters /*[0] finished wave-pairs, [1] flagged rows*/, uint32_t head) {
+    unsigned long long *__restrict__ counters /*[0] finished wave-pairs, [1] flagged rows*/, uint32_t head,
+    uint4 *__restrict__ flagged_desc /*[slot / 64][4][64]: the flagged rows' descriptors, tiled like the bank*/,
+    uint32_t flagged_desc_cap /*slots*/) {
   extern __shared__ uint4 qs[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -219,7 +221,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(n_flagged, (uint32_t)__popcll(mask));
     base = __shfl(base, 0, 64);
-    if (flag) flagged[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(pidx, blk * 64 + lane);
+    if (flag) {
+      const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      flagged[slot] = make_uint2(pidx, blk * 64 + lane);
+      // the exact pass reads the row again, SLICES times: hand it over compactly instead of as 4 x 128-byte lines
+      // of the bank per reader (the row is in registers here)
+      if (slot < flagged_desc_cap) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          flagged_desc[((uint64_t)(slot >> 6) * 4 + c) * 64 + (slot & 63u)] =
+              make_uint4(b[4 * c + 0], b[4 * c + 1], b[4 * c + 2], b[4 * c + 3]);
+      }
+    }
   }
 }
 
@@ -236,6 +249,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__rest
                                                              uint2 *__restrict__ scratch /*[chunk][SLICES][64]*/,
                                                              uint32_t *__restrict__ arrivals /*[chunk], zero*/,
                                                              uint32_t chunk_cap, uint32_t lds_rows,
+                                                             const uint4 *__restrict__ flagged_desc,
                                                              uint2 *__restrict__ part) {
   extern __shared__ uint4 qs[];
   __shared__ uint2 merge[WAVES][64];
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__rest
   const uint32_t j_lo = slice * per, j_hi = min(nq, j_lo + per);
   const uint32_t cnt = j_hi > j_lo ? j_hi - j_lo : 0;
   // this workgroup's query slice (the same for every chunk it handles); chunk_cap == 0 <=> the slice does not fit
-  if (chunk_cap)
+  if (chunk_cap && (uint64_t)(blockIdx.x / SLICES) * 64 < n)  // (only workgroups that own a chunk need it)
     for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j_lo * 4 + i];
   __syncthreads();
   for (uint32_t chunk = blockIdx.x / SLICES; chunk * 64 < n && chunk < chunk_cap; chunk += gridDim.x / SLICES) {
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__rest
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (valid) v = bank[((uint64_t)(ent.y >> 6) * 4 + c) * 64 + (ent.y & 63u)];
+      if (valid) v = flagged_desc[((uint64_t)chunk * 4 + c) * 64 + lane];  // written by k_hamming_screen
       b[4 * c + 0] = v.x;
       b[4 * c + 1] = v.y;
       b[4 * c + 2] = v.z;
@@ -482,7 +496,7 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
     hipLaunchKernelGGL((k_hamming_screen<WAVES, NW>), dim3((n_work_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64), \
                        lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks,       \
                        q->d_desc, q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged,    \
-                       c->d_k1_counters, head);                                                                   \
+                       c->d_k1_counters, head, c->d_flagged_desc, c->rows_chunk_cap * 64);                        \
     break;
   switch (nw) {
     K1_SCREEN(8) K1_SCREEN(9) K1_SCREEN(10) K1_SCREEN(11) K1_SCREEN(12) K1_SCREEN(13)
@@ -501,7 +515,7 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   const uint32_t chunk_cap = per <= 1024 ? c->rows_chunk_cap : 0;  // ... and then every chunk takes the walking path
   hipLaunchKernelGGL((k_hamming_rows<RW, RS>), dim3(128 * RS), dim3(RW * 64), (size_t)rows_lds * 64, c->stream,
                      m->d_bank, q->d_desc, q->n, c->d_flagged, c->d_n_flagged, c->d_rows_scratch, c->d_rows_arrivals,
-                     chunk_cap, rows_lds, c->d_part);
+                     chunk_cap, rows_lds, c->d_flagged_desc, c->d_part);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

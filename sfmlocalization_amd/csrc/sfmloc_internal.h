@@ -159,6 +159,7 @@ struct Ctx {
   bool last_screened = false;
   uint2 *d_rows_scratch = nullptr;      // [rows_chunk_cap][8 slices][64] partial top-2 of the flagged-row pass
   uint32_t *d_rows_arrivals = nullptr;  // [rows_chunk_cap] arrival counters of that pass (self-resetting)
+  uint4 *d_flagged_desc = nullptr;      // [rows_chunk_cap][4][64] descriptors of the flagged rows (tiled like the bank)
   uint32_t rows_chunk_cap = 0;          // chunks of 64 flagged rows the sliced pass has scratch for (rest: fallback)
   unsigned long long *d_k1_counters = nullptr;  // [2] finished wave-pairs, flagged rows (since stats reset)
   int k1_finish_ops = 0;
