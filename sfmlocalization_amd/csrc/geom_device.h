@@ -392,6 +392,29 @@ GDN int seven_point(const double *x1, const double *x2, double *F) {
 // bit-identical; what changes is that nothing is dynamically indexed (no scratch) and the 7x9 eliminations run
 // 63-wide.  (ax, ay, bx, by): the coordinates of point l / 9 (any value in lane 63).  All lanes return the
 // number of solutions; lane l < 9 * n returns F[l] (solution l / 9, entry l % 9) in *f_out.
+// wave64 maximum of a 32-bit unsigned value by DPP (quad permutes, row shifts, row broadcasts: ~8 cycles a step
+// instead of a ~100-cycle ds_bpermute); every lane returns the result
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define SFM_DPP_MAX(ctrl, rmask)                                                                          \
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false))
+  SFM_DPP_MAX(0xB1, 0xF);   // quad_perm:[1,0,3,2]
+  SFM_DPP_MAX(0x4E, 0xF);   // quad_perm:[2,3,0,1]
+  SFM_DPP_MAX(0x114, 0xF);  // row_shr:4
+  SFM_DPP_MAX(0x118, 0xF);  // row_shr:8   -> lanes 12..15 of a row hold the row maximum
+  SFM_DPP_MAX(0x142, 0xA);  // row_bcast:15 into rows 1 and 3
+  SFM_DPP_MAX(0x143, 0xC);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave maximum
+#undef SFM_DPP_MAX
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// a double held by lane `src` (wave-uniform index), in every lane: two v_readlane instead of two ds_bpermute
+__device__ __forceinline__ double wave_read_f64(double v, int src) {
+  const uint64_t u = d2u(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src);
+  return u2d(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int wave_seven_point(double ax, double ay, double bx, double by, double *f_out) {
   const int lane = (int)(threadIdx.x & 63u);
   const int row = lane / 9, col = lane - 9 * row;  // lane 63: row 7 (inactive)
@@ -402,20 +425,19 @@ __device__ __forceinline__ int wave_seven_point(double ax, double ay, double bx,
   double a = (col < 6) ? ((c3 == 2) ? pa : pa * pb) : pb;  // bx*ax bx*ay bx by*ax by*ay by ax ay 1
   uint64_t perm = 0x876543210ull;  // nibble j = perm[j]
   for (int k = 0; k < 7; ++k) {
-    // complete pivoting: largest |A[i][j]|, i >= k, j >= k; first in row-major order on ties
+    // complete pivoting: largest |A[i][j]|, i >= k, j >= k; first in row-major order on ties.  |x| >= 0 orders like
+    // its bit pattern, so the arg-max is two 32-bit wave maxima (high word, then low word among the lanes that hold
+    // the high maximum) and the lowest lane of the ballot of the winners; not eligible / NaN = key 0, and a maximum
+    // of 0 is the reference's "best <= 0 -> no solution".
     const double aa = dabs(a);
-    double bv = (live && row >= k && col >= k && aa == aa) ? aa : -1.0;
-    int bi = lane;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ov = __shfl_xor(bv, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      if (ov > bv || (ov == bv && oi < bi)) {
-        bv = ov;
-        bi = oi;
-      }
-    }
-    if (!(bv > 0.0)) return 0;
+    // (dabs keeps the sign of -0.0, which compares equal to +0.0 as a double: clear it in the bit key)
+    const uint64_t key = (live && row >= k && col >= k && aa == aa) ? (d2u(aa) & 0x7FFFFFFFFFFFFFFFull) : 0ull;
+    const uint32_t khi = (uint32_t)(key >> 32), klo = (uint32_t)key;
+    const uint32_t mhi = wave_max_u32(khi);
+    const uint32_t mlo = wave_max_u32(khi == mhi ? klo : 0u);
+    if ((mhi | mlo) == 0u) return 0;
+    const unsigned long long win = __ballot(khi == mhi && klo == mlo);
+    const int bi = __builtin_ctzll(win);
     const int pi = bi / 9, pj = bi - 9 * pi;
     const int sr = (row == k) ? pi : (row == pi) ? k : row;
     const int sc = (col == k) ? pj : (col == pj) ? k : col;
@@ -425,7 +447,7 @@ __device__ __forceinline__ int wave_seven_point(double ax, double ay, double bx,
       perm &= ~((0xFull << (4 * k)) | (0xFull << (4 * pj)));
       perm |= (nj << (4 * k)) | (nk << (4 * pj));
     }
-    const double piv = __shfl(a, k * 9 + k, 64);
+    const double piv = wave_read_f64(a, k * 9 + k);
     if (live && row == k && col >= k) a = a / piv;
     const double rk = __shfl(a, live ? k * 9 + col : lane, 64);   // normalised pivot row at my column
     const double fct = __shfl(a, live ? row * 9 + k : lane, 64);  // my row's entry in the pivot column
@@ -439,8 +461,8 @@ __device__ __forceinline__ int wave_seven_point(double ax, double ay, double bx,
 #pragma unroll
     for (int q = 0; q < 9; ++q)
       if ((int)((perm >> (4 * q)) & 0xFull) == c) pos = q;
-    const double v1 = __shfl(a, pos < 7 ? pos * 9 + 7 : 0, 64);
-    const double v2 = __shfl(a, pos < 7 ? pos * 9 + 8 : 0, 64);
+    const double v1 = wave_read_f64(a, pos < 7 ? pos * 9 + 7 : 0);
+    const double v2 = wave_read_f64(a, pos < 7 ? pos * 9 + 8 : 0);
     f1[c] = (pos < 7) ? -v1 : (pos == 7 ? 1.0 : 0.0);
     f2[c] = (pos < 7) ? -v2 : (pos == 8 ? 1.0 : 0.0);
   }
