@@ -1304,19 +1304,54 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
     s_k[b] = live ? A.hyp_k[b] : 0;
   }
   __syncthreads();
-  for (int b = 0; b < batch; ++b) {
-    const long it = iter0 + b;
-    if (it >= n_iter || it >= n_iter_evaluated) break;
-    const double nfa = s_nfa[b];
+  // The sequential rule only acts at two kinds of hypotheses: one whose NFA improves on the running minimum, and the
+  // one that ends the uniform phase.  Everything in between is skipped by a block-wide "first index below the
+  // minimum" search instead of a dependent 512-step loop.
+  __shared__ int s_first[kThreads / 64];
+  auto first_below = [&](int from, int limit, double thr) -> int {
+    int mine = 0x7FFFFFFF;
+    for (int b = from + tid; b < limit; b += kThreads)
+      if (s_nfa[b] < thr) {
+        mine = b;
+        break;
+      }
+    for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off, 64));
+    __syncthreads();  // s_first of the previous search is no longer read
+    if ((tid & 63) == 0) s_first[tid >> 6] = mine;
+    __syncthreads();
+    int r = s_first[0];
+    for (int w = 1; w < kThreads / 64; ++w) r = min(r, s_first[w]);
+    return r;
+  };
+  int b = 0;
+  for (;;) {
+    // hypotheses b .. limit-1 were evaluated and are within the budget
+    long lim = n_iter - iter0;
+    if (lim > n_iter_evaluated - iter0) lim = n_iter_evaluated - iter0;
+    if (lim > batch) lim = batch;
+    const int limit = (int)lim;
+    if (b >= limit) break;
+    int e = first_below(b, limit, min_nfa);
+    if (n_reserve) {  // "it + 1 == n_iter" with budget in reserve
+      const long eb = n_iter - 1 - iter0;
+      if (eb >= b && eb < limit && eb < e) e = (int)eb;
+    }
+    if (e >= limit) {
+      processed = limit;
+      break;
+    }
+    const long it = iter0 + e;
+    const double nfa = s_nfa[e];
     bool better = false;
     if (nfa < min_nfa) {
       better = true;
       min_nfa = nfa;
-      n_in = s_k[b];
-      errmax = s_err[b];
-      best_b = b;
+      n_in = s_k[e];
+      errmax = s_err[e];
+      best_b = e;
     }
-    processed = b + 1;
+    processed = e + 1;
+    b = e + 1;
     if ((better && min_nfa < 0.0) || (it + 1 == n_iter && n_reserve)) {
       if (n_in == 0) {
         n_iter++;
