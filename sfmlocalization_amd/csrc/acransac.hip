@@ -810,21 +810,43 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
   if (ng == 0) return;
   const uint32_t off = view_off[v];
   const uint32_t np = put_count[v];
-  for (uint32_t p = lane; p < ng; p += 64) {
-    const uint32_t pp = geo_idx[off + p];
-    const uint32_t i = match_i[off + pp];
-    const uint32_t j = match_key[off + pp] & 0xFFFFu;
-    const int32_t lm = row_landmark[off + i];
-    if (lm < 0) continue;
-    uint32_t dist = 0;
-    for (int32_t k = (int32_t)np - 1; k >= 0; --k) {  // last putative match with the same query feature
-      const uint32_t kk = match_key[off + k];
-      if ((kk & 0xFFFFu) == j) {
-        dist = kk >> 16;
-        break;
+  // the view's putative keys in LDS (one segment per wave): the "last match with the same query feature" search
+  // below is a dependent backward scan, far too slow against L2
+  __shared__ uint32_t s_keys[4][kFMaxM];
+  uint32_t *keys = s_keys[threadIdx.x >> 6];
+  const bool staged = np <= (uint32_t)kFMaxM;
+  if (staged) {
+    for (uint32_t k = lane; k < np; k += 64) keys[k] = match_key[off + k];
+    wave_lds_sync();
+  }
+  for (uint32_t p0 = 0; p0 < ng; p0 += 64) {
+    const uint32_t p = p0 + lane;
+    bool has = false;
+    uint32_t j = 0, dist = 0;
+    int32_t lm = -1;
+    if (p < ng) {
+      const uint32_t pp = geo_idx[off + p];
+      const uint32_t i = match_i[off + pp];
+      j = match_key[off + pp] & 0xFFFFu;
+      lm = row_landmark[off + i];
+      has = lm >= 0;
+    }
+    if (has) {
+      for (int32_t k = (int32_t)np - 1; k >= 0; --k) {  // last putative match with the same query feature
+        const uint32_t kk = staged ? keys[k] : match_key[off + k];
+        if ((kk & 0xFFFFu) == j) {
+          dist = kk >> 16;
+          break;
+        }
       }
     }
-    const uint32_t slot = atomicAdd(n_cand, 1u);
+    // one atomic per wave step instead of one per candidate (a few thousand on one counter otherwise)
+    const unsigned long long mask = __ballot(has);
+    uint32_t slot0 = 0;
+    if (lane == 0 && mask) slot0 = atomicAdd(n_cand, (uint32_t)__popcll(mask));
+    slot0 = __shfl(slot0, 0, 64);
+    if (!has) continue;
+    const uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     if (slot >= cap) {
       atomicOr(status, 2);
       continue;
