@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Create / use / destroy every handle type repeatedly and watch the device's free memory (hipMemGetInfo through
+torch): a leak shows as a steady drop."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sfmlocalization_amd as S  # noqa: E402
+from sfmlocalization_amd import synth  # noqa: E402
+
+m = synth.make_map(3, n_views=30, desc_per_view=400, views_per_place=10, landmarks_per_place=300, obs_per_view=150)
+q = synth.make_query(m, 5, n_feat=800, n_copies=250)
+img = synth.texture_image(3, 240, 320)
+bgr = np.stack([img, img, img], 2)
+free = []
+for it in range(60):
+    with S.Map(m.view_id, m.view_off, m.desc, view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark,
+               landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic,
+               bow=np.random.rand(30, 16).astype(np.float32)) as dm:
+        dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
+        ctxs = [dm.context() for _ in range(3)]
+        for c in ctxs:
+            c.begin(dq)
+        for c in ctxs:
+            c.end()
+        dm.localize(dq)
+        dm.bow_select(np.random.rand(16).astype(np.float32), 5)
+        qv = dm.query_from_view(2)
+        dm.match_one_to_one(qv, np.array([1], np.uint32))
+        dm.track(3)
+        qv.close()
+        for c in ctxs:
+            c.close()
+        dq.close()
+    ak = S.Akaze(320, 240)
+    ak.detect_and_compute(img)
+    ak.close()
+    S.dense_gray(bgr, 64)
+    if it % 10 == 9:
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+        print(it + 1, "iterations, free MiB:", free[-1] // (1 << 20), flush=True)
+drop = (free[0] - free[-1]) / (1 << 20)
+print("drop between iteration 10 and 60: %.1f MiB" % drop)
+assert drop < 64, "device memory keeps shrinking"
+print("OK")
