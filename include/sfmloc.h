@@ -132,6 +132,8 @@ int sfmloc_scan(const char *sfm_dir, const char *match_dir, sfmloc_scan_info *in
 /* view table of a map: ids [n_views], row offsets [n_views+1], camera centres [n_views*3] (only for maps opened
  * from sfm_data.json; used for the dead-reckoning restriction getLocalViews, SfMDataUtils.cpp:210-227) */
 int sfmloc_map_views(const sfmloc_map *map, uint32_t *view_id, uint32_t *view_off, double *center);
+/* image width, height of every view [n_views*2] (sfm_data views; the default size of a query without an image) */
+int sfmloc_map_view_sizes(const sfmloc_map *map, uint32_t *wh);
 
 typedef struct sfmloc_map_info {
   uint64_t n_rows;

@@ -98,7 +98,7 @@ class KernelStats(C.Structure):
 SYMBOLS = [
     "sfmloc_last_error", "sfmloc_abi_version", "sfmloc_device_count", "sfmloc_default_params",
     "sfmloc_map_create", "sfmloc_map_destroy", "sfmloc_map_get_info", "sfmloc_open", "sfmloc_scan",
-    "sfmloc_map_views",
+    "sfmloc_map_views", "sfmloc_map_view_sizes",
     "sfmloc_query_create", "sfmloc_query_destroy",
     "sfmloc_match_putative", "sfmloc_putative_read", "sfmloc_putative_read_rows", "sfmloc_sync",
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",

@@ -1,0 +1,553 @@
+// OpenMVGLocalization_AKAZE, the reference's localisation tool (OpenMVGLocalization_AKAZE/src/localization.cpp:64-590),
+// as a C++ host program over the C ABI of libsfmloc_hip.so -- the reference's own host language for this path.
+//
+//   OpenMVGLocalization_AKAZE <queryImage|dir> <sfmDataDir> <matchDir> <outputFolder>
+//        [-f=0.6] [-r=200] [-k=0] [-x= -y= -z= -d=-1] [-a=BOWfile.yml] [-p=PCAfile.yml] [-i=1] [-g=4.0] [--featdir=DIR]
+//
+// Same arguments, console messages and output files (<outputFolder>/<base>.json with the reference's keys and
+// Eigen IOFormat(6) matrices; the failure form has the first three keys only, localization.cpp:84-153).
+// Differences, all forced by what this image has: image decoding is built in for PNG (8-bit, via zlib) and binary
+// PGM/PPM only -- no libjpeg headers here -- and otherwise the query's features are taken from
+// <featdir>/<base>.desc/.feat (the files extractAKAZESingleImg writes, AKAZEOpenCV.cpp:80-111); the BoW shortlist
+// (-k) uses <featdir>/<base>.bow (the dense-feature chain lives in sfmlocalization_amd/engine.py::DenseBow); -w and
+// -gm are accepted and ignored.  The Python mirror (sfmlocalization_amd/engine.py) covers the same contract.
+#include <dirent.h>
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sfmloc.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// cv::CommandLineParser syntax: positionals, -k=v / --key=v, bare flags
+// ---------------------------------------------------------------------------------------------------------
+bool is_number(const std::string &s) {
+  char *end = nullptr;
+  std::strtod(s.c_str(), &end);
+  return !s.empty() && end && *end == '\0';
+}
+
+struct Args {
+  std::vector<std::string> pos;
+  std::map<std::string, std::string> opt;
+  std::string get(std::initializer_list<const char *> names, const char *def) const {
+    std::string v = def;
+    for (const char *n : names) {
+      auto it = opt.find(n);
+      if (it != opt.end()) v = it->second;
+    }
+    return v;
+  }
+};
+
+Args parse_args(int argc, char **argv) {
+  Args a;
+  for (int i = 1; i < argc; ++i) {
+    std::string s = argv[i];
+    if (s.size() > 1 && s[0] == '-' && !is_number(s)) {
+      size_t p = s.find_first_not_of('-');
+      std::string kv = s.substr(p == std::string::npos ? s.size() : p);
+      size_t eq = kv.find('=');
+      if (eq == std::string::npos)
+        a.opt[kv] = "true";
+      else
+        a.opt[kv.substr(0, eq)] = kv.substr(eq + 1);
+    } else {
+      a.pos.push_back(s);
+    }
+  }
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// paths and files
+// ---------------------------------------------------------------------------------------------------------
+std::string join(const std::string &a, const std::string &b) {
+  if (a.empty()) return b;
+  return a.back() == '/' ? a + b : a + "/" + b;
+}
+std::string basename_of(const std::string &p) {
+  size_t s = p.find_last_of('/');
+  return s == std::string::npos ? p : p.substr(s + 1);
+}
+std::string dirname_of(const std::string &p) {
+  size_t s = p.find_last_of('/');
+  return s == std::string::npos ? std::string("") : p.substr(0, s);
+}
+std::string stem_of(const std::string &p) {
+  std::string b = basename_of(p);
+  size_t d = b.find_last_of('.');
+  return d == std::string::npos ? b : b.substr(0, d);
+}
+std::string ext_of(const std::string &p) {
+  std::string b = basename_of(p);
+  size_t d = b.find_last_of('.');
+  return d == std::string::npos ? std::string("") : b.substr(d + 1);
+}
+bool is_file(const std::string &p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+bool is_dir(const std::string &p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+bool image_ext(const std::string &e) {  // localization.cpp:204-206
+  return e == "jpg" || e == "JPG" || e == "jpeg" || e == "JPEG" || e == "png" || e == "PNG";
+}
+bool read_all(const std::string &p, std::vector<uint8_t> *out) {
+  FILE *f = fopen(p.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out->resize(n > 0 ? (size_t)n : 0);
+  const bool ok = n >= 0 && fread(out->data(), 1, out->size(), f) == out->size();
+  fclose(f);
+  return ok;
+}
+
+// .desc: [u64 N][N x 64 B]  (FileUtils.cpp:77-103)
+bool read_desc(const std::string &p, std::vector<uint8_t> *rows) {
+  std::vector<uint8_t> raw;
+  if (!read_all(p, &raw) || raw.size() < 8) return false;
+  uint64_t n;
+  memcpy(&n, raw.data(), 8);
+  if (raw.size() != 8 + n * 64) return false;
+  rows->assign(raw.begin() + 8, raw.end());
+  return true;
+}
+// .feat: "x y size angle" per line (AKAZEOpenCV.cpp:80-81)
+bool read_feat(const std::string &p, std::vector<float> *xy) {
+  FILE *f = fopen(p.c_str(), "r");
+  if (!f) return false;
+  xy->clear();
+  double x, y, s, a;
+  while (fscanf(f, "%lf %lf %lf %lf", &x, &y, &s, &a) == 4) {
+    xy->push_back((float)x);
+    xy->push_back((float)y);
+  }
+  fclose(f);
+  return true;
+}
+// .bow: [i32 rows][i32 cols][i32 type][data], CV_64F or CV_32F (FileUtils.cpp:43-75)
+bool read_bow(const std::string &p, std::vector<float> *v) {
+  std::vector<uint8_t> raw;
+  if (!read_all(p, &raw) || raw.size() < 12) return false;
+  int32_t r, c, t;
+  memcpy(&r, raw.data(), 4);
+  memcpy(&c, raw.data() + 4, 4);
+  memcpy(&t, raw.data() + 8, 4);
+  const size_t n = (size_t)r * c;
+  v->resize(n);
+  if (t == 6 && raw.size() == 12 + 8 * n) {
+    for (size_t i = 0; i < n; ++i) {
+      double d;
+      memcpy(&d, raw.data() + 12 + 8 * i, 8);
+      (*v)[i] = (float)d;
+    }
+    return true;
+  }
+  if (t == 5 && raw.size() == 12 + 4 * n) {
+    memcpy(v->data(), raw.data() + 12, 4 * n);
+    return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// image decoding: 8-bit PNG (gray / RGB / RGBA / gray+alpha / palette, non-interlaced) and binary PGM / PPM -> gray
+// imread(IMREAD_GRAYSCALE) semantics for colour: OpenCV's (R*4899 + G*9617 + B*1868 + 8192) >> 14
+// ---------------------------------------------------------------------------------------------------------
+uint8_t to_gray(int r, int g, int b) { return (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14); }
+
+bool decode_pnm(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int *w, int *h) {
+  if (raw.size() < 2 || raw[0] != 'P' || (raw[1] != '5' && raw[1] != '6')) return false;
+  size_t p = 2;
+  int vals[3], nv = 0;
+  while (nv < 3 && p < raw.size()) {
+    while (p < raw.size() && isspace(raw[p])) ++p;
+    if (p < raw.size() && raw[p] == '#') {
+      while (p < raw.size() && raw[p] != '\n') ++p;
+      continue;
+    }
+    int v = 0;
+    bool any = false;
+    while (p < raw.size() && isdigit(raw[p])) {
+      v = v * 10 + (raw[p++] - '0');
+      any = true;
+    }
+    if (!any) return false;
+    vals[nv++] = v;
+  }
+  if (nv < 3 || vals[2] != 255 || p >= raw.size()) return false;
+  ++p;  // single whitespace after maxval
+  *w = vals[0];
+  *h = vals[1];
+  const size_t n = (size_t)*w * *h, ch = raw[1] == '6' ? 3 : 1;
+  if (raw.size() < p + n * ch) return false;
+  gray->resize(n);
+  for (size_t i = 0; i < n; ++i)
+    (*gray)[i] = ch == 1 ? raw[p + i] : to_gray(raw[p + 3 * i], raw[p + 3 * i + 1], raw[p + 3 * i + 2]);
+  return true;
+}
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+bool decode_png(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int *w, int *h) {
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (raw.size() < 33 || memcmp(raw.data(), sig, 8) != 0) return false;
+  size_t p = 8;
+  int bit_depth = 0, color = 0, interlace = 0;
+  std::vector<uint8_t> idat, plte;
+  bool have_hdr = false;
+  while (p + 12 <= raw.size()) {
+    const uint32_t len = be32(&raw[p]);
+    const char *type = reinterpret_cast<const char *>(&raw[p + 4]);
+    if (p + 12 + len > raw.size()) return false;
+    const uint8_t *data = &raw[p + 8];
+    if (!memcmp(type, "IHDR", 4) && len >= 13) {
+      *w = (int)be32(data);
+      *h = (int)be32(data + 4);
+      bit_depth = data[8];
+      color = data[9];
+      interlace = data[12];
+      have_hdr = true;
+    } else if (!memcmp(type, "PLTE", 4)) {
+      plte.assign(data, data + len);
+    } else if (!memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), data, data + len);
+    } else if (!memcmp(type, "IEND", 4)) {
+      break;
+    }
+    p += 12 + len;
+  }
+  if (!have_hdr || bit_depth != 8 || interlace != 0 || *w <= 0 || *h <= 0) return false;
+  const int ch = color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : color == 6 ? 4 : 0;
+  if (!ch) return false;
+  const size_t stride = (size_t)*w * ch;
+  std::vector<uint8_t> buf((stride + 1) * (size_t)*h);
+  uLongf out_len = buf.size();
+  if (uncompress(buf.data(), &out_len, idat.data(), idat.size()) != Z_OK || out_len != buf.size()) return false;
+  std::vector<uint8_t> img(stride * (size_t)*h);
+  for (int y = 0; y < *h; ++y) {  // undo the scanline filters
+    const uint8_t ft = buf[(stride + 1) * y];
+    const uint8_t *src = &buf[(stride + 1) * y + 1];
+    uint8_t *dst = &img[stride * y];
+    const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
+    for (size_t x = 0; x < stride; ++x) {
+      const int a = x >= (size_t)ch ? dst[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+      int pred = 0;
+      switch (ft) {
+        case 0: pred = 0; break;
+        case 1: pred = a; break;
+        case 2: pred = b; break;
+        case 3: pred = (a + b) >> 1; break;
+        case 4: {
+          const int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+        } break;
+        default: return false;
+      }
+      dst[x] = (uint8_t)(src[x] + pred);
+    }
+  }
+  const size_t n = (size_t)*w * *h;
+  gray->resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t *px = &img[i * ch];
+    if (color == 0 || color == 4) {
+      (*gray)[i] = px[0];
+    } else if (color == 3) {
+      if ((size_t)px[0] * 3 + 2 >= plte.size()) return false;
+      (*gray)[i] = to_gray(plte[px[0] * 3], plte[px[0] * 3 + 1], plte[px[0] * 3 + 2]);
+    } else {
+      (*gray)[i] = to_gray(px[0], px[1], px[2]);
+    }
+  }
+  return true;
+}
+
+bool load_gray(const std::string &path, std::vector<uint8_t> *gray, int *w, int *h) {
+  std::vector<uint8_t> raw;
+  if (!read_all(path, &raw)) return false;
+  return decode_png(raw, gray, w, h) || decode_pnm(raw, gray, w, h);
+}
+
+// image_describer.txt (cv::FileStorage YAML, AKAZEOption.cpp:44-55; defaults AKAZEOption.h:31-34)
+struct AkazeOption {
+  int desc_ch = 3, nOct = 4, nOctLay = 4;
+  float thres = 0.001f;
+};
+AkazeOption read_image_describer(const std::string &p) {
+  AkazeOption o;
+  FILE *f = fopen(p.c_str(), "r");
+  if (!f) return o;
+  char line[512];
+  while (fgets(line, sizeof(line), f)) {
+    char key[128];
+    double v;
+    if (sscanf(line, " %127[^:]: %lf", key, &v) == 2) {
+      if (!strcmp(key, "desc_ch")) o.desc_ch = (int)v;
+      if (!strcmp(key, "thres")) o.thres = (float)v;
+      if (!strcmp(key, "nOct")) o.nOct = (int)v;
+      if (!strcmp(key, "nOctLay")) o.nOctLay = (int)v;
+    }
+  }
+  fclose(f);
+  return o;
+}
+
+// Eigen IOFormat(6, 0, ",", ",\n", rowPrefix, rowSuffix, "[", "]"): 6 significant digits, columns aligned
+std::string eigen_format(const double *m, int rows, int cols, const char *row_prefix, const char *row_suffix) {
+  std::vector<std::string> cells((size_t)rows * cols);
+  size_t width = 0;
+  for (int i = 0; i < rows * cols; ++i) {
+    char b[64];
+    snprintf(b, sizeof(b), "%.6g", m[i]);
+    cells[i] = b;
+    width = std::max(width, cells[i].size());
+  }
+  std::string s = "[";
+  for (int r = 0; r < rows; ++r) {
+    if (r) s += ",\n";
+    s += row_prefix;
+    for (int c = 0; c < cols; ++c) {
+      if (c) s += ",";
+      const std::string &cell = cells[(size_t)r * cols + c];
+      s += std::string(width - cell.size(), ' ') + cell;
+    }
+    s += row_suffix;
+  }
+  return s + "]";
+}
+
+// saveResultJson (localization.cpp:84-153)
+bool write_result_json(const std::string &out_dir, const std::string &query, const std::string &sfm_json,
+                       const std::string &match_dir, const sfmloc_pose *pose, const uint32_t *pq, const uint32_t *pl) {
+  const std::string path = join(out_dir, stem_of(query) + ".json");
+  FILE *f = fopen(path.c_str(), "w");
+  if (!f) return false;
+  fprintf(f, "{\n\t\"filename\": \"%s\",\n\t\"sfm_data\": \"%s\",\n", query.c_str(), sfm_json.c_str());
+  if (!pose) {
+    fprintf(f, "\t\"matches_dir\": \"%s\"\n}\n", match_dir.c_str());
+  } else {
+    fprintf(f, "\t\"matches_dir\": \"%s\",\n", match_dir.c_str());
+    fprintf(f, "\t\"K\": %s,\n", eigen_format(pose->K, 3, 3, "[", "]").c_str());
+    fprintf(f, "\t\"R\": %s,\n", eigen_format(pose->R, 3, 3, "[", "]").c_str());
+    fprintf(f, "\t\"t\": %s,\n", eigen_format(pose->center, 3, 1, "", "").c_str());
+    fprintf(f, "\t\"pair\": [");
+    for (int i = 0; i < pose->n_inliers; ++i) fprintf(f, "%s[%u,%u]", i ? "," : "", pq[i], pl[i]);
+    fprintf(f, "]\n}\n");
+  }
+  fclose(f);
+  return true;
+}
+
+float round6(float v) {  // what the reference reads back from the .feat it wrote (6 significant digits)
+  char b[64];
+  snprintf(b, sizeof(b), "%.6g", (double)v);
+  return strtof(b, nullptr);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  const Args a = parse_args(argc, argv);
+  if (a.pos.size() < 4 || a.opt.count("h") || a.opt.count("help")) {
+    printf("usage: OpenMVGLocalization_AKAZE <queryImage|dir> <sfmDataDir> <matchDir> <outputFolder> [-f=0.6] [-r=200] "
+           "[-k=0] [-x= -y= -z= -d=-1] [-i=1] [-g=4.0] [--featdir=DIR]\n");
+    return 1;
+  }
+  const std::string query = a.pos[0], sfm_dir = a.pos[1], match_dir = a.pos[2], out_dir = a.pos[3];
+  const double f_ratio = atof(a.get({"f", "fDistRatio"}, "0.6").c_str());
+  const int ransac_round = atoi(a.get({"r", "ransacRound"}, "200").c_str());
+  const int knn_bow = atoi(a.get({"k", "knnbow"}, "0").c_str());
+  const double cx = atof(a.get({"x", "cenLocX"}, "0.0").c_str()), cy = atof(a.get({"y", "cenLocY"}, "0.0").c_str()),
+               cz = atof(a.get({"z", "cenLocZ"}, "0.0").c_str()), radius = atof(a.get({"d", "cenRadius"}, "-1.0").c_str());
+  const std::string bow_model = a.get({"a", "bowModelFile"}, "");
+  int every = atoi(a.get({"i", "locEvryNFrame"}, "1").c_str());
+  const double geom = atof(a.get({"g", "geomLimit"}, "4.0").c_str());
+  const std::string featdir_opt = a.get({"featdir"}, "");
+  const int device = atoi(a.get({"device"}, "0").c_str());
+  if (every <= 0) every = 1;
+
+  printf("Start localizing input image.\n");
+  std::vector<std::string> images;
+  if (is_file(query)) {
+    if (!image_ext(ext_of(query))) {
+      printf("Input image is not JPEG or PNG file\n");
+      return 1;
+    }
+    images.push_back(query);
+  } else if (is_dir(query)) {
+    if (DIR *d = opendir(query.c_str())) {
+      while (dirent *e = readdir(d))
+        if (image_ext(ext_of(e->d_name))) images.push_back(join(query, e->d_name));
+      closedir(d);
+    }
+    std::sort(images.begin(), images.end());
+    if (images.empty()) {
+      printf("JPEG or PNG file is not found in input image directory\n");
+      return 1;
+    }
+  } else {
+    images.push_back(query);  // with precomputed features the image itself may be absent
+  }
+
+  const std::string sfm_json = join(sfm_dir, "sfm_data.json");
+  sfmloc_params prm;
+  sfmloc_default_params(&prm);
+  prm.dist_ratio = (float)f_ratio;
+  prm.ransac_round = ransac_round;
+  prm.geom_precision = geom;
+  prm.bow_knn = knn_bow;
+  prm.device = device;
+  sfmloc_map *map = nullptr;
+  if (sfmloc_open(sfm_dir.c_str(), match_dir.c_str(), &prm, &map)) {
+    fprintf(stderr, "%s\n", sfmloc_last_error());
+    return 1;
+  }
+  sfmloc_map_info info;
+  sfmloc_map_get_info(map, &info);
+  std::vector<uint32_t> view_wh(2 * (size_t)info.n_views), view_id(info.n_views), view_off(info.n_views + 1);
+  std::vector<double> centers(3 * (size_t)info.n_views);
+  sfmloc_map_view_sizes(map, view_wh.data());
+  sfmloc_map_views(map, view_id.data(), view_off.data(), centers.data());
+  const AkazeOption ak_opt = read_image_describer(join(match_dir, "image_describer.txt"));
+  mkdir(out_dir.c_str(), 0777);
+
+  std::map<std::pair<int, int>, sfmloc_akaze *> extractors;
+  int n_img = 0, match_next = 0, rc_all = 0;
+  for (const std::string &img : images) {
+    ++n_img;
+    if (n_img % every == 0) {  // localization.cpp:289-298
+    } else if (match_next <= 0) {
+      continue;
+    } else {
+      --match_next;
+    }
+    const std::string base = stem_of(img);
+    const std::string fdir = featdir_opt.empty() ? dirname_of(img) : featdir_opt;
+    int w = info.n_views ? (int)view_wh[0] : 0, h = info.n_views ? (int)view_wh[1] : 0;
+    std::vector<uint8_t> desc;
+    std::vector<float> xy;
+    std::vector<uint8_t> gray;
+    int gw = 0, gh = 0;
+    const bool have_img = load_gray(img, &gray, &gw, &gh);
+    if (have_img) {
+      w = gw;
+      h = gh;
+    }
+    if (!(read_desc(join(fdir, base + ".desc"), &desc) && read_feat(join(fdir, base + ".feat"), &xy) &&
+          xy.size() == desc.size() / 64 * 2)) {
+      if (!have_img) {
+        fprintf(stderr, "cannot decode %s (PNG and PGM/PPM only in this build) nor read precomputed features for it\n",
+                img.c_str());
+        write_result_json(out_dir, img, sfm_json, match_dir, nullptr, nullptr, nullptr);
+        continue;
+      }
+      if (ak_opt.desc_ch != 3) {
+        fprintf(stderr, "only the 3-channel M-LDB descriptor the reference uses is implemented\n");
+        rc_all = 1;
+        break;
+      }
+      printf("Extract features from query image\n");  // localization.cpp:313
+      sfmloc_akaze *&ak = extractors[{w, h}];
+      if (!ak && sfmloc_akaze_create(device, w, h, ak_opt.nOct, ak_opt.nOctLay, ak_opt.thres, &ak)) {
+        fprintf(stderr, "%s\n", sfmloc_last_error());
+        rc_all = 1;
+        break;
+      }
+      const uint32_t cap = 65536;
+      std::vector<float> kp((size_t)cap * 6);
+      desc.assign((size_t)cap * 64, 0);
+      uint32_t n = 0;
+      if (sfmloc_akaze_detect_and_compute(ak, gray.data(), kp.data(), desc.data(), cap, &n)) {
+        fprintf(stderr, "%s\n", sfmloc_last_error());
+        rc_all = 1;
+        break;
+      }
+      desc.resize((size_t)n * 64);
+      xy.resize((size_t)n * 2);
+      for (uint32_t i = 0; i < n; ++i) {
+        xy[2 * i] = round6(kp[6 * i]);
+        xy[2 * i + 1] = round6(kp[6 * i + 1]);
+      }
+    }
+    const uint32_t nq = (uint32_t)(desc.size() / 64);
+
+    // view pre-selection (localization.cpp:332-361): getLocalViews -- squared distance against the UN-squared radius,
+    // as the reference does (SfMDataUtils.cpp:210-227) --, then the BoW shortlist when more views than knn remain
+    std::vector<uint32_t> sel;
+    bool use_sel = false;
+    if (radius > 0) {
+      use_sel = true;
+      for (uint32_t v = 0; v < info.n_views; ++v) {
+        const double dx = centers[3 * v] - cx, dy = centers[3 * v + 1] - cy, dz = centers[3 * v + 2] - cz;
+        if (dx * dx + dy * dy + dz * dz <= radius) sel.push_back(v);
+      }
+    }
+    sfmloc_pose pose;
+    memset(&pose, 0, sizeof(pose));
+    std::vector<uint32_t> pq(4096), pl(4096);
+    bool attempted = false;
+    if (!(use_sel && sel.empty())) {
+      std::vector<float> bow;
+      if (knn_bow > 0 && !bow_model.empty() && read_bow(join(fdir, base + ".bow"), &bow)) {
+        const uint32_t n_cand = use_sel ? (uint32_t)sel.size() : info.n_views;
+        if (n_cand > (uint32_t)knn_bow) {  // localization.cpp:346
+          std::vector<uint32_t> out(knn_bow);
+          uint32_t n_out = 0;
+          if (sfmloc_bow_select(map, bow.data(), use_sel ? sel.data() : nullptr, n_cand, (uint32_t)knn_bow, out.data(),
+                                &n_out)) {
+            fprintf(stderr, "%s\n", sfmloc_last_error());
+            rc_all = 1;
+            break;
+          }
+          sel.assign(out.begin(), out.begin() + n_out);
+          use_sel = true;
+        }
+      }
+      sfmloc_query *q = nullptr;
+      if (sfmloc_query_create(map, desc.data(), xy.data(), nq, (uint32_t)w, (uint32_t)h, &q)) {
+        fprintf(stderr, "%s\n", sfmloc_last_error());
+        rc_all = 1;
+        break;
+      }
+      const int rc = sfmloc_localize(map, q, use_sel ? sel.data() : nullptr, use_sel ? (uint32_t)sel.size() : 0, &pose,
+                                     pq.data(), pl.data(), 4096);
+      sfmloc_query_destroy(q);
+      if (rc) {
+        fprintf(stderr, "%s\n", sfmloc_last_error());
+        rc_all = 1;
+        break;
+      }
+      attempted = true;
+    }
+    if (!pose.ok) {
+      printf("%s\n", attempted ? "Fail to estimate camera matrix" : "Not enough putative matches");
+      write_result_json(out_dir, img, sfm_json, match_dir, nullptr, nullptr, nullptr);
+      continue;
+    }
+    printf("#inliers = %d\n", pose.n_inliers);
+    write_result_json(out_dir, img, sfm_json, match_dir, &pose, pq.data(), pl.data());
+    match_next = every - 1;
+    printf("complete\n");
+  }
+  for (auto &kv : extractors)
+    if (kv.second) sfmloc_akaze_destroy(kv.second);
+  sfmloc_map_destroy(map);
+  return rc_all;
+}

@@ -537,4 +537,13 @@ int sfmloc_map_views(const sfmloc_map *map, uint32_t *view_id, uint32_t *view_of
   return SFMLOC_OK;
 }
 
+int sfmloc_map_view_sizes(const sfmloc_map *map, uint32_t *wh) {
+  SFM_CHECK(map && wh, SFMLOC_EINVAL, "sfmloc_map_view_sizes: null argument");
+  const Map *m = reinterpret_cast<const Map *>(map);
+  SFM_CHECK(m->h_view_wh.size() == 2 * (size_t)m->n_views, SFMLOC_EINVAL,
+            "sfmloc_map_view_sizes: the map was created without view sizes");
+  memcpy(wh, m->h_view_wh.data(), m->h_view_wh.size() * sizeof(uint32_t));
+  return SFMLOC_OK;
+}
+
 }  // extern "C"

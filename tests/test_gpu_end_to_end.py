@@ -63,3 +63,14 @@ def test_image_to_pose(tmp_path):
         assert len(d["pair"]) >= 11
     assert n_ok >= 2
     ak.close()
+    # the same PNG queries through the C++ host program: its own PNG decoder + GPU AKAZE + localisation
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sfmlocalization_amd", "bin",
+                       "OpenMVGLocalization_AKAZE")
+    out2 = tmp_path / "out_cc"
+    r = subprocess.run([cli, str(qdir), str(tmp_path / "sfm"), str(tmp_path / "matches"), str(out2), "-r=25"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("Extract features from query image") == 3
+    for name in truth:
+        assert (out2 / (name + ".json")).read_bytes() == (out / (name + ".json")).read_bytes(), name

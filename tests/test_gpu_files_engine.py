@@ -114,6 +114,46 @@ def test_command_line_writes_the_reference_json(toy):
     assert engine.main([str(root / "queries"), str(root), str(root / "matches"), str(out)]) == 1
 
 
+CLI_BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sfmlocalization_amd", "bin",
+                       "OpenMVGLocalization_AKAZE")
+
+
+def _run_cli(args):
+    import subprocess
+    env = dict(os.environ)
+    r = subprocess.run([CLI_BIN] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=300)
+    return r.returncode, r.stdout, r.stderr
+
+
+def test_cpp_command_line_equals_python_mirror(toy):
+    """The C++ host program over the C ABI (sfmlocalization_amd/csrc/localize_cli.cpp, the reference's own host
+    language for this tool) writes byte-identical result files to the Python mirror's, prints the reference's
+    messages and exits like it."""
+    m, root, names, queries = toy
+    assert os.path.exists(CLI_BIN), "build it: make -C sfmlocalization_amd/csrc"
+    out_py, out_cc = root / "cmp_py", root / "cmp_cc"
+    args = [root / "queries", root / "sfm", root / "matches"]
+    assert engine.main([str(a) for a in args] + [str(out_py), "-f=0.6", "-r=25"]) == 0
+    rc, so, se = _run_cli(args + [out_cc, "-f=0.6", "-r=25"])
+    assert rc == 0, se
+    assert so.startswith("Start localizing input image.") and so.count("complete") == 3
+    assert "Fail to estimate camera matrix" in so or "Not enough putative matches" in so
+    for base, _ in queries:
+        assert (out_cc / (base + ".json")).read_bytes() == (out_py / (base + ".json")).read_bytes(), base
+    # dead-reckoning restriction and the error exit
+    rc, so, se = _run_cli([root / "queries" / "q000.jpg", root / "sfm", root / "matches", root / "cmp_cc2", "-r=25",
+                           "-x=1000", "-y=1000", "-z=1000", "-d=4"])
+    assert rc == 0 and "t" not in json.load(open(root / "cmp_cc2" / "q000.json")) and "Not enough putative matches" in so
+    rc, so, se = _run_cli([root / "queries", root, root / "matches", root / "cmp_cc3"])
+    assert rc == 1 and "cannot be read" in se
+    rc, so, se = _run_cli([root / "queries" / "q000.jpg", root / "sfm", root / "matches", root / "cmp_cc4", "-r=25",
+                           "-x=%g" % m.view_C[0, 0], "-y=%g" % m.view_C[0, 1], "-z=%g" % m.view_C[0, 2], "-d=40"])
+    out_py4 = root / "cmp_py4"
+    engine.main([str(root / "queries" / "q000.jpg"), str(root / "sfm"), str(root / "matches"), str(out_py4), "-r=25",
+                 "-x=%g" % m.view_C[0, 0], "-y=%g" % m.view_C[0, 1], "-z=%g" % m.view_C[0, 2], "-d=40"])
+    assert (root / "cmp_cc4" / "q000.json").read_bytes() == (out_py4 / "q000.json").read_bytes()
+
+
 def test_engine_mirror_return_convention(toy):
     m, root, names, queries = toy
     A = np.array([[0, -2.0, 0, 10], [2.0, 0, 0, -5], [0, 0, 2.0, 1]])      # similarity: scale 2, rot 90 deg about z
