@@ -1,0 +1,242 @@
+// sfmloc::LocalizeEngine -- the reference's in-process localisation class (VisionLocalizeServer/src/LocalizeEngine.h:42-83,
+// LocalizeEngine.cc:84-661) as a header-only C++ wrapper over the C ABI of sfmloc.h.
+//
+// Same constructor arguments and the same localize() contract: returns [t(3), R(9 row-major)] in the frame of the A
+// matrix (LocalizeEngine.cc:593-625), an EMPTY vector on failure (:453,481,579); points2D / points3D are the 2D-3D
+// correspondences of the resection (n x 2, n x 3, the latter A-transformed, :520-553), pointsInlier the indices of
+// the inliers among them, times the six stage durations of :651-657 (this implementation measures the whole call:
+// times[5] carries it, the others are 0 -- the per-kernel split is sfmloc_stats_read).
+// What cannot be mirrored without OpenCV: cv::Mat arguments become plain buffers (8-bit gray image or precomputed
+// descriptors + keypoints); iBeacon pre-selection (beaconKnnNum) is out of scope and must be 0; guidedMatching must
+// be false (no caller of the reference sets it).  Not re-entrant, like the original: one engine per concurrent user
+// (localizeImage.cc:71-74) -- or use sfmloc_context directly to share one map.
+#ifndef SFMLOC_ENGINE_HPP
+#define SFMLOC_ENGINE_HPP
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "sfmloc.h"
+
+namespace sfmloc {
+
+class LocalizeEngine {
+ public:
+  LocalizeEngine(const std::string &sfmDataDir, const std::string &matchDir, const std::string &AmatFile,
+                 double secondTestRatio, int ransacRound, double ransacPrecision, bool guidedMatching,
+                 int beaconKnnNum = 0, int bowKnnNum = 0, int device = 0)
+      : mMatchDir(matchDir), mBowKnnNum(bowKnnNum), mDevice(device) {
+    if (guidedMatching) throw std::invalid_argument("guided matching is not implemented");
+    if (beaconKnnNum) throw std::invalid_argument("iBeacon view pre-selection is out of scope");
+    sfmloc_params p;
+    sfmloc_default_params(&p);
+    p.dist_ratio = (float)secondTestRatio;
+    p.ransac_round = ransacRound;
+    p.geom_precision = ransacPrecision;
+    p.bow_knn = bowKnnNum;
+    p.device = device;
+    if (sfmloc_open(sfmDataDir.c_str(), matchDir.c_str(), &p, &mMap)) throw std::runtime_error(sfmloc_last_error());
+    sfmloc_map_info info;
+    sfmloc_map_get_info(mMap, &info);
+    mViews = info.n_views;
+    mCenters.resize(3 * (size_t)mViews);
+    if (sfmloc_map_views(mMap, nullptr, nullptr, mCenters.data())) mCenters.clear();
+    if (!AmatFile.empty()) readAmat(AmatFile);  // cv::FileStorage "A": 3x4 (LocalizeEngine.cc:116-118)
+    readImageDescriber(matchDir + "/image_describer.txt");
+  }
+  LocalizeEngine(const LocalizeEngine &) = delete;
+  LocalizeEngine &operator=(const LocalizeEngine &) = delete;
+  ~LocalizeEngine() {
+    for (auto &kv : mAkaze)
+      if (kv.second) sfmloc_akaze_destroy(kv.second);
+    if (mMap) sfmloc_map_destroy(mMap);
+  }
+
+  // LocalizeEngine::localize on an 8-bit gray image (extraction on the GPU with the map's image_describer.txt options)
+  std::vector<double> localize(const uint8_t *gray, int width, int height, bool bReturnKeypoints,
+                               std::vector<double> &points2D, std::vector<double> &points3D,
+                               std::vector<int> &pointsInlier, bool bReturnTime, std::vector<double> &times,
+                               const std::vector<double> &center = std::vector<double>(), double radius = -1.0,
+                               const std::vector<float> *bow = nullptr) {
+    sfmloc_akaze *&ak = mAkaze[std::make_pair(width, height)];
+    if (!ak && sfmloc_akaze_create(mDevice, width, height, mNOct, mNOctLay, mThres, &ak))
+      throw std::runtime_error(sfmloc_last_error());
+    const uint32_t cap = 65536;
+    std::vector<float> kp((size_t)cap * 6);
+    std::vector<uint8_t> desc((size_t)cap * 64);
+    uint32_t n = 0;
+    if (sfmloc_akaze_detect_and_compute(ak, gray, kp.data(), desc.data(), cap, &n))
+      throw std::runtime_error(sfmloc_last_error());
+    std::vector<float> xy((size_t)n * 2);
+    for (uint32_t i = 0; i < n; ++i) {  // the .feat round trip of the reference (AKAZEOpenCV.cpp:80-111)
+      xy[2 * i] = round6(kp[6 * i]);
+      xy[2 * i + 1] = round6(kp[6 * i + 1]);
+    }
+    return localizeFeatures(desc.data(), xy.data(), n, width, height, bReturnKeypoints, points2D, points3D,
+                            pointsInlier, bReturnTime, times, center, radius, bow);
+  }
+
+  // the same from the output of extractAKAZESingleImg: desc [n x 64] (.desc rows), keypoints [n x 2]
+  std::vector<double> localizeFeatures(const uint8_t *desc, const float *kptXY, uint32_t n, int width, int height,
+                                       bool bReturnKeypoints, std::vector<double> &points2D,
+                                       std::vector<double> &points3D, std::vector<int> &pointsInlier,
+                                       bool bReturnTime, std::vector<double> &times,
+                                       const std::vector<double> &center = std::vector<double>(), double radius = -1.0,
+                                       const std::vector<float> *bow = nullptr) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<double> result;
+    points2D.clear();
+    points3D.clear();
+    pointsInlier.clear();
+    std::vector<uint32_t> sel;
+    bool useSel = false;
+    if (center.size() == 3 && radius > 0 && !mCenters.empty()) {  // getLocalViews (LocalizeEngine.cc:200-; squared vs un-squared)
+      useSel = true;
+      for (uint32_t v = 0; v < mViews; ++v) {
+        double c[3] = {mCenters[3 * v], mCenters[3 * v + 1], mCenters[3 * v + 2]};
+        if (mHaveA) applyA(c);
+        const double dx = c[0] - center[0], dy = c[1] - center[1], dz = c[2] - center[2];
+        if (dx * dx + dy * dy + dz * dz <= radius) sel.push_back(v);
+      }
+      if (sel.empty()) return result;
+    }
+    if (bow && mBowKnnNum > 0) {
+      const uint32_t nCand = useSel ? (uint32_t)sel.size() : mViews;
+      if (nCand > (uint32_t)mBowKnnNum) {  // LocalizeEngine.cc:342
+        std::vector<uint32_t> out(mBowKnnNum);
+        uint32_t nOut = 0;
+        if (sfmloc_bow_select(mMap, bow->data(), useSel ? sel.data() : nullptr, nCand, (uint32_t)mBowKnnNum, out.data(),
+                              &nOut))
+          throw std::runtime_error(sfmloc_last_error());
+        sel.assign(out.begin(), out.begin() + nOut);
+        useSel = true;
+      }
+    }
+    sfmloc_query *q = nullptr;
+    if (sfmloc_query_create(mMap, desc, kptXY, n, (uint32_t)width, (uint32_t)height, &q))
+      throw std::runtime_error(sfmloc_last_error());
+    sfmloc_pose pose;
+    std::memset(&pose, 0, sizeof(pose));
+    std::vector<uint32_t> pq(4096), pl(4096);
+    const int rc = sfmloc_localize(mMap, q, useSel ? sel.data() : nullptr, useSel ? (uint32_t)sel.size() : 0, &pose,
+                                   pq.data(), pl.data(), 4096);
+    if (rc) {
+      sfmloc_query_destroy(q);
+      throw std::runtime_error(sfmloc_last_error());
+    }
+    if (bReturnKeypoints && pose.n_matches_2d3d > 0) {
+      const uint32_t cap = (uint32_t)pose.n_matches_2d3d;
+      std::vector<uint32_t> qf(cap), lm(cap), inl(4096);
+      points2D.assign((size_t)cap * 2, 0.0);
+      points3D.assign((size_t)cap * 3, 0.0);
+      uint32_t n2 = 0;
+      sfmloc_pose tmp;
+      if (sfmloc_match_set_read(mMap, &n2, qf.data(), lm.data(), points2D.data(), points3D.data(), cap) ||
+          sfmloc_pose_read(mMap, &tmp, nullptr, nullptr, inl.data(), 4096)) {
+        sfmloc_query_destroy(q);
+        throw std::runtime_error(sfmloc_last_error());
+      }
+      if (mHaveA)
+        for (uint32_t i = 0; i < n2; ++i) applyA(&points3D[3 * (size_t)i]);
+      for (int i = 0; i < pose.n_inliers; ++i) pointsInlier.push_back((int)inl[i]);
+    }
+    sfmloc_query_destroy(q);
+    if (bReturnTime) {
+      times.assign(6, 0.0);
+      times[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (!pose.ok) return result;
+    double c[3] = {pose.center[0], pose.center[1], pose.center[2]};
+    double R[9];
+    std::memcpy(R, pose.R, sizeof(R));
+    if (mHaveA) {  // localising in the A-transformed map (LocalizeEngine.cc:121-144) = transforming the result
+      applyA(c);
+      const double det = mA[0] * (mA[5] * mA[10] - mA[6] * mA[9]) - mA[1] * (mA[4] * mA[10] - mA[6] * mA[8]) +
+                         mA[2] * (mA[4] * mA[9] - mA[5] * mA[8]);
+      const double s = std::cbrt(det);
+      double Rn[9];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+          Rn[3 * i + j] = (R[3 * i] * mA[4 * j] + R[3 * i + 1] * mA[4 * j + 1] + R[3 * i + 2] * mA[4 * j + 2]) / s;
+      std::memcpy(R, Rn, sizeof(R));
+    }
+    result.assign(c, c + 3);
+    result.insert(result.end(), R, R + 9);
+    return result;
+  }
+
+  sfmloc_map *map() const { return mMap; }
+
+ private:
+  static float round6(float v) {
+    char b[64];
+    std::snprintf(b, sizeof(b), "%.6g", (double)v);
+    return std::strtof(b, nullptr);
+  }
+  void applyA(double *p) const {
+    const double x = p[0], y = p[1], z = p[2];
+    for (int i = 0; i < 3; ++i) p[i] = mA[4 * i] * x + mA[4 * i + 1] * y + mA[4 * i + 2] * z + mA[4 * i + 3];
+  }
+  void readAmat(const std::string &path) {
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) throw std::runtime_error("Cannot find A mat file");
+    std::string txt;
+    char buf[4096];
+    size_t k;
+    while ((k = std::fread(buf, 1, sizeof(buf), f)) > 0) txt.append(buf, k);
+    std::fclose(f);
+    const size_t a = txt.find("A:"), d = txt.find("data:", a == std::string::npos ? 0 : a);
+    const size_t lb = txt.find('[', d == std::string::npos ? 0 : d), rb = txt.find(']', lb == std::string::npos ? 0 : lb);
+    if (a == std::string::npos || d == std::string::npos || lb == std::string::npos || rb == std::string::npos)
+      throw std::runtime_error("A mat file: no 3x4 matrix \"A\"");
+    std::string body = txt.substr(lb + 1, rb - lb - 1);
+    for (char &ch : body)
+      if (ch == ',' || ch == '\n') ch = ' ';
+    const char *s = body.c_str();
+    char *e = nullptr;
+    int n = 0;
+    for (double v = std::strtod(s, &e); s != e && n < 12; v = std::strtod(s, &e)) {
+      mA[n++] = v;
+      s = e;
+    }
+    if (n != 12) throw std::runtime_error("A mat file: \"A\" must hold 12 values");
+    mHaveA = true;
+  }
+  void readImageDescriber(const std::string &path) {  // AKAZEOption.cpp:44-55; defaults AKAZEOption.h:31-34
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[512];
+    while (std::fgets(line, sizeof(line), f)) {
+      char key[128];
+      double v;
+      if (std::sscanf(line, " %127[^:]: %lf", key, &v) == 2) {
+        if (!std::strcmp(key, "thres")) mThres = (float)v;
+        if (!std::strcmp(key, "nOct")) mNOct = (int)v;
+        if (!std::strcmp(key, "nOctLay")) mNOctLay = (int)v;
+      }
+    }
+    std::fclose(f);
+  }
+
+  std::string mMatchDir;
+  sfmloc_map *mMap = nullptr;
+  uint32_t mViews = 0;
+  std::vector<double> mCenters;
+  double mA[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  bool mHaveA = false;
+  int mBowKnnNum = 0, mDevice = 0;
+  float mThres = 0.001f;
+  int mNOct = 4, mNOctLay = 4;
+  std::map<std::pair<int, int>, sfmloc_akaze *> mAkaze;
+};
+
+}  // namespace sfmloc
+#endif  // SFMLOC_ENGINE_HPP

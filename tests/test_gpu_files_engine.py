@@ -180,6 +180,27 @@ def test_engine_mirror_return_convention(toy):
     none, _ = e0.localize(fileio.read_desc(root / "queries" / (base3 + ".desc")),
                           fileio.read_feat(root / "queries" / (base3 + ".feat"))[:, :2], 640, 480)
     assert none == []                                                        # LocalizeEngine.cc:453,481,579
+    # the header-only C++ class (include/sfmloc_engine.hpp) driven by tests/cpp/engine_smoke.cpp: same numbers
+    import subprocess
+    smoke = os.path.join(os.path.dirname(CLI_BIN), "engine_smoke")
+    qd, qf = str(root / "queries" / (base + ".desc")), str(root / "queries" / (base + ".feat"))
+
+    def run_cpp(amat, extra=()):
+        r = subprocess.run([smoke, str(root / "sfm"), str(root / "matches"), amat, qd, qf, "640", "480"] + list(extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().split("\n")
+        vals = [] if lines[0] == "FAIL" else [float(x) for x in lines[0].split()]
+        return vals, int(lines[1]), [int(x) for x in lines[2].split()], int(lines[3])
+
+    v0, n23, inl, ntimes = run_cpp("-")
+    assert v0 == r0 and ntimes == 6 and n23 == ex0["pose"].n_matches_2d3d and len(inl) == ex0["pose"].n_inliers
+    v1, _, _, _ = run_cpp(str(root / "Amat.yml"))
+    np.testing.assert_allclose(v1, r1, rtol=0, atol=1e-12)
+    vfar, _, _, _ = run_cpp("-", ["1000", "1000", "1000", "1"])
+    assert vfar == []
+    vnear, _, _, _ = run_cpp("-", ["%r" % q.C_true[0], "%r" % q.C_true[1], "%r" % q.C_true[2], "1600"])
+    assert vnear == near
     e0.close()
     e1.close()
 
