@@ -536,8 +536,23 @@ int main(int argc, char **argv) {
       }
       attempted = true;
     }
+    if (!attempted) {  // no view near the given position: nothing was matched
+      printf("Not enough putative matches\n");
+      write_result_json(out_dir, img, sfm_json, match_dir, nullptr, nullptr, nullptr);
+      continue;
+    }
+    printf("number of putative matches : %d\n", pose.n_putative_views);  // localization.cpp:416
+    if (pose.n_putative_views == 0) {
+      printf("Not enough putative matches\n");  // :420
+      write_result_json(out_dir, img, sfm_json, match_dir, nullptr, nullptr, nullptr);
+      continue;
+    }
+    printf("number of geometric matches : %d\n", pose.n_geometric_views);  // :458
+    printf("mapFeatTo3DFeat size = %d\n", pose.n_matches_2d3d);             // :476
+    printf("cpt = %d\n", pose.n_matches_2d3d);                              // :502
     if (!pose.ok) {
-      printf("%s\n", attempted ? "Fail to estimate camera matrix" : "Not enough putative matches");
+      printf("Fail to estimate camera matrix\n");  // :512
+      printf("#inliers = %d\n", pose.n_inliers);
       write_result_json(out_dir, img, sfm_json, match_dir, nullptr, nullptr, nullptr);
       continue;
     }

@@ -308,11 +308,24 @@ def main(argv=None):
                         dense = DenseBow(o["bowModelFile"], o["pcaModelFile"] or None, device=o["device"])
                     bow = dense.compute(bgr)
         res, ex = eng.localize(desc, feat[:, :2], w, h, center=center, radius=o["cenRadius"], bow=bow)
-        if not res:
-            print("Fail to estimate camera matrix" if ex else "Not enough putative matches")
+        pose = ex.get("pose")
+        if pose is None:                                # no view near the given position: nothing was matched
+            print("Not enough putative matches")
             fileio.write_result_json(out_dir, img, sfm_json, match_dir)
             continue
-        pose = ex["pose"]
+        print(f"number of putative matches : {pose.n_putative_views}")      # localization.cpp:416
+        if pose.n_putative_views == 0:
+            print("Not enough putative matches")                             # :420
+            fileio.write_result_json(out_dir, img, sfm_json, match_dir)
+            continue
+        print(f"number of geometric matches : {pose.n_geometric_views}")     # :458
+        print(f"mapFeatTo3DFeat size = {pose.n_matches_2d3d}")               # :476
+        print(f"cpt = {pose.n_matches_2d3d}")                                # :502
+        if not res:
+            print("Fail to estimate camera matrix")                          # :512
+            print(f"#inliers = {pose.n_inliers}")
+            fileio.write_result_json(out_dir, img, sfm_json, match_dir)
+            continue
         print(f"#inliers = {pose.n_inliers}")
         fileio.write_result_json(out_dir, img, sfm_json, match_dir, K=np.array(pose.K), R=np.array(pose.R),
                                  center=np.array(pose.center), pairs=ex["pairs"])

@@ -125,7 +125,7 @@ def _run_cli(args):
     return r.returncode, r.stdout, r.stderr
 
 
-def test_cpp_command_line_equals_python_mirror(toy):
+def test_cpp_command_line_equals_python_mirror(toy, capsys):
     """The C++ host program over the C ABI (sfmlocalization_amd/csrc/localize_cli.cpp, the reference's own host
     language for this tool) writes byte-identical result files to the Python mirror's, prints the reference's
     messages and exits like it."""
@@ -133,9 +133,13 @@ def test_cpp_command_line_equals_python_mirror(toy):
     assert os.path.exists(CLI_BIN), "build it: make -C sfmlocalization_amd/csrc"
     out_py, out_cc = root / "cmp_py", root / "cmp_cc"
     args = [root / "queries", root / "sfm", root / "matches"]
+    capsys.readouterr()
     assert engine.main([str(a) for a in args] + [str(out_py), "-f=0.6", "-r=25"]) == 0
+    py_out = capsys.readouterr().out
     rc, so, se = _run_cli(args + [out_cc, "-f=0.6", "-r=25"])
     assert rc == 0, se
+    assert so == py_out                                 # the same console messages, line for line
+    assert "number of putative matches : " in so and "number of geometric matches : " in so and "cpt = " in so
     assert so.startswith("Start localizing input image.") and so.count("complete") == 3
     assert "Fail to estimate camera matrix" in so or "Not enough putative matches" in so
     for base, _ in queries:
