@@ -9,8 +9,8 @@
 // Differences, all forced by what this image has: image decoding is built in for PNG (8-bit, via zlib) and binary
 // PGM/PPM only -- no libjpeg headers here -- and otherwise the query's features are taken from
 // <featdir>/<base>.desc/.feat (the files extractAKAZESingleImg writes, AKAZEOpenCV.cpp:80-111); the BoW shortlist
-// (-k) uses <featdir>/<base>.bow (the dense-feature chain lives in sfmlocalization_amd/engine.py::DenseBow); -w and
-// -gm are accepted and ignored.  The Python mirror (sfmlocalization_amd/engine.py) covers the same contract.
+// (-k) uses <featdir>/<base>.bow if present, else the dense-feature chain on the decoded colour image; -w and -gm are
+// accepted and ignored.  The Python mirror (sfmlocalization_amd/engine.py) covers the same contract.
 #include <dirent.h>
 #include <sys/stat.h>
 #include <zlib.h>
@@ -172,7 +172,7 @@ bool read_bow(const std::string &p, std::vector<float> *v) {
 // ---------------------------------------------------------------------------------------------------------
 uint8_t to_gray(int r, int g, int b) { return (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14); }
 
-bool decode_pnm(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int *w, int *h) {
+bool decode_pnm(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int *w, int *h, std::vector<uint8_t> *bgr) {
   if (raw.size() < 2 || raw[0] != 'P' || (raw[1] != '5' && raw[1] != '6')) return false;
   size_t p = 2;
   int vals[3], nv = 0;
@@ -198,14 +198,20 @@ bool decode_pnm(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int
   const size_t n = (size_t)*w * *h, ch = raw[1] == '6' ? 3 : 1;
   if (raw.size() < p + n * ch) return false;
   gray->resize(n);
-  for (size_t i = 0; i < n; ++i)
-    (*gray)[i] = ch == 1 ? raw[p + i] : to_gray(raw[p + 3 * i], raw[p + 3 * i + 1], raw[p + 3 * i + 2]);
+  bgr->resize(3 * n);
+  for (size_t i = 0; i < n; ++i) {
+    const int r = raw[p + ch * i], g = ch == 1 ? r : raw[p + 3 * i + 1], b = ch == 1 ? r : raw[p + 3 * i + 2];
+    (*gray)[i] = ch == 1 ? (uint8_t)r : to_gray(r, g, b);
+    (*bgr)[3 * i] = (uint8_t)b;
+    (*bgr)[3 * i + 1] = (uint8_t)g;
+    (*bgr)[3 * i + 2] = (uint8_t)r;
+  }
   return true;
 }
 
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
-bool decode_png(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int *w, int *h) {
+bool decode_png(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int *w, int *h, std::vector<uint8_t> *bgr) {
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (raw.size() < 33 || memcmp(raw.data(), sig, 8) != 0) return false;
   size_t p = 8;
@@ -265,24 +271,32 @@ bool decode_png(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int
   }
   const size_t n = (size_t)*w * *h;
   gray->resize(n);
+  bgr->resize(3 * n);
   for (size_t i = 0; i < n; ++i) {
     const uint8_t *px = &img[i * ch];
+    int r, g, b;
     if (color == 0 || color == 4) {
+      r = g = b = px[0];
       (*gray)[i] = px[0];
     } else if (color == 3) {
       if ((size_t)px[0] * 3 + 2 >= plte.size()) return false;
-      (*gray)[i] = to_gray(plte[px[0] * 3], plte[px[0] * 3 + 1], plte[px[0] * 3 + 2]);
+      r = plte[px[0] * 3], g = plte[px[0] * 3 + 1], b = plte[px[0] * 3 + 2];
+      (*gray)[i] = to_gray(r, g, b);
     } else {
-      (*gray)[i] = to_gray(px[0], px[1], px[2]);
+      r = px[0], g = px[1], b = px[2];
+      (*gray)[i] = to_gray(r, g, b);
     }
+    (*bgr)[3 * i] = (uint8_t)b;  // imread(IMREAD_COLOR) order
+    (*bgr)[3 * i + 1] = (uint8_t)g;
+    (*bgr)[3 * i + 2] = (uint8_t)r;
   }
   return true;
 }
 
-bool load_gray(const std::string &path, std::vector<uint8_t> *gray, int *w, int *h) {
+bool load_gray(const std::string &path, std::vector<uint8_t> *gray, int *w, int *h, std::vector<uint8_t> *bgr) {
   std::vector<uint8_t> raw;
   if (!read_all(path, &raw)) return false;
-  return decode_png(raw, gray, w, h) || decode_pnm(raw, gray, w, h);
+  return decode_png(raw, gray, w, h, bgr) || decode_pnm(raw, gray, w, h, bgr);
 }
 
 // image_describer.txt (cv::FileStorage YAML, AKAZEOption.cpp:44-55; defaults AKAZEOption.h:31-34)
@@ -308,6 +322,139 @@ AkazeOption read_image_describer(const std::string &p) {
   fclose(f);
   return o;
 }
+
+// cv::FileStorage YAML as OpenCV writes BOWfile.yml / PCAfile.yml (TrainBoW): scalars, strings, !!opencv-matrix
+struct CvYaml {
+  std::map<std::string, double> num;
+  std::map<std::string, std::string> str;
+  struct Mat {
+    int rows = 0, cols = 0;
+    std::vector<float> data;
+  };
+  std::map<std::string, Mat> mat;
+};
+bool read_cv_yaml(const std::string &path, CvYaml *y) {
+  std::vector<uint8_t> raw;
+  if (!read_all(path, &raw)) return false;
+  std::vector<std::string> lines;  // (a matrix may sit on one very long line)
+  for (size_t a = 0; a < raw.size();) {
+    size_t b = a;
+    while (b < raw.size() && raw[b] != '\n') ++b;
+    std::string l(raw.begin() + a, raw.begin() + b);
+    while (!l.empty() && l.back() == '\r') l.pop_back();
+    lines.push_back(l);
+    a = b + 1;
+  }
+  auto trim = [](std::string v) {
+    const size_t a = v.find_first_not_of(" \t"), b = v.find_last_not_of(" \t");
+    return a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
+  };
+  for (size_t i = 0; i < lines.size();) {
+    const std::string ln = lines[i++];
+    if (ln.empty() || ln[0] == '%' || ln[0] == ' ' || ln[0] == '\t' || ln.compare(0, 3, "---") == 0) continue;
+    const size_t c = ln.find(':');
+    if (c == std::string::npos) continue;
+    const std::string key = trim(ln.substr(0, c)), rest = trim(ln.substr(c + 1));
+    if (rest.compare(0, 15, "!!opencv-matrix") == 0) {
+      CvYaml::Mat m;
+      std::string body;
+      while (i < lines.size() && !lines[i].empty() && (lines[i][0] == ' ' || lines[i][0] == '\t')) {
+        const std::string s = trim(lines[i++]);
+        if (s.compare(0, 5, "rows:") == 0) m.rows = atoi(s.c_str() + 5);
+        else if (s.compare(0, 5, "cols:") == 0) m.cols = atoi(s.c_str() + 5);
+        else if (s.compare(0, 3, "dt:") == 0) {}
+        else if (s.compare(0, 5, "data:") == 0) body = s.substr(5);
+        else body += " " + s;
+      }
+      for (char &ch : body)
+        if (ch == '[' || ch == ']' || ch == ',') ch = ' ';
+      const char *p = body.c_str();
+      char *e = nullptr;
+      for (double v = strtod(p, &e); p != e; v = strtod(p, &e)) {
+        m.data.push_back((float)v);
+        p = e;
+      }
+      if ((size_t)m.rows * m.cols != m.data.size()) return false;
+      y->mat[key] = m;
+    } else if (!rest.empty() && rest[0] == '"') {
+      y->str[key] = rest.substr(1, rest.size() >= 2 ? rest.size() - 2 : 0);
+    } else {
+      y->num[key] = atof(rest.c_str());
+      y->str[key] = rest;
+    }
+  }
+  return true;
+}
+
+// The query-side BoW vector (DenseLocalFeatureWrapper -> PcaWrapper -> BoFSpatialPyramids, localization.cpp:346-361):
+// colour image -> 300x300 gray (sfmloc_dense_gray) -> AKAZE descriptors at the dense grid (sfmloc_akaze_compute,
+// cv::AKAZE::create() defaults) as floats -> PCA + BoF (sfmloc_bof_compute)
+struct DenseBow {
+  sfmloc_bof *bof = nullptr;
+  sfmloc_akaze *ak = nullptr;
+  int size = 300, device = 0;
+  std::vector<float> grid;  // x, y, size, class_id
+  bool init(const std::string &bow_file, const std::string &pca_file, int dev) {
+    device = dev;
+    CvYaml b, p;
+    if (!read_cv_yaml(bow_file, &b) || !b.mat.count("Centers")) return false;
+    sfmloc_bof_desc d;
+    memset(&d, 0, sizeof(d));
+    const CvYaml::Mat &cen = b.mat["Centers"];
+    d.K = cen.rows;
+    d.in_dim = 61;
+    d.centers = cen.data.data();
+    size = d.resized_image_size = b.num.count("ResizedImageSize") ? (int)b.num["ResizedImageSize"] : 300;
+    d.use_spatial_pyramid = b.num.count("UseSpatialPyramid") ? (int)b.num["UseSpatialPyramid"] : 1;
+    d.pyramid_level = b.num.count("PyramidLevel") ? (int)b.num["PyramidLevel"] : 2;
+    const std::string norm = b.str.count("NormBofFeatureType") ? b.str["NormBofFeatureType"] : "L1";
+    d.norm_type = norm == "NONE" ? 0 : norm == "L2" ? 1 : 2;
+    if (!pca_file.empty()) {
+      if (!read_cv_yaml(pca_file, &p) || !p.mat.count("EigenVectorsPCA") || !p.mat.count("EigenValuesPCA") ||
+          !p.mat.count("MeanPCA"))
+        return false;
+      d.n_pca = (int)p.num["DimPCA"];
+      d.pca_mean = p.mat["MeanPCA"].data.data();
+      d.pca_eigvec = p.mat["EigenVectorsPCA"].data.data();  // first n_pca rows of [in_dim x in_dim]
+      d.pca_eigval = p.mat["EigenValuesPCA"].data.data();
+    }
+    if (sfmloc_bof_create(&d, device, &bof)) return false;
+    if (sfmloc_akaze_create(device, size, size, 4, 4, 0.001f, &ak)) return false;
+    float fs = 4.0f;  // DenseFeatureDetector.cpp:44-69 with DenseLocalFeatureWrapper.h:32-38
+    for (int s = 0; s < 4; ++s) {
+      for (int y = 0; y < size; y += 6)
+        for (int x = 0; x < size; x += 6) {
+          grid.push_back((float)x);
+          grid.push_back((float)y);
+          grid.push_back(fs);
+          grid.push_back((float)s);
+        }
+      fs = fs * 1.5f;
+    }
+    return true;
+  }
+  bool compute(const std::vector<uint8_t> &bgr, int w, int h, std::vector<float> *out) {
+    std::vector<uint8_t> gray((size_t)size * size);
+    if (sfmloc_dense_gray(device, bgr.data(), (uint32_t)w, (uint32_t)h, (uint32_t)size, gray.data())) return false;
+    const uint32_t n = (uint32_t)(grid.size() / 4);
+    std::vector<uint8_t> desc((size_t)n * 64);
+    if (sfmloc_akaze_compute(ak, gray.data(), grid.data(), n, desc.data(), nullptr)) return false;
+    std::vector<float> feats((size_t)n * 61), kxy((size_t)n * 2);
+    for (uint32_t i = 0; i < n; ++i) {
+      for (int k = 0; k < 61; ++k) feats[(size_t)i * 61 + k] = (float)desc[(size_t)i * 64 + k];  // convertTo(CV_32FC1)
+      kxy[2 * i] = grid[4 * i];
+      kxy[2 * i + 1] = grid[4 * i + 1];
+    }
+    std::vector<double> bow(sfmloc_bof_dim(bof));
+    if (sfmloc_bof_compute(bof, feats.data(), kxy.data(), n, bow.data())) return false;
+    out->assign(bow.begin(), bow.end());
+    return true;
+  }
+  ~DenseBow() {
+    if (ak) sfmloc_akaze_destroy(ak);
+    if (bof) sfmloc_bof_destroy(bof);
+  }
+};
 
 // Eigen IOFormat(6, 0, ",", ",\n", rowPrefix, rowSuffix, "[", "]"): 6 significant digits, columns aligned
 std::string eigen_format(const double *m, int rows, int cols, const char *row_prefix, const char *row_suffix) {
@@ -377,6 +524,7 @@ int main(int argc, char **argv) {
   const double cx = atof(a.get({"x", "cenLocX"}, "0.0").c_str()), cy = atof(a.get({"y", "cenLocY"}, "0.0").c_str()),
                cz = atof(a.get({"z", "cenLocZ"}, "0.0").c_str()), radius = atof(a.get({"d", "cenRadius"}, "-1.0").c_str());
   const std::string bow_model = a.get({"a", "bowModelFile"}, "");
+  const std::string pca_model = a.get({"p", "pcaModelFile"}, "");
   int every = atoi(a.get({"i", "locEvryNFrame"}, "1").c_str());
   const double geom = atof(a.get({"g", "geomLimit"}, "4.0").c_str());
   const std::string featdir_opt = a.get({"featdir"}, "");
@@ -429,6 +577,7 @@ int main(int argc, char **argv) {
   mkdir(out_dir.c_str(), 0777);
 
   std::map<std::pair<int, int>, sfmloc_akaze *> extractors;
+  DenseBow dense;
   int n_img = 0, match_next = 0, rc_all = 0;
   for (const std::string &img : images) {
     ++n_img;
@@ -443,9 +592,9 @@ int main(int argc, char **argv) {
     int w = info.n_views ? (int)view_wh[0] : 0, h = info.n_views ? (int)view_wh[1] : 0;
     std::vector<uint8_t> desc;
     std::vector<float> xy;
-    std::vector<uint8_t> gray;
+    std::vector<uint8_t> gray, bgr;
     int gw = 0, gh = 0;
-    const bool have_img = load_gray(img, &gray, &gw, &gh);
+    const bool have_img = load_gray(img, &gray, &gw, &gh, &bgr);
     if (have_img) {
       w = gw;
       h = gh;
@@ -505,7 +654,20 @@ int main(int argc, char **argv) {
     bool attempted = false;
     if (!(use_sel && sel.empty())) {
       std::vector<float> bow;
-      if (knn_bow > 0 && !bow_model.empty() && read_bow(join(fdir, base + ".bow"), &bow)) {
+      bool have_bow = false;
+      if (knn_bow > 0 && !bow_model.empty()) {
+        // a precomputed <base>.bow next to the features if there is one, else from the colour image as the reference does
+        have_bow = read_bow(join(fdir, base + ".bow"), &bow);
+        if (!have_bow && have_img) {
+          if (!dense.bof && !dense.init(bow_model, pca_model, device)) {
+            fprintf(stderr, "cannot load the BoW / PCA model (%s)\n", sfmloc_last_error());
+            rc_all = 1;
+            break;
+          }
+          have_bow = dense.compute(bgr, gw, gh, &bow);
+        }
+      }
+      if (have_bow) {
         const uint32_t n_cand = use_sel ? (uint32_t)sel.size() : info.n_views;
         if (n_cand > (uint32_t)knn_bow) {  // localization.cpp:346
           std::vector<uint32_t> out(knn_bow);

@@ -74,3 +74,31 @@ def test_image_to_pose(tmp_path):
     assert r.stdout.count("Extract features from query image") == 3
     for name in truth:
         assert (out2 / (name + ".json")).read_bytes() == (out / (name + ".json")).read_bytes(), name
+    # BoW shortlist computed from the query IMAGE (-k -a -p): dense AKAZE -> PCA -> BoF in both programs; the map's
+    # .bow files hold what the same chain gives for the map images, so the shortlist is meaningful
+    rngb = np.random.Generator(np.random.PCG64(21))
+    K, npca = 12, 10
+    pca = {"DimPCA": npca, "EigenVectorsPCA": rngb.normal(size=(61, 61)).astype(np.float32),
+           "EigenValuesPCA": rngb.uniform(0.5, 4.0, (61, 1)).astype(np.float32),
+           "MeanPCA": rngb.uniform(0, 255, (1, 61)).astype(np.float32)}
+    bowm = {"ResizedImageSize": 300, "UseSpatialPyramid": 1, "PyramidLevel": 2, "NormBofFeatureType": "L1",
+            "Centers": (rngb.normal(size=(K, npca)) * 30).astype(np.float32)}
+    fileio.write_cv_yaml(tmp_path / "matches" / "PCAfile.yml", pca)
+    fileio.write_cv_yaml(tmp_path / "matches" / "BOWfile.yml", bowm)
+    db = engine.DenseBow(str(tmp_path / "matches" / "BOWfile.yml"), str(tmp_path / "matches" / "PCAfile.yml"))
+    for k, (R, C, img) in enumerate(views):
+        vec = db.compute(np.stack([img, img, img], 2))
+        fileio.write_mat_bin(tmp_path / "matches" / (f"img{k:06d}.bow"), vec.reshape(-1, 1))
+    db.close()
+    common = [str(qdir), str(tmp_path / "sfm"), str(tmp_path / "matches")]
+    opts = ["-r=25", "-k=4", "-a=" + str(tmp_path / "matches" / "BOWfile.yml"), "-p=" + str(tmp_path / "matches" / "PCAfile.yml")]
+    out3, out4 = tmp_path / "out_bow_py", tmp_path / "out_bow_cc"
+    assert engine.main(common + [str(out3)] + opts) == 0
+    r = subprocess.run([cli] + common + [str(out4)] + opts, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    n_loc = 0
+    for name in truth:
+        a, b = (out4 / (name + ".json")).read_bytes(), (out3 / (name + ".json")).read_bytes()
+        assert a == b, name
+        n_loc += b'"t"' in b
+    assert n_loc >= 1
