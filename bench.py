@@ -30,7 +30,7 @@ OPS_PER_PAIR = 35  # 16 xor + 16 bcnt + lshl_or + med3 + min (hamming.hip)
 
 
 # HBM bytes per K1 launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs of this same
-# command, corrected as MI355X_MICROARCH.md prescribes; tools/run_profile_r01c.sh + tools/pmc_summary.py)
+# command, corrected as MI355X_MICROARCH.md prescribes; tools/run_profile.sh + tools/pmc_summary.py)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary_screen.json")
 
 
