@@ -338,6 +338,18 @@ int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin
 int sfmloc_akaze_levels(const sfmloc_akaze *ak, int *n_levels, int *wh);
 int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt);
 
+/* cv::imread of the query image, host side (AKAZEOpenCV.cpp:60 `imread(filename, IMREAD_GRAYSCALE)` for extraction;
+ * DenseLocalFeatureWrapper.cpp:85 and localizeImage.cc:463 `IMREAD_COLOR` for the dense-BoW front end).  Decodes
+ * JPEG (baseline / extended / progressive Huffman, 8 bit, 4:4:4 / 4:2:2 / 4:2:0 / gray -- libjpeg's default path
+ * restated: islow IDCT, fancy upsampling, fixed-point YCbCr->RGB; gray = the Y plane as JCS_GRAYSCALE gives it), PNG
+ * (8 bit, non-interlaced; colour -> gray as png_set_rgb_to_gray(1, .299, .587)) and binary PGM / PPM.
+ * color == 0: out is h x w gray; color != 0: out is h x w x 3 in B G R order.  With out == NULL only *width and
+ * *height are returned (size query).  SFMLOC_EIO for a file that cannot be read or decoded, SFMLOC_ECAP when `cap`
+ * bytes do not hold the image.  No device is needed. */
+int sfmloc_image_decode(const uint8_t *bytes, uint64_t n_bytes, int32_t color, uint8_t *out, uint64_t cap,
+                        int32_t *width, int32_t *height);
+int sfmloc_image_read(const char *path, int32_t color, uint8_t *out, uint64_t cap, int32_t *width, int32_t *height);
+
 /* Dense-BoW front end (DenseLocalFeatureWrapper.cpp:89-99): colour image (BGR, 8-bit,
  * row-major h x w x 3) -> cv::resize(size x size, INTER_CUBIC) -> BGR2GRAY -> normalize(0, 255, NORM_MINMAX);
  * gray_out [size*size].  The grid keypoints (DenseFeatureDetector.cpp:44-69) and the chaining into

@@ -76,12 +76,40 @@ class LocalizeEngine {
     if (sfmloc_akaze_detect_and_compute(ak, gray, kp.data(), desc.data(), cap, &n))
       throw std::runtime_error(sfmloc_last_error());
     std::vector<float> xy((size_t)n * 2);
-    for (uint32_t i = 0; i < n; ++i) {  // the .feat round trip of the reference (AKAZEOpenCV.cpp:80-111)
-      xy[2 * i] = round6(kp[6 * i]);
-      xy[2 * i + 1] = round6(kp[6 * i + 1]);
+    for (uint32_t i = 0; i < n; ++i) {  // locFeat takes KeyPoint::pt as is (LocalizeEngine.cc:228-231); only the
+      xy[2 * i] = kp[6 * i];            // command-line tool reads the 6-digit .feat text back
+      xy[2 * i + 1] = kp[6 * i + 1];
     }
     return localizeFeatures(desc.data(), xy.data(), n, width, height, bReturnKeypoints, points2D, points3D,
                             pointsInlier, bReturnTime, times, center, radius, bow);
+  }
+
+  // the server's calls: a decoded colour image (B G R, what cv::imdecode / cv::imread(IMREAD_COLOR) hand to
+  // LocalizeEngine::localize, localizeImage.cc:393/463); cv::AKAZE::detectAndCompute converts it with BGR2GRAY
+  std::vector<double> localizeBGR(const uint8_t *bgr, int width, int height, bool bReturnKeypoints,
+                                  std::vector<double> &points2D, std::vector<double> &points3D,
+                                  std::vector<int> &pointsInlier, bool bReturnTime, std::vector<double> &times,
+                                  const std::vector<double> &center = std::vector<double>(), double radius = -1.0,
+                                  const std::vector<float> *bow = nullptr) {
+    std::vector<uint8_t> gray((size_t)width * height);
+    for (size_t i = 0; i < gray.size(); ++i)
+      gray[i] = (uint8_t)((bgr[3 * i + 2] * 4899 + bgr[3 * i + 1] * 9617 + bgr[3 * i] * 1868 + 8192) >> 14);
+    return localize(gray.data(), width, height, bReturnKeypoints, points2D, points3D, pointsInlier, bReturnTime, times,
+                    center, radius, bow);
+  }
+
+  // ... and an image file (JPEG / PNG / PGM / PPM) through the library's own imread
+  std::vector<double> localizeImageFile(const std::string &path, bool bReturnKeypoints, std::vector<double> &points2D,
+                                        std::vector<double> &points3D, std::vector<int> &pointsInlier,
+                                        bool bReturnTime, std::vector<double> &times,
+                                        const std::vector<double> &center = std::vector<double>(),
+                                        double radius = -1.0, const std::vector<float> *bow = nullptr) {
+    int32_t w = 0, h = 0;
+    if (sfmloc_image_read(path.c_str(), 1, nullptr, 0, &w, &h)) throw std::runtime_error(sfmloc_last_error());
+    std::vector<uint8_t> bgr((size_t)w * h * 3);
+    if (sfmloc_image_read(path.c_str(), 1, bgr.data(), bgr.size(), &w, &h)) throw std::runtime_error(sfmloc_last_error());
+    return localizeBGR(bgr.data(), w, h, bReturnKeypoints, points2D, points3D, pointsInlier, bReturnTime, times, center,
+                       radius, bow);
   }
 
   // the same from the output of extractAKAZESingleImg: desc [n x 64] (.desc rows), keypoints [n x 2]
@@ -176,11 +204,6 @@ class LocalizeEngine {
   sfmloc_map *map() const { return mMap; }
 
  private:
-  static float round6(float v) {
-    char b[64];
-    std::snprintf(b, sizeof(b), "%.6g", (double)v);
-    return std::strtof(b, nullptr);
-  }
   void applyA(double *p) const {
     const double x = p[0], y = p[1], z = p[2];
     for (int i = 0; i < 3; ++i) p[i] = mA[4 * i] * x + mA[4 * i + 1] * y + mA[4 * i + 2] * z + mA[4 * i + 3];

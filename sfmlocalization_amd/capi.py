@@ -110,7 +110,7 @@ SYMBOLS = [
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
-    "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile",
+    "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
 ]
 
 _bound = False
@@ -253,6 +253,45 @@ def dense_gray(bgr, size=300, device=0):
         raise ValueError("dense_gray: expected an h x w x 3 BGR image")
     out = np.zeros((size, size), np.uint8)
     _check(_L().sfmloc_dense_gray(device, _ptr(bgr, C.c_uint8), w, h, size, _ptr(out, C.c_uint8)))
+    return out
+
+
+def image_decode(data, color=False):
+    """sfmloc_image_decode: the bytes of a JPEG / PNG / PGM / PPM file -> what cv::imread returns for it: u8 [h, w]
+    (IMREAD_GRAYSCALE, AKAZEOpenCV.cpp:60) or u8 [h, w, 3] in B G R order (IMREAD_COLOR,
+    DenseLocalFeatureWrapper.cpp:85).  Host code; raises SfmlocError (SFMLOC_EIO) for an undecodable file."""
+    raw = np.frombuffer(bytes(data), dtype=np.uint8)
+    w, h = C.c_int32(0), C.c_int32(0)
+    L = _L()
+    L.sfmloc_image_decode.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_int32, C.POINTER(C.c_uint8), C.c_uint64,
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    _check(L.sfmloc_image_decode(_ptr(raw, C.c_uint8), raw.size, int(bool(color)), None, 0, C.byref(w), C.byref(h)))
+    out = np.zeros((h.value, w.value, 3) if color else (h.value, w.value), np.uint8)
+    _check(L.sfmloc_image_decode(_ptr(raw, C.c_uint8), raw.size, int(bool(color)), _ptr(out, C.c_uint8), out.size,
+                                 C.byref(w), C.byref(h)))
+    return out
+
+
+def image_size(path):
+    """(width, height) of an image file from its header (sfmloc_image_read with a NULL buffer)."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    L = _L()
+    L.sfmloc_image_read.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32)]
+    _check(L.sfmloc_image_read(os.fsencode(path), 0, None, 0, C.byref(w), C.byref(h)))
+    return w.value, h.value
+
+
+def image_read(path, color=False):
+    """sfmloc_image_read: cv::imread(path, IMREAD_GRAYSCALE | IMREAD_COLOR) as the reference's tools call it."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    L = _L()
+    L.sfmloc_image_read.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32)]
+    bpath = os.fsencode(path)
+    _check(L.sfmloc_image_read(bpath, int(bool(color)), None, 0, C.byref(w), C.byref(h)))
+    out = np.zeros((h.value, w.value, 3) if color else (h.value, w.value), np.uint8)
+    _check(L.sfmloc_image_read(bpath, int(bool(color)), _ptr(out, C.c_uint8), out.size, C.byref(w), C.byref(h)))
     return out
 
 

@@ -6,14 +6,12 @@
 //
 // Same arguments, console messages and output files (<outputFolder>/<base>.json with the reference's keys and
 // Eigen IOFormat(6) matrices; the failure form has the first three keys only, localization.cpp:84-153).
-// Differences, all forced by what this image has: image decoding is built in for PNG (8-bit, via zlib) and binary
-// PGM/PPM only -- no libjpeg headers here -- and otherwise the query's features are taken from
-// <featdir>/<base>.desc/.feat (the files extractAKAZESingleImg writes, AKAZEOpenCV.cpp:80-111); the BoW shortlist
+// Images are decoded by the library's own cv::imread (sfmloc_image_read: JPEG, PNG, binary PGM/PPM); when the image
+// cannot be decoded the query's features are taken from <featdir>/<base>.desc/.feat (the files extractAKAZESingleImg writes, AKAZEOpenCV.cpp:80-111); the BoW shortlist
 // (-k) uses <featdir>/<base>.bow if present, else the dense-feature chain on the decoded colour image; -w and -gm are
 // accepted and ignored.  The Python mirror (sfmlocalization_amd/engine.py) covers the same contract.
 #include <dirent.h>
 #include <sys/stat.h>
-#include <zlib.h>
 
 #include <algorithm>
 #include <cmath>
@@ -167,136 +165,16 @@ bool read_bow(const std::string &p, std::vector<float> *v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// image decoding: 8-bit PNG (gray / RGB / RGBA / gray+alpha / palette, non-interlaced) and binary PGM / PPM -> gray
-// imread(IMREAD_GRAYSCALE) semantics for colour: OpenCV's (R*4899 + G*9617 + B*1868 + 8192) >> 14
+// image decoding = the library's cv::imread (sfmloc_image_read: JPEG, PNG, binary PGM/PPM)
 // ---------------------------------------------------------------------------------------------------------
-uint8_t to_gray(int r, int g, int b) { return (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14); }
-
-bool decode_pnm(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int *w, int *h, std::vector<uint8_t> *bgr) {
-  if (raw.size() < 2 || raw[0] != 'P' || (raw[1] != '5' && raw[1] != '6')) return false;
-  size_t p = 2;
-  int vals[3], nv = 0;
-  while (nv < 3 && p < raw.size()) {
-    while (p < raw.size() && isspace(raw[p])) ++p;
-    if (p < raw.size() && raw[p] == '#') {
-      while (p < raw.size() && raw[p] != '\n') ++p;
-      continue;
-    }
-    int v = 0;
-    bool any = false;
-    while (p < raw.size() && isdigit(raw[p])) {
-      v = v * 10 + (raw[p++] - '0');
-      any = true;
-    }
-    if (!any) return false;
-    vals[nv++] = v;
-  }
-  if (nv < 3 || vals[2] != 255 || p >= raw.size()) return false;
-  ++p;  // single whitespace after maxval
-  *w = vals[0];
-  *h = vals[1];
-  const size_t n = (size_t)*w * *h, ch = raw[1] == '6' ? 3 : 1;
-  if (raw.size() < p + n * ch) return false;
-  gray->resize(n);
-  bgr->resize(3 * n);
-  for (size_t i = 0; i < n; ++i) {
-    const int r = raw[p + ch * i], g = ch == 1 ? r : raw[p + 3 * i + 1], b = ch == 1 ? r : raw[p + 3 * i + 2];
-    (*gray)[i] = ch == 1 ? (uint8_t)r : to_gray(r, g, b);
-    (*bgr)[3 * i] = (uint8_t)b;
-    (*bgr)[3 * i + 1] = (uint8_t)g;
-    (*bgr)[3 * i + 2] = (uint8_t)r;
-  }
+bool load_image(const std::string &path, bool color, std::vector<uint8_t> *px, int *w, int *h) {
+  int32_t iw = 0, ih = 0;
+  if (sfmloc_image_read(path.c_str(), color ? 1 : 0, nullptr, 0, &iw, &ih)) return false;
+  px->resize((size_t)iw * ih * (color ? 3 : 1));
+  if (sfmloc_image_read(path.c_str(), color ? 1 : 0, px->data(), px->size(), &iw, &ih)) return false;
+  *w = iw;
+  *h = ih;
   return true;
-}
-
-uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-
-bool decode_png(const std::vector<uint8_t> &raw, std::vector<uint8_t> *gray, int *w, int *h, std::vector<uint8_t> *bgr) {
-  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-  if (raw.size() < 33 || memcmp(raw.data(), sig, 8) != 0) return false;
-  size_t p = 8;
-  int bit_depth = 0, color = 0, interlace = 0;
-  std::vector<uint8_t> idat, plte;
-  bool have_hdr = false;
-  while (p + 12 <= raw.size()) {
-    const uint32_t len = be32(&raw[p]);
-    const char *type = reinterpret_cast<const char *>(&raw[p + 4]);
-    if (p + 12 + len > raw.size()) return false;
-    const uint8_t *data = &raw[p + 8];
-    if (!memcmp(type, "IHDR", 4) && len >= 13) {
-      *w = (int)be32(data);
-      *h = (int)be32(data + 4);
-      bit_depth = data[8];
-      color = data[9];
-      interlace = data[12];
-      have_hdr = true;
-    } else if (!memcmp(type, "PLTE", 4)) {
-      plte.assign(data, data + len);
-    } else if (!memcmp(type, "IDAT", 4)) {
-      idat.insert(idat.end(), data, data + len);
-    } else if (!memcmp(type, "IEND", 4)) {
-      break;
-    }
-    p += 12 + len;
-  }
-  if (!have_hdr || bit_depth != 8 || interlace != 0 || *w <= 0 || *h <= 0) return false;
-  const int ch = color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : color == 6 ? 4 : 0;
-  if (!ch) return false;
-  const size_t stride = (size_t)*w * ch;
-  std::vector<uint8_t> buf((stride + 1) * (size_t)*h);
-  uLongf out_len = buf.size();
-  if (uncompress(buf.data(), &out_len, idat.data(), idat.size()) != Z_OK || out_len != buf.size()) return false;
-  std::vector<uint8_t> img(stride * (size_t)*h);
-  for (int y = 0; y < *h; ++y) {  // undo the scanline filters
-    const uint8_t ft = buf[(stride + 1) * y];
-    const uint8_t *src = &buf[(stride + 1) * y + 1];
-    uint8_t *dst = &img[stride * y];
-    const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
-    for (size_t x = 0; x < stride; ++x) {
-      const int a = x >= (size_t)ch ? dst[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
-      int pred = 0;
-      switch (ft) {
-        case 0: pred = 0; break;
-        case 1: pred = a; break;
-        case 2: pred = b; break;
-        case 3: pred = (a + b) >> 1; break;
-        case 4: {
-          const int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
-          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-        } break;
-        default: return false;
-      }
-      dst[x] = (uint8_t)(src[x] + pred);
-    }
-  }
-  const size_t n = (size_t)*w * *h;
-  gray->resize(n);
-  bgr->resize(3 * n);
-  for (size_t i = 0; i < n; ++i) {
-    const uint8_t *px = &img[i * ch];
-    int r, g, b;
-    if (color == 0 || color == 4) {
-      r = g = b = px[0];
-      (*gray)[i] = px[0];
-    } else if (color == 3) {
-      if ((size_t)px[0] * 3 + 2 >= plte.size()) return false;
-      r = plte[px[0] * 3], g = plte[px[0] * 3 + 1], b = plte[px[0] * 3 + 2];
-      (*gray)[i] = to_gray(r, g, b);
-    } else {
-      r = px[0], g = px[1], b = px[2];
-      (*gray)[i] = to_gray(r, g, b);
-    }
-    (*bgr)[3 * i] = (uint8_t)b;  // imread(IMREAD_COLOR) order
-    (*bgr)[3 * i + 1] = (uint8_t)g;
-    (*bgr)[3 * i + 2] = (uint8_t)r;
-  }
-  return true;
-}
-
-bool load_gray(const std::string &path, std::vector<uint8_t> *gray, int *w, int *h, std::vector<uint8_t> *bgr) {
-  std::vector<uint8_t> raw;
-  if (!read_all(path, &raw)) return false;
-  return decode_png(raw, gray, w, h, bgr) || decode_pnm(raw, gray, w, h, bgr);
 }
 
 // image_describer.txt (cv::FileStorage YAML, AKAZEOption.cpp:44-55; defaults AKAZEOption.h:31-34)
@@ -594,7 +472,7 @@ int main(int argc, char **argv) {
     std::vector<float> xy;
     std::vector<uint8_t> gray, bgr;
     int gw = 0, gh = 0;
-    const bool have_img = load_gray(img, &gray, &gw, &gh, &bgr);
+    const bool have_img = load_image(img, false, &gray, &gw, &gh);  // imread(IMREAD_GRAYSCALE), AKAZEOpenCV.cpp:60
     if (have_img) {
       w = gw;
       h = gh;
@@ -664,7 +542,8 @@ int main(int argc, char **argv) {
             rc_all = 1;
             break;
           }
-          have_bow = dense.compute(bgr, gw, gh, &bow);
+          int cw = 0, ch = 0;  // imread(IMREAD_COLOR), DenseLocalFeatureWrapper.cpp:85
+          have_bow = load_image(img, true, &bgr, &cw, &ch) && dense.compute(bgr, cw, ch, &bow);
         }
       }
       if (have_bow) {

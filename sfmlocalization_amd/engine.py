@@ -23,30 +23,24 @@ IMAGE_EXT = ("jpg", "JPG", "jpeg", "JPEG", "png", "PNG")  # localization.cpp:204
 
 def _image_size(path, default):
     try:
-        from PIL import Image
-        with Image.open(path) as im:
-            return im.size
-    except Exception:
+        return capi.image_size(path)
+    except capi.SfmlocError:
         return default
 
 
 def _load_gray(path):
-    """imread(filename, IMREAD_GRAYSCALE) (AKAZEOpenCV.cpp:61) through PIL."""
+    """imread(filename, IMREAD_GRAYSCALE) (AKAZEOpenCV.cpp:60) = sfmloc_image_read; None when not decodable."""
     try:
-        from PIL import Image
-        with Image.open(path) as im:
-            return np.asarray(im.convert("L"), dtype=np.uint8)
-    except Exception:
+        return capi.image_read(path, color=False)
+    except capi.SfmlocError:
         return None
 
 
 def _load_bgr(path):
-    """imread(filename, IMREAD_COLOR) (DenseLocalFeatureWrapper.cpp:85) through PIL: h x w x 3, B G R order."""
+    """imread(filename, IMREAD_COLOR) (DenseLocalFeatureWrapper.cpp:85): h x w x 3, B G R order."""
     try:
-        from PIL import Image
-        with Image.open(path) as im:
-            return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8)[:, :, ::-1])
-    except Exception:
+        return capi.image_read(path, color=True)
+    except capi.SfmlocError:
         return None
 
 
@@ -98,12 +92,22 @@ class LocalizeEngine:
         return desc, kp[:, :4]
 
     def localize_image(self, gray, **kw):
-        """LocalizeEngine::localize on an image (LocalizeEngine.cc:288-661): extract, then localize()."""
+        """LocalizeEngine::localize on an image (LocalizeEngine.cc:288-661): extract, then localize().  A colour
+        image (h x w x 3, B G R -- what the server decodes, localizeImage.cc:393/463) goes through cvtColor BGR2GRAY
+        first, as cv::AKAZE::detectAndCompute does with a multi-channel input."""
+        gray = np.asarray(gray)
+        if gray.ndim == 3:
+            b, g, r = (gray[:, :, i].astype(np.int32) for i in range(3))
+            gray = ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
         desc, kp = self.extract(gray)
-        h, w = np.asarray(gray).shape
+        h, w = gray.shape
         res, ex = self.localize(desc, kp[:, :2], w, h, **kw)
         ex["n_features"] = len(desc)
         return res, ex
+
+    def localize_file(self, path, **kw):
+        """The server's entry point on a stored image (localizeImage.cc:463: imread(path, IMREAD_COLOR) -> localize)."""
+        return self.localize_image(capi.image_read(path, color=True), **kw)
 
     # getLocalViews (SfMDataUtils.cpp:210-227 / LocalizeEngine.cc:200-): NOTE the reference compares the SQUARED
     # distance with the un-squared radius; reproduced.

@@ -1,5 +1,6 @@
 // Drives sfmloc::LocalizeEngine (include/sfmloc_engine.hpp) the way VisionLocalizeServer drives the reference's class:
 //   engine_smoke <sfmDataDir> <matchDir> <AmatFile|-> <query.desc> <query.feat> <width> <height> [cx cy cz radius]
+//   engine_smoke <sfmDataDir> <matchDir> <AmatFile|-> --image <file.jpg|png>        (localizeImage.cc:463: imread + localize)
 // prints the 12 returned doubles (or "FAIL"), the number of 2D-3D points and the inlier indices.
 #include <cstdio>
 #include <cstdlib>
@@ -22,9 +23,25 @@ static bool slurp(const char *p, std::vector<uint8_t> *out) {
 }
 
 int main(int argc, char **argv) {
-  if (argc < 8) return 2;
+  const bool image_mode = argc >= 6 && !strcmp(argv[4], "--image");
+  if (argc < 8 && !image_mode) return 2;
   try {
     sfmloc::LocalizeEngine eng(argv[1], argv[2], strcmp(argv[3], "-") ? argv[3] : "", 0.6, 25, 4.0, false, 0, 0);
+    if (image_mode) {
+      std::vector<double> p2, p3, times;
+      std::vector<int> inl;
+      const std::vector<double> r = eng.localizeImageFile(argv[5], true, p2, p3, inl, true, times);
+      if (r.empty()) {
+        printf("FAIL\n");
+      } else {
+        for (double v : r) printf("%.17g ", v);
+        printf("\n");
+      }
+      printf("%zu\n", p2.size() / 2);
+      for (int i : inl) printf("%d ", i);
+      printf("\n%zu\n", times.size());
+      return 0;
+    }
     std::vector<uint8_t> raw;
     if (!slurp(argv[4], &raw) || raw.size() < 8) return 3;
     const uint32_t n = (uint32_t)((raw.size() - 8) / 64);

@@ -74,6 +74,43 @@ def test_image_to_pose(tmp_path):
     assert r.stdout.count("Extract features from query image") == 3
     for name in truth:
         assert (out2 / (name + ".json")).read_bytes() == (out / (name + ".json")).read_bytes(), name
+    # the same views as colour JPEGs (what a phone sends): both programs decode them with sfmloc_image_read -- the Y
+    # plane, as imread(IMREAD_GRAYSCALE) gets it from libjpeg -- and still find the poses
+    jdir = tmp_path / "qj"
+    jdir.mkdir()
+    for k, (name, (R, C)) in enumerate(truth.items()):
+        g = synth.render_plane_view(tex, PPM, R, C, F, W, H)
+        Image.fromarray(np.stack([g, g, g], 2)).save(jdir / f"{name}.jpg", quality=92, progressive=(k == 1))
+    outj, outj2 = tmp_path / "out_jpg", tmp_path / "out_jpg_cc"
+    assert engine.main([str(jdir), str(tmp_path / "sfm"), str(tmp_path / "matches"), str(outj), "-r=25"]) == 0
+    r = subprocess.run([cli, str(jdir), str(tmp_path / "sfm"), str(tmp_path / "matches"), str(outj2), "-r=25"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    n_ok = 0
+    for name, (R, C) in truth.items():
+        assert (outj2 / (name + ".json")).read_bytes() == (outj / (name + ".json")).read_bytes(), name
+        d = json.load(open(outj / (name + ".json")))
+        if "t" in d:
+            n_ok += 1
+            assert np.abs(np.array(d["t"]) - C).max() < 0.2, (name, d["t"], C)
+    assert n_ok >= 2
+    # the server's entry (localizeImage.cc:463): imread(IMREAD_COLOR) -> LocalizeEngine::localize, where cv::AKAZE
+    # converts BGR2GRAY itself; the Python and the header-only C++ class give the same twelve numbers
+    eng = engine.LocalizeEngine(str(tmp_path / "sfm"), str(tmp_path / "matches"), None, 0.6, 25, 4.0, False, 0, 0)
+    smoke = os.path.join(os.path.dirname(cli), "engine_smoke")
+    n_ok = 0
+    for name, (R, C) in truth.items():
+        res, ex = eng.localize_file(str(jdir / f"{name}.jpg"))
+        r = subprocess.run([smoke, str(tmp_path / "sfm"), str(tmp_path / "matches"), "-", "--image", str(jdir / f"{name}.jpg")],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        first = r.stdout.strip().split("\n")[0]
+        assert ([] if first == "FAIL" else [float(x) for x in first.split()]) == list(res), name
+        if res:
+            n_ok += 1
+            assert np.abs(np.array(res[0:3]) - C).max() < 0.2
+    assert n_ok >= 2
+    eng.close()
     # BoW shortlist computed from the query IMAGE (-k -a -p): dense AKAZE -> PCA -> BoF in both programs; the map's
     # .bow files hold what the same chain gives for the map images, so the shortlist is meaningful
     rngb = np.random.Generator(np.random.PCG64(21))
