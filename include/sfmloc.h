@@ -129,6 +129,15 @@ typedef struct sfmloc_scan_info {
 } sfmloc_scan_info;
 int sfmloc_scan(const char *sfm_dir, const char *match_dir, sfmloc_scan_info *info);
 
+/* The view table of an sfm_data.json on its own (host only): what ExtFeatAndMatch iterates over before any
+ * reconstruction exists (computeFeaturesAndMatches.cpp:118-126, AKAZEOpenCV.cpp:122-131).  Views come in id order
+ * (Views is a std::map); image_path = root_path / file name and stays valid until sfmloc_view_list_close. */
+typedef struct sfmloc_view_list sfmloc_view_list;
+int sfmloc_view_list_open(const char *sfm_data_json, sfmloc_view_list **out, uint32_t *n_views);
+int sfmloc_view_list_get(const sfmloc_view_list *list, uint32_t k, uint32_t *view_id, uint32_t *width,
+                         uint32_t *height, const char **image_path);
+void sfmloc_view_list_close(sfmloc_view_list *list);
+
 /* view table of a map: ids [n_views], row offsets [n_views+1], camera centres [n_views*3] (only for maps opened
  * from sfm_data.json; used for the dead-reckoning restriction getLocalViews, SfMDataUtils.cpp:210-227) */
 int sfmloc_map_views(const sfmloc_map *map, uint32_t *view_id, uint32_t *view_off, double *center);

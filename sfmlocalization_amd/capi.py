@@ -111,6 +111,7 @@ SYMBOLS = [
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
     "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
+    "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close",
 ]
 
 _bound = False

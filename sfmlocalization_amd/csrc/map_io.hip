@@ -546,4 +546,68 @@ int sfmloc_map_view_sizes(const sfmloc_map *map, uint32_t *wh) {
   return SFMLOC_OK;
 }
 
+// ---- the view table of an sfm_data.json alone (ExtFeatAndMatch works on <matchDir>/sfm_data.json before any
+//      reconstruction exists: computeFeaturesAndMatches.cpp:118-126) ----
+struct ViewList {
+  std::vector<uint32_t> id, w, h;
+  std::vector<std::string> image;  // root_path / filename
+};
+
+int sfmloc_view_list_open(const char *sfm_data_json, sfmloc_view_list **out, uint32_t *n_views) {
+  SFM_CHECK(sfm_data_json && out, SFMLOC_EINVAL, "sfmloc_view_list_open: null argument");
+  std::string text;
+  SFM_CHECK(read_file(sfm_data_json, text), SFMLOC_EIO, "The input sfm_data.json file \"%s\" cannot be read.",
+            sfm_data_json);
+  JParser P(text);
+  JVal root;
+  SFM_CHECK(P.value(root) && root.kind == JVal::Obj, SFMLOC_EIO, "%s: not a JSON object (%s)", sfm_data_json,
+            P.err.c_str());
+  const JVal *rp = root.get("root_path");
+  const std::string root_path = (rp && rp->kind == JVal::Str) ? rp->str : "";
+  const JVal *views = root.get("views");
+  SFM_CHECK(views && views->kind == JVal::Arr, SFMLOC_EIO, "%s: no \"views\" array", sfm_data_json);
+  std::vector<ViewRec> recs;
+  for (const JVal &e : views->arr) {
+    const JVal *val = e.get("value");
+    if (!val) val = e.get("values");
+    const JVal *pw = val ? val->get("ptr_wrapper") : nullptr;
+    const JVal *d = pw ? pw->get("data") : nullptr;
+    if (!d) continue;
+    ViewRec r;
+    r.id = (uint32_t)jint(d->get("id_view"), jint(e.get("key"), 0));
+    const JVal *fn = d->get("filename");
+    r.filename = fn ? fn->str : "";
+    r.w = (uint32_t)jint(d->get("width"), 0);
+    r.h = (uint32_t)jint(d->get("height"), 0);
+    r.id_intrinsic = r.id_pose = 0;
+    recs.push_back(r);
+  }
+  std::stable_sort(recs.begin(), recs.end(), [](const ViewRec &a, const ViewRec &b) { return a.id < b.id; });  // Views is a std::map
+  ViewList *L = new ViewList;
+  for (const ViewRec &r : recs) {
+    L->id.push_back(r.id);
+    L->w.push_back(r.w);
+    L->h.push_back(r.h);
+    const size_t s = r.filename.find_last_of("/\\");
+    L->image.push_back(join(root_path, s == std::string::npos ? r.filename : r.filename.substr(s + 1)));
+  }
+  if (n_views) *n_views = (uint32_t)L->id.size();
+  *out = reinterpret_cast<sfmloc_view_list *>(L);
+  return SFMLOC_OK;
+}
+
+int sfmloc_view_list_get(const sfmloc_view_list *list, uint32_t k, uint32_t *view_id, uint32_t *width, uint32_t *height,
+                         const char **image_path) {
+  SFM_CHECK(list, SFMLOC_EINVAL, "sfmloc_view_list_get: null list");
+  const ViewList *L = reinterpret_cast<const ViewList *>(list);
+  SFM_CHECK(k < L->id.size(), SFMLOC_EINVAL, "sfmloc_view_list_get: view %u of %zu", k, L->id.size());
+  if (view_id) *view_id = L->id[k];
+  if (width) *width = L->w[k];
+  if (height) *height = L->h[k];
+  if (image_path) *image_path = L->image[k].c_str();
+  return SFMLOC_OK;
+}
+
+void sfmloc_view_list_close(sfmloc_view_list *list) { delete reinterpret_cast<ViewList *>(list); }
+
 }  // extern "C"

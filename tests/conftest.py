@@ -19,7 +19,8 @@ def pytest_sessionstart(session):
     lib = os.path.join(ROOT, "sfmlocalization_amd", "lib", "libsfmloc_hip.so")
     cli = os.path.join(ROOT, "sfmlocalization_amd", "bin", "OpenMVGLocalization_AKAZE")
     smoke = os.path.join(ROOT, "sfmlocalization_amd", "bin", "engine_smoke")
-    if not (os.path.exists(lib) and os.path.exists(cli) and os.path.exists(smoke)):
+    extf = os.path.join(ROOT, "sfmlocalization_amd", "bin", "ExtFeatAndMatch")
+    if not (os.path.exists(lib) and os.path.exists(cli) and os.path.exists(smoke) and os.path.exists(extf)):
         subprocess.call(["make", "-C", os.path.join(ROOT, "sfmlocalization_amd", "csrc")])
 
 

@@ -74,3 +74,38 @@ def test_pair_modes(tmp_path, oracle_c):
     for k in exp:
         np.testing.assert_array_equal(put[k][0], exp[k][0])
     assert extfeat.main([str(match_dir), "-v=2", "-mf=3"]) == 1  # mutually exclusive options
+
+
+def test_cpp_tool_writes_the_same_files(tmp_path):
+    """sfmlocalization_amd/bin/ExtFeatAndMatch (C++ over the C ABI) against the Python mirror: every output file
+    byte for byte, in track mode and in video-pair mode, and the same exit codes."""
+    import shutil
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sfmlocalization_amd", "bin",
+                       "ExtFeatAndMatch")
+    (tmp_path / "a").mkdir()
+    match_py, names = render_sequence(tmp_path / "a", n=5)
+    match_cc = tmp_path / "matches_cc"
+    match_cc.mkdir()
+    shutil.copy(match_py / "sfm_data.json", match_cc / "sfm_data.json")
+    for mode in (["-mf=3", "-mm=20", "-r=150"], ["-v=2", "-mm=20", "-r=150"]):
+        for d in (match_py, match_cc):
+            for f in ("matches.putative.txt", "matches.f.txt"):
+                if os.path.exists(d / f):
+                    os.remove(d / f)
+        assert extfeat.main([str(match_py)] + mode) == 0
+        r = subprocess.run([exe, str(match_cc)] + mode, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "Start Putative Matching..." in r.stdout and "number of geometric matches" in r.stdout
+        files = sorted(f for f in os.listdir(match_py))
+        assert files == sorted(os.listdir(match_cc))
+        for f in files:
+            if f != "sfm_data.json":
+                assert (match_py / f).read_bytes() == (match_cc / f).read_bytes(), (mode, f)
+        assert os.path.getsize(match_cc / "matches.f.txt") > 100
+    r = subprocess.run([exe, str(match_cc), "-v=2", "-mf=3"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1
+    r = subprocess.run([exe, str(match_cc), "-sm"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Skip matching" in r.stdout
+    r = subprocess.run([exe, str(tmp_path / "nowhere")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Cannot load" in r.stderr
