@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=8,
                     help="queries per all-gather when --gpus > 1 (a multiple of the world size keeps the P3P stage balanced; "
                          "small batches keep the two-slot pipeline full over a short timed region)")
+    ap.add_argument("--bow-knn", type=int, default=0,
+                    help="> 0: BASELINE configs[2] -- every query first shortlists this many views by BoW distance "
+                         "(sfmloc_bow_select over a synthetic .bow matrix) and runs the path on those (1 GPU only); "
+                         "use with --views 10000")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -108,6 +112,30 @@ def cpu_baseline(m, queries, seconds):
                       "C oracle, OpenMP, -O3 -march=x86-64-v3"}
 
 
+def cpu_baseline_shortlist(m, queries, bow, qbow, knn, seconds):
+    """configs[2] on the host: exact L2 shortlist over the .bow matrix (NumPy), then the C oracle's whole path on the
+    shortlisted views (OpenMP), whole queries until `seconds` are spent."""
+    from oracle import oracle_c, pipeline as opipe
+    threads = max(1, min(16, os.cpu_count() or 1, oracle_c.max_threads()))
+    t0 = time.perf_counter()
+    done, ok, t_bow = 0, 0, 0.0
+    while done < len(queries) and (done == 0 or time.perf_counter() - t0 < seconds):
+        q = queries[done]
+        t1 = time.perf_counter()
+        d = ((bow - qbow[done][None, :]) ** 2).sum(1)
+        sel = np.sort(np.argsort(d, kind="stable")[:knn]).astype(np.uint32)
+        t_bow += time.perf_counter() - t1
+        r = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=sel, ransac_round=25, threads=threads)
+        ok += int(bool(r["ok"]))
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{done} whole queries ({queries[0].desc.shape[0]} feats): exact BoW shortlist k={knn} of {m.n_views} "
+                      f"views in NumPy ({t_bow / done * 1e3:.1f} ms/query) + the C oracle's path on the shortlisted views "
+                      f"(exact 2-NN + ratio, F-matrix AC-RANSAC, 2D-3D set, P3P AC-RANSAC; localised {ok}/{done}); "
+                      "OpenMP, -O3 -march=x86-64-v3"}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -135,13 +163,23 @@ def main():
     # every rank builds the same seeded map and keeps its shard of views (contiguous view ranges)
     m = synth.make_map(2, n_views=a.views, desc_per_view=a.desc_per_view)
     queries = [synth.make_query(m, 1000 + i, n_feat=a.nq) for i in range(a.queries)]
+    bow = qbow = None
+    if a.bow_knn > 0:
+        if world > 1 or forced:
+            raise SystemExit("--bow-knn is a single-GPU workload in this bench (the sharded shortlist is dist.py's bow_shortlists)")
+        # one BoW prototype per place + noise per view: the shortlist finds the query's place (TrainBoW's vectors are
+        # 500-dimensional, BoFUtils.cpp:43-45)
+        rng = np.random.Generator(np.random.PCG64(33))
+        place_bow = rng.uniform(0, 1, (len(m.place_center), 500)).astype(np.float32)
+        bow = (place_bow[m.view_place] + rng.normal(0, 0.05, (a.views, 500))).astype(np.float32)
+        qbow = [(place_bow[q.place] + rng.normal(0, 0.05, 500)).astype(np.float32) for q in queries]
     v0 = (a.views * rank) // world
     v1 = (a.views * (rank + 1)) // world
     r0, r1 = int(m.view_off[v0]), int(m.view_off[v1])
     params = S.default_params(device=local_rank, profile=1, ransac_round=25)
     dev_map = S.Map(m.view_id[v0:v1], m.view_off[v0:v1 + 1] - m.view_off[v0], m.desc[r0:r1], params=params,
                     view_wh=m.view_wh[v0:v1], kpt_xy=m.kpt_xy[r0:r1], row_landmark=m.row_landmark[r0:r1],
-                    landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+                    landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic, bow=bow)
     dqs = [dev_map.query(q.desc, q.kpt_xy, q.width, q.height) for q in queries]
     lat = []
     n_ok = [0]
@@ -184,7 +222,10 @@ def main():
         if busy[k]:
             finish(k)
         t_begin[k] = time.perf_counter()
-        ctxs[k].begin(dqs[i % len(dqs)])
+        if qbow is not None:   # configs[2]: shortlist + path in one asynchronous call, the shortlist stays on the device
+            ctxs[k].begin_bow(dqs[i % len(dqs)], qbow[i % len(dqs)], a.bow_knn)
+        else:
+            ctxs[k].begin(dqs[i % len(dqs)])
         busy[k] = True
 
     def run(first, count):
@@ -232,18 +273,24 @@ def main():
         dev_map.set_profile(2)   # K1 events only: every bracketed stage costs ~10 us of idle GPU on the critical path
         for i in range(min(a.steps, 32)):
             t1 = time.perf_counter()
-            ctxs[0].begin(dqs[i % len(dqs)])
+            if qbow is not None:
+                ctxs[0].begin_bow(dqs[i % len(dqs)], qbow[i % len(dqs)], a.bow_knn)
+            else:
+                ctxs[0].begin(dqs[i % len(dqs)])
             ctxs[0].end()
             lat_single.append(time.perf_counter() - t1)
         st1 = dev_map.stats()
         iso = (st1.total_ms[0] / max(1, st1.launches[0]), st1.hamming_lane_ops / max(1, st1.launches[0]))
-    dev_map.match_putative(dqs[0])  # outside the timed region: number of emitted matches for the byte count
+    sel0 = dev_map.bow_select(qbow[0], a.bow_knn) if qbow is not None else None
+    dev_map.match_putative(dqs[0], sel0)  # outside the timed region: number of emitted matches for the byte count
     n_match = int(dev_map.putative_read()[0].sum())
     if world > 1:
         ok_t = torch.tensor([n_ok[0]], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ok_t)
         n_ok[0] = int(ok_t.item())
     rows_rank = r1 - r0
+    if sel0 is not None:   # only the shortlisted views are scanned
+        rows_rank = int(sum(int(m.view_off[v + 1] - m.view_off[v]) for v in sel0))
     alg_bytes = 64 * rows_rank + 64 * a.nq + 12 * n_match
     achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
     pairs = rows_rank * a.nq
@@ -270,7 +317,9 @@ def main():
             "config": {"workload": f"{a.views}-image / {m.n_rows}-descriptor synthetic map, {a.nq} feats/query, "
                                    "whole per-query path: brute-force Hamming 2-NN + Lowe ratio -> >=16 filter -> "
                                    "F-matrix AC-RANSAC (25 rounds) -> 2D-3D set -> P3P AC-RANSAC (4096) -> pose; "
-                                   f"{nctx} queries in flight",
+                                   f"{nctx} queries in flight"
+                                   + (f"; every query first shortlists {a.bow_knn} views by exact L2 over the "
+                                      f"{a.views} x 500 .bow matrix (BASELINE configs[2])" if a.bow_knn > 0 else ""),
                        "views": a.views, "rows": int(m.n_rows), "nq": a.nq,
                        "parallelism": (f"bank sharded by view x{world}, one all-gather of candidate parts per "
                                        f"{a.batch}-query batch" if world > 1 else "1 GPU, whole bank"),
@@ -306,7 +355,8 @@ def main():
                 "valu_frac": iso[1] / (iso[0] * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                 "pairs_per_s": pairs / (iso[0] * 1e-3)}
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(m, queries, a.cpu_seconds)
+            out["cpu_baseline"] = (cpu_baseline_shortlist(m, queries, bow, qbow, a.bow_knn, a.cpu_seconds)
+                                   if a.bow_knn > 0 else cpu_baseline(m, queries, a.cpu_seconds))
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()

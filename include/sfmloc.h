@@ -256,6 +256,13 @@ typedef struct sfmloc_context sfmloc_context;
 int sfmloc_context_create(sfmloc_map *map, sfmloc_context **out);
 void sfmloc_context_destroy(sfmloc_context *ctx);
 int sfmloc_localize_begin(sfmloc_context *ctx, sfmloc_query *q, const uint32_t *view_sel, uint32_t n_sel);
+/* localization.cpp:346-368 / LocalizeEngine.cc:333-361 in one asynchronous call: shortlist the `knn` candidate views
+ * nearest to `query_bow` (exactly as sfmloc_bow_select) and localise on them.  The shortlist stays on the device --
+ * the bank blocks to scan are derived from it by a kernel -- so nothing waits for the host between the two stages.
+ * As in the reference the shortlist applies only when more than `knn` candidates remain; cand_views NULL = all
+ * views.  Finish with sfmloc_localize_end.  Same result as sfmloc_bow_select + sfmloc_localize_begin, bit for bit. */
+int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const float *query_bow, uint32_t knn,
+                              const uint32_t *cand_views, uint32_t n_cand);
 int sfmloc_localize_end(sfmloc_context *ctx, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,
                         uint32_t cap);
 /* n queries against all views, n_contexts of them in flight (0 = 4).  poses[n]; pair buffers may be NULL,

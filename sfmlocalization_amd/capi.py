@@ -111,7 +111,7 @@ SYMBOLS = [
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
     "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
-    "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close",
+    "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close", "sfmloc_localize_bow_begin",
 ]
 
 _bound = False
@@ -727,6 +727,19 @@ class Context:
         else:
             p, n, keep = _sel(view_sel)
             _check(_L().sfmloc_localize_begin(self._h, q._h, p, n))
+
+    def begin_bow(self, q, bow, knn, cand_views=None):
+        """sfmloc_localize_bow_begin: BoW shortlist (knn of the candidate views, all views when None) + the whole
+        path on it, asynchronous, the shortlist never leaving the device.  Finish with end()."""
+        b = np.ascontiguousarray(bow, dtype=np.float32).ravel()
+        L = _L()
+        L.sfmloc_localize_bow_begin.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32,
+                                                C.POINTER(C.c_uint32), C.c_uint32]
+        if cand_views is None:
+            _check(L.sfmloc_localize_bow_begin(self._h, q._h, _ptr(b, C.c_float), int(knn), None, 0))
+        else:
+            p, n, keep = _sel(cand_views)
+            _check(L.sfmloc_localize_bow_begin(self._h, q._h, _ptr(b, C.c_float), int(knn), p, n))
 
     def shard_begin(self, q, view_sel=None):
         """K1..K3 + candidate emission on this shard (asynchronous)."""

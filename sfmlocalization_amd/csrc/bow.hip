@@ -33,13 +33,39 @@ __global__ __launch_bounds__(256) void k_bow_dist(const float *__restrict__ bow,
   if (lane == 0) dist_bits[p] = __float_as_uint(s);
 }
 
+// exclusive prefix sum of one value per thread over a 1024-thread workgroup (wave shuffles + one LDS hop); every
+// thread also gets the grand total
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *wave_tot /*[16] LDS*/, uint32_t *total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= (uint32_t)off) inc += o;
+  }
+  __syncthreads();  // wave_tot of an earlier call is no longer read
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, tot = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16; ++w) {
+    const uint32_t t = wave_tot[w];
+    if (w < wave) before += t;
+    tot += t;
+  }
+  *total = tot;
+  return before + inc - v;
+}
+
 // One 1024-thread workgroup: exact k-th smallest distance by a 3-pass radix select on the float bits
 // (11+11+10), then an order-preserving compaction of {dist < T} plus the first (k - #less) of {dist == T}.
+// Every search over the histogram and every scan over the per-thread counts is a block-wide scan: the first version
+// left them to thread 0 and spent 130 us on 10 000 views, most of it in those loops.
 __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ dist_bits, uint32_t n,
                                                    const uint32_t *__restrict__ cand, uint32_t k,
                                                    uint32_t *__restrict__ out_sel) {
   __shared__ uint32_t hist[2048];
-  __shared__ uint32_t scan[1024];
+  __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t sh_prefix, sh_rank;
   const uint32_t tid = threadIdx.x;
   if (k > n) k = n;
@@ -58,14 +84,15 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
       if (match) atomicAdd(&hist[(x >> shifts[pass]) & (bins - 1)], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t acc = 0, b = 0;
-      for (; b < bins; ++b) {
-        if (acc + hist[b] >= rank) break;
-        acc += hist[b];
-      }
-      sh_prefix = prefix | (b << shifts[pass]);
-      sh_rank = rank - acc;
+    // the bin holding the rank-th element: thread t owns bins 2t, 2t+1 (1024 bins in the last pass: bin t, and 0)
+    const uint32_t per = bins / 1024;  // 2 or 1
+    const uint32_t h0 = hist[tid * per], h1 = per == 2 ? hist[tid * per + 1] : 0u;
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan_1024(h0 + h1, wave_tot, &total);
+    if (before < rank && rank <= before + h0 + h1) {  // exactly one thread (total >= rank by construction)
+      const bool second = rank > before + h0;
+      sh_prefix = prefix | ((tid * per + (second ? 1u : 0u)) << shifts[pass]);
+      sh_rank = rank - before - (second ? h0 : 0u);
     }
     __syncthreads();
     prefix = sh_prefix;
@@ -78,19 +105,8 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
   const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
   uint32_t c_eq = 0;
   for (uint32_t i = lo; i < hi; ++i) c_eq += (dist_bits[i] == T);
-  scan[tid] = c_eq;
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t acc = 0;
-    for (uint32_t t = 0; t < 1024; ++t) {
-      const uint32_t v = scan[t];
-      scan[t] = acc;
-      acc += v;
-    }
-  }
-  __syncthreads();
-  uint32_t eq_before = scan[tid];
-  __syncthreads();
+  uint32_t total;
+  const uint32_t eq_before = block_exclusive_scan_1024(c_eq, wave_tot, &total);
   uint32_t c_sel = 0;
   {
     uint32_t e = eq_before;
@@ -103,18 +119,7 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
       }
     }
   }
-  scan[tid] = c_sel;
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t acc = 0;
-    for (uint32_t t = 0; t < 1024; ++t) {
-      const uint32_t v = scan[t];
-      scan[t] = acc;
-      acc += v;
-    }
-  }
-  __syncthreads();
-  uint32_t pos = scan[tid];
+  uint32_t pos = block_exclusive_scan_1024(c_sel, wave_tot, &total);
   uint32_t e = eq_before;
   for (uint32_t i = lo; i < hi; ++i) {
     const uint32_t x = dist_bits[i];

@@ -285,9 +285,14 @@ struct ClearedScope {  // the flag must not outlive the call that set it
   ~ClearedScope() { c->cleared = false; }
 };
 
-int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel) {
+int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel = nullptr);
+int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel = nullptr);
+
+// d_sel: a selection that lives on the device (ascending view indices, n_sel of them; the BoW shortlist of
+// sfmloc_localize_bow_begin) -- the block list is then built by a kernel and the host never sees the views
+int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel) {
   Map *m = c->map;
-  const bool all_views = (view_sel == nullptr);
+  const bool all_views = (view_sel == nullptr && d_sel == nullptr);
   if (all_views) n_sel = m->n_views;
   SFM_CHECK(n_sel <= m->n_views, SFMLOC_EINVAL, "view selection: n_sel %u > n_views %u", n_sel, m->n_views);
 
@@ -295,7 +300,17 @@ int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_se
   // position of its first block in that list
   uint32_t n_work_blocks = m->n_blocks;
   c->last_blocks.clear();
-  if (!all_views) {
+  c->last_blocks_on_device = false;
+  if (d_sel) {
+    // launch bound the host can know: every selected view overlaps at most max_view_blocks blocks
+    const uint64_t bound = std::min<uint64_t>(m->n_blocks, (uint64_t)n_sel * m->max_view_blocks);
+    n_work_blocks = (uint32_t)bound;
+    if (n_sel) {
+      int rc = launch_blocks_from_views(c, d_sel, n_sel, n_work_blocks);
+      if (rc) return rc;
+    }
+    c->last_blocks_on_device = true;
+  } else if (!all_views) {
     if (c->pinned_busy) SFM_HIP(hipEventSynchronize(c->pinned_busy));  // previous upload still reading the staging
     uint32_t *h_sel = c->h_pinned;
     uint32_t *h_w0 = c->h_pinned + m->n_views;
@@ -428,13 +443,13 @@ int ctx_resection_wait(Ctx *c) {
   return SFMLOC_EHIP;
 }
 
-int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel) {
+int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel) {
   SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_localize_begin: context already has a query in flight");
   c->t_begin = now_s();
   ClearedScope cs{c};
   int rc = ctx_reset_for_query(c, q);
   if (rc) return rc;
-  rc = ctx_match_putative(c, q, view_sel, n_sel);
+  rc = ctx_match_putative(c, q, view_sel, n_sel, d_sel);
   if (rc) return rc;
   rc = check_stage(c, q, "sfmloc_localize");
   if (rc) return rc;
@@ -581,6 +596,11 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
   MAP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   m->n_rows = d->n_rows;
   m->n_blocks = (uint32_t)((d->n_rows + kBlockRows - 1) / kBlockRows);
+  m->max_view_blocks = 0;
+  for (uint32_t v = 0; v < d->n_views; ++v) {
+    const uint32_t r0 = d->view_off[v], r1 = d->view_off[v + 1];
+    if (r1 > r0) m->max_view_blocks = std::max(m->max_view_blocks, (r1 - 1) / kBlockRows - r0 / kBlockRows + 1);
+  }
   m->n_views = d->n_views;
   m->n_landmarks = d->row_landmark ? d->n_landmarks : 0;
   m->h_view_id.assign(d->view_id, d->view_id + d->n_views);
@@ -837,8 +857,14 @@ int sfmloc_putative_read_rows(sfmloc_map *map, uint32_t *best0, uint32_t *best1)
       b1 = k;
     }
   };
+  if (c->last_blocks_on_device) {  // the list was built on the device (BoW shortlist); padding names no block
+    c->last_blocks.resize(nwb);
+    SFM_HIP(hipMemcpy(c->last_blocks.data(), c->d_block_list, nwb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    c->last_blocks_on_device = false;
+  }
   for (uint64_t w = 0; w < nwb; ++w) {
     const uint32_t blk = c->last_all_views ? (uint32_t)w : c->last_blocks[w];
+    if (blk == 0xFFFFFFFFu) continue;
     for (uint32_t l = 0; l < kBlockRows; ++l) {
       const uint64_t r = (uint64_t)blk * kBlockRows + l;
       if (r >= m->n_rows) break;
@@ -968,6 +994,42 @@ int sfmloc_localize_begin(sfmloc_context *ctx, sfmloc_query *query, const uint32
   SFM_CHECK(q->map == c->map, SFMLOC_EINVAL, "sfmloc_localize_begin: query belongs to another map");
   SFM_HIP(hipSetDevice(c->map->device));
   return ctx_localize_begin(c, q, view_sel, n_sel);
+}
+
+int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const float *query_bow, uint32_t knn,
+                              const uint32_t *cand_views, uint32_t n_cand) {
+  SFM_CHECK(ctx && query && query_bow, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: null argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  Query *q = reinterpret_cast<Query *>(query);
+  Map *m = c->map;
+  SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: query belongs to another map");
+  SFM_CHECK(m->bow_dim > 0 && m->d_bow, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: the map has no .bow vectors");
+  SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: context already has a query in flight");
+  if (!cand_views) n_cand = m->n_views;
+  SFM_CHECK(n_cand <= m->n_views, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: n_cand > n_views");
+  SFM_HIP(hipSetDevice(m->device));
+  // "if (knnbow > 0 && viewList.size() > knnbow)" (localization.cpp:346, LocalizeEngine.cc:342): otherwise every
+  // candidate is matched
+  if (knn == 0 || n_cand <= knn) return ctx_localize_begin(c, q, cand_views, cand_views ? n_cand : 0);
+  if (cand_views) {
+    for (uint32_t i = 0; i < n_cand; ++i) {
+      SFM_CHECK(cand_views[i] < m->n_views, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: view index out of range");
+      SFM_CHECK(i == 0 || cand_views[i - 1] < cand_views[i], SFMLOC_EINVAL,
+                "sfmloc_localize_bow_begin: candidate views must be strictly ascending");
+    }
+    SFM_HIP(hipMemcpyAsync(c->d_bow_cand, cand_views, n_cand * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  }
+  SFM_HIP(hipMemcpyAsync(c->d_bow_query, query_bow, m->bow_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  int rc;
+  {
+    EventScope ev(c, SFMLOC_K_BOW);
+    rc = launch_bow_select(m, c->stream, c->d_bow_query, cand_views ? c->d_bow_cand : nullptr, n_cand, knn,
+                           c->d_bow_dist, c->d_bow_sel);
+  }
+  if (rc) return rc;
+  // K8 leaves the knn views in ascending order in d_bow_sel; everything downstream reads the selection on the device
+  uint32_t dummy = 0;
+  return ctx_localize_begin(c, q, &dummy, knn, c->d_bow_sel);
 }
 
 int sfmloc_localize_end(sfmloc_context *ctx, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,

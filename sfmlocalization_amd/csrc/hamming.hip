@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256) void k_tile_bank(const uint4 *__restrict__ row
   bank[(block * 4 + plane) * 64 + lane] = rows[t];
 }
 
+constexpr uint32_t kNoBlock = 0xFFFFFFFFu;  // block-list entry that names no bank block
+
 template <int R, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
     const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
@@ -66,8 +68,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t widx = w0 + r;
-    const bool valid = widx < n_work_blocks;
-    blk[r] = valid ? (block_list ? block_list[widx] : widx) : 0xFFFFFFFFu;
+    blk[r] = (widx < n_work_blocks) ? (block_list ? block_list[widx] : widx) : kNoBlock;
+    const bool valid = blk[r] != kNoBlock;  // padding of a device-built list (k_blocks_from_views)
     best0[r] = best1[r] = SFMLOC_NOMATCH;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -79,7 +81,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
       b[r][4 * c + 3] = v.w;
     }
   }
-  const bool wave_has_work = w0 < n_work_blocks;  // wave uniform
+  bool wave_has_work = false;  // wave uniform
+#pragma unroll
+  for (int r = 0; r < R; ++r) wave_has_work = wave_has_work || blk[r] != kNoBlock;
 
   for (uint32_t j0 = j_begin; j0 < j_end; j0 += lds_rows) {
     const uint32_t cnt = min(lds_rows, j_end - j0);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kScreenHead = 64;  // measured: 64 and 128 within 1 %, 256+ slower (profiles/r01_k1_screen_sweep.txt)
 
-template <int WAVES, int NW>
+template <int WAVES, int NW, int kScreenBatch>
 __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
     const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
     const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t lds_rows, const uint16_t *__restrict__ ratio_cnt,
@@ -140,8 +144,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t w0 = blockIdx.x * WAVES + wave;
-  const bool valid = w0 < n_work_blocks;
-  const uint32_t blk = valid ? (block_list ? block_list[w0] : w0) : 0u;
+  const uint32_t blk = (w0 < n_work_blocks) ? (block_list ? block_list[w0] : w0) : kNoBlock;
+  const bool valid = blk != kNoBlock;  // false also for the padding of a device-built list
+  if (!__syncthreads_or(valid)) return;
   uint32_t b[16];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -181,11 +186,50 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
     }
     // (b) screened tail.  A finished pair is exact, so it also tightens (best0, best1) and with them T: the
     // threshold only ever shrinks towards ratio_cnt[d1], which keeps every earlier decision valid.
+    // kScreenBatch > 1 (short block lists, e.g. a BoW shortlist, where a SIMD holds two to four waves and the latency
+    // of one xor -> bcnt chain is exposed): that many query rows per step, their prefix sums as independent chains;
+    // the votes then see the threshold as of the start of the step -- a larger one, so still valid.  With the chip
+    // full (kScreenBatch = 1) the plain loop below is 1 % faster.
+    if constexpr (kScreenBatch > 1)
+    for (; jj + kScreenBatch <= cnt; jj += kScreenBatch) {
+      uint32_t acc[kScreenBatch];
+#pragma unroll
+      for (int u = 0; u < kScreenBatch; ++u) {
+        uint32_t q[4 * ((NW + 3) / 4)];
+#pragma unroll
+        for (int c = 0; c < (NW + 3) / 4; ++c) {
+          const uint4 v = qs[(jj + u) * 4 + c];
+          q[4 * c + 0] = v.x, q[4 * c + 1] = v.y, q[4 * c + 2] = v.z, q[4 * c + 3] = v.w;
+        }
+        uint32_t a = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) a += __builtin_popcount(b[k] ^ q[k]);
+        acc[u] = a;
+      }
+#pragma unroll
+      for (int u = 0; u < kScreenBatch; ++u) {
+        if (__any(acc[u] < T)) {
+          ++n_finished;
+          uint32_t a = acc[u];
+#pragma unroll
+          for (int c = NW / 4; c < 4; ++c) {
+            const uint4 v = qs[(jj + u) * 4 + c];
+            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (4 * c + k >= NW) a += __builtin_popcount(b[4 * c + k] ^ q[k]);
+          }
+          flag = flag || (a < T);
+          top2_push(best0, best1, (a << 16) | (j0 + jj + u));
+          T = (uint32_t)cnt_s[best1 >> 16];
+        }
+      }
+    }
 #pragma unroll 2
-    for (; jj < cnt; ++jj) {
+    for (; jj < cnt; ++jj) {  // kScreenBatch = 1: every row; else the rows left over at the end of a slice
       uint32_t q[16];
 #pragma unroll
-      for (int c = 0; c < (NW + 3) / 4; ++c) {
+      for (int c = 0; c < 4; ++c) {
         const uint4 v = qs[jj * 4 + c];
         q[4 * c + 0] = v.x, q[4 * c + 1] = v.y, q[4 * c + 2] = v.z, q[4 * c + 3] = v.w;
       }
@@ -194,11 +238,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
       for (int k = 0; k < NW; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
       if (__any(acc < T)) {
         ++n_finished;
-#pragma unroll
-        for (int c = (NW + 3) / 4; c < 4; ++c) {
-          const uint4 v = qs[jj * 4 + c];
-          q[4 * c + 0] = v.x, q[4 * c + 1] = v.y, q[4 * c + 2] = v.z, q[4 * c + 3] = v.w;
-        }
 #pragma unroll
         for (int k = NW; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
         flag = flag || (acc < T);
@@ -552,13 +591,20 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   if (!c->cleared) SFM_HIP(hipMemsetAsync(c->d_n_flagged, 0, sizeof(uint32_t), c->stream));
 #define K1_SCREEN(NW)                                                                                              \
   case NW:                                                                                                        \
-    hipLaunchKernelGGL((k_hamming_screen<WAVES, NW>), dim3((n_work_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64), \
-                       lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks,       \
-                       q->d_desc, q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged,    \
-                       c->d_k1_counters, head, c->d_flagged_desc, c->rows_chunk_cap * 64);                        \
+    hipLaunchKernelGGL((k_hamming_screen<WAVES, NW, 1>), dim3((n_work_blocks + WAVES - 1) / WAVES),               \
+                       dim3(WAVES * 64), lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr,   \
+                       n_work_blocks, q->d_desc, q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged,     \
+                       c->d_n_flagged, c->d_k1_counters, head, c->d_flagged_desc, c->rows_chunk_cap * 64);        \
     break;
-  switch (nw) {
-    K1_SCREEN(8) K1_SCREEN(9) K1_SCREEN(10) K1_SCREEN(11) K1_SCREEN(12) K1_SCREEN(13)
+  if (nw == 10 && n_work_blocks < 16u * (uint32_t)m->n_cu) {  // fewer than four waves per SIMD: batched tail
+    hipLaunchKernelGGL((k_hamming_screen<WAVES, 10, 4>), dim3((n_work_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64),
+                       lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks, q->d_desc,
+                       q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged, c->d_k1_counters,
+                       head, c->d_flagged_desc, c->rows_chunk_cap * 64);
+  } else {
+    switch (nw) {
+      K1_SCREEN(8) K1_SCREEN(9) K1_SCREEN(10) K1_SCREEN(11) K1_SCREEN(12) K1_SCREEN(13)
+    }
   }
 #undef K1_SCREEN
   // executed VALU lane-ops, deterministic part (the finished pairs are counted on the device): exact head 35 per
@@ -575,6 +621,76 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   hipLaunchKernelGGL((k_hamming_rows<RW, RS>), dim3(128 * RS), dim3(RW * 64), (size_t)rows_lds * 64, c->stream,
                      m->d_bank, q->d_desc, q->n, c->d_flagged, c->d_n_flagged, c->d_rows_scratch, c->d_rows_arrivals,
                      chunk_cap, rows_lds, c->d_flagged_desc, c->d_part);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+// The host loop of ctx_match_putative on the device, for a view selection that never leaves the GPU (the BoW
+// shortlist, K8): ascending selected views -> ascending list of the 64-row bank blocks they overlap (a block shared
+// by two selected views appears once) + per view the list position of its first block; the list is padded with
+// kNoBlock up to `bound`, the launch size the host can know without reading the selection back.
+__global__ __launch_bounds__(1024) void k_blocks_from_views(const uint32_t *__restrict__ sel, uint32_t n_sel,
+                                                            const uint32_t *__restrict__ view_off,
+                                                            uint32_t *__restrict__ view_sel_out,
+                                                            uint32_t *__restrict__ widx0, uint32_t *__restrict__ block_list,
+                                                            uint32_t bound) {
+  __shared__ uint32_t s_last[1024];  // inclusive running max of (last block + 1) over the non-empty views so far
+  __shared__ uint32_t s_cnt[1024];   // inclusive scan of the blocks each view adds
+  __shared__ uint32_t s_carry_last, s_carry_cnt;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_carry_last = 0, s_carry_cnt = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_sel; base += 1024) {
+    const uint32_t k = base + tid;
+    uint32_t v = 0, r0 = 0, r1 = 0;
+    if (k < n_sel) {
+      v = sel[k];
+      r0 = view_off[v];
+      r1 = view_off[v + 1];
+    }
+    const bool nonempty = r1 > r0;
+    const uint32_t b0 = r0 / kBlockRows, b1 = nonempty ? (r1 - 1) / kBlockRows : 0;
+    s_last[tid] = nonempty ? b1 + 1 : 0;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive max-scan
+      const uint32_t o = tid >= off ? s_last[tid - off] : 0;
+      __syncthreads();
+      s_last[tid] = max(s_last[tid], o);
+      __syncthreads();
+    }
+    // last block (+1) of the nearest earlier non-empty selected view: views ascend, so it is the running maximum
+    const uint32_t prev = max(s_carry_last, tid ? s_last[tid - 1] : 0u);
+    const bool share = nonempty && prev != 0 && prev - 1 == b0;
+    const uint32_t add = nonempty ? (b1 - b0 + 1 - (share ? 1u : 0u)) : 0u;
+    s_cnt[tid] = add;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive sum-scan
+      const uint32_t o = tid >= off ? s_cnt[tid - off] : 0;
+      __syncthreads();
+      s_cnt[tid] += o;
+      __syncthreads();
+    }
+    const uint32_t start = s_carry_cnt + s_cnt[tid] - add;
+    if (k < n_sel) {
+      view_sel_out[k] = v;
+      widx0[k] = nonempty ? (share ? start - 1 : start) : 0u;
+      for (uint32_t b = b0 + (share ? 1u : 0u), w = start; nonempty && b <= b1; ++b, ++w)
+        if (w < bound) block_list[w] = b;
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      s_carry_last = max(s_carry_last, s_last[1023]);
+      s_carry_cnt += s_cnt[1023];
+    }
+    __syncthreads();
+  }
+  for (uint32_t w = s_carry_cnt + tid; w < bound; w += 1024) block_list[w] = kNoBlock;
+}
+
+int launch_blocks_from_views(Ctx *c, const uint32_t *d_sel, uint32_t n_sel, uint32_t bound) {
+  Map *m = c->map;
+  hipLaunchKernelGGL(k_blocks_from_views, dim3(1), dim3(1024), 0, c->stream, d_sel, n_sel, m->d_view_off, c->d_view_sel,
+                     c->d_view_widx0, c->d_block_list, bound);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

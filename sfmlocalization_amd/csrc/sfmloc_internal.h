@@ -107,6 +107,7 @@ struct Map {
 
   uint64_t n_rows = 0;
   uint32_t n_blocks = 0;  // ceil(n_rows / 64)
+  uint32_t max_view_blocks = 0;  // most 64-row blocks any one view overlaps (launch bound of a device-side selection)
   uint32_t n_views = 0;
   uint32_t n_landmarks = 0;
   std::vector<uint32_t> h_view_id, h_view_off, h_view_wh;
@@ -199,6 +200,7 @@ struct Ctx {
   bool last_all_views = false;
   uint32_t last_n_work_blocks = 0;
   std::vector<uint32_t> last_blocks;  // host copy of the block list (empty = all)
+  bool last_blocks_on_device = false; // the list was built by k_blocks_from_views: fetch it when a reader needs it
   bool cleared = false;  // k_query_reset already cleared this query's counters: the stages skip their own memsets
   struct Query *last_query = nullptr;  // query of the last putative call
   struct Query *in_flight = nullptr;   // query of a begun, not yet ended, localisation
@@ -225,6 +227,7 @@ int match_putative_on(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel
 // hamming.hip
 int launch_tile_bank(const uint4 *d_rows, uint64_t row0, uint64_t n_rows_chunk, uint4 *d_bank, hipStream_t s);
 int launch_hamming_top2(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split);
+int launch_blocks_from_views(Ctx *c, const uint32_t *d_sel, uint32_t n_sel, uint32_t bound);
 int launch_merge_ratio_compact(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, uint32_t split,
                                uint32_t n_work_blocks);
 

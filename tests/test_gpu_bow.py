@@ -108,3 +108,65 @@ def test_sharded_shortlist_equals_unsharded(oracle_c):
     assert sorted(got) == ref.tolist()
     for sm in shards:
         sm.close()
+
+
+def test_shortlist_chain_on_the_device_equals_two_steps():
+    """sfmloc_localize_bow_begin (shortlist -> block list -> scan, all on the device) against sfmloc_bow_select +
+    sfmloc_localize_begin: the same pose, inliers and pairs bit for bit -- on a ragged map (views of very different
+    sizes, empty ones, neighbours sharing a 64-row block), with and without a candidate restriction, with more than
+    1024 views selected, with the exact (unscreened) scan, and when the shortlist does not apply (knn >= candidates)."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    for seed, kw, nq in ((31, dict(n_views=60, desc_per_view=400, views_per_place=10, landmarks_per_place=300,
+                                   obs_per_view=140, ragged=True), 900),
+                         (32, dict(n_views=2600, desc_per_view=40, views_per_place=20, landmarks_per_place=60,
+                                   obs_per_view=30), 800),
+                         (33, dict(n_views=48, desc_per_view=500, views_per_place=8, landmarks_per_place=300,
+                                   obs_per_view=150), 300)):      # nq < 768: the exact kernel, query rows split
+        m = synth.make_map(seed, **kw)
+        nv = m.n_views
+        proto = rng.uniform(0, 1, (len(m.place_center), 500)).astype(np.float32)
+        bow = (proto[m.view_place] + rng.normal(0, 0.05, (nv, 500))).astype(np.float32)
+        with S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25), view_wh=m.view_wh,
+                   kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id, landmark_X=m.landmark_X,
+                   intrinsic=m.intrinsic, bow=bow) as dm:
+            ctx = dm.context()
+            n_ok = 0
+            for trial in range(3):
+                q = synth.make_query(m, 500 + trial, n_feat=nq, place=trial % len(m.place_center))
+                dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
+                qb = (proto[q.place] + rng.normal(0, 0.05, 500)).astype(np.float32)
+                cands = [None, np.sort(rng.choice(nv, nv // 2, replace=False)).astype(np.uint32)]
+                for cand in cands:
+                    n_cand = nv if cand is None else len(cand)
+                    for knn in (1, 7, min(n_cand - 1, 1500), n_cand, n_cand + 5):
+                        if knn < n_cand:
+                            sel = dm.bow_select(qb, knn, cand)
+                        else:
+                            sel = cand                               # the shortlist does not apply
+                        ctx.begin(dq, sel)
+                        ref = ctx.end()
+                        ctx.begin_bow(dq, qb, knn, cand)
+                        got = ctx.end()
+                        tag = f"seed {seed} trial {trial} knn {knn} cand {n_cand}"
+                        assert got[0].ok == ref[0].ok and got[0].n_inliers == ref[0].n_inliers, tag
+                        n_ok += int(got[0].ok)
+                        assert got[0].n_putative_views == ref[0].n_putative_views, tag
+                        assert got[0].n_matches_2d3d == ref[0].n_matches_2d3d, tag
+                        np.testing.assert_array_equal(got[1], ref[1], err_msg=tag)
+                        np.testing.assert_array_equal(got[2], ref[2], err_msg=tag)
+                        np.testing.assert_array_equal(np.array(got[0].P).view(np.uint64),
+                                                      np.array(ref[0].P).view(np.uint64), err_msg=tag)
+                dq.close()
+            ctx.close()
+            assert n_ok >= 6, (seed, n_ok)       # the comparison is not between two failures
+    # errors: a map without .bow vectors
+    m = synth.make_map(34, n_views=20, desc_per_view=100, views_per_place=10, landmarks_per_place=80, obs_per_view=40)
+    with S.Map(m.view_id, m.view_off, m.desc, view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark,
+               landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic) as dm:
+        q = synth.make_query(m, 1, n_feat=100)
+        dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
+        ctx = dm.context()
+        with pytest.raises(S.SfmlocError):
+            ctx.begin_bow(dq, np.zeros(500, np.float32), 5)
+        ctx.close()
+        dq.close()

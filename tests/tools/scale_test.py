@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sfmlocalization_amd as S  # noqa: E402
 from sfmlocalization_amd import synth  # noqa: E402
 from oracle import oracle_c  # noqa: E402
