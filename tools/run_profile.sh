@@ -9,6 +9,9 @@ timeout -k 10 600 python bench.py > gpurun_out/bench_default.log 2>&1 || exit 1
 tail -1 gpurun_out/bench_default.log
 timeout -k 10 300 python bench.py --in-flight 1 --steps 40 --warmup 4 --no-cpu-baseline > gpurun_out/bench_latency.log 2>&1 || exit 1
 tail -1 gpurun_out/bench_latency.log | cut -c1-200
+# BASELINE configs[2]: 10 k views, BoW shortlist k = 100, with its own CPU baseline
+timeout -k 10 400 python bench.py --views 10000 --bow-knn 100 --steps 384 --warmup 16 > gpurun_out/bench_cfg3.log 2>&1 || exit 1
+tail -1 gpurun_out/bench_cfg3.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_run -- python3 $R/bench.py --steps 30 --warmup 4 --no-cpu-baseline > $R/gpurun_out/bench_prof_run.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_run -- python3 $R/bench.py --steps 6 --warmup 2 --in-flight 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch_run.log 2>&1 || exit 1
