@@ -366,6 +366,21 @@ int sfmloc_image_decode(const uint8_t *bytes, uint64_t n_bytes, int32_t color, u
                         int32_t *width, int32_t *height);
 int sfmloc_image_read(const char *path, int32_t color, uint8_t *out, uint64_t cap, int32_t *width, int32_t *height);
 
+/* The server's per-user image undistortion in front of LocalizeEngine::localize (localizeImage.cc:149-177, SURVEY
+ * 8f-4).  _create = the once-per-camera part, host arithmetic only (no device needed):
+ *   newCameraMat = getOptimalNewCameraMatrix(K, dist, size, 1.0, size, &validRoi)  +  cv::undistort's CV_16SC2 maps;
+ * _apply = the per-image part on the GPU: undistort(image, K, dist, newCameraMat) then the crop to validRoi --
+ * fixed-point bilinear remap, zero border.  K row-major 3x3; dist = k1 k2 p1 p2 [k3 [k4 k5 k6]] (n_dist 0, 4, 5, 8).
+ * src: height x width x channels (1 or 3) u8; dst: roi_h x roi_w x channels.  _info: new camera matrix [9] and
+ * validRoi [4] = x y w h; _maps: the full-size maps (xy [h*w*2] i16, frac [h*w] u16 = fy<<5|fx) for parity tests. */
+typedef struct sfmloc_undistorter sfmloc_undistorter;
+int sfmloc_undistorter_create(int device, const double *K, const double *dist, uint32_t n_dist, uint32_t width,
+                              uint32_t height, sfmloc_undistorter **out);
+void sfmloc_undistorter_destroy(sfmloc_undistorter *u);
+int sfmloc_undistorter_info(const sfmloc_undistorter *u, double *new_camera, int32_t *roi);
+int sfmloc_undistorter_maps(const sfmloc_undistorter *u, int16_t *xy, uint16_t *frac);
+int sfmloc_undistorter_apply(sfmloc_undistorter *u, const uint8_t *src, uint32_t channels, uint8_t *dst, uint64_t cap);
+
 /* Dense-BoW front end (DenseLocalFeatureWrapper.cpp:89-99): colour image (BGR, 8-bit,
  * row-major h x w x 3) -> cv::resize(size x size, INTER_CUBIC) -> BGR2GRAY -> normalize(0, 255, NORM_MINMAX);
  * gray_out [size*size].  The grid keypoints (DenseFeatureDetector.cpp:44-69) and the chaining into

@@ -28,6 +28,38 @@
 
 namespace sfmloc {
 
+// The per-user undistortion the server applies before LocalizeEngine::localize (localizeImage.cc:149-177):
+// getOptimalNewCameraMatrix(K, dist, size, 1.0, size, &validRoi) once, then cv::undistort + crop per image (GPU).
+class Undistorter {
+ public:
+  Undistorter(const double K[9], const std::vector<double> &dist, int width, int height, int device = 0) {
+    if (sfmloc_undistorter_create(device, K, dist.empty() ? nullptr : dist.data(), (uint32_t)dist.size(), (uint32_t)width,
+                                  (uint32_t)height, &mU))
+      throw std::runtime_error(sfmloc_last_error());
+    sfmloc_undistorter_info(mU, mNewCamera, mRoi);
+  }
+  Undistorter(const Undistorter &) = delete;
+  Undistorter &operator=(const Undistorter &) = delete;
+  ~Undistorter() { sfmloc_undistorter_destroy(mU); }
+  const double *newCameraMatrix() const { return mNewCamera; }  // 3x3 row-major
+  int roiX() const { return mRoi[0]; }
+  int roiY() const { return mRoi[1]; }
+  int roiWidth() const { return mRoi[2]; }
+  int roiHeight() const { return mRoi[3]; }
+  // src: height x width x channels (1 or 3) -> the valid region, roiHeight() x roiWidth() x channels
+  std::vector<uint8_t> apply(const uint8_t *src, int channels) {
+    std::vector<uint8_t> out((size_t)mRoi[2] * mRoi[3] * channels);
+    if (sfmloc_undistorter_apply(mU, src, (uint32_t)channels, out.data(), out.size()))
+      throw std::runtime_error(sfmloc_last_error());
+    return out;
+  }
+
+ private:
+  sfmloc_undistorter *mU = nullptr;
+  double mNewCamera[9];
+  int32_t mRoi[4];
+};
+
 class LocalizeEngine {
  public:
   LocalizeEngine(const std::string &sfmDataDir, const std::string &matchDir, const std::string &AmatFile,

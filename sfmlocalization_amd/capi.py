@@ -112,6 +112,8 @@ SYMBOLS = [
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
     "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
     "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close", "sfmloc_localize_bow_begin",
+    "sfmloc_undistorter_create", "sfmloc_undistorter_destroy", "sfmloc_undistorter_info", "sfmloc_undistorter_maps",
+    "sfmloc_undistorter_apply",
 ]
 
 _bound = False
@@ -294,6 +296,60 @@ def image_read(path, color=False):
     out = np.zeros((h.value, w.value, 3) if color else (h.value, w.value), np.uint8)
     _check(L.sfmloc_image_read(bpath, int(bool(color)), _ptr(out, C.c_uint8), out.size, C.byref(w), C.byref(h)))
     return out
+
+
+class Undistorter:
+    """sfmloc_undistorter: the server's per-user undistortion (localizeImage.cc:149-177).  new_camera (3x3) and roi
+    (x, y, w, h) are what getOptimalNewCameraMatrix(K, dist, size, 1.0, size, &validRoi) returns; apply() is
+    cv::undistort + the crop to validRoi, on the GPU."""
+
+    def __init__(self, K, dist, width, height, device=0):
+        L = _L()
+        L.sfmloc_undistorter_create.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint32,
+                                                C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sfmloc_undistorter_destroy.restype = None
+        L.sfmloc_undistorter_destroy.argtypes = [C.c_void_p]
+        L.sfmloc_undistorter_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.sfmloc_undistorter_maps.argtypes = [C.c_void_p, C.POINTER(C.c_int16), C.POINTER(C.c_uint16)]
+        L.sfmloc_undistorter_apply.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint8),
+                                               C.c_uint64]
+        Kc = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        d = np.ascontiguousarray(dist, dtype=np.float64).ravel()
+        self._h = C.c_void_p()
+        self.width, self.height = int(width), int(height)
+        _check(L.sfmloc_undistorter_create(device, _ptr(Kc, C.c_double), _ptr(d, C.c_double) if d.size else None,
+                                           d.size, self.width, self.height, C.byref(self._h)))
+        P = np.zeros(9, np.float64)
+        roi = np.zeros(4, np.int32)
+        _check(L.sfmloc_undistorter_info(self._h, _ptr(P, C.c_double), _ptr(roi, C.c_int32)))
+        self.new_camera = P.reshape(3, 3)
+        self.roi = tuple(int(v) for v in roi)
+
+    def maps(self):
+        xy = np.zeros((self.height, self.width, 2), np.int16)
+        fr = np.zeros((self.height, self.width), np.uint16)
+        _check(_L().sfmloc_undistorter_maps(self._h, _ptr(xy, C.c_int16), _ptr(fr, C.c_uint16)))
+        return xy, fr
+
+    def apply(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        if img.shape[0] != self.height or img.shape[1] != self.width:
+            raise ValueError("Undistorter.apply: image size differs from the plan's")
+        out = np.zeros((self.roi[3], self.roi[2]) if img.ndim == 2 else (self.roi[3], self.roi[2], ch), np.uint8)
+        _check(_L().sfmloc_undistorter_apply(self._h, _ptr(img, C.c_uint8), ch, _ptr(out, C.c_uint8), out.size))
+        return out
+
+    def close(self):
+        if self._h:
+            _L().sfmloc_undistorter_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def debug_math(op, x, out_stride, device=0):

@@ -155,6 +155,26 @@ class LocalizeEngine:
         return list(c) + list(R.ravel()), extras
 
 
+class UserCamera:
+    """What execLocalizeImage keeps per user (localizeImage.cc:133-168): the user's K and dist (OpenCV YAML files with
+    the keys "K" and "dist"), and from them the new camera matrix, the valid region and the undistortion maps."""
+
+    def __init__(self, k_mat_file, dist_mat_file, width, height, device=0):
+        self.K = np.asarray(fileio.read_cv_yaml(k_mat_file)["K"], np.float64).reshape(3, 3)
+        self.dist = np.asarray(fileio.read_cv_yaml(dist_mat_file)["dist"], np.float64).ravel()
+        self.undistorter = capi.Undistorter(self.K, self.dist, width, height, device=device)
+
+    def close(self):
+        self.undistorter.close()
+
+
+def exec_localize_image(engine, camera, bgr, **kw):
+    """execLocalizeImage (localizeImage.cc:61-200) from the decoded image on: undistort with the user's camera, crop to
+    the valid region, LocalizeEngine::localize.  -> (result, extras) as LocalizeEngine.localize_image."""
+    und = camera.undistorter.apply(bgr)          # cv::undistort + undistortImage(validRoi)
+    return engine.localize_image(und, **kw)
+
+
 def dense_grid_keypoints(size=300, step=6, levels=4, init_scale=4.0, scale_mul=1.5, bound=0):
     """DenseFeatureDetector::detectImpl (BoWCommon/src/DenseFeatureDetector.cpp:44-69) with the constants of
     DenseLocalFeatureWrapper.h:32-38: per scale level s a regular grid (x fastest), size = init_scale * mul^s,

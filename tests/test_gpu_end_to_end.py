@@ -110,6 +110,21 @@ def test_image_to_pose(tmp_path):
             n_ok += 1
             assert np.abs(np.array(res[0:3]) - C).max() < 0.2
     assert n_ok >= 2
+    # the server's whole chain (execLocalizeImage, localizeImage.cc:133-200): the user's K / dist files -> undistort
+    # (GPU) -> crop to the valid region -> localize.  A distortion-free user camera: the undistorted image is the
+    # input resampled by a fraction of a pixel, and the pose stays where it was.
+    fileio.write_cv_yaml(tmp_path / "K.yml", {"K": np.array([[F, 0, W / 2.0], [0, F, H / 2.0], [0, 0, 1.0]])})
+    fileio.write_cv_yaml(tmp_path / "dist.yml", {"dist": np.zeros((1, 5))})
+    cam = engine.UserCamera(str(tmp_path / "K.yml"), str(tmp_path / "dist.yml"), W, H)
+    assert cam.undistorter.roi[2] >= W - 2 and cam.undistorter.roi[3] >= H - 2
+    n_ok = 0
+    for name, (R, C) in truth.items():
+        res, ex = engine.exec_localize_image(eng, cam, S.image_read(str(jdir / f"{name}.jpg"), color=True))
+        if res:
+            n_ok += 1
+            assert np.abs(np.array(res[0:3]) - C).max() < 0.3
+    assert n_ok >= 2
+    cam.close()
     eng.close()
     # BoW shortlist computed from the query IMAGE (-k -a -p): dense AKAZE -> PCA -> BoF in both programs; the map's
     # .bow files hold what the same chain gives for the map images, so the shortlist is meaningful
