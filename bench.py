@@ -65,6 +65,12 @@ def parse():
                     help="> 0: BASELINE configs[2] -- every query first shortlists this many views by BoW distance "
                          "(sfmloc_bow_select over a synthetic .bow matrix) and runs the path on those (1 GPU only); "
                          "use with --views 10000")
+    ap.add_argument("--from-images", action="store_true",
+                    help="image-in serving mode (1 GPU): every step first extracts AKAZE + M-LDB features from a synthetic "
+                         "640x480 image on the GPU (sfmloc_akaze_detect_and_compute, its own stream), then localises the "
+                         "step's query; --in-flight worker threads, one extractor and one context each.  The map is "
+                         "synthetic, so the localised descriptors are the synthetic query's, not the image's: the point is "
+                         "the cost of extraction sharing the GPU and the host with the path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -247,6 +253,40 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    img_mode = None
+    if a.from_images:
+        if sharded is not None:
+            raise SystemExit("--from-images is a single-GPU mode")
+        import threading
+        imgs = [synth.texture_image(900 + k, 480, 640) for k in range(4)]
+        extractors = [S.Akaze(640, 480, device=local_rank) for _ in range(nctx)]
+        n_feat = [0]
+        lock = threading.Lock()
+
+        def worker(k, first, count):
+            for i in range(first + k, first + count, nctx):
+                t1 = time.perf_counter()
+                kp, _ = extractors[k].detect_and_compute(imgs[i % len(imgs)])
+                if qbow is not None:
+                    ctxs[k].begin_bow(dqs[i % len(dqs)], qbow[i % len(dqs)], a.bow_knn)
+                else:
+                    ctxs[k].begin(dqs[i % len(dqs)])
+                pose, _, _ = ctxs[k].end()
+                with lock:
+                    lat.append(time.perf_counter() - t1)
+                    n_ok[0] += int(pose.ok)
+                    n_feat[0] = len(kp)
+
+        def run_images(first, count):
+            ts = [threading.Thread(target=worker, args=(k, first, count)) for k in range(nctx)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+
+        run = run_images  # noqa: F811
+        img_mode = {"extractors": extractors, "n_feat": n_feat}
+
     run(0, a.warmup)
     fence()
     dev_map.stats_reset()
@@ -345,6 +385,10 @@ def main():
                                   "pairs_finished_frac": st.hamming_pairs_finished / max(1, st.hamming_pairs),
                                   "rows_flagged_per_query": st.hamming_rows_flagged / max(1, st.launches[0])}},
         }
+        if img_mode is not None:
+            out["config"]["workload"] += ("; image-in mode: each step first runs AKAZE + M-LDB extraction of a 640x480 "
+                                          f"synthetic image on the GPU ({img_mode['n_feat'][0]} keypoints)")
+            out["latency_ms"]["p50_image_in_at_throughput"] = float(np.percentile(lat_throughput, 50) * 1e3)
         if iso is not None:
             # the same kernel with nothing else on the GPU (the latency phase): what the kernel itself achieves; in
             # the timed region its launches share the chip with the other queries in flight, which stretches them
@@ -358,6 +402,9 @@ def main():
             out["cpu_baseline"] = (cpu_baseline_shortlist(m, queries, bow, qbow, a.bow_knn, a.cpu_seconds)
                                    if a.bow_knn > 0 else cpu_baseline(m, queries, a.cpu_seconds))
         print(json.dumps(out), flush=True)
+    if img_mode is not None:
+        for e in img_mode["extractors"]:
+            e.close()
     for c in ctxs:
         c.close()
     if sharded is not None:
