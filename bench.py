@@ -16,8 +16,10 @@ import sys
 import time
 
 # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
+# (so does the image-in mode: a context and an extractor stream per worker)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or
-                                                    os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1") else "8")
+                                                    os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1" or
+                                                    "--from-images" in sys.argv) else "8")
 
 import numpy as np  # noqa: E402
 
