@@ -318,21 +318,6 @@ __global__ void k_kcontrast(const unsigned int *hmax_bits, const unsigned int *h
   *kcontrast = (nelements < nthreshold) ? 0.03f : hmax * ((float)k / 300.0f);
 }
 
-// pm_g2 with the contrast factor of this octave (kcontrast * 0.75 per octave change)
-// pm_g2 of the Scharr gradient of Lsmooth (scale 1, weights 3/10), the two derivative images never stored
-__global__ void k_flow_g2(const float *__restrict__ ls, float *__restrict__ dst, int w, int h,
-                          const float *kcontrast, int octave);
-
-__global__ void k_pm_g2(const float *__restrict__ lx, const float *__restrict__ ly, float *__restrict__ dst, size_t n,
-                        const float *kcontrast, int octave) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float kc = *kcontrast;
-  for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
-  const float inv_k = 1.0f / (kc * kc);
-  dst[i] = 1.0f / (1.0f + inv_k * (lx[i] * lx[i] + ly[i] * ly[i]));
-}
-
 // nld_step_scalar: Ld_out = Ld + half_step * flux, zero flux across the image border -- up to K steps in one launch
 // (temporal blocking): a 32 x 8 tile is loaded with a halo of K pixels, step s is computed in LDS on the tile grown by
 // K - 1 - s pixels, the last step on the tile itself.  Per pixel the arithmetic is that of a step-per-launch kernel, so
@@ -405,35 +390,107 @@ __device__ __forceinline__ float scharr_at(const float *__restrict__ src, int w,
   return wm * r0 + ws * (rm + rp);
 }
 
-__global__ void k_flow_g2(const float *__restrict__ ls, float *__restrict__ dst, int w, int h,
-                          const float *kcontrast, int octave) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  const float lx = scharr_at(ls, w, h, x, y, 1, 1, 3.0f, 10.0f);
-  const float ly = scharr_at(ls, w, h, x, y, 0, 1, 3.0f, 10.0f);
+// gaussian_2D_convolution(5 x 5, separable, BORDER_REPLICATE) of the level's start image -> Lsmooth, and the
+// Perona-Malik g2 conductivity 1 / (1 + |grad Lsmooth|^2 / k^2) from it (Scharr, scale 1), in one launch: a 32 x 8
+// tile with the source halo in LDS (3 px: 2 for the taps of the column pass's rows / the row pass's columns, 1 for the
+// Scharr stencil on Lsmooth).  The row pass, the column pass and the Scharr sums run in the order a kernel per pass
+// would use, so the images are the same bit for bit.
+__global__ __launch_bounds__(256) void k_smooth_flow(const float *__restrict__ src, float *__restrict__ lsmooth,
+                                                     float *__restrict__ g2, int w, int h, Taps t,
+                                                     const float *kcontrast, int octave) {
+  constexpr int TX = 32, TY = 8;
+  constexpr int SX = TX + 6, SY = TY + 6;  // source region
+  constexpr int MX = TX + 2, MY = TY + 6;  // row-pass region: Lsmooth's columns, the column pass's rows
+  constexpr int LX = TX + 2, LY = TY + 2;  // Lsmooth region
+  __shared__ float sS[SY][SX + 1];
+  __shared__ float sM[MY][MX + 1];
+  __shared__ float sL[LY][LX + 1];
+  const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int ly = ty; ly < SY; ly += TY)
+    for (int lx = tx; lx < SX; lx += TX) {
+      const int gx = X0 - 3 + lx, gy = Y0 - 3 + ly;
+      sS[ly][lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? src[(size_t)gy * w + gx] : 0.0f;
+    }
+  __syncthreads();
+  for (int ly = ty; ly < MY; ly += TY)  // row pass at (X0 - 1 + lx, Y0 - 3 + ly)
+    for (int lx = tx; lx < MX; lx += TX) {
+      const int gx = X0 - 1 + lx, gy = Y0 - 3 + ly;
+      if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+      float acc = 0.0f;
+      for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * sS[ly][clampi(gx + i - 2, 0, w - 1) - (X0 - 3)];
+      sM[ly][lx] = acc;
+    }
+  __syncthreads();
+  for (int ly = ty; ly < LY; ly += TY)  // column pass at (X0 - 1 + lx, Y0 - 1 + ly)
+    for (int lx = tx; lx < LX; lx += TX) {
+      const int gx = X0 - 1 + lx, gy = Y0 - 1 + ly;
+      if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+      float acc = 0.0f;
+      for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * sM[clampi(gy + i - 2, 0, h - 1) - (Y0 - 3)][lx];
+      sL[ly][lx] = acc;
+      if (lx >= 1 && lx <= TX && ly >= 1 && ly <= TY) lsmooth[(size_t)gy * w + gx] = acc;
+    }
+  __syncthreads();
+  const int x = X0 + tx, y = Y0 + ty;
+  if (x >= w || y >= h) return;
+  const int xm = reflect101(x - 1, w) - (X0 - 1), xp = reflect101(x + 1, w) - (X0 - 1), xc = tx + 1;
+  const int ym = reflect101(y - 1, h) - (Y0 - 1), yp = reflect101(y + 1, h) - (Y0 - 1), yc = ty + 1;
+  const float ws = 3.0f, wm = 10.0f;
+  float lx_, ly_;
+  {
+    const float r0 = sL[yc][xp] - sL[yc][xm], rm = sL[ym][xp] - sL[ym][xm], rp = sL[yp][xp] - sL[yp][xm];
+    lx_ = wm * r0 + ws * (rm + rp);
+  }
+  {
+    const float r0 = sL[yp][xc] - sL[ym][xc], rm = sL[yp][xm] - sL[ym][xm], rp = sL[yp][xp] - sL[ym][xp];
+    ly_ = wm * r0 + ws * (rm + rp);
+  }
   float kc = *kcontrast;
   for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
   const float inv_k = 1.0f / (kc * kc);
-  dst[(size_t)y * w + x] = 1.0f / (1.0f + inv_k * (lx * lx + ly * ly));
+  g2[(size_t)y * w + x] = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
 }
 
-__global__ void k_scharr_xy(const float *__restrict__ src, float *__restrict__ lx, float *__restrict__ ly, int w, int h,
-                            int scale, float ws, float wm) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  lx[(size_t)y * w + x] = scharr_at(src, w, h, x, y, 1, scale, ws, wm);
-  ly[(size_t)y * w + x] = scharr_at(src, w, h, x, y, 0, scale, ws, wm);
+// Compute_Multiscale_Derivatives, Compute_Determinant_Hessian_Response and the candidate pass of
+// Find_Scale_Space_Extrema run on the finished scale space and are independent between evolution levels: one launch over
+// ALL levels each (blockIdx.y = a row of the stacked images) instead of one per level -- 48 launches become 3.
+struct LevelTab {
+  int n;
+  int row0[kMaxLevels + 1];  // first stacked row of each level
+  int w[kMaxLevels], h[kMaxLevels], sc[kMaxLevels], sigma_size[kMaxLevels];
+  unsigned int off[kMaxLevels];
+  float ws[kMaxLevels], wm[kMaxLevels];
+};
+
+__device__ __forceinline__ int level_of_row(const LevelTab &T, int row) {
+  int i = 0;
+  while (i + 1 < T.n && row >= T.row0[i + 1]) ++i;
+  return i;
 }
 
-__global__ void k_hessian_det(const float *__restrict__ lx, const float *__restrict__ ly, float *__restrict__ ldet,
-                              int w, int h, int scale, float ws, float wm, float sf2) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+__global__ void k_scharr_xy_all(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly, LevelTab T) {
+  const int i = level_of_row(T, blockIdx.y);
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
   if (x >= w) return;
+  const float *src = ls + T.off[i];
+  lx[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 1, T.sc[i], T.ws[i], T.wm[i]);
+  ly[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 0, T.sc[i], T.ws[i], T.wm[i]);
+}
+
+__global__ void k_hessian_det_all(const float *__restrict__ lx_all, const float *__restrict__ ly_all,
+                                  float *__restrict__ ldet, LevelTab T) {
+  const int i = level_of_row(T, blockIdx.y);
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
+  if (x >= w) return;
+  const float *lx = lx_all + T.off[i], *ly = ly_all + T.off[i];
+  const int scale = T.sc[i];
+  const float ws = T.ws[i], wm = T.wm[i], sf2 = (float)(scale * scale);
   const float lxx = scharr_at(lx, w, h, x, y, 1, scale, ws, wm);
   const float lyy = scharr_at(ly, w, h, x, y, 0, scale, ws, wm);
   const float lxy = scharr_at(lx, w, h, x, y, 0, scale, ws, wm);
   const float a = lxx * sf2, b = lxy * sf2, c = lyy * sf2;
-  ldet[(size_t)y * w + x] = a * c - b * b;
+  ldet[T.off[i] + (size_t)y * w + x] = a * c - b * b;
 }
 
 struct Candidate9 {
@@ -442,13 +499,12 @@ struct Candidate9 {
   float pad2[3];
 };
 
-// Find_Scale_Space_Extrema, the order-independent part: 3x3 strict maxima above the threshold that also pass the
-// descriptor-support border test (candidates failing it never change OpenCV's keypoint list)
-__global__ void k_extrema(const float *__restrict__ ldet, int w, int h, int level, int sigma_size_, float dthreshold,
-                          Candidate9 *out, unsigned int cap, unsigned int *n_out) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+__global__ void k_extrema_all(const float *__restrict__ ldet_all, LevelTab T, float dthreshold, Candidate9 *out,
+                              unsigned int cap, unsigned int *n_out) {
+  const int i = level_of_row(T, blockIdx.y);
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
   if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
-  const float *D = ldet;
+  const float *D = ldet_all + T.off[i];
   const float v = D[(size_t)y * w + x];
   if (!(v > dthreshold && v >= 0.00001f)) return;
   float p[9];
@@ -456,17 +512,18 @@ __global__ void k_extrema(const float *__restrict__ ldet, int w, int h, int leve
     for (int dx = -1; dx <= 1; ++dx) p[(dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
   if (!(v > p[3] && v > p[5] && v > p[0] && v > p[1] && v > p[2] && v > p[6] && v > p[7] && v > p[8])) return;
   const float smax = 10.0f * sqrtf(2.0f);
+  const int sigma_size_ = T.sigma_size[i];
   const int left_x = fround_d((float)x - smax * sigma_size_) - 1, right_x = fround_d((float)x + smax * sigma_size_) + 1;
   const int up_y = fround_d((float)y - smax * sigma_size_) - 1, down_y = fround_d((float)y + smax * sigma_size_) + 1;
   if (left_x < 0 || right_x >= w || up_y < 0 || down_y >= h) return;
   const unsigned int slot = atomicAdd(n_out, 1u);
   if (slot >= cap) return;
   Candidate9 c;
-  c.level = level;
+  c.level = i;
   c.x = x;
   c.y = y;
   c.pad = 0;
-  for (int i = 0; i < 9; ++i) c.patch[i] = p[i];
+  for (int k = 0; k < 9; ++k) c.patch[k] = p[k];
   c.pad2[0] = c.pad2[1] = c.pad2[2] = 0.0f;
   out[slot] = c;
 }
@@ -667,6 +724,30 @@ int scharr(Akaze *a, const float *src, float *dst, int w, int h, int xorder, int
   return SFMLOC_OK;
 }
 
+LevelTab level_tab(const Akaze *a) {
+  const AkPlan &P = a->plan;
+  LevelTab T;
+  memset(&T, 0, sizeof(T));
+  T.n = P.nlev;
+  int row = 0;
+  for (int i = 0; i < P.nlev; ++i) {
+    const AkLevel &L = P.lev[i];
+    const float wgt = 10.0f / 3.0f;
+    const float norm = 1.0f / (2.0f * (float)L.sigma_size * (wgt + 2.0f));
+    T.row0[i] = row;
+    T.w[i] = L.w;
+    T.h[i] = L.h;
+    T.sc[i] = L.sigma_size;
+    T.off[i] = (unsigned int)L.off;
+    T.ws[i] = norm;
+    T.wm[i] = wgt * norm;
+    T.sigma_size[i] = fround_h(L.esigma * 1.5f / (float)(1 << L.octave));  // the extrema pass's border test
+    row += L.h;
+  }
+  T.row0[P.nlev] = row;
+  return T;
+}
+
 // Create_Nonlinear_Scale_Space + Compute_Multiscale_Derivatives + Compute_Determinant_Hessian_Response
 int build_scale_space(Akaze *a, const uint8_t *gray) {
   const AkPlan &P = a->plan;
@@ -706,10 +787,12 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
       hipLaunchKernelGGL(k_halfsample, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lt + Lp.off, Lp.w, Lp.h, half, L.w, L.h);
       start = half;
     }
-    rc = gauss(a, start, a->d_Lsmooth + L.off, a->d_t0, L.w, L.h, P.g10, 5);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_flow_g2, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lsmooth + L.off, a->d_t2, L.w, L.h,
-                       a->d_kcontrast, L.octave);
+    {
+      Taps t5;
+      for (int k = 0; k < 9; ++k) t5.k[k] = k < 5 ? P.g10[k] : 0.0f;
+      hipLaunchKernelGGL(k_smooth_flow, dim3((L.w + 31) / 32, (L.h + 7) / 8), dim3(256), 0, s, start,
+                         a->d_Lsmooth + L.off, a->d_t2, L.w, L.h, t5, a->d_kcontrast, L.octave);
+    }
     const float *cur = start;
     // destination of step st: alternate so that step nsteps-1 writes Lt; `start` is never written
     const dim3 tgrid((L.w + kNldTileX - 1) / kNldTileX, (L.h + kNldTileY - 1) / kNldTileY);
@@ -730,18 +813,11 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
     if (L.nsteps == 0 && start != Lt)
       AK_HIP(hipMemcpyAsync(Lt, start, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
-  for (int i = 0; i < P.nlev; ++i) {
-    const AkLevel &L = P.lev[i];
-    const int sc = L.sigma_size;
-    const float wgt = 10.0f / 3.0f;
-    const float norm = 1.0f / (2.0f * (float)sc * (wgt + 2.0f));
-    const float ws = norm, wm = wgt * norm;
-    float *Ls = a->d_Lsmooth + L.off, *Lx = a->d_Lx + L.off, *Ly = a->d_Ly + L.off;
-    hipLaunchKernelGGL(k_scharr_xy, grid2(L.w, L.h), dim3(128), 0, s, Ls, Lx, Ly, L.w, L.h, sc, ws, wm);
-    hipLaunchKernelGGL(k_hessian_det, grid2(L.w, L.h), dim3(128), 0, s, Lx, Ly, a->d_Ldet + L.off, L.w, L.h, sc, ws, wm,
-                       (float)(sc * sc));
-    AK_HIP(hipGetLastError());
-  }
+  const LevelTab T = level_tab(a);
+  const dim3 agrid((a->w + 127) / 128, T.row0[T.n]);
+  hipLaunchKernelGGL(k_scharr_xy_all, agrid, dim3(128), 0, s, a->d_Lsmooth, a->d_Lx, a->d_Ly, T);
+  hipLaunchKernelGGL(k_hessian_det_all, agrid, dim3(128), 0, s, a->d_Lx, a->d_Ly, a->d_Ldet, T);
+  AK_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
@@ -900,12 +976,10 @@ int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float
   if (rc) return rc;
   // candidates of every level
   SFM_HIP(hipMemsetAsync(a->d_ncand, 0, sizeof(unsigned int), a->stream));
-  for (int i = 0; i < P.nlev; ++i) {
-    const AkLevel &L = P.lev[i];
-    const float ratio = (float)(1 << L.octave);
-    const int sigma_size_ = fround_h(L.esigma * 1.5f / ratio);
-    hipLaunchKernelGGL(k_extrema, grid2(L.w, L.h), dim3(128), 0, a->stream, a->d_Ldet + L.off, L.w, L.h, i, sigma_size_,
-                       a->thres, a->d_cand, a->cand_cap, a->d_ncand);
+  {
+    const LevelTab T = level_tab(a);
+    hipLaunchKernelGGL(k_extrema_all, dim3((a->w + 127) / 128, T.row0[T.n]), dim3(128), 0, a->stream, a->d_Ldet, T, a->thres,
+                       a->d_cand, a->cand_cap, a->d_ncand);
   }
   SFM_HIP(hipGetLastError());
   unsigned int nc = 0;
