@@ -229,20 +229,42 @@ __device__ __forceinline__ uint64_t sorted_key_at(const uint64_t (&key)[E], int 
 
 // logcombi tables of OpenMVG (float): logc_n[k] = log10 C(n,k), logc_k[m] = log10 C(m,s); L10[i] = log10(i).
 // logcombi(k,n) = sum_{i=1..min(k,n-k)} (L10[n-i+1] - L10[i]) accumulated in double in that order, so the
-// values for k = 0..n/2 are the running sums of one sequential pass (thread 0); the rest is symmetry.
-__device__ void logcombi_tables_block(int s, int n, const double *__restrict__ L10, float *logc_n, float *logc_k) {
+// values for k = 0..n/2 are the running sums of one sequential pass; the rest is symmetry.  The pass itself cannot be
+// split (the rounding of every partial sum is part of the result), but its terms can be fetched by the whole
+// workgroup: `terms` (n / 2 + 1 doubles of LDS) takes L10[n-k+1] - L10[k], then thread 0 adds them up out of LDS with
+// eight loads in flight -- the same sums as a loop over global memory, which cost ~50 us of dependent L2 latency per
+// call on the critical path of K3 and K5.
+__device__ void logc_n_block(int n, const double *__restrict__ L10, double *terms, float *logc_n, int n_threads) {
+  const int kmax = n / 2;  // 2 k <= n
+  for (int k = 1 + (int)threadIdx.x; k <= kmax; k += n_threads) terms[k] = L10[n - k + 1] - L10[k];
+  __syncthreads();
   if (threadIdx.x == 0) {
     double r = 0.0;
     logc_n[0] = 0.0f;
     logc_n[n] = 0.0f;
-    for (int k = 1; 2 * k <= n; ++k) {
-      if (k < n) {
-        r += L10[n - k + 1] - L10[k];
-        logc_n[k] = (float)r;
-        logc_n[n - k] = (float)r;
+    int k = 1;
+    for (; k + 7 <= kmax; k += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = terms[k + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        r += t[u];
+        logc_n[k + u] = (float)r;
+        logc_n[n - k - u] = (float)r;
       }
     }
+    for (; k <= kmax; ++k) {
+      r += terms[k];
+      logc_n[k] = (float)r;
+      logc_n[n - k] = (float)r;
+    }
   }
+}
+
+__device__ void logcombi_tables_block(int s, int n, const double *__restrict__ L10, double *terms, float *logc_n,
+                                      float *logc_k) {
+  logc_n_block(n, L10, terms, logc_n, kThreads);
   for (int m = threadIdx.x; m <= n; m += kThreads) {
     float v = 0.0f;
     if (s < m) {
@@ -351,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
     return seven_point(x1, x2, models);
   };
 
-  logcombi_tables_block(s, m, A.L10, S.logc_n, S.logc_k);
+  logcombi_tables_block(s, m, A.L10, reinterpret_cast<double *>(S.key), S.logc_n, S.logc_k);  // S.key: free until the first sort
 
   double min_nfa = pos_inf();
   int n_in = 0;
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
 //     evaluate the (up to 3) models side by side.
 // Results are bit-identical to k_fmatrix_filter (same samples, same arithmetic per value, same tie rules).
 // ---------------------------------------------------------------------------------------------------
-constexpr int kF2Waves = 8;
+constexpr int kF2Waves = 16;
 constexpr int kF2Threads = kF2Waves * 64;
 constexpr int kF2MaxM = 512;   // putative matches per view (one wave sorts one model's residuals)
 constexpr int kF2Batch = 32;   // uniform iterations solved speculatively per batch
@@ -548,19 +570,8 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
     S.pts[p][2] = s2 * (double)b.x + t2x;
     S.pts[p][3] = s2 * (double)b.y + t2y;
   }
-  // logcombi tables (logcombi_tables_block is written for 256 threads)
-  if (tid == 0) {
-    double r = 0.0;
-    S.logc_n[0] = 0.0f;
-    S.logc_n[m] = 0.0f;
-    for (int k = 1; 2 * k <= m; ++k) {
-      if (k < m) {
-        r += A.L10[m - k + 1] - A.L10[k];
-        S.logc_n[k] = (float)r;
-        S.logc_n[m - k] = (float)r;
-      }
-    }
-  }
+  // logcombi tables (logcombi_tables_block is written for 256 threads); pre_models is free until the first batch
+  logc_n_block(m, A.L10, &S.pre_models[0][0], S.logc_n, kF2Threads);
   for (int q = tid; q <= m; q += kF2Threads) {
     float val = 0.0f;
     if (s < q) {
@@ -991,7 +1002,8 @@ __global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
     A.xn[2 * i] = A.pt2d[2 * i] * inv_f + cx;
     A.xn[2 * i + 1] = A.pt2d[2 * i + 1] * inv_f + cy;
   }
-  logcombi_tables_block(3, n, A.L10, A.logc_n, A.logc_k);
+  __shared__ double s_terms[kP3pMaxN / 2 + 1];
+  logcombi_tables_block(3, n, A.L10, s_terms, A.logc_n, A.logc_k);
 }
 
 constexpr int kP3pWaveSeg = kP3pMaxN / 4;  // elements one wave sorts when the four models run side by side
