@@ -285,6 +285,23 @@ struct ClearedScope {  // the flag must not outlive the call that set it
   ~ClearedScope() { c->cleared = false; }
 };
 
+// A short scan is cut into query slices (more waves, better balance, ~7 % more arithmetic) only when the GPU has
+// nothing else to fill it with, i.e. when no other context of the map has work queued.
+static void ctx_mark_busy(Ctx *c) {
+  Map *m = c->map;
+  c->k1_may_slice = m->busy_ctx.load(std::memory_order_relaxed) - (c->counted_busy ? 1 : 0) <= 0;
+  if (!c->counted_busy) {
+    c->counted_busy = true;
+    m->busy_ctx.fetch_add(1, std::memory_order_relaxed);
+  }
+}
+static void ctx_mark_idle(Ctx *c) {
+  if (c->counted_busy) {
+    c->counted_busy = false;
+    c->map->busy_ctx.fetch_sub(1, std::memory_order_relaxed);
+  }
+}
+
 int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel = nullptr);
 int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel = nullptr);
 
@@ -443,8 +460,17 @@ int ctx_resection_wait(Ctx *c) {
   return SFMLOC_EHIP;
 }
 
+static int ctx_localize_begin_impl(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel);
+
 int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel) {
   SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_localize_begin: context already has a query in flight");
+  ctx_mark_busy(c);
+  const int rc = ctx_localize_begin_impl(c, q, view_sel, n_sel, d_sel);
+  if (rc) ctx_mark_idle(c);
+  return rc;
+}
+
+static int ctx_localize_begin_impl(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel) {
   c->t_begin = now_s();
   ClearedScope cs{c};
   int rc = ctx_reset_for_query(c, q);
@@ -471,6 +497,7 @@ int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_se
 int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t cap) {
   SFM_CHECK(c->in_flight != nullptr, SFMLOC_EINVAL, "sfmloc_localize_end: no query in flight on this context");
   c->in_flight = nullptr;
+  ctx_mark_idle(c);
   int rc = ctx_resection_wait(c);
   if (rc) return rc;
   HostResult *h = reinterpret_cast<HostResult *>(c->h_result);
@@ -713,6 +740,7 @@ void sfmloc_context_destroy(sfmloc_context *ctx) {
   if (!c) return;
   Map *m = c->map;
   hipSetDevice(m->device);
+  ctx_mark_idle(c);
   auto it = std::find(m->pool.begin(), m->pool.end(), c);
   if (it != m->pool.end()) m->pool.erase(it);
   auto ib = std::find(m->batch_ctx.begin(), m->batch_ctx.end(), c);
@@ -1051,6 +1079,7 @@ int sfmloc_shard_begin(sfmloc_context *ctx, sfmloc_query *query, const uint32_t 
   SFM_CHECK(q->map == c->map, SFMLOC_EINVAL, "sfmloc_shard_begin: query belongs to another map");
   SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_shard_begin: context has a query in flight");
   SFM_HIP(hipSetDevice(c->map->device));
+  ctx_mark_busy(c);  // until sfmloc_context_sync
   ClearedScope cs{c};
   int rc = ctx_reset_for_query(c, q);
   if (rc) return rc;
@@ -1080,6 +1109,7 @@ int sfmloc_context_sync(sfmloc_context *ctx) {
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   SFM_HIP(hipSetDevice(c->map->device));
   SFM_HIP(hipStreamSynchronize(c->stream));
+  if (c->in_flight == nullptr) ctx_mark_idle(c);
   return SFMLOC_OK;
 }
 

@@ -163,15 +163,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
   uint32_t T = 0;                                            // accept needs (nearest distance) < T
   bool flag = false;
   uint32_t n_finished = 0;
-  for (uint32_t j0 = 0; j0 < nq; j0 += lds_rows) {
-    const uint32_t cnt = min(lds_rows, nq - j0);
+  // gridDim.y > 1 (short block lists): this workgroup screens the query rows [j_begin, j_end) only, with its own exact
+  // head and threshold.  A bank row that the whole query would accept is accepted by the slice holding its nearest row
+  // (the slice's second-nearest is no nearer than the global one), so the union of the slices' flags still covers
+  // every accepted row; k_hamming_rows then recomputes the flagged rows against ALL query rows, as before.
+  const uint32_t per = (nq + gridDim.y - 1) / gridDim.y;
+  const uint32_t j_begin = blockIdx.y * per, j_end = min(nq, j_begin + per), head_end = j_begin + head;
+  for (uint32_t j0 = j_begin; j0 < j_end; j0 += lds_rows) {
+    const uint32_t cnt = min(lds_rows, j_end - j0);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
     __syncthreads();
     if (!valid) continue;
     uint32_t jj = 0;
     // (a) exact head
-    for (; jj < cnt && j0 + jj < head; ++jj) {
+    for (; jj < cnt && j0 + jj < head_end; ++jj) {
       const uint4 q0 = qs[jj * 4 + 0], q1 = qs[jj * 4 + 1], q2 = qs[jj * 4 + 2], q3 = qs[jj * 4 + 3];
       const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                               q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
       top2_push(best0, best1, (acc << 16) | (j0 + jj));
-      if (j0 + jj + 1 == head || j0 + jj + 1 == nq) {
+      if (j0 + jj + 1 == head_end || j0 + jj + 1 == j_end) {
         T = (best1 != SFMLOC_NOMATCH) ? (uint32_t)cnt_s[best1 >> 16] : 0u;
         flag = (best0 >> 16) < T;
       }
@@ -250,8 +256,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
   const uint32_t pidx = w0 * 64 + lane;
   // unflagged rows are rejected: K2 reads the mask and never touches their (stale) partial-result slots, so the
   // only per-row bytes this kernel writes are 8 per 64 rows
-  const unsigned long long mask = __ballot(flag);
-  if (lane == 0) flagmask[w0] = mask;
+  unsigned long long mask = __ballot(flag);
+  if (gridDim.y == 1) {
+    if (lane == 0) flagmask[w0] = mask;
+  } else {  // the mask was cleared before the launch; only rows no other slice has flagged yet join the list
+    unsigned long long old = 0;
+    if (lane == 0 && mask) old = atomicOr(&flagmask[w0], mask);
+    old = __shfl(old, 0, 64);
+    mask &= ~old;
+    flag = (mask >> lane) & 1ull;
+  }
   if (lane == 0) {
     atomicAdd(&counters[0], (unsigned long long)n_finished);
     if (mask) atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
@@ -589,15 +603,29 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   const uint32_t lds_rows = 512;
   const size_t lds_bytes = (size_t)lds_rows * 64;
   if (!c->cleared) SFM_HIP(hipMemsetAsync(c->d_n_flagged, 0, sizeof(uint32_t), c->stream));
+  // query slices for a short block list: aim at 8 waves per SIMD (3 200 blocks in one slice leave the fullest SIMDs 4
+  // waves and the average 3.1: 0.39 ms; four slices: 0.33 ms although each pays its own exact head), every slice at
+  // least 6 heads long so that screening still pays
+  static const int qsplit_env = [] {
+    const char *e = getenv("SFMLOC_K1_QSPLIT");
+    return e ? atoi(e) : 0;
+  }();
+  uint32_t qsplit = 1;
+  while (qsplit < 4 && (uint64_t)n_work_blocks * qsplit < 32ull * (uint64_t)m->n_cu && q->n / (qsplit * 2) >= 6 * head)
+    qsplit *= 2;
+  if (!c->k1_may_slice) qsplit = 1;  // other queries are queued on the GPU: their scans fill it, slices only add work
+  if (qsplit_env == 1 || qsplit_env == 2 || qsplit_env == 4) qsplit = (uint32_t)qsplit_env;
+  if (qsplit > 1)
+    SFM_HIP(hipMemsetAsync(c->d_flagmask, 0, (size_t)n_work_blocks * sizeof(unsigned long long), c->stream));
 #define K1_SCREEN(NW)                                                                                              \
   case NW:                                                                                                        \
-    hipLaunchKernelGGL((k_hamming_screen<WAVES, NW, 1>), dim3((n_work_blocks + WAVES - 1) / WAVES),               \
+    hipLaunchKernelGGL((k_hamming_screen<WAVES, NW, 1>), dim3((n_work_blocks + WAVES - 1) / WAVES, qsplit),       \
                        dim3(WAVES * 64), lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr,   \
                        n_work_blocks, q->d_desc, q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged,     \
                        c->d_n_flagged, c->d_k1_counters, head, c->d_flagged_desc, c->rows_chunk_cap * 64);        \
     break;
   if (nw == 10 && n_work_blocks < 16u * (uint32_t)m->n_cu) {  // fewer than four waves per SIMD: batched tail
-    hipLaunchKernelGGL((k_hamming_screen<WAVES, 10, 4>), dim3((n_work_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64),
+    hipLaunchKernelGGL((k_hamming_screen<WAVES, 10, 4>), dim3((n_work_blocks + WAVES - 1) / WAVES, qsplit), dim3(WAVES * 64),
                        lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks, q->d_desc,
                        q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged, c->d_k1_counters,
                        head, c->d_flagged_desc, c->rows_chunk_cap * 64);
@@ -610,7 +638,7 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   // executed VALU lane-ops, deterministic part (the finished pairs are counted on the device): exact head 35 per
   // pair, screened tail 2*nw+1, plus (sfmloc_stats_read) 2*(16-nw)+5 per finished pair
   const uint64_t rows = (uint64_t)n_work_blocks * kBlockRows;
-  c->stats.hamming_lane_ops += rows * head * 35 + rows * (q->n - head) * (uint64_t)(2 * nw + 1);
+  c->stats.hamming_lane_ops += rows * head * qsplit * 35 + rows * (q->n - head * qsplit) * (uint64_t)(2 * nw + 1);
   c->k1_finish_ops = 2 * (16 - nw) + 5;
   SFM_HIP(hipGetLastError());
   // the exact pass over the flagged rows: chunks of 64 rows x kRowSlices query slices, see k_hamming_rows

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -108,6 +109,7 @@ struct Map {
   uint64_t n_rows = 0;
   uint32_t n_blocks = 0;  // ceil(n_rows / 64)
   uint32_t max_view_blocks = 0;  // most 64-row blocks any one view overlaps (launch bound of a device-side selection)
+  std::atomic<int> busy_ctx{0};  // contexts with work queued (begin .. end / sync): K1 slices a short scan only when alone
   uint32_t n_views = 0;
   uint32_t n_landmarks = 0;
   std::vector<uint32_t> h_view_id, h_view_off, h_view_wh;
@@ -201,6 +203,8 @@ struct Ctx {
   uint32_t last_n_work_blocks = 0;
   std::vector<uint32_t> last_blocks;  // host copy of the block list (empty = all)
   bool last_blocks_on_device = false; // the list was built by k_blocks_from_views: fetch it when a reader needs it
+  bool counted_busy = false;          // this context is counted in Map::busy_ctx
+  bool k1_may_slice = true;           // no other context had work queued when this query began
   bool cleared = false;  // k_query_reset already cleared this query's counters: the stages skip their own memsets
   struct Query *last_query = nullptr;  // query of the last putative call
   struct Query *in_flight = nullptr;   // query of a begun, not yet ended, localisation
