@@ -263,6 +263,10 @@ int sfmloc_localize_begin(sfmloc_context *ctx, sfmloc_query *q, const uint32_t *
  * views.  Finish with sfmloc_localize_end.  Same result as sfmloc_bow_select + sfmloc_localize_begin, bit for bit. */
 int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const float *query_bow, uint32_t knn,
                               const uint32_t *cand_views, uint32_t n_cand);
+/* the same, synchronous, on the map's own context (as sfmloc_localize; the stage read-backs then refer to it) */
+int sfmloc_localize_bow(sfmloc_map *map, sfmloc_query *query, const float *query_bow, uint32_t knn,
+                        const uint32_t *cand_views, uint32_t n_cand, sfmloc_pose *out, uint32_t *pair_qfeat,
+                        uint32_t *pair_landmark, uint32_t cap);
 int sfmloc_localize_end(sfmloc_context *ctx, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,
                         uint32_t cap);
 /* n queries against all views, n_contexts of them in flight (0 = 4).  poses[n]; pair buffers may be NULL,

@@ -168,26 +168,20 @@ class LocalizeEngine {
       }
       if (sel.empty()) return result;
     }
-    if (bow && mBowKnnNum > 0) {
-      const uint32_t nCand = useSel ? (uint32_t)sel.size() : mViews;
-      if (nCand > (uint32_t)mBowKnnNum) {  // LocalizeEngine.cc:342
-        std::vector<uint32_t> out(mBowKnnNum);
-        uint32_t nOut = 0;
-        if (sfmloc_bow_select(mMap, bow->data(), useSel ? sel.data() : nullptr, nCand, (uint32_t)mBowKnnNum, out.data(),
-                              &nOut))
-          throw std::runtime_error(sfmloc_last_error());
-        sel.assign(out.begin(), out.begin() + nOut);
-        useSel = true;
-      }
-    }
     sfmloc_query *q = nullptr;
     if (sfmloc_query_create(mMap, desc, kptXY, n, (uint32_t)width, (uint32_t)height, &q))
       throw std::runtime_error(sfmloc_last_error());
     sfmloc_pose pose;
     std::memset(&pose, 0, sizeof(pose));
     std::vector<uint32_t> pq(4096), pl(4096);
-    const int rc = sfmloc_localize(mMap, q, useSel ? sel.data() : nullptr, useSel ? (uint32_t)sel.size() : 0, &pose,
-                                   pq.data(), pl.data(), 4096);
+    const uint32_t *selp = useSel ? sel.data() : nullptr;
+    const uint32_t nsel = useSel ? (uint32_t)sel.size() : 0;
+    // with a BoW vector the shortlist (applied when more than bowKnnNum views remain, LocalizeEngine.cc:342) and the
+    // path run as one call, the shortlist staying on the device
+    const int rc = (bow && mBowKnnNum > 0)
+                       ? sfmloc_localize_bow(mMap, q, bow->data(), (uint32_t)mBowKnnNum, selp, nsel, &pose, pq.data(),
+                                             pl.data(), 4096)
+                       : sfmloc_localize(mMap, q, selp, nsel, &pose, pq.data(), pl.data(), 4096);
     if (rc) {
       sfmloc_query_destroy(q);
       throw std::runtime_error(sfmloc_last_error());

@@ -111,7 +111,7 @@ SYMBOLS = [
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
     "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
-    "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close", "sfmloc_localize_bow_begin",
+    "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close", "sfmloc_localize_bow_begin", "sfmloc_localize_bow",
     "sfmloc_undistorter_create", "sfmloc_undistorter_destroy", "sfmloc_undistorter_info", "sfmloc_undistorter_maps",
     "sfmloc_undistorter_apply",
 ]
@@ -600,6 +600,26 @@ class Map:
             sel_p, n_sel, keep = _sel(view_sel)
         _check(_L().sfmloc_localize(self._h, q._h, sel_p, n_sel, C.byref(pose), _ptr(pq, C.c_uint32),
                                     _ptr(pl, C.c_uint32), cap))
+        k = pose.n_inliers if pose.ok else 0
+        return pose, pq[:k].copy(), pl[:k].copy()
+
+    def localize_bow(self, q, query_bow, knn, cand_views=None, cap=4096):
+        """sfmloc_localize_bow: BoW shortlist (when more than knn candidates remain) + the whole path in one call on
+        the map's own context; -> (Pose, pair_qfeat, pair_landmark)."""
+        pose = Pose()
+        pq = np.zeros(cap, np.uint32)
+        pl = np.zeros(cap, np.uint32)
+        b = np.ascontiguousarray(query_bow, dtype=np.float32).ravel()
+        if cand_views is None:
+            sel_p, n_sel = None, 0
+        else:
+            sel_p, n_sel, keep = _sel(cand_views)
+        L = _L()
+        L.sfmloc_localize_bow.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32),
+                                          C.c_uint32, C.POINTER(Pose), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                          C.c_uint32]
+        _check(L.sfmloc_localize_bow(self._h, q._h, _ptr(b, C.c_float), int(knn), sel_p, n_sel, C.byref(pose),
+                                     _ptr(pq, C.c_uint32), _ptr(pl, C.c_uint32), cap))
         k = pose.n_inliers if pose.ok else 0
         return pose, pq[:k].copy(), pl[:k].copy()
 

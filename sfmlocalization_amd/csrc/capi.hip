@@ -1160,6 +1160,19 @@ int sfmloc_localize(sfmloc_map *map, sfmloc_query *query, const uint32_t *view_s
   return ctx_localize_end(m->ctx0, out, pair_qfeat, pair_landmark, cap);
 }
 
+int sfmloc_localize_bow(sfmloc_map *map, sfmloc_query *query, const float *query_bow, uint32_t knn,
+                        const uint32_t *cand_views, uint32_t n_cand, sfmloc_pose *out, uint32_t *pair_qfeat,
+                        uint32_t *pair_landmark, uint32_t cap) {
+  SFM_CHECK(map && query && out, SFMLOC_EINVAL, "sfmloc_localize_bow: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  int rc = sfmloc_localize_bow_begin(reinterpret_cast<sfmloc_context *>(m->ctx0), query, query_bow, knn, cand_views, n_cand);
+  if (rc) {
+    m->ctx0->in_flight = nullptr;
+    return rc;
+  }
+  return ctx_localize_end(m->ctx0, out, pair_qfeat, pair_landmark, cap);
+}
+
 int sfmloc_localize_batch(sfmloc_map *map, sfmloc_query *const *queries, uint32_t n, uint32_t n_contexts,
                           sfmloc_pose *poses, uint32_t *pair_qfeat, uint32_t *pair_landmark, uint32_t pair_stride) {
   SFM_CHECK(map && (n == 0 || (queries && poses)), SFMLOC_EINVAL, "sfmloc_localize_batch: null argument");

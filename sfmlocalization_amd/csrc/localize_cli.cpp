@@ -546,29 +546,19 @@ int main(int argc, char **argv) {
           have_bow = load_image(img, true, &bgr, &cw, &ch) && dense.compute(bgr, cw, ch, &bow);
         }
       }
-      if (have_bow) {
-        const uint32_t n_cand = use_sel ? (uint32_t)sel.size() : info.n_views;
-        if (n_cand > (uint32_t)knn_bow) {  // localization.cpp:346
-          std::vector<uint32_t> out(knn_bow);
-          uint32_t n_out = 0;
-          if (sfmloc_bow_select(map, bow.data(), use_sel ? sel.data() : nullptr, n_cand, (uint32_t)knn_bow, out.data(),
-                                &n_out)) {
-            fprintf(stderr, "%s\n", sfmloc_last_error());
-            rc_all = 1;
-            break;
-          }
-          sel.assign(out.begin(), out.begin() + n_out);
-          use_sel = true;
-        }
-      }
       sfmloc_query *q = nullptr;
       if (sfmloc_query_create(map, desc.data(), xy.data(), nq, (uint32_t)w, (uint32_t)h, &q)) {
         fprintf(stderr, "%s\n", sfmloc_last_error());
         rc_all = 1;
         break;
       }
-      const int rc = sfmloc_localize(map, q, use_sel ? sel.data() : nullptr, use_sel ? (uint32_t)sel.size() : 0, &pose,
-                                     pq.data(), pl.data(), 4096);
+      // with a BoW vector: shortlist (when more than knn views remain, localization.cpp:346) + path in one call, the
+      // shortlist staying on the device
+      const uint32_t *selp = use_sel ? sel.data() : nullptr;
+      const uint32_t nsel = use_sel ? (uint32_t)sel.size() : 0;
+      const int rc = have_bow ? sfmloc_localize_bow(map, q, bow.data(), (uint32_t)knn_bow, selp, nsel, &pose, pq.data(),
+                                                    pl.data(), 4096)
+                              : sfmloc_localize(map, q, selp, nsel, &pose, pq.data(), pl.data(), 4096);
       sfmloc_query_destroy(q);
       if (rc) {
         fprintf(stderr, "%s\n", sfmloc_last_error());

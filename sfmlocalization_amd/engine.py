@@ -130,13 +130,14 @@ class LocalizeEngine:
             if len(view_sel) == 0:
                 return [], {}
         knn = int(self.params.bow_knn)
-        if bow is not None and knn > 0:
-            n_cand = self.map.n_views if view_sel is None else len(view_sel)
-            if n_cand > knn:                         # localization.cpp:346 / LocalizeEngine.cc:342
-                view_sel = self.map.bow_select(np.asarray(bow, np.float64).astype(np.float32), knn, view_sel)
         q = self.map.query(desc, kpt_xy, width, height)
         try:
-            pose, pq, pl = self.map.localize(q, view_sel)
+            if bow is not None and knn > 0:
+                # the shortlist applies when more than knn views remain (localization.cpp:346 / LocalizeEngine.cc:342);
+                # shortlist and path are one call, the selected views never leave the device
+                pose, pq, pl = self.map.localize_bow(q, np.asarray(bow, np.float64).astype(np.float32), knn, view_sel)
+            else:
+                pose, pq, pl = self.map.localize(q, view_sel)
         finally:
             q.close()
         extras = {"pose": pose, "pairs": list(zip(pq.tolist(), pl.tolist()))}
