@@ -173,8 +173,8 @@ def main():
     queries = [synth.make_query(m, 1000 + i, n_feat=a.nq) for i in range(a.queries)]
     bow = qbow = None
     if a.bow_knn > 0:
-        if world > 1 or forced:
-            raise SystemExit("--bow-knn is a single-GPU workload in this bench (the sharded shortlist is dist.py's bow_shortlists)")
+        # N > 1 (BASELINE configs[3]): the .bow matrix shards with the views; every batch first runs the sharded
+        # shortlist (one small all-gather of each rank's k best, dist.py bow_shortlists), then the sharded path
         # one BoW prototype per place + noise per view: the shortlist finds the query's place (TrainBoW's vectors are
         # 500-dimensional, BoFUtils.cpp:43-45)
         rng = np.random.Generator(np.random.PCG64(33))
@@ -187,7 +187,8 @@ def main():
     params = S.default_params(device=local_rank, profile=1, ransac_round=25)
     dev_map = S.Map(m.view_id[v0:v1], m.view_off[v0:v1 + 1] - m.view_off[v0], m.desc[r0:r1], params=params,
                     view_wh=m.view_wh[v0:v1], kpt_xy=m.kpt_xy[r0:r1], row_landmark=m.row_landmark[r0:r1],
-                    landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic, bow=bow)
+                    landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic,
+                    bow=None if bow is None else bow[v0:v1])
     dqs = [dev_map.query(q.desc, q.kpt_xy, q.width, q.height) for q in queries]
     lat = []
     n_ok = [0]
@@ -217,7 +218,11 @@ def main():
         idx = list(range(first, first + count))
         batches = [idx[k:k + a.batch] for k in range(0, len(idx), a.batch)]
         t_mark = [time.perf_counter(), time.perf_counter()]   # batch b was enqueued when batch b-2 was yielded
-        stream = sharded.localize_stream([[dqs[i % len(dqs)] for i in b] for b in batches], gather_results=False)
+        sels = None
+        if qbow is not None:   # generator: the shortlist of batch b is computed when the pipeline reaches it
+            sels = (sharded.bow_shortlists(dev_map, [qbow[i % len(dqs)] for i in b], a.bow_knn) for b in batches)
+        stream = sharded.localize_stream([[dqs[i % len(dqs)] for i in b] for b in batches], gather_results=False,
+                                         view_sels=sels)
         for b, res in zip(batches, stream):
             now = time.perf_counter()
             lat.extend([now - t_mark[0]] * len(b))          # a query's latency in batch mode = its batch's wall time
@@ -323,7 +328,10 @@ def main():
             lat_single.append(time.perf_counter() - t1)
         st1 = dev_map.stats()
         iso = (st1.total_ms[0] / max(1, st1.launches[0]), st1.hamming_lane_ops / max(1, st1.launches[0]))
-    sel0 = dev_map.bow_select(qbow[0], a.bow_knn) if qbow is not None else None
+    sel0 = None
+    if qbow is not None:   # this rank's part of the first query's shortlist (collective when sharded)
+        sel0 = (sharded.bow_shortlists(dev_map, [qbow[0]], a.bow_knn)[0] if sharded is not None
+                else dev_map.bow_select(qbow[0], a.bow_knn))
     dev_map.match_putative(dqs[0], sel0)  # outside the timed region: number of emitted matches for the byte count
     n_match = int(dev_map.putative_read()[0].sum())
     if world > 1:

@@ -58,6 +58,18 @@ def shard_views(view_off, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def _k_best(dist, ids, k):
+    """Indices of the k smallest (distance, view id) pairs, in that order, without sorting all of them."""
+    n = len(dist)
+    if k >= n:
+        return np.lexsort((ids, dist))[:k]
+    t = np.partition(dist, k - 1)[k - 1]
+    less = np.nonzero(dist < t)[0]
+    eq = np.nonzero(dist == t)[0]                      # ascending index = ascending view id
+    sel = np.concatenate([less, eq[:k - len(less)]])
+    return sel[np.lexsort((ids[sel], dist[sel]))]
+
+
 def merge_bow_shortlists(local_dist, local_view_id, k, world, all_gather):
     """Sharded BoW shortlist: `local_dist[i]` = this rank's distance for its view `local_view_id[i]`
     (ascending ids).  Every rank contributes its k best (distance, view id) pairs; the global k best -- ties to the
@@ -65,15 +77,14 @@ def merge_bow_shortlists(local_dist, local_view_id, k, world, all_gather):
     indices among them (what sfmloc_shard_begin takes as view_sel).  `all_gather(arr [k, 2] f64) -> [world, k, 2]`."""
     local_dist = np.asarray(local_dist, np.float32)
     local_view_id = np.asarray(local_view_id, np.int64)
-    order = np.lexsort((local_view_id, local_dist))[:k]
+    order = _k_best(local_dist, local_view_id, k)
     mine = np.full((k, 2), np.inf, np.float64)
     mine[:len(order), 0] = local_dist[order]
     mine[:len(order), 1] = local_view_id[order]
     allp = np.asarray(all_gather(mine)).reshape(world * k, 2)
     allp = allp[np.isfinite(allp[:, 0])]
     best = allp[np.lexsort((allp[:, 1], allp[:, 0]))[:k]]
-    chosen = set(int(v) for v in best[:, 1])
-    return np.array([i for i, v in enumerate(local_view_id) if int(v) in chosen], np.uint32)
+    return np.nonzero(np.isin(local_view_id, best[:, 1].astype(np.int64)))[0].astype(np.uint32)
 
 
 class ShardedLocalizer:
@@ -146,7 +157,7 @@ class ShardedLocalizer:
         mine = np.full((B, k, 2), np.inf, np.float64)
         for b, qb in enumerate(query_bows):
             d = local_map.bow_distances(qb)
-            order = np.lexsort((ids, d))[:k]
+            order = _k_best(d, ids, k)
             mine[b, :len(order), 0] = d[order]
             mine[b, :len(order), 1] = ids[order]
         if self.world > 1:
@@ -163,25 +174,27 @@ class ShardedLocalizer:
             p = allp[:, b].reshape(-1, 2)
             p = p[np.isfinite(p[:, 0])]
             best = p[np.lexsort((p[:, 1], p[:, 0]))[:k]]
-            chosen = set(int(v) for v in best[:, 1])
-            sels.append(np.array([i for i, v in enumerate(ids) if int(v) in chosen], np.uint32))
+            sels.append(np.nonzero(np.isin(ids, best[:, 1].astype(np.int64)))[0].astype(np.uint32))
         return sels
 
     def localize_batch(self, queries, gather_results=True, view_sels=None):
         return self._finish(queries, self._stage1(queries, 0, view_sels), 0, gather_results)
 
-    def localize_stream(self, batches, gather_results=False):
+    def localize_stream(self, batches, gather_results=False, view_sels=None):
         """Generator over batches (lists of queries), yielding each batch's {index: result} in order.  With a
         two-slot compute object the shard-local stage of batch i+1 is already queued on the GPU while batch i goes
         through the collective and its P3P stage, so the exchange and the latency-bound tail hide under the next
-        batch's Hamming scans.  Every rank must iterate the same batches."""
+        batch's Hamming scans.  Every rank must iterate the same batches.  view_sels: optional iterable, per batch the
+        list of this shard's view selections (e.g. from bow_shortlists), consumed lazily batch by batch."""
         prev = None
         slot = 0
+        sels_it = iter(view_sels) if view_sels is not None else None   # per batch: this shard's view selections
         for batch in batches:
+            sels = next(sels_it) if sels_it is not None else None
             if self.n_slots < 2:
-                yield self.localize_batch(batch, gather_results)
+                yield self.localize_batch(batch, gather_results, view_sels=sels)
                 continue
-            cur = (batch, self._stage1(batch, slot), slot)
+            cur = (batch, self._stage1(batch, slot, sels), slot)
             if prev is not None:
                 yield self._finish(*prev, gather_results)
             prev = cur
