@@ -65,6 +65,16 @@ def test_merge_bow_shortlists_equals_global_selection():
         assert got == glob
 
 
+def test_k_best_equals_full_sort():
+    """dist._k_best (partition + tie handling) against the full (distance, id) sort it replaces."""
+    rng = np.random.Generator(np.random.PCG64(16))
+    for n in (1, 2, 9, 100, 1000):
+        d = rng.integers(0, max(2, n // 7), n).astype(np.float32)
+        ids = np.arange(n, dtype=np.int64) * 2 + 5
+        for k in sorted({1, 2, n // 3 + 1, n - 1 if n > 1 else 1, n, n + 3}):
+            np.testing.assert_array_equal(D._k_best(d, ids, k), np.lexsort((ids, d))[:k])
+
+
 class OracleShardCompute:
     """stand-in for HipShardCompute built on the oracle (tests only)"""
 
