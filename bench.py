@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--nq", type=int, default=2000)
     ap.add_argument("--queries", type=int, default=8, help="distinct synthetic queries cycled through")
     ap.add_argument("--in-flight", type=int, default=4, help="queries in flight (contexts); 1 = latency mode")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=0,
                     help="queries per all-gather when --gpus > 1 (a multiple of the world size keeps the P3P stage balanced; "
-                         "small batches keep the two-slot pipeline full over a short timed region)")
+                         "small batches keep the two-slot pipeline full over a short timed region).  Default: the world "
+                         "size, at least 4 -- measured on one rank: 411 queries/s over 40 steps with 4, 383 with 8")
     ap.add_argument("--bow-knn", type=int, default=0,
                     help="> 0: BASELINE configs[2] -- every query first shortlists this many views by BoW distance "
                          "(sfmloc_bow_select over a synthetic .bow matrix) and runs the path on those (1 GPU only); "
@@ -148,6 +149,8 @@ def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.batch <= 0:
+        a.batch = world * max(1, (4 + world - 1) // world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
