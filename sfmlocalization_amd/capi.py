@@ -751,8 +751,11 @@ class Akaze:
         """-> kpts [n x 6] (x, y, size, angle, response, class_id), desc [n x 64] (.desc rows)."""
         gray = np.ascontiguousarray(gray, np.uint8)
         assert gray.shape == (self.height, self.width)
-        kp = np.zeros((cap, 6), np.float32)
-        desc = np.zeros((cap, 64), np.uint8)
+        if getattr(self, "_out_cap", 0) != cap:      # output staging kept between calls (5.8 MB at the default cap)
+            self._out_kp = np.zeros((cap, 6), np.float32)
+            self._out_desc = np.zeros((cap, 64), np.uint8)
+            self._out_cap = cap
+        kp, desc = self._out_kp, self._out_desc
         n = C.c_uint32()
         _check(_L().sfmloc_akaze_detect_and_compute(self._h, _ptr(gray, C.c_uint8), _ptr(kp, C.c_float),
                                                     _ptr(desc, C.c_uint8), cap, C.byref(n)))
