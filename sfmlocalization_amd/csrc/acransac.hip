@@ -809,12 +809,14 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
                                                          const uint32_t *landmark_id, const double *landmark_X,
                                                          Candidate *cand, uint32_t cap, uint32_t *n_cand,
                                                          int *status, uint32_t min_putative, uint32_t *view_stats) {
+  // one workgroup (four waves) per selected view: the stage is a chain of dependent loads per candidate, so the waves
+  // take 64 candidates each side by side instead of one wave walking them 64 at a time
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t gw = blockIdx.x;
   if (gw >= n_sel) return;
   const uint32_t v = view_sel ? view_sel[gw] : gw;
   const uint32_t ng = geo_count[v];
-  if (lane == 0) {  // the counts the reference prints (localization.cpp:416,458)
+  if (threadIdx.x == 0) {  // the counts the reference prints (localization.cpp:416,458)
     if (put_count[v] >= min_putative) atomicAdd(&view_stats[0], 1u);
     if (ng > 0) atomicAdd(&view_stats[1], 1u);
   }
@@ -823,14 +825,13 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
   const uint32_t np = put_count[v];
   // the view's putative keys in LDS (one segment per wave): the "last match with the same query feature" search
   // below is a dependent backward scan, far too slow against L2
-  __shared__ uint32_t s_keys[4][kFMaxM];
-  uint32_t *keys = s_keys[threadIdx.x >> 6];
+  __shared__ uint32_t keys[kFMaxM];
   const bool staged = np <= (uint32_t)kFMaxM;
   if (staged) {
-    for (uint32_t k = lane; k < np; k += 64) keys[k] = match_key[off + k];
-    wave_lds_sync();
+    for (uint32_t k = threadIdx.x; k < np; k += 256) keys[k] = match_key[off + k];
+    __syncthreads();
   }
-  for (uint32_t p0 = 0; p0 < ng; p0 += 64) {
+  for (uint32_t p0 = (threadIdx.x >> 6) * 64; p0 < ng; p0 += 256) {
     const uint32_t p = p0 + lane;
     bool has = false;
     uint32_t j = 0, dist = 0;
@@ -1640,7 +1641,7 @@ int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_view
     SFM_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
   }
   if (n_sel == 0 || q->n == 0) return SFMLOC_OK;
-  hipLaunchKernelGGL(k_emit_candidates, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_emit_candidates, dim3(n_sel), dim3(256), 0, c->stream,
                      all_views ? nullptr : c->d_view_sel, n_sel, m->d_view_off, m->d_view_id, c->d_view_count,
                      c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, m->d_row_landmark,
                      m->d_landmark_id, m->d_landmark_X,
