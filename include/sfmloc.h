@@ -129,6 +129,15 @@ typedef struct sfmloc_scan_info {
 } sfmloc_scan_info;
 int sfmloc_scan(const char *sfm_dir, const char *match_dir, sfmloc_scan_info *info);
 
+/* Packed map file: everything sfmloc_open reads from sfm_data.json and the per-view .desc / .feat / .bow
+ * files, as ONE binary written once by sfmloc_pack (host only) -- a server then opens a 10 000-view map at disk speed
+ * instead of parsing a large JSON and 20 000 small files.  sfmloc_open_packed(path) gives the same map as
+ * sfmloc_open(sfm_dir, match_dir); sfmloc_scan_packed is the host-only check (same fields as sfmloc_scan).  The file
+ * is little-endian and versioned by its 8-byte magic; SFMLOC_EIO for anything else. */
+int sfmloc_pack(const char *sfm_dir, const char *match_dir, const char *out_path);
+int sfmloc_scan_packed(const char *path, sfmloc_scan_info *info);
+int sfmloc_open_packed(const char *path, const sfmloc_params *params, sfmloc_map **out);
+
 /* The view table of an sfm_data.json on its own (host only): what ExtFeatAndMatch iterates over before any
  * reconstruction exists (computeFeaturesAndMatches.cpp:118-126, AKAZEOpenCV.cpp:122-131).  Views come in id order
  * (Views is a std::map); image_path = root_path / file name and stays valid until sfmloc_view_list_close. */

@@ -13,6 +13,8 @@
 #ifndef SFMLOC_ENGINE_HPP
 #define SFMLOC_ENGINE_HPP
 
+#include <sys/stat.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -75,7 +77,12 @@ class LocalizeEngine {
     p.geom_precision = ransacPrecision;
     p.bow_knn = bowKnnNum;
     p.device = device;
-    if (sfmloc_open(sfmDataDir.c_str(), matchDir.c_str(), &p, &mMap)) throw std::runtime_error(sfmloc_last_error());
+    // sfmDataDir may also name a packed map file written by sfmloc_pack
+    struct stat st;
+    const bool packed = ::stat(sfmDataDir.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+    if (packed ? sfmloc_open_packed(sfmDataDir.c_str(), &p, &mMap)
+               : sfmloc_open(sfmDataDir.c_str(), matchDir.c_str(), &p, &mMap))
+      throw std::runtime_error(sfmloc_last_error());
     sfmloc_map_info info;
     sfmloc_map_get_info(mMap, &info);
     mViews = info.n_views;

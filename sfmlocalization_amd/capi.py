@@ -112,6 +112,7 @@ SYMBOLS = [
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
     "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
     "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close", "sfmloc_localize_bow_begin", "sfmloc_localize_bow",
+    "sfmloc_pack", "sfmloc_scan_packed", "sfmloc_open_packed",
     "sfmloc_undistorter_create", "sfmloc_undistorter_destroy", "sfmloc_undistorter_info", "sfmloc_undistorter_maps",
     "sfmloc_undistorter_apply",
 ]
@@ -234,6 +235,20 @@ def scan(sfm_dir, match_dir):
     """sfmloc_scan: parse <sfm_dir>/sfm_data.json + <match_dir>/*.desc|feat|bow on the host, no GPU."""
     info = ScanInfo()
     _check(_L().sfmloc_scan(os.fsencode(sfm_dir), os.fsencode(match_dir), C.byref(info)))
+    return {f: getattr(info, f) for f, _ in ScanInfo._fields_}
+
+
+def pack(sfm_dir, match_dir, out_path):
+    """sfmloc_pack: the map's files -> one packed binary (host only)."""
+    _check(_L().sfmloc_pack(os.fsencode(sfm_dir), os.fsencode(match_dir), os.fsencode(out_path)))
+
+
+def scan_packed(path):
+    """sfmloc_scan_packed: the fields of scan() from a packed map file, no GPU."""
+    info = ScanInfo()
+    L = _L()
+    L.sfmloc_scan_packed.argtypes = [C.c_char_p, C.POINTER(ScanInfo)]
+    _check(L.sfmloc_scan_packed(os.fsencode(path), C.byref(info)))
     return {f: getattr(info, f) for f, _ in ScanInfo._fields_}
 
 
@@ -435,6 +450,27 @@ class Map:
                                      _ptr(self.view_center, C.c_double)))
         return self
 
+    @classmethod
+    def open_packed(cls, path, params=None):
+        """sfmloc_open_packed: the map written by pack(); equal to open() on the files it was packed from."""
+        self = cls.__new__(cls)
+        self._h = None
+        self._children = weakref.WeakSet()
+        self.params = params if params is not None else default_params()
+        h = C.c_void_p()
+        L = _L()
+        L.sfmloc_open_packed.argtypes = [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_void_p)]
+        _check(L.sfmloc_open_packed(os.fsencode(path), C.byref(self.params), C.byref(h)))
+        self._h = h
+        i = self.info()
+        self.n_rows, self.n_views = i["n_rows"], i["n_views"]
+        self.view_id = np.zeros(self.n_views, np.uint32)
+        self.view_off = np.zeros(self.n_views + 1, np.uint32)
+        self.view_center = np.zeros((self.n_views, 3), np.float64)
+        _check(L.sfmloc_map_views(self._h, _ptr(self.view_id, C.c_uint32), _ptr(self.view_off, C.c_uint32),
+                                  _ptr(self.view_center, C.c_double)))
+        return self
+
     def close(self):
         if self._h is not None:
             # queries and contexts hold pointers into the map: release them first, whatever order the
@@ -602,6 +638,12 @@ class Map:
                                     _ptr(pl, C.c_uint32), cap))
         k = pose.n_inliers if pose.ok else 0
         return pose, pq[:k].copy(), pl[:k].copy()
+
+    def view_sizes(self):
+        """sfmloc_map_view_sizes: (width, height) of every view, [n_views, 2]."""
+        wh = np.zeros((self.n_views, 2), np.uint32)
+        _check(_L().sfmloc_map_view_sizes(self._h, _ptr(wh, C.c_uint32)))
+        return wh
 
     def localize_bow(self, q, query_bow, knn, cand_views=None, cap=4096):
         """sfmloc_localize_bow: BoW shortlist (when more than knn candidates remain) + the whole path in one call on

@@ -432,7 +432,7 @@ int main(int argc, char **argv) {
     images.push_back(query);  // with precomputed features the image itself may be absent
   }
 
-  const std::string sfm_json = join(sfm_dir, "sfm_data.json");
+  const std::string sfm_json = is_file(sfm_dir) ? sfm_dir : join(sfm_dir, "sfm_data.json");
   sfmloc_params prm;
   sfmloc_default_params(&prm);
   prm.dist_ratio = (float)f_ratio;
@@ -441,7 +441,10 @@ int main(int argc, char **argv) {
   prm.bow_knn = knn_bow;
   prm.device = device;
   sfmloc_map *map = nullptr;
-  if (sfmloc_open(sfm_dir.c_str(), match_dir.c_str(), &prm, &map)) {
+  // <sfmDataDir> may also name a packed map file written by sfmloc_pack (one binary instead of sfm_data.json and the
+  // per-view files); the result JSON then cites that file as "sfm_data"
+  if (is_file(sfm_dir) ? sfmloc_open_packed(sfm_dir.c_str(), &prm, &map)
+                       : sfmloc_open(sfm_dir.c_str(), match_dir.c_str(), &prm, &map)) {
     fprintf(stderr, "%s\n", sfmloc_last_error());
     return 1;
   }

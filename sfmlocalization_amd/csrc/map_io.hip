@@ -453,13 +453,81 @@ bad:
 
 using namespace sfmloc;
 
-extern "C" {
+// ---- packed map file: everything load_scene produces, as one little-endian binary.  Opening a
+//      10 000-view map from the reference's files means parsing a large JSON and 20 000 small files (the .feat files
+//      are text); the packed file is read at disk speed.  Layout: "SFMLOCM1", then the scalars, then each array as
+//      u64 count + raw elements, in the order of write_packed below. ----
+namespace {
+const char kPackMagic[8] = {'S', 'F', 'M', 'L', 'O', 'C', 'M', '1'};
 
-int sfmloc_scan(const char *sfm_dir, const char *match_dir, sfmloc_scan_info *info) {
-  SFM_CHECK(sfm_dir && match_dir && info, SFMLOC_EINVAL, "sfmloc_scan: null argument");
-  Scene S;
-  int rc = load_scene(sfm_dir, match_dir, S);
-  if (rc) return rc;
+template <typename T>
+bool put_vec(FILE *f, const std::vector<T> &v) {
+  const uint64_t n = v.size();
+  return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <typename T>
+bool get_vec(FILE *f, std::vector<T> &v, uint64_t max_elems) {
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, f) != 1 || n > max_elems) return false;
+  v.resize((size_t)n);
+  return n == 0 || fread(v.data(), sizeof(T), (size_t)n, f) == n;
+}
+
+bool write_packed(const char *path, const Scene &S) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return false;
+  const double sc[6] = {S.focal, S.ppx, S.ppy, S.k1, S.k2, S.k3};
+  const uint32_t u[5] = {S.intrinsic_type, S.bow_dim, S.n_views_total, S.n_landmarks_total, S.n_obs_used};
+  bool ok = fwrite(kPackMagic, 8, 1, f) == 1 && fwrite(sc, sizeof(sc), 1, f) == 1 && fwrite(u, sizeof(u), 1, f) == 1;
+  ok = ok && put_vec(f, S.view_id) && put_vec(f, S.view_off) && put_vec(f, S.view_wh) && put_vec(f, S.desc) &&
+       put_vec(f, S.kpt) && put_vec(f, S.row_landmark) && put_vec(f, S.landmark_id) && put_vec(f, S.landmark_X) &&
+       put_vec(f, S.view_center) && put_vec(f, S.bow);
+  uint64_t nf = S.view_file.size();
+  ok = ok && fwrite(&nf, 8, 1, f) == 1;
+  for (const std::string &name : S.view_file) {
+    const uint64_t len = name.size();
+    ok = ok && fwrite(&len, 8, 1, f) == 1 && (len == 0 || fwrite(name.data(), 1, len, f) == len);
+  }
+  return (fclose(f) == 0) && ok;
+}
+
+int read_packed(const char *path, Scene &S) {
+  FILE *f = fopen(path, "rb");
+  SFM_CHECK(f != nullptr, SFMLOC_EIO, "packed map \"%s\" cannot be read", path);
+  char magic[8];
+  double sc[6];
+  uint32_t u[5];
+  const uint64_t kMax = 1ull << 36;
+  bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, kPackMagic, 8) == 0 && fread(sc, sizeof(sc), 1, f) == 1 &&
+            fread(u, sizeof(u), 1, f) == 1;
+  ok = ok && get_vec(f, S.view_id, kMax) && get_vec(f, S.view_off, kMax) && get_vec(f, S.view_wh, kMax) &&
+       get_vec(f, S.desc, kMax) && get_vec(f, S.kpt, kMax) && get_vec(f, S.row_landmark, kMax) &&
+       get_vec(f, S.landmark_id, kMax) && get_vec(f, S.landmark_X, kMax) && get_vec(f, S.view_center, kMax) &&
+       get_vec(f, S.bow, kMax);
+  uint64_t nf = 0;
+  ok = ok && fread(&nf, 8, 1, f) == 1 && nf <= (1ull << 28);
+  for (uint64_t i = 0; ok && i < nf; ++i) {
+    uint64_t len = 0;
+    ok = fread(&len, 8, 1, f) == 1 && len <= 65536;
+    if (!ok) break;
+    std::string name((size_t)len, '\0');
+    ok = len == 0 || fread(&name[0], 1, (size_t)len, f) == len;
+    S.view_file.push_back(std::move(name));
+  }
+  fclose(f);
+  // the invariants sfmloc_map_create relies on
+  const size_t nv = S.view_id.size();
+  ok = ok && S.view_off.size() == nv + 1 && S.view_wh.size() == 2 * nv && S.desc.size() % 64 == 0 &&
+       (nv == 0 || S.view_off[nv] == S.desc.size() / 64) && S.kpt.size() == 2 * (S.desc.size() / 64) &&
+       S.row_landmark.size() == S.desc.size() / 64 && S.landmark_X.size() == 3 * S.landmark_id.size() &&
+       (S.view_center.empty() || S.view_center.size() == 3 * nv) && (S.bow.empty() || S.bow.size() == (size_t)u[1] * nv);
+  SFM_CHECK(ok, SFMLOC_EIO, "packed map \"%s\" is truncated, corrupt or of another version", path);
+  S.focal = sc[0], S.ppx = sc[1], S.ppy = sc[2], S.k1 = sc[3], S.k2 = sc[4], S.k3 = sc[5];
+  S.intrinsic_type = u[0], S.bow_dim = u[1], S.n_views_total = u[2], S.n_landmarks_total = u[3], S.n_obs_used = u[4];
+  return SFMLOC_OK;
+}
+
+void scene_info(const Scene &S, sfmloc_scan_info *info) {
   memset(info, 0, sizeof(*info));
   info->n_views_total = S.n_views_total;
   info->n_views_posed = (uint32_t)S.view_id.size();
@@ -485,15 +553,9 @@ int sfmloc_scan(const char *sfm_dir, const char *match_dir, sfmloc_scan_info *in
   long long ls = 0;
   for (int32_t x : S.row_landmark) ls += x;
   info->row_landmark_sum = ls;
-  return SFMLOC_OK;
 }
 
-int sfmloc_open(const char *sfm_dir, const char *match_dir, const sfmloc_params *params, sfmloc_map **out) {
-  SFM_CHECK(sfm_dir && match_dir && out, SFMLOC_EINVAL, "sfmloc_open: null argument");
-  *out = nullptr;
-  Scene S;
-  int rc = load_scene(sfm_dir, match_dir, S);
-  if (rc) return rc;
+int scene_to_map(const Scene &S, const sfmloc_params *params, sfmloc_map **out) {
   sfmloc_map_desc d;
   memset(&d, 0, sizeof(d));
   d.n_views = (uint32_t)S.view_id.size();
@@ -516,12 +578,60 @@ int sfmloc_open(const char *sfm_dir, const char *match_dir, const sfmloc_params 
   d.intrinsic_type = S.intrinsic_type;
   d.bow_dim = S.bow_dim;
   d.bow = S.bow.empty() ? nullptr : S.bow.data();
-  rc = sfmloc_map_create(&d, params, out);
+  const int rc = sfmloc_map_create(&d, params, out);
   if (rc) return rc;
   Map *m = reinterpret_cast<Map *>(*out);
   m->h_view_center = S.view_center;
   m->h_view_file = S.view_file;
   return SFMLOC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sfmloc_scan(const char *sfm_dir, const char *match_dir, sfmloc_scan_info *info) {
+  SFM_CHECK(sfm_dir && match_dir && info, SFMLOC_EINVAL, "sfmloc_scan: null argument");
+  Scene S;
+  int rc = load_scene(sfm_dir, match_dir, S);
+  if (rc) return rc;
+  scene_info(S, info);
+  return SFMLOC_OK;
+}
+
+int sfmloc_open(const char *sfm_dir, const char *match_dir, const sfmloc_params *params, sfmloc_map **out) {
+  SFM_CHECK(sfm_dir && match_dir && out, SFMLOC_EINVAL, "sfmloc_open: null argument");
+  *out = nullptr;
+  Scene S;
+  int rc = load_scene(sfm_dir, match_dir, S);
+  if (rc) return rc;
+  return scene_to_map(S, params, out);
+}
+
+int sfmloc_pack(const char *sfm_dir, const char *match_dir, const char *out_path) {
+  SFM_CHECK(sfm_dir && match_dir && out_path, SFMLOC_EINVAL, "sfmloc_pack: null argument");
+  Scene S;
+  int rc = load_scene(sfm_dir, match_dir, S);
+  if (rc) return rc;
+  SFM_CHECK(write_packed(out_path, S), SFMLOC_EIO, "sfmloc_pack: cannot write \"%s\"", out_path);
+  return SFMLOC_OK;
+}
+
+int sfmloc_scan_packed(const char *path, sfmloc_scan_info *info) {
+  SFM_CHECK(path && info, SFMLOC_EINVAL, "sfmloc_scan_packed: null argument");
+  Scene S;
+  int rc = read_packed(path, S);
+  if (rc) return rc;
+  scene_info(S, info);
+  return SFMLOC_OK;
+}
+
+int sfmloc_open_packed(const char *path, const sfmloc_params *params, sfmloc_map **out) {
+  SFM_CHECK(path && out, SFMLOC_EINVAL, "sfmloc_open_packed: null argument");
+  *out = nullptr;
+  Scene S;
+  int rc = read_packed(path, S);
+  if (rc) return rc;
+  return scene_to_map(S, params, out);
 }
 
 int sfmloc_map_views(const sfmloc_map *map, uint32_t *view_id, uint32_t *view_off, double *center) {

@@ -63,7 +63,9 @@ class LocalizeEngine:
         self.params = capi.default_params(dist_ratio=second_test_ratio, ransac_round=ransac_round,
                                           geom_precision=ransac_precision, bow_knn=bow_knn_num, device=device,
                                           profile=profile)
-        self.map = capi.Map.open(sfm_data_dir, match_dir, self.params)
+        # sfm_data_dir may also name a packed map file written by capi.pack / sfmloc_pack
+        self.map = (capi.Map.open_packed(sfm_data_dir, self.params) if os.path.isfile(sfm_data_dir)
+                    else capi.Map.open(sfm_data_dir, match_dir, self.params))
         self.A = None
         if amat_file:
             y = fileio.read_cv_yaml(amat_file)           # LocalizeEngine.cc:116-118
@@ -279,16 +281,21 @@ def main(argv=None):
     else:
         # the reference would fail in imread; with precomputed features the image itself may be absent
         images = [query]
-    sfm_json = os.path.join(sfm_dir, "sfm_data.json")
+    packed = os.path.isfile(sfm_dir)            # a packed map file (capi.pack) in place of the sfm_data directory
+    sfm_json = sfm_dir if packed else os.path.join(sfm_dir, "sfm_data.json")
     try:
         eng = LocalizeEngine(sfm_dir, match_dir, None, o["fDistRatio"], o["ransacRound"], o["geomLimit"],
                              o["guidedMatch"], 0, o["knnbow"], device=o["device"])
     except capi.SfmlocError as e:
         print(str(e), file=sys.stderr)
         return 1
-    sd = fileio.read_sfm_data(sfm_json)
-    v0 = sd["views"][0]["value"]["ptr_wrapper"]["data"]
-    default_wh = (int(v0["width"]), int(v0["height"]))
+    if packed:
+        wh0 = eng.map.view_sizes()[0]
+        default_wh = (int(wh0[0]), int(wh0[1]))
+    else:
+        sd = fileio.read_sfm_data(sfm_json)
+        v0 = sd["views"][0]["value"]["ptr_wrapper"]["data"]
+        default_wh = (int(v0["width"]), int(v0["height"]))
     every = o["locEvryNFrame"] if o["locEvryNFrame"] > 0 else 1
     os.makedirs(out_dir, exist_ok=True)
     n_img, match_next = 0, 0

@@ -104,6 +104,30 @@ def test_native_loader_reads_the_contract(toy_map):
     assert info["row_landmark_sum"] == int(m.row_landmark[rows].astype(np.int64).sum())
 
 
+def test_packed_map_file_round_trip(toy_map, tmp_path):
+    """sfmloc_pack -> one binary; sfmloc_scan_packed reports exactly what sfmloc_scan reports from the files it was
+    packed from (descriptor hash, keypoint and landmark sums included); damaged files are refused."""
+    m, sfm_dir, match_dir, names = toy_map
+    packed = str(tmp_path / "toy.sfmlocmap")
+    capi.pack(sfm_dir, match_dir, packed)
+    assert capi.scan_packed(packed) == capi.scan(sfm_dir, match_dir)
+    raw = open(packed, "rb").read()
+    assert raw[:8] == b"SFMLOCM1" and len(raw) > 64 * info_rows(m)
+    for bad in (raw[:len(raw) // 2], b"SFMLOCM2" + raw[8:], raw[:8]):
+        (tmp_path / "bad.bin").write_bytes(bad)
+        with pytest.raises(capi.SfmlocError) as ei:
+            capi.scan_packed(str(tmp_path / "bad.bin"))
+        assert ei.value.code == capi.EIO
+    with pytest.raises(capi.SfmlocError):
+        capi.scan_packed(str(tmp_path / "missing.bin"))
+    with pytest.raises(capi.SfmlocError):
+        capi.pack(str(tmp_path), match_dir, packed)            # no sfm_data.json there
+
+
+def info_rows(m):
+    return int(m.view_off[-1]) // 2
+
+
 def test_native_loader_errors(toy_map, tmp_path):
     m, sfm_dir, match_dir, names = toy_map
     with pytest.raises(capi.SfmlocError) as ei:

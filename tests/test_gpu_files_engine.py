@@ -82,6 +82,52 @@ def test_open_equals_in_memory_map(toy, oracle_c):
                 assert np.abs(np.array(pose.center) - q.C_true).max() < 0.3
 
 
+def test_open_packed_equals_open(toy, tmp_path):
+    """sfmloc_pack + sfmloc_open_packed: the same map as sfmloc_open on the files (view table, camera centres, every
+    localisation bit for bit), opened without touching them again."""
+    import time
+    m, root, names, queries = toy
+    packed = str(tmp_path / "toy.sfmlocmap")
+    capi.pack(str(root / "sfm"), str(root / "matches"), packed)
+    p = S.default_params(ransac_round=25)
+    t0 = time.perf_counter()
+    a = capi.Map.open(str(root / "sfm"), str(root / "matches"), p)
+    t1 = time.perf_counter()
+    b = capi.Map.open_packed(packed, p)
+    t2 = time.perf_counter()
+    try:
+        assert (a.n_views, a.n_rows) == (b.n_views, b.n_rows)
+        np.testing.assert_array_equal(a.view_id, b.view_id)
+        np.testing.assert_array_equal(a.view_off, b.view_off)
+        np.testing.assert_array_equal(a.view_center, b.view_center)
+        for base, q in queries:
+            desc = fileio.read_desc(root / "queries" / (base + ".desc"))
+            kp = fileio.read_feat(root / "queries" / (base + ".feat"))[:, :2]
+            ra = a.localize(a.query(desc, kp, 640, 480))
+            rb = b.localize(b.query(desc, kp, 640, 480))
+            assert ra[0].ok == rb[0].ok and ra[0].n_inliers == rb[0].n_inliers
+            np.testing.assert_array_equal(ra[1], rb[1])
+            np.testing.assert_array_equal(np.array(ra[0].P).view(np.uint64), np.array(rb[0].P).view(np.uint64))
+        assert (t2 - t1) < (t1 - t0)          # no JSON, no text .feat files
+    finally:
+        a.close()
+        b.close()
+    # both command-line programs take the packed file in place of <sfmDataDir>: same poses as from the directory
+    import subprocess
+    out_d, out_p, out_c = tmp_path / "o_dir", tmp_path / "o_packed", tmp_path / "o_packed_cc"
+    assert engine.main([str(root / "queries"), str(root / "sfm"), str(root / "matches"), str(out_d), "-r=25"]) == 0
+    assert engine.main([str(root / "queries"), packed, str(root / "matches"), str(out_p), "-r=25"]) == 0
+    r = subprocess.run([CLI_BIN, str(root / "queries"), packed, str(root / "matches"), str(out_c), "-r=25"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for base, q in queries:
+        jd, jp = json.load(open(out_d / (base + ".json"))), json.load(open(out_p / (base + ".json")))
+        assert jp["sfm_data"] == packed and jd["sfm_data"].endswith("sfm_data.json")
+        for key in ("K", "R", "t", "pair"):
+            assert jd.get(key) == jp.get(key), (base, key)
+        assert (out_c / (base + ".json")).read_bytes() == (out_p / (base + ".json")).read_bytes(), base
+
+
 def test_command_line_writes_the_reference_json(toy):
     m, root, names, queries = toy
     out = root / "loc_out"
