@@ -36,6 +36,17 @@ def test_errors():
         S.Undistorter(K, [], 1, 480)
 
 
+def test_apply_needs_the_gpu():
+    """The plan is host arithmetic; the per-image remap is a kernel and there is no CPU fallback for it."""
+    if S.device_count() > 0:
+        pytest.skip("GPU present")
+    K, dist, (w, h) = CAMERAS[2]
+    with S.Undistorter(K, dist, w, h) as u:
+        with pytest.raises(S.SfmlocError) as ei:
+            u.apply(np.zeros((h, w), np.uint8))
+        assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)      # SFMLOC_ENODEV
+
+
 def _pattern(x, y):
     """A smooth scene on the normalised image plane."""
     return 128 + 60 * np.sin(14 * x) * np.cos(11 * y) + 50 * np.cos(5 * x * y + 3 * y)
