@@ -289,6 +289,8 @@ def main(argv=None):
     except capi.SfmlocError as e:
         print(str(e), file=sys.stderr)
         return 1
+    # the query's view index in the reference's match files: id of the LAST view of sfm_data + 1 (localization.cpp:371)
+    ind_query_file = int(eng.map.view_id[-1]) + 1 if eng.map.n_views else 0
     if packed:
         wh0 = eng.map.view_sizes()[0]
         default_wh = (int(wh0[0]), int(wh0[1]))
@@ -296,6 +298,7 @@ def main(argv=None):
         sd = fileio.read_sfm_data(sfm_json)
         v0 = sd["views"][0]["value"]["ptr_wrapper"]["data"]
         default_wh = (int(v0["width"]), int(v0["height"]))
+        ind_query_file = max(int(v["value"]["ptr_wrapper"]["data"]["id_view"]) for v in sd["views"]) + 1
     every = o["locEvryNFrame"] if o["locEvryNFrame"] > 0 else 1
     os.makedirs(out_dir, exist_ok=True)
     n_img, match_next = 0, 0
@@ -350,6 +353,18 @@ def main(argv=None):
             print("Not enough putative matches")                             # :420
             fileio.write_result_json(out_dir, img, sfm_json, match_dir)
             continue
+        if o["writematch"]:
+            # -w: exportPairWiseMatches(map_geometricMatches, <matchDir>/matches.fQ.txt) (localization.cpp:452-455);
+            # the putative list goes to a per-query folder the reference deletes again (:399-403, :585).  Pair =
+            # (view id, id of the last view of sfm_data + 1), matches in AC-RANSAC's inlier order.
+            cnt, mi, mj, _ = eng.map.putative_read()
+            gc, gi = eng.map.geometric_read()
+            geo = {}
+            for v in np.nonzero(gc)[0]:
+                o0 = int(eng.map.view_off[v])
+                pp = gi[o0:o0 + int(gc[v])].astype(np.int64)
+                geo[(int(eng.map.view_id[v]), ind_query_file)] = (mi[o0 + pp], mj[o0 + pp])
+            fileio.write_matches_txt(os.path.join(match_dir, "matches.fQ.txt"), geo)
         print(f"number of geometric matches : {pose.n_geometric_views}")     # :458
         print(f"mapFeatTo3DFeat size = {pose.n_matches_2d3d}")               # :476
         print(f"cpt = {pose.n_matches_2d3d}")                                # :502

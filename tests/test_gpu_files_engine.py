@@ -202,6 +202,31 @@ def test_cpp_command_line_equals_python_mirror(toy, capsys):
     engine.main([str(root / "queries" / "q000.jpg"), str(root / "sfm"), str(root / "matches"), str(out_py4), "-r=25",
                  "-x=%g" % m.view_C[0, 0], "-y=%g" % m.view_C[0, 1], "-z=%g" % m.view_C[0, 2], "-d=40"])
     assert (root / "cmp_cc4" / "q000.json").read_bytes() == (out_py4 / "q000.json").read_bytes()
+    # -w: <matchDir>/matches.fQ.txt = the geometric matches of the (last) query, keyed (view id, last view id + 1)
+    # (localization.cpp:371,452-455): the same bytes from both programs, and the oracle's inlier lists
+    fq = root / "matches" / "matches.fQ.txt"
+    one = [str(root / "queries" / "q000.jpg"), str(root / "sfm"), str(root / "matches")]
+    assert engine.main(one + [str(root / "w_py"), "-r=25", "-w"]) == 0
+    py_bytes = fq.read_bytes()
+    os.remove(fq)
+    rc, so, se = _run_cli(one + [root / "w_cc", "-r=25", "-w"])
+    assert rc == 0, se
+    assert fq.read_bytes() == py_bytes and len(py_bytes) > 100
+    got = fileio.read_matches_txt(fq)
+    sub, keep, rows = posed_submap(m, (4,))
+    sub.kpt_xy = np.concatenate([fileio.read_feat(root / "matches" / (names[k] + ".feat"))[:, :2] for k in keep])
+    desc = fileio.read_desc(root / "queries" / "q000.desc")
+    kp = fileio.read_feat(root / "queries" / "q000.feat")[:, :2]
+    exp = opipe.localize(sub, desc, kp, (640, 480))
+    ind_q = int(max(m.view_id)) + 1
+    assert sorted(got) == [(int(sub.view_id[v]), ind_q) for v in np.nonzero(exp["geo_count"])[0]]
+    for v in np.nonzero(exp["geo_count"])[0]:
+        o0 = int(sub.view_off[v])
+        pp = exp["geo_idx"][o0:o0 + int(exp["geo_count"][v])].astype(np.int64)
+        gi, gj = got[(int(sub.view_id[v]), ind_q)]
+        np.testing.assert_array_equal(gi, exp["put_i"][o0 + pp])
+        np.testing.assert_array_equal(gj, exp["put_j"][o0 + pp])
+    os.remove(fq)
 
 
 def test_engine_mirror_return_convention(toy):
