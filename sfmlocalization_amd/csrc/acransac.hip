@@ -1013,6 +1013,7 @@ struct P3pShared {
   uint64_t key[kP3pMaxN];
   uint32_t idx[kP3pMaxN];
   double models[48];
+  P3pPrep prep;  // Kneip's intermediates + the quartic's roots (lane 0), read by the four model lanes
   int nm;
   double red_nfa[kThreads / 64];
   int red_k[kThreads / 64];
@@ -1035,7 +1036,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
   if (tid == 0) {
     int32_t smp[3];
     ac_sample<3>(st.identity ? nullptr : A.vec_index, st.n_index, A.seed, STAGE_P3P, A.stream, (uint32_t)it, smp);
-    double x[6], X[9], mm[48];
+    double x[6], X[9];
     for (int i = 0; i < 3; ++i) {
       x[2 * i] = A.xn[2 * smp[i]];
       x[2 * i + 1] = A.xn[2 * smp[i] + 1];
@@ -1043,12 +1044,12 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
       X[3 * i + 1] = A.pt3d[3 * smp[i] + 1];
       X[3 * i + 2] = A.pt3d[3 * smp[i] + 2];
     }
-    const int k = p3p_kneip(x, X, mm);
-    S.nm = k;
-    for (int q = 0; q < 12 * k; ++q) S.models[q] = mm[q];
+    S.nm = p3p_kneip_prepare(x, X, S.prep);
   }
   __syncthreads();
   const int nm = S.nm;
+  if (tid < nm) p3p_kneip_model(S.prep, tid, S.models + 12 * tid);  // the four roots' models side by side
+  __syncthreads();
   const double logalpha0 = det_log10(3.14159265358979323846);
   const double loge0 = det_log10(4.0 * (double)(n - s));
   double best = pos_inf();

@@ -210,7 +210,8 @@ GD double quartic_polish(const double a[5], double x) {
   return x;
 }
 
-GD void solve_quartic_real(const double a[5], double out[4]) {
+// the four candidates before their Newton polish (out[i], and whether root i is real and gets polished)
+GD void solve_quartic_raw(const double a[5], double out[4], int real[4]) {
   const double b = a[1] / a[0], c = a[2] / a[0], d = a[3] / a[0], e = a[4] / a[0];
   const double b2 = b * b;
   const double p = c - 0.375 * b2;
@@ -218,7 +219,8 @@ GD void solve_quartic_real(const double a[5], double out[4]) {
   const double r = e - 0.25 * b * d + 0.0625 * b2 * c - 0.01171875 * b2 * b2;
   const double shift = -0.25 * b;
   double y[4];
-  int real[4] = {0, 0, 0, 0};
+  #pragma unroll
+  for (int i = 0; i < 4; ++i) real[i] = 0;
   if (is_nan(p) || is_nan(q) || is_nan(r) || is_inf(p) || is_inf(q) || is_inf(r)) {
     #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = q_nan();
@@ -298,11 +300,15 @@ GD void solve_quartic_real(const double a[5], double out[4]) {
     }
   }
   #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    double x = y[i] + shift;
-    if (real[i]) x = quartic_polish(a, x);
-    out[i] = x;
-  }
+  for (int i = 0; i < 4; ++i) out[i] = y[i] + shift;
+}
+
+GD void solve_quartic_real(const double a[5], double out[4]) {
+  int real[4];
+  solve_quartic_raw(a, out, real);
+  #pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (real[i]) out[i] = quartic_polish(a, out[i]);
 }
 
 GD double det3c(const double *a, const double *b, const double *c) {
@@ -519,7 +525,16 @@ GD void transpose3(const double A[9], double T[9]) {
 }
 
 // x2d: 3 x 2 normalised image points, X: 3 x 3 world points (row = point); models: 4 x 12 [R|t] row-major.
-GD int p3p_kneip(const double *x2d, const double *X, double *models) {
+// Kneip's P3P in two parts: everything up to the quartic's four roots (one lane), then one model per root (the four
+// are independent, so k_p3p_eval gives them to four lanes); p3p_kneip below is the two put together.
+struct P3pPrep {
+  double f_1, f_2, p_1, p_2, d_12, b;
+  double N[9], T[9], P1[3];
+  double fac[5], roots[4];  // the quartic and its roots BEFORE the Newton polish, which is per root
+  int real[4];
+};
+
+GD int p3p_kneip_prepare(const double *x2d, const double *X, P3pPrep &S) {
   double P1[3] = {X[0], X[1], X[2]}, P2[3] = {X[3], X[4], X[5]}, P3[3] = {X[6], X[7], X[8]};
   double f1[3] = {x2d[0], x2d[1], 1.0}, f2[3] = {x2d[2], x2d[3], 1.0}, f3[3] = {x2d[4], x2d[5], 1.0};
   normalize3(f1);
@@ -603,14 +618,38 @@ GD int p3p_kneip(const double *x2d, const double *X, double *models) {
            p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2.0 * f_2_pw2 * p_2_pw2 * p_1 * d_12 +
            p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
 
-  double roots[4];
-  solve_quartic_real(fac, roots);
-
-  double NT[9];
-  transpose3(N, NT);
+  solve_quartic_raw(fac, S.roots, S.real);
   #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const double cos_theta = roots[i];
+  for (int k = 0; k < 5; ++k) S.fac[k] = fac[k];
+  S.f_1 = f_1, S.f_2 = f_2, S.p_1 = p_1, S.p_2 = p_2, S.d_12 = d_12, S.b = b;
+  #pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    S.N[k] = N[k];
+    S.T[k] = T[k];
+  }
+  S.P1[0] = P1[0], S.P1[1] = P1[1], S.P1[2] = P1[2];
+  return 4;
+}
+
+// the model of root i: M = [R | -R C], 3 x 4 row major
+GD void p3p_kneip_model(const P3pPrep &S, int i, double *M) {
+  const double f_1 = S.f_1, f_2 = S.f_2, p_1 = S.p_1, p_2 = S.p_2, d_12 = S.d_12, b = S.b;
+  double N[9], T[9], NT[9];
+  #pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    N[k] = S.N[k];
+    T[k] = S.T[k];
+  }
+  const double P1[3] = {S.P1[0], S.P1[1], S.P1[2]};
+  transpose3(N, NT);
+  {
+    double cos_theta = S.roots[i];
+    if (S.real[i]) {
+      double fac[5];
+      #pragma unroll
+      for (int k = 0; k < 5; ++k) fac[k] = S.fac[k];
+      cos_theta = quartic_polish(fac, cos_theta);
+    }
     const double cot_alpha =
         (-f_1 * p_1 / f_2 - cos_theta * p_2 + d_12 * b) / (-f_1 * cos_theta * p_2 / f_2 + p_1 - d_12);
     const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
@@ -632,7 +671,6 @@ GD int p3p_kneip(const double *x2d, const double *X, double *models) {
     transpose3(T, TT);
     matmul3(TT, QN, R);
     matvec3(R, C, t);
-    double *M = models + 12 * i;
     #pragma unroll
     for (int r = 0; r < 3; ++r) {
       M[4 * r + 0] = R[3 * r + 0];
@@ -641,6 +679,13 @@ GD int p3p_kneip(const double *x2d, const double *X, double *models) {
       M[4 * r + 3] = -t[r];
     }
   }
+}
+
+GD int p3p_kneip(const double *x2d, const double *X, double *models) {
+  P3pPrep S;
+  if (!p3p_kneip_prepare(x2d, X, S)) return 0;
+  #pragma unroll
+  for (int i = 0; i < 4; ++i) p3p_kneip_model(S, i, models + 12 * i);
   return 4;
 }
 
