@@ -913,19 +913,20 @@ __global__ __launch_bounds__(256) void k_candidates_win(const unsigned char *par
 
 // single wave: compact the winners in ascending query-feature order (SfMDataUtils.cpp:121-124) and assemble
 // pt2D / pt3D (localization.cpp:479-501; pinhole get_ud_pixel is the identity)
-__global__ __launch_bounds__(256) void k_match_set_finish(const unsigned char *parts, uint64_t part_bytes,
+__global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *parts, uint64_t part_bytes,
                                                           uint32_t cap, const unsigned long long *best,
                                                           const uint32_t *winner, uint32_t nq, const float2 *q_kpt,
                                                           uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
                                                           double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
                                                           double ppy, double k1, double k2, double k3) {
-  // one workgroup; winners are compacted in query-feature order, 256 features per pass
-  __shared__ uint32_t wave_cnt[4];
+  // one workgroup; winners are compacted in query-feature order, 1024 features per pass (a pass is a chain of
+  // dependent loads, so fewer, wider passes)
+  __shared__ uint32_t wave_cnt[16];
   __shared__ uint32_t base_s;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();
-  for (uint32_t j0 = 0; j0 < nq; j0 += 256) {
+  for (uint32_t j0 = 0; j0 < nq; j0 += 1024) {
     const uint32_t j = j0 + threadIdx.x;
     const bool has = j < nq && best[j] != ~0ull;
     const unsigned long long mask = __ballot(has);
@@ -949,7 +950,11 @@ __global__ __launch_bounds__(256) void k_match_set_finish(const unsigned char *p
       pt3d[3 * pos + 2] = c.X[2];
     }
     __syncthreads();
-    if (threadIdx.x == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (uint32_t w = 0; w < 16; ++w) t += wave_cnt[w];
+      base_s += t;
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) *ms_n = base_s;
@@ -1667,7 +1672,7 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
   hipLaunchKernelGGL(k_candidates_win, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
                      c->d_best64, c->d_winner);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(256), 0, c->stream, parts, part_bytes, cap, c->d_best64,
+  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(1024), 0, c->stream, parts, part_bytes, cap, c->d_best64,
                      c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d,
                      c->map->intrinsic_type == 3 ? 1 : 0, c->map->focal, c->map->ppx, c->map->ppy, c->map->k1, c->map->k2,
                      c->map->k3);
