@@ -318,6 +318,7 @@ int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_se
   uint32_t n_work_blocks = m->n_blocks;
   c->last_blocks.clear();
   c->last_blocks_on_device = false;
+  c->flagmask_zeroed = false;
   if (d_sel) {
     // launch bound the host can know: every selected view overlaps at most max_view_blocks blocks
     const uint64_t bound = std::min<uint64_t>(m->n_blocks, (uint64_t)n_sel * m->max_view_blocks);

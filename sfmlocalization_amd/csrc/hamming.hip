@@ -615,8 +615,9 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
     qsplit *= 2;
   if (!c->k1_may_slice) qsplit = 1;  // other queries are queued on the GPU: their scans fill it, slices only add work
   if (qsplit_env == 1 || qsplit_env == 2 || qsplit_env == 4) qsplit = (uint32_t)qsplit_env;
-  if (qsplit > 1)
+  if (qsplit > 1 && !c->flagmask_zeroed)
     SFM_HIP(hipMemsetAsync(c->d_flagmask, 0, (size_t)n_work_blocks * sizeof(unsigned long long), c->stream));
+  c->flagmask_zeroed = false;
 #define K1_SCREEN(NW)                                                                                              \
   case NW:                                                                                                        \
     hipLaunchKernelGGL((k_hamming_screen<WAVES, NW, 1>), dim3((n_work_blocks + WAVES - 1) / WAVES, qsplit),       \
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(1024) void k_blocks_from_views(const uint32_t *__re
                                                             const uint32_t *__restrict__ view_off,
                                                             uint32_t *__restrict__ view_sel_out,
                                                             uint32_t *__restrict__ widx0, uint32_t *__restrict__ block_list,
-                                                            uint32_t bound) {
+                                                            uint32_t bound, unsigned long long *__restrict__ flagmask) {
   __shared__ uint32_t s_last[1024];  // inclusive running max of (last block + 1) over the non-empty views so far
   __shared__ uint32_t s_cnt[1024];   // inclusive scan of the blocks each view adds
   __shared__ uint32_t s_carry_last, s_carry_cnt;
@@ -713,13 +714,16 @@ __global__ __launch_bounds__(1024) void k_blocks_from_views(const uint32_t *__re
     __syncthreads();
   }
   for (uint32_t w = s_carry_cnt + tid; w < bound; w += 1024) block_list[w] = kNoBlock;
+  // a sliced scan ORs its row flags into the per-block masks: clear them here rather than with one more launch
+  for (uint32_t w = tid; w < bound; w += 1024) flagmask[w] = 0ull;
 }
 
 int launch_blocks_from_views(Ctx *c, const uint32_t *d_sel, uint32_t n_sel, uint32_t bound) {
   Map *m = c->map;
   hipLaunchKernelGGL(k_blocks_from_views, dim3(1), dim3(1024), 0, c->stream, d_sel, n_sel, m->d_view_off, c->d_view_sel,
-                     c->d_view_widx0, c->d_block_list, bound);
+                     c->d_view_widx0, c->d_block_list, bound, c->d_flagmask);
   SFM_HIP(hipGetLastError());
+  c->flagmask_zeroed = true;
   return SFMLOC_OK;
 }
 

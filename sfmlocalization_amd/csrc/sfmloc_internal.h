@@ -203,6 +203,7 @@ struct Ctx {
   uint32_t last_n_work_blocks = 0;
   std::vector<uint32_t> last_blocks;  // host copy of the block list (empty = all)
   bool last_blocks_on_device = false; // the list was built by k_blocks_from_views: fetch it when a reader needs it
+  bool flagmask_zeroed = false;       // k_blocks_from_views has just cleared d_flagmask for the coming scan
   bool counted_busy = false;          // this context is counted in Map::busy_ctx
   bool k1_may_slice = true;           // no other context had work queued when this query began
   bool cleared = false;  // k_query_reset already cleared this query's counters: the stages skip their own memsets
