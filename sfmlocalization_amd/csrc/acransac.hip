@@ -488,7 +488,8 @@ constexpr int kF2Batch = 32;   // uniform iterations solved speculatively per ba
 
 struct F2Shared {
   uint32_t idx[kF2Waves][kF2MaxM];  // sorted match indices of the model each wave evaluated last
-  double pts[kF2MaxM][4];  // normalised (x, y) of the map keypoint, (u, w) of the query keypoint
+  double pts[4][kF2MaxM];  // normalised x, y of the map keypoint, u, w of the query keypoint (one plane each: a
+                           // wave reading element p of 64 consecutive matches hits 64 different banks)
   int32_t vec_index[kF2MaxM];
   int32_t best_inl[kF2MaxM];
   float logc_n[kF2MaxM + 1];
@@ -565,10 +566,10 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
     const uint32_t j = A.match_key[off + p] & 0xFFFFu;
     const float2 a = A.map_kpt[off + i];
     const float2 b = A.q_kpt6[j];
-    S.pts[p][0] = s1 * (double)a.x + t1x;
-    S.pts[p][1] = s1 * (double)a.y + t1y;
-    S.pts[p][2] = s2 * (double)b.x + t2x;
-    S.pts[p][3] = s2 * (double)b.y + t2y;
+    S.pts[0][p] = s1 * (double)a.x + t1x;
+    S.pts[1][p] = s1 * (double)a.y + t1y;
+    S.pts[2][p] = s2 * (double)b.x + t2x;
+    S.pts[3][p] = s2 * (double)b.y + t2y;
   }
   // logcombi tables (logcombi_tables_block is written for 256 threads); pre_models is free until the first batch
   logc_n_block(m, A.L10, &S.pre_models[0][0], S.logc_n, kF2Threads);
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
     for (int q = 1; q < 7; ++q)
       if (r == q) pidx = smp[q];
     double f = 0.0;
-    const int nm = wave_seven_point(S.pts[pidx][0], S.pts[pidx][1], S.pts[pidx][2], S.pts[pidx][3], &f);
+    const int nm = wave_seven_point(S.pts[0][pidx], S.pts[1][pidx], S.pts[2][pidx], S.pts[3][pidx], &f);
     if (lane < 9 * nm) models[lane] = f;
     if (lane == 0) *nm_out = nm;
   };
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
     for (int r = 0; r < E; ++r) {
       const int p = (r << 6) + lane;
       uint64_t kv = ~0ull;
-      if (p < m) kv = d2u(err_fmatrix(M, S.pts[p][0], S.pts[p][1], S.pts[p][2], S.pts[p][3]));
+      if (p < m) kv = d2u(err_fmatrix(M, S.pts[0][p], S.pts[1][p], S.pts[2][p], S.pts[3][p]));
       key[r] = kv;
       idx[r] = (uint32_t)p;
     }
