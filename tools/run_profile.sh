@@ -14,6 +14,9 @@ timeout -k 10 400 python bench.py --views 10000 --bow-knn 100 --steps 384 --warm
 tail -1 gpurun_out/bench_cfg3.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_run -- python3 $R/bench.py --steps 30 --warmup 4 --no-cpu-baseline > $R/gpurun_out/bench_prof_run.log 2>&1 || exit 1
+# the same with one query in flight: a launch's duration is then the kernel's own (in the default run four queries share
+# the chip and every launch is stretched by the others' work), and rocprof's average agrees with bench.py's events
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_lat_run -- python3 $R/bench.py --in-flight 1 --steps 40 --warmup 4 --no-cpu-baseline > $R/gpurun_out/bench_prof_lat_run.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_run -- python3 $R/bench.py --steps 6 --warmup 2 --in-flight 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch_run.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_run -- python3 $R/bench.py --steps 6 --warmup 2 --in-flight 1 --no-cpu-baseline > $R/gpurun_out/pmc_write_run.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc_sq_run -- python3 $R/bench.py --steps 6 --warmup 2 --in-flight 1 --no-cpu-baseline > $R/gpurun_out/pmc_sq_run.log 2>&1 || exit 1
