@@ -28,6 +28,9 @@ for it in range(60):
             c.end()
         dm.localize(dq)
         dm.bow_select(np.random.rand(16).astype(np.float32), 5)
+        ctxs[0].begin_bow(dq, np.random.rand(16).astype(np.float32), 5)
+        ctxs[0].end()
+        dm.localize_bow(dq, np.random.rand(16).astype(np.float32), 5)
         qv = dm.query_from_view(2)
         dm.match_one_to_one(qv, np.array([1], np.uint32))
         dm.track(3)
@@ -39,6 +42,9 @@ for it in range(60):
     ak.detect_and_compute(img)
     ak.close()
     S.dense_gray(bgr, 64)
+    with S.Undistorter(np.array([[300.0, 0, 160], [0, 300, 120], [0, 0, 1]]), [-0.2, 0.05, 0, 0], 320, 240) as ud:
+        ud.apply(bgr)
+        ud.apply(img)
     if it % 10 == 9:
         torch.cuda.synchronize()
         free.append(torch.cuda.mem_get_info()[0])
