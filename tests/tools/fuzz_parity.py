@@ -37,8 +37,9 @@ def one(seed):
     nq = int(rng.choice([300, 700, 900, 1500, 2300]))
     p = S.default_params(dist_ratio=ratio, ransac_round=rounds)
     n_cmp = 0
+    bow = np.sqrt(rng.random((n_views, 64))).astype(np.float32)       # .bow vectors for the shortlist chain
     with S.Map(m.view_id, m.view_off, m.desc, params=p, view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark,
-               landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic) as dm:
+               landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic, bow=bow) as dm:
         for k in range(3):
             q = synth.make_query(m, seed * 10 + k, n_feat=nq, n_copies=int(rng.integers(0, min(nq, 400))),
                                  outlier_frac=float(rng.uniform(0.0, 0.7)))
@@ -65,8 +66,23 @@ def one(seed):
             c = dm.context()
             c.begin(dq, sel)
             pose2, pq2, _ = c.end()
-            c.close()
             assert bool(pose2.ok) == exp["ok"] and (not exp["ok"] or np.array_equal(pq2, exp["pair_qfeat"]))
+            # shortlist + path in one call (the shortlist never leaves the device) against the oracle's shortlist
+            # followed by the oracle's path on it
+            if rng.uniform() < 0.5:
+                n_cand = n_views if sel is None else len(sel)
+                knn = int(rng.integers(1, n_cand + 3))
+                qb = (bow[rng.integers(0, n_views)] + rng.normal(0, 0.05, 64)).astype(np.float32)
+                osel = oracle_c.bow_select(bow, qb, knn, sel) if knn < n_cand else sel
+                exp_b = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=osel, ratio=ratio,
+                                       ransac_round=rounds)
+                c.begin_bow(dq, qb, knn, sel)
+                pose3, pq3, _ = c.end()
+                assert bool(pose3.ok) == exp_b["ok"], "shortlist chain: ok flag"
+                if exp_b["ok"]:
+                    assert np.array_equal(pq3, exp_b["pair_qfeat"]), "shortlist chain: pairs"
+                    assert np.array_equal(bits(np.array(pose3.P)), bits(exp_b["P"].ravel())), "shortlist chain: P"
+            c.close()
             dq.close()
             n_cmp += 1
     return n_cmp
