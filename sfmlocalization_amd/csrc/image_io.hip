@@ -12,7 +12,7 @@
 //         Y plane itself -- no colour conversion, no upsampling.  tests/test_image_io.py pins every mode against
 //         libjpeg-turbo (through PIL) bit for bit.
 //   PNG   8 bit, non-interlaced: gray, gray+alpha, RGB, RGBA, palette.  IMREAD_GRAYSCALE on a colour PNG is libpng's
-//         png_set_rgb_to_gray(1, 0.299, 0.587) (grfmt_png.cpp): (9797 R + 19234 G + 3737 B + 16384) >> 15, and the
+//         png_set_rgb_to_gray(1, 0.299, 0.587) (grfmt_png.cpp): (9797 R + 19234 G + 3737 B) >> 15 (truncated), and the
 //         pixel itself when R == G == B.
 //   PGM/PPM binary, maxval 255 (cvtColor BGR2GRAY for colour, as grfmt_pxm.cpp does through icvCvt_BGR2Gray).
 #include <zlib.h>
@@ -91,10 +91,11 @@ inline uint32_t be32(const uint8_t *p) {
   return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
 }
 
-// libpng png_do_rgb_to_gray, 8 bit, no gamma; coefficients of png_set_rgb_to_gray_fixed(29900, 58700)
+// libpng png_do_rgb_to_gray, 8 bit, no gamma; coefficients of png_set_rgb_to_gray_fixed(29900, 58700); libpng
+// truncates ("the historical approach"), it does not round -- pinned against libpng 1.6 itself in tests/test_image_io.py
 inline uint8_t png_rgb_to_gray(int r, int g, int b) {
   if (r == g && r == b) return (uint8_t)r;
-  return (uint8_t)((9797 * r + 19234 * g + 3737 * b + 16384) >> 15);
+  return (uint8_t)((9797 * r + 19234 * g + 3737 * b) >> 15);
 }
 
 bool decode_png(const uint8_t *raw, size_t n_raw, bool color, Image *im, std::string *err) {

@@ -3,8 +3,8 @@ DenseLocalFeatureWrapper.cpp:85 IMREAD_COLOR).  Host code of the C-ABI library, 
 
 Pinned: JPEG against libjpeg-turbo (the committed fixtures of tests/golden/make_image_fixtures.py, and live through
 PIL when Pillow is importable), bit for bit, in colour (JCS_RGB, fancy upsampling) and gray (JCS_GRAYSCALE = Y plane);
-PNG colour against PIL (lossless).  PNG colour -> gray follows libpng's png_set_rgb_to_gray as OpenCV's decoder sets it
-up; that formula is restated here independently (no libpng binding in this image)."""
+PNG against libpng 1.6 itself (libpng16.so.16 is in the image; driven through ctypes exactly as OpenCV's decoder drives
+it), colour and gray, every accepted colour type and bit depth."""
 import io
 import os
 
@@ -22,9 +22,100 @@ PNG_NAMES = ["rgb", "rgba", "gray", "palette", "gray_alpha"]
 
 def png_gray(bgr):
     b, g, r = (bgr[:, :, i].astype(np.int64) for i in range(3))
-    out = (9797 * r + 19234 * g + 3737 * b + 16384) >> 15
+    out = (9797 * r + 19234 * g + 3737 * b) >> 15          # libpng truncates (png_do_rgb_to_gray)
     same = (r == g) & (r == b)
     return np.where(same, r, out).astype(np.uint8)
+
+
+def libpng_read(path, color):
+    """What OpenCV's PNG decoder does (grfmt_png.cpp PngDecoder::readData), executed by libpng itself through ctypes:
+    strip 16 -> 8 bits and alpha, palette -> RGB, low-bit gray -> 8 bits, then png_set_bgr (colour out of colour),
+    png_set_gray_to_rgb (colour out of gray) or png_set_rgb_to_gray(1, 0.299, 0.587) (gray)."""
+    import ctypes as C
+    png = C.CDLL("libpng16.so.16")
+    libc = C.CDLL(None)
+    libc.fopen.restype, libc.fopen.argtypes = C.c_void_p, [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    png.png_create_read_struct.restype = C.c_void_p
+    png.png_create_read_struct.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    png.png_create_info_struct.restype, png.png_create_info_struct.argtypes = C.c_void_p, [C.c_void_p]
+    png.png_init_io.argtypes = [C.c_void_p, C.c_void_p]
+    png.png_read_info.argtypes = [C.c_void_p, C.c_void_p]
+    for f in ("png_get_image_width", "png_get_image_height"):
+        getattr(png, f).restype, getattr(png, f).argtypes = C.c_uint32, [C.c_void_p, C.c_void_p]
+    for f in ("png_get_color_type", "png_get_bit_depth"):
+        getattr(png, f).restype, getattr(png, f).argtypes = C.c_ubyte, [C.c_void_p, C.c_void_p]
+    png.png_set_rgb_to_gray.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+    for f in ("png_set_strip_alpha", "png_set_palette_to_rgb", "png_set_expand_gray_1_2_4_to_8", "png_set_strip_16",
+              "png_set_bgr", "png_set_gray_to_rgb"):
+        getattr(png, f).argtypes = [C.c_void_p]
+    png.png_read_update_info.argtypes = [C.c_void_p, C.c_void_p]
+    png.png_get_rowbytes.restype, png.png_get_rowbytes.argtypes = C.c_size_t, [C.c_void_p, C.c_void_p]
+    png.png_read_image.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    png.png_read_end.argtypes = [C.c_void_p, C.c_void_p]
+    png.png_destroy_read_struct.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]
+    fp = libc.fopen(os.fsencode(path), b"rb")
+    assert fp
+    p = C.c_void_p(png.png_create_read_struct(b"1.6.37", None, None, None))
+    info = C.c_void_p(png.png_create_info_struct(p))
+    png.png_init_io(p, fp)
+    png.png_read_info(p, info)
+    w, h = png.png_get_image_width(p, info), png.png_get_image_height(p, info)
+    ct, bd = png.png_get_color_type(p, info), png.png_get_bit_depth(p, info)
+    if bd == 16:
+        png.png_set_strip_16(p)
+    png.png_set_strip_alpha(p)
+    if ct == 3:
+        png.png_set_palette_to_rgb(p)
+    if ct == 0 and bd < 8:
+        png.png_set_expand_gray_1_2_4_to_8(p)
+    if (ct & 2 or ct == 3) and color:
+        png.png_set_bgr(p)
+    elif color:
+        png.png_set_gray_to_rgb(p)
+    else:
+        png.png_set_rgb_to_gray(p, 1, 0.299, 0.587)
+    png.png_read_update_info(p, info)
+    rb = png.png_get_rowbytes(p, info)
+    buf = np.zeros((h, rb), np.uint8)
+    rows = (C.c_void_p * h)(*[buf.ctypes.data + i * rb for i in range(h)])
+    png.png_read_image(p, rows)
+    png.png_read_end(p, None)
+    png.png_destroy_read_struct(C.byref(p), C.byref(info), None)
+    libc.fclose(fp)
+    return buf.reshape(h, -1, 3)[:, :w] if color else buf[:, :w]
+
+
+def test_png_equals_libpng_itself(tmp_path):
+    """The PNG reader against libpng 1.6 (the library under OpenCV's decoder), driven the way grfmt_png.cpp drives it:
+    every colour type and bit depth the reader accepts, gray and colour output, bit for bit -- including libpng's
+    truncating RGB -> gray."""
+    import ctypes
+    try:
+        ctypes.CDLL("libpng16.so.16")
+    except OSError:
+        pytest.skip("libpng16 is not in this image")
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    img[5:9, :, 1] = img[5:9, :, 0]
+    img[5:9, :, 2] = img[5:9, :, 0]                                   # exact grays inside a colour image
+    alpha = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    cases = {"rgb": Image.fromarray(img), "rgba": Image.fromarray(np.dstack([img, alpha])),
+             "gray": Image.fromarray(img[:, :, 0]), "la": Image.fromarray(np.dstack([img[:, :, 0], alpha]), "LA"),
+             "pal256": Image.fromarray(img).quantize(256), "pal16": Image.fromarray(img).quantize(16),
+             "pal2": Image.fromarray(img).quantize(2), "bilevel": Image.fromarray(img[:, :, 0]).convert("1"),
+             "gray16": Image.fromarray((img[:, :, 0].astype(np.uint16) * 257 + 13))}
+    for name, im in cases.items():
+        path = str(tmp_path / (name + ".png"))
+        im.save(path, "PNG")
+        for color in (False, True):
+            np.testing.assert_array_equal(capi.image_read(path, color), libpng_read(path, color), err_msg=f"{name} {color}")
+    for name in PNG_NAMES:
+        path = os.path.join(GOLD, name + ".png")
+        for color in (False, True):
+            np.testing.assert_array_equal(capi.image_read(path, color), libpng_read(path, color), err_msg=name)
 
 
 @pytest.mark.parametrize("name", JPEG_NAMES)
