@@ -270,6 +270,14 @@ int load_scene(const char *sfm_dir, const char *match_dir, Scene &S) {
                   S.ppx = pp->arr[0].num;
                   S.ppy = pp->arr[1].num;
                 }
+                // other OpenMVG camera models (radial_k1, brown_t2, fisheye) would need their own get_ud_pixel: refuse
+                // them rather than treat them as an undistorted pinhole
+                for (const char *other : {"disto_k1", "disto_t2", "fisheye"})
+                  if (d->get(other)) {
+                    set_error("%s: intrinsic 0 carries \"%s\": only pinhole and pinhole_radial_k3 cameras are supported",
+                              sfm_path.c_str(), other);
+                    return SFMLOC_EIO;
+                  }
                 const JVal *dk = d->get("disto_k3");
                 if (dk && dk->arr.size() == 3) {
                   S.intrinsic_type = 3;

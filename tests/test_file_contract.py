@@ -128,6 +128,19 @@ def info_rows(m):
     return int(m.view_off[-1]) // 2
 
 
+def test_native_loader_refuses_other_camera_models(toy_map, tmp_path):
+    """A map whose intrinsic is another OpenMVG model (radial_k1, brown_t2 ...) is refused instead of being localised
+    with the wrong undistortion."""
+    m, sfm_dir, match_dir, names = toy_map
+    text = open(os.path.join(sfm_dir, "sfm_data.json")).read()
+    assert '"principal_point"' in text
+    bad = text.replace('"principal_point"', '"disto_k1": [0.1], "principal_point"', 1)
+    (tmp_path / "sfm_data.json").write_text(bad)
+    with pytest.raises(capi.SfmlocError) as ei:
+        capi.scan(str(tmp_path), match_dir)
+    assert ei.value.code == capi.EIO and "disto_k1" in str(ei.value) and "pinhole_radial_k3" in str(ei.value)
+
+
 def test_native_loader_errors(toy_map, tmp_path):
     m, sfm_dir, match_dir, names = toy_map
     with pytest.raises(capi.SfmlocError) as ei:
