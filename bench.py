@@ -440,7 +440,7 @@ def main():
                 "valu_achieved": iso[1] / (iso[0] * 1e-3) / 1e12,
                 "valu_frac": iso[1] / (iso[0] * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                 "pairs_per_s": pairs / (iso[0] * 1e-3)}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = (cpu_baseline_shortlist(m, queries, bow, qbow, a.bow_knn, a.cpu_seconds)
                                    if a.bow_knn > 0 else cpu_baseline(m, queries, a.cpu_seconds))
         print(json.dumps(out), flush=True)
