@@ -2,43 +2,87 @@
 """bench.py -- the reference's headline metric on MI355X.
 
 metric : query images localised per second (BASELINE.json), whole job over all N GPUs
-step   : one pass of the hot path over one query (inputs resident in HBM before the timed region)
-N = 1  : BASELINE.json configs[1] -- 1 k-image / 2 M-descriptor synthetic map, 2 k feats/query
-N > 1  : the same map sharded by view across the N ranks (strong scaling)
+step   : one pass of the hot path over one BATCH of `--batch` queries (256: the batch BASELINE configs[3] names);
+         query descriptors, keypoints and BoW vectors are resident in HBM before the timed region
+N = 1  : BASELINE.json configs[2] -- 10 k-image / 20 M-descriptor synthetic map, 2 k feats/query, every query first
+         shortlists k = 100 views by exact L2 over the 10 000 x 500 .bow matrix, then runs the whole path on them
+N > 1  : the same map and workload with the bank (and the .bow matrix) sharded by view across the N ranks
+         (BASELINE configs[3]/[4]): sharded shortlist (one small all-gather of per-shard k best), shard
+         local K1..K3, ONE all-gather of candidate parts per batch over RCCL, P3P of query i on rank i mod N.
+         Strong scaling on a fixed map.
 
-Prints ONE JSON line (rank 0).  Adds `roofline` (dominant kernel = K1 Hamming 2-NN) and `cpu_baseline`
-(the C oracle timed on this host's cores on a bounded sample).
+`python bench.py --gpus N` without a launcher starts the N ranks itself (before any GPU call) through
+torch.distributed.run and relays rank 0's JSON line; under a launcher a rank insists on WORLD_SIZE == --gpus.
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel family (K1 Hamming 2-NN) measured live, one launch
+in flight, on the FULL 20 M-row bank of the same map (SURVEY 8d cfg 3); `cpu_baseline` = the C oracle timed on this
+host's cores on a bounded sample of the same workload (N = 1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-# one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
-# (so does the image-in mode: a context and an extractor stream per worker)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or
-                                                    os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1" or
-                                                    "--from-images" in sys.argv) else "8")
-
-import numpy as np  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
-VALU_PEAK_TOPS = 39.1  # measured ceiling of the xor+bcnt instruction mix at 8 waves/SIMD (profiles/r01_valu_rates.jsonl)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_COPY_GBS = 6290.0
+# Issue ceiling of K1's instruction mix (v_xor_b32 + v_bcnt_u32_b32 1:1) at 8 waves per SIMD on a balanced
+# persistent grid: tools/valu_rates.hip -> profiles/r02_valu_rates.jsonl (in-kernel stamps and wall time agree)
+VALU_PEAK_TOPS = 51.0
 OPS_PER_PAIR = 35  # 16 xor + 16 bcnt + lshl_or + med3 + min (hamming.hip)
 
+# HBM bytes per launch of the roofline kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
+# runs of this command, corrected as MI355X_MICROARCH.md prescribes; tools/run_profile.sh + tools/pmc_summary.py).
+# PMC cannot be collected from inside this process, so this one field is read from the committed summary.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary_fullscan.json")
 
-# HBM bytes per K1 launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs of this same
-# command, corrected as MI355X_MICROARCH.md prescribes; tools/run_profile.sh + tools/pmc_summary.py)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary_screen.json")
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="queries per step (and per all-gather when --gpus > 1)")
+    ap.add_argument("--views", type=int, default=10000)
+    ap.add_argument("--desc-per-view", type=int, default=2000)
+    ap.add_argument("--nq", type=int, default=2000)
+    ap.add_argument("--bow-knn", type=int, default=100,
+                    help="views shortlisted per query by BoW distance (BASELINE configs[2]); 0 = every view is "
+                         "scanned (configs[1] with --views 1000)")
+    ap.add_argument("--queries", type=int, default=16, help="distinct synthetic queries cycled through")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="queries in flight per GPU (contexts); 0 = 8 with a shortlist, 4 for full scans; 1 = latency mode")
+    ap.add_argument("--from-images", action="store_true",
+                    help="image-in serving mode (1 GPU): every query first extracts AKAZE + M-LDB features from a synthetic "
+                         "640x480 image on the GPU (sfmloc_akaze_detect_and_compute, its own stream); --in-flight worker "
+                         "threads, one extractor and one context each.  The map is synthetic, so the localised descriptors "
+                         "are the synthetic query's, not the image's: the point is the cost of extraction sharing the GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-phase", action="store_true", help="skip the full-bank scan and the N_q sweep")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args(argv)
 
 
-def pmc_traffic(default_workload):
-    """HBM bytes per launch of the dominant kernel, or None when no PMC pass exists for this workload."""
-    if not default_workload or not os.path.exists(PMC_SUMMARY):
+def spawn_ranks(a):
+    """`--gpus N` (N > 1) without a launcher: start N fresh ranks as CHILD processes -- this parent has made no GPU
+    call and never will -- relay their output (rank 0 prints the JSON line) and return their exit status."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_traffic(match):
+    """HBM bytes per launch of the roofline kernel, or None when no PMC pass exists for this workload."""
+    if not match or not os.path.exists(PMC_SUMMARY):
         return None, None
     with open(PMC_SUMMARY) as fh:
         d = json.load(fh)
@@ -50,57 +94,12 @@ def pmc_traffic(default_workload):
     return tot, os.path.relpath(PMC_SUMMARY, ROOT)
 
 
-def hbm_regime():
-    """The same kernel family where it IS HBM-bound: few query rows per bank pass, measured by
-    tools/hbm_sweep.py on the GPU box and committed; reported next to the headline workload's (VALU-bound) figure."""
-    path = os.path.join(ROOT, "profiles", "r01_k1_small_nq_hbm_sweep.jsonl")
-    if not os.path.exists(path):
-        return None
-    rows = [json.loads(ln) for ln in open(path) if ln.strip()]
-    rows = [r for r in rows if r.get("nq", 99) <= 8]
-    if not rows:
-        return None
-    best = max(rows, key=lambda r: r["bank_GBps"])
-    return {"nq": best["nq"], "bank_rows": best["rows"], "achieved": best["bank_GBps"], "unit": "GB/s of bank bytes",
-            "peak": HBM_PEAK_GBS, "frac": best["bank_GBps"] / HBM_PEAK_GBS,
-            "note": "plus 12.5 % partial-result writes; 6.3 TB/s is the measured copy peak of this chip",
-            "source": os.path.relpath(path, ROOT)}
-
-
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--views", type=int, default=1000)
-    ap.add_argument("--desc-per-view", type=int, default=2000)
-    ap.add_argument("--nq", type=int, default=2000)
-    ap.add_argument("--queries", type=int, default=8, help="distinct synthetic queries cycled through")
-    ap.add_argument("--in-flight", type=int, default=4, help="queries in flight (contexts); 1 = latency mode")
-    ap.add_argument("--batch", type=int, default=0,
-                    help="queries per all-gather when --gpus > 1 (a multiple of the world size keeps the P3P stage balanced; "
-                         "small batches keep the two-slot pipeline full over a short timed region).  Default: the world "
-                         "size, at least 4 -- measured on one rank: 411 queries/s over 40 steps with 4, 383 with 8")
-    ap.add_argument("--bow-knn", type=int, default=0,
-                    help="> 0: BASELINE configs[2] -- every query first shortlists this many views by BoW distance "
-                         "(sfmloc_bow_select over a synthetic .bow matrix) and runs the path on those (1 GPU only); "
-                         "use with --views 10000")
-    ap.add_argument("--from-images", action="store_true",
-                    help="image-in serving mode (1 GPU): every step first extracts AKAZE + M-LDB features from a synthetic "
-                         "640x480 image on the GPU (sfmloc_akaze_detect_and_compute, its own stream), then localises the "
-                         "step's query; --in-flight worker threads, one extractor and one context each.  The map is "
-                         "synthetic, so the localised descriptors are the synthetic query's, not the image's: the point is "
-                         "the cost of extraction sharing the GPU and the host with the path")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
-
-
 def cpu_baseline(m, queries, seconds):
     """The C oracle's restatement of the whole per-query path on this host's cores (OpenMP), on a bounded
-    sample of the SAME workload: exact 2-NN + ratio on a sample of views (scaled to the full bank: that stage is
+    sample of the full-scan workload: exact 2-NN + ratio on a sample of views (scaled to the full bank: that stage is
     linear in rows) plus the query's own place's views, where every later stage (F-matrix AC-RANSAC, 2D-3D set,
     P3P AC-RANSAC) does all its work."""
+    import numpy as np
     from oracle import oracle_c, pipeline as opipe
     threads = max(1, min(16, os.cpu_count() or 1, oracle_c.max_threads()))
     q = queries[0]
@@ -141,14 +140,15 @@ def cpu_baseline(m, queries, seconds):
 def cpu_baseline_shortlist(m, queries, bow, qbow, knn, seconds):
     """configs[2] on the host: exact L2 shortlist over the .bow matrix (NumPy), then the C oracle's whole path on the
     shortlisted views (OpenMP), whole queries until `seconds` are spent."""
+    import numpy as np
     from oracle import oracle_c, pipeline as opipe
     threads = max(1, min(16, os.cpu_count() or 1, oracle_c.max_threads()))
     t0 = time.perf_counter()
     done, ok, t_bow = 0, 0, 0.0
-    while done < len(queries) and (done == 0 or time.perf_counter() - t0 < seconds):
-        q = queries[done]
+    while done == 0 or time.perf_counter() - t0 < seconds:
+        q = queries[done % len(queries)]
         t1 = time.perf_counter()
-        d = ((bow - qbow[done][None, :]) ** 2).sum(1)
+        d = ((bow - qbow[done % len(queries)][None, :]) ** 2).sum(1)
         sel = np.sort(np.argsort(d, kind="stable")[:knn]).astype(np.uint32)
         t_bow += time.perf_counter() - t1
         r = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=sel, ransac_round=25, threads=threads)
@@ -162,16 +162,81 @@ def cpu_baseline_shortlist(m, queries, bow, qbow, knn, seconds):
                       "OpenMP, -O3 -march=x86-64-v3"}
 
 
+def synth_bow(m, queries, seed=33):
+    """One BoW prototype per place + noise per view: the shortlist finds the query's place (TrainBoW's vectors are
+    500-dimensional, BoFUtils.cpp:43-45)."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    place_bow = rng.uniform(0, 1, (len(m.place_center), 500)).astype(np.float32)
+    bow = (place_bow[m.view_place] + rng.normal(0, 0.05, (m.n_views, 500))).astype(np.float32)
+    qbow = [(place_bow[q.place] + rng.normal(0, 0.05, 500)).astype(np.float32) for q in queries]
+    return bow, qbow
+
+
+def roofline_phase(S, dev_map, dq, rows, nq, n_reps=5):
+    """K1 on the FULL bank of this map, one launch in flight, bracketed by HIP events on the stream it runs on
+    (sfmloc_stats_read, params.profile = 2): the isolated kernel time that `rocprofv3 --kernel-trace --stats` of this
+    command reproduces.  Returns (ms per scan (screen + rows kernels), issued lane-ops per scan, emitted matches,
+    stats)."""
+    dev_map.set_profile(2)
+    dev_map.match_putative(dq)      # warm
+    dev_map.sync()
+    dev_map.stats_reset()
+    for _ in range(n_reps):
+        dev_map.match_putative(dq)
+        dev_map.sync()              # one in flight
+    st = dev_map.stats()
+    n_match = int(dev_map.putative_read()[0].sum())
+    ms = st.total_ms[0] / max(1, st.launches[0])
+    return ms, st.hamming_lane_ops / max(1, st.launches[0]), n_match, st
+
+
+def nq_sweep_phase(S, dev_map, rows, n_reps=10):
+    """The same kernel family where it IS HBM-bound: N_q = 1, 2, 4, 8 query rows per pass over the
+    full bank (larger than the 256 MiB Infinity Cache), measured live."""
+    import numpy as np
+    from sfmlocalization_amd import synth
+    rng = np.random.Generator(np.random.PCG64(5))
+    out = []
+    for nq in (1, 2, 4, 8):
+        q = dev_map.query(synth.random_descriptors(rng, nq))
+        for _ in range(2):
+            dev_map.match_putative(q)
+        dev_map.sync()
+        dev_map.stats_reset()
+        for _ in range(n_reps):
+            dev_map.match_putative(q)
+            dev_map.sync()
+        st = dev_map.stats()
+        ms = st.total_ms[0] / max(1, st.launches[0])
+        out.append({"nq": nq, "kernel_ms": ms, "bank_GBps": (rows * 64 + nq * 64) / (ms * 1e-3) / 1e9})
+        q.close()
+    return out
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))   # before torch / HIP are touched in this process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.batch <= 0:
-        a.batch = world * max(1, (4 + world - 1) // world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches "
+              f"its own ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr)
+        sys.exit(2)
+    shortlist = a.bow_knn > 0
+    nctx = a.in_flight if a.in_flight > 0 else (8 if shortlist else 4)
+    forced = os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1"
+    sharded_mode = world > 1 or forced
+    # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
+    # (so does the image-in mode: a context and an extractor stream per worker)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, 2 * nctx if (sharded_mode or a.from_images) else nctx))))
+
+    import numpy as np
+    sys.path.insert(0, ROOT)
     import torch
     dist = None
-    forced = os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1"
     if world > 1 or (forced and "RANK" in os.environ):
         import torch.distributed as dist_
         dist = dist_
@@ -183,45 +248,41 @@ def main():
         else:
             dist.init_process_group(backend)
             local_rank = local_rank % max(1, torch.cuda.device_count())
+        assert dist.get_world_size() == a.gpus, "process group size differs from --gpus"
     torch.cuda.set_device(local_rank)
 
     import sfmlocalization_amd as S
     from sfmlocalization_amd import synth
 
     # every rank builds the same seeded map and keeps its shard of views (contiguous view ranges)
+    t_gen = time.perf_counter()
     m = synth.make_map(2, n_views=a.views, desc_per_view=a.desc_per_view)
     queries = [synth.make_query(m, 1000 + i, n_feat=a.nq) for i in range(a.queries)]
     bow = qbow = None
-    if a.bow_knn > 0:
-        # N > 1 (BASELINE configs[3]): the .bow matrix shards with the views; every batch first runs the sharded
-        # shortlist (one small all-gather of each rank's k best, dist.py bow_shortlists), then the sharded path
-        # one BoW prototype per place + noise per view: the shortlist finds the query's place (TrainBoW's vectors are
-        # 500-dimensional, BoFUtils.cpp:43-45)
-        rng = np.random.Generator(np.random.PCG64(33))
-        place_bow = rng.uniform(0, 1, (len(m.place_center), 500)).astype(np.float32)
-        bow = (place_bow[m.view_place] + rng.normal(0, 0.05, (a.views, 500))).astype(np.float32)
-        qbow = [(place_bow[q.place] + rng.normal(0, 0.05, 500)).astype(np.float32) for q in queries]
+    if shortlist:
+        bow, qbow = synth_bow(m, queries)
+    t_gen = time.perf_counter() - t_gen
     v0 = (a.views * rank) // world
     v1 = (a.views * (rank + 1)) // world
     r0, r1 = int(m.view_off[v0]), int(m.view_off[v1])
-    params = S.default_params(device=local_rank, profile=1, ransac_round=25)
+    params = S.default_params(device=local_rank, profile=0, ransac_round=25)
     dev_map = S.Map(m.view_id[v0:v1], m.view_off[v0:v1 + 1] - m.view_off[v0], m.desc[r0:r1], params=params,
                     view_wh=m.view_wh[v0:v1], kpt_xy=m.kpt_xy[r0:r1], row_landmark=m.row_landmark[r0:r1],
                     landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic,
                     bow=None if bow is None else bow[v0:v1])
     dqs = [dev_map.query(q.desc, q.kpt_xy, q.width, q.height) for q in queries]
+    if shortlist:
+        for dq, qb in zip(dqs, qbow):
+            dq.set_bow(qb)          # the query's BoW vector is an input: resident before the timed region
     lat = []
     n_ok = [0]
-    nctx = max(1, a.in_flight)
     sharded = None
-    # SFMLOC_BENCH_FORCE_SHARDED=1: rehearse the N>1 code path (parts, collective, merge) on a single rank
-    if world > 1 or forced:
-        # bank sharded by view; per batch: stage 1 on every shard, ONE all-gather of candidate parts over RCCL,
-        # stage 2 of each query on its owner rank (sfmlocalization_amd/dist.py)
+    xchg = {}
+    if sharded_mode:
         from sfmlocalization_amd import dist as D
-        cap = 4096
-        comp = D.HipShardCompute(dev_map, cap, n_contexts=nctx, device=torch.device("cuda", local_rank))
-        sharded = D.ShardedLocalizer(comp, cap, rank=rank, world=world, always_gather=forced and dist is not None)
+        comp = D.HipShardCompute(dev_map, n_contexts=nctx, device=torch.device("cuda", local_rank))
+        sharded = D.ShardedLocalizer(comp, rank=rank, world=world, always_gather=forced and dist is not None,
+                                     n_views_global=a.views)
     ctxs = [dev_map.context() for _ in range(nctx)] if sharded is None else []
     t_begin = [0.0] * nctx
     busy = [False] * nctx
@@ -232,41 +293,38 @@ def main():
         n_ok[0] += int(pose.ok)
         busy[k] = False
 
+    def begin(k, i):
+        dq = dqs[i % len(dqs)]
+        if shortlist:   # configs[2]: shortlist + path in one asynchronous call, the shortlist stays on the device
+            ctxs[k].begin_bow(dq, None, a.bow_knn)
+        else:
+            ctxs[k].begin(dq)
+
     def run_sharded(first, count):
-        """`count` steps starting at step `first`, in batches of a.batch through the two-slot pipeline: stage 1 of
+        """`count` queries starting at query `first`, in batches of a.batch through the two-slot pipeline: stage 1 of
         batch b+1 is queued before batch b's all-gather and P3P stage."""
         idx = list(range(first, first + count))
         batches = [idx[k:k + a.batch] for k in range(0, len(idx), a.batch)]
         t_mark = [time.perf_counter(), time.perf_counter()]   # batch b was enqueued when batch b-2 was yielded
-        sels = None
-        if qbow is not None:   # generator: the shortlist of batch b is computed when the pipeline reaches it
-            sels = (sharded.bow_shortlists(dev_map, [qbow[i % len(dqs)] for i in b], a.bow_knn) for b in batches)
         stream = sharded.localize_stream([[dqs[i % len(dqs)] for i in b] for b in batches], gather_results=False,
-                                         view_sels=sels)
+                                         bow_knn=a.bow_knn if shortlist else 0)
         for b, res in zip(batches, stream):
             now = time.perf_counter()
             lat.extend([now - t_mark[0]] * len(b))          # a query's latency in batch mode = its batch's wall time
             t_mark = [t_mark[1], now]
             n_ok[0] += sum(int(r["ok"]) for r in res.values())
 
-    def step(i):
-        # one step = one query through the whole path; up to `nctx` steps overlap on the GPU
-        k = i % nctx
-        if busy[k]:
-            finish(k)
-        t_begin[k] = time.perf_counter()
-        if qbow is not None:   # configs[2]: shortlist + path in one asynchronous call, the shortlist stays on the device
-            ctxs[k].begin_bow(dqs[i % len(dqs)], qbow[i % len(dqs)], a.bow_knn)
-        else:
-            ctxs[k].begin(dqs[i % len(dqs)])
-        busy[k] = True
-
     def run(first, count):
         if sharded is not None:
             run_sharded(first, count)
-        else:
-            for i in range(first, first + count):
-                step(i)
+            return
+        for i in range(first, first + count):   # up to `nctx` queries overlap on the GPU
+            k = i % nctx
+            if busy[k]:
+                finish(k)
+            t_begin[k] = time.perf_counter()
+            begin(k, i)
+            busy[k] = True
 
     def drain():
         for k in range(nctx):
@@ -294,10 +352,7 @@ def main():
             for i in range(first + k, first + count, nctx):
                 t1 = time.perf_counter()
                 kp, _ = extractors[k].detect_and_compute(imgs[i % len(imgs)])
-                if qbow is not None:
-                    ctxs[k].begin_bow(dqs[i % len(dqs)], qbow[i % len(dqs)], a.bow_knn)
-                else:
-                    ctxs[k].begin(dqs[i % len(dqs)])
+                begin(k, i)
                 pose, _, _ = ctxs[k].end()
                 with lock:
                     lat.append(time.perf_counter() - t1)
@@ -314,66 +369,69 @@ def main():
         run = run_images  # noqa: F811
         img_mode = {"extractors": extractors, "n_feat": n_feat}
 
-    run(0, a.warmup)
+    n_timed = a.steps * a.batch
+    run(0, a.warmup * a.batch)
     fence()
     dev_map.stats_reset()
+    if sharded is not None:
+        sharded.reset_counters()
     lat.clear()
     n_ok[0] = 0
     fence()
     t0 = time.perf_counter()
-    run(0, a.steps)
+    run(0, n_timed)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    st = dev_map.stats()
-    k1_ms = st.total_ms[0] / max(1, st.launches[0])
     lat_throughput = list(lat)
-    # per-query latency proper: the same queries one at a time (outside the timed region; with several queries in
-    # flight a query's wall time is mostly queueing behind the others' Hamming scans)
-    lat_single = []
-    iso = None
-    if sharded is None:
-        dev_map.stats_reset()
-        dev_map.set_profile(2)   # K1 events only: every bracketed stage costs ~10 us of idle GPU on the critical path
-        for i in range(min(a.steps, 32)):
-            t1 = time.perf_counter()
-            if qbow is not None:
-                ctxs[0].begin_bow(dqs[i % len(dqs)], qbow[i % len(dqs)], a.bow_knn)
-            else:
-                ctxs[0].begin(dqs[i % len(dqs)])
-            ctxs[0].end()
-            lat_single.append(time.perf_counter() - t1)
-        st1 = dev_map.stats()
-        iso = (st1.total_ms[0] / max(1, st1.launches[0]), st1.hamming_lane_ops / max(1, st1.launches[0]))
-    sel0 = None
-    if qbow is not None:   # this rank's part of the first query's shortlist (collective when sharded)
-        sel0 = (sharded.bow_shortlists(dev_map, [qbow[0]], a.bow_knn)[0] if sharded is not None
-                else dev_map.bow_select(qbow[0], a.bow_knn))
-    dev_map.match_putative(dqs[0], sel0)  # outside the timed region: number of emitted matches for the byte count
-    n_match = int(dev_map.putative_read()[0].sum())
+    n_ok_timed = n_ok[0]
     if world > 1:
-        ok_t = torch.tensor([n_ok[0]], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        ok_t = torch.tensor([n_ok_timed], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ok_t)
-        n_ok[0] = int(ok_t.item())
-    rows_rank = r1 - r0
-    if sel0 is not None:   # only the shortlisted views are scanned
-        rows_rank = int(sum(int(m.view_off[v + 1] - m.view_off[v]) for v in sel0))
-    alg_bytes = 64 * rows_rank + 64 * a.nq + 12 * n_match
-    achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
-    pairs = rows_rank * a.nq
-    # VALU lane-instructions K1 actually issued (counted by the library: the screening kernel rejects most pairs on
-    # a 10-dword prefix distance, so this is below 35 per pair)
-    lane_ops = st.hamming_lane_ops / max(1, st.launches[0])
-    valu = lane_ops / (k1_ms * 1e-3) / 1e12
+        n_ok_timed = int(ok_t.item())
+    if sharded is not None:
+        xchg = sharded.counters()
 
-    traffic, traffic_src = pmc_traffic(world == 1 and (a.views, a.desc_per_view, a.nq) == (1000, 2000, 2000))
+    # ---- outside the timed region -------------------------------------------------------------------------------
+    # (a) stage split and the in-path K1 launches: the same queries again with every stage bracketed by HIP events
+    dev_map.set_profile(1)
+    dev_map.stats_reset()
+    n_prof = min(n_timed, 4 * a.batch)
+    lat.clear()
+    run(0, n_prof)
+    fence()
+    st = dev_map.stats()
+    # (b) per-query latency proper: one query in flight (with several in flight a query's wall time is mostly queueing)
+    lat_single = []
+    if sharded is None:
+        dev_map.set_profile(0)
+        for i in range(min(n_timed, 64)):
+            t1 = time.perf_counter()
+            begin(0, i)
+            pose = ctxs[0].end()[0]
+            lat_single.append(time.perf_counter() - t1)
+        stage_seconds = [float(x) for x in pose.stage_seconds]
+    # (c) the roofline kernel: full-bank scan of this rank's bank, one launch in flight
+    roof = sweep = None
+    rows_rank = r1 - r0
+    if not a.no_roofline_phase:
+        k1_ms, lane_ops, n_match, st_roof = roofline_phase(S, dev_map, dqs[0], rows_rank, a.nq)
+        alg_bytes = 64 * rows_rank + 64 * a.nq + 12 * n_match
+        pairs = rows_rank * a.nq
+        roof = (k1_ms, lane_ops, n_match, alg_bytes, pairs, st_roof)
+        sweep = nq_sweep_phase(S, dev_map, rows_rank)
+    dev_map.set_profile(0)
     if rank == 0:
+        sel_rows = None
+        if shortlist and sharded is None:
+            sel0 = dev_map.bow_select(qbow[0], a.bow_knn)
+            sel_rows = int(sum(int(m.view_off[v + 1] - m.view_off[v]) for v in sel0))
         out = {
             "metric": "query images localized/sec",
-            "value": a.steps / dt,
+            "value": n_timed / dt,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -382,67 +440,82 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "u32 popcount (Hamming)",
+            "dtype": "u32 popcount (Hamming); f64 geometry",
             "data": "synthetic",
-            "config": {"workload": f"{a.views}-image / {m.n_rows}-descriptor synthetic map, {a.nq} feats/query, "
-                                   "whole per-query path: brute-force Hamming 2-NN + Lowe ratio -> >=16 filter -> "
+            "config": {"workload": (f"BASELINE configs[{2 if world == 1 else 3}]: " if (shortlist and a.views == 10000) else "")
+                                   + f"{a.views}-image / {m.n_rows}-descriptor synthetic map, {a.nq} feats/query, "
+                                   + (f"BoW shortlist of {a.bow_knn} views (exact L2 over the {a.views} x 500 .bow matrix) then "
+                                      if shortlist else "")
+                                   + "the whole per-query path: brute-force Hamming 2-NN + Lowe ratio -> >=16 filter -> "
                                    "F-matrix AC-RANSAC (25 rounds) -> 2D-3D set -> P3P AC-RANSAC (4096) -> pose; "
-                                   f"{nctx} queries in flight"
-                                   + (f"; every query first shortlists {a.bow_knn} views by exact L2 over the "
-                                      f"{a.views} x 500 .bow matrix (BASELINE configs[2])" if a.bow_knn > 0 else ""),
-                       "views": a.views, "rows": int(m.n_rows), "nq": a.nq,
-                       "parallelism": (f"bank sharded by view x{world}, one all-gather of candidate parts per "
-                                       f"{a.batch}-query batch" if world > 1 else "1 GPU, whole bank"),
-                       "queries_localised": f"{n_ok[0]}/{a.steps}"},
+                                   f"one step = a batch of {a.batch} queries, {nctx} in flight per GPU",
+                       "views": a.views, "rows": int(m.n_rows), "nq": a.nq, "bow_knn": a.bow_knn, "batch": a.batch,
+                       "queries_per_step": a.batch, "queries_timed": n_timed, "in_flight_per_gpu": nctx,
+                       "parallelism": (f"bank + .bow sharded by view x{world}; per {a.batch}-query batch one all-gather of "
+                                       "per-shard k-best BoW keys and ONE all-gather of candidate parts (RCCL), P3P of "
+                                       "query i on rank i mod N" if world > 1 else "1 GPU, whole bank"),
+                       "queries_localised": f"{n_ok_timed}/{n_timed}",
+                       "map_generation_s": round(t_gen, 1)},
             "latency_ms": {"p50": float(np.percentile(lat_single or lat_throughput, 50) * 1e3),
                            "p95": float(np.percentile(lat_single or lat_throughput, 95) * 1e3),
                            "mode": "one query in flight" if lat_single else f"{a.batch}-query batches",
                            "p50_at_throughput": float(np.percentile(lat_throughput, 50) * 1e3),
                            "p95_at_throughput": float(np.percentile(lat_throughput, 95) * 1e3)},
-            "stage_ms": {"putMatch(K1+K2)": (st.total_ms[0] + st.total_ms[1]) / a.steps,
-                         "geoMatch(K3)": st.total_ms[2] / a.steps, "matchSet(K4)": st.total_ms[3] / a.steps,
-                         "PnP(K5)": st.total_ms[4] / a.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (PMC FETCH_SIZE*2+WRITE_SIZE)", "traffic_source": traffic_src,
-                         "kernel": "k_hamming_screen (+k_hamming_rows)", "kernel_ms": k1_ms,
-                         "algorithmic_bytes": alg_bytes,
-                         "note": "SURVEY F7: at N_q=2000 the kernel is VALU-bound (intensity N_q/2 lane-ops/byte)",
-                         "valu": {"achieved": valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
-                                  "frac": valu / VALU_PEAK_TOPS, "ops_per_pair_exact": OPS_PER_PAIR,
-                                  "ops_per_pair_issued": lane_ops / max(1, pairs),
-                                  "pairs_per_s": pairs / (k1_ms * 1e-3),
-                                  "pairs_finished_frac": st.hamming_pairs_finished / max(1, st.hamming_pairs),
-                                  "rows_flagged_per_query": st.hamming_rows_flagged / max(1, st.launches[0])}},
+            "stage_ms": {"note": f"HIP-event brackets per stage over {n_prof} queries re-run after the timed region with "
+                                 f"{nctx} in flight (a bracket contains the other queries' work)",
+                         "selectBow(K8)": st.total_ms[5] / max(1, n_prof),
+                         "putMatch(K1+K2)": (st.total_ms[0] + st.total_ms[1]) / max(1, n_prof),
+                         "geoMatch(K3)": st.total_ms[2] / max(1, n_prof), "matchSet(K4)": st.total_ms[3] / max(1, n_prof),
+                         "PnP(K5)": st.total_ms[4] / max(1, n_prof)},
         }
-        # with several queries in flight the launches overlap: a launch's event bracket (kernel_ms) then contains the
-        # others' work, so also report what the chip did over the whole timed region (all launches' work / wall time)
-        n_launch = max(1, st.launches[0])
-        out["roofline"]["timed_region_aggregate"] = {
-            "achieved": alg_bytes * n_launch / dt / 1e9, "unit": "GB/s",
-            "frac": alg_bytes * n_launch / dt / 1e9 / HBM_PEAK_GBS,
-            "valu_achieved": st.hamming_lane_ops / dt / 1e12, "valu_frac": st.hamming_lane_ops / dt / 1e12 / VALU_PEAK_TOPS,
-            "launches": int(n_launch), "wall_ms": dt * 1e3,
-            "note": "K1 launches of the timed region only; dt is the region's wall time (max over ranks)"}
-        hr = hbm_regime()
-        if hr is not None:
-            out["roofline"]["hbm_bound_regime"] = hr
+        if lat_single:
+            out["latency_ms"]["stage_seconds_last_query"] = dict(zip(
+                ["selectBeacon", "selectBow", "extFeat", "putMatch", "geoMatch", "PnP", "others"], stage_seconds))
+        if xchg:
+            out["exchange"] = xchg
+        if roof is not None:
+            k1_ms, lane_ops, n_match, alg_bytes, pairs, st_roof = roof
+            achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
+            valu = lane_ops / (k1_ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(world == 1 and (a.views, a.desc_per_view, a.nq) == (10000, 2000, 2000))
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_unit": "bytes/launch (PMC FETCH_SIZE*2+WRITE_SIZE of separate rocprofv3 --pmc passes; read from "
+                                "the committed summary, PMC cannot run inside this process)",
+                "traffic_source": traffic_src,
+                "kernel": "k_hamming_screen (+k_hamming_rows): full-bank scan of this map, one launch in flight, "
+                          "after the timed region",
+                "kernel_ms": k1_ms, "launches": int(st_roof.launches[0]), "algorithmic_bytes": alg_bytes,
+                "bank_rows": rows_rank, "nq": a.nq, "emitted_matches": n_match,
+                "note": "SURVEY F7: at N_q=2000 the kernel is VALU-bound (intensity N_q/2 lane-ops per bank byte against "
+                        "a machine balance of ~6): frac against HBM is <1 % whatever the kernel; `valu` is the bound "
+                        "that applies, `hbm_bound_regime` the same kernel family where HBM is the bound",
+                "valu": {"achieved": valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": valu / VALU_PEAK_TOPS,
+                         "peak_source": "profiles/r02_valu_rates.jsonl (xor+bcnt mix, 8 waves/SIMD, balanced grid)",
+                         "ops_per_pair_exact": OPS_PER_PAIR, "ops_per_pair_issued": lane_ops / max(1, pairs),
+                         "pairs_per_s": pairs / (k1_ms * 1e-3),
+                         "pairs_finished_frac": st_roof.hamming_pairs_finished / max(1, st_roof.hamming_pairs),
+                         "rows_flagged_per_scan": st_roof.hamming_rows_flagged / max(1, st_roof.launches[0])}}
+            if sweep:
+                best = max(sweep, key=lambda r: r["bank_GBps"])
+                out["roofline"]["hbm_bound_regime"] = {
+                    "measured": "live, this run: N_q query rows per full-bank pass, one launch in flight",
+                    "sweep": sweep, "nq": best["nq"], "bank_rows": rows_rank, "achieved": best["bank_GBps"],
+                    "unit": "GB/s of bank bytes", "peak": HBM_PEAK_GBS, "frac": best["bank_GBps"] / HBM_PEAK_GBS,
+                    "frac_of_measured_copy": best["bank_GBps"] / HBM_COPY_GBS,
+                    "note": "plus 12.5 % partial-result writes; 6.29 TB/s is the guide's measured float4 copy"}
+            # the K1 launches inside the path (short block list of the shortlist): event brackets with nctx in flight
+            if st.launches[0]:
+                out["roofline"]["in_path_scan"] = {
+                    "rows_per_query": sel_rows, "event_bracket_ms": st.total_ms[0] / st.launches[0],
+                    "note": "side note only: brackets of overlapping launches contain queue wait"}
         if img_mode is not None:
-            out["config"]["workload"] += ("; image-in mode: each step first runs AKAZE + M-LDB extraction of a 640x480 "
+            out["config"]["workload"] += ("; image-in mode: each query first runs AKAZE + M-LDB extraction of a 640x480 "
                                           f"synthetic image on the GPU ({img_mode['n_feat'][0]} keypoints)")
-            out["latency_ms"]["p50_image_in_at_throughput"] = float(np.percentile(lat_throughput, 50) * 1e3)
-        if iso is not None:
-            # the same kernel with nothing else on the GPU (the latency phase): what the kernel itself achieves; in
-            # the timed region its launches share the chip with the other queries in flight, which stretches them
-            out["roofline"]["isolated"] = {
-                "kernel_ms": iso[0], "achieved": alg_bytes / (iso[0] * 1e-3) / 1e9,
-                "frac": alg_bytes / (iso[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "valu_achieved": iso[1] / (iso[0] * 1e-3) / 1e12,
-                "valu_frac": iso[1] / (iso[0] * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                "pairs_per_s": pairs / (iso[0] * 1e-3)}
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = (cpu_baseline_shortlist(m, queries, bow, qbow, a.bow_knn, a.cpu_seconds)
-                                   if a.bow_knn > 0 else cpu_baseline(m, queries, a.cpu_seconds))
+                                   if shortlist else cpu_baseline(m, queries, a.cpu_seconds))
         print(json.dumps(out), flush=True)
     if img_mode is not None:
         for e in img_mode["extractors"]:

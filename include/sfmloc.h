@@ -172,6 +172,10 @@ typedef struct sfmloc_query sfmloc_query;
 int sfmloc_query_create(sfmloc_map *map, const uint8_t *desc /*[n*64]*/, const float *kpt_xy /*[n*2] or NULL*/,
                         uint32_t n, uint32_t width, uint32_t height, sfmloc_query **out);
 void sfmloc_query_destroy(sfmloc_query *q);
+/* The query's BoW vector [bow_dim of the map] made resident with the query (what calcBoF produced for it,
+ * LocalizeEngine.cc:337-340): sfmloc_localize_bow_begin / sfmloc_shard_bow_keys then take query_bow = NULL and no
+ * per-call upload happens.  Synchronous. */
+int sfmloc_query_set_bow(sfmloc_query *q, const float *query_bow);
 
 /* ------------------------------------------------------------------------- */
 /* Stage A6+A7: putative matching.                                             */
@@ -269,7 +273,8 @@ int sfmloc_localize_begin(sfmloc_context *ctx, sfmloc_query *q, const uint32_t *
  * nearest to `query_bow` (exactly as sfmloc_bow_select) and localise on them.  The shortlist stays on the device --
  * the bank blocks to scan are derived from it by a kernel -- so nothing waits for the host between the two stages.
  * As in the reference the shortlist applies only when more than `knn` candidates remain; cand_views NULL = all
- * views.  Finish with sfmloc_localize_end.  Same result as sfmloc_bow_select + sfmloc_localize_begin, bit for bit. */
+ * views.  query_bow NULL = the vector made resident by sfmloc_query_set_bow.  Finish with sfmloc_localize_end.
+ * Same result as sfmloc_bow_select + sfmloc_localize_begin, bit for bit. */
 int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const float *query_bow, uint32_t knn,
                               const uint32_t *cand_views, uint32_t n_cand);
 /* the same, synchronous, on the map's own context (as sfmloc_localize; the stage read-backs then refer to it) */
@@ -296,8 +301,25 @@ int sfmloc_localize_batch(sfmloc_map *map, sfmloc_query *const *queries, uint32_
 /* ------------------------------------------------------------------------- */
 uint64_t sfmloc_part_bytes(uint32_t cap);
 int sfmloc_shard_begin(sfmloc_context *ctx, sfmloc_query *q, const uint32_t *view_sel, uint32_t n_sel);
+/* writes the part's header (true count) and its first min(count, cap) candidates to dst_dev; bytes beyond are left
+ * as they were (the merging side reads `count` entries only) */
 int sfmloc_shard_export(sfmloc_context *ctx, void *dst_dev, uint32_t cap);
 int sfmloc_context_sync(sfmloc_context *ctx);
+/* Ordering against a stream of the caller (e.g. the one its collective runs on) without blocking the host:
+ *   _signal: everything queued on the context so far happens before work queued on hip_stream from now on;
+ *   _wait:   everything queued on hip_stream so far happens before work queued on the context from now on.
+ * hip_stream is a hipStream_t of the same device (NULL = the default stream). */
+int sfmloc_context_signal(sfmloc_context *ctx, void *hip_stream);
+int sfmloc_context_wait(sfmloc_context *ctx, void *hip_stream);
+/* Sharded BoW shortlist (selectViewByBoF over a map split by view).  _shard_bow_keys ranks this shard's
+ * views against the query's BoW vector (query_bow, or NULL for the resident one) and writes its knn best to keys_dev
+ * [knn] as sortable 64-bit keys (float32 distance bits << 32 | view id; ~0 = padding).  The caller all-gathers the key
+ * lists; _shard_begin_bow takes the n_parts lists (list p at keys_dev + p*part_stride_keys keys; 0 = back to back),
+ * keeps the shard's part of the GLOBAL knn best (ties to the lower view id, as the unsharded sfmloc_bow_select) and
+ * runs sfmloc_shard_begin on it -- all on the device, asynchronously.  knn <= 1024, n_parts*knn <= 8192. */
+int sfmloc_shard_bow_keys(sfmloc_context *ctx, sfmloc_query *q, const float *query_bow, uint32_t knn, void *keys_dev);
+int sfmloc_shard_begin_bow(sfmloc_context *ctx, sfmloc_query *q, const void *keys_dev, uint32_t n_parts,
+                           uint64_t part_stride_keys, uint32_t knn);
 /* part p starts at parts_dev + p*part_stride (part_stride = 0 means sfmloc_part_bytes(cap): back to back) */
 int sfmloc_merge_begin(sfmloc_context *ctx, sfmloc_query *q, const void *parts_dev, uint32_t n_parts, uint32_t cap,
                        uint64_t part_stride);

@@ -75,17 +75,18 @@ def localize(m, q_desc, q_kpt, q_wh, view_sel=None, ratio=0.6, ransac_round=25, 
     return out
 
 
-def shard_candidates(m, q_desc, q_kpt, q_wh, v0, v1, **kw):
+def shard_candidates(m, q_desc, q_kpt, q_wh, v0, v1, view_sel=None, **kw):
     """What ONE shard (views [v0, v1) of map m) contributes for a query: the 2D-3D candidates of its geometric
     matches, as the structured array of sfmlocalization_amd.dist.CANDIDATE_DTYPE.  Order keys carry the global
     view id, so parts of different shards merge into exactly the unsharded candidate set."""
     from sfmlocalization_amd import dist as D
-    sel = np.arange(v0, v1, dtype=np.uint32)
-    r = localize(m, q_desc, q_kpt, q_wh, view_sel=sel, **kw) if v1 > v0 else None
+    # view_sel: the shard's views to search (global indices inside [v0, v1), ascending; e.g. its part of a shortlist)
+    sel = np.arange(v0, v1, dtype=np.uint32) if view_sel is None else np.asarray(view_sel, dtype=np.uint32)
+    r = localize(m, q_desc, q_kpt, q_wh, view_sel=sel, **kw) if len(sel) else None
     out = []
     if r is not None:
         cnt, mi, mj, md = r["put_count"], r["put_i"], r["put_j"], r["put_d"]
-        for v in range(v0, v1):
+        for v in (int(x) for x in sel):
             gc = int(r["geo_count"][v])
             off = int(m.view_off[v])
             for p in range(gc):

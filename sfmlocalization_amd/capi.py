@@ -115,6 +115,8 @@ SYMBOLS = [
     "sfmloc_pack", "sfmloc_scan_packed", "sfmloc_open_packed",
     "sfmloc_undistorter_create", "sfmloc_undistorter_destroy", "sfmloc_undistorter_info", "sfmloc_undistorter_maps",
     "sfmloc_undistorter_apply",
+    "sfmloc_query_set_bow", "sfmloc_context_signal", "sfmloc_context_wait", "sfmloc_shard_bow_keys",
+    "sfmloc_shard_begin_bow",
 ]
 
 _bound = False
@@ -202,6 +204,11 @@ def _L():
         L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
         L.sfmloc_stats_reset.argtypes = [C.c_void_p]
         L.sfmloc_set_profile.argtypes = [C.c_void_p, C.c_int]
+        L.sfmloc_query_set_bow.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.sfmloc_context_signal.argtypes = [C.c_void_p, C.c_void_p]
+        L.sfmloc_context_wait.argtypes = [C.c_void_p, C.c_void_p]
+        L.sfmloc_shard_bow_keys.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
+        L.sfmloc_shard_begin_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32]
         _bound = True
     return L
 
@@ -852,7 +859,7 @@ class Context:
     def begin_bow(self, q, bow, knn, cand_views=None):
         """sfmloc_localize_bow_begin: BoW shortlist (knn of the candidate views, all views when None) + the whole
         path on it, asynchronous, the shortlist never leaving the device.  Finish with end()."""
-        b = np.ascontiguousarray(bow, dtype=np.float32).ravel()
+        b = None if bow is None else np.ascontiguousarray(bow, dtype=np.float32).ravel()   # None: q.set_bow()'s
         L = _L()
         L.sfmloc_localize_bow_begin.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32,
                                                 C.POINTER(C.c_uint32), C.c_uint32]
@@ -861,6 +868,25 @@ class Context:
         else:
             p, n, keep = _sel(cand_views)
             _check(L.sfmloc_localize_bow_begin(self._h, q._h, _ptr(b, C.c_float), int(knn), p, n))
+
+    def shard_bow_keys(self, q, knn, keys_dev_ptr, bow=None):
+        """sfmloc_shard_bow_keys: this shard's knn best (distance, view id) keys -> device buffer [knn] u64."""
+        b = None if bow is None else np.ascontiguousarray(bow, dtype=np.float32).ravel()
+        _check(_L().sfmloc_shard_bow_keys(self._h, q._h, _ptr(b, C.c_float), int(knn), C.c_void_p(keys_dev_ptr)))
+
+    def shard_begin_bow(self, q, keys_dev_ptr, n_parts, knn, part_stride_keys=0):
+        """sfmloc_shard_begin_bow: global knn best among the gathered key lists -> this shard's views -> K1..K3 +
+        candidate emission, all on the device."""
+        _check(_L().sfmloc_shard_begin_bow(self._h, q._h, C.c_void_p(keys_dev_ptr), int(n_parts),
+                                           int(part_stride_keys), int(knn)))
+
+    def signal(self, hip_stream=0):
+        """sfmloc_context_signal: `hip_stream` (a hipStream_t as an integer) waits for this context's queued work."""
+        _check(_L().sfmloc_context_signal(self._h, C.c_void_p(hip_stream)))
+
+    def wait(self, hip_stream=0):
+        """sfmloc_context_wait: this context waits for the work queued on `hip_stream` so far."""
+        _check(_L().sfmloc_context_wait(self._h, C.c_void_p(hip_stream)))
 
     def shard_begin(self, q, view_sel=None):
         """K1..K3 + candidate emission on this shard (asynchronous)."""
@@ -916,6 +942,11 @@ class Query:
                                         int(width), int(height), C.byref(h)))
         self._h = h
         m._children.add(self)
+
+    def set_bow(self, bow):
+        """sfmloc_query_set_bow: the query's BoW vector becomes resident with it."""
+        b = np.ascontiguousarray(bow, dtype=np.float32).ravel()
+        _check(_L().sfmloc_query_set_bow(self._h, _ptr(b, C.c_float)))
 
     @classmethod
     def _from_view(cls, m, view_index):

@@ -1659,6 +1659,25 @@ int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_view
   return SFMLOC_OK;
 }
 
+// a context's candidate part -> a caller's buffer: the 16-byte header (true count) and the candidates that exist, at
+// most cap of them (a fixed-size copy would move cap * 40 bytes for a few hundred candidates)
+__global__ __launch_bounds__(256) void k_export_part(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
+                                                     uint32_t cap) {
+  const uint32_t n = min(*reinterpret_cast<const uint32_t *>(src), cap);
+  const uint64_t words = (kPartHeaderBytes + (uint64_t)n * sizeof(Candidate)) / 8;  // both multiples of 8
+  const uint2 *s8 = reinterpret_cast<const uint2 *>(src);
+  uint2 *d8 = reinterpret_cast<uint2 *>(dst);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x)
+    d8[i] = s8[i];
+}
+
+int launch_export_part(Ctx *c, void *dst_dev, uint32_t cap) {
+  hipLaunchKernelGGL(k_export_part, dim3(8), dim3(256), 0, c->stream, c->d_cand_part,
+                     reinterpret_cast<unsigned char *>(dst_dev), cap);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
                              uint64_t part_bytes, uint32_t cap) {
   if (!c->cleared) {

@@ -132,6 +132,74 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
   }
 }
 
+// ----- sharded shortlist -----------------------------------------------------------------------------
+// Every rank ranks its own views; what travels is each rank's k best as ONE sortable 64-bit key per view,
+//   key = (float32 distance bits) << 32 | global view id
+// (non-negative floats order like their bit patterns; equal distances fall to the lower view id, which is how the
+// unsharded k_bow_topk breaks ties because view ids ascend with the view index).  Lists shorter than k are padded
+// with ~0.
+__global__ __launch_bounds__(256) void k_bow_keys(const uint32_t *__restrict__ dist_bits, const uint32_t *__restrict__ sel,
+                                                  uint32_t n_sel, const uint32_t *__restrict__ view_id, uint32_t k,
+                                                  unsigned long long *__restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  unsigned long long key = ~0ull;
+  if (i < n_sel) {
+    const uint32_t v = sel[i];
+    key = ((unsigned long long)dist_bits[v] << 32) | (unsigned long long)view_id[v];
+  }
+  keys[i] = key;
+}
+
+// One 1024-thread workgroup per query: the k smallest of the n_parts x k gathered keys (rank by counting: the keys
+// are distinct), then those whose view id belongs to this shard (binary search in the ascending local id table) as
+// ASCENDING local view indices, padded with the phantom view (index n_views) up to n_pad entries.
+constexpr uint32_t kBowMergeMaxKeys = 8192;
+__global__ __launch_bounds__(1024) void k_bow_merge_select(const unsigned long long *__restrict__ keys, uint32_t n_parts,
+                                                           uint64_t part_stride, uint32_t k,
+                                                           const uint32_t *__restrict__ view_id, uint32_t n_views,
+                                                           uint32_t n_pad, uint32_t *__restrict__ sel_out) {
+  // all scratch in the dynamic region (16-byte aligned base): keys [n_parts * k] u64, then this shard's winners'
+  // local indices [1024] (unordered), then their count
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = n_parts * k;
+  unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(s_raw);
+  uint32_t *s_mine = reinterpret_cast<uint32_t *>(s_raw + (size_t)((n + 1) & ~1u) * 8);
+  uint32_t &s_n_mine = s_mine[1024];
+  if (tid == 0) s_n_mine = 0;
+  for (uint32_t i = tid; i < n; i += 1024) s_keys[i] = keys[(uint64_t)(i / k) * part_stride + (i % k)];
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const unsigned long long mine = s_keys[i];
+    if (mine == ~0ull) continue;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; ++j) rank += (s_keys[j] < mine);
+    if (rank >= k) continue;
+    const uint32_t id = (uint32_t)mine;
+    uint32_t lo = 0, hi = n_views;  // first local view with id >= the key's
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (view_id[mid] < id) lo = mid + 1;
+      else hi = mid;
+    }
+    if (lo < n_views && view_id[lo] == id) {
+      const uint32_t slot = atomicAdd(&s_n_mine, 1u);
+      if (slot < 1024) s_mine[slot] = lo;
+    }
+  }
+  __syncthreads();
+  const uint32_t n_mine = min(min(s_n_mine, 1024u), n_pad);
+  for (uint32_t i = tid; i < n_pad; i += 1024) sel_out[i] = n_views;  // phantom padding
+  __syncthreads();
+  if (tid < n_mine) {
+    const uint32_t v = s_mine[tid];
+    uint32_t pos = 0;
+    for (uint32_t j = 0; j < n_mine; ++j) pos += (s_mine[j] < v);
+    sel_out[pos] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bof_assign(const float *__restrict__ desc, const float *__restrict__ kxy,
                                                     int n, int in_dim, const float *__restrict__ pca_mean,
                                                     const float *__restrict__ pca_evec,
@@ -223,6 +291,36 @@ int launch_bow_select(Map *m, hipStream_t s, const float *d_query, const uint32_
                      d_query, d_dist_bits);
   SFM_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, s, d_dist_bits, n_cand, d_cand, k, d_out_sel);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_bow_keys(Map *m, hipStream_t s, const float *d_query, uint32_t k, uint32_t *d_dist_bits, uint32_t *d_sel_tmp,
+                    unsigned long long *d_keys_out) {
+  if (k == 0) return SFMLOC_OK;
+  const uint32_t kk = k < m->n_views ? k : m->n_views;
+  if (kk) {
+    int rc = launch_bow_select(m, s, d_query, nullptr, m->n_views, kk, d_dist_bits, d_sel_tmp);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_bow_keys, dim3((k + 255) / 256), dim3(256), 0, s, d_dist_bits, d_sel_tmp, kk, m->d_view_id, k,
+                     d_keys_out);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_bow_merge_select(Map *m, hipStream_t s, const unsigned long long *d_keys, uint32_t n_parts,
+                            uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out) {
+  const uint64_t n = (uint64_t)n_parts * k;
+  SFM_CHECK(n > 0 && n <= kBowMergeMaxKeys && k <= 1024, SFMLOC_EINVAL,
+            "sharded shortlist: %u parts x %u keys (at most %u keys in all, k <= 1024)", n_parts, k, kBowMergeMaxKeys);
+  const size_t lds = (size_t)((n + 1) & ~1ull) * 8 + 1024 * 4 + 16;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_merge_select),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(kBowMergeMaxKeys * 8 + 1024 * 4 + 16));
+  SFM_HIP(attr);
+  hipLaunchKernelGGL(k_bow_merge_select, dim3(1), dim3(1024), lds, s, d_keys, n_parts, part_stride_keys, k, m->d_view_id,
+                     m->n_views, n_pad, d_sel_out);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -129,6 +129,8 @@ void free_ctx(Ctx *c) {
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_result) hipHostFree(c->h_result);
   if (c->pinned_busy) hipEventDestroy(c->pinned_busy);
+  if (c->xev_out) hipEventDestroy(c->xev_out);
+  if (c->xev_in) hipEventDestroy(c->xev_in);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -160,10 +162,10 @@ int make_ctx(Map *m, Ctx **out) {
   const uint64_t n_pad = (uint64_t)m->n_blocks * kBlockRows;
   uint64_t *acct = &c->hbm_bytes;
   CTX_TRY(dev_alloc(acct, &c->d_part, (size_t)n_pad));
-  CTX_TRY(dev_alloc(acct, &c->d_view_sel, (size_t)m->n_views));
-  CTX_TRY(dev_alloc(acct, &c->d_view_widx0, (size_t)m->n_views));
+  CTX_TRY(dev_alloc(acct, &c->d_view_sel, (size_t)m->n_views + 1));
+  CTX_TRY(dev_alloc(acct, &c->d_view_widx0, (size_t)m->n_views + 1));
   CTX_TRY(dev_alloc(acct, &c->d_block_list, (size_t)m->n_blocks));
-  CTX_TRY(dev_alloc(acct, &c->d_view_count, (size_t)m->n_views));
+  CTX_TRY(dev_alloc(acct, &c->d_view_count, (size_t)m->n_views + 1));  // + the phantom view (sfmloc_internal.h)
   CTX_TRY(dev_alloc(acct, &c->d_match_i, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_match_key, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_flagged, (size_t)n_pad));
@@ -176,7 +178,7 @@ int make_ctx(Map *m, Ctx **out) {
   CTX_HIP(hipMemset(c->d_rows_arrivals, 0, (size_t)c->rows_chunk_cap * sizeof(uint32_t)));
   CTX_TRY(dev_alloc(acct, &c->d_k1_counters, (size_t)2));
   CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
-  CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views));
+  CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views + 1));
   CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
   // everything a finished query reports lives in ONE device record laid out as HostResult: one D2H copy per query
   CTX_TRY(dev_alloc(acct, &c->d_result, sizeof(HostResult)));
@@ -212,16 +214,18 @@ int make_ctx(Map *m, Ctx **out) {
     CTX_TRY(dev_alloc(acct, &c->d_bow_query, (size_t)m->bow_dim));
     CTX_TRY(dev_alloc(acct, &c->d_bow_dist, (size_t)m->n_views));
     CTX_TRY(dev_alloc(acct, &c->d_bow_cand, (size_t)m->n_views));
-    CTX_TRY(dev_alloc(acct, &c->d_bow_sel, (size_t)m->n_views));
+    CTX_TRY(dev_alloc(acct, &c->d_bow_sel, (size_t)m->n_views + 1));
   }
   CTX_HIP(hipHostMalloc((void **)&c->h_pinned, ((size_t)2 * m->n_views + m->n_blocks + 16) * sizeof(uint32_t),
                         hipHostMallocDefault));
   CTX_HIP(hipHostMalloc(&c->h_result, sizeof(HostResult), hipHostMallocDefault));
   memset(c->h_result, 0, sizeof(HostResult));
   CTX_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
-  CTX_HIP(hipMemsetAsync(c->d_view_count, 0, (size_t)m->n_views * sizeof(uint32_t), c->stream));
-  CTX_HIP(hipMemsetAsync(c->d_geo_count, 0, (size_t)m->n_views * sizeof(uint32_t), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_view_count, 0, ((size_t)m->n_views + 1) * sizeof(uint32_t), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_geo_count, 0, ((size_t)m->n_views + 1) * sizeof(uint32_t), c->stream));
   CTX_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
+  CTX_HIP(hipEventCreateWithFlags(&c->xev_out, hipEventDisableTiming));
+  CTX_HIP(hipEventCreateWithFlags(&c->xev_in, hipEventDisableTiming));
   CTX_HIP(hipMemsetAsync(c->d_pose, 0, sizeof(Pose), c->stream));
   CTX_HIP(hipMemsetAsync(c->d_p3p_state, 0, sizeof(P3pState), c->stream));
   CTX_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void k_query_reset(uint32_t *view_count, uint3
                                                      int *status, uint32_t *cand_header, uint32_t *view_stats,
                                                      uint32_t *ms_n) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t < n_views) {
+  if (t <= n_views) {  // <= : the phantom view's slot too
     view_count[t] = 0;
     geo_count[t] = 0;
   }
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void k_query_reset(uint32_t *view_count, uint3
 int ctx_reset_for_query(Ctx *c, const Query *q) {
   Map *m = c->map;
   const uint32_t nq = q->n ? q->n : 1;
-  const uint32_t n = m->n_views > nq ? m->n_views : nq;
+  const uint32_t n = m->n_views + 1 > nq ? m->n_views + 1 : nq;
   hipLaunchKernelGGL(k_query_reset, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_view_count, c->d_geo_count,
                      m->n_views, c->d_best64, nq, c->d_n_flagged, c->d_status,
                      reinterpret_cast<uint32_t *>(c->d_cand_part), c->d_view_stats, c->d_ms_n);
@@ -373,7 +377,7 @@ int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_se
       split *= 2;
   }
 
-  if (!c->cleared) SFM_HIP(hipMemsetAsync(c->d_view_count, 0, (size_t)m->n_views * sizeof(uint32_t), c->stream));
+  if (!c->cleared) SFM_HIP(hipMemsetAsync(c->d_view_count, 0, ((size_t)m->n_views + 1) * sizeof(uint32_t), c->stream));
   c->last_split = split;
   c->last_nq = q->n;
   c->last_n_sel = n_sel;
@@ -412,7 +416,7 @@ int check_stage(Ctx *c, Query *q, const char *who) {
 int ctx_geometric_filter(Ctx *c, Query *q) {
   Map *m = c->map;
   if (!c->cleared) {
-    SFM_HIP(hipMemsetAsync(c->d_geo_count, 0, (size_t)m->n_views * sizeof(uint32_t), c->stream));
+    SFM_HIP(hipMemsetAsync(c->d_geo_count, 0, ((size_t)m->n_views + 1) * sizeof(uint32_t), c->stream));
     SFM_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
   }
   if (q->n == 0 || c->last_n_sel == 0) return SFMLOC_OK;
@@ -675,9 +679,20 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
     if (d_stage) hipFree(d_stage);
   }
 
-  SFM_TRY(dev_upload(acct, &m->d_view_off, d->view_off, (size_t)d->n_views + 1, s));
-  SFM_TRY(dev_upload(acct, &m->d_view_id, d->view_id, (size_t)d->n_views, s));
-  if (d->view_wh) SFM_TRY(dev_upload(acct, &m->d_view_wh, d->view_wh, (size_t)d->n_views * 2, s));
+  {  // view tables + the phantom (empty) view at index n_views (sfmloc_internal.h)
+    std::vector<uint32_t> off(d->view_off, d->view_off + d->n_views + 1), id(d->view_id, d->view_id + d->n_views);
+    off.push_back((uint32_t)d->n_rows);
+    id.push_back(0xFFFFFFu);
+    SFM_TRY(dev_upload(acct, &m->d_view_off, off.data(), off.size(), s));
+    SFM_TRY(dev_upload(acct, &m->d_view_id, id.data(), id.size(), s));
+    if (d->view_wh) {
+      std::vector<uint32_t> wh(d->view_wh, d->view_wh + 2 * (size_t)d->n_views);
+      wh.push_back(1);
+      wh.push_back(1);
+      SFM_TRY(dev_upload(acct, &m->d_view_wh, wh.data(), wh.size(), s));
+    }
+    MAP_HIP(hipStreamSynchronize(s));  // the staging vectors go out of scope
+  }
   if (d->kpt_xy) SFM_TRY(dev_upload(acct, (float **)&m->d_kpt, d->kpt_xy, (size_t)d->n_rows * 2, s));
   if (d->row_landmark) {
     SFM_TRY(dev_upload(acct, &m->d_row_landmark, d->row_landmark, (size_t)d->n_rows, s));
@@ -817,7 +832,19 @@ void sfmloc_query_destroy(sfmloc_query *query) {
   if (q->d_desc) hipFree(q->d_desc);
   if (q->d_kpt) hipFree(q->d_kpt);
   if (q->d_kpt6) hipFree(q->d_kpt6);
+  if (q->d_bow) hipFree(q->d_bow);
   delete q;
+}
+
+int sfmloc_query_set_bow(sfmloc_query *query, const float *query_bow) {
+  SFM_CHECK(query && query_bow, SFMLOC_EINVAL, "sfmloc_query_set_bow: null argument");
+  Query *q = reinterpret_cast<Query *>(query);
+  Map *m = q->map;
+  SFM_CHECK(m && m->bow_dim > 0, SFMLOC_EINVAL, "sfmloc_query_set_bow: the map has no .bow vectors");
+  SFM_HIP(hipSetDevice(m->device));
+  if (!q->d_bow) SFM_HIP(hipMalloc((void **)&q->d_bow, (size_t)m->bow_dim * sizeof(float)));
+  SFM_HIP(hipMemcpy(q->d_bow, query_bow, (size_t)m->bow_dim * sizeof(float), hipMemcpyHostToDevice));
+  return SFMLOC_OK;
 }
 
 // ----- stage-level API on the map's own context -------------------------------------------------------
@@ -1027,10 +1054,12 @@ int sfmloc_localize_begin(sfmloc_context *ctx, sfmloc_query *query, const uint32
 
 int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const float *query_bow, uint32_t knn,
                               const uint32_t *cand_views, uint32_t n_cand) {
-  SFM_CHECK(ctx && query && query_bow, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: null argument");
+  SFM_CHECK(ctx && query, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: null argument");
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   Query *q = reinterpret_cast<Query *>(query);
   Map *m = c->map;
+  SFM_CHECK(query_bow || q->d_bow, SFMLOC_EINVAL,
+            "sfmloc_localize_bow_begin: no BoW vector (pass one, or make it resident with sfmloc_query_set_bow)");
   SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: query belongs to another map");
   SFM_CHECK(m->bow_dim > 0 && m->d_bow, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: the map has no .bow vectors");
   SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: context already has a query in flight");
@@ -1048,12 +1077,13 @@ int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const fl
     }
     SFM_HIP(hipMemcpyAsync(c->d_bow_cand, cand_views, n_cand * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   }
-  SFM_HIP(hipMemcpyAsync(c->d_bow_query, query_bow, m->bow_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (query_bow)
+    SFM_HIP(hipMemcpyAsync(c->d_bow_query, query_bow, m->bow_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
   int rc;
   {
     EventScope ev(c, SFMLOC_K_BOW);
-    rc = launch_bow_select(m, c->stream, c->d_bow_query, cand_views ? c->d_bow_cand : nullptr, n_cand, knn,
-                           c->d_bow_dist, c->d_bow_sel);
+    rc = launch_bow_select(m, c->stream, query_bow ? c->d_bow_query : q->d_bow, cand_views ? c->d_bow_cand : nullptr,
+                           n_cand, knn, c->d_bow_dist, c->d_bow_sel);
   }
   if (rc) return rc;
   // K8 leaves the knn views in ascending order in d_bow_sel; everything downstream reads the selection on the device
@@ -1098,10 +1128,80 @@ int sfmloc_shard_export(sfmloc_context *ctx, void *dst_dev, uint32_t cap) {
   SFM_CHECK(ctx && dst_dev && cap > 0, SFMLOC_EINVAL, "sfmloc_shard_export: bad argument");
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   SFM_HIP(hipSetDevice(c->map->device));
-  const uint32_t n = cap < c->cand_cap ? cap : c->cand_cap;
-  // header (with the true count: the merging side flags count > cap) + the first n candidates
-  SFM_HIP(hipMemcpyAsync(dst_dev, c->d_cand_part, kPartHeaderBytes + (size_t)n * sizeof(Candidate),
-                         hipMemcpyDeviceToDevice, c->stream));
+  // header (with the true count: the merging side flags count > cap) + the candidates that exist, at most cap
+  return launch_export_part(c, dst_dev, cap < c->cand_cap ? cap : c->cand_cap);
+}
+
+int sfmloc_shard_bow_keys(sfmloc_context *ctx, sfmloc_query *query, const float *query_bow, uint32_t knn,
+                          void *keys_dev) {
+  SFM_CHECK(ctx && query && keys_dev && knn > 0, SFMLOC_EINVAL, "sfmloc_shard_bow_keys: bad argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  Query *q = reinterpret_cast<Query *>(query);
+  Map *m = c->map;
+  SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_shard_bow_keys: query belongs to another map");
+  SFM_CHECK(m->bow_dim > 0 && m->d_bow, SFMLOC_EINVAL, "sfmloc_shard_bow_keys: the map has no .bow vectors");
+  SFM_CHECK(query_bow || q->d_bow, SFMLOC_EINVAL, "sfmloc_shard_bow_keys: no BoW vector");
+  SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_shard_bow_keys: context has a query in flight");
+  SFM_CHECK(knn <= 1024, SFMLOC_EINVAL, "sfmloc_shard_bow_keys: knn %u > 1024", knn);
+  SFM_HIP(hipSetDevice(m->device));
+  ctx_mark_busy(c);
+  if (query_bow)
+    SFM_HIP(hipMemcpyAsync(c->d_bow_query, query_bow, m->bow_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  EventScope ev(c, SFMLOC_K_BOW);
+  return launch_bow_keys(m, c->stream, query_bow ? c->d_bow_query : q->d_bow, knn, c->d_bow_dist, c->d_bow_cand,
+                         reinterpret_cast<unsigned long long *>(keys_dev));
+}
+
+int sfmloc_shard_begin_bow(sfmloc_context *ctx, sfmloc_query *query, const void *keys_dev, uint32_t n_parts,
+                           uint64_t part_stride_keys, uint32_t knn) {
+  SFM_CHECK(ctx && query && keys_dev && n_parts > 0 && knn > 0, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: bad argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  Query *q = reinterpret_cast<Query *>(query);
+  Map *m = c->map;
+  SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: query belongs to another map");
+  SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: context has a query in flight");
+  if (part_stride_keys == 0) part_stride_keys = knn;
+  SFM_CHECK(part_stride_keys >= knn, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: part_stride_keys < knn");
+  SFM_HIP(hipSetDevice(m->device));
+  ctx_mark_busy(c);  // until sfmloc_context_sync
+  ClearedScope cs{c};
+  int rc = ctx_reset_for_query(c, q);
+  if (rc) return rc;
+  // this shard's part of the global knn best: ascending local view indices, padded with the phantom view up to
+  // n_pad = min(knn, n_views) entries -- the launch sizes below depend on n_pad only, never on the outcome
+  const uint32_t n_pad = knn < m->n_views ? knn : m->n_views;
+  {
+    EventScope ev(c, SFMLOC_K_BOW);
+    rc = launch_bow_merge_select(m, c->stream, reinterpret_cast<const unsigned long long *>(keys_dev), n_parts,
+                                 part_stride_keys, knn, n_pad, c->d_bow_sel);
+  }
+  if (rc) return rc;
+  uint32_t dummy = 0;
+  rc = ctx_match_putative(c, q, &dummy, n_pad, c->d_bow_sel);
+  if (rc) return rc;
+  rc = check_stage(c, q, "sfmloc_shard_begin_bow");
+  if (rc) return rc;
+  rc = ctx_geometric_filter(c, q);
+  if (rc) return rc;
+  EventScope ev(c, SFMLOC_K_MATCHSET);
+  return launch_emit_candidates(c, q, c->last_n_sel, c->last_all_views);
+}
+
+int sfmloc_context_signal(sfmloc_context *ctx, void *hip_stream) {
+  SFM_CHECK(ctx, SFMLOC_EINVAL, "sfmloc_context_signal: null context");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  SFM_HIP(hipSetDevice(c->map->device));
+  SFM_HIP(hipEventRecord(c->xev_out, c->stream));
+  SFM_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), c->xev_out, 0));
+  return SFMLOC_OK;
+}
+
+int sfmloc_context_wait(sfmloc_context *ctx, void *hip_stream) {
+  SFM_CHECK(ctx, SFMLOC_EINVAL, "sfmloc_context_wait: null context");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  SFM_HIP(hipSetDevice(c->map->device));
+  SFM_HIP(hipEventRecord(c->xev_in, reinterpret_cast<hipStream_t>(hip_stream)));
+  SFM_HIP(hipStreamWaitEvent(c->stream, c->xev_in, 0));
   return SFMLOC_OK;
 }
 

@@ -116,9 +116,12 @@ struct Map {
   std::vector<double> h_view_center;     // [n_views*3], maps opened from sfm_data.json only
   std::vector<std::string> h_view_file;  // view filenames, same
   uint4 *d_bank = nullptr;         // tiled64, n_blocks*64 rows (zero padded)
-  uint32_t *d_view_off = nullptr;  // [n_views+1]
-  uint32_t *d_view_id = nullptr;   // [n_views]
-  uint32_t *d_view_wh = nullptr;   // [n_views*2]
+  // The view tables carry one extra, EMPTY view at index n_views ("phantom": no rows, id 0xFFFFFF): a device-built
+  // selection whose length the host cannot know (the sharded BoW shortlist) is padded with it, and every kernel
+  // treats it as a view without descriptors.  Per-view arrays of a context are sized n_views + 1 for the same reason.
+  uint32_t *d_view_off = nullptr;  // [n_views+2]  (view_off[n_views+1] = view_off[n_views] = n_rows)
+  uint32_t *d_view_id = nullptr;   // [n_views+1]
+  uint32_t *d_view_wh = nullptr;   // [(n_views+1)*2]
   float2 *d_kpt = nullptr;         // [n_rows]
   int32_t *d_row_landmark = nullptr;
   uint32_t *d_landmark_id = nullptr;
@@ -194,6 +197,7 @@ struct Ctx {
   uint32_t *d_bow_sel = nullptr;     // [n_views]
   void *h_result = nullptr;  // pinned: what a finished query copies back in one go (capi.hip HostResult)
   hipEvent_t pinned_busy = nullptr;  // recorded after the last upload out of h_pinned
+  hipEvent_t xev_out = nullptr, xev_in = nullptr;  // ordering against a caller's stream (sfmloc_context_signal / _wait)
 
   // state of the last putative call
   uint32_t last_split = 0;
@@ -223,6 +227,7 @@ struct Query {
   uint4 *d_desc = nullptr;  // [n_pad*4], row major, zero padded to a multiple of 64 rows
   float2 *d_kpt = nullptr;   // full precision (locFeat, AKAZEOpenCV.cpp:77-79): used for pt2D
   float2 *d_kpt6 = nullptr;  // after the .feat text round trip (6 significant digits): used by the F-matrix filter
+  float *d_bow = nullptr;    // the query's BoW vector, resident (sfmloc_query_set_bow), [bow_dim] or null
   std::vector<float> h_kpt;
 };
 
@@ -251,6 +256,12 @@ struct BofModel {
 };
 int launch_bow_select(Map *m, hipStream_t s, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
                       uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel);
+// sharded shortlist: this shard's k best as sortable keys (distance bits << 32 | global view id), and
+// the shard's part of the global k best among n_parts key lists
+int launch_bow_keys(Map *m, hipStream_t s, const float *d_query, uint32_t k, uint32_t *d_dist_bits, uint32_t *d_sel_tmp,
+                    unsigned long long *d_keys_out);
+int launch_bow_merge_select(Map *m, hipStream_t s, const unsigned long long *d_keys, uint32_t n_parts,
+                            uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out);
 int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const float *d_kxy, int n, uint32_t *d_counts,
                double *d_out, float *d_out_f32);
 
@@ -261,6 +272,7 @@ int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *
 int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, int min_putative = -1);
 int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
 int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
+int launch_export_part(Ctx *c, void *dst_dev, uint32_t cap);
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
                              uint64_t part_bytes, uint32_t cap);
 int launch_p3p_init(Ctx *c);

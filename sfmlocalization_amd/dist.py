@@ -87,58 +87,164 @@ def merge_bow_shortlists(local_dist, local_view_id, k, world, all_gather):
     return np.nonzero(np.isin(local_view_id, best[:, 1].astype(np.int64)))[0].astype(np.uint32)
 
 
+def bow_key(dist_f32, view_id):
+    """The sortable key a shard publishes per shortlisted view: float32 distance bits << 32 | view id (non-negative
+    floats order like their bit patterns; ties fall to the lower view id, as in the unsharded selection)."""
+    bits = np.asarray(dist_f32, np.float32).view(np.uint32).astype(np.uint64)
+    return (bits << np.uint64(32)) | np.asarray(view_id, np.uint64)
+
+
+BOW_KEY_PAD = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def select_from_keys(gathered_keys, k, local_view_id):
+    """gathered_keys [world, k] u64 (one query) -> ascending LOCAL indices of this shard's views among the global k
+    best.  Host restatement of k_bow_merge_select (tests, CPU stand-ins)."""
+    allk = np.asarray(gathered_keys, np.uint64).ravel()
+    allk = np.sort(allk[allk != BOW_KEY_PAD])[:k]
+    ids = (allk & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    return np.nonzero(np.isin(np.asarray(local_view_id, np.int64), ids))[0].astype(np.uint32)
+
+
 class ShardedLocalizer:
-    """compute.stage1(queries[, slot]) -> torch.uint8 [B, part_bytes] on compute.device (this shard's parts, possibly
-    still being written: compute.stage1_wait(slot) blocks until they are final);
-    compute.stage2(indices, gathered[world, B, part_bytes][, slot]) -> {index: result} for the queries this rank owns.
+    """One batch = (optional) sharded BoW shortlist -> stage 1 on every shard -> ONE all-gather of candidate parts ->
+    stage 2 (2D-3D selection + P3P) of query i on rank i mod world.
+
+    The exchange sends `cap` candidates per (query, shard) (512: a shard typically holds a few hundred); every rank
+    sees every part header after the gather, so all ranks agree -- without another collective -- when some shard had
+    more, and the batch is then exchanged again at `cap_full`.
+
+    compute protocol (HipShardCompute below; the CPU tests plug in a stand-in built on the oracle):
+      stage1(queries, slot, cap) -> uint8 [B, part_bytes(cap)] on compute.device (possibly still being written)
+      bow_keys(queries, knn, slot) -> int64 [B, knn] (u64 bit patterns)        } only for bow_knn > 0
+      stage1_bow(queries, gathered_keys [world, B, knn], knn, slot, cap)        }
+      before_collective(slot) / after_collective(slot): order the slot's streams against the collective's (optional)
+      stage2(indices, gathered [world, B, part_bytes(cap)], slot, cap) -> {index: result} for the queries owned here.
     A compute object with `n_slots >= 2` lets two batches overlap (localize_stream)."""
 
-    def __init__(self, compute, cap, rank=None, world=None, group=None, always_gather=False):
+    def __init__(self, compute, cap=512, rank=None, world=None, group=None, always_gather=False, cap_full=None,
+                 n_views_global=None):
         import torch.distributed as dist
         self.dist = dist
         self.always_gather = always_gather   # run the collective even on one rank (rehearsal of the N>1 path)
         self.compute = compute
         self.cap = cap
+        self.cap_full = max(cap, cap_full if cap_full is not None else getattr(compute, "cap_full", cap))
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.n_slots = int(getattr(compute, "n_slots", 1))
+        self.n_views_global = n_views_global
+        self.reset_counters()
+
+    def reset_counters(self):
+        self._n_batches = self._n_queries = self._n_redo = 0
+        self._bytes_parts = self._bytes_keys = 0
+        self._max_count = 0
+
+    def counters(self):
+        nb = max(1, self._n_batches)
+        return {"batches": self._n_batches, "queries": self._n_queries,
+                "candidate_allgather_bytes_per_batch_per_rank": self._bytes_parts / nb,
+                "bow_key_allgather_bytes_per_batch_per_rank": self._bytes_keys / nb,
+                "exchange_cap": self.cap, "exchange_cap_full": self.cap_full,
+                "max_candidates_of_one_shard_for_one_query": int(self._max_count),
+                "batches_exchanged_again_at_full_cap": self._n_redo}
 
     def owner(self, i):
         return i % self.world
 
-    def _stage1(self, queries, slot, view_sels=None):
-        kw = {} if view_sels is None else {"view_sels": view_sels}
-        if self.n_slots > 1:
-            return self.compute.stage1(queries, slot, **kw)
-        return self.compute.stage1(queries, **kw)
+    # ----- collectives --------------------------------------------------------------------------------------------
+    def _comm_stream(self):
+        return getattr(self.compute, "comm", None)
 
-    def _finish(self, queries, parts, slot, gather_results):
+    def _all_gather(self, send):
+        """send [B, ...] -> ([world, B, ...] on send's device, event) -- on the compute object's collective stream (if
+        any); the event marks the gather's completion on that stream (None without one)."""
+        import contextlib
         import torch
-        B = len(queries)
-        assert parts.dtype == torch.uint8 and tuple(parts.shape) == (B, part_bytes(self.cap))
-        if hasattr(self.compute, "stage1_wait"):
-            self.compute.stage1_wait(slot)     # the parts are written on the compute object's own streams
-        # concatenated along dim 0 (the layout every backend accepts), viewed as [world, B, part_bytes]
-        flat = torch.empty((self.world * B, parts.shape[1]), dtype=torch.uint8, device=parts.device)
-        if self.world > 1 or self.always_gather:
-            if parts.is_cuda and self.dist.get_backend(self.group) == "gloo":
-                # rehearsal of the N>1 path without RCCL (e.g. two ranks sharing one GPU): stage through the host
-                host = torch.empty(flat.shape, dtype=torch.uint8)
-                self.dist.all_gather_into_tensor(host, parts.cpu().contiguous(), group=self.group)
-                flat.copy_(host)
+        out = torch.empty((self.world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        comm = self._comm_stream()
+        scope = torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()
+        with scope:
+            if self.world > 1 or self.always_gather:
+                flat = out.view((self.world * send.shape[0],) + tuple(send.shape[1:]))
+                if send.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                    # rehearsal of the N>1 path without RCCL (e.g. two ranks sharing one GPU): stage through the host
+                    if comm is not None:
+                        comm.synchronize()
+                    host = torch.empty(flat.shape, dtype=send.dtype)
+                    self.dist.all_gather_into_tensor(host, send.cpu().contiguous(), group=self.group)
+                    flat.copy_(host)
+                else:
+                    self.dist.all_gather_into_tensor(flat, send.contiguous(), group=self.group)
             else:
-                self.dist.all_gather_into_tensor(flat, parts.contiguous(), group=self.group)
+                out[0].copy_(send)
+            ev = comm.record_event() if comm is not None else None
+        return out, ev
+
+    def _before(self, slot):
+        if hasattr(self.compute, "before_collective"):
+            self.compute.before_collective(slot)
+
+    def _after(self, slot):
+        if hasattr(self.compute, "after_collective"):
+            self.compute.after_collective(slot)
+
+    # ----- one batch ----------------------------------------------------------------------------------------------
+    def _use_bow(self, bow_knn):
+        """localization.cpp:346: the shortlist applies only when more than knn candidate views remain."""
+        if not bow_knn:
+            return False
+        return self.n_views_global is None or self.n_views_global > bow_knn
+
+    def _stage1(self, queries, slot, cap, bow_knn=0, keys_all=None):
+        if self._use_bow(bow_knn):
+            if keys_all is None:
+                keys = self.compute.bow_keys(queries, bow_knn, slot)
+                self._before(slot)
+                keys_all, _ = self._all_gather(keys)
+                self._after(slot)
+                self._bytes_keys += keys.numel() * keys.element_size()
+            parts = self.compute.stage1_bow(queries, keys_all, bow_knn, slot, cap)
         else:
-            flat.copy_(parts)
-        if flat.is_cuda:
-            torch.cuda.current_stream(flat.device).synchronize()   # stage 2 reads `flat` on other streams
-        gathered = flat.view(self.world, B, parts.shape[1])
+            parts = self.compute.stage1(queries, slot, cap)
+        self._before(slot)
+        gathered, ev = self._all_gather(parts)
+        # the slot's contexts do nothing more until stage 2 of THIS batch: they wait for this gather right away, so that
+        # a later batch's collectives on the same stream never stand between a batch and its own stage 2
+        self._after(slot)
+        self._bytes_parts += parts.numel() * parts.element_size()
+        return gathered, keys_all, ev
+
+    def _begin(self, queries, slot, bow_knn=0):
+        gathered, keys_all, ev = self._stage1(queries, slot, self.cap, bow_knn)
+        return (queries, gathered, keys_all, slot, bow_knn, ev)
+
+    def _finish(self, state, gather_results):
+        import torch
+        queries, gathered, keys_all, slot, bow_knn, ev = state
+        B = len(queries)
+        cap = self.cap
+        assert gathered.dtype == torch.uint8 and tuple(gathered.shape) == (self.world, B, part_bytes(cap))
+        # every rank holds every header: the same decision everywhere, no extra collective
+        if ev is not None:
+            ev.synchronize()
+        counts = gathered[:, :, :4].contiguous().view(torch.int32)
+        mx = int(counts.max().item()) if counts.numel() else 0
+        self._max_count = max(self._max_count, mx)
+        if mx > cap:
+            if mx > self.cap_full:
+                raise OverflowError(f"a shard produced {mx} candidates for one query; parts hold at most {self.cap_full}")
+            cap = self.cap_full
+            self._n_redo += 1
+            gathered, _, ev = self._stage1(queries, slot, cap, bow_knn, keys_all)
+            if ev is not None:
+                ev.synchronize()
+        self._n_batches += 1
+        self._n_queries += B
         mine = [i for i in range(B) if self.owner(i) == self.rank]
-        if self.n_slots > 1:
-            local = self.compute.stage2(mine, gathered, slot)
-        else:
-            local = self.compute.stage2(mine, gathered)
+        local = self.compute.stage2(mine, gathered, slot, cap)
         if not gather_results or self.world == 1:
             return local
         allres = [None] * self.world
@@ -148,75 +254,46 @@ class ShardedLocalizer:
             out.update(d)
         return out
 
-    def bow_shortlists(self, local_map, query_bows, k):
-        """Per query: the LOCAL view indices of the global k-nearest .bow vectors (exact, equal to the unsharded
-        sfmloc_bow_select).  One small all-gather for the whole batch."""
-        import torch
-        ids = np.asarray(local_map.view_id, np.int64)
-        B = len(query_bows)
-        mine = np.full((B, k, 2), np.inf, np.float64)
-        for b, qb in enumerate(query_bows):
-            d = local_map.bow_distances(qb)
-            order = _k_best(d, ids, k)
-            mine[b, :len(order), 0] = d[order]
-            mine[b, :len(order), 1] = ids[order]
-        if self.world > 1:
-            t = torch.from_numpy(mine)
-            dev = getattr(self.compute, "device", torch.device("cpu"))
-            t = t.to(dev)
-            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=dev)
-            self.dist.all_gather_into_tensor(out.view(self.world * B, k, 2), t, group=self.group)
-            allp = out.cpu().numpy()
-        else:
-            allp = mine[None]
-        sels = []
-        for b in range(B):
-            p = allp[:, b].reshape(-1, 2)
-            p = p[np.isfinite(p[:, 0])]
-            best = p[np.lexsort((p[:, 1], p[:, 0]))[:k]]
-            sels.append(np.nonzero(np.isin(ids, best[:, 1].astype(np.int64)))[0].astype(np.uint32))
-        return sels
+    def localize_batch(self, queries, gather_results=True, bow_knn=0):
+        return self._finish(self._begin(queries, 0, bow_knn), gather_results)
 
-    def localize_batch(self, queries, gather_results=True, view_sels=None):
-        return self._finish(queries, self._stage1(queries, 0, view_sels), 0, gather_results)
-
-    def localize_stream(self, batches, gather_results=False, view_sels=None):
+    def localize_stream(self, batches, gather_results=False, bow_knn=0):
         """Generator over batches (lists of queries), yielding each batch's {index: result} in order.  With a
-        two-slot compute object the shard-local stage of batch i+1 is already queued on the GPU while batch i goes
-        through the collective and its P3P stage, so the exchange and the latency-bound tail hide under the next
-        batch's Hamming scans.  Every rank must iterate the same batches.  view_sels: optional iterable, per batch the
-        list of this shard's view selections (e.g. from bow_shortlists), consumed lazily batch by batch."""
+        two-slot compute object the shard-local stage of batch i+1 (and its collectives) is already queued while batch
+        i goes through its P3P stage, so the exchange and the latency-bound tail hide under the next batch's Hamming
+        scans.  Every rank must iterate the same batches."""
         prev = None
         slot = 0
-        sels_it = iter(view_sels) if view_sels is not None else None   # per batch: this shard's view selections
         for batch in batches:
-            sels = next(sels_it) if sels_it is not None else None
             if self.n_slots < 2:
-                yield self.localize_batch(batch, gather_results, view_sels=sels)
+                yield self.localize_batch(batch, gather_results, bow_knn)
                 continue
-            cur = (batch, self._stage1(batch, slot, sels), slot)
+            cur = self._begin(batch, slot, bow_knn)
             if prev is not None:
-                yield self._finish(*prev, gather_results)
+                yield self._finish(prev, gather_results)
             prev = cur
             slot ^= 1
         if prev is not None:
-            yield self._finish(*prev, gather_results)
+            yield self._finish(prev, gather_results)
 
 
 class HipShardCompute:
     """Stage 1 / stage 2 on one MI355X through the C ABI.  `shard_map` is a capi.Map holding this rank's views
-    (with the FULL landmark table); queries are capi.Query objects created on it.  Two slots of `n_contexts`
-    contexts each, so that ShardedLocalizer.localize_stream can overlap consecutive batches."""
+    (with the FULL landmark table); queries are capi.Query objects created on it (with a resident BoW vector when the
+    shortlist is used).  Two slots of `n_contexts` contexts each, so that ShardedLocalizer.localize_stream can overlap
+    consecutive batches.  Nothing here blocks the host between stage 1 and the collective: the contexts' streams and
+    the collective's stream (`comm`) are ordered by events (sfmloc_context_signal / _wait)."""
 
     n_slots = 2
+    cap_full = 16384      # candidates a context's part holds (sfmloc_internal.h Ctx::cand_cap)
 
-    def __init__(self, shard_map, cap, n_contexts=4, device=None):
+    def __init__(self, shard_map, cap=None, n_contexts=4, device=None):
         import torch
         self.map = shard_map
-        self.cap = cap
         self.device = torch.device("cuda", shard_map.params.device) if device is None else device
+        self.comm = torch.cuda.Stream(self.device)
         self.ctxs = [[shard_map.context() for _ in range(n_contexts)] for _ in range(self.n_slots)]
-        self._parts = [None] * self.n_slots
+        self._buf = {}
         self._queries = [None] * self.n_slots
 
     def close(self):
@@ -224,32 +301,68 @@ class HipShardCompute:
             for c in cs:
                 c.close()
 
-    def stage1(self, queries, slot=0, view_sels=None):
+    def _tensor(self, name, slot, shape, dtype):
+        """persistent per (name, slot, shape): the C ABI writes every byte that is read back, so no clearing (and a
+        fill on torch's stream would race with the writes on the contexts' streams)"""
+        import torch
+        key = (name, slot, tuple(shape), dtype)
+        t = self._buf.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()
+            self._buf[key] = t
+        return t
+
+    def before_collective(self, slot=0):
+        for c in self.ctxs[slot]:
+            c.signal(self.comm.cuda_stream)       # the collective waits for the slot's queued work
+
+    def after_collective(self, slot=0):
+        for c in self.ctxs[slot]:
+            c.wait(self.comm.cuda_stream)         # the slot's later work waits for the collective
+
+    def bow_keys(self, queries, knn, slot=0):
         import torch
         B = len(queries)
-        pb = part_bytes(self.cap)
-        parts = self._parts[slot]
-        if parts is None or parts.shape[0] != B:
-            # persistent per slot; sfmloc_shard_export writes every byte of a part, so no clearing is needed (and a
-            # fill on torch's stream would race with the exports on the contexts' streams)
-            parts = torch.empty((B, pb), dtype=torch.uint8, device=self.device)
-            torch.cuda.current_stream(self.device).synchronize()
-            self._parts[slot] = parts
+        keys = self._tensor("keys", slot, (B, knn), torch.int64)
+        cs = self.ctxs[slot]
+        base = keys.data_ptr()
+        for i, q in enumerate(queries):
+            cs[i % len(cs)].shard_bow_keys(q, knn, base + i * knn * 8)
+        return keys
+
+    def stage1_bow(self, queries, keys_all, knn, slot=0, cap=512):
+        import torch
+        B = len(queries)
+        world = keys_all.shape[0]
+        pb = part_bytes(cap)
+        parts = self._tensor("parts", slot, (B, pb), torch.uint8)
+        base, kbase = parts.data_ptr(), keys_all.data_ptr()
+        cs = self.ctxs[slot]
+        for i, q in enumerate(queries):
+            c = cs[i % len(cs)]
+            # query i's key lists: keys_all[r, i, :] for r in range(world) -> stride B*knn keys
+            c.shard_begin_bow(q, kbase + i * knn * 8, world, knn, part_stride_keys=B * knn)
+            c.shard_export(base + i * pb, cap)
+        self._queries[slot] = queries
+        return parts
+
+    def stage1(self, queries, slot=0, cap=512, view_sels=None):
+        import torch
+        B = len(queries)
+        pb = part_bytes(cap)
+        parts = self._tensor("parts", slot, (B, pb), torch.uint8)
         base = parts.data_ptr()
         cs = self.ctxs[slot]
         for i, q in enumerate(queries):
             c = cs[i % len(cs)]
-            # K1..K3 + candidate emission, asynchronous; view_sels[i]: this shard's views to scan (BoW shortlist)
+            # K1..K3 + candidate emission, asynchronous; view_sels[i]: this shard's views to scan
             c.shard_begin(q, None if view_sels is None else view_sels[i])
-            c.shard_export(base + i * pb, self.cap)  # device-to-device copy on the same stream
+            c.shard_export(base + i * pb, cap)  # on the same stream
         self._queries[slot] = queries
         return parts
 
-    def stage1_wait(self, slot=0):
-        for c in self.ctxs[slot]:
-            c.sync()                               # the collective runs on torch's stream
-
-    def stage2(self, indices, gathered, slot=0):
+    def stage2(self, indices, gathered, slot=0, cap=512):
         world, B, pb = gathered.shape
         base = gathered.data_ptr()
         out = {}
@@ -263,7 +376,7 @@ class HipShardCompute:
                 j, cj = pending.pop(0)
                 out[j] = _pose_tuple(cj.end())
             # query i's parts: gathered[r, i, :] for r in range(world) -> stride B*pb
-            c.merge_begin(queries[i], base + i * pb, world, self.cap, part_stride=B * pb)
+            c.merge_begin(queries[i], base + i * pb, world, cap, part_stride=B * pb)
             pending.append((i, c))
         for j, cj in pending:
             out[j] = _pose_tuple(cj.end())

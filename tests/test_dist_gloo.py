@@ -84,21 +84,45 @@ class OracleShardCompute:
 
     n_slots = 2      # so that ShardedLocalizer.localize_stream takes its pipelined branch
 
-    def stage1(self, queries, slot=0):
+    def _parts(self, queries, slot, cap, sels=None):
         from oracle import pipeline as opipe
         if not hasattr(self, "queries"):
             self.queries = {}
         self.queries[slot] = queries
-        rows = [D.pack_part(opipe.shard_candidates(self.m, q.desc, q.kpt_xy, (q.width, q.height), self.v0, self.v1),
-                            self.cap) for q in queries]
+        rows = []
+        for i, q in enumerate(queries):
+            kw = {} if sels is None else {"view_sel": sels[i]}
+            c = opipe.shard_candidates(self.m, q.desc, q.kpt_xy, (q.width, q.height), self.v0, self.v1, **kw)
+            buf = D.pack_part(c[:cap], cap)
+            buf[:4] = np.frombuffer(np.uint32(len(c)).tobytes(), np.uint8)    # the header keeps the true count
+            rows.append(buf)
         return torch.from_numpy(np.stack(rows))
 
-    def stage2(self, indices, gathered, slot=0):
+    def stage1(self, queries, slot=0, cap=None):
+        return self._parts(queries, slot, cap or self.cap)
+
+    def bow_keys(self, queries, knn, slot=0):
+        """this shard's knn best (float32 L2 distance, view id) keys per query, padded with ~0"""
+        ids = self.m.view_id[self.v0:self.v1]
+        out = np.full((len(queries), knn), D.BOW_KEY_PAD, np.uint64)
+        for i, q in enumerate(queries):
+            d = ((self.m.extra["bow"][self.v0:self.v1] - q.bow[None, :]) ** 2).sum(1, dtype=np.float32)
+            keys = np.sort(D.bow_key(d, ids))[:knn]
+            out[i, :len(keys)] = keys
+        return torch.from_numpy(out.view(np.int64))
+
+    def stage1_bow(self, queries, keys_all, knn, slot=0, cap=None):
+        ka = keys_all.numpy().view(np.uint64)
+        ids = self.m.view_id[self.v0:self.v1]
+        sels = [self.v0 + D.select_from_keys(ka[:, i, :], knn, ids) for i in range(len(queries))]
+        return self._parts(queries, slot, cap or self.cap, sels)
+
+    def stage2(self, indices, gathered, slot=0, cap=None):
         from oracle import pipeline as opipe
         g = gathered.numpy()
         out = {}
         for i in indices:
-            parts = [D.unpack_part(g[r, i], self.cap) for r in range(g.shape[0])]
+            parts = [D.unpack_part(g[r, i], cap or self.cap) for r in range(g.shape[0])]
             out[i] = opipe.merge_candidates(parts, self.queries[slot][i].kpt_xy, self.m.intrinsic)
         return out
 
@@ -116,6 +140,22 @@ def _worker(rank, world, port, q):
         v0, v1 = D.shard_views(m.view_off, world)[rank]
         loc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), cap=2048)
         res = loc.localize_batch(queries)
+        # a small exchange capacity overflows on some shard: every rank sees it in the gathered headers and the batch
+        # is exchanged again at the full capacity -- same results
+        small = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), cap=8, cap_full=2048)
+        res_small = small.localize_batch(queries)
+        assert small.counters()["batches_exchanged_again_at_full_cap"] == 1
+        for k in res:
+            assert res_small[k]["ok"] == res[k]["ok"] and np.array_equal(res_small[k]["ms_qfeat"], res[k]["ms_qfeat"])
+        # sharded BoW shortlist (two collectives per batch): equal to shortlisting over the whole map
+        rng = np.random.Generator(np.random.PCG64(77))
+        m.extra["bow"] = rng.integers(0, 4, (m.n_views, 12)).astype(np.float32)     # many tied distances
+        knn = 7
+        for k, qq in enumerate(queries):
+            qq.bow = m.extra["bow"][(5 * k) % m.n_views] + rng.integers(0, 2, 12).astype(np.float32)
+        bowloc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), cap=2048, n_views_global=m.n_views)
+        res_bow = bowloc.localize_batch(queries, bow_knn=knn)
+        assert bowloc.counters()["bow_key_allgather_bytes_per_batch_per_rank"] == len(queries) * knn * 8
         # the pipelined form over three uneven batches must give the same per-query results
         batches = [[queries[0], queries[1]], [queries[2]], [queries[2], queries[0]]]
         for b, out in zip(batches, loc.localize_stream(batches, gather_results=True)):
@@ -126,7 +166,10 @@ def _worker(rank, world, port, q):
                     assert np.array_equal(np.asarray(out[i]["pair_qfeat"]), np.asarray(res[k]["pair_qfeat"]))
                     assert np.array_equal(np.asarray(out[i]["P"]), np.asarray(res[k]["P"]))
         if rank == 0:
-            q.put({i: {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for i, r in res.items()})
+            pack = lambda rr: {i: {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()}  # noqa: E731
+                               for i, r in rr.items()}
+            q.put({"plain": pack(res), "bow": pack(res_bow),
+                   "qbow": [qq.bow.tolist() for qq in queries], "bow_mat": m.extra["bow"].tolist(), "knn": knn})
     except Exception as e:  # surface the failure instead of letting the parent time out
         import traceback
         q.put({"error": f"rank {rank}: {e}\n{traceback.format_exc()}"})
@@ -154,10 +197,18 @@ def test_two_ranks_equal_unsharded():
     m = synth.make_map(31, n_views=24, desc_per_view=220, views_per_place=8, landmarks_per_place=200,
                        obs_per_view=90, ragged=True)
     n_ok = 0
+    bow_mat = np.array(res["bow_mat"], np.float32)
     for k in range(3):
         qq = synth.make_query(m, 700 + k, n_feat=260, n_copies=110, outlier_frac=0.2, place=k % 3)
+        # the sharded shortlist + path equals the shortlist over the whole map + the unsharded path
+        d = ((bow_mat - np.array(res["qbow"][k], np.float32)[None, :]) ** 2).sum(1, dtype=np.float32)
+        sel = np.sort(np.lexsort((m.view_id, d))[:res["knn"]]).astype(np.uint32)
+        exp_b = opipe.localize(m, qq.desc, qq.kpt_xy, (qq.width, qq.height), view_sel=sel)
+        got_b = res["bow"][str(k)] if str(k) in res["bow"] else res["bow"][k]
+        assert got_b["ok"] == exp_b["ok"]
+        np.testing.assert_array_equal(got_b.get("ms_qfeat", []), exp_b["ms_qfeat"])
         exp = opipe.localize(m, qq.desc, qq.kpt_xy, (qq.width, qq.height))
-        got = res[k]
+        got = res["plain"][k]
         assert got["ok"] == exp["ok"]
         np.testing.assert_array_equal(got["ms_qfeat"], exp["ms_qfeat"])
         np.testing.assert_array_equal(got["ms_landmark"], exp["ms_landmark"])

@@ -170,3 +170,102 @@ def test_shortlist_chain_on_the_device_equals_two_steps():
             ctx.begin_bow(dq, np.zeros(500, np.float32), 5)
         ctx.close()
         dq.close()
+
+
+def test_sharded_shortlist_chain_on_the_device_equals_unsharded():
+    """sfmloc_shard_bow_keys -> (all-gather of the key lists) -> sfmloc_shard_begin_bow -> parts -> sfmloc_merge_begin
+    over three shards of one map on one GPU -- a ragged map, tied BoW distances, a one-view shard, knn larger than a
+    shard -- against sfmloc_localize_bow on the whole map: pose, inliers, pairs bit for bit.  The same through
+    dist.ShardedLocalizer (world 1, the resident query BoW vector, an exchange capacity small enough to force the
+    second exchange at full capacity)."""
+    import torch
+    from sfmlocalization_amd import dist as D
+    rng = np.random.Generator(np.random.PCG64(91))
+    m = synth.make_map(41, n_views=40, desc_per_view=400, views_per_place=10, landmarks_per_place=300, obs_per_view=140,
+                       ragged=True, view_id_stride=3)
+    nv = m.n_views
+    proto = rng.integers(0, 3, (len(m.place_center), 24)).astype(np.float32)
+    bow = (proto[m.view_place] + rng.integers(0, 2, (nv, 24))).astype(np.float32)      # integer-valued: many exact ties
+    kw = dict(params=S.default_params(ransac_round=25), landmark_id=m.landmark_id, landmark_X=m.landmark_X,
+              intrinsic=m.intrinsic)
+    full = S.Map(m.view_id, m.view_off, m.desc, view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark,
+                 bow=bow, **kw)
+    cuts = [(0, 17), (17, 18), (18, nv)]
+    shards = []
+    for a, b in cuts:
+        r0, r1 = int(m.view_off[a]), int(m.view_off[b])
+        shards.append(S.Map(m.view_id[a:b], m.view_off[a:b + 1] - m.view_off[a], m.desc[r0:r1], view_wh=m.view_wh[a:b],
+                            kpt_xy=m.kpt_xy[r0:r1], row_landmark=m.row_landmark[r0:r1], bow=bow[a:b], **kw))
+    ctxs = [sm.context() for sm in shards]
+    cap = 4096
+    pb = D.part_bytes(cap)
+    n_ok = 0
+    for trial in range(4):
+        q = synth.make_query(m, 300 + trial, n_feat=900, place=trial % len(m.place_center))
+        qb = (proto[q.place] + rng.integers(0, 2, 24)).astype(np.float32)
+        fq = full.query(q.desc, q.kpt_xy, q.width, q.height)
+        for knn in (1, 5, 12, 25):
+            ref = full.localize_bow(fq, qb, knn)
+            keys = torch.zeros((3, knn), dtype=torch.int64, device="cuda")
+            parts = torch.zeros((3, pb), dtype=torch.uint8, device="cuda")
+            sqs = [sm.query(q.desc, q.kpt_xy, q.width, q.height) for sm in shards]
+            for s, (c, sq) in enumerate(zip(ctxs, sqs)):
+                c.shard_bow_keys(sq, knn, keys.data_ptr() + s * knn * 8, bow=qb)
+                c.sync()
+            # the key lists are the shard's knn best (float32 distance bits << 32 | view id), padded with ~0
+            hk = keys.cpu().numpy().view(np.uint64)
+            d_all = full.bow_distances(qb)
+            for s, (a, b) in enumerate(cuts):
+                exp = np.sort(D.bow_key(d_all[a:b], m.view_id[a:b]))[:knn]
+                np.testing.assert_array_equal(np.sort(hk[s][hk[s] != D.BOW_KEY_PAD]), exp)
+            glob = set(full.bow_select(qb, knn).tolist())
+            got_sel = set()
+            for s, (c, sq) in enumerate(zip(ctxs, sqs)):
+                got_sel |= set(cuts[s][0] + int(i) for i in D.select_from_keys(hk, knn, m.view_id[cuts[s][0]:cuts[s][1]]))
+                c.shard_begin_bow(sq, keys.data_ptr(), 3, knn)
+                c.shard_export(parts.data_ptr() + s * pb, cap)
+                c.sync()
+            assert got_sel == glob
+            ctxs[2].merge_begin(sqs[2], parts.data_ptr(), 3, cap)
+            pose, pq, pl = ctxs[2].end()
+            tag = f"trial {trial} knn {knn}"
+            assert pose.ok == ref[0].ok and pose.n_inliers == ref[0].n_inliers, tag
+            assert pose.n_matches_2d3d == ref[0].n_matches_2d3d, tag
+            np.testing.assert_array_equal(pq, ref[1], err_msg=tag)
+            np.testing.assert_array_equal(pl, ref[2], err_msg=tag)
+            np.testing.assert_array_equal(np.array(pose.P).view(np.uint64), np.array(ref[0].P).view(np.uint64), err_msg=tag)
+            n_ok += int(pose.ok)
+            for sq in sqs:
+                sq.close()
+        fq.close()
+    assert n_ok >= 6, n_ok
+    for c in ctxs:
+        c.close()
+    # the torch.distributed layer, one rank, the whole map as the only shard
+    qs, refs = [], []
+    for trial in range(5):
+        q = synth.make_query(m, 400 + trial, n_feat=900, place=trial % len(m.place_center))
+        qb = (proto[q.place] + rng.integers(0, 2, 24)).astype(np.float32)
+        dq = full.query(q.desc, q.kpt_xy, q.width, q.height)
+        dq.set_bow(qb)
+        qs.append(dq)
+        refs.append(full.localize_bow(dq, qb, 9))
+    comp = D.HipShardCompute(full, n_contexts=2)
+    for xcap in (512, 4):                     # 4: every shard overflows -> the batch is exchanged again at full capacity
+        loc = D.ShardedLocalizer(comp, cap=xcap, rank=0, world=1, n_views_global=nv)
+        outs = list(loc.localize_stream([qs[:2], qs[2:]], bow_knn=9))
+        res = {0: outs[0][0], 1: outs[0][1], 2: outs[1][0], 3: outs[1][1], 4: outs[1][2]}
+        for i, ref in enumerate(refs):
+            assert res[i]["ok"] == bool(ref[0].ok), (xcap, i)
+            np.testing.assert_array_equal(res[i]["pair_qfeat"], ref[1])
+            if ref[0].ok:
+                np.testing.assert_array_equal(res[i]["P"].ravel().view(np.uint64), np.array(ref[0].P).view(np.uint64))
+        cn = loc.counters()
+        assert cn["batches"] == 2 and cn["batches_exchanged_again_at_full_cap"] == (2 if xcap == 4 else 0), cn
+        assert cn["bow_key_allgather_bytes_per_batch_per_rank"] == 2.5 * 9 * 8
+    comp.close()
+    for dq in qs:
+        dq.close()
+    for sm in shards:
+        sm.close()
+    full.close()

@@ -1,0 +1,241 @@
+// From the pure xor+bcnt instruction mix up to the screened K1 loop, one ingredient at a time, at 8 waves per SIMD on
+// an exactly balanced persistent grid (LDS sized so that exactly 4 workgroups of 8 waves fit a CU; grid = 4 x CUs).
+// Every wave owns one "bank row" per lane (16 random dwords in VGPRs) and walks the same query block `reps` times.
+// Reports, per rung: wall time, VALU wave-instructions per pair (counted from the source), cycles per VALU
+// instruction per SIMD (from wall time and from in-kernel s_memtime stamps, median over waves) and the clock held.
+//
+//   0 mix        10 x (v_xor_b32 vgpr, v_bcnt_u32_b32 into 4 rotating accumulators): the ceiling of the mix
+//   1 chain      the same with ONE accumulator chain per pair (what the production loop does)
+//   2 vote       + v_cmp / any-lane vote / branch per pair (threshold 0: never taken)
+//   3 lds        query rows from LDS by broadcast ds_read_b128 (the production structure), vote never taken
+//   4 lds+finish 3 with the real threshold: ~4 % of the wave-pairs finish the remaining 6 dwords + top-2 update
+//   5 smem       query rows through the scalar cache (s_load), SGPR operands of v_xor, vote never taken
+//   6 smem+finish 5 with the real threshold
+//   7 smem2      6 with two query rows per vote (one branch per two pairs)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const u32x4 __attribute__((address_space(4))) *cptr4;
+typedef const u32x2 __attribute__((address_space(4))) *cptr2;
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ void top2_push(uint32_t &b0, uint32_t &b1, uint32_t key) { b1 = umed3(b0, b1, key); b0 = min(b0, key); }
+
+constexpr int NW = 10;
+constexpr int WAVES = 8;
+constexpr uint32_t LDS_ROWS = 512;
+
+template <int MODE>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_ladder(const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t thr,
+                                                          int reps, const uint16_t *__restrict__ ratio_cnt,
+                                                          uint32_t *__restrict__ out, unsigned long long *__restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4 *qs = reinterpret_cast<uint4 *>(smem);
+  uint16_t *cnt_s = reinterpret_cast<uint16_t *>(smem + LDS_ROWS * 64);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t b[16];
+  uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; b[k] = h; }
+  for (uint32_t i = threadIdx.x; i < 513; i += WAVES * 64) cnt_s[i] = ratio_cnt[i];
+  __syncthreads();
+  uint32_t best0 = 0xFFFFFFFFu, best1 = 0xFFFFFFFFu, T = thr, nfin = 0;
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  unsigned long long t0, t1, r0, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+  for (int rep = 0; rep < reps; ++rep) {
+    if (MODE <= 2) {
+      uint32_t q = (uint32_t)rep * 0x9E3779B9u + lane;
+#pragma unroll 4
+      for (uint32_t j = 0; j < nq; ++j) {
+        q += 0x7F4A7C15u;  // 1 VALU of bookkeeping per pair (counted)
+        if (MODE == 0) {
+#pragma unroll
+          for (int k = 0; k < NW; k += 2) {
+            a0 += __builtin_popcount(b[k] ^ q);
+            a1 += __builtin_popcount(b[k + 1] ^ q);
+          }
+          a2 ^= a0; a3 ^= a1;  // 2 more VALU (counted)
+        } else {
+          uint32_t acc = 0;
+#pragma unroll
+          for (int k = 0; k < NW; ++k) acc += __builtin_popcount(b[k] ^ q);
+          if (MODE == 2) {
+            if (__any(acc < T)) { ++nfin; top2_push(best0, best1, (acc << 16) | j); }
+          } else {
+            a0 ^= acc;
+          }
+        }
+      }
+    } else if (MODE == 3 || MODE == 4) {
+      for (uint32_t j0 = 0; j0 < nq; j0 += LDS_ROWS) {
+        const uint32_t cnt = min(LDS_ROWS, nq - j0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
+        __syncthreads();
+#pragma unroll 2
+        for (uint32_t jj = 0; jj < cnt; ++jj) {
+          uint32_t q[16];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const uint4 v = qs[jj * 4 + c];
+            q[4 * c + 0] = v.x, q[4 * c + 1] = v.y, q[4 * c + 2] = v.z, q[4 * c + 3] = v.w;
+          }
+          uint32_t acc = 0;
+#pragma unroll
+          for (int k = 0; k < NW; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
+          if (__any(acc < T)) {
+            ++nfin;
+#pragma unroll
+            for (int k = NW; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
+            top2_push(best0, best1, (acc << 16) | (j0 + jj));
+            if (MODE == 4) T = (uint32_t)cnt_s[min(best1 >> 16, 512u)];
+          }
+        }
+      }
+    } else {  // 5, 6, 7: scalar-cache query rows
+      cptr4 qc = (cptr4)qdesc;
+      constexpr int STEP = MODE == 7 ? 2 : 1;
+      // software pipeline: the prefix dwords of the NEXT step's rows are requested before this step's arithmetic, so a
+      // scalar load has a whole step (x the other waves of the SIMD) to return
+      u32x4 n0[STEP], n1[STEP];
+      u32x2 n2[STEP];
+#pragma unroll
+      for (int u = 0; u < STEP; ++u) {
+        n0[u] = qc[u * 4 + 0], n1[u] = qc[u * 4 + 1];
+        n2[u] = *(cptr2)(qc + u * 4 + 2);
+      }
+#pragma unroll 2
+      for (uint32_t j = 0; j + STEP <= nq; j += STEP) {
+        uint32_t acc[STEP];
+        uint32_t q[STEP][NW];
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+          const uint32_t t[NW] = {n0[u].x, n0[u].y, n0[u].z, n0[u].w, n1[u].x, n1[u].y, n1[u].z, n1[u].w, n2[u].x, n2[u].y};
+#pragma unroll
+          for (int k = 0; k < NW; ++k) q[u][k] = t[k];
+        }
+        const uint32_t jn = (j + 2 * STEP <= nq) ? j + STEP : j;   // the last step re-requests its own rows
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+          n0[u] = qc[(jn + u) * 4 + 0], n1[u] = qc[(jn + u) * 4 + 1];
+          n2[u] = *(cptr2)(qc + (jn + u) * 4 + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+          uint32_t a = 0;
+#pragma unroll
+          for (int k = 0; k < NW; ++k) a += __builtin_popcount(b[k] ^ q[u][k]);
+          acc[u] = a;
+        }
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) any = any || (acc[u] < T);
+        if (__any(any)) {
+#pragma unroll
+          for (int u = 0; u < STEP; ++u) {
+            if (STEP == 1 || __any(acc[u] < T)) {
+              ++nfin;
+              const u32x2 q2 = *((cptr2)(qc + (j + u) * 4 + 2) + 1);
+              const u32x4 q3 = qc[(j + u) * 4 + 3];
+              const uint32_t qq[6] = {q2.x, q2.y, q3.x, q3.y, q3.z, q3.w};
+              uint32_t a = acc[u];
+#pragma unroll
+              for (int k = 0; k < 6; ++k) a += __builtin_popcount(b[NW + k] ^ qq[k]);
+              top2_push(best0, best1, (a << 16) | (j + u));
+              if (MODE >= 6) T = (uint32_t)cnt_s[min(best1 >> 16, 512u)];
+            }
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+  out[blockIdx.x * blockDim.x + threadIdx.x] = best0 ^ best1 ^ a0 ^ a1 ^ a2 ^ a3 ^ nfin ^ T;
+  if (lane == 0) {
+    const uint32_t w = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    stamps[3 * w] = t1 - t0;
+    stamps[3 * w + 1] = r1 - r0;
+    stamps[3 * w + 2] = nfin;
+  }
+}
+
+template <int MODE>
+void run(const char *name, int cus, const uint4 *d_q, uint32_t nq, uint32_t thr, const uint16_t *d_cnt, uint32_t *d_out,
+         unsigned long long *d_st, double valu_per_pair, double valu_per_finish) {
+  const int reps = 6;
+  const int blocks = cus * 4;
+  const size_t lds = 40 * 1024;  // 4 workgroups per CU exactly (160 KiB): 8 waves per SIMD, nothing queued
+  auto kern = k_ladder<MODE>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, 0, d_q, nq, thr, 1, d_cnt, d_out, d_st);  // warm
+  float best = 1e9f;
+  for (int it = 0; it < 3; ++it) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, 0, d_q, nq, thr, reps, d_cnt, d_out, d_st);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+  }
+  const int n_waves = blocks * WAVES;
+  std::vector<unsigned long long> st(3 * (size_t)n_waves);
+  CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> cyc, clk;
+  double fin = 0;
+  for (int w = 0; w < n_waves; ++w) {
+    cyc.push_back((double)st[3 * w]);
+    clk.push_back((double)st[3 * w] / ((double)st[3 * w + 1] * 10.0));
+    fin += (double)st[3 * w + 2];
+  }
+  std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+  const double pairs_per_wave = (double)nq * reps;
+  const double fin_frac = fin / ((double)n_waves * pairs_per_wave);
+  const double insts = valu_per_pair + fin_frac * valu_per_finish;       // VALU wave-instructions per pair
+  const double clock = clk[clk.size() / 2];
+  const double cyc_stamp = cyc[cyc.size() / 2] / pairs_per_wave / 8.0;   // per pair per SIMD (8 waves share a SIMD)
+  const double cyc_wall = best * 1e-3 * clock * 1e9 / pairs_per_wave / 8.0;
+  printf("{\"rung\": \"%s\", \"ms\": %.3f, \"clock_ghz\": %.3f, \"finished_frac\": %.4f, \"valu_per_pair\": %.2f, "
+         "\"cycles_per_pair_per_simd_stamps\": %.2f, \"cycles_per_pair_per_simd_wall\": %.2f, "
+         "\"cycles_per_valu_inst_stamps\": %.3f, \"cycles_per_valu_inst_wall\": %.3f, \"T_lane_ops_per_s_wall\": %.2f, "
+         "\"stamp_spread_p5_p95\": [%.0f, %.0f]}\n",
+         name, best, clock, fin_frac, insts, cyc_stamp, cyc_wall, cyc_stamp / insts, cyc_wall / insts,
+         (double)n_waves * 64 * pairs_per_wave * insts / (best * 1e-3) / 1e12, cyc[cyc.size() / 20], cyc[cyc.size() * 19 / 20]);
+  fflush(stdout);
+}
+
+int main() {
+  hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+  const int cus = p.multiProcessorCount;
+  const uint32_t nq = 2048;
+  std::vector<uint32_t> hq((size_t)nq * 16);
+  uint64_t s = 88172645463325252ull;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 16); };
+  for (auto &v : hq) v = rnd();
+  std::vector<uint16_t> cnt(513);
+  for (int d1 = 0; d1 <= 512; ++d1) { int c = 0; for (int d0 = 0; d0 <= 512; ++d0) if ((float)d0 / (float)d1 < 0.6f) c = d0 + 1; cnt[d1] = (uint16_t)c; }
+  uint4 *d_q; uint16_t *d_cnt; uint32_t *d_out; unsigned long long *d_st;
+  CK(hipMalloc(&d_q, hq.size() * 4 + 4096)); CK(hipMalloc(&d_cnt, 513 * 2 + 64));
+  CK(hipMalloc(&d_out, (size_t)cus * 4 * WAVES * 64 * 4)); CK(hipMalloc(&d_st, (size_t)cus * 4 * WAVES * 3 * 8));
+  CK(hipMemcpy(d_q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_cnt, cnt.data(), 513 * 2, hipMemcpyHostToDevice));
+  // threshold of the production kernel on uniform random bits: second-nearest of 64 exact rows ~ 233 -> ratio_cnt ~ 139
+  const uint32_t thr = 139;
+  // VALU wave-instructions per pair, counted from the loops above
+  run<0>("0 mix (4 accumulators)", cus, d_q, nq, 0, d_cnt, d_out, d_st, 2 * NW + 3, 0);
+  run<1>("1 one accumulator chain", cus, d_q, nq, 0, d_cnt, d_out, d_st, 2 * NW + 2, 0);
+  run<2>("2 + vote (never taken)", cus, d_q, nq, 0, d_cnt, d_out, d_st, 2 * NW + 2, 0);
+  run<3>("3 lds rows, vote never taken", cus, d_q, nq, 0, d_cnt, d_out, d_st, 2 * NW + 1, 0);
+  run<4>("4 lds rows + finish", cus, d_q, nq, thr, d_cnt, d_out, d_st, 2 * NW + 1, 12 + 5);
+  run<5>("5 smem rows, vote never taken", cus, d_q, nq, 0, d_cnt, d_out, d_st, 2 * NW + 1, 0);
+  run<6>("6 smem rows + finish", cus, d_q, nq, thr, d_cnt, d_out, d_st, 2 * NW + 1, 12 + 5);
+  run<7>("7 smem rows, two per vote + finish", cus, d_q, nq, thr, d_cnt, d_out, d_st, 2 * NW + 1.5, 12 + 6);
+  return 0;
+}

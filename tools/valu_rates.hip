@@ -1,7 +1,10 @@
 // Per-instruction issue cost of the integer VALU ops K1 is made of, on gfx950.
 // One kernel per instruction mix; each wave runs a long unrolled loop of independent chains and stamps
 // s_memtime (shader clock) and s_memrealtime (100 MHz) around it.  Prints cycles per wave-instruction at
-// 1, 2 and 4 waves per SIMD and the clock the chip held.
+// 1, 2, 4 and 8 waves per SIMD and the clock the chip held.  The grid is persistent and exactly balanced: every
+// workgroup (4 waves = one per SIMD) asks for 160 KiB / w of LDS, so a CU takes exactly w of them and the grid is
+// w x CUs -- in-kernel stamps and wall time then describe the same thing (round 1 measured at <= 4 waves per SIMD on
+// whatever placement the dispatcher chose, and its wall-time column under-read the ceiling).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,6 +34,10 @@ __global__ __launch_bounds__(256) void k_mix(uint32_t *out, unsigned long long *
     } else if (MIX == 2) {  // xor then bcnt (the K1 pair), 4 chains
       REP8(asm volatile("v_xor_b32 %4, %8, %4\n\tv_bcnt_u32_b32 %0, %4, %0\n\tv_xor_b32 %5, %8, %5\n\tv_bcnt_u32_b32 %1, %5, %1\n\t"
                         "v_xor_b32 %6, %8, %6\n\tv_bcnt_u32_b32 %2, %6, %2\n\tv_xor_b32 %7, %8, %7\n\tv_bcnt_u32_b32 %3, %7, %3"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(q));)
+    } else if (MIX == 10) {  // xor + bcnt, software pipelined: a bcnt never reads the xor issued right before it
+      REP8(asm volatile("v_xor_b32 %4, %8, %4\n\tv_xor_b32 %5, %8, %5\n\tv_bcnt_u32_b32 %0, %6, %0\n\tv_bcnt_u32_b32 %1, %7, %1\n\t"
+                        "v_xor_b32 %6, %8, %6\n\tv_xor_b32 %7, %8, %7\n\tv_bcnt_u32_b32 %2, %4, %2\n\tv_bcnt_u32_b32 %3, %5, %3"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(q));)
     } else if (MIX == 3) {  // v_med3_u32
       REP8(asm volatile("v_med3_u32 %0, %8, %0, %1\n\tv_med3_u32 %1, %8, %1, %2\n\tv_med3_u32 %2, %8, %2, %3\n\tv_med3_u32 %3, %8, %3, %4\n\t"
@@ -76,13 +83,15 @@ template <int MIX>
 void run(const char *name, int cus, uint32_t *d_out, unsigned long long *d_st) {
   const int iters = 2000;
   const int insts_per_iter = 64;
-  for (int wps : {1, 2, 4}) {
+  for (int wps : {1, 2, 4, 8}) {
     const int wg_per_cu = wps;  // 256 threads = 4 waves = 1 per SIMD
     const int n_waves = cus * wg_per_cu * 4;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_mix<MIX>, dim3(cus * wg_per_cu), dim3(256), 0, 0, d_out, d_st, 1u, 200);  // warm
+    const size_t lds = (size_t)(160 * 1024 / wps) & ~(size_t)1023;  // exactly wps workgroups fit a CU
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mix<MIX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_mix<MIX>, dim3(cus * wg_per_cu), dim3(256), lds, 0, d_out, d_st, 1u, 200);  // warm
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_mix<MIX>, dim3(cus * wg_per_cu), dim3(256), 0, 0, d_out, d_st, 7u, iters);
+    hipLaunchKernelGGL(k_mix<MIX>, dim3(cus * wg_per_cu), dim3(256), lds, 0, d_out, d_st, 7u, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> st(2 * n_waves);
@@ -101,11 +110,12 @@ int main() {
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
   const int cus = p.multiProcessorCount;
   uint32_t *d_out; unsigned long long *d_st;
-  CK(hipMalloc(&d_out, (size_t)cus * 4 * 256 * 4)); CK(hipMalloc(&d_st, (size_t)cus * 4 * 4 * 2 * 8));
+  CK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * 4)); CK(hipMalloc(&d_st, (size_t)cus * 8 * 4 * 2 * 8));
   run<0>("v_xor_b32", cus, d_out, d_st);
   run<1>("v_bcnt_u32_b32", cus, d_out, d_st);
   run<2>("xor+bcnt", cus, d_out, d_st);
   run<6>("xor(sgpr)+bcnt", cus, d_out, d_st);
+  run<10>("xor+bcnt (pipelined)", cus, d_out, d_st);
   run<3>("v_med3_u32", cus, d_out, d_st);
   run<4>("v_min_u32", cus, d_out, d_st);
   run<5>("v_lshl_or_b32", cus, d_out, d_st);
