@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--bow-knn", type=int, default=100,
                     help="views shortlisted per query by BoW distance (BASELINE configs[2]); 0 = every view is "
                          "scanned (configs[1] with --views 1000)")
-    ap.add_argument("--queries", type=int, default=16, help="distinct synthetic queries cycled through")
+    ap.add_argument("--queries", type=int, default=64, help="distinct synthetic queries cycled through")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="queries in flight per GPU (contexts); 0 = 8 with a shortlist, 4 for full scans; 1 = latency mode")
     ap.add_argument("--from-images", action="store_true",
@@ -231,7 +231,8 @@ def main():
     sharded_mode = world > 1 or forced
     # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
     # (so does the image-in mode: a context and an extractor stream per worker)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, 2 * nctx if (sharded_mode or a.from_images) else nctx))))
+    # (+2: the map's own stream and torch's; measured: 8 contexts on 8 queues lose 20 % to two streams sharing one)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, (2 * nctx if (sharded_mode or a.from_images) else nctx) + 2))))
 
     import numpy as np
     sys.path.insert(0, ROOT)

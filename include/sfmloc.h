@@ -324,6 +324,23 @@ int sfmloc_shard_begin_bow(sfmloc_context *ctx, sfmloc_query *q, const void *key
 int sfmloc_merge_begin(sfmloc_context *ctx, sfmloc_query *q, const void *parts_dev, uint32_t n_parts, uint32_t cap,
                        uint64_t part_stride);
 /* ... then sfmloc_localize_end(ctx, ...) */
+/* The exchange of a whole BATCH in one buffer per shard ("packed part"): header {u32 total, n_queries, budget, flags},
+ * u32 count[n_queries], u32 offset[n_queries], then (16-byte aligned) the candidates of all the batch's queries back
+ * to back -- a shard sends what it found (a few MB per 256-query batch) instead of n_queries fixed-capacity parts.
+ *   sfmloc_packed_bytes(n_queries, budget)   size of one packed part holding up to `budget` candidates in all;
+ *   sfmloc_shard_export_packed               appends the context's candidates (after sfmloc_shard_begin[_bow]) as query
+ *                                            `query_index` of the batch; the caller zeroes the first 16 bytes of
+ *                                            packed_dev before the batch's first export.  When the budget does not
+ *                                            suffice the query is recorded empty, flags |= 1, and `total` still counts
+ *                                            every candidate: after the all-gather every rank sees total > budget and
+ *                                            repeats the batch with a larger budget;
+ *   sfmloc_merge_begin_packed                sfmloc_merge_begin over the gathered packed parts (part p at packed_dev +
+ *                                            p*part_stride; 0 = back to back) for the batch's query `query_index`. */
+uint64_t sfmloc_packed_bytes(uint32_t n_queries, uint32_t budget);
+int sfmloc_shard_export_packed(sfmloc_context *ctx, void *packed_dev, uint32_t n_queries, uint32_t budget,
+                               uint32_t query_index);
+int sfmloc_merge_begin_packed(sfmloc_context *ctx, sfmloc_query *q, const void *packed_dev, uint32_t n_parts,
+                              uint64_t part_stride, uint32_t n_queries, uint32_t budget, uint32_t query_index);
 
 /* ------------------------------------------------------------------------- */
 /* Stage A5: bag-of-words view shortlist.                                        */

@@ -116,7 +116,7 @@ SYMBOLS = [
     "sfmloc_undistorter_create", "sfmloc_undistorter_destroy", "sfmloc_undistorter_info", "sfmloc_undistorter_maps",
     "sfmloc_undistorter_apply",
     "sfmloc_query_set_bow", "sfmloc_context_signal", "sfmloc_context_wait", "sfmloc_shard_bow_keys",
-    "sfmloc_shard_begin_bow",
+    "sfmloc_shard_begin_bow", "sfmloc_packed_bytes", "sfmloc_shard_export_packed", "sfmloc_merge_begin_packed",
 ]
 
 _bound = False
@@ -209,6 +209,11 @@ def _L():
         L.sfmloc_context_wait.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_shard_bow_keys.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
         L.sfmloc_shard_begin_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32]
+        L.sfmloc_packed_bytes.restype = C.c_uint64
+        L.sfmloc_packed_bytes.argtypes = [C.c_uint32, C.c_uint32]
+        L.sfmloc_shard_export_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.sfmloc_merge_begin_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32,
+                                                C.c_uint32, C.c_uint32]
         _bound = True
     return L
 
@@ -232,6 +237,10 @@ def _sel(view_sel):
 
 def device_count():
     return int(_L().sfmloc_device_count())
+
+
+def packed_bytes(n_queries, budget):
+    return int(_L().sfmloc_packed_bytes(n_queries, budget))
 
 
 def part_bytes(cap):
@@ -879,6 +888,13 @@ class Context:
         candidate emission, all on the device."""
         _check(_L().sfmloc_shard_begin_bow(self._h, q._h, C.c_void_p(keys_dev_ptr), int(n_parts),
                                            int(part_stride_keys), int(knn)))
+
+    def shard_export_packed(self, packed_dev_ptr, n_queries, budget, query_index):
+        _check(_L().sfmloc_shard_export_packed(self._h, C.c_void_p(packed_dev_ptr), n_queries, budget, query_index))
+
+    def merge_begin_packed(self, q, packed_dev_ptr, n_parts, n_queries, budget, query_index, part_stride=0):
+        _check(_L().sfmloc_merge_begin_packed(self._h, q._h, C.c_void_p(packed_dev_ptr), n_parts, part_stride, n_queries,
+                                              budget, query_index))
 
     def signal(self, hip_stream=0):
         """sfmloc_context_signal: `hip_stream` (a hipStream_t as an integer) waits for this context's queued work."""

@@ -878,35 +878,63 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
 // A "part" is what one shard contributes for one query: 16-byte header {u32 n_cand, pad} + cap candidates.
 // The selection kernels run over n_parts parts laid out back to back (n_parts = 1 on a single GPU; after the
 // all-gather it is the number of shards).  Candidate c of part p has the global index p*cap + c.
-__device__ __forceinline__ const Candidate *part_cands(const unsigned char *parts, uint64_t part_bytes, uint32_t p) {
-  return reinterpret_cast<const Candidate *>(parts + (uint64_t)p * part_bytes + kPartHeaderBytes);
+//
+// PACKED parts (the multi-GPU exchange, sfmloc_shard_export_packed): one buffer per shard for a whole batch of B
+// queries -- header {u32 total, n_queries, budget, flags}, u32 count[B], u32 offset[B], then (16-byte aligned) the
+// candidates of all B queries back to back in arrival order; query i's are [offset[i], offset[i] + count[i]).  The
+// kernels address a candidate of part p as p*cap + c with cap = the budget and c counted from the start of the
+// buffer's candidate area, so the two layouts differ only in where a part's range lies.
+struct PartLayout {
+  uint32_t packed_b;  // 0 = plain part; else B of the packed layout
+  uint32_t qi;        // query index inside the packed batch
+};
+__host__ __device__ __forceinline__ uint64_t packed_cands_offset(uint32_t n_queries) {
+  return (16ull + 8ull * n_queries + 15ull) & ~15ull;
 }
-__device__ __forceinline__ uint32_t part_count(const unsigned char *parts, uint64_t part_bytes, uint32_t p,
-                                               uint32_t cap) {
-  return min(*reinterpret_cast<const uint32_t *>(parts + (uint64_t)p * part_bytes), cap);
+__device__ __forceinline__ const Candidate *part_cands(const unsigned char *parts, uint64_t part_bytes, uint32_t p,
+                                                       PartLayout L) {
+  return reinterpret_cast<const Candidate *>(parts + (uint64_t)p * part_bytes +
+                                             (L.packed_b ? packed_cands_offset(L.packed_b) : (uint64_t)kPartHeaderBytes));
+}
+// candidates [c0, c1) of part p belong to this query
+__device__ __forceinline__ void part_range(const unsigned char *parts, uint64_t part_bytes, uint32_t p, uint32_t cap,
+                                           PartLayout L, uint32_t *c0, uint32_t *c1) {
+  const uint32_t *h = reinterpret_cast<const uint32_t *>(parts + (uint64_t)p * part_bytes);
+  if (L.packed_b) {
+    const uint32_t n = h[4 + L.qi], off = h[4 + L.packed_b + L.qi];
+    *c0 = min(off, cap);
+    *c1 = min(off + n, cap);
+  } else {
+    *c0 = 0;
+    *c1 = min(h[0], cap);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_candidates_min(const unsigned char *parts, uint32_t n_parts,
                                                         uint64_t part_bytes, uint32_t cap, uint32_t nq,
-                                                        unsigned long long *best, int *status) {
+                                                        unsigned long long *best, int *status, PartLayout L) {
   for (uint32_t p = blockIdx.y; p < n_parts; p += gridDim.y) {
-    const Candidate *cand = part_cands(parts, part_bytes, p);
-    const uint32_t n = part_count(parts, part_bytes, p, cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0 &&
-        *reinterpret_cast<const uint32_t *>(parts + (uint64_t)p * part_bytes) > cap)
-      atomicOr(status, 2);  // a shard produced more candidates than its part holds
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+    const Candidate *cand = part_cands(parts, part_bytes, p, L);
+    uint32_t c0, c1;
+    part_range(parts, part_bytes, p, cap, L, &c0, &c1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const uint32_t *h = reinterpret_cast<const uint32_t *>(parts + (uint64_t)p * part_bytes);
+      // a shard produced more candidates than its part holds (packed: than the batch's budget, or than a context holds)
+      if (L.packed_b ? (h[0] > cap || h[3] != 0) : (h[0] > cap)) atomicOr(status, 2);
+    }
+    for (uint32_t c = c0 + blockIdx.x * blockDim.x + threadIdx.x; c < c1; c += gridDim.x * blockDim.x)
       if (cand[c].qfeat < nq) atomicMin(&best[cand[c].qfeat], (unsigned long long)cand[c].order);
   }
 }
 
 __global__ __launch_bounds__(256) void k_candidates_win(const unsigned char *parts, uint32_t n_parts,
                                                         uint64_t part_bytes, uint32_t cap, uint32_t nq,
-                                                        const unsigned long long *best, uint32_t *winner) {
+                                                        const unsigned long long *best, uint32_t *winner, PartLayout L) {
   for (uint32_t p = blockIdx.y; p < n_parts; p += gridDim.y) {
-    const Candidate *cand = part_cands(parts, part_bytes, p);
-    const uint32_t n = part_count(parts, part_bytes, p, cap);
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+    const Candidate *cand = part_cands(parts, part_bytes, p, L);
+    uint32_t c0, c1;
+    part_range(parts, part_bytes, p, cap, L, &c0, &c1);
+    for (uint32_t c = c0 + blockIdx.x * blockDim.x + threadIdx.x; c < c1; c += gridDim.x * blockDim.x)
       if (cand[c].qfeat < nq && best[cand[c].qfeat] == (unsigned long long)cand[c].order)
         winner[cand[c].qfeat] = p * cap + c;
   }
@@ -919,7 +947,7 @@ __global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *
                                                           const uint32_t *winner, uint32_t nq, const float2 *q_kpt,
                                                           uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
                                                           double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
-                                                          double ppy, double k1, double k2, double k3) {
+                                                          double ppy, double k1, double k2, double k3, PartLayout L) {
   // one workgroup; winners are compacted in query-feature order, 1024 features per pass (a pass is a chain of
   // dependent loads, so fewer, wider passes)
   __shared__ uint32_t wave_cnt[16];
@@ -938,7 +966,7 @@ __global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *
     if (has) {
       const uint32_t pos = pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       const uint32_t w = winner[j];
-      const Candidate c = part_cands(parts, part_bytes, w / cap)[w % cap];
+      const Candidate c = part_cands(parts, part_bytes, w / cap, L)[w % cap];
       ms_qfeat[pos] = j;
       ms_landmark[pos] = c.landmark_id;
       const float2 kp = q_kpt[j];
@@ -1678,8 +1706,50 @@ int launch_export_part(Ctx *c, void *dst_dev, uint32_t cap) {
   return SFMLOC_OK;
 }
 
+// a context's candidates appended to a batch's packed part (layout: PartLayout above).  One workgroup: lane 0 claims
+// [off, off + n) of the candidate area with one atomic on the header's running total, then everybody copies.
+__global__ __launch_bounds__(256) void k_export_packed(const unsigned char *__restrict__ src, uint32_t src_cap,
+                                                       unsigned char *__restrict__ dst, uint32_t n_queries,
+                                                       uint32_t budget, uint32_t qi) {
+  __shared__ uint32_t s_off, s_n;
+  uint32_t *h = reinterpret_cast<uint32_t *>(dst);
+  if (threadIdx.x == 0) {
+    const uint32_t n_true = *reinterpret_cast<const uint32_t *>(src);
+    const uint32_t n = min(n_true, src_cap);
+    if (n_true > src_cap) atomicOr(&h[3], 2u);      // the context itself overflowed: candidates are lost
+    const uint32_t off = atomicAdd(&h[0], n);       // the total keeps counting past the budget: every rank sees by how much
+    const bool fits = (uint64_t)off + n <= budget;
+    if (!fits) atomicOr(&h[3], 1u);
+    h[1] = n_queries;
+    h[2] = budget;
+    h[4 + qi] = fits ? n : 0u;
+    h[4 + n_queries + qi] = fits ? off : 0u;
+    s_off = off;
+    s_n = fits ? n : 0u;
+  }
+  __syncthreads();
+  const uint2 *s8 = reinterpret_cast<const uint2 *>(src + kPartHeaderBytes);
+  uint2 *d8 = reinterpret_cast<uint2 *>(dst + packed_cands_offset(n_queries) + (uint64_t)s_off * sizeof(Candidate));
+  const uint64_t words = (uint64_t)s_n * (sizeof(Candidate) / 8);
+  for (uint64_t i = threadIdx.x; i < words; i += blockDim.x) d8[i] = s8[i];
+}
+
+uint64_t packed_part_bytes(uint32_t n_queries, uint32_t budget) {
+  return packed_cands_offset(n_queries) + (uint64_t)budget * sizeof(Candidate);
+}
+
+int launch_export_packed(Ctx *c, void *dst_dev, uint32_t n_queries, uint32_t budget, uint32_t qi) {
+  hipLaunchKernelGGL(k_export_packed, dim3(1), dim3(256), 0, c->stream, c->d_cand_part, c->cand_cap,
+                     reinterpret_cast<unsigned char *>(dst_dev), n_queries, budget, qi);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
-                             uint64_t part_bytes, uint32_t cap) {
+                             uint64_t part_bytes, uint32_t cap, uint32_t packed_b, uint32_t packed_qi) {
+  PartLayout L;
+  L.packed_b = packed_b;
+  L.qi = packed_qi;
   if (!c->cleared) {
     SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
     SFM_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
@@ -1687,15 +1757,15 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
   if (q->n == 0 || n_parts == 0) return SFMLOC_OK;
   const dim3 grid(16, n_parts < 64 ? n_parts : 64);
   hipLaunchKernelGGL(k_candidates_min, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
-                     c->d_best64, c->d_status);
+                     c->d_best64, c->d_status, L);
   SFM_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_candidates_win, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
-                     c->d_best64, c->d_winner);
+                     c->d_best64, c->d_winner, L);
   SFM_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(1024), 0, c->stream, parts, part_bytes, cap, c->d_best64,
                      c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d,
                      c->map->intrinsic_type == 3 ? 1 : 0, c->map->focal, c->map->ppx, c->map->ppy, c->map->k1, c->map->k2,
-                     c->map->k3);
+                     c->map->k3, L);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -1214,8 +1214,38 @@ int sfmloc_context_sync(sfmloc_context *ctx) {
   return SFMLOC_OK;
 }
 
+uint64_t sfmloc_packed_bytes(uint32_t n_queries, uint32_t budget) { return packed_part_bytes(n_queries, budget); }
+
+int sfmloc_shard_export_packed(sfmloc_context *ctx, void *packed_dev, uint32_t n_queries, uint32_t budget,
+                               uint32_t query_index) {
+  SFM_CHECK(ctx && packed_dev && n_queries > 0 && query_index < n_queries, SFMLOC_EINVAL,
+            "sfmloc_shard_export_packed: bad argument");
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  SFM_HIP(hipSetDevice(c->map->device));
+  return launch_export_packed(c, packed_dev, n_queries, budget, query_index);
+}
+
+static int merge_begin_impl(sfmloc_context *ctx, sfmloc_query *query, const void *parts_dev, uint32_t n_parts,
+                            uint32_t cap, uint64_t part_stride, uint32_t packed_b, uint32_t packed_qi);
+
 int sfmloc_merge_begin(sfmloc_context *ctx, sfmloc_query *query, const void *parts_dev, uint32_t n_parts,
                        uint32_t cap, uint64_t part_stride) {
+  return merge_begin_impl(ctx, query, parts_dev, n_parts, cap, part_stride, 0, 0);
+}
+
+int sfmloc_merge_begin_packed(sfmloc_context *ctx, sfmloc_query *query, const void *packed_dev, uint32_t n_parts,
+                              uint64_t part_stride, uint32_t n_queries, uint32_t budget, uint32_t query_index) {
+  SFM_CHECK(n_queries > 0 && query_index < n_queries && budget > 0, SFMLOC_EINVAL,
+            "sfmloc_merge_begin_packed: bad argument");
+  if (part_stride == 0) part_stride = packed_part_bytes(n_queries, budget);
+  SFM_CHECK(part_stride >= packed_part_bytes(n_queries, budget), SFMLOC_EINVAL,
+            "sfmloc_merge_begin_packed: part_stride too small");
+  SFM_CHECK((uint64_t)n_parts * budget < (1ull << 32), SFMLOC_EINVAL, "sfmloc_merge_begin_packed: n_parts * budget >= 2^32");
+  return merge_begin_impl(ctx, query, packed_dev, n_parts, budget, part_stride, n_queries, query_index);
+}
+
+static int merge_begin_impl(sfmloc_context *ctx, sfmloc_query *query, const void *parts_dev, uint32_t n_parts,
+                            uint32_t cap, uint64_t part_stride, uint32_t packed_b, uint32_t packed_qi) {
   SFM_CHECK(ctx && query && parts_dev && n_parts > 0 && cap > 0, SFMLOC_EINVAL, "sfmloc_merge_begin: bad argument");
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   Query *q = reinterpret_cast<Query *>(query);
@@ -1231,8 +1261,9 @@ int sfmloc_merge_begin(sfmloc_context *ctx, sfmloc_query *query, const void *par
   {
     EventScope ev(c, SFMLOC_K_MATCHSET);
     if (part_stride == 0) part_stride = sfmloc_part_bytes(cap);
-    SFM_CHECK(part_stride >= sfmloc_part_bytes(cap), SFMLOC_EINVAL, "sfmloc_merge_begin: part_stride too small");
-    rc = launch_select_candidates(c, q, reinterpret_cast<const unsigned char *>(parts_dev), n_parts, part_stride, cap);
+    SFM_CHECK(packed_b || part_stride >= sfmloc_part_bytes(cap), SFMLOC_EINVAL, "sfmloc_merge_begin: part_stride too small");
+    rc = launch_select_candidates(c, q, reinterpret_cast<const unsigned char *>(parts_dev), n_parts, part_stride, cap,
+                                  packed_b, packed_qi);
   }
   if (rc) return rc;
   {

@@ -273,8 +273,12 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
 int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
 int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
 int launch_export_part(Ctx *c, void *dst_dev, uint32_t cap);
+// packed_b > 0: `parts` are packed batch parts of packed_b queries (acransac.hip PartLayout), cap = their budget,
+// and this query is number packed_qi of the batch
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
-                             uint64_t part_bytes, uint32_t cap);
+                             uint64_t part_bytes, uint32_t cap, uint32_t packed_b = 0, uint32_t packed_qi = 0);
+int launch_export_packed(Ctx *c, void *dst_dev, uint32_t n_queries, uint32_t budget, uint32_t qi);
+uint64_t packed_part_bytes(uint32_t n_queries, uint32_t budget);
 int launch_p3p_init(Ctx *c);
 int launch_p3p_round(Ctx *c, int batch);
 

@@ -106,30 +106,71 @@ def select_from_keys(gathered_keys, k, local_view_id):
     return np.nonzero(np.isin(np.asarray(local_view_id, np.int64), ids))[0].astype(np.uint32)
 
 
-class ShardedLocalizer:
-    """One batch = (optional) sharded BoW shortlist -> stage 1 on every shard -> ONE all-gather of candidate parts ->
-    stage 2 (2D-3D selection + P3P) of query i on rank i mod world.
+def packed_cands_offset(n_queries):
+    return (16 + 8 * n_queries + 15) // 16 * 16
 
-    The exchange sends `cap` candidates per (query, shard) (512: a shard typically holds a few hundred); every rank
-    sees every part header after the gather, so all ranks agree -- without another collective -- when some shard had
-    more, and the batch is then exchanged again at `cap_full`.
+
+def packed_bytes(n_queries, budget):
+    """One shard's exchange buffer for a batch (the C ABI's sfmloc_packed_bytes): header {u32 total, n_queries, budget,
+    flags}, u32 count[B], u32 offset[B], then the candidates of all B queries back to back."""
+    return packed_cands_offset(n_queries) + budget * CANDIDATE_DTYPE.itemsize
+
+
+def pack_batch(cands_list, budget):
+    """Host restatement of sfmloc_shard_export_packed over a whole batch (tests, CPU stand-ins)."""
+    B = len(cands_list)
+    buf = np.zeros(packed_bytes(B, budget), np.uint8)
+    hdr = buf[:16 + 8 * B].view(np.uint32)
+    base = packed_cands_offset(B)
+    off = 0
+    for i, c in enumerate(cands_list):
+        n = len(c)
+        fits = off + n <= budget
+        if fits:
+            hdr[4 + i], hdr[4 + B + i] = n, off
+            if n:
+                buf[base + off * 40: base + (off + n) * 40] = np.frombuffer(np.ascontiguousarray(c).tobytes(), np.uint8)
+        else:
+            hdr[3] |= 1
+        off += n
+    hdr[0], hdr[1], hdr[2] = off, B, budget
+    return buf
+
+
+def unpack_batch(buf, qi):
+    """Candidates of query qi in one shard's packed part."""
+    buf = np.ascontiguousarray(buf, np.uint8)
+    B = int(buf[4:8].view(np.uint32)[0])
+    hdr = buf[:16 + 8 * B].view(np.uint32)
+    n, off = int(hdr[4 + qi]), int(hdr[4 + B + qi])
+    base = packed_cands_offset(B)
+    return np.frombuffer(buf[base + off * 40: base + (off + n) * 40].tobytes(), CANDIDATE_DTYPE)
+
+
+class ShardedLocalizer:
+    """One batch = (optional) sharded BoW shortlist -> stage 1 on every shard -> ONE all-gather of the shards' packed
+    candidate parts -> stage 2 (2D-3D selection + P3P) of query i on rank i mod world.
+
+    A shard sends what it found: one packed part per batch holding up to `budget` = B x budget_per_query candidates
+    (a few MB for 256 queries) instead of B fixed-capacity parts.  Every rank sees every part header after the gather,
+    so all ranks agree -- without another collective -- when some shard needed more, and the batch is exchanged again
+    with a budget that fits (and the larger budget is kept for the batches that follow).
 
     compute protocol (HipShardCompute below; the CPU tests plug in a stand-in built on the oracle):
-      stage1(queries, slot, cap) -> uint8 [B, part_bytes(cap)] on compute.device (possibly still being written)
+      stage1(queries, slot, budget) -> uint8 [packed_bytes(B, budget)] on compute.device (possibly still being written)
       bow_keys(queries, knn, slot) -> int64 [B, knn] (u64 bit patterns)        } only for bow_knn > 0
-      stage1_bow(queries, gathered_keys [world, B, knn], knn, slot, cap)        }
+      stage1_bow(queries, gathered_keys [world, B, knn], knn, slot, budget)     }
       before_collective(slot) / after_collective(slot): order the slot's streams against the collective's (optional)
-      stage2(indices, gathered [world, B, part_bytes(cap)], slot, cap) -> {index: result} for the queries owned here.
+      stage2(indices, gathered [world, packed_bytes(B, budget)], slot, budget) -> {index: result} for the queries owned here.
     A compute object with `n_slots >= 2` lets two batches overlap (localize_stream)."""
 
-    def __init__(self, compute, cap=512, rank=None, world=None, group=None, always_gather=False, cap_full=None,
+    def __init__(self, compute, budget_per_query=256, rank=None, world=None, group=None, always_gather=False,
                  n_views_global=None):
         import torch.distributed as dist
         self.dist = dist
         self.always_gather = always_gather   # run the collective even on one rank (rehearsal of the N>1 path)
         self.compute = compute
-        self.cap = cap
-        self.cap_full = max(cap, cap_full if cap_full is not None else getattr(compute, "cap_full", cap))
+        self.budget_per_query = int(budget_per_query)
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
@@ -140,16 +181,16 @@ class ShardedLocalizer:
     def reset_counters(self):
         self._n_batches = self._n_queries = self._n_redo = 0
         self._bytes_parts = self._bytes_keys = 0
-        self._max_count = 0
+        self._max_total = 0
 
     def counters(self):
         nb = max(1, self._n_batches)
         return {"batches": self._n_batches, "queries": self._n_queries,
                 "candidate_allgather_bytes_per_batch_per_rank": self._bytes_parts / nb,
                 "bow_key_allgather_bytes_per_batch_per_rank": self._bytes_keys / nb,
-                "exchange_cap": self.cap, "exchange_cap_full": self.cap_full,
-                "max_candidates_of_one_shard_for_one_query": int(self._max_count),
-                "batches_exchanged_again_at_full_cap": self._n_redo}
+                "budget_candidates_per_query": self.budget_per_query,
+                "max_candidates_of_one_shard_for_one_batch": int(self._max_total),
+                "batches_exchanged_again_with_a_larger_budget": self._n_redo}
 
     def owner(self, i):
         return i % self.world
@@ -159,7 +200,7 @@ class ShardedLocalizer:
         return getattr(self.compute, "comm", None)
 
     def _all_gather(self, send):
-        """send [B, ...] -> ([world, B, ...] on send's device, event) -- on the compute object's collective stream (if
+        """send [n, ...] -> ([world, n, ...] on send's device, event) -- on the compute object's collective stream (if
         any); the event marks the gather's completion on that stream (None without one)."""
         import contextlib
         import torch
@@ -198,7 +239,7 @@ class ShardedLocalizer:
             return False
         return self.n_views_global is None or self.n_views_global > bow_knn
 
-    def _stage1(self, queries, slot, cap, bow_knn=0, keys_all=None):
+    def _stage1(self, queries, slot, budget, bow_knn=0, keys_all=None):
         if self._use_bow(bow_knn):
             if keys_all is None:
                 keys = self.compute.bow_keys(queries, bow_knn, slot)
@@ -206,45 +247,47 @@ class ShardedLocalizer:
                 keys_all, _ = self._all_gather(keys)
                 self._after(slot)
                 self._bytes_keys += keys.numel() * keys.element_size()
-            parts = self.compute.stage1_bow(queries, keys_all, bow_knn, slot, cap)
+            part = self.compute.stage1_bow(queries, keys_all, bow_knn, slot, budget)
         else:
-            parts = self.compute.stage1(queries, slot, cap)
+            part = self.compute.stage1(queries, slot, budget)
         self._before(slot)
-        gathered, ev = self._all_gather(parts)
+        gathered, ev = self._all_gather(part)
         # the slot's contexts do nothing more until stage 2 of THIS batch: they wait for this gather right away, so that
         # a later batch's collectives on the same stream never stand between a batch and its own stage 2
         self._after(slot)
-        self._bytes_parts += parts.numel() * parts.element_size()
+        self._bytes_parts += part.numel() * part.element_size()
         return gathered, keys_all, ev
 
     def _begin(self, queries, slot, bow_knn=0):
-        gathered, keys_all, ev = self._stage1(queries, slot, self.cap, bow_knn)
-        return (queries, gathered, keys_all, slot, bow_knn, ev)
+        budget = len(queries) * self.budget_per_query
+        gathered, keys_all, ev = self._stage1(queries, slot, budget, bow_knn)
+        return (queries, gathered, keys_all, slot, bow_knn, ev, budget)
 
     def _finish(self, state, gather_results):
         import torch
-        queries, gathered, keys_all, slot, bow_knn, ev = state
+        queries, gathered, keys_all, slot, bow_knn, ev, budget = state
         B = len(queries)
-        cap = self.cap
-        assert gathered.dtype == torch.uint8 and tuple(gathered.shape) == (self.world, B, part_bytes(cap))
-        # every rank holds every header: the same decision everywhere, no extra collective
-        if ev is not None:
-            ev.synchronize()
-        counts = gathered[:, :, :4].contiguous().view(torch.int32)
-        mx = int(counts.max().item()) if counts.numel() else 0
-        self._max_count = max(self._max_count, mx)
-        if mx > cap:
-            if mx > self.cap_full:
-                raise OverflowError(f"a shard produced {mx} candidates for one query; parts hold at most {self.cap_full}")
-            cap = self.cap_full
-            self._n_redo += 1
-            gathered, _, ev = self._stage1(queries, slot, cap, bow_knn, keys_all)
+        assert gathered.dtype == torch.uint8 and tuple(gathered.shape) == (self.world, packed_bytes(B, budget))
+        while True:
+            # every rank holds every header: the same decision everywhere, no extra collective
             if ev is not None:
                 ev.synchronize()
+            hdr = gathered[:, :16].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            mx = int(hdr[:, 0].max()) if hdr.size else 0
+            self._max_total = max(self._max_total, mx)
+            if int(np.bitwise_or.reduce(hdr[:, 3])) & 2:
+                raise OverflowError("a shard found more 2D-3D candidates for one query than a context's part holds")
+            if mx <= budget:
+                break
+            per = -(-mx * 5 // (4 * B))                       # 25 % head room, the larger budget is kept
+            self.budget_per_query = max(self.budget_per_query, (per + 63) // 64 * 64)
+            budget = B * self.budget_per_query
+            self._n_redo += 1
+            gathered, _, ev = self._stage1(queries, slot, budget, bow_knn, keys_all)
         self._n_batches += 1
         self._n_queries += B
         mine = [i for i in range(B) if self.owner(i) == self.rank]
-        local = self.compute.stage2(mine, gathered, slot, cap)
+        local = self.compute.stage2(mine, gathered, slot, budget)
         if not gather_results or self.world == 1:
             return local
         allres = [None] * self.world
@@ -285,7 +328,6 @@ class HipShardCompute:
     the collective's stream (`comm`) are ordered by events (sfmloc_context_signal / _wait)."""
 
     n_slots = 2
-    cap_full = 16384      # candidates a context's part holds (sfmloc_internal.h Ctx::cand_cap)
 
     def __init__(self, shard_map, cap=None, n_contexts=4, device=None):
         import torch
@@ -331,52 +373,59 @@ class HipShardCompute:
             cs[i % len(cs)].shard_bow_keys(q, knn, base + i * knn * 8)
         return keys
 
-    def stage1_bow(self, queries, keys_all, knn, slot=0, cap=512):
+    def _packed(self, slot, B, budget):
+        """the slot's packed part with its header zeroed on the collective's stream, which the slot's contexts then
+        wait for (the running total must be zero before the batch's first export)"""
         import torch
+        from . import capi
+        part = self._tensor("packed", slot, (capi.packed_bytes(B, budget),), torch.uint8)
+        with torch.cuda.stream(self.comm):
+            part[:16].zero_()
+        self.after_collective(slot)
+        return part
+
+    def stage1_bow(self, queries, keys_all, knn, slot=0, budget=0):
         B = len(queries)
         world = keys_all.shape[0]
-        pb = part_bytes(cap)
-        parts = self._tensor("parts", slot, (B, pb), torch.uint8)
-        base, kbase = parts.data_ptr(), keys_all.data_ptr()
+        part = self._packed(slot, B, budget)
+        base, kbase = part.data_ptr(), keys_all.data_ptr()
         cs = self.ctxs[slot]
         for i, q in enumerate(queries):
             c = cs[i % len(cs)]
             # query i's key lists: keys_all[r, i, :] for r in range(world) -> stride B*knn keys
             c.shard_begin_bow(q, kbase + i * knn * 8, world, knn, part_stride_keys=B * knn)
-            c.shard_export(base + i * pb, cap)
+            c.shard_export_packed(base, B, budget, i)
         self._queries[slot] = queries
-        return parts
+        return part
 
-    def stage1(self, queries, slot=0, cap=512, view_sels=None):
-        import torch
+    def stage1(self, queries, slot=0, budget=0, view_sels=None):
         B = len(queries)
-        pb = part_bytes(cap)
-        parts = self._tensor("parts", slot, (B, pb), torch.uint8)
-        base = parts.data_ptr()
+        part = self._packed(slot, B, budget)
+        base = part.data_ptr()
         cs = self.ctxs[slot]
         for i, q in enumerate(queries):
             c = cs[i % len(cs)]
             # K1..K3 + candidate emission, asynchronous; view_sels[i]: this shard's views to scan
             c.shard_begin(q, None if view_sels is None else view_sels[i])
-            c.shard_export(base + i * pb, cap)  # on the same stream
+            c.shard_export_packed(base, B, budget, i)  # on the same stream
         self._queries[slot] = queries
-        return parts
+        return part
 
-    def stage2(self, indices, gathered, slot=0, cap=512):
-        world, B, pb = gathered.shape
+    def stage2(self, indices, gathered, slot=0, budget=0):
+        world, pb = gathered.shape
         base = gathered.data_ptr()
         out = {}
         cs = self.ctxs[slot]
         n = len(cs)
         queries = self._queries[slot]
+        B = len(queries)
         pending = []
         for k, i in enumerate(indices):
             c = cs[k % n]
             if k >= n:
                 j, cj = pending.pop(0)
                 out[j] = _pose_tuple(cj.end())
-            # query i's parts: gathered[r, i, :] for r in range(world) -> stride B*pb
-            c.merge_begin(queries[i], base + i * pb, world, cap, part_stride=B * pb)
+            c.merge_begin_packed(queries[i], base, world, B, budget, i, part_stride=pb)
             pending.append((i, c))
         for j, cj in pending:
             out[j] = _pose_tuple(cj.end())

@@ -23,6 +23,27 @@ def test_shard_views_balanced_and_contiguous():
     assert D.shard_views(off, 2) == [(0, 6), (6, 10)]
 
 
+def test_packed_batch_layout_roundtrip():
+    """The packed exchange buffer (one per shard and batch): counts / offsets / candidates; a budget that does not
+    suffice leaves the query empty, sets the flag and keeps counting the total."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    lists = []
+    for n in (3, 0, 5, 1):
+        c = np.zeros(n, D.CANDIDATE_DTYPE)
+        c["order"] = rng.integers(0, 1 << 60, n)
+        c["qfeat"] = rng.integers(0, 2000, n)
+        c["X"] = rng.normal(size=(n, 3))
+        lists.append(c)
+    buf = D.pack_batch(lists, 16)
+    assert len(buf) == D.packed_bytes(4, 16) == 48 + 16 * 40 and buf[:16].view(np.uint32).tolist() == [9, 4, 16, 0]
+    for i, c in enumerate(lists):
+        assert (D.unpack_batch(buf, i) == c).all()
+    small = D.pack_batch(lists, 7)
+    assert small[:16].view(np.uint32).tolist() == [9, 4, 7, 1]
+    assert (D.unpack_batch(small, 0) == lists[0]).all() and len(D.unpack_batch(small, 2)) == 0
+    assert (D.unpack_batch(small, 3) == lists[3])[:0].all()
+
+
 def test_part_layout_roundtrip():
     c = np.zeros(3, D.CANDIDATE_DTYPE)
     c["order"] = [D.order_key(12, 7, 3), D.order_key(0, 0xFFFFFF, 0), D.order_key(512, 1, 2)]
@@ -89,17 +110,14 @@ class OracleShardCompute:
         if not hasattr(self, "queries"):
             self.queries = {}
         self.queries[slot] = queries
-        rows = []
+        cands = []
         for i, q in enumerate(queries):
             kw = {} if sels is None else {"view_sel": sels[i]}
-            c = opipe.shard_candidates(self.m, q.desc, q.kpt_xy, (q.width, q.height), self.v0, self.v1, **kw)
-            buf = D.pack_part(c[:cap], cap)
-            buf[:4] = np.frombuffer(np.uint32(len(c)).tobytes(), np.uint8)    # the header keeps the true count
-            rows.append(buf)
-        return torch.from_numpy(np.stack(rows))
+            cands.append(opipe.shard_candidates(self.m, q.desc, q.kpt_xy, (q.width, q.height), self.v0, self.v1, **kw))
+        return torch.from_numpy(D.pack_batch(cands, cap))
 
-    def stage1(self, queries, slot=0, cap=None):
-        return self._parts(queries, slot, cap or self.cap)
+    def stage1(self, queries, slot=0, budget=0):
+        return self._parts(queries, slot, budget)
 
     def bow_keys(self, queries, knn, slot=0):
         """this shard's knn best (float32 L2 distance, view id) keys per query, padded with ~0"""
@@ -111,18 +129,18 @@ class OracleShardCompute:
             out[i, :len(keys)] = keys
         return torch.from_numpy(out.view(np.int64))
 
-    def stage1_bow(self, queries, keys_all, knn, slot=0, cap=None):
+    def stage1_bow(self, queries, keys_all, knn, slot=0, budget=0):
         ka = keys_all.numpy().view(np.uint64)
         ids = self.m.view_id[self.v0:self.v1]
         sels = [self.v0 + D.select_from_keys(ka[:, i, :], knn, ids) for i in range(len(queries))]
-        return self._parts(queries, slot, cap or self.cap, sels)
+        return self._parts(queries, slot, budget, sels)
 
-    def stage2(self, indices, gathered, slot=0, cap=None):
+    def stage2(self, indices, gathered, slot=0, budget=0):
         from oracle import pipeline as opipe
         g = gathered.numpy()
         out = {}
         for i in indices:
-            parts = [D.unpack_part(g[r, i], cap or self.cap) for r in range(g.shape[0])]
+            parts = [D.unpack_batch(g[r], i) for r in range(g.shape[0])]
             out[i] = opipe.merge_candidates(parts, self.queries[slot][i].kpt_xy, self.m.intrinsic)
         return out
 
@@ -138,13 +156,14 @@ def _worker(rank, world, port, q):
                            obs_per_view=90, ragged=True)
         queries = [synth.make_query(m, 700 + k, n_feat=260, n_copies=110, outlier_frac=0.2, place=k % 3) for k in range(3)]
         v0, v1 = D.shard_views(m.view_off, world)[rank]
-        loc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), cap=2048)
+        loc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), budget_per_query=2048)
         res = loc.localize_batch(queries)
-        # a small exchange capacity overflows on some shard: every rank sees it in the gathered headers and the batch
-        # is exchanged again at the full capacity -- same results
-        small = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), cap=8, cap_full=2048)
+        assert loc.counters()["batches_exchanged_again_with_a_larger_budget"] == 0
+        # a budget too small for some shard: every rank sees that shard's total in the gathered headers and the batch is
+        # exchanged again with a budget that fits -- same results
+        small = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), budget_per_query=4)
         res_small = small.localize_batch(queries)
-        assert small.counters()["batches_exchanged_again_at_full_cap"] == 1
+        assert small.counters()["batches_exchanged_again_with_a_larger_budget"] == 1 and small.budget_per_query > 4
         for k in res:
             assert res_small[k]["ok"] == res[k]["ok"] and np.array_equal(res_small[k]["ms_qfeat"], res[k]["ms_qfeat"])
         # sharded BoW shortlist (two collectives per batch): equal to shortlisting over the whole map
@@ -153,7 +172,7 @@ def _worker(rank, world, port, q):
         knn = 7
         for k, qq in enumerate(queries):
             qq.bow = m.extra["bow"][(5 * k) % m.n_views] + rng.integers(0, 2, 12).astype(np.float32)
-        bowloc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), cap=2048, n_views_global=m.n_views)
+        bowloc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), n_views_global=m.n_views)
         res_bow = bowloc.localize_batch(queries, bow_knn=knn)
         assert bowloc.counters()["bow_key_allgather_bytes_per_batch_per_rank"] == len(queries) * knn * 8
         # the pipelined form over three uneven batches must give the same per-query results
