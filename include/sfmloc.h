@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SFMLOC_ABI_VERSION 1
+#define SFMLOC_ABI_VERSION 2   /* 2: sfmloc_params.guided_matching */
 #define SFMLOC_DESC_BYTES 64          /* FileUtils.cpp:77-92: 61 M-LDB bytes + 3 zero bytes */
 #define SFMLOC_NOMATCH 0xFFFFFFFFu
 #define SFMLOC_MAX_QUERY_ROWS 65535u  /* query feature index is packed into 16 bits of the match key */
@@ -71,6 +71,10 @@ typedef struct sfmloc_params {
   int profile;              /* 1 = bracket each stage with HIP events on the handle's stream, 2 = the Hamming scan only */
   int exact_rows;           /* 1 = keep the exact (nearest, second) pair of EVERY bank row (sfmloc_putative_read_rows);
                                0 = rows the screening kernel proves rejected are not finished (same matches) */
+  int guided_matching;      /* -gm guidedMatch (localization.cpp:82,183; computeFeaturesAndMatches.cpp:63,89; the map
+                               builder's default, ReconstructParam.py:71): every pair that passes the F-matrix AC-RANSAC
+                               has its matches replaced by OpenMVG's Geometry_guided_matching under the estimated F
+                               (MatchUtils.cpp:413-415) */
 } sfmloc_params;
 
 void sfmloc_default_params(sfmloc_params *p);
@@ -216,6 +220,10 @@ int sfmloc_geometric_filter(sfmloc_map *map, sfmloc_query *q);
 /* geo_count[n_views]; geo_idx[n_rows]: view v's inliers as indices into ITS putative list, stored at
  * view_off[v], in AC-RANSAC's inlier order (ascending residual).  Synchronises. */
 int sfmloc_geometric_read(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_idx, uint64_t cap);
+/* The same stage as (map feature i, query feature j) pairs, view v's list at view_off[v]: with guided matching these ARE
+ * the result (one match per map feature, ascending i; not a subset of the putative list, so sfmloc_geometric_read
+ * refuses), without it the putative matches the indices name.  Synchronises. */
+int sfmloc_geometric_read_pairs(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_i, uint32_t *geo_j, uint64_t cap);
 
 /* ------------------------------------------------------------------------- */
 /* Stage A9+A10: 2D-3D match set.                                              */
@@ -247,7 +255,10 @@ typedef struct sfmloc_pose {
   double K[9], R[9], t[3];   /* KRt_From_P, row-major */
   double center[3];          /* t_out = -R^T t: the "t" of the result JSON */
   double stage_seconds[7];   /* LocalizeEngine.cc:643-658 buckets: selectBeacon, selectBow, extFeat, putMatch,
-                                geoMatch, PnP, others */
+                                geoMatch, PnP, others.  Filled from the per-stage HIP events of this query when
+                                params.profile == 1 (selectBow = K8, putMatch = K1+K2, geoMatch = K3, PnP = 2D-3D set +
+                                P3P, others = the rest of the call's wall time; selectBeacon / extFeat are the caller's);
+                                otherwise only others = the call's wall time */
 } sfmloc_pose;
 
 int sfmloc_resection(sfmloc_map *map, sfmloc_query *q);
@@ -470,7 +481,9 @@ int sfmloc_track(sfmloc_map *map, uint32_t max_frame_dist, sfmloc_matches **out)
  * params.geom_precision) on the given putative lists -- pair k = (pairs[2k], pairs[2k+1]) owns
  * match_i/j[offsets[k] .. offsets[k+1]) -- keeping a pair iff it has more than 2.5*7 inliers; the surviving matches
  * come in AC-RANSAC's inlier order.  No minimum list length is applied here (the caller applies ExtFeatAndMatch's
- * minMatch, computeFeaturesAndMatches.cpp:211-221). */
+ * minMatch, computeFeaturesAndMatches.cpp:211-221).  With params.guided_matching a surviving pair's matches are
+ * replaced by the guided ones (all features of both images under the estimated F, one per feature of I, ascending;
+ * possibly none -- the pair keeps its entry, as in Robust_model_estimation). */
 int sfmloc_geometric_pairs(sfmloc_map *map, const uint32_t *pairs, uint32_t n_pairs, const uint64_t *offsets,
                            const uint32_t *match_i, const uint32_t *match_j, sfmloc_matches **out);
 

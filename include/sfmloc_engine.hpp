@@ -4,11 +4,12 @@
 // Same constructor arguments and the same localize() contract: returns [t(3), R(9 row-major)] in the frame of the A
 // matrix (LocalizeEngine.cc:593-625), an EMPTY vector on failure (:453,481,579); points2D / points3D are the 2D-3D
 // correspondences of the resection (n x 2, n x 3, the latter A-transformed, :520-553), pointsInlier the indices of
-// the inliers among them, times the six stage durations of :651-657 (this implementation measures the whole call:
-// times[5] carries it, the others are 0 -- the per-kernel split is sfmloc_stats_read).
+// the inliers among them, times the six stage durations of :651-657 (selectBeacon = 0: no iBeacon stage; selectBow,
+// putMatch, geoMatch, PnP from the query's per-stage HIP events, extFeat measured around the extraction by the image
+// entry points; lastTotalSeconds() is the whole call).
 // What cannot be mirrored without OpenCV: cv::Mat arguments become plain buffers (8-bit gray image or precomputed
-// descriptors + keypoints); iBeacon pre-selection (beaconKnnNum) is out of scope and must be 0; guidedMatching must
-// be false (no caller of the reference sets it).  Not re-entrant, like the original: one engine per concurrent user
+// descriptors + keypoints); iBeacon pre-selection (beaconKnnNum) is out of scope and must be 0.  guidedMatching is
+// honoured (sfmloc_params.guided_matching).  Not re-entrant, like the original: one engine per concurrent user
 // (localizeImage.cc:71-74) -- or use sfmloc_context directly to share one map.
 #ifndef SFMLOC_ENGINE_HPP
 #define SFMLOC_ENGINE_HPP
@@ -68,7 +69,6 @@ class LocalizeEngine {
                  double secondTestRatio, int ransacRound, double ransacPrecision, bool guidedMatching,
                  int beaconKnnNum = 0, int bowKnnNum = 0, int device = 0)
       : mMatchDir(matchDir), mBowKnnNum(bowKnnNum), mDevice(device) {
-    if (guidedMatching) throw std::invalid_argument("guided matching is not implemented");
     if (beaconKnnNum) throw std::invalid_argument("iBeacon view pre-selection is out of scope");
     sfmloc_params p;
     sfmloc_default_params(&p);
@@ -77,6 +77,7 @@ class LocalizeEngine {
     p.geom_precision = ransacPrecision;
     p.bow_knn = bowKnnNum;
     p.device = device;
+    p.guided_matching = guidedMatching ? 1 : 0;  // mGuidedMatching -> geometricMatch (LocalizeEngine.cc:459)
     // sfmDataDir may also name a packed map file written by sfmloc_pack
     struct stat st;
     const bool packed = ::stat(sfmDataDir.c_str(), &st) == 0 && S_ISREG(st.st_mode);
@@ -112,16 +113,21 @@ class LocalizeEngine {
     std::vector<float> kp((size_t)cap * 6);
     std::vector<uint8_t> desc((size_t)cap * 64);
     uint32_t n = 0;
+    const auto tFeat = std::chrono::steady_clock::now();
     if (sfmloc_akaze_detect_and_compute(ak, gray, kp.data(), desc.data(), cap, &n))
       throw std::runtime_error(sfmloc_last_error());
+    const double featSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tFeat).count();
     std::vector<float> xy((size_t)n * 2);
     for (uint32_t i = 0; i < n; ++i) {  // locFeat takes KeyPoint::pt as is (LocalizeEngine.cc:228-231); only the
       xy[2 * i] = kp[6 * i];            // command-line tool reads the 6-digit .feat text back
       xy[2 * i + 1] = kp[6 * i + 1];
     }
-    return localizeFeatures(desc.data(), xy.data(), n, width, height, bReturnKeypoints, points2D, points3D,
-                            pointsInlier, bReturnTime, times, center, radius, bow);
+    std::vector<double> r = localizeFeatures(desc.data(), xy.data(), n, width, height, bReturnKeypoints, points2D,
+                                             points3D, pointsInlier, bReturnTime, times, center, radius, bow);
+    if (bReturnTime && times.size() == 6) times[2] = featSeconds;  // "Extract feature from query image"
+    return r;
   }
+  double lastTotalSeconds() const { return mLastTotal; }
 
   // the server's calls: a decoded colour image (B G R, what cv::imdecode / cv::imread(IMREAD_COLOR) hand to
   // LocalizeEngine::localize, localizeImage.cc:393/463); cv::AKAZE::detectAndCompute converts it with BGR2GRAY
@@ -181,6 +187,7 @@ class LocalizeEngine {
     sfmloc_pose pose;
     std::memset(&pose, 0, sizeof(pose));
     std::vector<uint32_t> pq(4096), pl(4096);
+    if (bReturnTime) sfmloc_set_profile(mMap, 1);  // the reference's `times` come from this query's per-stage events
     const uint32_t *selp = useSel ? sel.data() : nullptr;
     const uint32_t nsel = useSel ? (uint32_t)sel.size() : 0;
     // with a BoW vector the shortlist (applied when more than bowKnnNum views remain, LocalizeEngine.cc:342) and the
@@ -189,6 +196,7 @@ class LocalizeEngine {
                        ? sfmloc_localize_bow(mMap, q, bow->data(), (uint32_t)mBowKnnNum, selp, nsel, &pose, pq.data(),
                                              pl.data(), 4096)
                        : sfmloc_localize(mMap, q, selp, nsel, &pose, pq.data(), pl.data(), 4096);
+    if (bReturnTime) sfmloc_set_profile(mMap, mProfile);
     if (rc) {
       sfmloc_query_destroy(q);
       throw std::runtime_error(sfmloc_last_error());
@@ -210,9 +218,13 @@ class LocalizeEngine {
       for (int i = 0; i < pose.n_inliers; ++i) pointsInlier.push_back((int)inl[i]);
     }
     sfmloc_query_destroy(q);
-    if (bReturnTime) {
-      times.assign(6, 0.0);
-      times[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (bReturnTime) {  // LocalizeEngine.cc:651-657: selectBeacon, selectBow, extFeat (the image entry points fill it),
+      times.assign(6, 0.0);  // putMatch, geoMatch, PnP
+      times[1] = pose.stage_seconds[1];
+      times[3] = pose.stage_seconds[3];
+      times[4] = pose.stage_seconds[4];
+      times[5] = pose.stage_seconds[5];
+      mLastTotal = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     if (!pose.ok) return result;
     double c[3] = {pose.center[0], pose.center[1], pose.center[2]};
@@ -289,6 +301,8 @@ class LocalizeEngine {
   double mA[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
   bool mHaveA = false;
   int mBowKnnNum = 0, mDevice = 0;
+  int mProfile = 0;          // params.profile outside a timed call
+  double mLastTotal = 0.0;   // wall time of the last localize call with bReturnTime
   float mThres = 0.001f;
   int mNOct = 4, mNOctLay = 4;
   std::map<std::pair<int, int>, sfmloc_akaze *> mAkaze;

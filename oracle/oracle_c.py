@@ -167,6 +167,34 @@ def fmatrix_filter(x1, wh1, x2, wh2, precision, n_iter, seed, stream):
             "iters": it.value}
 
 
+def guided_match(F_norm, errmax_norm, wh1, wh2, xy1, desc1, xy2, desc2, dist_ratio=0.6):
+    """GeometricFilter_FMatrix_AC::Geometry_guided_matching for one pair (F / errmax as fmatrix_filter returns them,
+    i.e. in the normalised frame); xy: .feat positions (float32).  -> (i[], j[]), one match per i, ascending."""
+    F = np.ascontiguousarray(F_norm, np.float64).reshape(9)
+    xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+    xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 64)
+    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 64)
+    n1, n2 = xy1.shape[0], xy2.shape[0]
+    oi = np.zeros(max(n1, 1), np.int32)
+    oj = np.zeros(max(n1, 1), np.int32)
+    L = lib()
+    L.orc_guided_match.restype = C.c_int
+    n = L.orc_guided_match(_p(F, C.c_double), C.c_double(errmax_norm), C.c_int(wh1[0]), C.c_int(wh1[1]),
+                           C.c_int(wh2[0]), C.c_int(wh2[1]), _p(xy1, C.c_float), _p(d1, C.c_uint8), C.c_int(n1),
+                           _p(xy2, C.c_float), _p(d2, C.c_uint8), C.c_int(n2), C.c_double(dist_ratio),
+                           _p(oi, C.c_int32), _p(oj, C.c_int32))
+    return oi[:n].astype(np.uint32), oj[:n].astype(np.uint32)
+
+
+def unnormalize_f(F_norm, wh1, wh2):
+    F = np.ascontiguousarray(F_norm, np.float64).reshape(9)
+    out = np.zeros(9, np.float64)
+    lib().orc_unnormalize_f(_p(F, C.c_double), C.c_int(wh1[0]), C.c_int(wh1[1]), C.c_int(wh2[0]), C.c_int(wh2[1]),
+                            _p(out, C.c_double))
+    return out.reshape(3, 3)
+
+
 def p3p_localize(pt2d, pt3d, focal, ppx, ppy, max_iteration, seed, stream=0):
     pt2d = np.ascontiguousarray(pt2d, np.float64).reshape(-1, 2)
     pt3d = np.ascontiguousarray(pt3d, np.float64).reshape(-1, 3)

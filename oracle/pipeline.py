@@ -15,7 +15,7 @@ def round6(a):
 
 def localize(m, q_desc, q_kpt, q_wh, view_sel=None, ratio=0.6, ransac_round=25, geom_precision=4.0,
              min_putative=16, min_resection_points=8, min_inliers=10, p3p_max_iteration=4096,
-             seed=0x5f3759df12345678, threads=4):
+             seed=0x5f3759df12345678, threads=4, guided=False):
     """m: object with view_id, view_off, view_wh, desc, kpt_xy, row_landmark, landmark_id, landmark_X,
     intrinsic.  Returns a dict with every intermediate the product exposes."""
     import time as _time
@@ -44,7 +44,22 @@ def localize(m, q_desc, q_kpt, q_wh, view_sel=None, ratio=0.6, ransac_round=25, 
         r = oracle_c.fmatrix_filter(x1, tuple(int(t) for t in m.view_wh[v]), x2, q_wh, geom_precision,
                                     ransac_round, seed, stream=int(m.view_id[v]))
         f_stats[v] = r
-        if r["n"] > 0:
+        if r["n"] > 0 and guided:
+            # -gm (MatchUtils.cpp:413-415 -> Robust_model_estimation(..., bGuided_matching)): the view's matches become
+            # the guided ones -- over ALL features of both images; geo_idx then holds the map feature i, geo_j the
+            # query feature
+            n_v = int(m.view_off[v + 1]) - off
+            g_i, g_j = oracle_c.guided_match(r["F"], r["errmax"], tuple(int(t) for t in m.view_wh[v]), q_wh,
+                                             m.kpt_xy[off:off + n_v], m.desc[off:off + n_v], q6.astype(np.float32),
+                                             q_desc)
+            geo_count[v] = len(g_i)
+            geo_idx[off:off + len(g_i)] = g_i
+            out.setdefault("geo_j", np.full(m.desc.shape[0], 0xFFFFFFFF, np.uint32))[off:off + len(g_i)] = g_j
+            for a_, b_ in zip(g_i, g_j):
+                gv.append(v)
+                gi.append(int(a_))
+                gj.append(int(b_))
+        elif r["n"] > 0:
             geo_count[v] = r["n"]
             geo_idx[off:off + r["n"]] = r["inliers"]
             for p in r["inliers"]:
@@ -196,7 +211,8 @@ def track_akaze(descs, max_frame_dist, ratio=0.6):
     return {k: (np.array(v[0], np.uint32), np.array(v[1], np.uint32)) for k, v in sorted(matches.items())}
 
 
-def geometric_match(kpts, whs, view_ids, matches, ransac_round=4096, geom_precision=4.0, seed=0x5f3759df12345678):
+def geometric_match(kpts, whs, view_ids, matches, ransac_round=4096, geom_precision=4.0, seed=0x5f3759df12345678,
+                    guided=False, descs=None):
     """hulo::geometricMatch (MatchUtils.cpp:372-420) for map image pairs: F-matrix AC-RANSAC on every putative list,
     pairs with more than 2.5*7 inliers kept, matches in AC-RANSAC's inlier order.  kpts[v]: [n_v, 2] .feat x, y;
     whs[v]: (w, h); matches: {(I, J): (i[], j[])} over view indices."""
@@ -208,6 +224,10 @@ def geometric_match(kpts, whs, view_ids, matches, ransac_round=4096, geom_precis
         x2 = np.asarray(kpts[b], np.float64)[np.asarray(mj, np.int64)]
         r = oracle_c.fmatrix_filter(x1, tuple(int(t) for t in whs[a]), x2, tuple(int(t) for t in whs[b]), geom_precision,
                                     ransac_round, seed, stream=int(view_ids[a]))
-        if r["n"] > 0:
+        if r["n"] > 0 and guided:     # -gm: the pair's matches are re-derived from ALL features of both images
+            out[(a, b)] = oracle_c.guided_match(r["F"], r["errmax"], tuple(int(t) for t in whs[a]),
+                                                tuple(int(t) for t in whs[b]), np.asarray(kpts[a], np.float32), descs[a],
+                                                np.asarray(kpts[b], np.float32), descs[b])
+        elif r["n"] > 0:
             out[(a, b)] = (np.asarray(mi, np.uint32)[r["inliers"]], np.asarray(mj, np.uint32)[r["inliers"]])
     return out

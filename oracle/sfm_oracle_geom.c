@@ -802,6 +802,84 @@ int orc_fmatrix_filter(const double *x1, int w1, int h1, const double *x2, int w
 }
 
 /*
+ * GeometricFilter_FMatrix_AC::Geometry_guided_matching (OpenMVG 1.1 matching_image_collection/F_ACRobust.hpp) as
+ * ImageCollectionGeometricFilter::Robust_model_estimation calls it when b_guided_matching is set
+ * (MatchUtils.cpp:412-416 forwards hulo's -gm; d_distance_ratio keeps its default 0.6):
+ *   m_F                 = the AC-RANSAC model un-normalised, N2^T F N1 (ACKernelAdaptor::Unnormalize)
+ *   m_dPrecision_robust = sqrt(errorMax) / N2(0,0)            (ACKernelAdaptor::unormalizeError)
+ *   geometry_aware::GuidedMatching<Mat3, EpipolarDistanceError>(m_F, camI = NULL, regions I, camJ = NULL, regions J,
+ *                                                               Square(m_dPrecision_robust), Square(0.6), matches)
+ * (the SfM_Data hulo::geometricMatch hands over holds views only, MatchUtils.cpp:381-410, so no intrinsic is found
+ * and the positions are the raw .feat ones): for every feature i of image I, over ALL features j of image J in index
+ * order, those with EpipolarDistanceError(F, x_i, x_j) < threshold compete by Binary_Regions::
+ * SquaredDescriptorDistance (the Hamming distance, squared); distanceRatio<double> keeps best / second best
+ * (strict <, so the lowest j wins ties) and the match (i, best j) is kept iff a second candidate exists and
+ * best < Square(ratio) * second.  One entry per i, ascending i (IndMatch::getDeduplicated sorts by (i, j)).
+ * OpenMVG's source is not in this image: restated from its published algorithm -- PARITY UNPINNED.
+ *   F_norm, errmax_norm: orc_fmatrix_filter's out_F / out_errmax.  xy: float pairs as .feat stores them.
+ * Returns the number of matches written to out_i / out_j.
+ */
+static int hamming64(const uint8_t *a, const uint8_t *b) {
+  int d = 0;
+  for (int k = 0; k < 64; ++k) d += __builtin_popcount((unsigned)(a[k] ^ b[k]));
+  return d;
+}
+
+void orc_unnormalize_f(const double *F, int w1, int h1, int w2, int h2, double *Fp) {
+  const double s1 = 1.0 / sqrt((double)(w1 * h1)), s2 = 1.0 / sqrt((double)(w2 * h2));
+  const double N1[9] = {s1, 0.0, -0.5 * (double)w1 * s1, 0.0, s1, -0.5 * (double)h1 * s1, 0.0, 0.0, 1.0};
+  const double N2[9] = {s2, 0.0, -0.5 * (double)w2 * s2, 0.0, s2, -0.5 * (double)h2 * s2, 0.0, 0.0, 1.0};
+  double T[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) T[3 * r + c] = (N2[r] * F[c] + N2[3 + r] * F[3 + c]) + N2[6 + r] * F[6 + c];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Fp[3 * r + c] = (T[3 * r] * N1[c] + T[3 * r + 1] * N1[3 + c]) + T[3 * r + 2] * N1[6 + c];
+}
+
+int orc_guided_match(const double *F_norm, double errmax_norm, int w1, int h1, int w2, int h2, const float *xy1,
+                     const uint8_t *desc1, int n1, const float *xy2, const uint8_t *desc2, int n2, double dist_ratio,
+                     int32_t *out_i, int32_t *out_j) {
+  double F[9];
+  orc_unnormalize_f(F_norm, w1, h1, w2, h2, F);
+  const double s2 = 1.0 / sqrt((double)(w2 * h2));
+  const double pr = sqrt(errmax_norm) / s2;
+  const double err_th = pr * pr;
+  const double ratio2 = dist_ratio * dist_ratio;
+  int n = 0;
+  for (int i = 0; i < n1; ++i) {
+    const double x = (double)xy1[2 * i], y = (double)xy1[2 * i + 1];
+    const double l0 = (F[0] * x + F[1] * y) + F[2];
+    const double l1 = (F[3] * x + F[4] * y) + F[5];
+    const double l2 = (F[6] * x + F[7] * y) + F[8];
+    const double den = l0 * l0 + l1 * l1;
+    double bd = DBL_MAX, sbd = DBL_MAX;
+    int idx = 0;
+    for (int j = 0; j < n2; ++j) {
+      const double u = (double)xy2[2 * j], v = (double)xy2[2 * j + 1];
+      const double num = (l0 * u + l1 * v) + l2;
+      const double e = (num * num) / den;
+      if (e < err_th) {
+        const int d = hamming64(desc1 + 64 * (size_t)i, desc2 + 64 * (size_t)j);
+        const double dd = (double)(d * d);
+        if (dd < bd) {
+          idx = j;
+          sbd = bd;
+          bd = dd;
+        } else if (dd < sbd) {
+          sbd = dd;
+        }
+      }
+    }
+    if (sbd != DBL_MAX && bd < ratio2 * sbd) {
+      out_i[n] = i;
+      out_j[n] = idx;
+      ++n;
+    }
+  }
+  return n;
+}
+
+/*
  * SfM_Localizer::Localize with a valid pinhole intrinsic (P3P branch) on resection_data.pt2D / pt3D
  * (localization.cpp:479-509): AC-RANSAC on K^-1-normalised points, logalpha0 = log10(pi), no upper bound on
  * the precision, max_iteration iterations.  Returns the number of inliers if it exceeds 2.5*3, else 0.

@@ -34,6 +34,7 @@ class Params(C.Structure):
         ("device", C.c_int),
         ("profile", C.c_int),
         ("exact_rows", C.c_int),
+        ("guided_matching", C.c_int),
     ]
 
 
@@ -116,7 +117,7 @@ SYMBOLS = [
     "sfmloc_undistorter_create", "sfmloc_undistorter_destroy", "sfmloc_undistorter_info", "sfmloc_undistorter_maps",
     "sfmloc_undistorter_apply",
     "sfmloc_query_set_bow", "sfmloc_context_signal", "sfmloc_context_wait", "sfmloc_shard_bow_keys",
-    "sfmloc_shard_begin_bow", "sfmloc_packed_bytes", "sfmloc_shard_export_packed", "sfmloc_merge_begin_packed",
+    "sfmloc_geometric_read_pairs", "sfmloc_shard_begin_bow", "sfmloc_packed_bytes", "sfmloc_shard_export_packed", "sfmloc_merge_begin_packed",
 ]
 
 _bound = False
@@ -166,6 +167,7 @@ def _L():
         U32P, F64P = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
         L.sfmloc_geometric_filter.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_geometric_read.argtypes = [C.c_void_p, U32P, U32P, C.c_uint64]
+        L.sfmloc_geometric_read_pairs.argtypes = [C.c_void_p, U32P, U32P, U32P, C.c_uint64]
         L.sfmloc_match_set.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_match_set_read.argtypes = [C.c_void_p, U32P, U32P, U32P, F64P, F64P, C.c_uint32]
         L.sfmloc_resection.argtypes = [C.c_void_p, C.c_void_p]
@@ -613,6 +615,17 @@ class Map:
         idx = np.full(self.n_rows, NOMATCH, np.uint32)
         _check(_L().sfmloc_geometric_read(self._h, _ptr(cnt, C.c_uint32), _ptr(idx, C.c_uint32), self.n_rows))
         return cnt, idx
+
+    def geometric_read_pairs(self):
+        """-> geo_count[V], geo_i[n_rows], geo_j[n_rows]: each view's geometric matches as (map feature, query feature),
+        view v's list at view_off[v] -- the guided matches with params.guided_matching, else the putative matches the
+        inlier indices name."""
+        cnt = np.zeros(self.n_views, np.uint32)
+        gi = np.full(self.n_rows, NOMATCH, np.uint32)
+        gj = np.full(self.n_rows, NOMATCH, np.uint32)
+        _check(_L().sfmloc_geometric_read_pairs(self._h, _ptr(cnt, C.c_uint32), _ptr(gi, C.c_uint32),
+                                                _ptr(gj, C.c_uint32), self.n_rows))
+        return cnt, gi, gj
 
     def match_set(self, q):
         _check(_L().sfmloc_match_set(self._h, q._h))

@@ -304,6 +304,7 @@ struct FFilterArgs {
   int min_putative;
   const double *L10;
   uint32_t *geo_count, *geo_idx;
+  double *geo_model;  // [view][10]: the winning F (normalised frame) and its errorMax, for guided matching; or null
   int *status;
   int skip_le;  // k_fmatrix_filter leaves views with at most this many putative matches to k_fmatrix_fast
 };
@@ -319,6 +320,7 @@ struct FShared {
   int pre_nm[kFPre];
   double cur_models[27];
   int cur_nm;
+  double best_model[9];
   double red_nfa[kThreads / 64];
   int red_k[kThreads / 64];
 };
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
         min_nfa = b.nfa;
         n_in = b.k;
         for (int p = tid; p < n_in; p += kThreads) S.best_inl[p] = (int32_t)S.idx[p];
+        if (tid < 9) S.best_model[tid] = M[tid];
       }
     }
     if ((better && min_nfa < 0.0) || (iter + 1 == n_iter && n_reserve)) {
@@ -464,6 +467,13 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
   if ((double)n_in > 7 * 2.5) {
     for (int p = tid; p < n_in; p += kThreads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
     if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
+    if (A.geo_model && tid == 0) {  // errorMax = the residual of the last inlier (the list ascends by residual)
+      double x, y, u, w;
+      point(S.best_inl[n_in - 1], x, y, u, w);
+      double *gm = A.geo_model + 10 * (size_t)v;
+      for (int q = 0; q < 9; ++q) gm[q] = S.best_model[q];
+      gm[9] = err_fmatrix(S.best_model, x, y, u, w);
+    }
   } else if (tid == 0) {
     A.geo_count[v] = 0;
   }
@@ -765,6 +775,7 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
       if (better) {
         for (int p = tid; p < n_in; p += kF2Threads) S.best_inl[p] = (int32_t)S.idx[bk][p];
         inl_valid = true;
+        if (tid < 9) S.best_model[tid] = S.pre_models[0][9 * bk + tid];  // read again only behind a barrier
       }
       if ((better && min_nfa < 0.0) || (iter + 1 == n_iter && n_reserve)) {
         if (n_in == 0) {
@@ -790,6 +801,15 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
     if (!inl_valid) rebuild_inliers(false);
     for (int p = tid; p < n_in; p += kF2Threads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
     if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
+    __syncthreads();
+    if (A.geo_model && tid == 0) {  // errorMax = the residual of the last inlier (the list ascends by residual)
+      const int pl = S.best_inl[n_in - 1];
+      double Mb[9];
+      for (int q = 0; q < 9; ++q) Mb[q] = S.best_model[q];
+      double *gm = A.geo_model + 10 * (size_t)v;
+      for (int q = 0; q < 9; ++q) gm[q] = Mb[q];
+      gm[9] = err_fmatrix(Mb, S.pts[0][pl], S.pts[1][pl], S.pts[2][pl], S.pts[3][pl]);
+    }
   } else if (tid == 0) {
     A.geo_count[v] = 0;
   }
@@ -806,7 +826,11 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
                                                          const uint32_t *view_off, const uint32_t *view_id,
                                                          const uint32_t *put_count, const uint32_t *match_i,
                                                          const uint32_t *match_key, const uint32_t *geo_count,
-                                                         const uint32_t *geo_idx, const int32_t *row_landmark,
+                                                         const uint32_t *geo_idx,
+                                                         const uint32_t *geo_j /*null: geo_idx indexes the putative list;
+                                                                                 else (geo_idx, geo_j) = (map feature, query
+                                                                                 feature) of a guided match*/,
+                                                         const int32_t *row_landmark,
                                                          const uint32_t *landmark_id, const double *landmark_X,
                                                          Candidate *cand, uint32_t cap, uint32_t *n_cand,
                                                          int *status, uint32_t min_putative, uint32_t *view_stats) {
@@ -838,20 +862,31 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
     uint32_t j = 0, dist = 0;
     int32_t lm = -1;
     if (p < ng) {
-      const uint32_t pp = geo_idx[off + p];
-      const uint32_t i = match_i[off + pp];
-      j = match_key[off + pp] & 0xFFFFu;
+      uint32_t i;
+      if (geo_j) {
+        i = geo_idx[off + p];
+        j = geo_j[off + p];
+      } else {
+        const uint32_t pp = geo_idx[off + p];
+        i = match_i[off + pp];
+        j = match_key[off + pp] & 0xFFFFu;
+      }
       lm = row_landmark[off + i];
       has = lm >= 0;
     }
     if (has) {
+      bool found = false;
       for (int32_t k = (int32_t)np - 1; k >= 0; --k) {  // last putative match with the same query feature
         const uint32_t kk = staged ? keys[k] : match_key[off + k];
         if ((kk & 0xFFFFu) == j) {
           dist = kk >> 16;
+          found = true;
           break;
         }
       }
+      // featDist has no entry for a query feature no putative match of this view hit (only possible for guided
+      // matches): matchProviderToMatchSet then skips the match (SfMDataUtils.cpp:105-106)
+      has = found;
     }
     // one atomic per wave step instead of one per candidate (a few thousand on one counter otherwise)
     const unsigned long long mask = __ballot(has);
@@ -1645,7 +1680,9 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
   A.L10 = m->d_L10;
   A.geo_count = c->d_geo_count;
   A.geo_idx = c->d_geo_idx;
+  A.geo_model = m->params.guided_matching ? c->d_geo_model : nullptr;
   A.status = c->d_status;
+  c->geo_is_pairs = false;
   // views with <= kF2MaxM putative matches take the wave-parallel kernel, the rest (if any: the second launch
   // returns at once for the others) the block-wide one; SFMLOC_K3_FAST=0 sends every view to the latter
   static const bool fast = [] {
@@ -1678,7 +1715,8 @@ int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_view
   if (n_sel == 0 || q->n == 0) return SFMLOC_OK;
   hipLaunchKernelGGL(k_emit_candidates, dim3(n_sel), dim3(256), 0, c->stream,
                      all_views ? nullptr : c->d_view_sel, n_sel, m->d_view_off, m->d_view_id, c->d_view_count,
-                     c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, m->d_row_landmark,
+                     c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx,
+                     c->geo_is_pairs ? c->d_geo_j : nullptr, m->d_row_landmark,
                      m->d_landmark_id, m->d_landmark_X,
                      reinterpret_cast<Candidate *>(c->d_cand_part + kPartHeaderBytes), c->cand_cap,
                      reinterpret_cast<uint32_t *>(c->d_cand_part), c->d_status, (uint32_t)m->params.min_putative,

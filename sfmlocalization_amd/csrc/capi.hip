@@ -93,12 +93,14 @@ struct EventScope {
   }
 };
 
-int drain_events(Ctx *c) {
+// per_kind_ms (optional, [SFMLOC_K_COUNT]): the drained brackets' time by kind, for the caller's own bookkeeping
+int drain_events(Ctx *c, double *per_kind_ms = nullptr) {
   for (auto &pe : c->pending_events) {
     float ms = 0.f;
     SFM_HIP(hipEventSynchronize(pe.second.second));
     SFM_HIP(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
     c->stats.total_ms[pe.first] += ms;
+    if (per_kind_ms) per_kind_ms[pe.first] += ms;
     c->stats.launches[pe.first] += 1;
     c->event_pool.push_back(pe.second);
   }
@@ -123,7 +125,8 @@ void free_ctx(Ctx *c) {
                   c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
                   c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,
                   c->d_inlier_idx,
-                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters, c->d_flagmask, c->d_rows_scratch, c->d_rows_arrivals, c->d_flagged_desc};
+                  c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters, c->d_flagmask, c->d_rows_scratch, c->d_rows_arrivals, c->d_flagged_desc,
+                  c->d_geo_model, c->d_geo_j,     c->d_guided_row};
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -180,6 +183,7 @@ int make_ctx(Map *m, Ctx **out) {
   CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
   CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views + 1));
   CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
+  CTX_TRY(dev_alloc(acct, &c->d_geo_model, ((size_t)m->n_views + 1) * 10));
   // everything a finished query reports lives in ONE device record laid out as HostResult: one D2H copy per query
   CTX_TRY(dev_alloc(acct, &c->d_result, sizeof(HostResult)));
   {
@@ -421,7 +425,11 @@ int ctx_geometric_filter(Ctx *c, Query *q) {
   }
   if (q->n == 0 || c->last_n_sel == 0) return SFMLOC_OK;
   EventScope ev(c, SFMLOC_K_FMATRIX);
-  return launch_fmatrix_filter(c, q, c->last_n_sel, c->last_all_views);
+  int rc = launch_fmatrix_filter(c, q, c->last_n_sel, c->last_all_views);
+  if (rc) return rc;
+  // -gm (MatchUtils.cpp:413-415): the surviving views' matches are re-derived under the estimated F
+  if (m->params.guided_matching) rc = launch_guided_matching(c, q, c->last_n_sel, c->last_all_views);
+  return rc;
 }
 
 int ctx_match_set(Ctx *c, Query *q) {
@@ -456,7 +464,11 @@ int ctx_resection_wait(Ctx *c) {
   for (int guard = 0; guard < 64; ++guard) {
     SFM_HIP(hipStreamSynchronize(c->stream));
     if (h->state.done) return SFMLOC_OK;
-    int rc = ctx_resection_enqueue(c, false);
+    int rc;
+    {
+      EventScope ev(c, SFMLOC_K_P3P);
+      rc = ctx_resection_enqueue(c, false);
+    }
     if (rc) return rc;
     rc = ctx_fetch_result(c);
     if (rc) return rc;
@@ -519,8 +531,26 @@ int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *p
     if (pair_qfeat) memcpy(pair_qfeat, h->pair_qfeat, k * sizeof(uint32_t));
     if (pair_landmark) memcpy(pair_landmark, h->pair_landmark, k * sizeof(uint32_t));
   }
+  // the reference's `times` (LocalizeEngine.cc:643-658): with params.profile = 1 every stage of this query was
+  // bracketed by HIP events on its stream -- selectBow = K8, putMatch = K1 + K2, geoMatch = K3, PnP = 2D-3D set + P3P
+  // (the reference's PnP bucket runs from the end of geometricMatch to the end of Localize), others = the rest of the
+  // wall time begin -> end.  Without profiling only the total is known and it goes to `others`.
   for (int i = 0; i < 7; ++i) out->stage_seconds[i] = 0.0;
-  out->stage_seconds[6] = now_s() - c->t_begin;  // wall time begin -> end; per-kernel split: sfmloc_stats_read
+  const double wall = now_s() - c->t_begin;
+  if (c->map->params.profile == 1) {
+    double per[SFMLOC_K_COUNT] = {0};
+    rc = drain_events(c, per);
+    if (rc) return rc;
+    out->stage_seconds[1] = per[SFMLOC_K_BOW] * 1e-3;
+    out->stage_seconds[3] = (per[SFMLOC_K_HAMMING] + per[SFMLOC_K_COMPACT]) * 1e-3;
+    out->stage_seconds[4] = per[SFMLOC_K_FMATRIX] * 1e-3;
+    out->stage_seconds[5] = (per[SFMLOC_K_MATCHSET] + per[SFMLOC_K_P3P]) * 1e-3;
+    double sum = 0.0;
+    for (int i = 0; i < 6; ++i) sum += out->stage_seconds[i];
+    out->stage_seconds[6] = wall > sum ? wall - sum : 0.0;
+  } else {
+    out->stage_seconds[6] = wall;
+  }
   return SFMLOC_OK;
 }
 
@@ -560,6 +590,7 @@ void sfmloc_default_params(sfmloc_params *p) {
   p->device = 0;
   p->profile = 0;
   p->exact_rows = 0;
+  p->guided_matching = 0;       // -gm: false (localization.cpp:82, computeFeaturesAndMatches.cpp:63)
 }
 
 int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfmloc_map **out) {
@@ -632,6 +663,7 @@ int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfm
   for (uint32_t v = 0; v < d->n_views; ++v) {
     const uint32_t r0 = d->view_off[v], r1 = d->view_off[v + 1];
     if (r1 > r0) m->max_view_blocks = std::max(m->max_view_blocks, (r1 - 1) / kBlockRows - r0 / kBlockRows + 1);
+    m->max_view_rows = std::max(m->max_view_rows, r1 - r0);
   }
   m->n_views = d->n_views;
   m->n_landmarks = d->row_landmark ? d->n_landmarks : 0;
@@ -958,6 +990,8 @@ int sfmloc_geometric_read(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_id
   SFM_HIP(hipMemcpy(cnt.data(), c->d_geo_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (geo_count) memcpy(geo_count, cnt.data(), cnt.size() * sizeof(uint32_t));
   if (geo_idx) {
+    SFM_CHECK(!c->geo_is_pairs, SFMLOC_EINVAL,
+              "sfmloc_geometric_read: guided matches are not indices into the putative lists; use sfmloc_geometric_read_pairs");
     SFM_CHECK(cap >= m->n_rows, SFMLOC_ECAP, "sfmloc_geometric_read: cap too small");
     std::vector<uint32_t> gi(m->n_rows);
     SFM_HIP(hipMemcpy(gi.data(), c->d_geo_idx, gi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -967,6 +1001,41 @@ int sfmloc_geometric_read(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_id
   int st = 0;
   SFM_HIP(hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
   SFM_CHECK((st & 1) == 0, SFMLOC_ECAP, "a view has more than 2048 putative matches (F-matrix workspace)");
+  return SFMLOC_OK;
+}
+
+int sfmloc_geometric_read_pairs(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_i, uint32_t *geo_j, uint64_t cap) {
+  SFM_CHECK(map, SFMLOC_EINVAL, "sfmloc_geometric_read_pairs: null map");
+  Map *m = reinterpret_cast<Map *>(map);
+  Ctx *c = m->ctx0;
+  SFM_HIP(hipSetDevice(m->device));
+  SFM_HIP(hipStreamSynchronize(c->stream));
+  std::vector<uint32_t> cnt(m->n_views);
+  SFM_HIP(hipMemcpy(cnt.data(), c->d_geo_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (geo_count) memcpy(geo_count, cnt.data(), cnt.size() * sizeof(uint32_t));
+  if (geo_i || geo_j) {
+    SFM_CHECK(cap >= m->n_rows, SFMLOC_ECAP, "sfmloc_geometric_read_pairs: cap too small");
+    std::vector<uint32_t> gi(m->n_rows), gj;
+    SFM_HIP(hipMemcpy(gi.data(), c->d_geo_idx, gi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> pi, pk;
+    if (c->geo_is_pairs) {
+      gj.resize(m->n_rows);
+      SFM_HIP(hipMemcpy(gj.data(), c->d_geo_j, gj.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    } else {  // indices into the putative lists: resolve them
+      pi.resize(m->n_rows);
+      pk.resize(m->n_rows);
+      SFM_HIP(hipMemcpy(pi.data(), c->d_match_i, pi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      SFM_HIP(hipMemcpy(pk.data(), c->d_match_key, pk.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    for (uint32_t v = 0; v < m->n_views; ++v) {
+      const uint32_t off = m->h_view_off[v];
+      for (uint32_t k = 0; k < cnt[v]; ++k) {
+        const uint32_t g = gi[off + k];
+        if (geo_i) geo_i[off + k] = c->geo_is_pairs ? g : pi[off + g];
+        if (geo_j) geo_j[off + k] = c->geo_is_pairs ? gj[off + k] : (pk[off + g] & 0xFFFFu);
+      }
+    }
+  }
   return SFMLOC_OK;
 }
 

@@ -9,7 +9,7 @@
 // Images are decoded by the library's own cv::imread (sfmloc_image_read: JPEG, PNG, binary PGM/PPM); when the image
 // cannot be decoded the query's features are taken from <featdir>/<base>.desc/.feat (the files extractAKAZESingleImg writes, AKAZEOpenCV.cpp:80-111); the BoW shortlist
 // (-k) uses <featdir>/<base>.bow if present, else the dense-feature chain on the decoded colour image; -w writes
-// <matchDir>/matches.fQ.txt as the reference does; -gm is accepted and ignored.  The Python mirror (sfmlocalization_amd/engine.py) covers the same contract.
+// <matchDir>/matches.fQ.txt as the reference does; -gm = guided matching in the geometric stage (:82,183,451).  The Python mirror (sfmlocalization_amd/engine.py) covers the same contract.
 #include <dirent.h>
 #include <sys/stat.h>
 
@@ -408,6 +408,9 @@ int main(int argc, char **argv) {
   std::string wm = a.get({"w", "writematch"}, "false");
   for (char &ch : wm) ch = (char)tolower(ch);
   const bool write_match = wm == "1" || wm == "true" || wm == "yes";
+  std::string gm = a.get({"gm", "guidedMatch"}, "false");   // localization.cpp:82,183
+  for (char &ch : gm) ch = (char)tolower(ch);
+  const bool guided = gm == "1" || gm == "true" || gm == "yes";
   const std::string featdir_opt = a.get({"featdir"}, "");
   const int device = atoi(a.get({"device"}, "0").c_str());
   if (every <= 0) every = 1;
@@ -443,6 +446,7 @@ int main(int argc, char **argv) {
   prm.geom_precision = geom;
   prm.bow_knn = knn_bow;
   prm.device = device;
+  prm.guided_matching = guided ? 1 : 0;
   sfmloc_map *map = nullptr;
   // <sfmDataDir> may also name a packed map file written by sfmloc_pack (one binary instead of sfm_data.json and the
   // per-view files); the result JSON then cites that file as "sfm_data"
@@ -601,9 +605,9 @@ int main(int argc, char **argv) {
       // putative list goes to a per-query folder the reference deletes again (:399-403, :585), so only this file stays.
       // Pair = (view id, id of the last view of sfm_data + 1), matches in AC-RANSAC's inlier order.
       const uint64_t nr = view_off[info.n_views];
-      std::vector<uint32_t> cnt(info.n_views), mi(nr), mj(nr), gc(info.n_views), gi(nr);
-      if (sfmloc_putative_read(map, cnt.data(), mi.data(), mj.data(), nullptr, nr) ||
-          sfmloc_geometric_read(map, gc.data(), gi.data(), nr)) {
+      // (with -gm the matches are the guided ones, in ascending map-feature order)
+      std::vector<uint32_t> gc(info.n_views), gi(nr), gj(nr);
+      if (sfmloc_geometric_read_pairs(map, gc.data(), gi.data(), gj.data(), nr)) {
         fprintf(stderr, "%s\n", sfmloc_last_error());
         rc_all = 1;
         break;
@@ -615,10 +619,7 @@ int main(int argc, char **argv) {
         for (uint32_t v = 0; v < info.n_views; ++v) {
           if (!gc[v]) continue;
           fprintf(fm, "%u %u\n%u\n", view_id[v], ind_query_file, gc[v]);
-          for (uint32_t k = 0; k < gc[v]; ++k) {
-            const uint32_t pp = gi[view_off[v] + k];
-            fprintf(fm, "%u %u\n", mi[view_off[v] + pp], mj[view_off[v] + pp]);
-          }
+          for (uint32_t k = 0; k < gc[v]; ++k) fprintf(fm, "%u %u\n", gi[view_off[v] + k], gj[view_off[v] + k]);
         }
         fclose(fm);
       }

@@ -386,11 +386,33 @@ int sfmloc_geometric_pairs(sfmloc_map *map, const uint32_t *pairs, uint32_t n_pa
       // ExtFeatAndMatch's minMatch, computeFeaturesAndMatches.cpp:211-221)
       rc = launch_fmatrix_filter(c, q, (uint32_t)sel.size(), false, 0);
     }
+    const bool guided = m->params.guided_matching != 0;
+    std::vector<uint32_t> passed(sel.size(), 0);
+    if (rc == SFMLOC_OK && guided) {
+      // which pairs passed the filter must be read before the guided lists replace the inlier counts: a pair whose
+      // guided list comes out empty keeps its (empty) entry
+      for (size_t t = 0; t < sel.size(); ++t)
+        hipMemcpyAsync(&passed[t], c->d_geo_count + sel[t], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+      hipStreamSynchronize(c->stream);
+      rc = launch_guided_matching(c, q, (uint32_t)sel.size(), false);
+    }
     for (size_t t = 0; rc == SFMLOC_OK && t < sel.size(); ++t) {
       const uint32_t a = sel[t], k = first_to_pair[a];
       uint32_t ng = 0;
       hipMemcpyAsync(&ng, c->d_geo_count + a, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
       hipStreamSynchronize(c->stream);
+      if (guided) {
+        if (passed[t] == 0) continue;
+        auto &pr = pm[{a, b}];
+        if (ng == 0) continue;
+        std::vector<uint32_t> gi(ng), gj(ng);
+        hipMemcpyAsync(gi.data(), c->d_geo_idx + m->h_view_off[a], ng * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        hipMemcpyAsync(gj.data(), c->d_geo_j + m->h_view_off[a], ng * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        hipStreamSynchronize(c->stream);
+        pr.first.assign(gi.begin(), gi.end());
+        pr.second.assign(gj.begin(), gj.end());
+        continue;
+      }
       if (ng == 0) continue;  // pairs that fail the filter get no entry
       std::vector<uint32_t> gi(ng);
       hipMemcpyAsync(gi.data(), c->d_geo_idx + m->h_view_off[a], ng * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);

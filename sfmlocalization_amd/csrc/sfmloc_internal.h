@@ -109,6 +109,7 @@ struct Map {
   uint64_t n_rows = 0;
   uint32_t n_blocks = 0;  // ceil(n_rows / 64)
   uint32_t max_view_blocks = 0;  // most 64-row blocks any one view overlaps (launch bound of a device-side selection)
+  uint32_t max_view_rows = 0;    // most rows of any one view
   std::atomic<int> busy_ctx{0};  // contexts with work queued (begin .. end / sync): K1 slices a short scan only when alone
   uint32_t n_views = 0;
   uint32_t n_landmarks = 0;
@@ -173,6 +174,11 @@ struct Ctx {
   // --- geometric stages ---
   uint32_t *d_geo_count = nullptr;  // [n_views]
   uint32_t *d_geo_idx = nullptr;    // [n_rows]
+  double *d_geo_model = nullptr;    // [(n_views+1)*10] per view: AC-RANSAC's F (normalised frame, 9) + errorMax
+  // guided matching (-gm): allocated on first use
+  uint32_t *d_geo_j = nullptr;        // [n_rows] query feature of each guided match (geo_idx then holds the map feature)
+  uint32_t *d_guided_row = nullptr;   // [n_rows] per bank row: its guided query feature or SFMLOC_NOMATCH
+  bool geo_is_pairs = false;          // the last geometric stage left (i, j) lists, not indices into the putative lists
   int *d_status = nullptr;
   unsigned char *d_cand_part = nullptr;  // this context's candidate part: header + cand_cap candidates
   uint32_t cand_cap = 1u << 14;
@@ -271,6 +277,10 @@ int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *
 // min_putative < 0: the map's params.min_putative (the query path's >=16 rule, localization.cpp:408-415)
 int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, int min_putative = -1);
 int launch_match_set(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
+// guided.hip: GeometricFilter_FMatrix_AC::Geometry_guided_matching for the views that passed K3 (their geo lists are
+// replaced by (map feature, query feature) lists in d_geo_idx / d_geo_j)
+int ensure_guided_workspace(Ctx *c);
+int launch_guided_matching(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
 int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_views);
 int launch_export_part(Ctx *c, void *dst_dev, uint32_t cap);
 // packed_b > 0: `parts` are packed batch parts of packed_b queries (acransac.hip PartLayout), cap = their budget,

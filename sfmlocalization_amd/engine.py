@@ -55,14 +55,12 @@ class LocalizeEngine:
 
     def __init__(self, sfm_data_dir, match_dir, amat_file=None, second_test_ratio=0.6, ransac_round=25,
                  ransac_precision=4.0, guided_matching=False, beacon_knn_num=0, bow_knn_num=0, device=0, profile=0):
-        if guided_matching:
-            raise NotImplementedError("guided matching (-gm) is off in every caller of the reference's localiser")
         if beacon_knn_num:
             raise NotImplementedError("iBeacon view pre-selection is out of scope (SURVEY.md 2.1)")
         self.sfm_data_dir, self.match_dir = sfm_data_dir, match_dir
         self.params = capi.default_params(dist_ratio=second_test_ratio, ransac_round=ransac_round,
                                           geom_precision=ransac_precision, bow_knn=bow_knn_num, device=device,
-                                          profile=profile)
+                                          profile=profile, guided_matching=int(bool(guided_matching)))
         # sfm_data_dir may also name a packed map file written by capi.pack / sfmloc_pack
         self.map = (capi.Map.open_packed(sfm_data_dir, self.params) if os.path.isfile(sfm_data_dir)
                     else capi.Map.open(sfm_data_dir, match_dir, self.params))
@@ -101,10 +99,14 @@ class LocalizeEngine:
         if gray.ndim == 3:
             b, g, r = (gray[:, :, i].astype(np.int32) for i in range(3))
             gray = ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+        t_feat = time.perf_counter()
         desc, kp = self.extract(gray)
+        t_feat = time.perf_counter() - t_feat
         h, w = gray.shape
         res, ex = self.localize(desc, kp[:, :2], w, h, **kw)
         ex["n_features"] = len(desc)
+        if "times" in ex:
+            ex["times"][2] = t_feat
         return res, ex
 
     def localize_file(self, path, **kw):
@@ -133,6 +135,9 @@ class LocalizeEngine:
                 return [], {}
         knn = int(self.params.bow_knn)
         q = self.map.query(desc, kpt_xy, width, height)
+        prof = int(self.map.params.profile)
+        if return_time and prof != 1:
+            self.map.set_profile(1)          # the reference's `times` come from this query's per-stage events
         try:
             if bow is not None and knn > 0:
                 # the shortlist applies when more than knn views remain (localization.cpp:346 / LocalizeEngine.cc:342);
@@ -142,9 +147,15 @@ class LocalizeEngine:
                 pose, pq, pl = self.map.localize(q, view_sel)
         finally:
             q.close()
+            if return_time and prof != 1:
+                self.map.set_profile(prof)
         extras = {"pose": pose, "pairs": list(zip(pq.tolist(), pl.tolist()))}
         if return_time:
-            extras["times"] = [0.0, 0.0, 0.0, 0.0, 0.0, time.perf_counter() - t0]
+            # LocalizeEngine.cc:651-657: selectBeacon (no iBeacon stage here), selectBow, extFeat (localize_image fills
+            # it), putMatch, geoMatch, PnP
+            ss = list(pose.stage_seconds)
+            extras["times"] = [0.0, ss[1], 0.0, ss[3], ss[4], ss[5]]
+            extras["time_total"] = time.perf_counter() - t0
         if not pose.ok:
             return [], extras
         R = np.array(pose.R).reshape(3, 3)
@@ -357,13 +368,12 @@ def main(argv=None):
             # -w: exportPairWiseMatches(map_geometricMatches, <matchDir>/matches.fQ.txt) (localization.cpp:452-455);
             # the putative list goes to a per-query folder the reference deletes again (:399-403, :585).  Pair =
             # (view id, id of the last view of sfm_data + 1), matches in AC-RANSAC's inlier order.
-            cnt, mi, mj, _ = eng.map.putative_read()
-            gc, gi = eng.map.geometric_read()
+            # (with -gm the matches are the guided ones, in ascending map-feature order)
+            gc, gi, gj = eng.map.geometric_read_pairs()
             geo = {}
             for v in np.nonzero(gc)[0]:
                 o0 = int(eng.map.view_off[v])
-                pp = gi[o0:o0 + int(gc[v])].astype(np.int64)
-                geo[(int(eng.map.view_id[v]), ind_query_file)] = (mi[o0 + pp], mj[o0 + pp])
+                geo[(int(eng.map.view_id[v]), ind_query_file)] = (gi[o0:o0 + int(gc[v])], gj[o0:o0 + int(gc[v])])
             fileio.write_matches_txt(os.path.join(match_dir, "matches.fQ.txt"), geo)
         print(f"number of geometric matches : {pose.n_geometric_views}")     # :458
         print(f"mapFeatTo3DFeat size = {pose.n_matches_2d3d}")               # :476

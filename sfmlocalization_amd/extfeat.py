@@ -8,8 +8,8 @@ the map-building client of the same C ABI:
 
 extractAKAZE (AKAZEOpenCV.cpp:116-187) = sfmloc_akaze_detect_and_compute per image; matchAKAZE / trackAKAZE
 (MatchUtils.cpp:73-277) = sfmloc_match_pairs / sfmloc_track; geometricMatch (MatchUtils.cpp:372-420) =
-sfmloc_geometric_pairs.  Files that already exist are kept, as in the reference.  Guided matching (-gm) is not
-implemented (the flag is accepted and ignored with a message).
+sfmloc_geometric_pairs, with -gm under guided matching (the map builder's default, reconstructGraph.py:155-163).
+Files that already exist are kept, as in the reference.
 """
 import os
 import sys
@@ -146,14 +146,13 @@ def main(argv=None):
     if o["skipMathing"]:
         print("Skip matching option is set. Exit without feature matching.")
         return 1          # the reference returns 1 here (:147)
-    if o["guidedMatch"]:
-        print("guided matching is not implemented; continuing without it", file=sys.stderr)
 
     off, desc, kpt = _load_bank(views)
     wh = np.array([[v["w"], v["h"]] for v in views], np.uint32)
     idx_of = {vid: k for k, vid in enumerate(ids)}
     params = capi.default_params(dist_ratio=o["fdistratio"], ransac_round=o["ransacround"],
-                                 geom_precision=float(o["geomError"]), device=o["device"])
+                                 geom_precision=float(o["geomError"]), device=o["device"],
+                                 guided_matching=int(bool(o["guidedMatch"])))       # -gm: MatchUtils.cpp:413-415
     put_path = os.path.join(match_dir, "matches.putative.txt")
     f_path = os.path.join(match_dir, "matches.f.txt")
     with capi.Map(np.array(ids, np.uint32), off, desc, params=params, view_wh=wh, kpt_xy=kpt) as dm:

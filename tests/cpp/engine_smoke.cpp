@@ -40,6 +40,8 @@ int main(int argc, char **argv) {
       printf("%zu\n", p2.size() / 2);
       for (int i : inl) printf("%d ", i);
       printf("\n%zu\n", times.size());
+      for (double v : times) printf("%.9g ", v);
+      printf("%.9g\n", eng.lastTotalSeconds());
       return 0;
     }
     std::vector<uint8_t> raw;
@@ -71,6 +73,8 @@ int main(int argc, char **argv) {
     printf("%zu\n", p2.size() / 2);
     for (int i : inl) printf("%d ", i);
     printf("\n%zu\n", times.size());
+    for (double v : times) printf("%.9g ", v);   // the six buckets of LocalizeEngine.cc:651-657, then the call's wall time
+    printf("%.9g\n", eng.lastTotalSeconds());
   } catch (const std::exception &e) {
     fprintf(stderr, "%s\n", e.what());
     return 1;

@@ -61,6 +61,41 @@ def test_track_mode_end_to_end(tmp_path, oracle_c):
     assert all(os.path.getmtime(match_dir / p) == t for p, t in stamp.items() if p != "image_describer.txt")
 
 
+def test_guided_matching_end_to_end(tmp_path, oracle_c):
+    """-gm (the map builder's default, reconstructGraph.py:155-163): matches.f.txt holds, for every pair that passes the
+    F-matrix AC-RANSAC, OpenMVG's guided matches under the estimated F over ALL features of both images -- equal to the
+    oracle's, different from the unguided file, and identical from the C++ tool."""
+    import shutil
+    import subprocess
+    match_dir, names = render_sequence(tmp_path)
+    assert extfeat.main([str(match_dir), "-mf=3", "-mm=20", "-r=200", "-gm"]) == 0
+    bases = [os.path.splitext(n)[0] for n in names]
+    descs = [fileio.read_desc(match_dir / (b + ".desc")) for b in bases]
+    kps = [fileio.read_feat(match_dir / (b + ".feat"))[:, :2] for b in bases]
+    put = fileio.read_matches_txt(match_dir / "matches.putative.txt")
+    kept = {k: v for k, v in put.items() if len(v[0]) >= 20}
+    geo = fileio.read_matches_txt(match_dir / "matches.f.txt")
+    egeo = opipe.geometric_match(kps, [(W, H)] * len(names), list(range(len(names))), kept, ransac_round=200,
+                                 guided=True, descs=descs)
+    plain = opipe.geometric_match(kps, [(W, H)] * len(names), list(range(len(names))), kept, ransac_round=200)
+    assert list(geo) == list(egeo) == list(plain) and len(geo) >= 4
+    n_diff = 0
+    for k in egeo:
+        np.testing.assert_array_equal(geo[k][0], egeo[k][0])
+        np.testing.assert_array_equal(geo[k][1], egeo[k][1])
+        assert (np.diff(geo[k][0].astype(np.int64)) > 0).all()           # one match per feature of I, ascending
+        n_diff += int(len(geo[k][0]) != len(plain[k][0]) or not np.array_equal(np.sort(plain[k][0]), geo[k][0]))
+    assert n_diff >= 1                                                    # guided matching changes the map's matches
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sfmlocalization_amd", "bin",
+                       "ExtFeatAndMatch")
+    match_cc = tmp_path / "matches_cc"
+    match_cc.mkdir()
+    shutil.copy(match_dir / "sfm_data.json", match_cc / "sfm_data.json")
+    r = subprocess.run([exe, str(match_cc), "-mf=3", "-mm=20", "-r=200", "-gm"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert (match_cc / "matches.f.txt").read_bytes() == (match_dir / "matches.f.txt").read_bytes()
+
+
 def test_pair_modes(tmp_path, oracle_c):
     match_dir, names = render_sequence(tmp_path, n=4)
     assert extfeat.main([str(match_dir), "-sm"]) == 1            # extraction only; the reference returns 1 here

@@ -241,6 +241,12 @@ def test_engine_mirror_return_convention(toy):
     r0, ex0 = e0.localize(desc, kp, 640, 480, return_time=True)
     r1, _ = e1.localize(desc, kp, 640, 480)
     assert len(r0) == 12 and len(r1) == 12 and len(ex0["times"]) == 6        # LocalizeEngine.cc:593-602,651-657
+    # the reference's stage buckets: putMatch, geoMatch and PnP come from this query's HIP events, are non-zero and sum
+    # to no more than the call's wall time; no iBeacon / BoW / extraction stage ran in this call
+    t = ex0["times"]
+    assert t[0] == 0.0 and t[1] == 0.0 and t[2] == 0.0 and min(t[3:]) > 0.0 and sum(t) <= ex0["time_total"]
+    ss = list(ex0["pose"].stage_seconds)
+    assert abs(sum(ss) - ex0["time_total"]) < 0.05 and ss[6] >= 0.0
     c0, R0 = np.array(r0[:3]), np.array(r0[3:]).reshape(3, 3)
     c1, R1 = np.array(r1[:3]), np.array(r1[3:]).reshape(3, 3)
     np.testing.assert_allclose(c1, A[:, :3] @ c0 + A[:, 3], atol=1e-9)
@@ -266,10 +272,13 @@ def test_engine_mirror_return_convention(toy):
         assert r.returncode == 0, r.stderr
         lines = r.stdout.strip().split("\n")
         vals = [] if lines[0] == "FAIL" else [float(x) for x in lines[0].split()]
+        run_cpp.times = [float(x) for x in lines[4].split()] if len(lines) > 4 else []
         return vals, int(lines[1]), [int(x) for x in lines[2].split()], int(lines[3])
 
     v0, n23, inl, ntimes = run_cpp("-")
     assert v0 == r0 and ntimes == 6 and n23 == ex0["pose"].n_matches_2d3d and len(inl) == ex0["pose"].n_inliers
+    ct = run_cpp.times                        # six buckets + the call's wall time, from the C++ class
+    assert len(ct) == 7 and ct[0] == 0.0 and min(ct[3:6]) > 0.0 and sum(ct[:6]) <= ct[6]
     v1, _, _, _ = run_cpp(str(root / "Amat.yml"))
     np.testing.assert_allclose(v1, r1, rtol=0, atol=1e-12)
     vfar, _, _, _ = run_cpp("-", ["1000", "1000", "1000", "1"])

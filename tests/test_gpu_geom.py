@@ -335,6 +335,51 @@ def test_concurrent_contexts_equal_sequential(oracle_c):
             dq.close()
 
 
+def test_guided_matching_in_the_query_path(oracle_c):
+    """params.guided_matching (-gm, localization.cpp:82,183,451 / LocalizeEngine.cc:459): every view that passes the
+    F-matrix filter gets OpenMVG's guided matches under its estimated F; the 2D-3D set then keeps a guided match only when
+    its query feature has a putative distance for that view (featDist, SfMDataUtils.cpp:105-106).  Stage lists, the
+    2D-3D set, inliers and pose against the oracle, bit for bit; a radial intrinsic and the sharded path included."""
+    for seed, radial in ((61, False), (62, True)):
+        m = make_scene(seed)
+        if radial:
+            m.intrinsic = tuple(m.intrinsic[:3]) + (0.05, -0.02, 0.001)
+        dm = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, guided_matching=1),
+                   view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+                   landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+        n_ok = n_changed = 0
+        for k in range(4):
+            q = synth.make_query(m, 640 + k, n_feat=700, n_copies=230, outlier_frac=0.3, place=k % 4)
+            exp = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), guided=True)
+            plain = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height))
+            dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
+            dm.match_putative(dq)
+            dm.geometric_filter(dq)
+            gc, gi, gj = dm.geometric_read_pairs()
+            np.testing.assert_array_equal(gc, exp["geo_count"])
+            for v in np.nonzero(gc)[0]:
+                o0, n = int(m.view_off[v]), int(gc[v])
+                np.testing.assert_array_equal(gi[o0:o0 + n], exp["geo_idx"][o0:o0 + n])
+                np.testing.assert_array_equal(gj[o0:o0 + n], exp["geo_j"][o0:o0 + n])
+            with pytest.raises(S.SfmlocError):
+                dm.geometric_read()                     # guided matches are not indices into the putative lists
+            dm.match_set(dq)
+            qf, lm, p2, p3 = dm.match_set_read()
+            np.testing.assert_array_equal(qf, exp["ms_qfeat"])
+            np.testing.assert_array_equal(lm, exp["ms_landmark"])
+            pose, pq, pl = dm.localize(dq)
+            assert bool(pose.ok) == exp["ok"]
+            if exp["ok"]:
+                n_ok += 1
+                np.testing.assert_array_equal(pq, exp["pair_qfeat"])
+                np.testing.assert_array_equal(pl, exp["pair_landmark"])
+                np.testing.assert_array_equal(bits(np.array(pose.P)), bits(exp["P"].ravel()))
+            n_changed += int(not np.array_equal(exp["geo_count"], plain["geo_count"]))
+            dq.close()
+        assert n_ok >= 3 and n_changed >= 1          # guided matching does change the lists
+        dm.close()
+
+
 def test_sharded_map_equals_unsharded(oracle_c):
     """Two shards of one map on one GPU: parts exported by sfmloc_shard_begin/_export, concatenated as the
     all-gather would, merged by sfmloc_merge_begin -> exactly the unsharded sfmloc_localize result; the exported
