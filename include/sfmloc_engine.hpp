@@ -186,7 +186,7 @@ class LocalizeEngine {
       throw std::runtime_error(sfmloc_last_error());
     sfmloc_pose pose;
     std::memset(&pose, 0, sizeof(pose));
-    std::vector<uint32_t> pq(4096), pl(4096);
+    std::vector<uint32_t> pq(65536), pl(65536);  // a query has at most 65 535 features, hence inliers
     if (bReturnTime) sfmloc_set_profile(mMap, 1);  // the reference's `times` come from this query's per-stage events
     const uint32_t *selp = useSel ? sel.data() : nullptr;
     const uint32_t nsel = useSel ? (uint32_t)sel.size() : 0;
@@ -194,8 +194,8 @@ class LocalizeEngine {
     // path run as one call, the shortlist staying on the device
     const int rc = (bow && mBowKnnNum > 0)
                        ? sfmloc_localize_bow(mMap, q, bow->data(), (uint32_t)mBowKnnNum, selp, nsel, &pose, pq.data(),
-                                             pl.data(), 4096)
-                       : sfmloc_localize(mMap, q, selp, nsel, &pose, pq.data(), pl.data(), 4096);
+                                             pl.data(), 65536)
+                       : sfmloc_localize(mMap, q, selp, nsel, &pose, pq.data(), pl.data(), 65536);
     if (bReturnTime) sfmloc_set_profile(mMap, mProfile);
     if (rc) {
       sfmloc_query_destroy(q);
@@ -203,13 +203,13 @@ class LocalizeEngine {
     }
     if (bReturnKeypoints && pose.n_matches_2d3d > 0) {
       const uint32_t cap = (uint32_t)pose.n_matches_2d3d;
-      std::vector<uint32_t> qf(cap), lm(cap), inl(4096);
+      std::vector<uint32_t> qf(cap), lm(cap), inl(65536);
       points2D.assign((size_t)cap * 2, 0.0);
       points3D.assign((size_t)cap * 3, 0.0);
       uint32_t n2 = 0;
       sfmloc_pose tmp;
       if (sfmloc_match_set_read(mMap, &n2, qf.data(), lm.data(), points2D.data(), points3D.data(), cap) ||
-          sfmloc_pose_read(mMap, &tmp, nullptr, nullptr, inl.data(), 4096)) {
+          sfmloc_pose_read(mMap, &tmp, nullptr, nullptr, inl.data(), 65536)) {
         sfmloc_query_destroy(q);
         throw std::runtime_error(sfmloc_last_error());
       }

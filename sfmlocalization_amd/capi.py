@@ -644,7 +644,7 @@ class Map:
     def resection(self, q):
         _check(_L().sfmloc_resection(self._h, q._h))
 
-    def pose_read(self, cap=4096):
+    def pose_read(self, cap=65536):
         pose = Pose()
         pq = np.zeros(cap, np.uint32)
         pl = np.zeros(cap, np.uint32)
@@ -654,7 +654,7 @@ class Map:
         k = pose.n_inliers if pose.ok else 0
         return pose, pq[:k].copy(), pl[:k].copy(), ii[:k].copy()
 
-    def localize(self, q, view_sel=None, cap=4096):
+    def localize(self, q, view_sel=None, cap=65536):
         """sfmloc_localize: the whole per-query path; -> (Pose, pair_qfeat, pair_landmark)."""
         pose = Pose()
         pq = np.zeros(cap, np.uint32)
@@ -674,7 +674,7 @@ class Map:
         _check(_L().sfmloc_map_view_sizes(self._h, _ptr(wh, C.c_uint32)))
         return wh
 
-    def localize_bow(self, q, query_bow, knn, cand_views=None, cap=4096):
+    def localize_bow(self, q, query_bow, knn, cand_views=None, cap=65536):
         """sfmloc_localize_bow: BoW shortlist (when more than knn candidates remain) + the whole path in one call on
         the map's own context; -> (Pose, pair_qfeat, pair_landmark)."""
         pose = Pose()
@@ -934,7 +934,7 @@ class Context:
     def merge_begin(self, q, parts_dev_ptr, n_parts, cap, part_stride=0):
         _check(_L().sfmloc_merge_begin(self._h, q._h, C.c_void_p(parts_dev_ptr), n_parts, cap, part_stride))
 
-    def end(self, cap=4096):
+    def end(self, cap=65536):
         pose = Pose()
         pq = np.zeros(cap, np.uint32)
         pl = np.zeros(cap, np.uint32)

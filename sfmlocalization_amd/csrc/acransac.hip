@@ -305,17 +305,13 @@ struct FFilterArgs {
   const double *L10;
   uint32_t *geo_count, *geo_idx;
   double *geo_model;  // [view][10]: the winning F (normalised frame) and its errorMax, for guided matching; or null
+  uint32_t *large_count, *large_list;  // views with more than kFMaxM matches, queued for k_fmatrix_large (or null)
   int *status;
   int skip_le;  // k_fmatrix_filter leaves views with at most this many putative matches to k_fmatrix_fast
 };
 
-struct FShared {
-  uint64_t key[kFMaxM];
-  uint32_t idx[kFMaxM];
-  int32_t vec_index[kFMaxM];
-  int32_t best_inl[kFMaxM];
-  float logc_n[kFMaxM + 1];
-  float logc_k[kFMaxM + 1];
+// small per-view state of the block-wide form (always in LDS)
+struct FSmall {
   double pre_models[kFPre][27];
   int pre_nm[kFPre];
   double cur_models[27];
@@ -325,26 +321,55 @@ struct FShared {
   int red_k[kThreads / 64];
 };
 
-__global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
-  extern __shared__ unsigned char smem_raw[];
-  FShared &S = *reinterpret_cast<FShared *>(smem_raw);
+// where the per-match arrays of one view live: LDS for up to kFMaxM putative matches ...
+struct FShared {
+  uint64_t key[kFMaxM];
+  uint32_t idx[kFMaxM];
+  int32_t vec_index[kFMaxM];
+  int32_t best_inl[kFMaxM];
+  float logc_n[kFMaxM + 1];
+  float logc_k[kFMaxM + 1];
+  FSmall small;
+};
+struct FStoreLds {
+  FShared *S;
+  __device__ __forceinline__ uint64_t *key() const { return S->key; }
+  __device__ __forceinline__ uint32_t *idx() const { return S->idx; }
+  __device__ __forceinline__ int32_t *vec_index() const { return S->vec_index; }
+  __device__ __forceinline__ int32_t *best_inl() const { return S->best_inl; }
+  __device__ __forceinline__ float *logc_n() const { return S->logc_n; }
+  __device__ __forceinline__ float *logc_k() const { return S->logc_k; }
+};
+// ... and one of a few global-memory slots for a view with more (k_fmatrix_large): the reference has no limit on the
+// matches of a pair (MatchUtils.cpp:346-355), a near-duplicate of a map frame reaches several thousand
+constexpr int kFLargeMaxM = 65536;  // matches per view the slots hold (the log10 table and 16-bit query indices end there)
+constexpr int kFLargeSlots = 8;
+struct FStoreGlobal {
+  uint64_t *k;
+  uint32_t *i;
+  int32_t *vi, *bi;
+  float *ln, *lk;
+  __device__ __forceinline__ uint64_t *key() const { return k; }
+  __device__ __forceinline__ uint32_t *idx() const { return i; }
+  __device__ __forceinline__ int32_t *vec_index() const { return vi; }
+  __device__ __forceinline__ int32_t *best_inl() const { return bi; }
+  __device__ __forceinline__ float *logc_n() const { return ln; }
+  __device__ __forceinline__ float *logc_k() const { return lk; }
+};
+
+// F-matrix AC-RANSAC of ONE view by the whole workgroup (block-wide sort); `st` says where the per-match arrays are,
+// `max_m` how many matches they hold.  Returns false when the view has more matches than that.
+template <typename Store>
+__device__ bool fmatrix_filter_view(const FFilterArgs &A, uint32_t v, Store st, FSmall &S, int max_m) {
   const int tid = threadIdx.x;
-  const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
   const int m = (int)A.put_count[v];
   const uint32_t off = A.view_off[v];
   constexpr int s = 7;
-  if (m <= A.skip_le) return;
   if (m < A.min_putative || m <= s) {  // localization.cpp:408-415 ; ACRANSAC: nData <= sizeSample
     if (tid == 0) A.geo_count[v] = 0;
-    return;
+    return true;
   }
-  if (m > kFMaxM) {
-    if (tid == 0) {
-      A.geo_count[v] = 0;
-      atomicOr(A.status, 1);
-    }
-    return;
-  }
+  if (m > max_m) return false;
   // NormalizePoints(x, w, h) for both images
   const int w1 = (int)A.view_wh[2 * v], h1 = (int)A.view_wh[2 * v + 1];
   const int w2 = (int)A.qw, h2 = (int)A.qh;
@@ -375,7 +400,7 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
     return seven_point(x1, x2, models);
   };
 
-  logcombi_tables_block(s, m, A.L10, reinterpret_cast<double *>(S.key), S.logc_n, S.logc_k);  // S.key: free until the first sort
+  logcombi_tables_block(s, m, A.L10, reinterpret_cast<double *>(st.key()), st.logc_n(), st.logc_k());  // the key array is free until the first sort
 
   double min_nfa = pos_inf();
   int n_in = 0;
@@ -410,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
       if (tid == 0) {
         int32_t smp[7];
         double mm[27];
-        ac_sample<7>(S.vec_index, n_index, A.seed, STAGE_FMATRIX, stream, (uint32_t)iter, smp);
+        ac_sample<7>(st.vec_index(), n_index, A.seed, STAGE_FMATRIX, stream, (uint32_t)iter, smp);
         const int k = solve(smp, mm);
         S.cur_nm = k;
         for (int q = 0; q < 9 * k; ++q) S.cur_models[q] = mm[q];
@@ -431,18 +456,18 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
           point(p, x, y, u, w);
           kv = d2u(err_fmatrix(M, x, y, u, w));
         }
-        S.key[p] = kv;
-        S.idx[p] = (uint32_t)p;
+        st.key()[p] = kv;
+        st.idx()[p] = (uint32_t)p;
       }
       __syncthreads();
-      bitonic_sort(S.key, S.idx, P);
-      const NfaBest b = best_nfa_block(S.key, m, s, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k, S.red_nfa,
+      bitonic_sort(st.key(), st.idx(), P);
+      const NfaBest b = best_nfa_block(st.key(), m, s, max_thr, logalpha0, 0.5, loge0, st.logc_n(), st.logc_k(), S.red_nfa,
                                        S.red_k);
       if (b.nfa < min_nfa) {
         better = true;
         min_nfa = b.nfa;
         n_in = b.k;
-        for (int p = tid; p < n_in; p += kThreads) S.best_inl[p] = (int32_t)S.idx[p];
+        for (int p = tid; p < n_in; p += kThreads) st.best_inl()[p] = (int32_t)st.idx()[p];
         if (tid < 9) S.best_model[tid] = M[tid];
       }
     }
@@ -452,7 +477,7 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
         n_reserve--;
       } else {
         __syncthreads();
-        for (int p = tid; p < n_in; p += kThreads) S.vec_index[p] = S.best_inl[p];
+        for (int p = tid; p < n_in; p += kThreads) st.vec_index()[p] = st.best_inl()[p];
         n_index = n_in;
         identity = false;
         if (n_reserve) {
@@ -465,17 +490,64 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
   __syncthreads();
   if (min_nfa >= 0.0) n_in = 0;
   if ((double)n_in > 7 * 2.5) {
-    for (int p = tid; p < n_in; p += kThreads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
+    for (int p = tid; p < n_in; p += kThreads) A.geo_idx[off + p] = (uint32_t)st.best_inl()[p];
     if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
     if (A.geo_model && tid == 0) {  // errorMax = the residual of the last inlier (the list ascends by residual)
       double x, y, u, w;
-      point(S.best_inl[n_in - 1], x, y, u, w);
+      point(st.best_inl()[n_in - 1], x, y, u, w);
       double *gm = A.geo_model + 10 * (size_t)v;
       for (int q = 0; q < 9; ++q) gm[q] = S.best_model[q];
       gm[9] = err_fmatrix(S.best_model, x, y, u, w);
     }
   } else if (tid == 0) {
     A.geo_count[v] = 0;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
+  extern __shared__ unsigned char smem_raw[];
+  FShared &S = *reinterpret_cast<FShared *>(smem_raw);
+  const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
+  const int m = (int)A.put_count[v];
+  if (m <= A.skip_le) return;
+  if (!fmatrix_filter_view(A, v, FStoreLds{&S}, S.small, kFMaxM)) {
+    // more matches than the LDS form holds: queue the view for k_fmatrix_large
+    if (threadIdx.x == 0) {
+      A.geo_count[v] = 0;
+      if (A.large_list) {
+        const uint32_t slot = atomicAdd(A.large_count, 1u);
+        A.large_list[slot] = v;
+      } else {
+        atomicOr(A.status, 1);
+      }
+    }
+  }
+}
+
+// The views k_fmatrix_filter queued (more than kFMaxM putative matches): kFLargeSlots persistent workgroups, each
+// owning one global-memory slot, take them in turn.  Same algorithm, same arithmetic, same results; the sort runs
+// through L2 instead of LDS, which costs milliseconds for such a view instead of failing the query.
+struct FLargeArgs {
+  uint64_t *key;
+  uint32_t *idx;
+  int32_t *vec_index, *best_inl;
+  float *logc_n, *logc_k;
+  int slot_m;  // matches one slot holds: a power of two >= the map's longest view, at most kFLargeMaxM
+};
+__global__ __launch_bounds__(kThreads) void k_fmatrix_large(FFilterArgs A, FLargeArgs W) {
+  __shared__ FSmall S;
+  const uint32_t n = *A.large_count;
+  const size_t o = (size_t)blockIdx.x * W.slot_m;
+  FStoreGlobal st{W.key + o, W.idx + o, W.vec_index + o, W.best_inl + o, W.logc_n + (size_t)blockIdx.x * (W.slot_m + 1),
+                  W.logc_k + (size_t)blockIdx.x * (W.slot_m + 1)};
+  for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+    const uint32_t v = A.large_list[t];
+    if (!fmatrix_filter_view(A, v, st, S, W.slot_m) && threadIdx.x == 0) {
+      A.geo_count[v] = 0;
+      atomicOr(A.status, 1);  // more than 65 536 matches in one view
+    }
+    __syncthreads();
   }
 }
 
@@ -818,22 +890,26 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
 // ---------------------------------------------------------------------------------------------------
 // K4: 2D-3D candidates and their de-duplication
 // ---------------------------------------------------------------------------------------------------
-// One wave per selected view: every geometric match whose map feature has a landmark becomes a candidate
+// Every geometric match whose map feature has a landmark is a candidate for its query feature, ranked by
 //   order key = dist << 48 | view_id << 24 | position in the view's geometric list
 // (smaller is better; equal distance -> earlier in std::map iteration order = lower view id, then list order).
 // dist = featDist[(v,q)][j] = d0 of the LAST putative match of the view that hit query feature j.
-__global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_sel, uint32_t n_sel,
-                                                         const uint32_t *view_off, const uint32_t *view_id,
-                                                         const uint32_t *put_count, const uint32_t *match_i,
-                                                         const uint32_t *match_key, const uint32_t *geo_count,
-                                                         const uint32_t *geo_idx,
-                                                         const uint32_t *geo_j /*null: geo_idx indexes the putative list;
-                                                                                 else (geo_idx, geo_j) = (map feature, query
-                                                                                 feature) of a guided match*/,
-                                                         const int32_t *row_landmark,
-                                                         const uint32_t *landmark_id, const double *landmark_X,
-                                                         Candidate *cand, uint32_t cap, uint32_t *n_cand,
-                                                         int *status, uint32_t min_putative, uint32_t *view_stats) {
+// matchProviderToMatchSet keeps ONE candidate per query feature (the minimum), so that is all a context -- or a shard --
+// ever materialises: pass 1 (k_emit_min) computes every candidate's key and keeps the per-feature minimum with
+// atomicMin, pass 2 (k_emit_win) turns the candidates that ARE the minimum into the part.  A part therefore holds at
+// most one candidate per query feature (<= 65 535): no capacity can overflow however many geometric matches the views
+// have, and a shard's exchange shrinks to its winners.
+constexpr uint16_t kNoDist = 0xFFFFu;
+
+__global__ __launch_bounds__(256) void k_emit_min(const uint32_t *view_sel, uint32_t n_sel, const uint32_t *view_off,
+                                                  const uint32_t *view_id, const uint32_t *put_count,
+                                                  const uint32_t *match_i, const uint32_t *match_key,
+                                                  const uint32_t *geo_count, const uint32_t *geo_idx,
+                                                  const uint32_t *geo_j /*null: geo_idx indexes the putative list; else
+                                                                          (geo_idx, geo_j) = (map feature, query feature)
+                                                                          of a guided match*/,
+                                                  const int32_t *row_landmark, unsigned long long *best64,
+                                                  uint16_t *geo_dist, uint32_t min_putative, uint32_t *view_stats) {
   // one workgroup (four waves) per selected view: the stage is a chain of dependent loads per candidate, so the waves
   // take 64 candidates each side by side instead of one wave walking them 64 at a time
   const uint32_t lane = threadIdx.x & 63u;
@@ -856,51 +932,87 @@ __global__ __launch_bounds__(256) void k_emit_candidates(const uint32_t *view_se
     for (uint32_t k = threadIdx.x; k < np; k += 256) keys[k] = match_key[off + k];
     __syncthreads();
   }
+  const uint64_t vkey = (uint64_t)(view_id[v] & 0xFFFFFFu) << 24;
   for (uint32_t p0 = (threadIdx.x >> 6) * 64; p0 < ng; p0 += 256) {
     const uint32_t p = p0 + lane;
-    bool has = false;
-    uint32_t j = 0, dist = 0;
-    int32_t lm = -1;
-    if (p < ng) {
-      uint32_t i;
-      if (geo_j) {
-        i = geo_idx[off + p];
-        j = geo_j[off + p];
-      } else {
-        const uint32_t pp = geo_idx[off + p];
-        i = match_i[off + pp];
-        j = match_key[off + pp] & 0xFFFFu;
-      }
-      lm = row_landmark[off + i];
-      has = lm >= 0;
+    if (p >= ng) continue;
+    uint32_t i, j;
+    if (geo_j) {
+      i = geo_idx[off + p];
+      j = geo_j[off + p];
+    } else {
+      const uint32_t pp = geo_idx[off + p];
+      i = match_i[off + pp];
+      j = match_key[off + pp] & 0xFFFFu;
     }
-    if (has) {
-      bool found = false;
+    uint16_t dist16 = kNoDist;
+    if (row_landmark[off + i] >= 0) {
       for (int32_t k = (int32_t)np - 1; k >= 0; --k) {  // last putative match with the same query feature
         const uint32_t kk = staged ? keys[k] : match_key[off + k];
         if ((kk & 0xFFFFu) == j) {
-          dist = kk >> 16;
-          found = true;
+          dist16 = (uint16_t)(kk >> 16);
           break;
         }
       }
       // featDist has no entry for a query feature no putative match of this view hit (only possible for guided
-      // matches): matchProviderToMatchSet then skips the match (SfMDataUtils.cpp:105-106)
-      has = found;
+      // matches): matchProviderToMatchSet then skips the match (SfMDataUtils.cpp:105-106) -> dist16 stays kNoDist
     }
-    // one atomic per wave step instead of one per candidate (a few thousand on one counter otherwise)
+    geo_dist[off + p] = dist16;
+    if (dist16 != kNoDist)
+      atomicMin(&best64[j], ((unsigned long long)dist16 << 48) | vkey | (unsigned long long)(p & 0xFFFFFFu));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_emit_win(const uint32_t *view_sel, uint32_t n_sel, const uint32_t *view_off,
+                                                  const uint32_t *view_id, const uint32_t *match_i,
+                                                  const uint32_t *match_key, const uint32_t *geo_count,
+                                                  const uint32_t *geo_idx, const uint32_t *geo_j,
+                                                  const int32_t *row_landmark, const uint32_t *landmark_id,
+                                                  const double *landmark_X, const unsigned long long *best64,
+                                                  const uint16_t *geo_dist, Candidate *cand, uint32_t cap,
+                                                  uint32_t *n_cand, int *status) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t gw = blockIdx.x;
+  if (gw >= n_sel) return;
+  const uint32_t v = view_sel ? view_sel[gw] : gw;
+  const uint32_t ng = geo_count[v];
+  if (ng == 0) return;
+  const uint32_t off = view_off[v];
+  const uint64_t vkey = (uint64_t)(view_id[v] & 0xFFFFFFu) << 24;
+  for (uint32_t p0 = (threadIdx.x >> 6) * 64; p0 < ng; p0 += 256) {
+    const uint32_t p = p0 + lane;
+    bool has = false;
+    uint32_t i = 0, j = 0;
+    unsigned long long order = 0;
+    if (p < ng) {
+      const uint16_t d = geo_dist[off + p];
+      if (d != kNoDist) {
+        if (geo_j) {
+          i = geo_idx[off + p];
+          j = geo_j[off + p];
+        } else {
+          const uint32_t pp = geo_idx[off + p];
+          i = match_i[off + pp];
+          j = match_key[off + pp] & 0xFFFFu;
+        }
+        order = ((unsigned long long)d << 48) | vkey | (unsigned long long)(p & 0xFFFFFFu);
+        has = best64[j] == order;
+      }
+    }
+    // one atomic per wave step instead of one per winner
     const unsigned long long mask = __ballot(has);
     uint32_t slot0 = 0;
     if (lane == 0 && mask) slot0 = atomicAdd(n_cand, (uint32_t)__popcll(mask));
     slot0 = __shfl(slot0, 0, 64);
     if (!has) continue;
     const uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (slot >= cap) {
+    if (slot >= cap) {  // cannot happen: at most one winner per query feature and cap >= SFMLOC_MAX_QUERY_ROWS
       atomicOr(status, 2);
       continue;
     }
+    const int32_t lm = row_landmark[off + i];
     Candidate c;
-    c.order = ((uint64_t)dist << 48) | ((uint64_t)(view_id[v] & 0xFFFFFFu) << 24) | (uint64_t)(p & 0xFFFFFFu);
+    c.order = order;
     c.qfeat = j;
     c.landmark_id = landmark_id[lm];
     c.X[0] = landmark_X[3 * lm];
@@ -1072,11 +1184,21 @@ __global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
     A.xn[2 * i] = A.pt2d[2 * i] * inv_f + cx;
     A.xn[2 * i + 1] = A.pt2d[2 * i + 1] * inv_f + cy;
   }
+  // (the table pass wants n / 2 + 1 doubles of scratch: LDS up to kP3pMaxN correspondences, global beyond)
   __shared__ double s_terms[kP3pMaxN / 2 + 1];
-  logcombi_tables_block(3, n, A.L10, s_terms, A.logc_n, A.logc_k);
+  logcombi_tables_block(3, n, A.L10, n > kP3pMaxN ? A.ws_terms : s_terms, A.logc_n, A.logc_k);
 }
 
 constexpr int kP3pWaveSeg = kP3pMaxN / 4;  // elements one wave sorts when the four models run side by side
+// More than kP3pMaxN correspondences (the reference has no limit, localization.cpp:479-509; a near-duplicate of a map
+// frame with thousands of landmarks gets there): the residual sort of a hypothesis runs in a global-memory segment
+// instead of LDS, and a round evaluates only the first kP3pLargeBatch hypotheses (that many segments exist).  Both
+// kernels derive the round's size and the inlier-list stride from the same device-side n.
+constexpr int kP3pLargeBatch = 64;
+__device__ __forceinline__ int p3p_round_batch(int n, int batch) {
+  return (n > kP3pMaxN && batch > kP3pLargeBatch) ? kP3pLargeBatch : batch;
+}
+__device__ __forceinline__ size_t p3p_inl_stride(int n, int max_n) { return n > kP3pMaxN ? (size_t)max_n : (size_t)kP3pMaxN; }
 
 struct P3pShared {
   uint64_t key[kP3pMaxN];
@@ -1093,13 +1215,17 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
   const P3pState &st = *A.state;
   if (st.done) return;
   const int b = blockIdx.x;
-  if (b >= batch) return;
+  const int n = st.n;
+  if (b >= p3p_round_batch(n, batch)) return;
   const long it = (long)st.iter + b;
   if (it >= st.n_iter) return;
   extern __shared__ unsigned char smem_raw[];
   P3pShared &S = *reinterpret_cast<P3pShared *>(smem_raw);
   const int tid = threadIdx.x;
-  const int n = st.n;
+  const size_t inl_stride = p3p_inl_stride(n, A.max_n);
+  // where the block-wide sort of this hypothesis runs
+  uint64_t *const skey = n > kP3pMaxN ? A.ws_key + (size_t)b * A.max_n : S.key;
+  uint32_t *const sidx = n > kP3pMaxN ? A.ws_idx + (size_t)b * A.max_n : S.idx;
   constexpr int s = 3;
   const int P = next_pow2(n);
   if (tid == 0) {
@@ -1179,7 +1305,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
       }
     if (best_m >= 0) {
       best_err = S.red_err[best_m];
-      int32_t *dst = A.hyp_inl + (size_t)b * A.max_n;
+      int32_t *dst = A.hyp_inl + (size_t)b * inl_stride;
       const uint32_t *src = S.idx + (size_t)best_m * kP3pWaveSeg;
       for (int p = tid; p < best_k; p += kThreads) dst[p] = (int32_t)src[p];
     }
@@ -1192,20 +1318,20 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
       uint64_t kv = ~0ull;
       if (p < n)
         kv = d2u(err_resection(M, A.pt3d[3 * p], A.pt3d[3 * p + 1], A.pt3d[3 * p + 2], A.xn[2 * p], A.xn[2 * p + 1]));
-      S.key[p] = kv;
-      S.idx[p] = (uint32_t)p;
+      skey[p] = kv;
+      sidx[p] = (uint32_t)p;
     }
     __syncthreads();
-    bitonic_sort(S.key, S.idx, P);
-    const NfaBest r = best_nfa_block(S.key, n, s, pos_inf(), logalpha0, 1.0, loge0, A.logc_n, A.logc_k, S.red_nfa,
+    bitonic_sort(skey, sidx, P);
+    const NfaBest r = best_nfa_block(skey, n, s, pos_inf(), logalpha0, 1.0, loge0, A.logc_n, A.logc_k, S.red_nfa,
                                      S.red_k);
     if (r.nfa < best) {  // strict: the first model of the hypothesis wins ties, as the sequential loop does
       best = r.nfa;
       best_k = r.k;
       best_m = k;
-      best_err = u2d(S.key[r.k - 1]);
-      int32_t *dst = A.hyp_inl + (size_t)b * A.max_n;
-      for (int p = tid; p < best_k; p += kThreads) dst[p] = (int32_t)S.idx[p];
+      best_err = u2d(skey[r.k - 1]);
+      int32_t *dst = A.hyp_inl + (size_t)b * inl_stride;
+      for (int p = tid; p < best_k; p += kThreads) dst[p] = (int32_t)sidx[p];
     }
   }
   if (tid == 0) {
@@ -1390,6 +1516,8 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
   P3pState &st = *A.state;
   if (st.done) return;
   const int tid = threadIdx.x;
+  batch = p3p_round_batch(st.n, batch);  // what k_p3p_eval evaluated this round
+  const size_t inl_stride = p3p_inl_stride(st.n, A.max_n);
   // every thread replays the same scalar state machine; only the copies are cooperative
   long iter0 = st.iter, n_iter = st.n_iter, n_reserve = st.n_reserve;
   const long n_iter_evaluated = n_iter;  // k_p3p_eval ran hypotheses iter0 <= it < min(iter0+batch, n_iter)
@@ -1474,7 +1602,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
     }
   }
   if (best_b >= 0) {
-    const int32_t *src = A.hyp_inl + (size_t)best_b * A.max_n;
+    const int32_t *src = A.hyp_inl + (size_t)best_b * inl_stride;
     for (int p = tid; p < n_in; p += kThreads) A.best_inl[p] = src[p];
     if (index_changed)
       for (int p = tid; p < n_in; p += kThreads) A.vec_index[p] = src[p];
@@ -1657,6 +1785,26 @@ int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *
   return SFMLOC_OK;
 }
 
+// global-memory slots of k_fmatrix_large, allocated the first time a map whose longest view exceeds the LDS form is used
+static int ensure_fmatrix_large(Ctx *c) {
+  if (c->fl_key) return SFMLOC_OK;
+  Map *m = c->map;
+  int slot_m = 64;
+  while (slot_m < (int)m->max_view_rows && slot_m < kFLargeMaxM) slot_m <<= 1;
+  c->fl_slot_m = slot_m;
+  const size_t n = (size_t)kFLargeSlots * slot_m, n1 = (size_t)kFLargeSlots * (slot_m + 1);
+  SFM_HIP(hipMalloc((void **)&c->fl_key, n * sizeof(uint64_t)));
+  SFM_HIP(hipMalloc((void **)&c->fl_idx, n * sizeof(uint32_t)));
+  SFM_HIP(hipMalloc((void **)&c->fl_vec_index, n * sizeof(int32_t)));
+  SFM_HIP(hipMalloc((void **)&c->fl_best_inl, n * sizeof(int32_t)));
+  SFM_HIP(hipMalloc((void **)&c->fl_logc_n, n1 * sizeof(float)));
+  SFM_HIP(hipMalloc((void **)&c->fl_logc_k, n1 * sizeof(float)));
+  SFM_HIP(hipMalloc((void **)&c->fl_count, sizeof(uint32_t)));
+  SFM_HIP(hipMalloc((void **)&c->fl_list, ((size_t)m->n_views + 1) * sizeof(uint32_t)));
+  c->hbm_bytes += n * 20 + n1 * 8 + ((size_t)m->n_views + 2) * 4;
+  return SFMLOC_OK;
+}
+
 int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, int min_putative) {
   Map *m = c->map;
   if (n_sel == 0) return SFMLOC_OK;
@@ -1683,6 +1831,15 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
   A.geo_model = m->params.guided_matching ? c->d_geo_model : nullptr;
   A.status = c->d_status;
   c->geo_is_pairs = false;
+  A.large_count = nullptr;
+  A.large_list = nullptr;
+  if (m->max_view_rows > (uint32_t)kFMaxM) {
+    int rc = ensure_fmatrix_large(c);
+    if (rc) return rc;
+    SFM_HIP(hipMemsetAsync(c->fl_count, 0, sizeof(uint32_t), c->stream));
+    A.large_count = c->fl_count;
+    A.large_list = c->fl_list;
+  }
   // views with <= kF2MaxM putative matches take the wave-parallel kernel, the rest (if any: the second launch
   // returns at once for the others) the block-wide one; SFMLOC_K3_FAST=0 sends every view to the latter
   static const bool fast = [] {
@@ -1703,6 +1860,18 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_fmatrix_filter, dim3(n_sel), dim3(kThreads), lds, c->stream, A);
   SFM_HIP(hipGetLastError());
+  if (A.large_list) {  // some view of this map can have more than kFMaxM matches: the queue's consumer
+    FLargeArgs W;
+    W.key = c->fl_key;
+    W.idx = c->fl_idx;
+    W.vec_index = c->fl_vec_index;
+    W.best_inl = c->fl_best_inl;
+    W.logc_n = c->fl_logc_n;
+    W.logc_k = c->fl_logc_k;
+    W.slot_m = c->fl_slot_m;
+    hipLaunchKernelGGL(k_fmatrix_large, dim3(kFLargeSlots), dim3(kThreads), 0, c->stream, A, W);
+    SFM_HIP(hipGetLastError());
+  }
   return SFMLOC_OK;
 }
 
@@ -1711,16 +1880,20 @@ int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_view
   if (!c->cleared) {
     SFM_HIP(hipMemsetAsync(c->d_cand_part, 0, kPartHeaderBytes, c->stream));
     SFM_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
+    SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
   }
   if (n_sel == 0 || q->n == 0) return SFMLOC_OK;
-  hipLaunchKernelGGL(k_emit_candidates, dim3(n_sel), dim3(256), 0, c->stream,
-                     all_views ? nullptr : c->d_view_sel, n_sel, m->d_view_off, m->d_view_id, c->d_view_count,
-                     c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx,
-                     c->geo_is_pairs ? c->d_geo_j : nullptr, m->d_row_landmark,
-                     m->d_landmark_id, m->d_landmark_X,
+  const uint32_t *sel = all_views ? nullptr : c->d_view_sel;
+  const uint32_t *gj = c->geo_is_pairs ? c->d_geo_j : nullptr;
+  hipLaunchKernelGGL(k_emit_min, dim3(n_sel), dim3(256), 0, c->stream, sel, n_sel, m->d_view_off, m->d_view_id,
+                     c->d_view_count, c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, gj, m->d_row_landmark,
+                     c->d_best64, c->d_geo_dist, (uint32_t)m->params.min_putative, c->d_view_stats);
+  SFM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_emit_win, dim3(n_sel), dim3(256), 0, c->stream, sel, n_sel, m->d_view_off, m->d_view_id,
+                     c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, gj, m->d_row_landmark, m->d_landmark_id,
+                     m->d_landmark_X, c->d_best64, c->d_geo_dist,
                      reinterpret_cast<Candidate *>(c->d_cand_part + kPartHeaderBytes), c->cand_cap,
-                     reinterpret_cast<uint32_t *>(c->d_cand_part), c->d_status, (uint32_t)m->params.min_putative,
-                     c->d_view_stats);
+                     reinterpret_cast<uint32_t *>(c->d_cand_part), c->d_status);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
@@ -1845,7 +2018,10 @@ static P3pArgs make_p3p_args(Ctx *c) {
   A.max_iteration = m->params.p3p_max_iteration;
   A.min_resection_points = m->params.min_resection_points;
   A.min_inliers = m->params.min_inliers;
-  A.max_n = kP3pMaxN;
+  A.max_n = (int)c->p3p_cap;
+  A.ws_key = c->d_p3p_ws_key;
+  A.ws_idx = c->d_p3p_ws_idx;
+  A.ws_terms = c->d_p3p_terms;
   A.refine_pose = m->params.refine_pose;
   A.seed = m->params.seed;
   A.stream = 0;

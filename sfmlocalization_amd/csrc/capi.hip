@@ -126,7 +126,9 @@ void free_ctx(Ctx *c) {
                   c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,
                   c->d_inlier_idx,
                   c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters, c->d_flagmask, c->d_rows_scratch, c->d_rows_arrivals, c->d_flagged_desc,
-                  c->d_geo_model, c->d_geo_j,     c->d_guided_row};
+                  c->d_geo_model, c->d_geo_j,     c->d_guided_row, c->d_geo_dist,
+                  c->fl_key, c->fl_idx, c->fl_count, c->fl_list, c->fl_vec_index, c->fl_best_inl, c->fl_logc_n, c->fl_logc_k,
+                  c->d_pair_qfeat_big, c->d_pair_landmark_big, c->d_p3p_ws_key, c->d_p3p_ws_idx, c->d_p3p_terms};
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -196,6 +198,7 @@ int make_ctx(Map *m, Ctx **out) {
     c->d_pair_landmark = r->pair_landmark;
   }
   CTX_TRY(dev_alloc(acct, &c->d_cand_part, (size_t)kPartHeaderBytes + (size_t)c->cand_cap * sizeof(Candidate)));
+  CTX_TRY(dev_alloc(acct, &c->d_geo_dist, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_best64, (size_t)65536));
   CTX_TRY(dev_alloc(acct, &c->d_winner, (size_t)65536));
   CTX_TRY(dev_alloc(acct, &c->d_ms_n, (size_t)1));
@@ -453,6 +456,49 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
   return rc;
 }
 
+}  // namespace
+
+// Grows the P3P workspace of a context to hold `n` correspondences (a query has at most one per feature).  Rare: only a
+// query with more than kP3pMaxN features gets here; the stream is drained first because the arrays are replaced.
+int ctx_p3p_reserve(Ctx *c, uint32_t n) {
+  if (n <= c->p3p_cap) return SFMLOC_OK;
+  uint32_t cap = c->p3p_cap;
+  while (cap < n) cap <<= 1;
+  SFM_HIP(hipStreamSynchronize(c->stream));
+  void *old[] = {c->d_xn, c->d_logc_n, c->d_logc_k, c->d_vec_index, c->d_best_inl, c->d_hyp_inl, c->d_inlier_idx,
+                 c->d_pair_qfeat_big, c->d_pair_landmark_big, c->d_p3p_ws_key, c->d_p3p_ws_idx, c->d_p3p_terms};
+  for (void *p : old)
+    if (p) hipFree(p);
+  c->d_xn = nullptr;
+  c->d_logc_n = c->d_logc_k = nullptr;
+  c->d_vec_index = c->d_best_inl = c->d_hyp_inl = nullptr;
+  c->d_inlier_idx = c->d_pair_qfeat_big = c->d_pair_landmark_big = nullptr;
+  c->d_p3p_ws_key = nullptr;
+  c->d_p3p_ws_idx = nullptr;
+  c->d_p3p_terms = nullptr;
+  // hypothesis inlier lists: kP3pBatchMax lists of kP3pMaxN, or (more correspondences) kP3pLargeBatch lists of cap
+  const size_t large_batch = 64;  // acransac.hip kP3pLargeBatch
+  const size_t hyp = std::max<size_t>((size_t)kP3pBatchMax * kP3pMaxN, large_batch * cap);
+  SFM_HIP(hipMalloc((void **)&c->d_xn, (size_t)cap * 2 * sizeof(double)));
+  SFM_HIP(hipMalloc((void **)&c->d_logc_n, ((size_t)cap + 1) * sizeof(float)));
+  SFM_HIP(hipMalloc((void **)&c->d_logc_k, ((size_t)cap + 1) * sizeof(float)));
+  SFM_HIP(hipMalloc((void **)&c->d_vec_index, (size_t)cap * sizeof(int32_t)));
+  SFM_HIP(hipMalloc((void **)&c->d_best_inl, (size_t)cap * sizeof(int32_t)));
+  SFM_HIP(hipMalloc((void **)&c->d_hyp_inl, hyp * sizeof(int32_t)));
+  SFM_HIP(hipMalloc((void **)&c->d_inlier_idx, (size_t)cap * sizeof(uint32_t)));
+  SFM_HIP(hipMalloc((void **)&c->d_pair_qfeat_big, (size_t)cap * sizeof(uint32_t)));
+  SFM_HIP(hipMalloc((void **)&c->d_pair_landmark_big, (size_t)cap * sizeof(uint32_t)));
+  SFM_HIP(hipMalloc((void **)&c->d_p3p_ws_key, large_batch * cap * sizeof(uint64_t)));
+  SFM_HIP(hipMalloc((void **)&c->d_p3p_ws_idx, large_batch * cap * sizeof(uint32_t)));
+  SFM_HIP(hipMalloc((void **)&c->d_p3p_terms, ((size_t)cap / 2 + 2) * sizeof(double)));
+  c->d_pair_qfeat = c->d_pair_qfeat_big;  // no longer inside the HostResult record
+  c->d_pair_landmark = c->d_pair_landmark_big;
+  c->p3p_cap = cap;
+  return SFMLOC_OK;
+}
+
+namespace {
+
 int ctx_fetch_result(Ctx *c) {
   HostResult *h = reinterpret_cast<HostResult *>(c->h_result);
   SFM_HIP(hipMemcpyAsync(h, c->d_result, sizeof(HostResult), hipMemcpyDeviceToHost, c->stream));
@@ -490,7 +536,9 @@ int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_se
 static int ctx_localize_begin_impl(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel) {
   c->t_begin = now_s();
   ClearedScope cs{c};
-  int rc = ctx_reset_for_query(c, q);
+  int rc = ctx_p3p_reserve(c, q->n);
+  if (rc) return rc;
+  rc = ctx_reset_for_query(c, q);
   if (rc) return rc;
   rc = ctx_match_putative(c, q, view_sel, n_sel, d_sel);
   if (rc) return rc;
@@ -522,14 +570,21 @@ int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *p
   out->status |= h->status;
   out->n_putative_views = (int32_t)h->view_stats[0];
   out->n_geometric_views = (int32_t)h->view_stats[1];
-  SFM_CHECK((out->status & 1) == 0, SFMLOC_ECAP, "a view has more than 2048 putative matches (F-matrix workspace)");
+  // (none of these can be reached with data the reference accepts: a view's matches beyond 65 536, an internal
+  // inconsistency of the candidate part, more correspondences than the query has features)
+  SFM_CHECK((out->status & 1) == 0, SFMLOC_ECAP, "a view has more than 65536 putative matches");
   SFM_CHECK((out->status & 2) == 0, SFMLOC_ECAP, "more than %u 2D-3D candidates (match-set workspace)", c->cand_cap);
-  SFM_CHECK((out->status & 4) == 0, SFMLOC_ECAP, "more than %d 2D-3D correspondences (P3P workspace)", kP3pMaxN);
+  SFM_CHECK((out->status & 4) == 0, SFMLOC_ECAP, "more than %u 2D-3D correspondences (P3P workspace)", c->p3p_cap);
   if (out->ok && out->n_inliers > 0 && (pair_qfeat || pair_landmark)) {
     const uint32_t k = (uint32_t)out->n_inliers;
     SFM_CHECK(cap >= k, SFMLOC_ECAP, "pair buffers hold %u entries, %u inliers", cap, k);
-    if (pair_qfeat) memcpy(pair_qfeat, h->pair_qfeat, k * sizeof(uint32_t));
-    if (pair_landmark) memcpy(pair_landmark, h->pair_landmark, k * sizeof(uint32_t));
+    if (c->p3p_cap > (uint32_t)kP3pMaxN) {  // the pair lists live outside the HostResult record
+      if (pair_qfeat) SFM_HIP(hipMemcpy(pair_qfeat, c->d_pair_qfeat, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      if (pair_landmark) SFM_HIP(hipMemcpy(pair_landmark, c->d_pair_landmark, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    } else {
+      if (pair_qfeat) memcpy(pair_qfeat, h->pair_qfeat, k * sizeof(uint32_t));
+      if (pair_landmark) memcpy(pair_landmark, h->pair_landmark, k * sizeof(uint32_t));
+    }
   }
   // the reference's `times` (LocalizeEngine.cc:643-658): with params.profile = 1 every stage of this query was
   // bracketed by HIP events on its stream -- selectBow = K8, putMatch = K1 + K2, geoMatch = K3, PnP = 2D-3D set + P3P
@@ -1000,7 +1055,7 @@ int sfmloc_geometric_read(sfmloc_map *map, uint32_t *geo_count, uint32_t *geo_id
   }
   int st = 0;
   SFM_HIP(hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
-  SFM_CHECK((st & 1) == 0, SFMLOC_ECAP, "a view has more than 2048 putative matches (F-matrix workspace)");
+  SFM_CHECK((st & 1) == 0, SFMLOC_ECAP, "a view has more than 65536 putative matches");
   return SFMLOC_OK;
 }
 
@@ -1079,6 +1134,8 @@ int sfmloc_resection(sfmloc_map *map, sfmloc_query *query) {
   int rc = check_stage(c, q, "sfmloc_resection");
   if (rc) return rc;
   SFM_HIP(hipSetDevice(m->device));
+  rc = ctx_p3p_reserve(c, q->n);
+  if (rc) return rc;
   {
     EventScope ev(c, SFMLOC_K_P3P);
     rc = ctx_resection_enqueue(c, true);
@@ -1097,7 +1154,7 @@ int sfmloc_pose_read(sfmloc_map *map, sfmloc_pose *out, uint32_t *pair_qfeat, ui
   SFM_HIP(hipSetDevice(m->device));
   SFM_HIP(hipStreamSynchronize(c->stream));
   SFM_HIP(hipMemcpy(out, c->d_pose, sizeof(Pose), hipMemcpyDeviceToHost));
-  SFM_CHECK((out->status & 4) == 0, SFMLOC_ECAP, "more than %d 2D-3D correspondences (P3P workspace)", kP3pMaxN);
+  SFM_CHECK((out->status & 4) == 0, SFMLOC_ECAP, "more than %u 2D-3D correspondences (P3P workspace)", c->p3p_cap);
   if (out->ok && out->n_inliers > 0) {
     const uint32_t k = (uint32_t)out->n_inliers;
     if (pair_qfeat || pair_landmark || inlier_idx)
@@ -1325,6 +1382,10 @@ static int merge_begin_impl(sfmloc_context *ctx, sfmloc_query *query, const void
   SFM_CHECK(q->n == 0 || q->d_kpt, SFMLOC_EINVAL, "sfmloc_merge_begin: the query was created without keypoints");
   SFM_HIP(hipSetDevice(m->device));
   c->t_begin = now_s();
+  {
+    const int rcr = ctx_p3p_reserve(c, q->n);
+    if (rcr) return rcr;
+  }
   SFM_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
   int rc;
   {

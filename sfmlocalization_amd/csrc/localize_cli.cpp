@@ -550,7 +550,7 @@ int main(int argc, char **argv) {
     }
     sfmloc_pose pose;
     memset(&pose, 0, sizeof(pose));
-    std::vector<uint32_t> pq(4096), pl(4096);
+    std::vector<uint32_t> pq(65536), pl(65536);  // a query has at most 65 535 features, hence inliers
     bool attempted = false;
     if (!(use_sel && sel.empty())) {
       std::vector<float> bow;
@@ -579,13 +579,16 @@ int main(int argc, char **argv) {
       const uint32_t *selp = use_sel ? sel.data() : nullptr;
       const uint32_t nsel = use_sel ? (uint32_t)sel.size() : 0;
       const int rc = have_bow ? sfmloc_localize_bow(map, q, bow.data(), (uint32_t)knn_bow, selp, nsel, &pose, pq.data(),
-                                                    pl.data(), 4096)
-                              : sfmloc_localize(map, q, selp, nsel, &pose, pq.data(), pl.data(), 4096);
+                                                    pl.data(), 65536)
+                              : sfmloc_localize(map, q, selp, nsel, &pose, pq.data(), pl.data(), 65536);
       sfmloc_query_destroy(q);
       if (rc) {
-        fprintf(stderr, "%s\n", sfmloc_last_error());
+        // an error on ONE image does not end the run: the reference writes a result file for every image
+        // (localization.cpp:441,530); this one gets the failure form and the exit status remembers it
+        fprintf(stderr, "%s: %s\n", img.c_str(), sfmloc_last_error());
         rc_all = 1;
-        break;
+        write_result_json(out_dir, img, sfm_json, match_dir, nullptr, nullptr, nullptr);
+        continue;
       }
       attempted = true;
     }

@@ -428,7 +428,7 @@ int sfmloc_geometric_pairs(sfmloc_map *map, const uint32_t *pairs, uint32_t n_pa
     if (c->last_query == q) c->last_query = nullptr;
     free_query(q);
     if (rc) return rc;
-    SFM_CHECK((status & 1) == 0, SFMLOC_ECAP, "a pair has more than 2048 putative matches (F-matrix workspace)");
+    SFM_CHECK((status & 1) == 0, SFMLOC_ECAP, "a pair has more than 65536 putative matches");
   }
   Matches *M = flatten(pm);
   SFM_CHECK(M, SFMLOC_ENOMEM, "out of host memory");

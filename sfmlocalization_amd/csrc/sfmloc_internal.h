@@ -81,6 +81,9 @@ struct P3pArgs {
   double *hyp_err, *hyp_model;
   int32_t *hyp_inl;
   uint32_t *pair_qfeat, *pair_landmark, *inlier_idx;
+  uint64_t *ws_key;  // [kP3pLargeBatch * max_n] sort segments for more than kP3pMaxN correspondences, or null
+  uint32_t *ws_idx;
+  double *ws_terms;  // [max_n / 2 + 1]
   double focal, ppx, ppy;
   int max_iteration, min_resection_points, min_inliers, max_n, refine_pose;
   uint64_t seed;
@@ -179,9 +182,17 @@ struct Ctx {
   uint32_t *d_geo_j = nullptr;        // [n_rows] query feature of each guided match (geo_idx then holds the map feature)
   uint32_t *d_guided_row = nullptr;   // [n_rows] per bank row: its guided query feature or SFMLOC_NOMATCH
   bool geo_is_pairs = false;          // the last geometric stage left (i, j) lists, not indices into the putative lists
+  // K3 for views with more putative matches than its LDS form holds (acransac.hip k_fmatrix_large): allocated on first use
+  uint64_t *fl_key = nullptr;
+  uint32_t *fl_idx = nullptr, *fl_count = nullptr, *fl_list = nullptr;
+  int32_t *fl_vec_index = nullptr, *fl_best_inl = nullptr;
+  float *fl_logc_n = nullptr, *fl_logc_k = nullptr;
+  int fl_slot_m = 0;
   int *d_status = nullptr;
-  unsigned char *d_cand_part = nullptr;  // this context's candidate part: header + cand_cap candidates
-  uint32_t cand_cap = 1u << 14;
+  unsigned char *d_cand_part = nullptr;  // this context's candidate part: header + cand_cap candidates (one per query
+                                         // feature at most, so 2^16 can never overflow)
+  uint32_t cand_cap = 1u << 16;
+  uint16_t *d_geo_dist = nullptr;        // [n_rows] per geometric match: its featDist, or 0xFFFF = not a candidate
   unsigned long long *d_best64 = nullptr;  // [65536]
   uint32_t *d_winner = nullptr;            // [65536]
   uint32_t *d_ms_n = nullptr, *d_ms_qfeat = nullptr, *d_ms_landmark = nullptr;  // [65536]
@@ -192,7 +203,15 @@ struct Ctx {
   double *d_hyp_nfa = nullptr, *d_hyp_err = nullptr, *d_hyp_model = nullptr;
   int *d_hyp_k = nullptr;
   int32_t *d_hyp_inl = nullptr;  // [kP3pBatchMax * kP3pMaxN]
-  uint32_t *d_pair_qfeat = nullptr, *d_pair_landmark = nullptr, *d_inlier_idx = nullptr;  // [kP3pMaxN]
+  uint32_t *d_pair_qfeat = nullptr, *d_pair_landmark = nullptr, *d_inlier_idx = nullptr;  // [p3p_cap]
+  // the P3P arrays hold p3p_cap correspondences: kP3pMaxN to begin with, regrown (ctx_p3p_reserve) when a query with
+  // more features arrives; beyond kP3pMaxN the pair lists leave HostResult for buffers of their own and the sort of a
+  // hypothesis gets a global-memory segment
+  uint32_t p3p_cap = kP3pMaxN;
+  uint32_t *d_pair_qfeat_big = nullptr, *d_pair_landmark_big = nullptr;
+  uint64_t *d_p3p_ws_key = nullptr;
+  uint32_t *d_p3p_ws_idx = nullptr;
+  double *d_p3p_terms = nullptr;
   P3pState *d_p3p_state = nullptr;
   Pose *d_pose = nullptr;
   unsigned char *d_result = nullptr;  // one HostResult record; the six pointers below alias into it
@@ -289,6 +308,7 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
                              uint64_t part_bytes, uint32_t cap, uint32_t packed_b = 0, uint32_t packed_qi = 0);
 int launch_export_packed(Ctx *c, void *dst_dev, uint32_t n_queries, uint32_t budget, uint32_t qi);
 uint64_t packed_part_bytes(uint32_t n_queries, uint32_t budget);
+int ctx_p3p_reserve(Ctx *c, uint32_t n_query_rows);  // capi.hip: grow the P3P workspace to a query's feature count
 int launch_p3p_init(Ctx *c);
 int launch_p3p_round(Ctx *c, int batch);
 

@@ -42,6 +42,19 @@ def unpack_part(buf, cap):
                          CANDIDATE_DTYPE)
 
 
+def reduce_candidates(cands):
+    """What a shard materialises of its candidates (k_emit_min / k_emit_win): per query feature only the one with the
+    smallest order key -- matchProviderToMatchSet keeps one per feature anyway.  Host restatement for the tests."""
+    cands = np.asarray(cands, CANDIDATE_DTYPE)
+    if len(cands) == 0:
+        return cands
+    o = np.lexsort((cands["order"], cands["qfeat"]))
+    c = cands[o]
+    first = np.ones(len(c), bool)
+    first[1:] = c["qfeat"][1:] != c["qfeat"][:-1]
+    return c[first]
+
+
 def shard_views(view_off, world):
     """Contiguous view ranges [v0, v1) per rank, balanced by descriptor count; a view is never split
     (so the per-view >=16 filter and F-matrix RANSAC stay shard-local)."""

@@ -300,6 +300,7 @@ def main(argv=None):
     except capi.SfmlocError as e:
         print(str(e), file=sys.stderr)
         return 1
+    rc_all = 0
     # the query's view index in the reference's match files: id of the LAST view of sfm_data + 1 (localization.cpp:371)
     ind_query_file = int(eng.map.view_id[-1]) + 1 if eng.map.n_views else 0
     if packed:
@@ -353,7 +354,15 @@ def main(argv=None):
                     if dense is None:
                         dense = DenseBow(o["bowModelFile"], o["pcaModelFile"] or None, device=o["device"])
                     bow = dense.compute(bgr)
-        res, ex = eng.localize(desc, feat[:, :2], w, h, center=center, radius=o["cenRadius"], bow=bow)
+        try:
+            res, ex = eng.localize(desc, feat[:, :2], w, h, center=center, radius=o["cenRadius"], bow=bow)
+        except capi.SfmlocError as e:
+            # an error on ONE image does not end the run: the reference writes a result file for every image
+            # (localization.cpp:441,530); this one gets the failure form and the exit status remembers it
+            print(f"{img}: {e}", file=sys.stderr)
+            rc_all = 1
+            fileio.write_result_json(out_dir, img, sfm_json, match_dir)
+            continue
         pose = ex.get("pose")
         if pose is None:                                # no view near the given position: nothing was matched
             print("Not enough putative matches")
@@ -391,7 +400,7 @@ def main(argv=None):
     eng.close()
     if dense is not None:
         dense.close()
-    return 0
+    return rc_all
 
 
 if __name__ == "__main__":

@@ -113,7 +113,8 @@ class OracleShardCompute:
         cands = []
         for i, q in enumerate(queries):
             kw = {} if sels is None else {"view_sel": sels[i]}
-            cands.append(opipe.shard_candidates(self.m, q.desc, q.kpt_xy, (q.width, q.height), self.v0, self.v1, **kw))
+            cands.append(D.reduce_candidates(
+                opipe.shard_candidates(self.m, q.desc, q.kpt_xy, (q.width, q.height), self.v0, self.v1, **kw)))
         return torch.from_numpy(D.pack_batch(cands, cap))
 
     def stage1(self, queries, slot=0, budget=0):

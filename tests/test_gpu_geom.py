@@ -335,6 +335,50 @@ def test_concurrent_contexts_equal_sequential(oracle_c):
             dq.close()
 
 
+def test_no_size_limits_near_duplicate_of_a_large_frame(oracle_c):
+    """The reference has no limit on the matches of a view (MatchUtils.cpp:346-355) or on the 2D-3D correspondences
+    (localization.cpp:479-509).  A 5 200-feature query that nearly duplicates 5 000-row map frames: several thousand
+    putative matches per view (beyond the 2 048 the LDS form of K3 sorts -> k_fmatrix_large) and more than 4 096
+    correspondences (beyond the LDS form of K5 -> global sort segments, regrown P3P workspace, pair lists outside the
+    result record).  Every stage equal to the oracle, as for small inputs; whole-path and concurrent-context forms too."""
+    m = synth.make_map(71, n_views=5, desc_per_view=5000, views_per_place=5, landmarks_per_place=6000, obs_per_view=4900,
+                       map_flips=8)
+    p3p_it = 400                                   # the oracle's P3P sorts n residuals per model: keep the test short
+    dm = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, p3p_max_iteration=p3p_it),
+               view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+               landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    q = synth.make_query(m, 710, n_feat=5200, n_copies=4900, outlier_frac=0.05, query_flips=10)
+    exp, pose = compare_stages(m, q, dm, p3p_max_iteration=p3p_it)
+    assert exp["put_count"].max() > 2048, exp["put_count"]          # the K3 case
+    assert len(exp["ms_qfeat"]) > 4096, len(exp["ms_qfeat"])        # the K5 case
+    assert exp["ok"] and exp["n_inliers"] > 4096                    # ... and more inliers than the result record holds
+    # the whole path in one call, and through a context (the workspace regrows once per context)
+    dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
+    p1, pq1, pl1 = dm.localize(dq)
+    ctx = dm.context()
+    ctx.begin(dq)
+    p2, pq2, pl2 = ctx.end()
+    for p, pq, pl in ((p1, pq1, pl1), (p2, pq2, pl2)):
+        assert p.ok and p.n_inliers == exp["n_inliers"]
+        np.testing.assert_array_equal(pq, exp["pair_qfeat"])
+        np.testing.assert_array_equal(pl, exp["pair_landmark"])
+        np.testing.assert_array_equal(bits(np.array(p.P)), bits(exp["P"].ravel()))
+    # a small query afterwards on the same (regrown) context: unchanged behaviour
+    qs = synth.make_query(m, 711, n_feat=600, n_copies=250)
+    es = opipe.localize(m, qs.desc, qs.kpt_xy, (qs.width, qs.height), p3p_max_iteration=p3p_it)
+    dqs = dm.query(qs.desc, qs.kpt_xy, qs.width, qs.height)
+    ctx.begin(dqs)
+    p3, pq3, pl3 = ctx.end()
+    assert bool(p3.ok) == es["ok"]
+    if es["ok"]:
+        np.testing.assert_array_equal(pq3, es["pair_qfeat"])
+        np.testing.assert_array_equal(bits(np.array(p3.P)), bits(es["P"].ravel()))
+    ctx.close()
+    dq.close()
+    dqs.close()
+    dm.close()
+
+
 def test_guided_matching_in_the_query_path(oracle_c):
     """params.guided_matching (-gm, localization.cpp:82,183,451 / LocalizeEngine.cc:459): every view that passes the
     F-matrix filter gets OpenMVG's guided matches under its estimated F; the 2D-3D set then keeps a guided match only when
@@ -413,8 +457,10 @@ def test_sharded_map_equals_unsharded(oracle_c):
             c.sync()
             c.close()
             v0, v1 = ranges[s]
-            exp_c = opipe.shard_candidates(m, q.desc, q.kpt_xy, (q.width, q.height), v0, v1)
+            # a shard exports its winners only: per query feature the candidate with the smallest order key
+            exp_c = D.reduce_candidates(opipe.shard_candidates(m, q.desc, q.kpt_xy, (q.width, q.height), v0, v1))
             got_c = D.unpack_part(parts[s].cpu().numpy(), cap)
+            assert len(np.unique(got_c["qfeat"])) == len(got_c)
             got_c, exp_c = np.sort(got_c, order="order"), np.sort(exp_c, order="order")   # arrival order is free
             assert len(got_c) == len(exp_c)
             for f in ("order", "qfeat", "landmark_id", "X"):
