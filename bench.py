@@ -54,12 +54,16 @@ def parse(argv=None):
                          "scanned (configs[1] with --views 1000)")
     ap.add_argument("--queries", type=int, default=64, help="distinct synthetic queries cycled through")
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="queries in flight per GPU (contexts); 0 = 8 with a shortlist, 4 for full scans; 1 = latency mode")
+                    help="queries in flight per GPU (contexts); 0 = 12 with a shortlist, 4 for full scans; 1 = latency mode")
     ap.add_argument("--from-images", action="store_true",
                     help="image-in serving mode (1 GPU): every query first extracts AKAZE + M-LDB features from a synthetic "
                          "640x480 image on the GPU (sfmloc_akaze_detect_and_compute, its own stream); --in-flight worker "
                          "threads, one extractor and one context each.  The map is synthetic, so the localised descriptors "
                          "are the synthetic query's, not the image's: the point is the cost of extraction sharing the GPU")
+    ap.add_argument("--threads", type=int, default=0,
+                    help="host threads driving the contexts (1 GPU, no shortlist collective): 0/1 = one thread round-robins "
+                         "all contexts; N > 1 = N threads, each with its share of the contexts (the C ABI calls release the "
+                         "GIL, so the kernel launches of different queries are issued in parallel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-phase", action="store_true", help="skip the full-bank scan and the N_q sweep")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -226,7 +230,11 @@ def main():
               f"its own ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr)
         sys.exit(2)
     shortlist = a.bow_knn > 0
-    nctx = a.in_flight if a.in_flight > 0 else (8 if shortlist else 4)
+    # measured (profiles/r02_inflight_sweep.txt): with the shortlist 12 contexts driven by 4 host threads; full scans fill
+    # the chip with 4
+    nctx = a.in_flight if a.in_flight > 0 else (12 if shortlist else 4)
+    if a.threads == 0 and shortlist and nctx >= 8 and not a.from_images:
+        a.threads = 4
     forced = os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1"
     sharded_mode = world > 1 or forced
     # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
@@ -315,9 +323,46 @@ def main():
             t_mark = [t_mark[1], now]
             n_ok[0] += sum(int(r["ok"]) for r in res.values())
 
+    def run_threads(first, count):
+        import threading
+        nthr = min(a.threads, nctx)
+        lock = threading.Lock()
+
+        def worker(t):
+            mine = list(range(t, nctx, nthr))          # this thread's contexts
+            tb = {k: 0.0 for k in mine}
+            bz = {k: False for k in mine}
+            lat_l, ok_l = [], 0
+            for n, i in enumerate(range(first + t, first + count, nthr)):
+                k = mine[n % len(mine)]
+                if bz[k]:
+                    pose, _, _ = ctxs[k].end()
+                    lat_l.append(time.perf_counter() - tb[k])
+                    ok_l += int(pose.ok)
+                tb[k] = time.perf_counter()
+                begin(k, i)
+                bz[k] = True
+            for k in mine:
+                if bz[k]:
+                    pose, _, _ = ctxs[k].end()
+                    lat_l.append(time.perf_counter() - tb[k])
+                    ok_l += int(pose.ok)
+            with lock:
+                lat.extend(lat_l)
+                n_ok[0] += ok_l
+
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
     def run(first, count):
         if sharded is not None:
             run_sharded(first, count)
+            return
+        if a.threads > 1:
+            run_threads(first, count)
             return
         for i in range(first, first + count):   # up to `nctx` queries overlap on the GPU
             k = i % nctx
@@ -452,6 +497,7 @@ def main():
                                    f"one step = a batch of {a.batch} queries, {nctx} in flight per GPU",
                        "views": a.views, "rows": int(m.n_rows), "nq": a.nq, "bow_knn": a.bow_knn, "batch": a.batch,
                        "queries_per_step": a.batch, "queries_timed": n_timed, "in_flight_per_gpu": nctx,
+                       "host_threads": max(1, a.threads) if sharded is None else 1,
                        "parallelism": (f"bank + .bow sharded by view x{world}; per {a.batch}-query batch one all-gather of "
                                        "per-shard k-best BoW keys and ONE all-gather of candidate parts (RCCL), P3P of "
                                        "query i on rank i mod N" if world > 1 else "1 GPU, whole bank"),

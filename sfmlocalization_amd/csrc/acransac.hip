@@ -1967,9 +1967,14 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
   }
   if (q->n == 0 || n_parts == 0) return SFMLOC_OK;
   const dim3 grid(16, n_parts < 64 ? n_parts : 64);
-  hipLaunchKernelGGL(k_candidates_min, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
-                     c->d_best64, c->d_status, L);
-  SFM_HIP(hipGetLastError());
+  // the context's own part (single GPU: the emission just ran on this stream) already holds exactly the winners and
+  // d_best64 their keys, so the minimum pass would change nothing
+  const bool own_part = (parts == c->d_cand_part && n_parts == 1 && packed_b == 0 && c->cleared);
+  if (!own_part) {
+    hipLaunchKernelGGL(k_candidates_min, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
+                       c->d_best64, c->d_status, L);
+    SFM_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_candidates_win, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
                      c->d_best64, c->d_winner, L);
   SFM_HIP(hipGetLastError());

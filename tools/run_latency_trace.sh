@@ -1,6 +1,6 @@
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_lat -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --in-flight 1 --no-cpu-baseline $BENCH_ARGS > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_lat -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --batch 16 --in-flight 1 --no-cpu-baseline --no-roofline-phase $BENCH_ARGS > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT; python - <<'PY'
 import csv,glob,re
 f=glob.glob("gpurun_out/prof_lat/*/*kernel_trace.csv")[0]
@@ -8,7 +8,7 @@ rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # last query: find last k_hamming_screen
 import os
-first="k_bow_dist" if "--bow-knn" in os.environ.get("BENCH_ARGS","") else "k_hamming_screen"
+first="k_hamming_screen" if "--bow-knn 0" in os.environ.get("BENCH_ARGS","") else "k_bow_dist"
 idx=[i for i,r in enumerate(rows) if first in r["Kernel_Name"]]
 start=idx[-2]
 t0=int(rows[start]["Start_Timestamp"])
