@@ -7,7 +7,7 @@ landmarks), so every stage of the path has a planted answer: the query's true po
 sees and which of its descriptor copies sit at wrong image positions (outliers).
 
 Descriptor bytes: uniform random with bytes 61..63 and the top two bits of byte 60 zero (486 valid bits,
-FileUtils.cpp:77-92).  Not used by the product's compute path; bench.py and the tests build inputs here.
+FileUtils.cpp:77-92).  Test and benchmark infrastructure: it lives outside the product package (sfmlocalization_amd/), which never imports it.
 """
 from dataclasses import dataclass, field
 
@@ -259,7 +259,7 @@ def write_map_to_disk(m: SynthMap, sfm_dir, match_dir, unposed_views=(), with_bo
     `unposed_views`: view ids written without an extrinsic (they must be ignored by the localiser).
     Returns the list of image basenames."""
     import os
-    from . import fileio
+    from sfmlocalization_amd import fileio
     os.makedirs(sfm_dir, exist_ok=True)
     os.makedirs(match_dir, exist_ok=True)
     names = [f"img{int(v):06d}" for v in m.view_id]
@@ -351,3 +351,29 @@ def plane_camera(rng, center_xy, height_m, tilt=0.25):
     x /= np.linalg.norm(x)
     y = np.cross(z, x)
     return np.stack([x, y, z]), C
+
+
+def mldb_like_bank(S, n_images=48, target_rows=400000, nq=2000, device=0, seed0=100):
+    """A descriptor bank and a query block with the statistics of real M-LDB descriptors instead of uniform random bits:
+    AKAZE + M-LDB extraction (the product's K9, `S` = the sfmlocalization_amd package) over synthetic textured images;
+    the query block is the first eight images' descriptors, the bank the remaining images' descriptors replicated with
+    a growing number of random bit flips up to `target_rows` rows.  -> (query [nq, 64], bank [rows, 64], stats dict).
+    Unrelated M-LDB descriptors sit at 222 +- 42 bits of each other (uniform bits: 243 +- 11), which is what the
+    screening bound of the Hamming kernel is sensitive to."""
+    ak = S.Akaze(640, 480, device=device)
+    descs = []
+    for k in range(n_images):
+        descs.append(ak.detect_and_compute(texture_image(seed0 + k, 480, 640, n_blobs=900, n_rects=160))[1])
+    ak.close()
+    q = np.concatenate(descs[:8])[:nq]
+    base = np.concatenate(descs[8:])
+    reps = max(1, target_rows // max(1, len(base)))
+    rng = np.random.Generator(np.random.PCG64(1))
+    bank = np.concatenate([flip_bits(rng, base, 6 * r) if r else base for r in range(reps)])
+    a = np.unpackbits(q[:256], axis=1).astype(np.int32)
+    b = np.unpackbits(base[:2048], axis=1).astype(np.int32)
+    dist = (a[:, None, :] != b[None, :, :]).sum(2)
+    stats = {"images": n_images, "desc_per_image_mean": float(np.mean([len(d) for d in descs])), "nq": int(len(q)),
+             "rows": int(len(bank)), "pair_distance_mean": float(dist.mean()), "pair_distance_std": float(dist.std()),
+             "bits_set_mean": float(np.unpackbits(base, axis=1).sum(1).mean())}
+    return q, bank, stats

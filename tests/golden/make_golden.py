@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from oracle import oracle_np as onp  # noqa: E402
-from sfmlocalization_amd import synth  # noqa: E402
+import synthdata as synth  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

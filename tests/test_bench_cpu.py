@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 import bench
-from sfmlocalization_amd import synth
+import synthdata as synth
 
 
 def test_cpu_baseline_legs_report_the_contract_fields():

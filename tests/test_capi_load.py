@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/sfmloc.h but not exported"
     assert sorted(capi.SYMBOLS) == names, "capi.SYMBOLS out of date with include/sfmloc.h"
-    assert capi._L().sfmloc_abi_version() == 1
+    assert capi._L().sfmloc_abi_version() == 2      # 2: sfmloc_params.guided_matching
 
 
 def test_struct_layout_matches_header():

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from sfmlocalization_amd import dist as D
-from sfmlocalization_amd import synth
+import synthdata as synth
 
 
 def test_shard_views_balanced_and_contiguous():

@@ -7,7 +7,9 @@ import struct
 import numpy as np
 import pytest
 
-from sfmlocalization_amd import capi, fileio, synth
+from sfmlocalization_amd import capi, fileio
+
+import synthdata as synth
 
 
 def test_desc_layout_and_roundtrip(tmp_path):

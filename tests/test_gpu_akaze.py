@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import sfmlocalization_amd as S
-from sfmlocalization_amd import synth
+import synthdata as synth
 
 pytestmark = pytest.mark.gpu
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import sfmlocalization_amd as S
-from sfmlocalization_amd import synth
+import synthdata as synth
 
 pytestmark = pytest.mark.gpu
 

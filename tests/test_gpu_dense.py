@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import sfmlocalization_amd as S
-from sfmlocalization_amd import engine, fileio, synth
+from sfmlocalization_amd import engine, fileio
+import synthdata as synth
 from oracle import oracle_c
 
 pytestmark = pytest.mark.gpu

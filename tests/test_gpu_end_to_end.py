@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import sfmlocalization_amd as S
-from sfmlocalization_amd import engine, fileio, synth
+from sfmlocalization_amd import engine, fileio
+import synthdata as synth
 
 pytestmark = pytest.mark.gpu
 F, W, H, PPM = 800.0, 640, 480, 100.0

@@ -5,7 +5,9 @@ import os
 import numpy as np
 import pytest
 
-from sfmlocalization_amd import extfeat, fileio, synth
+from sfmlocalization_amd import extfeat, fileio
+
+import synthdata as synth
 from oracle import pipeline as opipe
 
 pytestmark = pytest.mark.gpu

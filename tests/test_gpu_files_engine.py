@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import sfmlocalization_amd as S
-from sfmlocalization_amd import capi, engine, fileio, synth
+from sfmlocalization_amd import capi, engine, fileio
+import synthdata as synth
 from oracle import pipeline as opipe
 
 pytestmark = pytest.mark.gpu

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import sfmlocalization_amd as S
-from sfmlocalization_amd import synth
+import synthdata as synth
 from oracle import pipeline as opipe
 
 pytestmark = pytest.mark.gpu

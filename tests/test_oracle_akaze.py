@@ -5,7 +5,7 @@ import math
 import numpy as np
 
 from oracle import oracle_np as onp
-from sfmlocalization_amd import synth
+import synthdata as synth
 
 
 def pad64(d):

@@ -8,7 +8,7 @@ import math
 import numpy as np
 import pytest
 
-from sfmlocalization_amd import synth
+import synthdata as synth
 
 
 def test_det_log10_matches_libm(oracle_c):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle_np as onp
-from sfmlocalization_amd import synth
+import synthdata as synth
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "hamming_planted.npz")
 INT_MAX = 2**31 - 1

@@ -226,7 +226,7 @@ def test_akaze_scale_change_is_an_octave_shift(oracle_c):
     a 2x box-downsampled image gives keypoints at half the position and half the size of the original's, found one
     octave lower, with descriptors that still match under the ratio test."""
     from oracle import oracle_np as onp
-    from sfmlocalization_amd import synth
+    import synthdata as synth
     g = synth.texture_image(4, 960, 1280)                        # h, w
     g2 = g.reshape(480, 2, 640, 2).astype(np.float32).mean(axis=(1, 3)).round().astype(np.uint8)
     kp, desc = oracle_c.akaze_detect_and_compute(g)

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import sfmlocalization_amd as S  # noqa: E402
-from sfmlocalization_amd import synth  # noqa: E402
+import synthdata as synth  # noqa: E402
 from oracle import oracle_c, pipeline as opipe  # noqa: E402
 
 

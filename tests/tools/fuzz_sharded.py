@@ -13,7 +13,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import sfmlocalization_amd as S  # noqa: E402
-from sfmlocalization_amd import dist as D, synth  # noqa: E402
+from sfmlocalization_amd import dist as D  # noqa: E402
+import synthdata as synth
 from oracle import oracle_c, pipeline as opipe  # noqa: E402
 
 

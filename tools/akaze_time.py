@@ -2,7 +2,7 @@ import os, sys, time, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sfmlocalization_amd as S
-from sfmlocalization_amd import synth
+import synthdata as synth
 for (h, w) in ((480, 640), (1080, 1920)):
     g = synth.texture_image(1, h, w, n_blobs=int(400 * w * h / 307200), n_rects=int(200 * w * h / 307200))
     ak = S.Akaze(w, h)

@@ -12,7 +12,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sfmlocalization_amd as S  # noqa: E402
-from sfmlocalization_amd import synth  # noqa: E402
+import synthdata as synth  # noqa: E402
 
 
 def main():

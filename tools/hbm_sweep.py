@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sfmlocalization_amd as S  # noqa: E402
-from sfmlocalization_amd import synth  # noqa: E402
+import synthdata as synth  # noqa: E402
 
 rows = int(os.environ.get("ROWS", 8_000_000))
 rng = np.random.Generator(np.random.PCG64(1))

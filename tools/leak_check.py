@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sfmlocalization_amd as S  # noqa: E402
-from sfmlocalization_amd import synth  # noqa: E402
+import synthdata as synth  # noqa: E402
 
 m = synth.make_map(3, n_views=30, desc_per_view=400, views_per_place=10, landmarks_per_place=300, obs_per_view=150)
 q = synth.make_query(m, 5, n_feat=800, n_copies=250)
