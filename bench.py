@@ -262,11 +262,13 @@ def main():
     shortlist = a.bow_knn > 0
     # measured (profiles/r02_inflight_sweep.txt): with the shortlist 12 contexts driven by 4 host threads; full scans fill
     # the chip with 4
-    nctx = a.in_flight if a.in_flight > 0 else (12 if shortlist else 4)
-    if a.threads == 0 and shortlist and nctx >= 8 and not a.from_images:
-        a.threads = 4
     forced = os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1"
     sharded_mode = world > 1 or forced
+    # (the sharded path keeps two slots of contexts: 8 per slot -- with 12 the 24 contexts and the collective's stream no
+    # longer get a hardware queue each and the rate drops by 40 %, profiles/r02_sharded_inflight_sweep.txt)
+    nctx = a.in_flight if a.in_flight > 0 else ((8 if sharded_mode else 12) if shortlist else 4)
+    if a.threads == 0 and shortlist and nctx >= 8 and not a.from_images and not sharded_mode:
+        a.threads = 4
     # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
     # (so does the image-in mode: a context and an extractor stream per worker)
     # (+2: the map's own stream and torch's; measured: 8 contexts on 8 queues lose 20 % to two streams sharing one)
