@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <exception>
 #include <new>
 
 #include "sfmloc_internal.h"
@@ -660,7 +661,21 @@ void sfmloc_default_params(sfmloc_params *p) {
   p->guided_matching = 0;       // -gm: false (localization.cpp:82, computeFeaturesAndMatches.cpp:63)
 }
 
+static int map_create_impl(const sfmloc_map_desc *d, const sfmloc_params *params, sfmloc_map **out);
+
 int sfmloc_map_create(const sfmloc_map_desc *d, const sfmloc_params *params, sfmloc_map **out) {
+  try {  // host-side containers are sized by the caller's counts: no exception may cross the C ABI
+    return map_create_impl(d, params, out);
+  } catch (const std::bad_alloc &) {
+    set_error("sfmloc_map_create: out of host memory");
+    return SFMLOC_ENOMEM;
+  } catch (const std::exception &e) {
+    set_error("sfmloc_map_create: %s", e.what());
+    return SFMLOC_EINVAL;
+  }
+}
+
+static int map_create_impl(const sfmloc_map_desc *d, const sfmloc_params *params, sfmloc_map **out) {
   SFM_CHECK(d && out, SFMLOC_EINVAL, "sfmloc_map_create: null argument");
   *out = nullptr;
   SFM_CHECK(d->n_views > 0 && d->view_id && d->view_off, SFMLOC_EINVAL, "sfmloc_map_create: no views");
@@ -923,10 +938,15 @@ void sfmloc_query_destroy(sfmloc_query *query) {
   if (!q) return;
   if (q->map) {
     hipSetDevice(q->map->device);
-    hipDeviceSynchronize();  // any context may still be reading the query
-    for (Ctx *c : q->map->pool)
-      if (c->last_query == q) c->last_query = nullptr;
-    if (q->map->ctx0 && q->map->ctx0->last_query == q) q->map->ctx0->last_query = nullptr;
+    // only the contexts that worked on THIS query can still be reading it: the others keep running (a server destroys a
+    // query per request while other users' queries are in flight)
+    std::vector<Ctx *> all = q->map->pool;
+    if (q->map->ctx0) all.push_back(q->map->ctx0);
+    for (Ctx *c : all)
+      if (c->last_query == q || c->in_flight == q) {
+        hipStreamSynchronize(c->stream);
+        if (c->last_query == q) c->last_query = nullptr;
+      }
   }
   if (q->d_desc) hipFree(q->d_desc);
   if (q->d_kpt) hipFree(q->d_kpt);

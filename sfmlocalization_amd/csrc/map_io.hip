@@ -3,10 +3,13 @@
 // (SfMDataUtils.cpp:33-46), HuloSfMRegionsProvider::load (all <base>.feat / <base>.desc), plus the optional
 // per-view <base>.bow vectors (BoFUtils.cpp:33-42).  The arrays it builds feed sfmloc_map_create.
 #include <errno.h>
+#include <sys/stat.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
+#include <new>
 #include <map>
 #include <string>
 #include <utility>
@@ -36,6 +39,8 @@ struct JVal {
 struct JParser {
   const char *p, *end;
   std::string err;
+  int depth = 0;  // value() recurses once per nesting level: a hostile file must not overflow the stack
+  static constexpr int kMaxDepth = 64;  // sfm_data.json nests 7 deep
   explicit JParser(const std::string &s) : p(s.data()), end(s.data() + s.size()) {}
   void ws() {
     while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
@@ -85,6 +90,12 @@ struct JParser {
     return true;
   }
   bool value(JVal &v) {
+    struct Depth {
+      int &d;
+      explicit Depth(int &x) : d(x) { ++d; }
+      ~Depth() { --d; }
+    } guard(depth);
+    if (depth > kMaxDepth) return fail("nested too deeply");
     ws();
     if (p >= end) return fail("unexpected end");
     if (*p == '{') {
@@ -354,6 +365,10 @@ int load_scene(const char *sfm_dir, const char *match_dir, Scene &S) {
       uint64_t n = 0;
       bool ok = fread(&n, sizeof(n), 1, f) == 1;
       const size_t at = S.desc.size();
+      if (ok) {  // the count comes from the file: it must fit what the file holds before anything is sized by it
+        struct stat fs;
+        ok = fstat(fileno(f), &fs) == 0 && fs.st_size >= 8 && n <= ((uint64_t)fs.st_size - 8) / 64;
+      }
       if (ok) {
         S.desc.resize(at + (size_t)n * 64);
         ok = n == 0 || fread(&S.desc[at], 64, (size_t)n, f) == (size_t)n;
@@ -477,6 +492,12 @@ template <typename T>
 bool get_vec(FILE *f, std::vector<T> &v, uint64_t max_elems) {
   uint64_t n = 0;
   if (fread(&n, 8, 1, f) != 1 || n > max_elems) return false;
+  // the count comes from the file: it must fit the bytes that are left before anything is sized by it
+  struct stat fs;
+  const long pos = ftell(f);
+  if (pos < 0 || fstat(fileno(f), &fs) != 0 || (uint64_t)fs.st_size < (uint64_t)pos ||
+      n > ((uint64_t)fs.st_size - (uint64_t)pos) / sizeof(T))
+    return false;
   v.resize((size_t)n);
   return n == 0 || fread(v.data(), sizeof(T), (size_t)n, f) == n;
 }
@@ -598,48 +619,88 @@ int scene_to_map(const Scene &S, const sfmloc_params *params, sfmloc_map **out) 
 extern "C" {
 
 int sfmloc_scan(const char *sfm_dir, const char *match_dir, sfmloc_scan_info *info) {
-  SFM_CHECK(sfm_dir && match_dir && info, SFMLOC_EINVAL, "sfmloc_scan: null argument");
-  Scene S;
-  int rc = load_scene(sfm_dir, match_dir, S);
-  if (rc) return rc;
-  scene_info(S, info);
-  return SFMLOC_OK;
+  try {
+    SFM_CHECK(sfm_dir && match_dir && info, SFMLOC_EINVAL, "sfmloc_scan: null argument");
+    Scene S;
+    int rc = load_scene(sfm_dir, match_dir, S);
+    if (rc) return rc;
+    scene_info(S, info);
+    return SFMLOC_OK;
+  } catch (const std::bad_alloc &) {
+    set_error("sfmloc_scan: out of host memory");
+    return SFMLOC_ENOMEM;
+  } catch (const std::exception &e) {
+    set_error("sfmloc_scan: %s", e.what());
+    return SFMLOC_EIO;
+  }
 }
 
 int sfmloc_open(const char *sfm_dir, const char *match_dir, const sfmloc_params *params, sfmloc_map **out) {
-  SFM_CHECK(sfm_dir && match_dir && out, SFMLOC_EINVAL, "sfmloc_open: null argument");
-  *out = nullptr;
-  Scene S;
-  int rc = load_scene(sfm_dir, match_dir, S);
-  if (rc) return rc;
-  return scene_to_map(S, params, out);
+  try {
+    SFM_CHECK(sfm_dir && match_dir && out, SFMLOC_EINVAL, "sfmloc_open: null argument");
+    *out = nullptr;
+    Scene S;
+    int rc = load_scene(sfm_dir, match_dir, S);
+    if (rc) return rc;
+    return scene_to_map(S, params, out);
+  } catch (const std::bad_alloc &) {
+    set_error("sfmloc_open: out of host memory");
+    return SFMLOC_ENOMEM;
+  } catch (const std::exception &e) {
+    set_error("sfmloc_open: %s", e.what());
+    return SFMLOC_EIO;
+  }
 }
 
 int sfmloc_pack(const char *sfm_dir, const char *match_dir, const char *out_path) {
-  SFM_CHECK(sfm_dir && match_dir && out_path, SFMLOC_EINVAL, "sfmloc_pack: null argument");
-  Scene S;
-  int rc = load_scene(sfm_dir, match_dir, S);
-  if (rc) return rc;
-  SFM_CHECK(write_packed(out_path, S), SFMLOC_EIO, "sfmloc_pack: cannot write \"%s\"", out_path);
-  return SFMLOC_OK;
+  try {
+    SFM_CHECK(sfm_dir && match_dir && out_path, SFMLOC_EINVAL, "sfmloc_pack: null argument");
+    Scene S;
+    int rc = load_scene(sfm_dir, match_dir, S);
+    if (rc) return rc;
+    SFM_CHECK(write_packed(out_path, S), SFMLOC_EIO, "sfmloc_pack: cannot write \"%s\"", out_path);
+    return SFMLOC_OK;
+  } catch (const std::bad_alloc &) {
+    set_error("sfmloc_pack: out of host memory");
+    return SFMLOC_ENOMEM;
+  } catch (const std::exception &e) {
+    set_error("sfmloc_pack: %s", e.what());
+    return SFMLOC_EIO;
+  }
 }
 
 int sfmloc_scan_packed(const char *path, sfmloc_scan_info *info) {
-  SFM_CHECK(path && info, SFMLOC_EINVAL, "sfmloc_scan_packed: null argument");
-  Scene S;
-  int rc = read_packed(path, S);
-  if (rc) return rc;
-  scene_info(S, info);
-  return SFMLOC_OK;
+  try {
+    SFM_CHECK(path && info, SFMLOC_EINVAL, "sfmloc_scan_packed: null argument");
+    Scene S;
+    int rc = read_packed(path, S);
+    if (rc) return rc;
+    scene_info(S, info);
+    return SFMLOC_OK;
+  } catch (const std::bad_alloc &) {
+    set_error("sfmloc_scan_packed: out of host memory");
+    return SFMLOC_ENOMEM;
+  } catch (const std::exception &e) {
+    set_error("sfmloc_scan_packed: %s", e.what());
+    return SFMLOC_EIO;
+  }
 }
 
 int sfmloc_open_packed(const char *path, const sfmloc_params *params, sfmloc_map **out) {
-  SFM_CHECK(path && out, SFMLOC_EINVAL, "sfmloc_open_packed: null argument");
-  *out = nullptr;
-  Scene S;
-  int rc = read_packed(path, S);
-  if (rc) return rc;
-  return scene_to_map(S, params, out);
+  try {
+    SFM_CHECK(path && out, SFMLOC_EINVAL, "sfmloc_open_packed: null argument");
+    *out = nullptr;
+    Scene S;
+    int rc = read_packed(path, S);
+    if (rc) return rc;
+    return scene_to_map(S, params, out);
+  } catch (const std::bad_alloc &) {
+    set_error("sfmloc_open_packed: out of host memory");
+    return SFMLOC_ENOMEM;
+  } catch (const std::exception &e) {
+    set_error("sfmloc_open_packed: %s", e.what());
+    return SFMLOC_EIO;
+  }
 }
 
 int sfmloc_map_views(const sfmloc_map *map, uint32_t *view_id, uint32_t *view_off, double *center) {
@@ -672,46 +733,54 @@ struct ViewList {
 };
 
 int sfmloc_view_list_open(const char *sfm_data_json, sfmloc_view_list **out, uint32_t *n_views) {
-  SFM_CHECK(sfm_data_json && out, SFMLOC_EINVAL, "sfmloc_view_list_open: null argument");
-  std::string text;
-  SFM_CHECK(read_file(sfm_data_json, text), SFMLOC_EIO, "The input sfm_data.json file \"%s\" cannot be read.",
-            sfm_data_json);
-  JParser P(text);
-  JVal root;
-  SFM_CHECK(P.value(root) && root.kind == JVal::Obj, SFMLOC_EIO, "%s: not a JSON object (%s)", sfm_data_json,
-            P.err.c_str());
-  const JVal *rp = root.get("root_path");
-  const std::string root_path = (rp && rp->kind == JVal::Str) ? rp->str : "";
-  const JVal *views = root.get("views");
-  SFM_CHECK(views && views->kind == JVal::Arr, SFMLOC_EIO, "%s: no \"views\" array", sfm_data_json);
-  std::vector<ViewRec> recs;
-  for (const JVal &e : views->arr) {
-    const JVal *val = e.get("value");
-    if (!val) val = e.get("values");
-    const JVal *pw = val ? val->get("ptr_wrapper") : nullptr;
-    const JVal *d = pw ? pw->get("data") : nullptr;
-    if (!d) continue;
-    ViewRec r;
-    r.id = (uint32_t)jint(d->get("id_view"), jint(e.get("key"), 0));
-    const JVal *fn = d->get("filename");
-    r.filename = fn ? fn->str : "";
-    r.w = (uint32_t)jint(d->get("width"), 0);
-    r.h = (uint32_t)jint(d->get("height"), 0);
-    r.id_intrinsic = r.id_pose = 0;
-    recs.push_back(r);
+  try {
+    SFM_CHECK(sfm_data_json && out, SFMLOC_EINVAL, "sfmloc_view_list_open: null argument");
+    std::string text;
+    SFM_CHECK(read_file(sfm_data_json, text), SFMLOC_EIO, "The input sfm_data.json file \"%s\" cannot be read.",
+              sfm_data_json);
+    JParser P(text);
+    JVal root;
+    SFM_CHECK(P.value(root) && root.kind == JVal::Obj, SFMLOC_EIO, "%s: not a JSON object (%s)", sfm_data_json,
+              P.err.c_str());
+    const JVal *rp = root.get("root_path");
+    const std::string root_path = (rp && rp->kind == JVal::Str) ? rp->str : "";
+    const JVal *views = root.get("views");
+    SFM_CHECK(views && views->kind == JVal::Arr, SFMLOC_EIO, "%s: no \"views\" array", sfm_data_json);
+    std::vector<ViewRec> recs;
+    for (const JVal &e : views->arr) {
+      const JVal *val = e.get("value");
+      if (!val) val = e.get("values");
+      const JVal *pw = val ? val->get("ptr_wrapper") : nullptr;
+      const JVal *d = pw ? pw->get("data") : nullptr;
+      if (!d) continue;
+      ViewRec r;
+      r.id = (uint32_t)jint(d->get("id_view"), jint(e.get("key"), 0));
+      const JVal *fn = d->get("filename");
+      r.filename = fn ? fn->str : "";
+      r.w = (uint32_t)jint(d->get("width"), 0);
+      r.h = (uint32_t)jint(d->get("height"), 0);
+      r.id_intrinsic = r.id_pose = 0;
+      recs.push_back(r);
+    }
+    std::stable_sort(recs.begin(), recs.end(), [](const ViewRec &a, const ViewRec &b) { return a.id < b.id; });  // Views is a std::map
+    ViewList *L = new ViewList;
+    for (const ViewRec &r : recs) {
+      L->id.push_back(r.id);
+      L->w.push_back(r.w);
+      L->h.push_back(r.h);
+      const size_t s = r.filename.find_last_of("/\\");
+      L->image.push_back(join(root_path, s == std::string::npos ? r.filename : r.filename.substr(s + 1)));
+    }
+    if (n_views) *n_views = (uint32_t)L->id.size();
+    *out = reinterpret_cast<sfmloc_view_list *>(L);
+    return SFMLOC_OK;
+  } catch (const std::bad_alloc &) {
+    set_error("sfmloc_view_list_open: out of host memory");
+    return SFMLOC_ENOMEM;
+  } catch (const std::exception &e) {
+    set_error("sfmloc_view_list_open: %s", e.what());
+    return SFMLOC_EIO;
   }
-  std::stable_sort(recs.begin(), recs.end(), [](const ViewRec &a, const ViewRec &b) { return a.id < b.id; });  // Views is a std::map
-  ViewList *L = new ViewList;
-  for (const ViewRec &r : recs) {
-    L->id.push_back(r.id);
-    L->w.push_back(r.w);
-    L->h.push_back(r.h);
-    const size_t s = r.filename.find_last_of("/\\");
-    L->image.push_back(join(root_path, s == std::string::npos ? r.filename : r.filename.substr(s + 1)));
-  }
-  if (n_views) *n_views = (uint32_t)L->id.size();
-  *out = reinterpret_cast<sfmloc_view_list *>(L);
-  return SFMLOC_OK;
 }
 
 int sfmloc_view_list_get(const sfmloc_view_list *list, uint32_t k, uint32_t *view_id, uint32_t *width, uint32_t *height,

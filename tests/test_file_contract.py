@@ -225,3 +225,40 @@ def test_native_loader_reads_golden_files():
     assert info["n_landmarks"] == 1 and info["n_observations"] == 1 and info["bow_dim"] == 4
     assert info["row_landmark_sum"] == -1 + 0 + -1          # rows 0 and 2 unobserved, feature 1 -> landmark slot 0
     assert (info["focal"], info["ppx"], info["ppy"]) == (800.0, 320.0, 240.0)
+
+
+def test_loader_refuses_hostile_files_without_crashing(tmp_path):
+    """Sizes read from files are checked against the file before anything is allocated by them, the JSON reader has a
+    nesting limit, and no C++ exception crosses the C ABI: damaged inputs give SFMLOC_EIO, never an abort."""
+    import struct
+    m = synth.make_map(3, n_views=4, desc_per_view=30, views_per_place=4, landmarks_per_place=40, obs_per_view=15)
+    sfm, mat = tmp_path / "sfm", tmp_path / "matches"
+    sfm.mkdir()
+    mat.mkdir()
+    names = synth.write_map_to_disk(m, str(sfm), str(mat))
+    assert capi.scan(str(sfm), str(mat))["n_rows"] == m.n_rows
+    # a .desc whose count field claims far more rows than the file holds (2^60 would be ~10^19 bytes)
+    victim = mat / (names[1] + ".desc")
+    good = victim.read_bytes()
+    for claimed in (1 << 60, 31, 1 << 33):
+        victim.write_bytes(struct.pack("<Q", claimed) + good[8:])
+        with pytest.raises(capi.SfmlocError) as e:
+            capi.scan(str(sfm), str(mat))
+        assert e.value.code == -4 and "truncated" in str(e.value)                 # SFMLOC_EIO
+    victim.write_bytes(good)
+    # a packed file with an absurd vector length
+    packed = tmp_path / "map.bin"
+    capi.pack(str(sfm), str(mat), str(packed))
+    raw = bytearray(packed.read_bytes())
+    assert capi.scan_packed(str(packed))["n_rows"] == m.n_rows
+    off = 8 + 48 + 20                                    # magic, six doubles, five u32: the first vector's length
+    raw[off:off + 8] = struct.pack("<Q", (1 << 36) - 1)
+    packed.write_bytes(bytes(raw))
+    with pytest.raises(capi.SfmlocError) as e:
+        capi.scan_packed(str(packed))
+    assert e.value.code == -4
+    # a deeply nested sfm_data.json (the reader recurses per level)
+    (sfm / "sfm_data.json").write_text("[" * 100000 + "]" * 100000)
+    with pytest.raises(capi.SfmlocError) as e:
+        capi.scan(str(sfm), str(mat))
+    assert e.value.code == -4
