@@ -323,7 +323,7 @@ __global__ void k_kcontrast(const unsigned int *hmax_bits, const unsigned int *h
 // K - 1 - s pixels, the last step on the tile itself.  Per pixel the arithmetic is that of a step-per-launch kernel, so
 // the images are the same bit for bit; the scale space of a VGA image is 166 steps, each shorter than a launch
 // (measured: 1.03 -> 0.96 ms per VGA image at 4 steps per launch; 6 and 8 bring nothing more).
-constexpr int kNldFuseMax = 8;
+constexpr int kNldFuseMax = 16;
 struct NldSteps {
   float half_step[kNldFuseMax];
 };
@@ -776,11 +776,20 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
     // the level starts from the previous level's Lt (half-sampled at an octave change); the FED steps ping-pong
     // between this level's Lt and a scratch image, arranged so that the last step lands in Lt without a copy
     const float *start = a->d_Lt + Lp.off;
-    static const int kFuse = [] {  // diffusion steps per launch (k_nld_steps); SFMLOC_AKAZE_FUSE=1..8 for tuning
+    // diffusion steps per launch (k_nld_steps): 4 on the large levels, where the tile halo's redundant work costs more
+    // than a launch; more on the upper octaves (<= 160 x 120), whose steps are each far shorter than a launch boundary and
+    // which hold most of the schedule's steps (133 of 165 at VGA).  SFMLOC_AKAZE_FUSE / _FUSE_SMALL = 1..16 for tuning.
+    static const int kFuseBig = [] {
       const char *e = getenv("SFMLOC_AKAZE_FUSE");
       const int v = e ? atoi(e) : 4;
       return (v >= 1 && v <= kNldFuseMax) ? v : 4;
     }();
+    static const int kFuseSmall = [] {
+      const char *e = getenv("SFMLOC_AKAZE_FUSE_SMALL");
+      const int v = e ? atoi(e) : 8;
+      return (v >= 1 && v <= kNldFuseMax) ? v : 8;
+    }();
+    const int kFuse = (L.w <= 160) ? kFuseSmall : kFuseBig;
     const int n_launch = (L.nsteps + kFuse - 1) / kFuse;
     if (L.octave > Lp.octave) {
       float *half = (n_launch % 2 == 0) ? Lt : a->d_t3;  // even number of launches: start (and end) in Lt
@@ -804,7 +813,10 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
       for (int k = 0; k < kNldFuseMax; ++k) hs.half_step[k] = k < n ? 0.5f * L.tsteps[st + k] : 0.0f;
 #define NLD_CASE(KK) \
   case KK: hipLaunchKernelGGL(k_nld_steps<KK>, tgrid, dim3(256), 0, s, cur, a->d_t2, dst, L.w, L.h, hs, n); break;
-      switch (n) { NLD_CASE(1) NLD_CASE(2) NLD_CASE(3) NLD_CASE(4) NLD_CASE(5) NLD_CASE(6) NLD_CASE(7) NLD_CASE(8) }
+      switch (n) {
+        NLD_CASE(1) NLD_CASE(2) NLD_CASE(3) NLD_CASE(4) NLD_CASE(5) NLD_CASE(6) NLD_CASE(7) NLD_CASE(8)
+        NLD_CASE(9) NLD_CASE(10) NLD_CASE(11) NLD_CASE(12) NLD_CASE(13) NLD_CASE(14) NLD_CASE(15) NLD_CASE(16)
+      }
 #undef NLD_CASE
       st += n;
       cur = dst;

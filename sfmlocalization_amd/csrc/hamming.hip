@@ -139,7 +139,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
     uint2 *__restrict__ flagged /*{part index, bank row}*/, uint32_t *__restrict__ n_flagged,
     unsigned long long *__restrict__ counters /*[0] finished wave-pairs, [1] flagged rows*/, uint32_t head,
     uint4 *__restrict__ flagged_desc /*[slot / 64][4][64]: the flagged rows' descriptors, tiled like the bank*/,
-    uint32_t flagged_desc_cap /*slots*/) {
+    uint32_t flagged_desc_cap /*slots*/,
+    const uint2 *__restrict__ head_part /*null, or [work block][lane]: the exact top-2 over the first `head` query rows,
+                                          computed once by k_hamming_top2 -- the slices then start from it instead of each
+                                          scanning a head of its own*/) {
   extern __shared__ uint4 qs[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -167,8 +170,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
   // head and threshold.  A bank row that the whole query would accept is accepted by the slice holding its nearest row
   // (the slice's second-nearest is no nearer than the global one), so the union of the slices' flags still covers
   // every accepted row; k_hamming_rows then recomputes the flagged rows against ALL query rows, as before.
-  const uint32_t per = (nq + gridDim.y - 1) / gridDim.y;
-  const uint32_t j_begin = blockIdx.y * per, j_end = min(nq, j_begin + per), head_end = j_begin + head;
+  // With a shared head the slices divide the rows AFTER it and start from its (best0, best1): any upper bound of the
+  // second-nearest distance gives a valid threshold, so every slice may use the head's.
+  const uint32_t base = head_part ? min(head, nq) : 0u;
+  const uint32_t per = (nq - base + gridDim.y - 1) / gridDim.y;
+  const uint32_t j_begin = base + blockIdx.y * per, j_end = min(nq, j_begin + per);
+  const uint32_t head_end = head_part ? j_begin : j_begin + head;
+  if (head_part && valid) {
+    const uint2 hp = head_part[(uint64_t)w0 * 64 + lane];
+    best0 = hp.x;
+    best1 = hp.y;
+    T = (best1 != SFMLOC_NOMATCH) ? (uint32_t)ratio_cnt[best1 >> 16] : 0u;
+    flag = (best0 >> 16) < T;
+  }
   for (uint32_t j0 = j_begin; j0 < j_end; j0 += lds_rows) {
     const uint32_t cnt = min(lds_rows, j_end - j0);
     __syncthreads();
@@ -540,9 +554,9 @@ __global__ __launch_bounds__(256) void k_merge_ratio_masked(
 
 template <int R, int WAVES>
 int launch_hamming_t(Ctx *c, const Query *q, uint32_t n_work_blocks, bool use_list, uint32_t split,
-                     uint32_t lds_rows_cap) {
+                     uint32_t lds_rows_cap, uint32_t nq_override = 0) {
   Map *m = c->map;
-  const uint32_t nq = q->n;
+  const uint32_t nq = nq_override ? nq_override : q->n;  // override: only the first rows (the shared head of a sliced scan)
   const uint32_t q_chunk = (nq + split - 1) / split;
   // LDS slice of the split's query rows (gfx950: 160 KiB per CU; the cap trades slice reloads for occupancy)
   uint32_t lds_rows = q_chunk < lds_rows_cap ? q_chunk : lds_rows_cap;
@@ -610,11 +624,22 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
     const char *e = getenv("SFMLOC_K1_QSPLIT");
     return e ? atoi(e) : 0;
   }();
+  // The head is shared: one exact pass over the first `head` query rows (k_hamming_top2) seeds every slice, so a slice
+  // costs no head of its own.  Four slices remain the optimum all the same (profiles/r02_k1_qsplit_sweep.txt: a
+  // shortlisted query takes 0.95 / 0.93 / 0.89 / 1.02 / 1.29 ms with 1 / 2 / 4 / 8 / 16 slices): a workgroup's fixed
+  // costs -- its bank rows, its query slice into LDS, two barriers -- stop amortising below ~500 query rows per slice.
   uint32_t qsplit = 1;
-  while (qsplit < 4 && (uint64_t)n_work_blocks * qsplit < 32ull * (uint64_t)m->n_cu && q->n / (qsplit * 2) >= 6 * head)
+  while (qsplit < 4 && (uint64_t)n_work_blocks * qsplit < 32ull * (uint64_t)m->n_cu && (q->n - head) / (qsplit * 2) >= 6 * head)
     qsplit *= 2;
   if (!c->k1_may_slice) qsplit = 1;  // other queries are queued on the GPU: their scans fill it, slices only add work
-  if (qsplit_env == 1 || qsplit_env == 2 || qsplit_env == 4) qsplit = (uint32_t)qsplit_env;
+  if (qsplit_env == 1 || qsplit_env == 2 || qsplit_env == 4 || qsplit_env == 8 || qsplit_env == 16)
+    qsplit = (uint32_t)qsplit_env;
+  const uint2 *head_part = nullptr;
+  if (qsplit > 1) {
+    int rc = launch_hamming_t<1, 8>(c, q, n_work_blocks, use_list, 1, 512, head);
+    if (rc) return rc;
+    head_part = c->d_part;
+  }
   if (qsplit > 1 && !c->flagmask_zeroed)
     SFM_HIP(hipMemsetAsync(c->d_flagmask, 0, (size_t)n_work_blocks * sizeof(unsigned long long), c->stream));
   c->flagmask_zeroed = false;
@@ -623,13 +648,14 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
     hipLaunchKernelGGL((k_hamming_screen<WAVES, NW, 1>), dim3((n_work_blocks + WAVES - 1) / WAVES, qsplit),       \
                        dim3(WAVES * 64), lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr,   \
                        n_work_blocks, q->d_desc, q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged,     \
-                       c->d_n_flagged, c->d_k1_counters, head, c->d_flagged_desc, c->rows_chunk_cap * 64);        \
+                       c->d_n_flagged, c->d_k1_counters, head, c->d_flagged_desc, c->rows_chunk_cap * 64,         \
+                       head_part);                                                                                \
     break;
   if (nw == 10 && n_work_blocks < 16u * (uint32_t)m->n_cu) {  // fewer than four waves per SIMD: batched tail
     hipLaunchKernelGGL((k_hamming_screen<WAVES, 10, 4>), dim3((n_work_blocks + WAVES - 1) / WAVES, qsplit), dim3(WAVES * 64),
                        lds_bytes, c->stream, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks, q->d_desc,
                        q->n, lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged, c->d_k1_counters,
-                       head, c->d_flagged_desc, c->rows_chunk_cap * 64);
+                       head, c->d_flagged_desc, c->rows_chunk_cap * 64, head_part);
   } else {
     switch (nw) {
       K1_SCREEN(8) K1_SCREEN(9) K1_SCREEN(10) K1_SCREEN(11) K1_SCREEN(12) K1_SCREEN(13)
@@ -639,7 +665,8 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   // executed VALU lane-ops, deterministic part (the finished pairs are counted on the device): exact head 35 per
   // pair, screened tail 2*nw+1, plus (sfmloc_stats_read) 2*(16-nw)+5 per finished pair
   const uint64_t rows = (uint64_t)n_work_blocks * kBlockRows;
-  c->stats.hamming_lane_ops += rows * head * qsplit * 35 + rows * (q->n - head * qsplit) * (uint64_t)(2 * nw + 1);
+  // (a sliced scan shares ONE head)
+  c->stats.hamming_lane_ops += rows * head * 35 + rows * (q->n - head) * (uint64_t)(2 * nw + 1);
   c->k1_finish_ops = 2 * (16 - nw) + 5;
   SFM_HIP(hipGetLastError());
   // the exact pass over the flagged rows: chunks of 64 rows x kRowSlices query slices, see k_hamming_rows

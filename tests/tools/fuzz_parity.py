@@ -35,7 +35,8 @@ def one(seed):
     ratio = float(rng.choice([0.5, 0.6, 0.8]))
     rounds = int(rng.choice([5, 25, 60, 200]))
     nq = int(rng.choice([300, 700, 900, 1500, 2300]))
-    p = S.default_params(dist_ratio=ratio, ransac_round=rounds)
+    guided = bool(rng.uniform() < 0.3)                     # -gm: guided matching in the geometric stage
+    p = S.default_params(dist_ratio=ratio, ransac_round=rounds, guided_matching=int(guided))
     n_cmp = 0
     bow = np.sqrt(rng.random((n_views, 64))).astype(np.float32)       # .bow vectors for the shortlist chain
     with S.Map(m.view_id, m.view_off, m.desc, params=p, view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark,
@@ -46,14 +47,23 @@ def one(seed):
             sel = None
             if rng.uniform() < 0.3:
                 sel = np.sort(rng.choice(n_views, int(rng.integers(1, n_views)), replace=False)).astype(np.uint32)
-            exp = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=sel, ratio=ratio, ransac_round=rounds)
+            exp = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=sel, ratio=ratio, ransac_round=rounds,
+                                 guided=guided)
             dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
             dm.match_putative(dq, sel)
             cnt, mi, mj, md = dm.putative_read()
             assert np.array_equal(cnt, exp["put_count"]) and np.array_equal(mi, exp["put_i"]) and np.array_equal(mj, exp["put_j"])
             dm.geometric_filter(dq)
-            gc, gi = dm.geometric_read()
-            assert np.array_equal(gc, exp["geo_count"]) and np.array_equal(gi, exp["geo_idx"]), "F-matrix filter"
+            if guided:
+                gc, gi, gj = dm.geometric_read_pairs()
+                assert np.array_equal(gc, exp["geo_count"]), "guided matching: counts"
+                for v in np.nonzero(gc)[0]:
+                    o0, n = int(m.view_off[v]), int(gc[v])
+                    assert np.array_equal(gi[o0:o0 + n], exp["geo_idx"][o0:o0 + n]), "guided matching: map features"
+                    assert np.array_equal(gj[o0:o0 + n], exp["geo_j"][o0:o0 + n]), "guided matching: query features"
+            else:
+                gc, gi = dm.geometric_read()
+                assert np.array_equal(gc, exp["geo_count"]) and np.array_equal(gi, exp["geo_idx"]), "F-matrix filter"
             dm.match_set(dq)
             qf, lm, p2, p3 = dm.match_set_read()
             assert np.array_equal(qf, exp["ms_qfeat"]) and np.array_equal(bits(p2), bits(exp["pt2d"])), "match set"
@@ -75,7 +85,7 @@ def one(seed):
                 qb = (bow[rng.integers(0, n_views)] + rng.normal(0, 0.05, 64)).astype(np.float32)
                 osel = oracle_c.bow_select(bow, qb, knn, sel) if knn < n_cand else sel
                 exp_b = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=osel, ratio=ratio,
-                                       ransac_round=rounds)
+                                       ransac_round=rounds, guided=guided)
                 c.begin_bow(dq, qb, knn, sel)
                 pose3, pq3, _ = c.end()
                 assert bool(pose3.ok) == exp_b["ok"], "shortlist chain: ok flag"

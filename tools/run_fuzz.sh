@@ -1,0 +1,5 @@
+# randomised parity campaigns on the final code of the round (copy the .txt files into profiles/)
+mkdir -p gpurun_out
+timeout -k 10 1000 python tests/tools/fuzz_parity.py ${N_PARITY:-600} 52000 > gpurun_out/fuzz_parity.txt 2>&1; rc=$?; tail -2 gpurun_out/fuzz_parity.txt; [ $rc -eq 0 ] || exit $rc
+timeout -k 10 600 python tests/tools/fuzz_sharded.py ${N_SHARDED:-300} 58000 > gpurun_out/fuzz_sharded.txt 2>&1; rc=$?; tail -2 gpurun_out/fuzz_sharded.txt; [ $rc -eq 0 ] || exit $rc
+timeout -k 10 600 python tests/tools/fuzz_mapside.py ${N_MAPSIDE:-300} > gpurun_out/fuzz_mapside.txt 2>&1; rc=$?; tail -2 gpurun_out/fuzz_mapside.txt; [ $rc -eq 0 ] || exit $rc
