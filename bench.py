@@ -29,9 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0
-# Issue ceiling of K1's instruction mix (v_xor_b32 + v_bcnt_u32_b32 1:1) at 8 waves per SIMD on a balanced
-# persistent grid: tools/valu_rates.hip -> profiles/r02_valu_rates.jsonl (in-kernel stamps and wall time agree)
-VALU_PEAK_TOPS = 51.0
+# Issue ceiling of K1's instruction mix (v_xor_b32 + v_bcnt_u32_b32 1:1): tools/valu_rates.hip at 8 waves per SIMD on an
+# exactly balanced grid (LDS-sized so that every SIMD holds exactly 8 waves; census in profiles/r02_valu_rates.jsonl),
+# lane-ops over WALL time.  The per-wave cycle stamps of the same run must not be used: all waves start within 0.7 us
+# but finish up to 1.4 ms apart (the SIMD's arbitration is not fair), so a wave's own duration divided by the waves per
+# SIMD over-reads the SIMD's rate by ~1.6x -- that is where round 1's "51 T from the stamps" came from.
+VALU_PEAK_TOPS = 41.3
 OPS_PER_PAIR = 35  # 16 xor + 16 bcnt + lshl_or + med3 + min (hamming.hip)
 
 # HBM bytes per launch of the roofline kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
@@ -66,6 +69,9 @@ def parse(argv=None):
                          "GIL, so the kernel launches of different queries are issued in parallel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-phase", action="store_true", help="skip the full-bank scan and the N_q sweep")
+    ap.add_argument("--no-real-stats", action="store_true",
+                    help="skip the side measurement on M-LDB-like descriptors (its scans run the same kernel on another "
+                         "bank: leave it out of a rocprofv3 run whose averages are meant for the 20 M-row scan)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args(argv)
 
@@ -90,12 +96,10 @@ def pmc_traffic(match):
         return None, None
     with open(PMC_SUMMARY) as fh:
         d = json.load(fh)
-    tot = 0.0
-    for k in ("k_hamming_screen", "k_hamming_rows"):
-        if k not in d or "hbm_bytes_per_dispatch" not in d[k]:
-            return None, None
-        tot += d[k]["hbm_bytes_per_dispatch"]["total"]
-    return tot, os.path.relpath(PMC_SUMMARY, ROOT)
+    k = "k_hamming_screen<8, 10, 1>"       # the full-bank scan (the short-list form is <8, 10, 4>)
+    if k not in d or "hbm_bytes_per_dispatch" not in d[k]:
+        return None, None
+    return d[k]["hbm_bytes_per_dispatch"]["total"], os.path.relpath(PMC_SUMMARY, ROOT)
 
 
 def cpu_baseline(m, queries, seconds):
@@ -307,6 +311,12 @@ def main():
     v1 = (a.views * (rank + 1)) // world
     r0, r1 = int(m.view_off[v0]), int(m.view_off[v1])
     params = S.default_params(device=local_rank, profile=0, ransac_round=25)
+    # diagnosis only (what each latency-bound stage costs the throughput); a line produced with these set is not the metric
+    diag = {k: int(os.environ[k]) for k in ("SFMLOC_DIAG_RANSAC_ROUND", "SFMLOC_DIAG_P3P_ITER") if k in os.environ}
+    if "SFMLOC_DIAG_RANSAC_ROUND" in diag:
+        params.ransac_round = diag["SFMLOC_DIAG_RANSAC_ROUND"]
+    if "SFMLOC_DIAG_P3P_ITER" in diag:
+        params.p3p_max_iteration = diag["SFMLOC_DIAG_P3P_ITER"]
     dev_map = S.Map(m.view_id[v0:v1], m.view_off[v0:v1 + 1] - m.view_off[v0], m.desc[r0:r1], params=params,
                     view_wh=m.view_wh[v0:v1], kpt_xy=m.kpt_xy[r0:r1], row_landmark=m.row_landmark[r0:r1],
                     landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic,
@@ -503,7 +513,7 @@ def main():
         sweep = nq_sweep_phase(S, dev_map, rows_rank)
     dev_map.set_profile(0)
     real_stats = None
-    if rank == 0 and world == 1 and not a.no_roofline_phase:
+    if rank == 0 and world == 1 and not a.no_roofline_phase and not a.no_real_stats:
         real_stats = real_statistics_phase(S, synth, local_rank)
     if rank == 0:
         sel_rows = None
@@ -537,7 +547,7 @@ def main():
                                        "per-shard k-best BoW keys and ONE all-gather of candidate parts (RCCL), P3P of "
                                        "query i on rank i mod N" if world > 1 else "1 GPU, whole bank"),
                        "queries_localised": f"{n_ok_timed}/{n_timed}",
-                       "map_generation_s": round(t_gen, 1)},
+                       "map_generation_s": round(t_gen, 1), **({"DIAGNOSTIC_OVERRIDES_NOT_THE_METRIC": diag} if diag else {})},
             "latency_ms": {"p50": float(np.percentile(lat_single or lat_throughput, 50) * 1e3),
                            "p95": float(np.percentile(lat_single or lat_throughput, 95) * 1e3),
                            "mode": "one query in flight" if lat_single else f"{a.batch}-query batches",
@@ -574,7 +584,9 @@ def main():
                         "a machine balance of ~6): frac against HBM is <1 % whatever the kernel; `valu` is the bound "
                         "that applies, `hbm_bound_regime` the same kernel family where HBM is the bound",
                 "valu": {"achieved": valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": valu / VALU_PEAK_TOPS,
-                         "peak_source": "profiles/r02_valu_rates.jsonl (xor+bcnt mix, 8 waves/SIMD, balanced grid)",
+                         "peak_source": "profiles/r02_valu_rates.jsonl (xor+bcnt mix, 8 waves/SIMD, exactly balanced grid, "
+                                        "lane-ops over wall time; K1 also issues cheaper v_cmp / v_xor, so it can read "
+                                        "a little above the pure mix)",
                          "ops_per_pair_exact": OPS_PER_PAIR, "ops_per_pair_issued": lane_ops / max(1, pairs),
                          "pairs_per_s": pairs / (k1_ms * 1e-3),
                          "pairs_finished_frac": st_roof.hamming_pairs_finished / max(1, st_roof.hamming_pairs),
