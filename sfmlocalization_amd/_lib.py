@@ -12,7 +12,8 @@ import sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsfmloc_hip.so")
+# SFMLOC_LIB_PATH: an instrumented build of the same library (tools/ only; e.g. the time-stamp build of K3 / K5)
+LIB_PATH = os.environ.get("SFMLOC_LIB_PATH") or os.path.join(_HERE, "lib", "libsfmloc_hip.so")
 _handle = None
 
 

@@ -29,6 +29,33 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// Diagnostic build only (make EXTRA=-DSFMLOC_STAMPS OUT=../lib/libsfmloc_hip_stamps.so, tools/k35_stamps.py): thread 0
+// of a workgroup records wall_clock64() (100 MHz) at stage boundaries of K3 and K5.  Compiles to nothing otherwise.
+#ifdef SFMLOC_STAMPS
+__device__ unsigned long long g_stamps_p3p[16 * 256 * 8];  // [round][hypothesis][point]
+__device__ unsigned long long g_stamps_sel[16 * 8];        // [round][point]
+__device__ unsigned long long g_stamps_f[256 * 64];        // [workgroup][event]: tag << 48 | time
+#define STAMP_P3P(rnd, b, k)                                                                      \
+  do {                                                                                            \
+    if (threadIdx.x == 0 && (rnd) < 16 && (b) < 256) g_stamps_p3p[(((rnd)*256) + (b)) * 8 + (k)] = wall_clock64(); \
+  } while (0)
+#define STAMP_SEL(rnd, k)                                                              \
+  do {                                                                                 \
+    if (threadIdx.x == 0 && (rnd) < 16) g_stamps_sel[(rnd)*8 + (k)] = wall_clock64(); \
+  } while (0)
+#define STAMP_F_DECL int stamp_f_n = 0
+#define STAMP_F(tag)                                                                                         \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && stamp_f_n < 64)                                              \
+      g_stamps_f[blockIdx.x * 64 + stamp_f_n++] = ((unsigned long long)(tag) << 48) | (wall_clock64() & 0xFFFFFFFFFFFFull); \
+  } while (0)
+#else
+#define STAMP_P3P(rnd, b, k) do {} while (0)
+#define STAMP_SEL(rnd, k) do {} while (0)
+#define STAMP_F_DECL do {} while (0)
+#define STAMP_F(tag) do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // block-wide helpers (256 threads)
 // ---------------------------------------------------------------------------------------------------
@@ -180,6 +207,133 @@ __device__ __forceinline__ void wave_sort_regs(uint64_t (&key)[E], uint32_t (&id
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same sort without LDS round trips (wave_sort_regs spends most of its time waiting for ds_bpermute: 33 dependent
+// exchange stages for 256 elements).  Two changes:
+//  * the element index rides in the low kPackBits bits of the 64-bit key, so a compare-exchange is one 64-bit compare
+//    and two selects.  The 10 bits it displaces are the last bits of the residual's mantissa; they are parked in LDS
+//    (`low`, one u32 per element, private to the wave) and put back after the sort.  Two keys that agree in everything
+//    BUT those bits are ordered by index instead of by value; if that was wrong the restored keys do not ascend, which
+//    is checked, and such a wave sorts again with wave_sort_regs.  The result is therefore always the order by
+//    (key, idx) of the exact sort.
+//  * lane ^ j exchanges are DPP moves (j = 1, 2, 4, 8) and gfx950's v_permlane16_swap / v_permlane32_swap (j = 16,
+//    32); which lanes keep the minimum at a stage is a compile-time lane mask, applied with s_xor + v_cndmask.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPackBits = 10;  // 64 * 16 elements at most
+constexpr uint64_t kPackMask = (1ull << kPackBits) - 1;
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_perm(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, false);  // every lane is written: no `old` operand
+}
+// the value lane ^ J holds
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, bool odd_half) {
+  if constexpr (J == 1) return dpp_perm<0xB1>(v);   // quad_perm:[1,0,3,2]
+  if constexpr (J == 2) return dpp_perm<0x4E>(v);   // quad_perm:[2,3,0,1]
+  if constexpr (J == 4) {                           // banks 0, 2 read lane + 4 (row_shl:4), banks 1, 3 lane - 4 (row_shr:4)
+    const int t = __builtin_amdgcn_mov_dpp((int)v, 0x104, 0xF, 0x5, false);  // (banks 1, 3 are written next)
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+  }
+  if constexpr (J == 8) return dpp_perm<0x128>(v);  // row_ror:8
+  if constexpr (J == 16) {  // rows 1, 3 of the first operand <-> rows 0, 2 of the second
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return odd_half ? r[0] : r[1];
+  }
+  if constexpr (J == 32) {  // upper half of the first operand <-> lower half of the second
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return odd_half ? r[0] : r[1];
+  }
+  return v;
+}
+// lane bit set in m -> b, else a (m is wave-uniform: an SGPR pair)
+__device__ __forceinline__ uint32_t select_by_mask(uint32_t a, uint32_t b, uint64_t m) {
+  uint32_t r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+  return r;
+}
+// lanes l of register r that keep the smaller key at stage (k, j < 64) of the ascending bitonic network
+constexpr uint64_t want_min_mask(int k, int j, int r) {
+  uint64_t m = 0;
+  for (int l = 0; l < 64; ++l) {
+    const bool up = ((((r << 6) | l) & k) == 0);
+    if (((l & j) == 0) == up) m |= 1ull << l;
+  }
+  return m;
+}
+
+template <int E, int K, int J>
+__device__ __forceinline__ void packed_stage(uint64_t (&key)[E], int lane) {
+  if constexpr (J >= 64) {
+    constexpr int jr = J >> 6;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      if ((r & jr) == 0) {
+        const int r2 = r | jr;
+        const bool up = ((r << 6) & K) == 0;
+        const uint64_t a = key[r], b = key[r2];
+        const bool swap = (a > b) == up;
+        key[r] = swap ? b : a;
+        key[r2] = swap ? a : b;
+      }
+    }
+  } else {
+    const bool odd_half = (lane & J) != 0;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const uint32_t lo = (uint32_t)key[r], hi = (uint32_t)(key[r] >> 32);
+      const uint32_t olo = lane_xor_u32<J>(lo, odd_half), ohi = lane_xor_u32<J>(hi, odd_half);
+      const uint64_t o = ((uint64_t)ohi << 32) | olo;
+      // take the partner's key where (partner < mine) == (this lane keeps the minimum)
+      const uint64_t less = __builtin_amdgcn_ballot_w64(o < key[r]);
+      const uint64_t take = ~(less ^ want_min_mask(K, J, r));
+      key[r] = ((uint64_t)select_by_mask(hi, ohi, take) << 32) | select_by_mask(lo, olo, take);
+    }
+  }
+}
+template <int E, int K, int J>
+__device__ __forceinline__ void packed_merge(uint64_t (&key)[E], int lane) {
+  packed_stage<E, K, J>(key, lane);
+  if constexpr (J > 1) packed_merge<E, K, (J >> 1)>(key, lane);
+}
+template <int E, int K>
+__device__ __forceinline__ void packed_network(uint64_t (&key)[E], int lane) {
+  if constexpr (K > 2) packed_network<E, (K >> 1)>(key, lane);
+  packed_merge<E, K, (K >> 1)>(key, lane);
+}
+
+// key[r] / idx[r]: element r*64 + lane on entry (idx is overwritten), sorted position r*64 + lane on return;
+// low: 64*E u32 of LDS owned by this wave (free on return).
+template <int E>
+__device__ __forceinline__ void wave_sort_fast(uint64_t (&key)[E], uint32_t (&idx)[E], uint32_t *low) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t p = (uint32_t)((r << 6) + lane);
+    low[p] = (uint32_t)(key[r] & kPackMask);
+    key[r] = (key[r] & ~kPackMask) | p;
+  }
+  packed_network<E, 64 * E>(key, lane);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    idx[r] = (uint32_t)(key[r] & kPackMask);
+    key[r] = (key[r] & ~kPackMask) | low[idx[r]];
+  }
+  // Keys that agree above the packed bits were ordered by index; that is the exact order unless their displaced bits
+  // descend somewhere, i.e. unless the restored keys are not ascending.  (Equal keys -- the +inf residuals of a
+  // degenerate model, the padding -- are in index order, which is the exact order.)
+  bool ambiguous = false;
+  uint64_t prev_last = 0ull;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    uint64_t before = __shfl_up(key[r], 1, 64);
+    if (lane == 0) before = prev_last;
+    if (before > key[r]) ambiguous = true;
+    if (r + 1 < E) prev_last = __shfl(key[r], 63, 64);
+  }
+  if (__builtin_amdgcn_ballot_w64(ambiguous) != 0ull) wave_sort_regs<E>(key, idx);  // any order is a valid input
 }
 
 // bestNFA over the sorted registers of wave_sort_regs (position r*64 + lane holds e_{position+1}); same
@@ -620,6 +774,8 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
   F2Shared &S = *reinterpret_cast<F2Shared *>(smem_raw);
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63;
+  STAMP_F_DECL;
+  STAMP_F(1);
   const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
   const int m = (int)A.put_count[v];
   const uint32_t off = A.view_off[v];
@@ -667,6 +823,7 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
     S.logc_k[q] = val;
   }
   __syncthreads();
+  STAMP_F(2);  // prelude done (value: m in the low bits is not needed; the tool reads put_count)
 
   // (the lambdas below must not capture the kernel-argument struct: that would put all of it on the stack)
   const uint64_t seed = A.seed;
@@ -705,8 +862,8 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
       key[r] = kv;
       idx[r] = (uint32_t)p;
     }
-    wave_sort_regs<E>(key, idx);
     uint32_t *iw = S.idx[wv];
+    wave_sort_fast<E>(key, idx, iw);
 #pragma unroll
     for (int r = 0; r < E; ++r) iw[(r << 6) + lane] = idx[r];
     return best_nfa_regs<E>(key, m, 7, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k);
@@ -753,6 +910,7 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
       __syncthreads();  // pre_* / res_* of the previous batch are no longer read
       for (int b = wv; b < B; b += kF2Waves) wave_solve(nullptr, m, iter + b, S.pre_models[b], &S.pre_nm[b]);
       __syncthreads();
+      STAMP_F(3);  // speculative solves done
       // flattened model list in iteration order
       if (tid == 0) {
         int n = 0;
@@ -819,13 +977,16 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
           }
         }
         __syncthreads();
+        STAMP_F(4);  // one evaluation round done
         done = (done + kF2Waves < total) ? done + kF2Waves : total;
       }
+      STAMP_F(5);  // uniform batch closed (incl. the inlier rebuild when the phase ended)
       iter += b_done;
     } else {
       __syncthreads();
       if (wv == 0) wave_solve(S.vec_index, n_index, iter, S.pre_models[0], &S.pre_nm[0]);
       __syncthreads();
+      STAMP_F(6);  // sequential iteration: solved
       const int nm = S.pre_nm[0];
       if (wv < nm) {
         const NfaBest r = wave_eval(&S.pre_models[0][9 * wv]);
@@ -865,9 +1026,11 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
         }
       }
       ++iter;
+      STAMP_F(7);  // sequential iteration: evaluated + replayed
     }
   }
   __syncthreads();
+  STAMP_F(8);
   if (min_nfa >= 0.0) n_in = 0;
   if ((double)n_in > 7 * 2.5) {
     if (!inl_valid) rebuild_inliers(false);
@@ -885,6 +1048,7 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
   } else if (tid == 0) {
     A.geo_count[v] = 0;
   }
+  STAMP_F(9);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1222,6 +1386,10 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
   extern __shared__ unsigned char smem_raw[];
   P3pShared &S = *reinterpret_cast<P3pShared *>(smem_raw);
   const int tid = threadIdx.x;
+#ifdef SFMLOC_STAMPS
+  const int stamp_round = st.rounds;
+#endif
+  STAMP_P3P(stamp_round, b, 0);
   const size_t inl_stride = p3p_inl_stride(n, A.max_n);
   // where the block-wide sort of this hypothesis runs
   uint64_t *const skey = n > kP3pMaxN ? A.ws_key + (size_t)b * A.max_n : S.key;
@@ -1239,12 +1407,15 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
       X[3 * i + 1] = A.pt3d[3 * smp[i] + 1];
       X[3 * i + 2] = A.pt3d[3 * smp[i] + 2];
     }
+    STAMP_P3P(stamp_round, b, 1);
     S.nm = p3p_kneip_prepare(x, X, S.prep);
   }
   __syncthreads();
+  STAMP_P3P(stamp_round, b, 2);
   const int nm = S.nm;
   if (tid < nm) p3p_kneip_model(S.prep, tid, S.models + 12 * tid);  // the four roots' models side by side
   __syncthreads();
+  STAMP_P3P(stamp_round, b, 3);
   const double logalpha0 = det_log10(3.14159265358979323846);
   const double loge0 = det_log10(4.0 * (double)(n - s));
   double best = pos_inf();
@@ -1264,7 +1435,11 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
       // (the lambda must not capture the kernel-argument struct: that would put all of it on the stack)
       const double *pt3d = A.pt3d, *xn = A.xn;
       const float *logc_n = A.logc_n, *logc_k = A.logc_k;
+#ifdef SFMLOC_STAMPS
+      auto run = [&M, &r, &r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b](auto e_tag) {
+#else
       auto run = [&M, &r, &r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0](auto e_tag) {
+#endif
         constexpr int E = decltype(e_tag)::value;
         uint64_t key[E];
         uint32_t idx[E];
@@ -1277,7 +1452,9 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
           key[rr] = kv;
           idx[rr] = (uint32_t)p;
         }
-        wave_sort_regs<E>(key, idx);
+        STAMP_P3P(stamp_round, b, 6);
+        wave_sort_fast<E>(key, idx, iw);
+        STAMP_P3P(stamp_round, b, 7);
 #pragma unroll
         for (int rr = 0; rr < E; ++rr) iw[(rr << 6) + lane] = idx[rr];
         r = best_nfa_regs<E>(key, n, 3, pos_inf(), logalpha0, 1.0, loge0, logc_n, logc_k);
@@ -1297,6 +1474,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
       S.red_err[wv] = r_err;
     }
     __syncthreads();
+    STAMP_P3P(stamp_round, b, 4);
     for (int k = 0; k < nm; ++k)
       if (S.red_nfa[k] < best) {  // strict: the first model of the hypothesis wins ties, as the sequential loop does
         best = S.red_nfa[k];
@@ -1341,6 +1519,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
     if (best_m >= 0)
       for (int q = 0; q < 12; ++q) A.hyp_model[12 * b + q] = S.models[12 * best_m + q];
   }
+  STAMP_P3P(stamp_round, b, 5);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1516,6 +1695,10 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
   P3pState &st = *A.state;
   if (st.done) return;
   const int tid = threadIdx.x;
+#ifdef SFMLOC_STAMPS
+  const int stamp_round = st.rounds;
+#endif
+  STAMP_SEL(stamp_round, 0);
   batch = p3p_round_batch(st.n, batch);  // what k_p3p_eval evaluated this round
   const size_t inl_stride = p3p_inl_stride(st.n, A.max_n);
   // every thread replays the same scalar state machine; only the copies are cooperative
@@ -1601,6 +1784,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
       }
     }
   }
+  STAMP_SEL(stamp_round, 1);
   if (best_b >= 0) {
     const int32_t *src = A.hyp_inl + (size_t)best_b * inl_stride;
     for (int p = tid; p < n_in; p += kThreads) A.best_inl[p] = src[p];
@@ -1626,6 +1810,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
       for (int q = 0; q < 12; ++q) st.model[q] = A.hyp_model[12 * best_b + q];
     if (done) st.done = 1;
   }
+  STAMP_SEL(stamp_round, 2);
   if (!done) return;
   // ----- ACRANSAC epilogue + SfM_Localizer::Localize + localization.cpp:511-547 -----
   __shared__ double Msh[12];
@@ -1698,6 +1883,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
       if (A.refine_pose) R.stage_seconds[0] = refine_cost;  // overwritten by the host; kept for sfmloc_pose_read
     }
   }
+  STAMP_SEL(stamp_round, 3);
 }
 
 // L10[i] = log10(i) for the logcombi tables, computed once per map on the device
@@ -1764,6 +1950,45 @@ __global__ __launch_bounds__(64) void k_debug_wave7(const double *in, int n, int
   if (lane < 27) o[1 + lane] = (lane < 9 * nm) ? f : 0.0;
 }
 
+// op 9: wave_sort_fast, one wave per row of P + 1 doubles (P = 64, 128, ... 1024 keys, then n: elements >= n are
+// padding); out[p] = index of the element at sorted position p, out[P + p] = its key as a double
+template <int E>
+__device__ void debug_sort_row(const double *x, double *o, int n, uint32_t *low) {
+  const int lane = threadIdx.x & 63;
+  uint64_t key[E];
+  uint32_t idx[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int p = (r << 6) + lane;
+    key[r] = p < n ? d2u(x[p]) : ~0ull;
+    idx[r] = (uint32_t)p;
+  }
+  wave_sort_fast<E>(key, idx, low);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int p = (r << 6) + lane;
+    o[p] = (double)idx[r];
+    o[64 * E + p] = u2d(key[r]);
+  }
+}
+__global__ __launch_bounds__(64) void k_debug_sort(const double *in, int n_rows, int in_stride, double *out, int out_stride) {
+  __shared__ uint32_t low[1024];
+  const int i = blockIdx.x;
+  if (i >= n_rows) return;
+  const double *x = in + (size_t)i * in_stride;
+  double *o = out + (size_t)i * out_stride;
+  const int P = in_stride - 1;
+  const int n = (int)x[P];
+  switch (P >> 6) {
+    case 1: debug_sort_row<1>(x, o, n, low); break;
+    case 2: debug_sort_row<2>(x, o, n, low); break;
+    case 4: debug_sort_row<4>(x, o, n, low); break;
+    case 8: debug_sort_row<8>(x, o, n, low); break;
+    case 16: debug_sort_row<16>(x, o, n, low); break;
+    default: break;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -1779,6 +2004,8 @@ int launch_debug_math(int op, const double *d_in, int n, int in_stride, double *
                       hipStream_t s) {
   if (op == 8)
     hipLaunchKernelGGL(k_debug_wave7, dim3(n), dim3(64), 0, s, d_in, n, in_stride, d_out, out_stride);
+  else if (op == 9)
+    hipLaunchKernelGGL(k_debug_sort, dim3(n), dim3(64), 0, s, d_in, n, in_stride, d_out, out_stride);
   else
     hipLaunchKernelGGL(k_debug_math, dim3((n + 63) / 64), dim3(64), 0, s, op, d_in, n, in_stride, d_out, out_stride);
   SFM_HIP(hipGetLastError());
@@ -2056,4 +2283,29 @@ int launch_p3p_round(Ctx *c, int batch) {
   return SFMLOC_OK;
 }
 
+
+#ifdef SFMLOC_STAMPS
+int debug_stamps_read(int which, unsigned long long *out, size_t n) {
+  hipDeviceSynchronize();
+  hipError_t e = which == 0   ? hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_p3p), n * 8)
+                 : which == 1 ? hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_sel), n * 8)
+                              : hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_f), n * 8);
+  return e == hipSuccess ? 0 : -1;
+}
+int debug_stamps_clear() {
+  static unsigned long long z[16 * 256 * 8];
+  hipDeviceSynchronize();
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_p3p), z, sizeof(z));
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_sel), z, 16 * 8 * 8);
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_f), z, 256 * 64 * 8);
+  return 0;
+}
+#endif
 }  // namespace sfmloc
+
+#ifdef SFMLOC_STAMPS
+extern "C" int sfmloc_debug_stamps_read(int which, unsigned long long *out, unsigned long long n) {
+  return sfmloc::debug_stamps_read(which, out, (size_t)n);
+}
+extern "C" int sfmloc_debug_stamps_clear(void) { return sfmloc::debug_stamps_clear(); }
+#endif

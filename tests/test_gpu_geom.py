@@ -37,6 +37,37 @@ def test_f64_primitives_bit_exact(oracle_c):
     np.testing.assert_array_equal(bits(got[:, 1]), bits(a / b))
 
 
+def test_wave_sort_fast_is_the_exact_order():
+    """K3 / K5 sort a model's residuals with the index packed into the key's low bits (acransac.hip wave_sort_fast);
+    the order must be the exact (key bits, index) order in every case, including the ones that force its fallback."""
+    rng = np.random.default_rng(77)
+    for P in (64, 128, 256, 512, 1024):
+        rows = []
+        for case in range(24):
+            n = int(rng.integers(1, P + 1)) if case % 3 else P
+            v = rng.random(P) * 10.0 ** rng.integers(-12, 6)
+            if case % 4 == 1:      # exact duplicates
+                v[rng.integers(0, P, P // 2)] = v[rng.integers(0, P, P // 2)]
+            if case % 4 == 2:      # keys that differ only in the bits the index displaces
+                base = v[:P // 4].view(np.uint64) & ~np.uint64(1023)
+                v[:P // 4] = (base | rng.integers(0, 1024, P // 4).astype(np.uint64)).view(np.float64)
+                v[P // 4:P // 2] = (base | rng.integers(0, 1024, P // 4).astype(np.uint64)).view(np.float64)
+                v = rng.permutation(v)
+            if case % 4 == 3:      # zeros, infinities
+                v[rng.integers(0, P, 5)] = 0.0
+                v[rng.integers(0, P, 5)] = np.inf
+            rows.append(np.concatenate([v, [float(n)]]))
+        x = np.array(rows)
+        got = S.debug_math(9, x, 2 * P)
+        for row, out in zip(x, got):
+            n = int(row[P])
+            key = row[:P].copy().view(np.uint64)
+            key[n:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            order = np.lexsort((np.arange(P), key))
+            assert np.array_equal(out[:P].astype(np.int64), order), (P, n)
+            assert np.array_equal(np.ascontiguousarray(out[P:2 * P]).view(np.uint64)[:n], key[order][:n]), (P, n)
+
+
 def test_polynomial_solvers_bit_exact(oracle_c):
     rng = np.random.Generator(np.random.PCG64(12))
     c = rng.normal(size=(500, 4)) * 10.0 ** rng.uniform(-2, 2, (500, 4))
