@@ -338,6 +338,53 @@ __device__ __forceinline__ void wave_sort_fast(uint64_t (&key)[E], uint32_t (&id
 
 // bestNFA over the sorted registers of wave_sort_regs (position r*64 + lane holds e_{position+1}); same
 // candidates, same per-lane visiting order and same reduction as best_nfa_wave
+// the two table entries of sorted position r*64 + lane (k = position + 1), fetched ahead of the sort
+template <int E>
+__device__ __forceinline__ void nfa_tables_fetch(float (&cn)[E], float (&ck)[E], int n, const float *logc_n,
+                                                 const float *logc_k) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int kk = (r << 6) + lane + 1;
+    cn[r] = kk <= n ? logc_n[kk] : 0.0f;
+    ck[r] = kk <= n ? logc_k[kk] : 0.0f;
+  }
+}
+// wave_reduce_nfa: the same first-minimum reduction for both forms below
+__device__ __forceinline__ NfaBest wave_reduce_nfa(double lb, int lk);
+
+// K5's form (one wave per SIMD, latency-bound): the logarithms of all E positions first, branch-free, so that the E
+// dependent chains interleave (values of positions that are not candidates are computed and dropped); table entries
+// fetched ahead of the sort
+template <int E>
+__device__ __forceinline__ NfaBest best_nfa_regs_ilp(const uint64_t (&key)[E], int n, int s, double max_thr,
+                                                     double logalpha0, double mult, double loge0, const float (&cn)[E],
+                                                     const float (&ck)[E]) {
+  const int lane = threadIdx.x & 63;
+  double lb = pos_inf();
+  int lk = 0x7FFFFFFF;
+  double l10[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) l10[r] = det_log10_inline(u2d(key[r]) + (double)FLT_EPSILON);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int kk = (r << 6) + lane + 1;
+    if (kk > s && kk <= n) {
+      const double ek = u2d(key[r]);
+      if (ek <= max_thr) {
+        const double logalpha = logalpha0 + mult * l10[r];
+        const double nfa = loge0 + logalpha * (double)(kk - s) + (double)cn[r] + (double)ck[r];
+        if (nfa < lb) {
+          lb = nfa;
+          lk = kk;
+        }
+      }
+    }
+  }
+  return wave_reduce_nfa(lb, lk);
+}
+
+// K3's form (sixteen waves share a compute unit, issue-bound: fewer instructions and registers matter, latency does not)
 template <int E>
 __device__ __forceinline__ NfaBest best_nfa_regs(const uint64_t (&key)[E], int n, int s, double max_thr,
                                                  double logalpha0, double mult, double loge0, const float *logc_n,
@@ -360,6 +407,9 @@ __device__ __forceinline__ NfaBest best_nfa_regs(const uint64_t (&key)[E], int n
       }
     }
   }
+  return wave_reduce_nfa(lb, lk);
+}
+__device__ __forceinline__ NfaBest wave_reduce_nfa(double lb, int lk) {
   for (int off = 32; off > 0; off >>= 1) {
     const double ob = __shfl_xor(lb, off, 64);
     const int ok = __shfl_xor(lk, off, 64);
@@ -1319,6 +1369,8 @@ __global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
     st.done = 0;
     st.rounds = 0;
     st.status = 0;
+    st.arrive = 0u;
+    st.finished = 0;
     st.min_nfa = pos_inf();
     st.errmax = pos_inf();
     for (int i = 0; i < 12; ++i) st.model[i] = 0.0;
@@ -1326,10 +1378,12 @@ __global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
     // localization.cpp:506 "cpt > MINUM_NUMBER_OF_POINT_RESECTION"; ACRANSAC: nData <= sizeSample -> nothing
     if (n <= A.min_resection_points || n <= 3) {
       st.done = 1;
+      st.finished = 1;  // nothing to estimate: the result record written below is final
       go = 0;
     }
     if (n > A.max_n) {
       st.done = 1;
+      st.finished = 1;
       st.status = 4;
       go = 0;
     }
@@ -1375,15 +1429,23 @@ struct P3pShared {
   double red_err[kThreads / 64];
 };
 
-__global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
+// A round's results go from the workgroup that computed them to the one that replays the round, which may sit on
+// another XCD (another L2): they are written through (agent-scope stores), so that delivering them needs no L2
+// write-back -- only the stores' completion, which the workgroup barrier in front of the counter waits for.
+template <typename T>
+__device__ __forceinline__ void store_through(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one hypothesis: sample, solve, evaluate the (up to 4) models, leave the best one's NFA / inliers / model in the
+// round's result arrays.  Executed by one workgroup of k_p3p_round.
+__device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch, unsigned char *smem_raw) {
   const P3pState &st = *A.state;
-  if (st.done) return;
   const int b = blockIdx.x;
   const int n = st.n;
   if (b >= p3p_round_batch(n, batch)) return;
   const long it = (long)st.iter + b;
   if (it >= st.n_iter) return;
-  extern __shared__ unsigned char smem_raw[];
   P3pShared &S = *reinterpret_cast<P3pShared *>(smem_raw);
   const int tid = threadIdx.x;
 #ifdef SFMLOC_STAMPS
@@ -1396,6 +1458,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
   uint32_t *const sidx = n > kP3pMaxN ? A.ws_idx + (size_t)b * A.max_n : S.idx;
   constexpr int s = 3;
   const int P = next_pow2(n);
+  const bool fast = P <= kP3pWaveSeg;
   if (tid == 0) {
     int32_t smp[3];
     ac_sample<3>(st.identity ? nullptr : A.vec_index, st.n_index, A.seed, STAGE_P3P, A.stream, (uint32_t)it, smp);
@@ -1421,7 +1484,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
   double best = pos_inf();
   int best_k = 0, best_m = -1;
   double best_err = pos_inf();
-  if (P <= kP3pWaveSeg) {
+  if (fast) {
     // fast path: the (up to 4) models of the hypothesis are evaluated side by side, one wave each, residuals
     // sorted in registers
     const int wv = tid >> 6, lane = tid & 63;
@@ -1443,13 +1506,16 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
         constexpr int E = decltype(e_tag)::value;
         uint64_t key[E];
         uint32_t idx[E];
+        float cn[E], ck[E];
+        nfa_tables_fetch<E>(cn, ck, n, logc_n, logc_k);  // in flight during the residuals and the sort
+        // the wave is alone on its SIMD: the E residuals of a lane are computed without branches (clamped index, then a
+        // select) so that their dependent f64 chains -- two divisions each -- interleave
 #pragma unroll
         for (int rr = 0; rr < E; ++rr) {
           const int p = (rr << 6) + lane;
-          uint64_t kv = ~0ull;
-          if (p < n)
-            kv = d2u(err_resection(M, pt3d[3 * p], pt3d[3 * p + 1], pt3d[3 * p + 2], xn[2 * p], xn[2 * p + 1]));
-          key[rr] = kv;
+          const int pc = p < n ? p : n - 1;
+          const double e = err_resection(M, pt3d[3 * pc], pt3d[3 * pc + 1], pt3d[3 * pc + 2], xn[2 * pc], xn[2 * pc + 1]);
+          key[rr] = p < n ? d2u(e) : ~0ull;
           idx[rr] = (uint32_t)p;
         }
         STAMP_P3P(stamp_round, b, 6);
@@ -1457,7 +1523,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
         STAMP_P3P(stamp_round, b, 7);
 #pragma unroll
         for (int rr = 0; rr < E; ++rr) iw[(rr << 6) + lane] = idx[rr];
-        r = best_nfa_regs<E>(key, n, 3, pos_inf(), logalpha0, 1.0, loge0, logc_n, logc_k);
+        r = best_nfa_regs_ilp<E>(key, n, 3, pos_inf(), logalpha0, 1.0, loge0, cn, ck);
         if (r.k != 0x7FFFFFFF) r_err = u2d(sorted_key_at<E>(key, r.k - 1));
       };
       switch (P >> 6) {
@@ -1485,7 +1551,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
       best_err = S.red_err[best_m];
       int32_t *dst = A.hyp_inl + (size_t)b * inl_stride;
       const uint32_t *src = S.idx + (size_t)best_m * kP3pWaveSeg;
-      for (int p = tid; p < best_k; p += kThreads) dst[p] = (int32_t)src[p];
+      for (int p = tid; p < best_k; p += kThreads) store_through(dst + p, (int32_t)src[p]);
     }
   } else
   for (int k = 0; k < nm; ++k) {
@@ -1509,15 +1575,15 @@ __global__ __launch_bounds__(kThreads) void k_p3p_eval(P3pArgs A, int batch) {
       best_m = k;
       best_err = u2d(skey[r.k - 1]);
       int32_t *dst = A.hyp_inl + (size_t)b * inl_stride;
-      for (int p = tid; p < best_k; p += kThreads) dst[p] = (int32_t)sidx[p];
+      for (int p = tid; p < best_k; p += kThreads) store_through(dst + p, (int32_t)sidx[p]);
     }
   }
   if (tid == 0) {
-    A.hyp_nfa[b] = best;
-    A.hyp_k[b] = best_k;
-    A.hyp_err[b] = best_err;
+    store_through(A.hyp_nfa + b, best);
+    store_through(A.hyp_k + b, best_k);
+    store_through(A.hyp_err + b, best_err);
     if (best_m >= 0)
-      for (int q = 0; q < 12; ++q) A.hyp_model[12 * b + q] = S.models[12 * best_m + q];
+      for (int q = 0; q < 12; ++q) store_through(A.hyp_model + 12 * b + q, S.models[12 * best_m + q]);
   }
   STAMP_P3P(stamp_round, b, 5);
 }
@@ -1691,9 +1757,16 @@ __device__ double refine_pose_block(const double *pt2d, const double *pt3d, cons
   return cost;
 }
 
-__global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
+// The sequential acceptance rule of ACRANSAC replayed over one round's results; executed by ONE workgroup, the last of
+// the round to deliver its hypothesis (k_p3p_round), so a round is a single launch.
+struct P3pReplayShared {
+  double nfa[kP3pBatchMax];
+  double err[kP3pBatchMax];
+  int k[kP3pBatchMax];
+  int first[kThreads / 64];
+};
+__device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pReplayShared &RS) {
   P3pState &st = *A.state;
-  if (st.done) return;
   const int tid = threadIdx.x;
 #ifdef SFMLOC_STAMPS
   const int stamp_round = st.rounds;
@@ -1710,9 +1783,9 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
   long processed = 0;
   bool index_changed = false;
   // the replay is a dependent chain over up to 512 hypotheses: read their results from LDS, not from L2
-  __shared__ double s_nfa[kP3pBatchMax];
-  __shared__ double s_err[kP3pBatchMax];
-  __shared__ int s_k[kP3pBatchMax];
+  double *const s_nfa = RS.nfa;
+  double *const s_err = RS.err;
+  int *const s_k = RS.k;
   for (int b = tid; b < batch && b < kP3pBatchMax; b += kThreads) {
     const bool live = iter0 + b < n_iter;
     s_nfa[b] = live ? A.hyp_nfa[b] : pos_inf();
@@ -1723,7 +1796,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
   // The sequential rule only acts at two kinds of hypotheses: one whose NFA improves on the running minimum, and the
   // one that ends the uniform phase.  Everything in between is skipped by a block-wide "first index below the
   // minimum" search instead of a dependent 512-step loop.
-  __shared__ int s_first[kThreads / 64];
+  int *const s_first = RS.first;
   auto first_below = [&](int from, int limit, double thr) -> int {
     int mine = 0x7FFFFFFF;
     for (int b = from + tid; b < limit; b += kThreads)
@@ -1809,13 +1882,43 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
     if (best_b >= 0)
       for (int q = 0; q < 12; ++q) st.model[q] = A.hyp_model[12 * best_b + q];
     if (done) st.done = 1;
+    st.arrive = 0u;  // the next round counts from zero
   }
   STAMP_SEL(stamp_round, 2);
-  if (!done) return;
-  // ----- ACRANSAC epilogue + SfM_Localizer::Localize + localization.cpp:511-547 -----
+}
+
+// One round of P3P AC-RANSAC in one launch: every workgroup evaluates one hypothesis and delivers it (release fence +
+// counter); the workgroup that arrives last -- it sees every result (acquire fence) -- replays the sequential rule and
+// writes the state of the next round.  Nobody waits for anybody, so there is no co-residency requirement; workgroups
+// without a hypothesis (past the batch or the budget) only count themselves in.  A launch on a finished state returns at
+// once (st.done is written by the previous launch's last workgroup, i.e. before this launch starts).
+__global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch) {
+  P3pState &st = *A.state;
+  if (st.done) return;
+  extern __shared__ unsigned char smem_raw[];
+  p3p_eval_hypothesis(A, batch, smem_raw);
+  __shared__ unsigned s_ticket;
+  __syncthreads();  // this workgroup's write-through stores have completed (and its LDS is free)
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&st.arrive, 1u);
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing cached here predates the other workgroups' results
+  p3p_replay(A, batch, *reinterpret_cast<P3pReplayShared *>(smem_raw));
+}
+
+// ACRANSAC's epilogue + SfM_Localizer::Localize + localization.cpp:511-547, once per query after the last round
+__global__ __launch_bounds__(kThreads) void k_p3p_finish(P3pArgs A) {
+  P3pState &st = *A.state;
+  if (!st.done || st.finished) return;
+  const int tid = threadIdx.x;
+  const double min_nfa = st.min_nfa, errmax = st.errmax;
+  const int n_in = st.n_in;
+#ifdef SFMLOC_STAMPS
+  const int stamp_round = st.rounds;
+#endif
+
   __shared__ double Msh[12];
-  if (tid == 0)
-    for (int q = 0; q < 12; ++q) Msh[q] = (best_b >= 0) ? A.hyp_model[12 * best_b + q] : st.model[q];
+  if (tid < 12) Msh[tid] = st.model[tid];
   __syncthreads();
   int n_final = n_in;
   if (min_nfa >= 0.0) n_final = 0;
@@ -1865,7 +1968,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
     R.ok = ok ? 1 : 0;
     R.n_inliers = n_final;
     R.n_matches_2d3d = st.n;
-    R.iterations = (int)(iter0 + processed);
+    R.iterations = st.iter;
     R.nfa = min_nfa;
     R.status = st.status;
     R.reserved = refine_iters;
@@ -1882,6 +1985,7 @@ __global__ __launch_bounds__(kThreads) void k_p3p_select(P3pArgs A, int batch) {
       }
       if (A.refine_pose) R.stage_seconds[0] = refine_cost;  // overwritten by the host; kept for sfmloc_pose_read
     }
+    st.finished = 1;
   }
   STAMP_SEL(stamp_round, 3);
 }
@@ -2270,15 +2374,21 @@ int launch_p3p_init(Ctx *c) {
 int launch_p3p_round(Ctx *c, int batch) {
   P3pArgs A = make_p3p_args(c);
   const size_t lds = sizeof(P3pShared);
+  static_assert(sizeof(P3pReplayShared) <= sizeof(P3pShared), "the replay reuses the round's LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_p3p_eval),
+    SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_p3p_round),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_p3p_eval, dim3(batch), dim3(kThreads), lds, c->stream, A, batch);
+  hipLaunchKernelGGL(k_p3p_round, dim3(batch), dim3(kThreads), lds, c->stream, A, batch);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_p3p_select, dim3(1), dim3(kThreads), 0, c->stream, A, batch);
+  return SFMLOC_OK;
+}
+
+int launch_p3p_finish(Ctx *c) {
+  P3pArgs A = make_p3p_args(c);
+  hipLaunchKernelGGL(k_p3p_finish, dim3(1), dim3(kThreads), 0, c->stream, A);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -466,6 +466,7 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
   const int rounds = first_call ? env_rounds : 6;
   for (int r = 0; r < rounds && rc == SFMLOC_OK; ++r)
     rc = launch_p3p_round(c, (first_call && r == 0) ? 64 : env_batch);
+  if (rc == SFMLOC_OK) rc = launch_p3p_finish(c);  // pose + inlier pairs once the state says "done"; a no-op before
   return rc;
 }
 

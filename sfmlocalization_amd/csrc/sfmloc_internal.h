@@ -63,6 +63,8 @@ struct Candidate {
 
 struct P3pState {
   int n, iter, n_iter, n_reserve, n_index, identity, n_in, done, rounds, status;
+  unsigned arrive;  // workgroups of the current round that have delivered their hypothesis (k_p3p_round)
+  int finished;     // the epilogue (pose, inlier pairs) has run (k_p3p_finish)
   double min_nfa, errmax;
   double model[12];
 };
@@ -311,5 +313,6 @@ uint64_t packed_part_bytes(uint32_t n_queries, uint32_t budget);
 int ctx_p3p_reserve(Ctx *c, uint32_t n_query_rows);  // capi.hip: grow the P3P workspace to a query's feature count
 int launch_p3p_init(Ctx *c);
 int launch_p3p_round(Ctx *c, int batch);
+int launch_p3p_finish(Ctx *c);
 
 }  // namespace sfmloc
