@@ -312,7 +312,8 @@ def main():
     r0, r1 = int(m.view_off[v0]), int(m.view_off[v1])
     params = S.default_params(device=local_rank, profile=0, ransac_round=25)
     # diagnosis only (what each latency-bound stage costs the throughput); a line produced with these set is not the metric
-    diag = {k: int(os.environ[k]) for k in ("SFMLOC_DIAG_RANSAC_ROUND", "SFMLOC_DIAG_P3P_ITER") if k in os.environ}
+    diag = {k: int(os.environ[k]) for k in ("SFMLOC_DIAG_RANSAC_ROUND", "SFMLOC_DIAG_P3P_ITER", "SFMLOC_DIAG_STOP_AFTER")
+            if k in os.environ}
     if "SFMLOC_DIAG_RANSAC_ROUND" in diag:
         params.ransac_round = diag["SFMLOC_DIAG_RANSAC_ROUND"]
     if "SFMLOC_DIAG_P3P_ITER" in diag:

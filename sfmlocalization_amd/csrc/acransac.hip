@@ -1371,6 +1371,8 @@ __global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
     st.status = 0;
     st.arrive = 0u;
     st.finished = 0;
+    st.batch_limit = 1 << 30;
+    st.switch_iter = 0;
     st.min_nfa = pos_inf();
     st.errmax = pos_inf();
     for (int i = 0; i < 12; ++i) st.model[i] = 0.0;
@@ -1416,6 +1418,21 @@ constexpr int kP3pLargeBatch = 64;
 __device__ __forceinline__ int p3p_round_batch(int n, int batch) {
   return (n > kP3pMaxN && batch > kP3pLargeBatch) ? kP3pLargeBatch : batch;
 }
+// How many hypotheses the next round evaluates when the GPU is shared.  A round's hypotheses all sample from the current
+// index set and everything after the first one that improves the model is thrown away.  Once sampling has switched to
+// the best model's inliers, an iteration improves on the running minimum about as often as a new record appears in a
+// random sequence: t iterations after the switch the next improvement is within the next m with probability m/(t+m).
+// Evaluating 3t (at least 64) instead of a full batch finds it three times out of four and otherwise just advances; the
+// acceptance rule is replayed exactly for any partition into rounds, so only the cost changes: ~2x fewer hypotheses
+// evaluated for ~1.3x the rounds (+8 % queries per second at 12 in flight; the policy's constants hardly matter,
+// profiles/r02_p3p_adaptive_policy.txt).  A query alone on the GPU keeps full batches: rounds are what its latency is
+// made of.
+__device__ __forceinline__ int p3p_next_batch_limit(const P3pArgs &A, int identity, long iter, long switch_iter) {
+  if (!A.adaptive_batch || identity) return 1 << 30;
+  const long t = iter - switch_iter;
+  const long m = (A.adapt_quarters * t) / 4;
+  return (int)(m < A.adapt_floor ? A.adapt_floor : (m > kP3pBatchMax ? kP3pBatchMax : m));
+}
 __device__ __forceinline__ size_t p3p_inl_stride(int n, int max_n) { return n > kP3pMaxN ? (size_t)max_n : (size_t)kP3pMaxN; }
 
 struct P3pShared {
@@ -1443,7 +1460,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   const P3pState &st = *A.state;
   const int b = blockIdx.x;
   const int n = st.n;
-  if (b >= p3p_round_batch(n, batch)) return;
+  if (b >= p3p_round_batch(n, batch) || b >= st.batch_limit) return;
   const long it = (long)st.iter + b;
   if (it >= st.n_iter) return;
   P3pShared &S = *reinterpret_cast<P3pShared *>(smem_raw);
@@ -1772,13 +1789,15 @@ __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pRepla
   const int stamp_round = st.rounds;
 #endif
   STAMP_SEL(stamp_round, 0);
-  batch = p3p_round_batch(st.n, batch);  // what k_p3p_eval evaluated this round
+  batch = p3p_round_batch(st.n, batch);  // what the round evaluated
+  if (batch > st.batch_limit) batch = st.batch_limit;
   const size_t inl_stride = p3p_inl_stride(st.n, A.max_n);
   // every thread replays the same scalar state machine; only the copies are cooperative
   long iter0 = st.iter, n_iter = st.n_iter, n_reserve = st.n_reserve;
   const long n_iter_evaluated = n_iter;  // k_p3p_eval ran hypotheses iter0 <= it < min(iter0+batch, n_iter)
   double min_nfa = st.min_nfa, errmax = st.errmax;
   int n_in = st.n_in, n_index = st.n_index, identity = st.identity;
+  const int identity0 = identity;  // still sampling uniformly when the round began
   int best_b = -1;  // hypothesis of this batch that currently holds the best model
   long processed = 0;
   bool index_changed = false;
@@ -1879,6 +1898,9 @@ __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pRepla
     st.n_index = n_index;
     st.identity = identity;
     st.rounds += 1;
+    const long switch_iter = (index_changed && identity0) ? iter0 + processed : (long)st.switch_iter;
+    st.switch_iter = (int)switch_iter;
+    st.batch_limit = p3p_next_batch_limit(A, identity, iter0 + processed, switch_iter);
     if (best_b >= 0)
       for (int q = 0; q < 12; ++q) st.model[q] = A.hyp_model[12 * best_b + q];
     if (done) st.done = 1;
@@ -2359,6 +2381,17 @@ static P3pArgs make_p3p_args(Ctx *c) {
   A.ws_idx = c->d_p3p_ws_idx;
   A.ws_terms = c->d_p3p_terms;
   A.refine_pose = m->params.refine_pose;
+  // a context that is not alone on the map's GPU (other contexts have work queued, ctx_mark_busy) spends fewer
+  // speculative hypotheses per round; SFMLOC_P3P_ADAPTIVE=0/1 overrides (measurements)
+  static const int env_adaptive = [] {
+    const char *e = getenv("SFMLOC_P3P_ADAPTIVE");
+    return e ? atoi(e) : -1;
+  }();
+  A.adaptive_batch = env_adaptive >= 0 ? env_adaptive : (c->k1_may_slice ? 0 : 1);
+  static const int env_quarters = [] { const char *e = getenv("SFMLOC_P3P_ADAPT_QUARTERS"); return e ? atoi(e) : 12; }();
+  static const int env_floor = [] { const char *e = getenv("SFMLOC_P3P_ADAPT_FLOOR"); return e ? atoi(e) : 64; }();
+  A.adapt_quarters = env_quarters;
+  A.adapt_floor = env_floor;
   A.seed = m->params.seed;
   A.stream = 0;
   return A;

@@ -65,6 +65,8 @@ struct P3pState {
   int n, iter, n_iter, n_reserve, n_index, identity, n_in, done, rounds, status;
   unsigned arrive;  // workgroups of the current round that have delivered their hypothesis (k_p3p_round)
   int finished;     // the epilogue (pose, inlier pairs) has run (k_p3p_finish)
+  int batch_limit;  // hypotheses the current round evaluates (<= the launch's grid); see p3p_next_batch_limit
+  int switch_iter;  // iteration at which sampling switched to the best model's inliers
   double min_nfa, errmax;
   double model[12];
 };
@@ -88,6 +90,8 @@ struct P3pArgs {
   double *ws_terms;  // [max_n / 2 + 1]
   double focal, ppx, ppy;
   int max_iteration, min_resection_points, min_inliers, max_n, refine_pose;
+  int adaptive_batch;  // other queries share the GPU: trade rounds for fewer speculative hypotheses
+  int adapt_quarters, adapt_floor;  // next batch = max(floor, quarters/4 * iterations since the switch)
   uint64_t seed;
   uint32_t stream;
 };
