@@ -270,7 +270,9 @@ def main():
     sharded_mode = world > 1 or forced
     # (the sharded path keeps two slots of contexts: 8 per slot -- with 12 the 24 contexts and the collective's stream no
     # longer get a hardware queue each and the rate drops by 40 %, profiles/r02_sharded_inflight_sweep.txt)
-    nctx = a.in_flight if a.in_flight > 0 else ((8 if sharded_mode else 12) if shortlist else 4)
+    # (images in: a worker thread owns an extractor stream and a context; 4 workers = 8 streams is the measured optimum,
+    # 12 workers -- 24 streams -- run at a third of it, profiles/r02_image_in_sweep.txt)
+    nctx = a.in_flight if a.in_flight > 0 else (4 if a.from_images else ((8 if sharded_mode else 12) if shortlist else 4))
     if a.threads == 0 and shortlist and nctx >= 8 and not a.from_images and not sharded_mode:
         a.threads = 4
     # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
