@@ -452,6 +452,124 @@ __global__ __launch_bounds__(256) void k_smooth_flow(const float *__restrict__ s
   g2[(size_t)y * w + x] = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
 }
 
+// A whole octave in ONE launch when its image fits in LDS three times (VGA: the 80 x 60 octave -- 4 800 pixels, but 99 of
+// the schedule's 165 diffusion steps, each ~2 us as a launch or a fused part of one: 213 us of a 760 us extraction).  One
+// 1024-thread workgroup keeps the evolving image, a second copy for the ping-pong and the conductivity resident and
+// walks the octave's levels: 5 x 5 Gaussian (row pass, column pass) -> Lsmooth (stored), Scharr -> conductivity, the
+// level's FED steps, Lt stored; the next level starts from what is already in LDS.  Per pixel the arithmetic is that of
+// k_smooth_flow and k_nld_steps, in the same order, so the images are the same bit for bit.
+constexpr int kOctaveRunMax = 8;  // levels of one octave
+constexpr int kResidentPix = 13;  // pixels per thread: 150 KB / 12 B / 1024 threads
+struct OctaveRun {
+  int n_levels, w, h, octave;
+  unsigned int off[kOctaveRunMax];  // offset of the level in the per-level image stacks
+  int nsteps[kOctaveRunMax];
+  int step0[kOctaveRunMax];         // index of the level's first half step in the table
+};
+
+__global__ __launch_bounds__(1024) void k_octave_resident(const float *__restrict__ start, float *__restrict__ Lt_all,
+                                                          float *__restrict__ Lsmooth_all, Taps t,
+                                                          const float *__restrict__ kcontrast,
+                                                          const float *__restrict__ half_steps, OctaveRun R) {
+  extern __shared__ float lds_f[];
+  const int w = R.w, h = R.h, n = w * h;
+  float *A = lds_f, *B = lds_f + n, *C = lds_f + 2 * n;
+  const int tid = threadIdx.x;
+  for (int p = tid; p < n; p += 1024) A[p] = start[p];
+  float kc = *kcontrast;
+  for (int o = 0; o < R.octave; ++o) kc = kc * 0.75f;
+  const float inv_k = 1.0f / (kc * kc);
+  __syncthreads();
+  for (int lv = 0; lv < R.n_levels; ++lv) {
+    // row pass A -> B, column pass B -> C (= Lsmooth)
+    for (int p = tid; p < n; p += 1024) {
+      const int y = p / w, x = p - y * w;
+      float acc = 0.0f;
+      for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * A[y * w + clampi(x + i - 2, 0, w - 1)];
+      B[p] = acc;
+    }
+    __syncthreads();
+    float *const lsm = Lsmooth_all + R.off[lv];
+    for (int p = tid; p < n; p += 1024) {
+      const int y = p / w, x = p - y * w;
+      float acc = 0.0f;
+      for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * B[clampi(y + i - 2, 0, h - 1) * w + x];
+      C[p] = acc;
+      lsm[p] = acc;
+    }
+    __syncthreads();
+    // conductivity from Lsmooth (C) -> B
+    for (int p = tid; p < n; p += 1024) {
+      const int y = p / w, x = p - y * w;
+      const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+      const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+      const float ws = 3.0f, wm = 10.0f;
+      float lx_, ly_;
+      {
+        const float r0 = C[y * w + xp] - C[y * w + xm], rm = C[ym * w + xp] - C[ym * w + xm],
+                    rp = C[yp * w + xp] - C[yp * w + xm];
+        lx_ = wm * r0 + ws * (rm + rp);
+      }
+      {
+        const float r0 = C[yp * w + x] - C[ym * w + x], rm = C[yp * w + xm] - C[ym * w + xm],
+                    rp = C[yp * w + xp] - C[ym * w + xp];
+        ly_ = wm * r0 + ws * (rm + rp);
+      }
+      B[p] = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
+    }
+    __syncthreads();
+    // FED steps: A -> C -> A ...  The conductivity does not change within a level, so a thread keeps the four sums
+    // (c + c_neighbour) of each of its pixels in registers; a neighbour outside the image is replaced by the pixel
+    // itself, whose difference is +0 and gives the +0 flux the per-launch kernel writes there.
+    float cxp[kResidentPix], cxn[kResidentPix], cyp[kResidentPix], cyn[kResidentPix];
+    int nb[kResidentPix];  // bit 0..3: neighbour x+1 / x-1 / y+1 / y-1 exists
+#pragma unroll
+    for (int k = 0; k < kResidentPix; ++k) {
+      const int p = tid + k * 1024;
+      cxp[k] = cxn[k] = cyp[k] = cyn[k] = 0.0f;
+      nb[k] = 0;
+      if (p < n) {
+        const int y = p / w, x = p - y * w;
+        const float cc = B[p];
+        int f = 0;
+        if (x + 1 < w) { cxp[k] = cc + B[p + 1]; f |= 1; }
+        if (x > 0) { cxn[k] = B[p - 1] + cc; f |= 2; }
+        if (y + 1 < h) { cyp[k] = cc + B[p + w]; f |= 4; }
+        if (y > 0) { cyn[k] = B[p - w] + cc; f |= 8; }
+        nb[k] = f;
+      }
+    }
+    float *cur = A, *nxt = C;
+    for (int s = 0; s < R.nsteps[lv]; ++s) {
+      const float half_step = half_steps[R.step0[lv] + s];
+#pragma unroll
+      for (int k = 0; k < kResidentPix; ++k) {
+        const int p = tid + k * 1024;
+        if (p < n) {
+          const int f = nb[k];
+          const float v = cur[p];
+          const float xpos = cxp[k] * (cur[(f & 1) ? p + 1 : p] - v);
+          const float xneg = cxn[k] * (v - cur[(f & 2) ? p - 1 : p]);
+          const float ypos = cyp[k] * (cur[(f & 4) ? p + w : p] - v);
+          const float yneg = cyn[k] * (v - cur[(f & 8) ? p - w : p]);
+          const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
+          nxt[p] = v + stp;
+        }
+      }
+      __syncthreads();
+      float *const tswap = cur;
+      cur = nxt;
+      nxt = tswap;
+    }
+    float *const lt = Lt_all + R.off[lv];
+    for (int p = tid; p < n; p += 1024) lt[p] = cur[p];
+    // the next level starts from `cur`; its scratch is the other image
+    A = cur;
+    C = nxt;
+    __syncthreads();
+  }
+}
+
 // Compute_Multiscale_Derivatives, Compute_Determinant_Hessian_Response and the candidate pass of
 // Find_Scale_Space_Extrema run on the finished scale space and are independent between evolution levels: one launch over
 // ALL levels each (blockIdx.y = a row of the stacked images) instead of one per level -- 48 launches become 3.
@@ -686,6 +804,7 @@ struct Akaze {
   float *d_Lt = nullptr, *d_Lsmooth = nullptr, *d_Lx = nullptr, *d_Ly = nullptr, *d_Ldet = nullptr;  // per-level stacks
   unsigned int *d_hist = nullptr;             // [0] hmax bits, [1..301] histogram + npoints
   float *d_kcontrast = nullptr;
+  float *d_half_steps = nullptr;              // [level][64]: 0.5 * tsteps, for k_octave_resident
   Candidate9 *d_cand = nullptr;
   unsigned int *d_ncand = nullptr;
   unsigned int cand_cap = 1u << 16;
@@ -770,9 +889,50 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
   hipLaunchKernelGGL(k_grad_hist, ggrid, dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist, a->d_hist + 1);
   hipLaunchKernelGGL(k_kcontrast, dim3(1), dim3(1), 0, s, a->d_hist, a->d_hist + 1, a->d_kcontrast);
   AK_HIP(hipGetLastError());
+  static const bool kResident = [] {  // SFMLOC_AKAZE_RESIDENT=0: the per-level kernels everywhere (comparison runs)
+    const char *e = getenv("SFMLOC_AKAZE_RESIDENT");
+    return !(e && atoi(e) == 0);
+  }();
   for (int i = 1; i < P.nlev; ++i) {
     const AkLevel &L = P.lev[i], &Lp = P.lev[i - 1];
     float *Lt = a->d_Lt + L.off;
+    // an octave whose image fits in LDS three times runs in one launch (k_octave_resident)
+    {
+      int j = i;
+      while (j + 1 < P.nlev && P.lev[j + 1].octave == L.octave) ++j;
+      const size_t lds = (size_t)3 * L.w * L.h * sizeof(float);
+      const bool whole = i == 1 || Lp.octave != L.octave;  // the octave's first level of the loop
+      if (kResident && whole && lds <= 150u * 1024u && j - i + 1 <= kOctaveRunMax && a->d_half_steps) {
+        const float *start = a->d_Lt + Lp.off;
+        if (L.octave > Lp.octave) {
+          hipLaunchKernelGGL(k_halfsample, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lt + Lp.off, Lp.w, Lp.h, a->d_t3, L.w, L.h);
+          start = a->d_t3;
+        }
+        OctaveRun R{};
+        R.n_levels = j - i + 1;
+        R.w = L.w;
+        R.h = L.h;
+        R.octave = L.octave;
+        for (int q = i; q <= j; ++q) {
+          R.off[q - i] = (unsigned int)P.lev[q].off;
+          R.nsteps[q - i] = P.lev[q].nsteps;
+          R.step0[q - i] = q * 64;
+        }
+        Taps t5;
+        for (int k = 0; k < 9; ++k) t5.k[k] = k < 5 ? P.g10[k] : 0.0f;
+        static bool attr_set = false;
+        if (!attr_set) {
+          AK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octave_resident),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(k_octave_resident, dim3(1), dim3(1024), lds, s, start, a->d_Lt, a->d_Lsmooth, t5,
+                           a->d_kcontrast, a->d_half_steps, R);
+        AK_HIP(hipGetLastError());
+        i = j;
+        continue;
+      }
+    }
     // the level starts from the previous level's Lt (half-sampled at an octave change); the FED steps ping-pong
     // between this level's Lt and a scratch image, arranged so that the last step lands in Lt without a copy
     const float *start = a->d_Lt + Lp.off;
@@ -893,7 +1053,7 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   hipSetDevice(a->device);
   if (a->stream) hipStreamSynchronize(a->stream);
   void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
-                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_cand, a->d_ncand,
+                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_cand, a->d_ncand,
                   a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -937,11 +1097,18 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   for (float **sp : stacks) A((void **)sp, tot * 4);
   A((void **)&a->d_hist, 302 * 4);
   A((void **)&a->d_kcontrast, 4);
+  A((void **)&a->d_half_steps, (size_t)kMaxLevels * 64 * 4);
   A((void **)&a->d_cand, (size_t)a->cand_cap * sizeof(Candidate9));
   A((void **)&a->d_ncand, 4);
   A((void **)&a->d_gauss25, 49 * 4);
   A((void **)&a->d_win, 64 * 4);
   A((void **)&a->d_pair, 486 * 2 * 2);
+  if (he == hipSuccess) {
+    std::vector<float> hs((size_t)kMaxLevels * 64, 0.0f);
+    for (int i = 0; i < a->plan.nlev; ++i)
+      for (int k = 0; k < a->plan.lev[i].nsteps && k < 64; ++k) hs[(size_t)i * 64 + k] = 0.5f * a->plan.lev[i].tsteps[k];
+    he = hipMemcpy(a->d_half_steps, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
+  }
   if (he == hipSuccess) he = hipMemcpy(a->d_gauss25, a->plan.gauss25, 49 * 4, hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipMemcpy(a->d_win, a->plan.win_ang1, 64 * 4, hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipMemcpy(a->d_pair, a->plan.pair_tab, 486 * 2 * 2, hipMemcpyHostToDevice);

@@ -632,8 +632,7 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   while (qsplit < 4 && (uint64_t)n_work_blocks * qsplit < 32ull * (uint64_t)m->n_cu && (q->n - head) / (qsplit * 2) >= 6 * head)
     qsplit *= 2;
   if (!c->k1_may_slice) qsplit = 1;  // other queries are queued on the GPU: their scans fill it, slices only add work
-  if (qsplit_env == 1 || qsplit_env == 2 || qsplit_env == 4 || qsplit_env == 8 || qsplit_env == 16)
-    qsplit = (uint32_t)qsplit_env;
+  if (qsplit_env >= 1 && qsplit_env <= 16) qsplit = (uint32_t)qsplit_env;
   const uint2 *head_part = nullptr;
   if (qsplit > 1) {
     int rc = launch_hamming_t<1, 8>(c, q, n_work_blocks, use_list, 1, 512, head);
