@@ -278,7 +278,7 @@ def main():
     # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
     # (so does the image-in mode: a context and an extractor stream per worker)
     # (+2: the map's own stream and torch's; measured: 8 contexts on 8 queues lose 20 % to two streams sharing one)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, (2 * nctx if (sharded_mode or a.from_images) else nctx) + 2))))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, (2 * nctx if sharded_mode else nctx) + 2))))
 
     import numpy as np
     sys.path.insert(0, ROOT)
@@ -436,6 +436,9 @@ def main():
         import threading
         imgs = [synth.texture_image(900 + k, 480, 640) for k in range(4)]
         extractors = [S.Akaze(640, 480, device=local_rank) for _ in range(nctx)]
+        if os.environ.get("SFMLOC_BENCH_SHARE_STREAM", "1") != "0":
+            for e, c in zip(extractors, ctxs):      # a worker's extractor and context take turns: one stream, one queue
+                e.share_stream(c)
         n_feat = [0]
         lock = threading.Lock()
 

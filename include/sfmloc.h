@@ -415,6 +415,11 @@ int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin
                          float *angle_out);
 /* scale-space introspection for parity tests: level sizes, and the stacked Ldet / Lt images of the last call */
 int sfmloc_akaze_levels(const sfmloc_akaze *ak, int *n_levels, int *wh);
+/* From now on the extractor queues its work on the context's stream (ctx = NULL: back on its own).  A server worker that
+ * extracts an image and then localises it with that context (localizeImage.cc:149-177 then LocalizeEngine::localize) does
+ * the two one after the other anyway; with one stream it occupies one hardware queue instead of two, and concurrent
+ * workers stop competing for queues (profiles/r02_image_in_sweep.txt).  The context must outlive the sharing. */
+int sfmloc_akaze_share_stream(sfmloc_akaze *ak, sfmloc_context *ctx);
 int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt);
 
 /* cv::imread of the query image, host side (AKAZEOpenCV.cpp:60 `imread(filename, IMREAD_GRAYSCALE)` for extraction;

@@ -111,6 +111,7 @@ SYMBOLS = [
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
+    "sfmloc_akaze_share_stream",
     "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
     "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close", "sfmloc_localize_bow_begin", "sfmloc_localize_bow",
     "sfmloc_pack", "sfmloc_scan_packed", "sfmloc_open_packed",
@@ -200,6 +201,7 @@ def _L():
         L.sfmloc_akaze_compute.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_uint32,
                                            C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
         L.sfmloc_akaze_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.sfmloc_akaze_share_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_akaze_read_levels.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.sfmloc_localize_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32,
                                             C.POINTER(Pose), U32P, U32P, C.c_uint32]
@@ -817,6 +819,10 @@ class Akaze:
         wh = (C.c_int * 64)()
         _check(_L().sfmloc_akaze_levels(h, C.byref(n), wh))
         self.levels = [(wh[2 * i], wh[2 * i + 1]) for i in range(n.value)]
+
+    def share_stream(self, ctx):
+        """sfmloc_akaze_share_stream: queue the extraction on the context's stream (None: back on its own)."""
+        _check(_L().sfmloc_akaze_share_stream(self._h, None if ctx is None else ctx._h))
 
     def detect_and_compute(self, gray, cap=65536):
         """-> kpts [n x 6] (x, y, size, angle, response, class_id), desc [n x 64] (.desc rows)."""

@@ -799,6 +799,7 @@ struct Akaze {
   float thres = 0.001f;
   AkPlan plan;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;  // the one created with the extractor (stream may be a context's, see _share_stream)
   uint8_t *d_gray = nullptr;
   float *d_img = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr;
   float *d_Lt = nullptr, *d_Lsmooth = nullptr, *d_Lx = nullptr, *d_Ly = nullptr, *d_Ldet = nullptr;  // per-level stacks
@@ -1057,7 +1058,7 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
                   a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc};
   for (void *p : ptrs)
     if (p) hipFree(p);
-  if (a->stream) hipStreamDestroy(a->stream);
+  if (a->own_stream) hipStreamDestroy(a->own_stream);
   delete a;
 }
 
@@ -1083,7 +1084,8 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   a->thres = threshold;
   make_plan(width, height, n_octaves, n_sublevels, a->plan);
   const size_t n0 = (size_t)width * height, tot = a->plan.total;
-  hipError_t he = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+  hipError_t he = hipStreamCreateWithFlags(&a->own_stream, hipStreamNonBlocking);
+  a->stream = a->own_stream;
   auto A = [&](void **p, size_t bytes) {
     if (he == hipSuccess) he = hipMalloc(p, bytes);
   };
@@ -1118,6 +1120,17 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
     return he == hipErrorOutOfMemory ? SFMLOC_ENOMEM : SFMLOC_EHIP;
   }
   *out = reinterpret_cast<sfmloc_akaze *>(a);
+  return SFMLOC_OK;
+}
+
+int sfmloc_akaze_share_stream(sfmloc_akaze *ak, sfmloc_context *ctx) {
+  SFM_CHECK(ak, SFMLOC_EINVAL, "sfmloc_akaze_share_stream: null extractor");
+  Akaze *a = reinterpret_cast<Akaze *>(ak);
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  SFM_CHECK(!c || c->map->device == a->device, SFMLOC_EINVAL, "sfmloc_akaze_share_stream: extractor and context on different devices");
+  hipSetDevice(a->device);
+  if (a->stream) hipStreamSynchronize(a->stream);
+  a->stream = c ? c->stream : a->own_stream;
   return SFMLOC_OK;
 }
 
