@@ -309,6 +309,110 @@ __global__ __launch_bounds__(128) void k_grad_hist(const float *__restrict__ lx,
     if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
+// The start of Create_Nonlinear_Scale_Space in four launches instead of thirteen (u8 -> f32, 2 x 2 Gaussian passes, a
+// copy, two Scharr passes, two fills, maximum, histogram, percentile).  Per pixel the arithmetic is that of the separate
+// kernels above, in the same order, so every image and the contrast factor are the same bit for bit.
+//  k_pre_rows   image (u8) -> row pass of the 9-tap Gaussian (level 0) and of the 5-tap one (contrast factor); clears
+//               the histogram words
+//  k_pre_cols   column passes -> Lt and Lsmooth of level 0, and the smoothed image of the contrast factor
+//  k_pre_grad   Scharr x / y of that image -> gradient magnitude (interior pixels; 0 elsewhere) and its maximum
+//  k_pre_hist   300-bin histogram of the magnitudes; the last workgroup to arrive turns it into kcontrast
+struct Taps2 {
+  float k9[9], k5[5];
+};
+__device__ __forceinline__ float scharr_at(const float *__restrict__ src, int w, int h, int x, int y, int xorder,
+                                           int scale, float ws, float wm);
+__global__ void k_pre_rows(const uint8_t *__restrict__ src, float *__restrict__ rows9, float *__restrict__ rows5, int w,
+                           int h, Taps2 t, unsigned int *hist /*[304]*/) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < 304; i += blockDim.x) hist[i] = 0u;
+  if (x >= w) return;
+  float v[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[i] = (float)src[(size_t)y * w + clampi(x + i - 4, 0, w - 1)] / 255.0f;
+  float a9 = 0.0f, a5 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a9 = a9 + t.k9[i] * v[i];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) a5 = a5 + t.k5[i] * v[i + 2];
+  rows9[(size_t)y * w + x] = a9;
+  rows5[(size_t)y * w + x] = a5;
+}
+__global__ void k_pre_cols(const float *__restrict__ rows9, const float *__restrict__ rows5, float *__restrict__ lt0,
+                           float *__restrict__ lsmooth0, float *__restrict__ sm5, int w, int h, Taps2 t) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  float a9 = 0.0f, a5 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a9 = a9 + t.k9[i] * rows9[(size_t)clampi(y + i - 4, 0, h - 1) * w + x];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) a5 = a5 + t.k5[i] * rows5[(size_t)clampi(y + i - 2, 0, h - 1) * w + x];
+  lt0[(size_t)y * w + x] = a9;
+  lsmooth0[(size_t)y * w + x] = a9;
+  sm5[(size_t)y * w + x] = a5;
+}
+__global__ __launch_bounds__(128) void k_pre_grad(const float *__restrict__ sm5, float *__restrict__ mag, int w, int h,
+                                                  unsigned int *hmax_bits) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.0f;
+  for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y) {
+    if (x >= w) continue;
+    float g = 0.0f;
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+      const float a = scharr_at(sm5, w, h, x, y, 1, 1, 3.0f, 10.0f);
+      const float b = scharr_at(sm5, w, h, x, y, 0, 1, 3.0f, 10.0f);
+      g = sqrtf(a * a + b * b);
+      m = fmaxf(m, g);
+    }
+    mag[(size_t)y * w + x] = g;
+  }
+  unsigned int bits = __float_as_uint(m);  // non-negative floats order like their bit patterns
+  for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off, 64));
+  if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(hmax_bits, bits);
+}
+__global__ __launch_bounds__(128) void k_pre_hist(const float *__restrict__ mag, int w, int h,
+                                                  unsigned int *hist_all /*[0] hmax bits, [1..301] bins + npoints, [302] arrivals*/,
+                                                  float *kcontrast) {
+  __shared__ unsigned int lh[301];
+  __shared__ unsigned int ticket;
+  for (int i = threadIdx.x; i < 301; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  unsigned int *hist = hist_all + 1;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const float hmax = __uint_as_float(hist_all[0]);
+  unsigned int mine = 0;
+  for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y)
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+      const float m = mag[(size_t)y * w + x];
+      if (m != 0.0f) {
+        int nbin = (int)floorf(300.0f * (m / hmax));
+        if (nbin == 300) nbin--;
+        atomicAdd(&lh[nbin], 1u);
+        ++mine;
+      }
+    }
+  if (mine) atomicAdd(&lh[300], mine);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 301; i += blockDim.x)
+    if (lh[i]) atomicAdd(&hist[i], lh[i]);
+  __syncthreads();  // this workgroup's atomics are issued ...
+  if (threadIdx.x == 0) {
+    __threadfence();  // ... and performed before it counts itself in
+    ticket = atomicAdd(&hist_all[302], 1u);
+  }
+  __syncthreads();
+  if (ticket != gridDim.x * gridDim.y - 1 || threadIdx.x != 0) return;
+  __threadfence();
+  // compute_k_percentile's tail (k_kcontrast), by the last workgroup; the histogram is read through atomics so that no
+  // stale cached word is used
+  const int npoints = (int)atomicAdd(&hist[300], 0u);
+  const int nthreshold = (int)((float)npoints * 0.7f);
+  int nelements = 0, k = 0;
+  for (k = 0; nelements < nthreshold && k < 300; k++) nelements += (int)atomicAdd(&hist[k], 0u);
+  *kcontrast = (nelements < nthreshold) ? 0.03f : hmax * ((float)k / 300.0f);
+}
+
 __global__ void k_kcontrast(const unsigned int *hmax_bits, const unsigned int *hist, float *kcontrast) {
   const float hmax = __uint_as_float(*hmax_bits);
   const int npoints = (int)hist[300];
@@ -875,8 +979,24 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
   const size_t n0 = (size_t)w * h;
   hipStream_t s = a->stream;
   AK_HIP(hipMemcpyAsync(a->d_gray, gray, n0, hipMemcpyHostToDevice, s));
+  int rc = SFMLOC_OK;
+  static const bool kFusedPre = [] {  // SFMLOC_AKAZE_FUSED_PRE=0: the thirteen separate launches (comparison runs)
+    const char *e = getenv("SFMLOC_AKAZE_FUSED_PRE");
+    return !(e && atoi(e) == 0);
+  }();
+  const dim3 ggrid((w + 127) / 128, (h + kGradRows - 1) / kGradRows);
+  if (kFusedPre) {
+    Taps2 t2;
+    for (int k = 0; k < 9; ++k) t2.k9[k] = P.g16[k];
+    for (int k = 0; k < 5; ++k) t2.k5[k] = P.g10[k];
+    hipLaunchKernelGGL(k_pre_rows, grid2(w, h), dim3(128), 0, s, a->d_gray, a->d_t3, a->d_t1, w, h, t2, a->d_hist);
+    hipLaunchKernelGGL(k_pre_cols, grid2(w, h), dim3(128), 0, s, a->d_t3, a->d_t1, a->d_Lt, a->d_Lsmooth, a->d_t0, w, h, t2);
+    hipLaunchKernelGGL(k_pre_grad, ggrid, dim3(128), 0, s, a->d_t0, a->d_t2, w, h, a->d_hist);
+    hipLaunchKernelGGL(k_pre_hist, ggrid, dim3(128), 0, s, a->d_t2, w, h, a->d_hist, a->d_kcontrast);
+    AK_HIP(hipGetLastError());
+  } else {
   hipLaunchKernelGGL(k_u8_to_f32, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, a->d_gray, a->d_img, n0);
-  int rc = gauss(a, a->d_img, a->d_Lt, a->d_t3, w, h, P.g16, 9);
+  rc = gauss(a, a->d_img, a->d_Lt, a->d_t3, w, h, P.g16, 9);
   if (rc) return rc;
   AK_HIP(hipMemcpyAsync(a->d_Lsmooth, a->d_Lt, n0 * sizeof(float), hipMemcpyDeviceToDevice, s));
   // contrast factor
@@ -885,11 +1005,11 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
   if (!rc) rc = scharr(a, a->d_t0, a->d_t2, w, h, 0, 1, 3.0f, 10.0f);
   if (rc) return rc;
   AK_HIP(hipMemsetAsync(a->d_hist, 0, 302 * sizeof(unsigned int), s));
-  const dim3 ggrid((w + 127) / 128, (h + kGradRows - 1) / kGradRows);
   hipLaunchKernelGGL(k_grad_max, ggrid, dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist);
   hipLaunchKernelGGL(k_grad_hist, ggrid, dim3(128), 0, s, a->d_t1, a->d_t2, w, h, a->d_hist, a->d_hist + 1);
   hipLaunchKernelGGL(k_kcontrast, dim3(1), dim3(1), 0, s, a->d_hist, a->d_hist + 1, a->d_kcontrast);
   AK_HIP(hipGetLastError());
+  }
   static const bool kResident = [] {  // SFMLOC_AKAZE_RESIDENT=0: the per-level kernels everywhere (comparison runs)
     const char *e = getenv("SFMLOC_AKAZE_RESIDENT");
     return !(e && atoi(e) == 0);
@@ -1097,7 +1217,7 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   A((void **)&a->d_t3, n0 * 4);
   float **stacks[] = {&a->d_Lt, &a->d_Lsmooth, &a->d_Lx, &a->d_Ly, &a->d_Ldet};
   for (float **sp : stacks) A((void **)sp, tot * 4);
-  A((void **)&a->d_hist, 302 * 4);
+  A((void **)&a->d_hist, 304 * 4);
   A((void **)&a->d_kcontrast, 4);
   A((void **)&a->d_half_steps, (size_t)kMaxLevels * 64 * 4);
   A((void **)&a->d_cand, (size_t)a->cand_cap * sizeof(Candidate9));
