@@ -577,3 +577,22 @@ def test_pose_refinement_extension(oracle_c):
     assert len(err0) >= 4 and np.mean(err1) <= np.mean(err0) * 1.05      # refinement does not hurt, usually helps
     base.close()
     ref.close()
+
+
+def test_shared_gpu_round_sizes_do_not_change_the_result():
+    """When other contexts have work queued, K5 evaluates fewer speculative hypotheses per round (acransac.hip
+    p3p_next_batch_limit); the acceptance rule is replayed exactly for any partition into rounds, so every stage must
+    still equal the oracle bit for bit.  The policy is chosen when the library first runs, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"SFMLOC_P3P_ADAPTIVE": "1"},
+                  {"SFMLOC_P3P_ADAPTIVE": "1", "SFMLOC_P3P_ADAPT_QUARTERS": "4", "SFMLOC_P3P_ADAPT_FLOOR": "16",
+                   "SFMLOC_P3P_ROUNDS": "3"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_parity.py"), "12", "77000"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "every stage bit-exact" in r.stdout
+
