@@ -410,6 +410,22 @@ def test_no_size_limits_near_duplicate_of_a_large_frame(oracle_c):
     dm.close()
 
 
+def test_between_the_register_sort_and_the_default_workspace(oracle_c):
+    """1 024 < correspondences <= 4 096: beyond what K5's one-wave-per-model register sort holds, inside the default
+    workspace -- the block-wide LDS sort of k_p3p_round (acransac.hip, the `else` of the fast path)."""
+    m = synth.make_map(73, n_views=4, desc_per_view=2600, views_per_place=4, landmarks_per_place=3200, obs_per_view=2500,
+                       map_flips=8)
+    p3p_it = 400
+    dm = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, p3p_max_iteration=p3p_it),
+               view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+               landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    q = synth.make_query(m, 730, n_feat=2700, n_copies=2400, outlier_frac=0.05, query_flips=10)
+    exp, pose = compare_stages(m, q, dm, p3p_max_iteration=p3p_it)
+    assert 1024 < len(exp["ms_qfeat"]) <= 4096, len(exp["ms_qfeat"])
+    assert exp["ok"]
+    dm.close()
+
+
 def test_guided_matching_in_the_query_path(oracle_c):
     """params.guided_matching (-gm, localization.cpp:82,183,451 / LocalizeEngine.cc:459): every view that passes the
     F-matrix filter gets OpenMVG's guided matches under its estimated F; the 2D-3D set then keeps a guided match only when
