@@ -60,7 +60,10 @@ typedef struct sfmloc_params {
   float dist_ratio;         /* -f fDistRatio, default 0.6 */
   int ransac_round;         /* -r ransacRound (F-matrix AC-RANSAC iterations), default 200; callers pass 25 */
   double geom_precision;    /* -g geomLimit, default 4.0 px */
-  int bow_knn;              /* -k knnbow, 0 = no shortlist */
+  int bow_knn;              /* -k knnbow, 0 = no shortlist.  Recorded with the map for the callers (the command-line tools
+                             * and engine mirrors read it back); the library itself takes the shortlist length as an
+                             * argument of sfmloc_bow_select / sfmloc_localize_bow_begin, because the reference decides it
+                             * per call (LocalizeEngine.cc:337-340: only when the map has more views than knn) */
   int min_putative;         /* MINUM_NUMBER_OF_POINT_PUTATIVE_MATCH = 16 */
   int min_resection_points; /* MINUM_NUMBER_OF_POINT_RESECTION = 8 (test is ">") */
   int min_inliers;          /* MINUM_NUMBER_OF_INLIER_RESECTION = 10 (test is ">") */
