@@ -1929,9 +1929,31 @@ __global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch) {
 }
 
 // ACRANSAC's epilogue + SfM_Localizer::Localize + localization.cpp:511-547, once per query after the last round
+// what the host reads after the stream has drained: the record's head (state -- "done?" --, pose, status, view counts)
+// and, of a finished query, the inlier pairs.  Written by the kernel itself into the pinned host record: a copy launch
+// per query (and per refill of rounds) less.
+__device__ void p3p_publish(const P3pArgs &A) {
+  if (!A.host) return;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(A.record);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(A.host);
+  constexpr int head = (int)(offsetof(HostResult, pair_qfeat) / sizeof(uint32_t));
+  for (int i = threadIdx.x; i < head; i += kThreads) dst[i] = src[i];
+  const P3pState &st = *A.state;
+  if (st.done && A.max_n <= kP3pMaxN) {  // (a regrown workspace keeps its pair lists outside the record)
+    const int k = A.result->ok ? A.result->n_inliers : 0;
+    for (int i = threadIdx.x; i < k; i += kThreads) {
+      A.host->pair_qfeat[i] = A.record->pair_qfeat[i];
+      A.host->pair_landmark[i] = A.record->pair_landmark[i];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_p3p_finish(P3pArgs A) {
   P3pState &st = *A.state;
-  if (!st.done || st.finished) return;
+  if (!st.done || st.finished) {  // rounds still to come, or nothing to estimate (k_p3p_init's verdict): just report
+    p3p_publish(A);
+    return;
+  }
   const int tid = threadIdx.x;
   const double min_nfa = st.min_nfa, errmax = st.errmax;
   const int n_in = st.n_in;
@@ -2009,6 +2031,8 @@ __global__ __launch_bounds__(kThreads) void k_p3p_finish(P3pArgs A) {
     }
     st.finished = 1;
   }
+  __syncthreads();  // the record is complete
+  p3p_publish(A);
   STAMP_SEL(stamp_round, 3);
 }
 
@@ -2351,6 +2375,8 @@ static P3pArgs make_p3p_args(Ctx *c) {
   P3pArgs A;
   A.state = c->d_p3p_state;
   A.result = c->d_pose;
+  A.record = reinterpret_cast<const HostResult *>(c->d_result);
+  A.host = reinterpret_cast<HostResult *>(c->h_result);
   A.ms_n = c->d_ms_n;
   A.ms_qfeat = c->d_ms_qfeat;
   A.ms_landmark = c->d_ms_landmark;

@@ -513,7 +513,10 @@ int ctx_p3p_reserve(Ctx *c, uint32_t n) {
 
 namespace {
 
-int ctx_fetch_result(Ctx *c) {
+// The host copy of the result record is written by k_p3p_finish itself (p3p_publish), which every call of
+// ctx_resection_enqueue ends with; a copy is only needed when the chain stops before K5 (measurements).
+int ctx_fetch_result(Ctx *c, bool no_p3p = false) {
+  if (!no_p3p) return SFMLOC_OK;
   HostResult *h = reinterpret_cast<HostResult *>(c->h_result);
   SFM_HIP(hipMemcpyAsync(h, c->d_result, sizeof(HostResult), hipMemcpyDeviceToHost, c->stream));
   return SFMLOC_OK;
@@ -582,7 +585,7 @@ static int ctx_localize_begin_impl(Ctx *c, Query *q, const uint32_t *view_sel, u
     rc = ctx_resection_enqueue(c, true);
   }
   if (rc) return rc;
-  rc = ctx_fetch_result(c);
+  rc = ctx_fetch_result(c, stop != 0);
   if (rc) return rc;
   c->in_flight = q;
   return SFMLOC_OK;

@@ -71,9 +71,12 @@ struct P3pState {
   double model[12];
 };
 
+struct HostResult;
 struct P3pArgs {
   P3pState *state;
   Pose *result;
+  const HostResult *record;  // the context's result record in device memory (state, pose, status, inlier pairs) ...
+  HostResult *host;          // ... and its pinned host copy, which k_p3p_finish fills itself (no copy launch)
   const uint32_t *ms_n, *ms_qfeat, *ms_landmark;
   const double *pt2d, *pt3d;
   double *xn;
