@@ -1288,24 +1288,10 @@ __global__ __launch_bounds__(256) void k_candidates_min(const unsigned char *par
   }
 }
 
-__global__ __launch_bounds__(256) void k_candidates_win(const unsigned char *parts, uint32_t n_parts,
-                                                        uint64_t part_bytes, uint32_t cap, uint32_t nq,
-                                                        const unsigned long long *best, uint32_t *winner, PartLayout L) {
-  for (uint32_t p = blockIdx.y; p < n_parts; p += gridDim.y) {
-    const Candidate *cand = part_cands(parts, part_bytes, p, L);
-    uint32_t c0, c1;
-    part_range(parts, part_bytes, p, cap, L, &c0, &c1);
-    for (uint32_t c = c0 + blockIdx.x * blockDim.x + threadIdx.x; c < c1; c += gridDim.x * blockDim.x)
-      if (cand[c].qfeat < nq && best[cand[c].qfeat] == (unsigned long long)cand[c].order)
-        winner[cand[c].qfeat] = p * cap + c;
-  }
-}
-
-// single wave: compact the winners in ascending query-feature order (SfMDataUtils.cpp:121-124) and assemble
-// pt2D / pt3D (localization.cpp:479-501; pinhole get_ud_pixel is the identity)
-__global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *parts, uint64_t part_bytes,
+__global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *parts, uint32_t n_parts,
+                                                          uint64_t part_bytes,
                                                           uint32_t cap, const unsigned long long *best,
-                                                          const uint32_t *winner, uint32_t nq, const float2 *q_kpt,
+                                                          uint32_t *winner, uint32_t nq, const float2 *q_kpt,
                                                           uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
                                                           double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
                                                           double ppy, double k1, double k2, double k3, PartLayout L) {
@@ -1315,6 +1301,16 @@ __global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *
   __shared__ uint32_t base_s;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_s = 0;
+  // which candidate holds each query feature's minimum (the parts hold winners only -- a few
+  // hundred candidates each --, so the one workgroup that compacts them can also find them: one launch less)
+  for (uint32_t p = 0; p < n_parts; ++p) {
+    const Candidate *cand = part_cands(parts, part_bytes, p, L);
+    uint32_t c0, c1;
+    part_range(parts, part_bytes, p, cap, L, &c0, &c1);
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += 1024)
+      if (cand[c].qfeat < nq && best[cand[c].qfeat] == (unsigned long long)cand[c].order)
+        winner[cand[c].qfeat] = p * cap + c;
+  }
   __syncthreads();
   for (uint32_t j0 = 0; j0 < nq; j0 += 1024) {
     const uint32_t j = j0 + threadIdx.x;
@@ -2352,10 +2348,7 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
                        c->d_best64, c->d_status, L);
     SFM_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_candidates_win, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
-                     c->d_best64, c->d_winner, L);
-  SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(1024), 0, c->stream, parts, part_bytes, cap, c->d_best64,
+  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(1024), 0, c->stream, parts, n_parts, part_bytes, cap, c->d_best64,
                      c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d,
                      c->map->intrinsic_type == 3 ? 1 : 0, c->map->focal, c->map->ppx, c->map->ppy, c->map->k1, c->map->k2,
                      c->map->k3, L);
