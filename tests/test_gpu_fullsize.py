@@ -1,0 +1,177 @@
+"""GPU: the path at BASELINE.json's full sizes.  The oracle cannot scan 20 M or 100 M rows in a test's time, so these
+tests use what does not depend on size: the oracle on the views that matter (the shortlist / a probe of views), unions of
+disjoint view selections, idempotence, and planted matches whose answer is known.
+configs[1]: 1 000 views / 2 M descriptors, every query scans the whole bank.
+configs[2]: 10 000 views / 20 M descriptors, BoW shortlist of 100 views, then the path on them.
+configs[3]: the same map split by view into 8 shards (here: 8 maps on the one GPU), candidate parts merged.
+configs[4]: 50 000 views / 100 M descriptors (6.4 GB) -- the scan alone, planted matches."""
+import numpy as np
+import pytest
+
+import sfmlocalization_amd as S
+import synthdata as synth
+from oracle import oracle_c
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.ascontiguousarray(a, np.float64)
+    u = a.view(np.uint64).copy()
+    u[np.isnan(a)] = 0x7FF8000000000000
+    return u
+
+
+def make_dev_map(m, bow=None, lo=0, hi=None):
+    hi = m.n_views if hi is None else hi
+    r0, r1 = int(m.view_off[lo]), int(m.view_off[hi])
+    return S.Map(m.view_id[lo:hi], m.view_off[lo:hi + 1] - m.view_off[lo], m.desc[r0:r1],
+                 params=S.default_params(ransac_round=25), view_wh=m.view_wh[lo:hi], kpt_xy=m.kpt_xy[r0:r1],
+                 row_landmark=m.row_landmark[r0:r1], landmark_id=m.landmark_id, landmark_X=m.landmark_X,
+                 intrinsic=m.intrinsic, bow=None if bow is None else bow[lo:hi])
+
+
+def check_pose(pose, pq, pl, exp):
+    assert bool(pose.ok) == exp["ok"]
+    if exp["ok"]:
+        np.testing.assert_array_equal(pq, exp["pair_qfeat"])
+        np.testing.assert_array_equal(pl, exp["pair_landmark"])
+        np.testing.assert_array_equal(bits(np.array(pose.P)), bits(exp["P"].ravel()))
+
+
+def test_config1_full_scan_of_two_million_rows(oracle_c):
+    """Every query scans all 1 000 views.  The matches of a full scan are the union of the matches of two disjoint view
+    selections (each view's decision depends only on the query); a second scan gives the same lists; and the whole
+    path equals the oracle run on the views that have any putative match at all (the others cannot contribute)."""
+    m = synth.make_map(2, n_views=1000, desc_per_view=2000)
+    dm = make_dev_map(m)
+    for seed in (1000, 1001):
+        q = synth.make_query(m, seed, n_feat=2000)
+        dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
+        dm.match_putative(dq)
+        cnt, mi, mj, md = [a.copy() for a in dm.putative_read()]
+        dm.match_putative(dq)
+        cnt2, mi2, mj2, _ = dm.putative_read()
+        assert np.array_equal(cnt, cnt2) and np.array_equal(mi, mi2) and np.array_equal(mj, mj2), "idempotence"
+        halves = [np.arange(0, 500, dtype=np.uint32), np.arange(500, 1000, dtype=np.uint32)]
+        for sel in halves:
+            dm.match_putative(dq, sel)
+            c, i, j, _ = dm.putative_read()
+            assert np.array_equal(c[sel], cnt[sel]), "a selection's views match as in the full scan"
+            for v in sel[c[sel] > 0]:
+                o0, n = int(m.view_off[v]), int(c[v])
+                assert np.array_equal(i[o0:o0 + n], mi[o0:o0 + n]) and np.array_equal(j[o0:o0 + n], mj[o0:o0 + n])
+        # the oracle's exact scan on a probe of views (the query's own place and a spread of others)
+        probe = np.unique(np.concatenate([np.nonzero(cnt >= 16)[0], np.arange(0, 1000, 97)])).astype(np.uint32)
+        e = oracle_c.match_to_query(q.desc, m.desc, m.view_off, probe, 0.6, threads=8)
+        for v in probe:
+            assert int(cnt[v]) == int(e[0][v]), f"view {v}"
+            o0, c = int(m.view_off[v]), int(cnt[v])
+            assert np.array_equal(mi[o0:o0 + c], e[1][o0:o0 + c]) and np.array_equal(mj[o0:o0 + c], e[2][o0:o0 + c])
+        # whole path: the views with >= 16 matches are the only ones the later stages look at
+        live = np.nonzero(cnt >= 16)[0].astype(np.uint32)
+        exp = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=live, ransac_round=25, threads=8)
+        pose, pq, pl = dm.localize(dq)
+        check_pose(pose, pq, pl, exp)
+        dq.close()
+    dm.close()
+
+
+def test_config2_and_config3_ten_thousand_views(oracle_c):
+    """configs[2]: shortlist k = 100 of 10 000 views (exact L2 over the .bow matrix), then the path -- equal to the
+    oracle's shortlist followed by the oracle's path on those views, bit for bit.  configs[3]: the same map as 8 shards
+    (8 maps of 1 250 views on the one GPU): per-shard k-best keys -> global shortlist -> per-shard stage 1 -> packed
+    parts -> merge on one shard's context; equal to the unsharded result."""
+    import bench
+    m = synth.make_map(2, n_views=10000, desc_per_view=2000)
+    queries = [synth.make_query(m, 1000 + i, n_feat=2000) for i in range(3)]
+    bow, qbow = bench.synth_bow(m, queries)
+    dm = make_dev_map(m, bow)
+    ctx = dm.context()
+    results = []
+    for q, qb in zip(queries, qbow):
+        sel = oracle_c.bow_select(bow, qb, 100, None)
+        exp = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=sel, ransac_round=25, threads=8)
+        dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
+        ctx.begin_bow(dq, qb, 100)
+        pose, pq, pl = ctx.end()
+        check_pose(pose, pq, pl, exp)
+        assert exp["ok"], "the planted query localises"
+        results.append((exp, sel))
+        dq.close()
+    ctx.close()
+    dm.close()
+    # ---- configs[3]: 8 shards by view, the device-side chain of the multi-GPU path on one GPU
+    import torch
+    from sfmlocalization_amd import capi
+    from sfmlocalization_amd import dist as D
+    n_sh, knn = 8, 100
+    bounds = [(10000 * r) // n_sh for r in range(n_sh + 1)]
+    shards = [make_dev_map(m, bow, bounds[r], bounds[r + 1]) for r in range(n_sh)]
+    sctx = [s.context() for s in shards]
+    budget = 256 * len(queries)
+    ppb = capi.packed_bytes(len(queries), budget)
+    packed = torch.zeros((n_sh, ppb), dtype=torch.uint8, device="cuda")
+    sqs_all = []
+    for qi, ((q, qb), (exp, sel)) in enumerate(zip(zip(queries, qbow), results)):
+        keys = torch.zeros((n_sh, knn), dtype=torch.int64, device="cuda")
+        sqs = [s.query(q.desc, q.kpt_xy, q.width, q.height) for s in shards]
+        sqs_all.append(sqs)
+        for r, (c, sq) in enumerate(zip(sctx, sqs)):
+            c.shard_bow_keys(sq, knn, keys.data_ptr() + r * knn * 8, bow=qb)
+            c.sync()
+        hk = keys.cpu().numpy().view(np.uint64)
+        got = np.concatenate([bounds[r] + D.select_from_keys(hk, knn, m.view_id[bounds[r]:bounds[r + 1]])
+                              for r in range(n_sh)])
+        assert np.array_equal(np.sort(got), np.sort(sel)), "global shortlist from the shards' k-best keys"
+        for r, (c, sq) in enumerate(zip(sctx, sqs)):
+            c.shard_begin_bow(sq, keys.data_ptr(), n_sh, knn)
+            c.shard_export_packed(packed.data_ptr() + r * ppb, len(queries), budget, qi)
+            c.sync()
+    for qi, (exp, sel) in enumerate(results):
+        owner = qi % n_sh
+        sctx[owner].merge_begin_packed(sqs_all[qi][owner], packed.data_ptr(), n_sh, len(queries), budget, qi)
+        pose, pq, pl = sctx[owner].end()
+        check_pose(pose, pq, pl, exp)
+    for sqs in sqs_all:
+        for sq in sqs:
+            sq.close()
+    for c in sctx:
+        c.close()
+    for s in shards:
+        s.close()
+
+
+def test_config4_scan_of_one_hundred_million_rows(oracle_c):
+    """50 000 views / 100 M descriptors = 6.4 GB in HBM, one 2 000-row query: matches planted in six views (first,
+    second, a third of the way, middle, the last two) come back exactly as the oracle finds them in those views, and no
+    other view reaches the 16 matches the later stages require (unrelated random descriptors never pass the ratio test
+    16 times)."""
+    V, per, nq = 50000, 2000, 2000
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = V * per
+    bank = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    bank[:, 61:] = 0
+    bank[:, 60] &= 0x3F
+    q = synth.random_descriptors(rng, nq)
+    probe = [0, 1, V // 3, V // 2, V - 2, V - 1]
+    for v in probe:
+        rows = v * per + rng.choice(per, 200, replace=False)
+        bank[rows] = synth.flip_bits(rng, q[rng.integers(0, nq, 200)], 30)
+    view_off = (np.arange(V + 1, dtype=np.uint64) * per).astype(np.uint32)
+    dm = S.Map(np.arange(V, dtype=np.uint32), view_off, bank)
+    dq = dm.query(q)
+    dm.match_putative(dq)
+    cnt, mi, mj, md = dm.putative_read()
+    for v in probe:
+        a, b = v * per, (v + 1) * per
+        e = oracle_c.match_to_query(q, bank[a:b], np.array([0, per], np.uint32), None, 0.6, threads=8)
+        c = int(cnt[v])
+        assert c == int(e[0][0]) and c >= 150
+        assert np.array_equal(mi[a:a + c], e[1][:c]) and np.array_equal(mj[a:a + c], e[2][:c])
+    others = np.ones(V, bool)
+    others[probe] = False
+    assert int(cnt[others].max()) < 16
+    dq.close()
+    dm.close()
