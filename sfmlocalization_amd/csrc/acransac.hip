@@ -2427,12 +2427,10 @@ int launch_p3p_round(Ctx *c, int batch) {
   P3pArgs A = make_p3p_args(c);
   const size_t lds = sizeof(P3pShared);
   static_assert(sizeof(P3pReplayShared) <= sizeof(P3pShared), "the replay reuses the round's LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_p3p_round),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  // (a function-local static with an initialiser: set once, safely, whichever host thread gets here first)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p3p_round),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(P3pShared));
+  SFM_HIP(attr);
   hipLaunchKernelGGL(k_p3p_round, dim3(batch), dim3(kThreads), lds, c->stream, A, batch);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;

@@ -1041,12 +1041,10 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
         }
         Taps t5;
         for (int k = 0; k < 9; ++k) t5.k[k] = k < 5 ? P.g10[k] : 0.0f;
-        static bool attr_set = false;
-        if (!attr_set) {
-          AK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octave_resident),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-          attr_set = true;
-        }
+        // (a function-local static with an initialiser: set once, safely, whichever host thread gets here first)
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octave_resident),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        AK_HIP(attr);
         hipLaunchKernelGGL(k_octave_resident, dim3(1), dim3(1024), lds, s, start, a->d_Lt, a->d_Lsmooth, t5,
                            a->d_kcontrast, a->d_half_steps, R);
         AK_HIP(hipGetLastError());

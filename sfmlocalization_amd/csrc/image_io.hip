@@ -917,19 +917,22 @@ struct Jpeg {
       return true;
     }
     // jdcolor.c build_ycc_rgb_table
-    static int cr_r[256], cb_b[256];
-    static long cr_g[256], cb_g[256];
-    static bool tables = false;
-    if (!tables) {
-      for (int i = 0; i < 256; ++i) {
-        const long x = i - 128;
-        cr_r[i] = (int)((91881L * x + 32768L) >> 16);
-        cb_b[i] = (int)((116130L * x + 32768L) >> 16);
-        cr_g[i] = -46802L * x;
-        cb_g[i] = -22554L * x + 32768L;
+    struct YccTables {
+      int cr_r[256], cb_b[256];
+      long cr_g[256], cb_g[256];
+      YccTables() {
+        for (int i = 0; i < 256; ++i) {
+          const long x = i - 128;
+          cr_r[i] = (int)((91881L * x + 32768L) >> 16);
+          cb_b[i] = (int)((116130L * x + 32768L) >> 16);
+          cr_g[i] = -46802L * x;
+          cb_g[i] = -22554L * x + 32768L;
+        }
       }
-      tables = true;
-    }
+    };
+    static const YccTables ycc_tab;  // built once, safely, whichever thread decodes first (server workers decode concurrently)
+    const int *const cr_r = ycc_tab.cr_r, *const cb_b = ycc_tab.cb_b;
+    const long *const cr_g = ycc_tab.cr_g, *const cb_g = ycc_tab.cb_g;
     auto clamp = [](int v) -> uint8_t { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
     std::vector<uint8_t> rows[3];
     for (int i = 0; i < 3; ++i) rows[i].resize((size_t)2 * comp[i].bw * 8 + 16);
