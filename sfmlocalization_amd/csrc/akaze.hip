@@ -556,6 +556,111 @@ __global__ __launch_bounds__(256) void k_smooth_flow(const float *__restrict__ s
   g2[(size_t)y * w + x] = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
 }
 
+// k_smooth_flow and the level's first k_nld_steps in ONE launch: a 32 x 8 tile computes Lsmooth and the conductivity on
+// itself grown by the K pixels of halo the K diffusion steps need (so the smoothing of the halo is done again by the
+// neighbouring tiles: ~3x the arithmetic of a level's cheapest pass, against a dependent launch per level -- the
+// extraction is a chain of launches, and with images in the whole path is bound by launches per second).  Lsmooth and
+// the conductivity of the tile proper go to global memory as before (derivatives later; further step launches of the
+// level).  Per pixel the arithmetic is that of the two kernels, in the same order: the images are the same bit for bit.
+template <int K>
+__global__ __launch_bounds__(256) void k_smooth_nld(const float *__restrict__ src, float *__restrict__ lsmooth,
+                                                    float *__restrict__ g2, float *__restrict__ Ld_out, int w, int h,
+                                                    Taps t, const float *kcontrast, int octave, NldSteps hs, int nsteps) {
+  constexpr int TX = kNldTileX, TY = kNldTileY;
+  constexpr int CX = TX + 2 * K, CY = TY + 2 * K;              // conductivity / evolving image: tile + K
+  constexpr int LX = CX + 2, LY = CY + 2;                      // Lsmooth: + 1 (Scharr)
+  constexpr int MX = LX, MY = LY + 4;                          // row pass: Lsmooth's columns, + 2 rows (column taps)
+  constexpr int SX = MX + 4, SY = MY;                          // source: + 2 columns (row taps)
+  __shared__ float sS[SY][SX + 1];
+  __shared__ float sM[MY][MX + 1];
+  __shared__ float sLs[LY][LX + 1];
+  __shared__ float sC[CY][CX + 1];
+  __shared__ float sL[2][CY][CX + 1];
+  const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY;        // the tile
+  const int sx0 = X0 - K - 3, sy0 = Y0 - K - 3;                // origins of the regions in the image
+  const int mx0 = X0 - K - 1, my0 = sy0;
+  const int lx0 = mx0, ly0 = Y0 - K - 1;
+  const int cx0 = X0 - K, cy0 = Y0 - K;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < SX * SY; i += 256) {
+    const int ly = i / SX, lx = i - ly * SX;
+    const int gx = sx0 + lx, gy = sy0 + ly;
+    sS[ly][lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? src[(size_t)gy * w + gx] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = tid; i < MX * MY; i += 256) {  // row pass
+    const int ly = i / MX, lx = i - ly * MX;
+    const int gx = mx0 + lx, gy = my0 + ly;
+    if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+    float acc = 0.0f;
+    for (int q = 0; q < 5; ++q) acc = acc + t.k[q] * sS[ly][clampi(gx + q - 2, 0, w - 1) - sx0];
+    sM[ly][lx] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < LX * LY; i += 256) {  // column pass
+    const int ly = i / LX, lx = i - ly * LX;
+    const int gx = lx0 + lx, gy = ly0 + ly;
+    if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+    float acc = 0.0f;
+    for (int q = 0; q < 5; ++q) acc = acc + t.k[q] * sM[clampi(gy + q - 2, 0, h - 1) - my0][lx];
+    sLs[ly][lx] = acc;
+    if (gx >= X0 && gx < X0 + TX && gy >= Y0 && gy < Y0 + TY) lsmooth[(size_t)gy * w + gx] = acc;
+  }
+  __syncthreads();
+  float kc = *kcontrast;
+  for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
+  const float inv_k = 1.0f / (kc * kc);
+  for (int i = tid; i < CX * CY; i += 256) {  // conductivity, and the evolving image's start
+    const int ly = i / CX, lx = i - ly * CX;
+    const int x = cx0 + lx, y = cy0 + ly;
+    const bool in = x >= 0 && x < w && y >= 0 && y < h;
+    sL[0][ly][lx] = in ? sS[y - sy0][x - sx0] : 0.0f;
+    float c = 0.0f;
+    if (in) {
+      const int xm = reflect101(x - 1, w) - lx0, xp = reflect101(x + 1, w) - lx0, xc = x - lx0;
+      const int ym = reflect101(y - 1, h) - ly0, yp = reflect101(y + 1, h) - ly0, yc = y - ly0;
+      const float ws = 3.0f, wm = 10.0f;
+      float lx_, ly_;
+      {
+        const float r0 = sLs[yc][xp] - sLs[yc][xm], rm = sLs[ym][xp] - sLs[ym][xm], rp = sLs[yp][xp] - sLs[yp][xm];
+        lx_ = wm * r0 + ws * (rm + rp);
+      }
+      {
+        const float r0 = sLs[yp][xc] - sLs[ym][xc], rm = sLs[yp][xm] - sLs[ym][xm], rp = sLs[yp][xp] - sLs[ym][xp];
+        ly_ = wm * r0 + ws * (rm + rp);
+      }
+      c = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
+      if (x >= X0 && x < X0 + TX && y >= Y0 && y < Y0 + TY) g2[(size_t)y * w + x] = c;
+    }
+    sC[ly][lx] = c;
+  }
+  __syncthreads();
+  // the steps, as in k_nld_steps (region of step s: the tile grown by K - 1 - s ... of the steps still to come)
+  const int tx = tid & (TX - 1), ty = tid / TX;
+  int cur = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const int m = K - (nsteps - 1 - s);
+    const float half_step = hs.half_step[s];
+    for (int ly = m + ty; ly < CY - m; ly += TY)
+      for (int lx = m + tx; lx < CX - m; lx += TX) {
+        const int gx = cx0 + lx, gy = cy0 + ly;
+        if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+        const float cc = sC[ly][lx], v = sL[cur][ly][lx];
+        float xpos = 0.0f, xneg = 0.0f, ypos = 0.0f, yneg = 0.0f;
+        if (gx + 1 < w) xpos = (cc + sC[ly][lx + 1]) * (sL[cur][ly][lx + 1] - v);
+        if (gx > 0) xneg = (sC[ly][lx - 1] + cc) * (v - sL[cur][ly][lx - 1]);
+        if (gy + 1 < h) ypos = (cc + sC[ly + 1][lx]) * (sL[cur][ly + 1][lx] - v);
+        if (gy > 0) yneg = (sC[ly - 1][lx] + cc) * (v - sL[cur][ly - 1][lx]);
+        const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
+        sL[cur ^ 1][ly][lx] = v + stp;
+      }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int gx = X0 + tx, gy = Y0 + ty;
+  if (gx < w && gy < h) Ld_out[(size_t)gy * w + gx] = sL[cur][K + ty][K + tx];
+}
+
 // A whole octave in ONE launch when its image fits in LDS three times (VGA: the 80 x 60 octave -- 4 800 pixels, but 99 of
 // the schedule's 165 diffusion steps, each ~2 us as a launch or a fused part of one: 213 us of a 760 us extraction).  One
 // 1024-thread workgroup keeps the evolving image, a second copy for the ping-pong and the conductivity resident and
@@ -1075,12 +1180,16 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
       hipLaunchKernelGGL(k_halfsample, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lt + Lp.off, Lp.w, Lp.h, half, L.w, L.h);
       start = half;
     }
-    {
-      Taps t5;
-      for (int k = 0; k < 9; ++k) t5.k[k] = k < 5 ? P.g10[k] : 0.0f;
+    Taps t5;
+    for (int k = 0; k < 9; ++k) t5.k[k] = k < 5 ? P.g10[k] : 0.0f;
+    static const bool kFuseSmooth = [] {  // SFMLOC_AKAZE_FUSE_SMOOTH=0: k_smooth_flow as a launch of its own (comparison runs)
+      const char *e = getenv("SFMLOC_AKAZE_FUSE_SMOOTH");
+      return !(e && atoi(e) == 0);
+    }();
+    const bool fuse_smooth = kFuseSmooth && L.nsteps > 0;
+    if (!fuse_smooth)
       hipLaunchKernelGGL(k_smooth_flow, dim3((L.w + 31) / 32, (L.h + 7) / 8), dim3(256), 0, s, start,
                          a->d_Lsmooth + L.off, a->d_t2, L.w, L.h, t5, a->d_kcontrast, L.octave);
-    }
     const float *cur = start;
     // destination of step st: alternate so that step nsteps-1 writes Lt; `start` is never written
     const dim3 tgrid((L.w + kNldTileX - 1) / kNldTileX, (L.h + kNldTileY - 1) / kNldTileY);
@@ -1090,6 +1199,21 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
       const int n = std::min(kFuse, L.nsteps - st);
       NldSteps hs;
       for (int k = 0; k < kNldFuseMax; ++k) hs.half_step[k] = k < n ? 0.5f * L.tsteps[st + k] : 0.0f;
+      if (j == 0 && fuse_smooth) {  // the level's smoothing + conductivity + first steps in one launch
+#define SNLD_CASE(KK)                                                                                                  \
+  case KK:                                                                                                             \
+    hipLaunchKernelGGL(k_smooth_nld<KK>, tgrid, dim3(256), 0, s, cur, a->d_Lsmooth + L.off, a->d_t2, dst, L.w, L.h, t5, \
+                       a->d_kcontrast, L.octave, hs, n);                                                               \
+    break;
+        switch (n) {
+          SNLD_CASE(1) SNLD_CASE(2) SNLD_CASE(3) SNLD_CASE(4) SNLD_CASE(5) SNLD_CASE(6) SNLD_CASE(7) SNLD_CASE(8)
+          SNLD_CASE(9) SNLD_CASE(10) SNLD_CASE(11) SNLD_CASE(12) SNLD_CASE(13) SNLD_CASE(14) SNLD_CASE(15) SNLD_CASE(16)
+        }
+#undef SNLD_CASE
+        st += n;
+        cur = dst;
+        continue;
+      }
 #define NLD_CASE(KK) \
   case KK: hipLaunchKernelGGL(k_nld_steps<KK>, tgrid, dim3(256), 0, s, cur, a->d_t2, dst, L.w, L.h, hs, n); break;
       switch (n) {
