@@ -66,10 +66,16 @@ def main():
                 o = [b[1] - b[0], b[2] - b[1], b[3] - b[2], b[6] - b[3], b[7] - b[6], b[4] - b[7], b[5] - b[4]]
                 return " ".join(f"{us(x):5.1f}" for x in o)
             med = np.median(blk, axis=0)
+            prep = (blk[:, 2] - blk[:, 1]) / 100.0
+            tot = (blk[:, 5] - blk[:, 0]) / 100.0
+            dist = (f" | prepare over the blocks: p10 {np.percentile(prep, 10):.1f} median {np.median(prep):.1f} "
+                    f"p90 {np.percentile(prep, 90):.1f} max {prep.max():.1f}; whole block: median {np.median(tot):.1f} "
+                    f"max {tot.max():.1f}")
             s0, s3 = sel[r, 0], sel[r, 3] if sel[r, 3] > 0 else sel[r, 2]
             print(f"  K5 round {r:2d}: {live.sum():3d} blocks, t0 {us(start - t_first):7.1f} us, span {us(end - start):5.1f} us "
                   f"| slowest block [sample prep model resid sort nfa write] {seg(last)} | entry spread "
-                  f"{us(blk[:, 0].max() - start):4.1f} | select: starts {us(s0 - end):4.1f} after, lasts {us(s3 - s0):4.1f}")
+                  f"{us(blk[:, 0].max() - start):4.1f} | select: starts {us(s0 - end):4.1f} after, lasts {us(s3 - s0):4.1f}"
+                  + dist)
         # ---- K3: per view timeline
         tags = (f >> np.uint64(48)).astype(np.int64).reshape(256, 64)
         tim = (f & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64).reshape(256, 64)
