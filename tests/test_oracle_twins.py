@@ -249,3 +249,53 @@ def test_akaze_scale_change_is_an_octave_shift(oracle_c):
     assert abs(np.median(ratio) - 2.0) < 0.25
     # the class_id (evolution level) of the large image's feature sits about one octave (4 sublevels) above
     assert abs(np.median(a[:, 5] - b[:, 5]) - 4.0) <= 1.0
+
+
+def test_akaze_scale_space_and_response_vs_scipy_twin(oracle_c):
+    """The non-linear scale space (Gaussian start, contrast factor, Perona-Malik conductivity, FED cycles, 2x
+    half-sampling) and the Hessian-determinant response of every evolution level against oracle/twins_akaze_np.py: SciPy
+    correlations in float64 with the FED steps in natural order.  Agreement is at float32 rounding (1e-6); a wrong tap,
+    border rule, FED cycle or derivative scale would be orders of magnitude above."""
+    from oracle import twins_akaze_np as TA
+    import synthdata as synth
+    n_kp = 0
+    for seed, (h, w) in ((3, (128, 160)), (5, (96, 192)), (8, (240, 320))):
+        g = synth.texture_image(seed, h, w)
+        kp, desc, ldet, lt = oracle_c.akaze_detect_and_compute(g, want_levels=True)
+        lv, Lt, Ls = TA.scale_space(g)
+        assert [(l["w"], l["h"]) for l in lv] == [tuple(x) for x in oracle_c.akaze_levels(w, h)]
+        off = 0
+        resp = []
+        for i, l in enumerate(lv):
+            n = l["w"] * l["h"]
+            o = lt[off:off + n].reshape(l["h"], l["w"]).astype(np.float64)
+            od = ldet[off:off + n].reshape(l["h"], l["w"]).astype(np.float64)
+            d = TA.hessian_response(Ls[i], l["sigma_size"])
+            resp.append(d)
+            assert np.abs(o - Lt[i]).max() < 2e-6, (seed, i, np.abs(o - Lt[i]).max())
+            assert np.abs(od - d).max() < 2e-5 * np.abs(od).max(), (seed, i)
+            off += n
+        # every keypoint the oracle reports sits on a local maximum of the twin's response at its level, above the
+        # detector threshold, with the response value it reports
+        n_kp += len(kp)
+        for x, y, size, ang, response, cls in kp:
+            l = lv[int(cls)]
+            r = 2 ** l["octave"]
+            cx, cy = int(round(x / r)), int(round(y / r))
+            win = resp[int(cls)][max(cy - 2, 0):cy + 3, max(cx - 2, 0):cx + 3]
+            assert win.max() > 0.001 * (1 - 1e-3)
+            assert abs(win.max() - response) < 1e-4 * response + 1e-9, (x, y, cls, win.max(), response)
+    assert n_kp >= 30, n_kp
+
+
+def test_fed_cycle_reaches_the_stopping_time(oracle_c):
+    """A FED cycle's steps sum to the diffusion time between two evolution levels (the property the schedule is built
+    on), for the times AKAZE's default 4 x 4 levels ask for, and its largest step exceeds the explicit scheme's stability
+    limit (which is the point of FED)."""
+    from oracle import twins_akaze_np as TA
+    lv = TA.levels(640, 480)
+    for a, b in zip(lv, lv[1:]):
+        T_ = b["etime"] - a["etime"]
+        tau = TA.fed_steps(T_)
+        assert abs(tau.sum() - T_) < 1e-9 * T_
+        assert tau.max() > 0.25 or len(tau) <= 1
