@@ -15,6 +15,7 @@ FED cycle -- shows up as a difference far above rounding (tests/test_oracle_twin
   halfsample         a 2 x 2 block mean (INTER_AREA at an exact factor of two)
   contrast factor    70th percentile of the gradient magnitude's 300-bin histogram (numpy.histogram)
   scale_space        Lt of every level;  hessian_response  the determinant of the scaled second derivatives
+  orientation, mldb  Compute_Main_Orientation and the full 3-channel M-LDB descriptor of a given keypoint, vectorised
 """
 import numpy as np
 from scipy import ndimage
@@ -124,3 +125,74 @@ def hessian_response(Lsmooth, sigma_size):
     lxx, lyy, lxy = scharr(lx, 1, s, ws, wm), scharr(ly, 0, s, ws, wm), scharr(lx, 0, s, ws, wm)
     s2 = float(s * s)
     return (lxx * s2) * (lyy * s2) - (lxy * s2) ** 2
+
+
+def derivatives(Lsmooth, sigma_size):
+    """the first derivatives the orientation and the descriptor sample (Scharr at the level's scale, times the scale)"""
+    s = sigma_size
+    norm = 1.0 / (2.0 * s * (10.0 / 3.0 + 2.0))
+    ws, wm = norm, (10.0 / 3.0) * norm
+    return scharr(Lsmooth, 1, s, ws, wm) * s, scharr(Lsmooth, 0, s, ws, wm) * s
+
+
+def _fround(v):
+    return np.trunc(np.asarray(v, np.float64) + 0.5).astype(int)      # (int)(f + 0.5f)
+
+
+def _at(img, y, x):
+    h, w = img.shape
+    return img[np.clip(y, 0, h - 1), np.clip(x, 0, w - 1)]
+
+
+def orientation(level, Lx, Ly, x, y, size):
+    """Compute_Main_Orientation: Gaussian-weighted first derivatives on a disc of radius 6 s, the dominant direction of
+    a pi/3 window sliding in steps of 0.15 rad -> angle in [0, 2 pi)"""
+    ratio = float(1 << level["octave"])
+    s = int(_fround(0.5 * size / ratio))
+    xf, yf = x / ratio, y / ratio
+    ii, jj = np.meshgrid(np.arange(-6, 7), np.arange(-6, 7), indexing="ij")
+    keep = ii * ii + jj * jj < 36
+    ii, jj = ii[keep], jj[keep]
+    g = np.exp(-(ii * ii + jj * jj) / 12.5) / (2.0 * np.pi * 6.25)
+    iy, ix = _fround(yf + jj * s), _fround(xf + ii * s)
+    rx, ry = g * _at(Lx, iy, ix), g * _at(Ly, iy, ix)
+    ang = np.mod(np.arctan2(ry, rx), 2 * np.pi)
+    best, out = 0.0, 0.0
+    a1 = 0.0
+    while a1 < 2 * np.pi:
+        a2 = a1 - 5 * np.pi / 3 if a1 + np.pi / 3 > 2 * np.pi else a1 + np.pi / 3
+        if a1 < a2:
+            m = (a1 < ang) & (ang < a2)
+        else:
+            m = ((ang > 0) & (ang < a2)) | ((ang > a1) & (ang < 2 * np.pi))
+        sx, sy = rx[m].sum(), ry[m].sum()
+        if sx * sx + sy * sy > best:
+            best, out = sx * sx + sy * sy, np.mod(np.arctan2(sy, sx), 2 * np.pi)
+        a1 += 0.15
+    return out
+
+
+def mldb(level, Lt, Lx, Ly, x, y, size, angle):
+    """Get_MLDB_Full_Descriptor (3 channels, pattern 10): 486 bits as a 0/1 array -- mean intensity and rotated mean
+    derivatives of the cells of a 2 x 2, a 3 x 3 and a 4 x 4 grid over the rotated, scaled patch, every pair compared"""
+    ratio = float(1 << level["octave"])
+    scale = int(_fround(0.5 * size / ratio))
+    xf, yf = x / ratio, y / ratio
+    co, si = np.cos(angle), np.sin(angle)
+    bits = []
+    for step in (10, 7, 5):
+        vals = []
+        for i in range(-10, 10, step):
+            for j in range(-10, 10, step):
+                kk, ll = np.meshgrid(np.arange(i, i + step), np.arange(j, j + step), indexing="ij")
+                sy = yf + (ll * co * scale + kk * si * scale)
+                sx = xf + (-ll * si * scale + kk * co * scale)
+                y1, x1 = _fround(sy), _fround(sx)
+                ri, rx, ry = _at(Lt, y1, x1), _at(Lx, y1, x1), _at(Ly, y1, x1)
+                vals.append((ri.mean(), (-rx * si + ry * co).mean(), (rx * co + ry * si).mean()))
+        vals = np.array(vals)
+        for pos in range(3):
+            v = vals[:, pos]
+            for a in range(len(v)):
+                bits.extend((v[a] > v[a + 1:]).astype(np.uint8))
+    return np.array(bits, np.uint8)

@@ -299,3 +299,29 @@ def test_fed_cycle_reaches_the_stopping_time(oracle_c):
         tau = TA.fed_steps(T_)
         assert abs(tau.sum() - T_) < 1e-9 * T_
         assert tau.max() > 0.25 or len(tau) <= 1
+
+
+def test_akaze_orientation_and_mldb_vs_numpy_twin(oracle_c):
+    """Main orientation and the 486-bit M-LDB descriptor of every keypoint the oracle reports, recomputed by the twin on
+    ITS OWN float64 scale space and derivatives: angles to 1e-5 rad (the oracle's fixed-order float32 atan2 / sincos
+    included), descriptor bits equal but for comparisons of near-equal cell means."""
+    from oracle import twins_akaze_np as TA
+    import synthdata as synth
+    n_kp, n_bits, n_diff = 0, 0, 0
+    for seed, (h, w) in ((8, (240, 320)), (11, (300, 400))):
+        g = synth.texture_image(seed, h, w)
+        kp, desc = oracle_c.akaze_detect_and_compute(g)
+        lv, Lt, Ls = TA.scale_space(g)
+        D = [TA.derivatives(Ls[i], l["sigma_size"]) for i, l in enumerate(lv)]
+        for (x, y, size, ang, resp, cls), d in zip(kp, desc):
+            c = int(cls)
+            a = TA.orientation(lv[c], D[c][0], D[c][1], float(x), float(y), float(size))
+            da = abs(a - float(ang))
+            assert min(da, 2 * np.pi - da) < 1e-5, (x, y, c, a, ang)
+            b = TA.mldb(lv[c], Lt[c], D[c][0], D[c][1], float(x), float(y), float(size), float(ang))
+            ob = np.unpackbits(d, bitorder="little")[:486]
+            n_diff += int((b != ob).sum())
+            n_bits += 486
+            n_kp += 1
+    assert n_kp >= 80, n_kp
+    assert n_diff <= 2e-4 * n_bits, (n_diff, n_bits)
