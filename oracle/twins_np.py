@@ -14,6 +14,8 @@ tests/test_oracle_twins.py:
   krt_from_p         KRt_From_P via scipy.linalg.rq (oracle: Givens rotations as OpenMVG does)
   logcombi           log10 C(n, k) via gammaln (oracle: running sums of a log10 table)
   best_nfa           the NFA minimum over the sorted residuals, vectorised
+  guided_match       Geometry_guided_matching vectorised: F to pixels as N2^T F N1, all point-line distances by one matrix
+                     product, Hamming distances from unpacked bits
   acransac           the AC-RANSAC loop in pure Python over the ORACLE's sample sequence (oracle_c.ac_sample is pinned by
                      the Random123 known answers), with the twin solvers and NFA: same acceptance decisions, same
                      inlier set
@@ -219,3 +221,37 @@ def acransac(n, s, n_models, fit, error, logalpha0, mult_error, n_iter, sample, 
     if min_nfa >= 0:
         inl = []
     return inl, best_model, err_max, min_nfa, it
+
+
+# ----- guided matching ----------------------------------------------------------------------------------------------
+def guided_match(F_norm, errmax_norm, wh1, wh2, xy1, desc1, xy2, desc2, dist_ratio=0.6):
+    """Geometry_guided_matching (descriptor variant) for one pair, vectorised and formulated independently of the C
+    oracle: F is taken to pixels as N2^T F N1 with the normalising similarities written out as matrices, the point-line
+    distances of ALL feature pairs come from one matrix product, the Hamming distances from numpy.unpackbits, the best /
+    second-best by a partial sort.  -> (i[], j[]) ascending in i."""
+    def norm_mat(w, h):
+        s = 1.0 / np.sqrt(float(w) * float(h))
+        return np.array([[s, 0, -0.5 * w * s], [0, s, -0.5 * h * s], [0, 0, 1.0]])
+    N1, N2 = norm_mat(*wh1), norm_mat(*wh2)
+    F = N2.T @ np.asarray(F_norm, np.float64).reshape(3, 3) @ N1
+    thr = (np.sqrt(errmax_norm) * np.sqrt(float(wh2[0]) * float(wh2[1]))) ** 2
+    x1 = np.c_[np.asarray(xy1, np.float64).reshape(-1, 2), np.ones(len(xy1))]
+    x2 = np.c_[np.asarray(xy2, np.float64).reshape(-1, 2), np.ones(len(xy2))]
+    lines = x1 @ F.T                                   # epipolar line of every feature of image 1 in image 2
+    num = lines @ x2.T                                 # [n1, n2]
+    e = num * num / (lines[:, 0] ** 2 + lines[:, 1] ** 2)[:, None]
+    b1 = np.unpackbits(np.asarray(desc1, np.uint8).reshape(-1, 64), axis=1).astype(np.int32)
+    b2 = np.unpackbits(np.asarray(desc2, np.uint8).reshape(-1, 64), axis=1).astype(np.int32)
+    ham = b1.sum(1)[:, None] + b2.sum(1)[None, :] - 2 * (b1 @ b2.T)
+    d2 = np.where(e < thr, (ham * ham).astype(np.float64), np.inf)
+    oi, oj = [], []
+    for i in range(d2.shape[0]):
+        row = d2[i]
+        if np.isfinite(row).sum() < 2:
+            continue
+        j = int(np.argmin(row))                        # first minimum = the lowest j on ties, as the sequential scan
+        second = np.partition(row, 1)[1]
+        if row[j] < dist_ratio * dist_ratio * second:
+            oi.append(i)
+            oj.append(j)
+    return np.array(oi, np.uint32), np.array(oj, np.uint32)

@@ -325,3 +325,42 @@ def test_akaze_orientation_and_mldb_vs_numpy_twin(oracle_c):
             n_kp += 1
     assert n_kp >= 80, n_kp
     assert n_diff <= 2e-4 * n_bits, (n_diff, n_bits)
+
+
+def test_guided_matching_vs_numpy_twin(oracle_c):
+    """Geometry_guided_matching (the -gm path): the C oracle against the vectorised twin (matrix-form unnormalisation of
+    F, all point-line distances by one product, Hamming distances from unpacked bits).  The accepted (i, j) lists must be
+    equal; a pair whose epipolar distance sits within rounding of the threshold may differ, so the scenes are checked
+    for such pairs and there are none in these seeds."""
+    import synthdata as synth
+    rng = np.random.default_rng(5)
+    total = 0
+    for trial in range(6):
+        n1, n2 = int(rng.integers(150, 400)), int(rng.integers(150, 400))
+        wh1, wh2 = (640, 480), (int(rng.choice([640, 800])), int(rng.choice([480, 600])))
+        X, a1, a2, _ = _scene(rng, 120)                       # exact projections: the 7-point F below is the true one
+        # a fundamental matrix of the two views from eight exact correspondences (normalised frames), via the twin
+        def nrm(x, wh):
+            s = 1.0 / np.sqrt(wh[0] * wh[1])
+            return (x - 0.5 * np.array(wh)) * s
+        Fs = T.seven_point(nrm(a1[:7], wh1), nrm(a2[:7], wh2))
+        # the solution with the smallest residual on the other points
+        def resid(F):
+            return np.abs(T.epipolar_error(F, nrm(a1, wh1), nrm(a2, wh2))).sum()
+        F = min(Fs, key=resid)
+        # features: the true correspondences (descriptors a few bits apart) plus clutter on both sides
+        d_true = synth.random_descriptors(rng, 120)
+        xy1 = np.r_[a1, rng.uniform(0, 1, (n1 - 120, 2)) * wh1].astype(np.float32)
+        xy2 = np.r_[a2, rng.uniform(0, 1, (n2 - 120, 2)) * wh2].astype(np.float32)
+        desc1 = np.r_[d_true, synth.random_descriptors(rng, n1 - 120)]
+        desc2 = np.r_[synth.flip_bits(rng, d_true, 25), synth.random_descriptors(rng, n2 - 120)]
+        errmax = float(rng.uniform(0.5, 4.0) ** 2 / (wh2[0] * wh2[1]))        # (pixels / sqrt(w h))^2: normalised frame
+        ei, ej = oracle_c.guided_match(F, errmax, wh1, wh2, xy1, desc1, xy2, desc2, 0.6)
+        ti, tj = T.guided_match(F, errmax, wh1, wh2, xy1, desc1, xy2, desc2, 0.6)
+        assert np.array_equal(ei, ti) and np.array_equal(ej, tj), trial
+        # (a feature needs two candidates inside its epipolar band for the ratio test, so only part of the true
+        # correspondences can be accepted in a sparse scene; the accepted ones are the true ones)
+        assert len(ei) >= 10, len(ei)
+        assert (ei[ej < 120] == ej[ej < 120]).mean() > 0.95
+        total += len(ei)
+    assert total > 150, total
