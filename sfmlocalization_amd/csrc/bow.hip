@@ -10,6 +10,7 @@
 // for K7) so that ranks and bins can be compared bit for bit.
 #include <math.h>
 
+#include "chain_device.h"
 #include "sfmloc_internal.h"
 
 namespace sfmloc {
@@ -63,13 +64,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 // left them to thread 0 and spent 130 us on 10 000 views, most of it in those loops.
 __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ dist_bits, uint32_t n,
                                                    const uint32_t *__restrict__ cand, uint32_t k,
-                                                   uint32_t *__restrict__ out_sel) {
+                                                   uint32_t *__restrict__ out_sel, ChainArgs chain) {
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t sh_prefix, sh_rank;
   const uint32_t tid = threadIdx.x;
   if (k > n) k = n;
-  if (k == 0) return;
+  if (k == 0) return;  // (the launcher never chains an empty shortlist)
   uint32_t prefix = 0, rank = k;  // the k-th smallest (1-based) within the elements matching `prefix`
   const int shifts[3] = {21, 10, 0};
   const uint32_t widths[3] = {11, 11, 10};
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
     }
     if (take) out_sel[pos++] = cand ? cand[i] : i;
   }
+  chain_after_shortlist(chain);  // the query's counters and the block list of the k views (chain_device.h)
 }
 
 // ----- sharded shortlist -----------------------------------------------------------------------------
@@ -158,7 +160,8 @@ constexpr uint32_t kBowMergeMaxKeys = 8192;
 __global__ __launch_bounds__(1024) void k_bow_merge_select(const unsigned long long *__restrict__ keys, uint32_t n_parts,
                                                            uint64_t part_stride, uint32_t k,
                                                            const uint32_t *__restrict__ view_id, uint32_t n_views,
-                                                           uint32_t n_pad, uint32_t *__restrict__ sel_out) {
+                                                           uint32_t n_pad, uint32_t *__restrict__ sel_out,
+                                                           ChainArgs chain) {
   // all scratch in the dynamic region (16-byte aligned base): keys [n_parts * k] u64, then this shard's winners'
   // local indices [1024] (unordered), then their count
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(1024) void k_bow_merge_select(const unsigned long l
     for (uint32_t j = 0; j < n_mine; ++j) pos += (s_mine[j] < v);
     sel_out[pos] = v;
   }
+  chain_after_shortlist(chain);
 }
 
 __global__ __launch_bounds__(256) void k_bof_assign(const float *__restrict__ desc, const float *__restrict__ kxy,
@@ -285,12 +289,15 @@ __global__ void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, 
 }  // namespace
 
 int launch_bow_select(Map *m, hipStream_t s, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
-                      uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel) {
+                      uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel, const ChainArgs *chain) {
+  SFM_CHECK(!chain || (n_cand > 0 && k > 0 && k <= n_cand), SFMLOC_EINVAL, "shortlist chain on an empty shortlist");
   if (n_cand == 0 || k == 0) return SFMLOC_OK;
+  ChainArgs C{};
+  if (chain) C = *chain;
   hipLaunchKernelGGL(k_bow_dist, dim3((n_cand + 3) / 4), dim3(256), 0, s, m->d_bow, m->bow_dim, d_cand, n_cand,
                      d_query, d_dist_bits);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, s, d_dist_bits, n_cand, d_cand, k, d_out_sel);
+  hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, s, d_dist_bits, n_cand, d_cand, k, d_out_sel, C);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
@@ -310,7 +317,10 @@ int launch_bow_keys(Map *m, hipStream_t s, const float *d_query, uint32_t k, uin
 }
 
 int launch_bow_merge_select(Map *m, hipStream_t s, const unsigned long long *d_keys, uint32_t n_parts,
-                            uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out) {
+                            uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out,
+                            const ChainArgs *chain) {
+  ChainArgs C{};
+  if (chain) C = *chain;
   const uint64_t n = (uint64_t)n_parts * k;
   SFM_CHECK(n > 0 && n <= kBowMergeMaxKeys && k <= 1024, SFMLOC_EINVAL,
             "sharded shortlist: %u parts x %u keys (at most %u keys in all, k <= 1024)", n_parts, k, kBowMergeMaxKeys);
@@ -320,7 +330,7 @@ int launch_bow_merge_select(Map *m, hipStream_t s, const unsigned long long *d_k
                                                      (int)(kBowMergeMaxKeys * 8 + 1024 * 4 + 16));
   SFM_HIP(attr);
   hipLaunchKernelGGL(k_bow_merge_select, dim3(1), dim3(1024), lds, s, d_keys, n_parts, part_stride_keys, k, m->d_view_id,
-                     m->n_views, n_pad, d_sel_out);
+                     m->n_views, n_pad, d_sel_out, C);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

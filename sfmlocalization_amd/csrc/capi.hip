@@ -15,6 +15,7 @@
 #include <exception>
 #include <new>
 
+#include "chain_device.h"
 #include "sfmloc_internal.h"
 
 namespace sfmloc {
@@ -261,35 +262,54 @@ void free_map(Map *m) {
 // Every counter / flag the stages of one query start from, cleared by ONE launch instead of eight memsets (each a
 // separate ~5 us dispatch on the query's critical path).  The stage functions keep their own memsets for callers
 // that drive them one at a time (Ctx::cleared says which applies).
-__global__ __launch_bounds__(256) void k_query_reset(uint32_t *view_count, uint32_t *geo_count, uint32_t n_views,
-                                                     unsigned long long *best64, uint32_t nq, uint32_t *n_flagged,
-                                                     int *status, uint32_t *cand_header, uint32_t *view_stats,
-                                                     uint32_t *ms_n) {
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t <= n_views) {  // <= : the phantom view's slot too
-    view_count[t] = 0;
-    geo_count[t] = 0;
-  }
-  if (t < nq) best64[t] = ~0ull;
-  if (t == 0) {
-    *n_flagged = 0;
-    *status = 0;
-    cand_header[0] = cand_header[1] = cand_header[2] = cand_header[3] = 0;  // kPartHeaderBytes = 16
-    view_stats[0] = view_stats[1] = 0;
-    *ms_n = 0;
-  }
+__global__ __launch_bounds__(256) void k_query_reset(QueryResetArgs R) {
+  query_reset_items(R, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);  // chain_device.h
+}
+
+QueryResetArgs make_reset_args(Ctx *c, const Query *q) {
+  QueryResetArgs R;
+  R.view_count = c->d_view_count;
+  R.geo_count = c->d_geo_count;
+  R.n_views = c->map->n_views;
+  R.best64 = c->d_best64;
+  R.nq = q->n ? q->n : 1;
+  R.n_flagged = c->d_n_flagged;
+  R.status = c->d_status;
+  R.cand_header = reinterpret_cast<uint32_t *>(c->d_cand_part);
+  R.view_stats = c->d_view_stats;
+  R.ms_n = c->d_ms_n;
+  return R;
 }
 
 int ctx_reset_for_query(Ctx *c, const Query *q) {
   Map *m = c->map;
+  if (c->chain_done) {  // the shortlist's workgroup already did it (chain_after_shortlist)
+    c->cleared = true;
+    return SFMLOC_OK;
+  }
   const uint32_t nq = q->n ? q->n : 1;
   const uint32_t n = m->n_views + 1 > nq ? m->n_views + 1 : nq;
-  hipLaunchKernelGGL(k_query_reset, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_view_count, c->d_geo_count,
-                     m->n_views, c->d_best64, nq, c->d_n_flagged, c->d_status,
-                     reinterpret_cast<uint32_t *>(c->d_cand_part), c->d_view_stats, c->d_ms_n);
+  hipLaunchKernelGGL(k_query_reset, dim3((n + 255) / 256), dim3(256), 0, c->stream, make_reset_args(c, q));
   SFM_HIP(hipGetLastError());
   c->cleared = true;
   return SFMLOC_OK;
+}
+
+// The chain a shortlist kernel runs after the shortlist (reset + block list of the knn selected views in d_sel)
+ChainArgs make_chain_args(Ctx *c, const Query *q, const uint32_t *d_sel, uint32_t n_sel) {
+  Map *m = c->map;
+  ChainArgs C;
+  C.enabled = 1;
+  C.reset = make_reset_args(c, q);
+  C.blocks.sel = d_sel;
+  C.blocks.n_sel = n_sel;
+  C.blocks.view_off = m->d_view_off;
+  C.blocks.view_sel_out = c->d_view_sel;
+  C.blocks.widx0 = c->d_view_widx0;
+  C.blocks.block_list = c->d_block_list;
+  C.blocks.bound = (uint32_t)std::min<uint64_t>(m->n_blocks, (uint64_t)n_sel * m->max_view_blocks);
+  C.blocks.flagmask = c->d_flagmask;
+  return C;
 }
 
 struct ClearedScope {  // the flag must not outlive the call that set it
@@ -335,7 +355,9 @@ int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_se
     // launch bound the host can know: every selected view overlaps at most max_view_blocks blocks
     const uint64_t bound = std::min<uint64_t>(m->n_blocks, (uint64_t)n_sel * m->max_view_blocks);
     n_work_blocks = (uint32_t)bound;
-    if (n_sel) {
+    if (n_sel && c->chain_done) {
+      c->flagmask_zeroed = true;  // (built by the shortlist's workgroup, chain_after_shortlist)
+    } else if (n_sel) {
       int rc = launch_blocks_from_views(c, d_sel, n_sel, n_work_blocks);
       if (rc) return rc;
     }
@@ -1264,13 +1286,18 @@ int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const fl
   int rc;
   {
     EventScope ev(c, SFMLOC_K_BOW);
+    // the workgroup that finishes the shortlist also clears the query's counters and builds the block list
+    const ChainArgs chain = make_chain_args(c, q, c->d_bow_sel, knn);
     rc = launch_bow_select(m, c->stream, query_bow ? c->d_bow_query : q->d_bow, cand_views ? c->d_bow_cand : nullptr,
-                           n_cand, knn, c->d_bow_dist, c->d_bow_sel);
+                           n_cand, knn, c->d_bow_dist, c->d_bow_sel, &chain);
   }
   if (rc) return rc;
   // K8 leaves the knn views in ascending order in d_bow_sel; everything downstream reads the selection on the device
   uint32_t dummy = 0;
-  return ctx_localize_begin(c, q, &dummy, knn, c->d_bow_sel);
+  c->chain_done = true;
+  rc = ctx_localize_begin(c, q, &dummy, knn, c->d_bow_sel);
+  c->chain_done = false;
+  return rc;
 }
 
 int sfmloc_localize_end(sfmloc_context *ctx, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *pair_landmark,
@@ -1347,19 +1374,23 @@ int sfmloc_shard_begin_bow(sfmloc_context *ctx, sfmloc_query *query, const void 
   SFM_HIP(hipSetDevice(m->device));
   ctx_mark_busy(c);  // until sfmloc_context_sync
   ClearedScope cs{c};
-  int rc = ctx_reset_for_query(c, q);
-  if (rc) return rc;
   // this shard's part of the global knn best: ascending local view indices, padded with the phantom view up to
   // n_pad = min(knn, n_views) entries -- the launch sizes below depend on n_pad only, never on the outcome
   const uint32_t n_pad = knn < m->n_views ? knn : m->n_views;
+  int rc;
   {
     EventScope ev(c, SFMLOC_K_BOW);
+    // the workgroup that merges the key lists also clears the query's counters and builds the block list
+    const ChainArgs chain = make_chain_args(c, q, c->d_bow_sel, n_pad);
     rc = launch_bow_merge_select(m, c->stream, reinterpret_cast<const unsigned long long *>(keys_dev), n_parts,
-                                 part_stride_keys, knn, n_pad, c->d_bow_sel);
+                                 part_stride_keys, knn, n_pad, c->d_bow_sel, n_pad ? &chain : nullptr);
   }
   if (rc) return rc;
+  c->chain_done = n_pad != 0;
+  rc = ctx_reset_for_query(c, q);
   uint32_t dummy = 0;
-  rc = ctx_match_putative(c, q, &dummy, n_pad, c->d_bow_sel);
+  if (!rc) rc = ctx_match_putative(c, q, &dummy, n_pad, c->d_bow_sel);
+  c->chain_done = false;
   if (rc) return rc;
   rc = check_stage(c, q, "sfmloc_shard_begin_bow");
   if (rc) return rc;

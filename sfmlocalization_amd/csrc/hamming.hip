@@ -16,6 +16,7 @@
 // thanks to the tiled64 layout (sfmloc_internal.h).
 #include <stdlib.h>
 
+#include "chain_device.h"
 #include "sfmloc_internal.h"
 
 namespace sfmloc {
@@ -689,59 +690,8 @@ __global__ __launch_bounds__(1024) void k_blocks_from_views(const uint32_t *__re
                                                             uint32_t *__restrict__ view_sel_out,
                                                             uint32_t *__restrict__ widx0, uint32_t *__restrict__ block_list,
                                                             uint32_t bound, unsigned long long *__restrict__ flagmask) {
-  __shared__ uint32_t s_last[1024];  // inclusive running max of (last block + 1) over the non-empty views so far
-  __shared__ uint32_t s_cnt[1024];   // inclusive scan of the blocks each view adds
-  __shared__ uint32_t s_carry_last, s_carry_cnt;
-  const uint32_t tid = threadIdx.x;
-  if (tid == 0) s_carry_last = 0, s_carry_cnt = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n_sel; base += 1024) {
-    const uint32_t k = base + tid;
-    uint32_t v = 0, r0 = 0, r1 = 0;
-    if (k < n_sel) {
-      v = sel[k];
-      r0 = view_off[v];
-      r1 = view_off[v + 1];
-    }
-    const bool nonempty = r1 > r0;
-    const uint32_t b0 = r0 / kBlockRows, b1 = nonempty ? (r1 - 1) / kBlockRows : 0;
-    s_last[tid] = nonempty ? b1 + 1 : 0;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive max-scan
-      const uint32_t o = tid >= off ? s_last[tid - off] : 0;
-      __syncthreads();
-      s_last[tid] = max(s_last[tid], o);
-      __syncthreads();
-    }
-    // last block (+1) of the nearest earlier non-empty selected view: views ascend, so it is the running maximum
-    const uint32_t prev = max(s_carry_last, tid ? s_last[tid - 1] : 0u);
-    const bool share = nonempty && prev != 0 && prev - 1 == b0;
-    const uint32_t add = nonempty ? (b1 - b0 + 1 - (share ? 1u : 0u)) : 0u;
-    s_cnt[tid] = add;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive sum-scan
-      const uint32_t o = tid >= off ? s_cnt[tid - off] : 0;
-      __syncthreads();
-      s_cnt[tid] += o;
-      __syncthreads();
-    }
-    const uint32_t start = s_carry_cnt + s_cnt[tid] - add;
-    if (k < n_sel) {
-      view_sel_out[k] = v;
-      widx0[k] = nonempty ? (share ? start - 1 : start) : 0u;
-      for (uint32_t b = b0 + (share ? 1u : 0u), w = start; nonempty && b <= b1; ++b, ++w)
-        if (w < bound) block_list[w] = b;
-    }
-    __syncthreads();
-    if (tid == 1023) {
-      s_carry_last = max(s_carry_last, s_last[1023]);
-      s_carry_cnt += s_cnt[1023];
-    }
-    __syncthreads();
-  }
-  for (uint32_t w = s_carry_cnt + tid; w < bound; w += 1024) block_list[w] = kNoBlock;
-  // a sliced scan ORs its row flags into the per-block masks: clear them here rather than with one more launch
-  for (uint32_t w = tid; w < bound; w += 1024) flagmask[w] = 0ull;
+  BlocksArgs B{sel, n_sel, view_off, view_sel_out, widx0, block_list, bound, flagmask};
+  blocks_from_views_block(B);  // chain_device.h
 }
 
 int launch_blocks_from_views(Ctx *c, const uint32_t *d_sel, uint32_t n_sel, uint32_t bound) {

@@ -244,6 +244,7 @@ struct Ctx {
   bool flagmask_zeroed = false;       // k_blocks_from_views has just cleared d_flagmask for the coming scan
   bool counted_busy = false;          // this context is counted in Map::busy_ctx
   bool k1_may_slice = true;           // no other context had work queued when this query began
+  bool chain_done = false;            // the shortlist kernel already cleared the counters and built the block list
   bool cleared = false;  // k_query_reset already cleared this query's counters: the stages skip their own memsets
   struct Query *last_query = nullptr;  // query of the last putative call
   struct Query *in_flight = nullptr;   // query of a begun, not yet ended, localisation
@@ -288,14 +289,16 @@ struct BofModel {
   int cap_n = 0;
   hipStream_t stream = nullptr;
 };
+struct ChainArgs;  // chain_device.h: what the shortlist's workgroup does on top of the shortlist (may be null)
 int launch_bow_select(Map *m, hipStream_t s, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
-                      uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel);
+                      uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel, const ChainArgs *chain = nullptr);
 // sharded shortlist: this shard's k best as sortable keys (distance bits << 32 | global view id), and
 // the shard's part of the global k best among n_parts key lists
 int launch_bow_keys(Map *m, hipStream_t s, const float *d_query, uint32_t k, uint32_t *d_dist_bits, uint32_t *d_sel_tmp,
                     unsigned long long *d_keys_out);
 int launch_bow_merge_select(Map *m, hipStream_t s, const unsigned long long *d_keys, uint32_t n_parts,
-                            uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out);
+                            uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out,
+                            const ChainArgs *chain = nullptr);
 int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const float *d_kxy, int n, uint32_t *d_counts,
                double *d_out, float *d_out_f32);
 
