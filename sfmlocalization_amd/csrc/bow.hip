@@ -71,6 +71,7 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
   const uint32_t tid = threadIdx.x;
   if (k > n) k = n;
   if (k == 0) return;  // (the launcher never chains an empty shortlist)
+  const uint32_t k_sel = k;
   uint32_t prefix = 0, rank = k;  // the k-th smallest (1-based) within the elements matching `prefix`
   const int shifts[3] = {21, 10, 0};
   const uint32_t widths[3] = {11, 11, 10};
@@ -130,6 +131,17 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
       ++e;
     }
     if (take) out_sel[pos++] = cand ? cand[i] : i;
+  }
+  if (chain.keys_out) {  // sharded shortlist: the selection as (distance bits << 32 | global view id), padded
+    __syncthreads();
+    for (uint32_t i = tid; i < chain.k_out; i += 1024) {
+      unsigned long long key = ~0ull;
+      if (i < k_sel) {
+        const uint32_t v = out_sel[i];
+        key = ((unsigned long long)dist_bits[v] << 32) | (unsigned long long)chain.key_view_id[v];
+      }
+      chain.keys_out[i] = key;
+    }
   }
   chain_after_shortlist(chain);  // the query's counters and the block list of the k views (chain_device.h)
 }
@@ -306,9 +318,18 @@ int launch_bow_keys(Map *m, hipStream_t s, const float *d_query, uint32_t k, uin
                     unsigned long long *d_keys_out) {
   if (k == 0) return SFMLOC_OK;
   const uint32_t kk = k < m->n_views ? k : m->n_views;
-  if (kk) {
-    int rc = launch_bow_select(m, s, d_query, nullptr, m->n_views, kk, d_dist_bits, d_sel_tmp);
-    if (rc) return rc;
+  if (kk) {  // the keys come out of the selection's own workgroup (no third launch)
+    ChainArgs C{};
+    C.keys_out = d_keys_out;
+    C.key_view_id = m->d_view_id;
+    C.k_out = k;
+    hipLaunchKernelGGL(k_bow_dist, dim3((m->n_views + 3) / 4), dim3(256), 0, s, m->d_bow, m->bow_dim,
+                       (const uint32_t *)nullptr, m->n_views, d_query, d_dist_bits);
+    SFM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, s, d_dist_bits, m->n_views, (const uint32_t *)nullptr, kk,
+                       d_sel_tmp, C);
+    SFM_HIP(hipGetLastError());
+    return SFMLOC_OK;
   }
   hipLaunchKernelGGL(k_bow_keys, dim3((k + 255) / 256), dim3(256), 0, s, d_dist_bits, d_sel_tmp, kk, m->d_view_id, k,
                      d_keys_out);

@@ -298,7 +298,7 @@ int ctx_reset_for_query(Ctx *c, const Query *q) {
 // The chain a shortlist kernel runs after the shortlist (reset + block list of the knn selected views in d_sel)
 ChainArgs make_chain_args(Ctx *c, const Query *q, const uint32_t *d_sel, uint32_t n_sel) {
   Map *m = c->map;
-  ChainArgs C;
+  ChainArgs C{};  // (keys_out = null: no key list)
   C.enabled = 1;
   C.reset = make_reset_args(c, q);
   C.blocks.sel = d_sel;

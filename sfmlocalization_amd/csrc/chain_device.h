@@ -106,11 +106,15 @@ __device__ __forceinline__ void blocks_from_views_block(const BlocksArgs &B) {
   for (uint32_t w = tid; w < B.bound; w += 1024) B.flagmask[w] = 0ull;
 }
 
-// what the shortlist's last workgroup does on top of the shortlist (enabled = 0: nothing)
+// what the shortlist's last workgroup does on top of the shortlist (enabled = 0: nothing); keys_out (k_bow_topk only):
+// the selection as sortable keys for the sharded shortlist, padded to k_out entries
 struct ChainArgs {
   int enabled;
   QueryResetArgs reset;
   BlocksArgs blocks;
+  unsigned long long *keys_out;
+  const uint32_t *key_view_id;
+  uint32_t k_out;
 };
 __device__ __forceinline__ void chain_after_shortlist(const ChainArgs &C) {
   if (!C.enabled) return;
