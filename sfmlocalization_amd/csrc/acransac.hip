@@ -512,6 +512,7 @@ struct FFilterArgs {
   uint32_t *large_count, *large_list;  // views with more than kFMaxM matches, queued for k_fmatrix_large (or null)
   int *status;
   int skip_le;  // k_fmatrix_filter leaves views with at most this many putative matches to k_fmatrix_fast
+  MergeMaskedArgs merge;  // enabled: k_fmatrix_fast first builds its view's putative list (K2 left to it)
 };
 
 // small per-view state of the block-wide form (always in LDS)
@@ -827,6 +828,10 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
   STAMP_F_DECL;
   STAMP_F(1);
   const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
+  if (A.merge.enabled) {  // K2 for this view (chain_device.h), by one wave; the others wait for its lists
+    if (wv == 0) merge_ratio_masked_view(A.merge, blockIdx.x, (uint32_t)lane);
+    __syncthreads();
+  }
   const int m = (int)A.put_count[v];
   const uint32_t off = A.view_off[v];
   constexpr int s = 7;
@@ -2220,6 +2225,16 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
     return !(e && atoi(e) == 0);
   }();
   A.skip_le = fast ? kF2MaxM : -1;
+  A.merge = MergeMaskedArgs{};
+  if (c->merge_is_deferred) {  // K2 was left to this stage (launch_merge_ratio_compact)
+    c->merge_is_deferred = false;
+    if (fast) {
+      A.merge = c->deferred_merge;  // k_fmatrix_fast runs on every selected view, whatever its size
+    } else {
+      int rc = launch_merge_masked_now(c, n_sel);
+      if (rc) return rc;
+    }
+  }
   if (fast) {
     const size_t lds2 = sizeof(F2Shared);
     static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast),
@@ -2229,8 +2244,10 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
     SFM_HIP(hipGetLastError());
   }
   const size_t lds = sizeof(FShared);
-  SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_filter),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_filter),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FShared));
+  SFM_HIP(attr1);
+  A.merge.enabled = 0;  // (the lists exist by now)
   hipLaunchKernelGGL(k_fmatrix_filter, dim3(n_sel), dim3(kThreads), lds, c->stream, A);
   SFM_HIP(hipGetLastError());
   if (A.large_list) {  // some view of this map can have more than kFMaxM matches: the queue's consumer

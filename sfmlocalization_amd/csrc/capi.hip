@@ -351,6 +351,7 @@ int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_se
   c->last_blocks.clear();
   c->last_blocks_on_device = false;
   c->flagmask_zeroed = false;
+  c->merge_is_deferred = false;  // (a merge left to a K3 that never ran belongs to an abandoned query)
   if (d_sel) {
     // launch bound the host can know: every selected view overlaps at most max_view_blocks blocks
     const uint64_t bound = std::min<uint64_t>(m->n_blocks, (uint64_t)n_sel * m->max_view_blocks);
@@ -589,11 +590,13 @@ static int ctx_localize_begin_impl(Ctx *c, Query *q, const uint32_t *view_sel, u
   if (rc) return rc;
   rc = ctx_reset_for_query(c, q);
   if (rc) return rc;
+  const int stop = diag_stop_after();
+  c->defer_merge = stop != 1;  // K3 follows on this context: its per-view workgroups build their own match lists
   rc = ctx_match_putative(c, q, view_sel, n_sel, d_sel);
+  c->defer_merge = false;
   if (rc) return rc;
   rc = check_stage(c, q, "sfmloc_localize");
   if (rc) return rc;
-  const int stop = diag_stop_after();
   if (stop != 1) {
     rc = ctx_geometric_filter(c, q);
     if (rc) return rc;
@@ -1323,7 +1326,9 @@ int sfmloc_shard_begin(sfmloc_context *ctx, sfmloc_query *query, const uint32_t 
   ClearedScope cs{c};
   int rc = ctx_reset_for_query(c, q);
   if (rc) return rc;
+  c->defer_merge = true;  // K3 follows on this context
   rc = ctx_match_putative(c, q, view_sel, n_sel);
+  c->defer_merge = false;
   if (rc) return rc;
   rc = check_stage(c, q, "sfmloc_shard_begin");
   if (rc) return rc;
@@ -1389,7 +1394,9 @@ int sfmloc_shard_begin_bow(sfmloc_context *ctx, sfmloc_query *query, const void 
   c->chain_done = n_pad != 0;
   rc = ctx_reset_for_query(c, q);
   uint32_t dummy = 0;
+  c->defer_merge = true;  // K3 follows on this context
   if (!rc) rc = ctx_match_putative(c, q, &dummy, n_pad, c->d_bow_sel);
+  c->defer_merge = false;
   c->chain_done = false;
   if (rc) return rc;
   rc = check_stage(c, q, "sfmloc_shard_begin_bow");

@@ -106,6 +106,68 @@ __device__ __forceinline__ void blocks_from_views_block(const BlocksArgs &B) {
   for (uint32_t w = tid; w < B.bound; w += 1024) B.flagmask[w] = 0ull;
 }
 
+// K2 after a screened scan (k_merge_ratio_masked), one wave per selected view: only rows whose mask bit is set can be
+// matches; a lane walks the set bits of one 64-row block, so all partial-result loads of the view are in flight at
+// once, and a wave scan of the per-lane accept counts places the accepted rows in ascending order.  Shared by the K2
+// kernel and by K3's per-view workgroup, which runs it for its own view when the merge was left to it (one launch less).
+struct MergeMaskedArgs {
+  int enabled;
+  const uint2 *part;
+  const unsigned long long *flagmask;
+  const uint32_t *view_sel, *view_widx0;
+  const uint32_t *view_off;
+  const uint16_t *ratio_cnt;
+  uint32_t *view_count, *match_i, *match_key;
+};
+__device__ __forceinline__ void merge_ratio_masked_view(const MergeMaskedArgs &M, uint32_t gw, uint32_t lane) {
+  constexpr uint32_t kNoMatch = 0xFFFFFFFFu;  // SFMLOC_NOMATCH
+  const uint32_t v = M.view_sel ? M.view_sel[gw] : gw;
+  const uint32_t off = M.view_off[v], end = M.view_off[v + 1];
+  const uint32_t blk0 = off >> 6;
+  const uint32_t widx0 = M.view_sel ? M.view_widx0[gw] : blk0;
+  const uint32_t n_blk = (end > off) ? (((end - 1) >> 6) - blk0 + 1) : 0;
+  uint32_t base = 0;
+  for (uint32_t c0 = 0; c0 < n_blk; c0 += 64) {  // 64 blocks (4096 rows) per pass
+    const uint32_t rel = c0 + lane;
+    unsigned long long w = 0;
+    if (rel < n_blk) {
+      w = M.flagmask[widx0 + rel];
+      // rows of the block that belong to neighbouring views
+      const uint64_t r_lo = (uint64_t)(blk0 + rel) << 6;
+      if (r_lo < off) w &= ~0ull << (off - r_lo);
+      if (r_lo + 64 > end) w &= (end > r_lo) ? (~0ull >> (r_lo + 64 - end)) : 0ull;
+    }
+    // pass 1: count the accepted rows of my block
+    uint32_t mine = 0;
+    unsigned long long acc_bits = 0;
+    for (unsigned long long t = w; t; t &= t - 1) {
+      const uint32_t bit = (uint32_t)__builtin_ctzll(t);
+      const uint2 p = M.part[((uint64_t)(widx0 + rel)) * 64 + bit];
+      if (p.y != kNoMatch && (p.x >> 16) < (uint32_t)M.ratio_cnt[p.y >> 16]) {
+        acc_bits |= 1ull << bit;
+        ++mine;
+      }
+    }
+    // exclusive scan over the lanes
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if ((int)lane >= d) incl += o;
+    }
+    uint32_t pos = base + incl - mine;
+    // pass 2: write them in ascending row order
+    for (unsigned long long t = acc_bits; t; t &= t - 1) {
+      const uint32_t bit = (uint32_t)__builtin_ctzll(t);
+      const uint2 p = M.part[((uint64_t)(widx0 + rel)) * 64 + bit];
+      M.match_i[off + pos] = (uint32_t)((((uint64_t)(blk0 + rel)) << 6) + bit - off);
+      M.match_key[off + pos] = p.x;
+      ++pos;
+    }
+    base += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) M.view_count[v] = base;
+}
+
 // what the shortlist's last workgroup does on top of the shortlist (enabled = 0: nothing); keys_out (k_bow_topk only):
 // the selection as sortable keys for the sharded shortlist, padded to k_out entries
 struct ChainArgs {

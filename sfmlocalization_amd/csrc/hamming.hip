@@ -498,59 +498,10 @@ __global__ __launch_bounds__(256) void k_merge_ratio_compact(
 // view, one LANE per 64-row block of the view: the lane walks the set bits of its mask word, so every partial-result
 // load of the view is in flight at once (the row-by-row kernel above pays one dependent load per hit); an exclusive
 // wave scan of the per-lane accept counts then gives each lane its place in the view's ascending list.
-__global__ __launch_bounds__(256) void k_merge_ratio_masked(
-    const uint2 *__restrict__ part, const unsigned long long *__restrict__ flagmask, const uint32_t *__restrict__ view_sel,
-    const uint32_t *__restrict__ view_widx0, uint32_t n_sel, const uint32_t *__restrict__ view_off,
-    const uint16_t *__restrict__ ratio_cnt, uint32_t *__restrict__ view_count, uint32_t *__restrict__ match_i,
-    uint32_t *__restrict__ match_key) {
-  const uint32_t lane = threadIdx.x & 63u;
+__global__ __launch_bounds__(256) void k_merge_ratio_masked(MergeMaskedArgs M, uint32_t n_sel) {
   const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= n_sel) return;
-  const uint32_t v = view_sel ? view_sel[gw] : gw;
-  const uint32_t off = view_off[v], end = view_off[v + 1];
-  const uint32_t blk0 = off >> 6;
-  const uint32_t widx0 = view_sel ? view_widx0[gw] : blk0;
-  const uint32_t n_blk = (end > off) ? (((end - 1) >> 6) - blk0 + 1) : 0;
-  uint32_t base = 0;
-  for (uint32_t c0 = 0; c0 < n_blk; c0 += 64) {  // 64 blocks (4096 rows) per pass
-    const uint32_t rel = c0 + lane;
-    unsigned long long w = 0;
-    if (rel < n_blk) {
-      w = flagmask[widx0 + rel];
-      // rows of the block that belong to neighbouring views
-      const uint64_t r_lo = (uint64_t)(blk0 + rel) << 6;
-      if (r_lo < off) w &= ~0ull << (off - r_lo);
-      if (r_lo + 64 > end) w &= (end > r_lo) ? (~0ull >> (r_lo + 64 - end)) : 0ull;
-    }
-    // pass 1: count the accepted rows of my block
-    uint32_t mine = 0;
-    unsigned long long acc_bits = 0;
-    for (unsigned long long t = w; t; t &= t - 1) {
-      const uint32_t bit = (uint32_t)__builtin_ctzll(t);
-      const uint2 p = part[((uint64_t)(widx0 + rel)) * 64 + bit];
-      if (p.y != SFMLOC_NOMATCH && (p.x >> 16) < (uint32_t)ratio_cnt[p.y >> 16]) {
-        acc_bits |= 1ull << bit;
-        ++mine;
-      }
-    }
-    // exclusive scan over the lanes
-    uint32_t incl = mine;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d, 64);
-      if ((int)lane >= d) incl += o;
-    }
-    uint32_t pos = base + incl - mine;
-    // pass 2: write them in ascending row order
-    for (unsigned long long t = acc_bits; t; t &= t - 1) {
-      const uint32_t bit = (uint32_t)__builtin_ctzll(t);
-      const uint2 p = part[((uint64_t)(widx0 + rel)) * 64 + bit];
-      match_i[off + pos] = (uint32_t)((((uint64_t)(blk0 + rel)) << 6) + bit - off);
-      match_key[off + pos] = p.x;
-      ++pos;
-    }
-    base += __shfl(incl, 63, 64);
-  }
-  if (lane == 0) view_count[v] = base;
+  merge_ratio_masked_view(M, gw, threadIdx.x & 63u);  // chain_device.h
 }
 
 template <int R, int WAVES>
@@ -755,9 +706,23 @@ int launch_merge_ratio_compact(Ctx *c, const Query *q, uint32_t n_sel, bool all_
   Map *m = c->map;
   if (n_sel == 0) return SFMLOC_OK;
   if (c->last_screened && split == 1) {
-    hipLaunchKernelGGL(k_merge_ratio_masked, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream, c->d_part, c->d_flagmask,
-                       all_views ? nullptr : c->d_view_sel, all_views ? nullptr : c->d_view_widx0, n_sel, m->d_view_off,
-                       m->d_ratio_cnt, c->d_view_count, c->d_match_i, c->d_match_key);
+    MergeMaskedArgs M;
+    M.enabled = 1;
+    M.part = c->d_part;
+    M.flagmask = c->d_flagmask;
+    M.view_sel = all_views ? nullptr : c->d_view_sel;
+    M.view_widx0 = all_views ? nullptr : c->d_view_widx0;
+    M.view_off = m->d_view_off;
+    M.ratio_cnt = m->d_ratio_cnt;
+    M.view_count = c->d_view_count;
+    M.match_i = c->d_match_i;
+    M.match_key = c->d_match_key;
+    if (c->defer_merge) {  // the caller runs K3 next on this context: its per-view workgroups merge their own views
+      c->deferred_merge = M;
+      c->merge_is_deferred = true;
+      return SFMLOC_OK;
+    }
+    hipLaunchKernelGGL(k_merge_ratio_masked, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream, M, n_sel);
     SFM_HIP(hipGetLastError());
     return SFMLOC_OK;
   }
@@ -765,6 +730,12 @@ int launch_merge_ratio_compact(Ctx *c, const Query *q, uint32_t n_sel, bool all_
                      c->last_screened ? c->d_flagmask : nullptr, n_work_blocks, split, all_views ? nullptr : c->d_view_sel,
                      all_views ? nullptr : c->d_view_widx0, n_sel, m->d_view_off, m->d_ratio_cnt, c->d_view_count,
                      c->d_match_i, c->d_match_key);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+int launch_merge_masked_now(Ctx *c, uint32_t n_sel) {
+  hipLaunchKernelGGL(k_merge_ratio_masked, dim3((n_sel + 3) / 4), dim3(256), 0, c->stream, c->deferred_merge, n_sel);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

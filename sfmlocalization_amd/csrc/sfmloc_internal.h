@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/sfmloc.h"
+#include "chain_device.h"
 
 namespace sfmloc {
 
@@ -245,6 +246,9 @@ struct Ctx {
   bool counted_busy = false;          // this context is counted in Map::busy_ctx
   bool k1_may_slice = true;           // no other context had work queued when this query began
   bool chain_done = false;            // the shortlist kernel already cleared the counters and built the block list
+  bool defer_merge = false;           // the caller runs K3 right after K1 on this context: K2 may be left to K3
+  bool merge_is_deferred = false;     // ... and was: launch_fmatrix_filter passes deferred_merge to k_fmatrix_fast
+  MergeMaskedArgs deferred_merge{};
   bool cleared = false;  // k_query_reset already cleared this query's counters: the stages skip their own memsets
   struct Query *last_query = nullptr;  // query of the last putative call
   struct Query *in_flight = nullptr;   // query of a begun, not yet ended, localisation
@@ -321,6 +325,7 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
 int launch_export_packed(Ctx *c, void *dst_dev, uint32_t n_queries, uint32_t budget, uint32_t qi);
 uint64_t packed_part_bytes(uint32_t n_queries, uint32_t budget);
 int ctx_p3p_reserve(Ctx *c, uint32_t n_query_rows);  // capi.hip: grow the P3P workspace to a query's feature count
+int launch_merge_masked_now(Ctx *c, uint32_t n_sel);  // hamming.hip: the deferred K2 as a launch of its own
 int launch_p3p_init(Ctx *c);
 int launch_p3p_round(Ctx *c, int batch);
 int launch_p3p_finish(Ctx *c);
