@@ -467,9 +467,9 @@ __device__ void logc_n_block(int n, const double *__restrict__ L10, double *term
 }
 
 __device__ void logcombi_tables_block(int s, int n, const double *__restrict__ L10, double *terms, float *logc_n,
-                                      float *logc_k) {
-  logc_n_block(n, L10, terms, logc_n, kThreads);
-  for (int m = threadIdx.x; m <= n; m += kThreads) {
+                                      float *logc_k, int n_threads = kThreads) {
+  logc_n_block(n, L10, terms, logc_n, n_threads);
+  for (int m = threadIdx.x; m <= n; m += n_threads) {
     float v = 0.0f;
     if (s < m) {
       int k = s;
@@ -1293,13 +1293,16 @@ __global__ __launch_bounds__(256) void k_candidates_min(const unsigned char *par
   }
 }
 
+__device__ void p3p_init_block(const P3pArgs &A, int n, int n_threads, double *s_terms);  // K5's start, below
+
 __global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *parts, uint32_t n_parts,
                                                           uint64_t part_bytes,
                                                           uint32_t cap, const unsigned long long *best,
                                                           uint32_t *winner, uint32_t nq, const float2 *q_kpt,
                                                           uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
                                                           double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
-                                                          double ppy, double k1, double k2, double k3, PartLayout L) {
+                                                          double ppy, double k1, double k2, double k3, PartLayout L,
+                                                          P3pArgs init /*K5's start, by this workgroup: one launch less*/) {
   // one workgroup; winners are compacted in query-feature order, 1024 features per pass (a pass is a chain of
   // dependent loads, so fewer, wider passes)
   __shared__ uint32_t wave_cnt[16];
@@ -1349,14 +1352,19 @@ __global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *
     __syncthreads();
   }
   if (threadIdx.x == 0) *ms_n = base_s;
+  // K5's initial state, normalised points and logcombi tables for the base_s correspondences just written
+  __shared__ double s_terms[kP3pMaxN / 2 + 1];
+  __syncthreads();
+  p3p_init_block(init, (int)base_s, 1024, s_terms);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // K5: P3P AC-RANSAC as rounds of (evaluate a batch of hypotheses | replay the sequential rule)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
+// the start of K5: the state machine's initial state, the K^-1-normalised image points and the logcombi tables.  A
+// workgroup of n_threads threads; n = the number of 2D-3D correspondences (what k_match_set_finish counted).
+__device__ void p3p_init_block(const P3pArgs &A, int n, int n_threads, double *s_terms) {
   P3pState &st = *A.state;
-  const int n = (int)*A.ms_n;
   __shared__ int go;
   if (threadIdx.x == 0) {
     st.n = n;
@@ -1401,13 +1409,16 @@ __global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
   // normalise by K^-1: x * (1/f) + (-pp/f)
   const double inv_f = 1.0 / A.focal;
   const double cx = -A.ppx * inv_f, cy = -A.ppy * inv_f;
-  for (int i = threadIdx.x; i < n; i += kThreads) {
+  for (int i = threadIdx.x; i < n; i += n_threads) {
     A.xn[2 * i] = A.pt2d[2 * i] * inv_f + cx;
     A.xn[2 * i + 1] = A.pt2d[2 * i + 1] * inv_f + cy;
   }
   // (the table pass wants n / 2 + 1 doubles of scratch: LDS up to kP3pMaxN correspondences, global beyond)
+  logcombi_tables_block(3, n, A.L10, n > kP3pMaxN ? A.ws_terms : s_terms, A.logc_n, A.logc_k, n_threads);
+}
+__global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
   __shared__ double s_terms[kP3pMaxN / 2 + 1];
-  logcombi_tables_block(3, n, A.L10, n > kP3pMaxN ? A.ws_terms : s_terms, A.logc_n, A.logc_k);
+  p3p_init_block(A, (int)*A.ms_n, kThreads, s_terms);
 }
 
 constexpr int kP3pWaveSeg = kP3pMaxN / 4;  // elements one wave sorts when the four models run side by side
@@ -2346,6 +2357,8 @@ int launch_export_packed(Ctx *c, void *dst_dev, uint32_t n_queries, uint32_t bud
   return SFMLOC_OK;
 }
 
+static P3pArgs make_p3p_args(Ctx *c);
+
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
                              uint64_t part_bytes, uint32_t cap, uint32_t packed_b, uint32_t packed_qi) {
   PartLayout L;
@@ -2368,8 +2381,9 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
   hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(1024), 0, c->stream, parts, n_parts, part_bytes, cap, c->d_best64,
                      c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d,
                      c->map->intrinsic_type == 3 ? 1 : 0, c->map->focal, c->map->ppx, c->map->ppy, c->map->k1, c->map->k2,
-                     c->map->k3, L);
+                     c->map->k3, L, make_p3p_args(c));
   SFM_HIP(hipGetLastError());
+  c->p3p_init_fused = true;  // launch_p3p_init is then a no-op for this query
   return SFMLOC_OK;
 }
 
@@ -2434,6 +2448,10 @@ static P3pArgs make_p3p_args(Ctx *c) {
 }
 
 int launch_p3p_init(Ctx *c) {
+  if (c->p3p_init_fused) {  // k_match_set_finish has done it
+    c->p3p_init_fused = false;
+    return SFMLOC_OK;
+  }
   P3pArgs A = make_p3p_args(c);
   hipLaunchKernelGGL(k_p3p_init, dim3(1), dim3(kThreads), 0, c->stream, A);
   SFM_HIP(hipGetLastError());

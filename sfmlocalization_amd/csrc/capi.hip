@@ -1182,6 +1182,8 @@ int sfmloc_match_set(sfmloc_map *map, sfmloc_query *query) {
   int rc = check_stage(m->ctx0, q, "sfmloc_match_set");
   if (rc) return rc;
   SFM_HIP(hipSetDevice(m->device));
+  rc = ctx_p3p_reserve(m->ctx0, q->n);  // K5's start runs at the end of this stage (k_match_set_finish)
+  if (rc) return rc;
   return ctx_match_set(m->ctx0, q);
 }
 

@@ -245,6 +245,7 @@ struct Ctx {
   bool flagmask_zeroed = false;       // k_blocks_from_views has just cleared d_flagmask for the coming scan
   bool counted_busy = false;          // this context is counted in Map::busy_ctx
   bool k1_may_slice = true;           // no other context had work queued when this query began
+  bool p3p_init_fused = false;        // k_match_set_finish has run K5's initialisation for the query in hand
   bool chain_done = false;            // the shortlist kernel already cleared the counters and built the block list
   bool defer_merge = false;           // the caller runs K3 right after K1 on this context: K2 may be left to K3
   bool merge_is_deferred = false;     // ... and was: launch_fmatrix_filter passes deferred_merge to k_fmatrix_fast
