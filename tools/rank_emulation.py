@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-rank run does per batch, measured on one GPU: the builder has a single device, and the N-rank
+throughput of the sharded path (dist.py) is, up to the collectives' latency, the rate at which a rank gets through its
+batches -- every rank runs stage 1 of every query on its 1/N of the map and stage 2 of every N-th query.
+
+The other ranks' contributions to the two all-gathers (their k-best BoW keys, their packed candidate parts) are computed
+ONCE, before the timed region, by running their shards on this same GPU; the timed region then runs rank 0 for real and
+`_all_gather` hands it [own live part, the others' stored parts].  The poses of rank 0's queries are compared with the
+unsharded path on the whole map first (same inliers, same pose bits), so the emulated exchange is the real one.
+
+Diagnostic: not the metric, no collective inside (its latency hides under the two-slot pipeline or does not -- only a
+real N-GPU run tells).  usage: python tools/rank_emulation.py --of 8 [--steps 8 --warmup 2 --in-flight 8]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--of", type=int, default=8, help="N: the emulated world size (this process is rank 0 of N)")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--views", type=int, default=10000)
+    ap.add_argument("--desc-per-view", type=int, default=2000)
+    ap.add_argument("--nq", type=int, default=2000)
+    ap.add_argument("--bow-knn", type=int, default=100)
+    ap.add_argument("--queries", type=int, default=64)
+    ap.add_argument("--in-flight", type=int, default=8, help="contexts per slot (the sharded path keeps two slots)")
+    ap.add_argument("--gang", type=int, default=0, help="queries per launch in stage 1 (0 = the library's default)")
+    a = ap.parse_args()
+    N, B = a.of, a.batch
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, 2 * a.in_flight + 2))))
+    import numpy as np
+    import torch
+    import bench
+    import sfmlocalization_amd as S
+    import synthdata as synth
+    from sfmlocalization_amd import dist as D
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    m = synth.make_map(2, n_views=a.views, desc_per_view=a.desc_per_view)
+    queries = [synth.make_query(m, 1000 + i, n_feat=a.nq) for i in range(a.queries)]
+    bow, qbow = bench.synth_bow(m, queries)
+    params = S.default_params(device=0, profile=0, ransac_round=25)
+    batch_ids = [i % len(queries) for i in range(B)]
+
+    def shard(r, n):
+        v0, v1 = (a.views * r) // n, (a.views * (r + 1)) // n
+        r0, r1 = int(m.view_off[v0]), int(m.view_off[v1])
+        dm = S.Map(m.view_id[v0:v1], m.view_off[v0:v1 + 1] - m.view_off[v0], m.desc[r0:r1], params=params,
+                   view_wh=m.view_wh[v0:v1], kpt_xy=m.kpt_xy[r0:r1], row_landmark=m.row_landmark[r0:r1],
+                   landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic, bow=bow[v0:v1])
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in queries]
+        for dq, qb in zip(dqs, qbow):
+            dq.set_bow(qb)
+        return dm, dqs
+
+    budget = B * 256
+    # ---- the other ranks' halves of the two exchanges, once --------------------------------------------------------
+    maps = [shard(r, N) for r in range(N)]
+    comps = [D.HipShardCompute(dm, n_contexts=(a.in_flight if r == 0 else 2), device=dev) for r, (dm, _) in enumerate(maps)]
+    keys = []
+    for comp, (dm, dqs) in zip(comps, maps):
+        k = comp.bow_keys([dqs[i] for i in batch_ids], a.bow_knn, 0)
+        for c in comp.ctxs[0]:
+            c.sync()
+        keys.append(k.clone())
+    keys_all = torch.stack(keys)                                   # [N, B, knn]
+    parts = [None] * N
+    for r in range(1, N):
+        dm, dqs = maps[r]
+        p = comps[r].stage1_bow([dqs[i] for i in batch_ids], keys_all, a.bow_knn, 0, budget)
+        for c in comps[r].ctxs[0]:
+            c.sync()
+        torch.cuda.synchronize()
+        parts[r] = p.clone()
+    for r in range(1, N):
+        comps[r].close()
+        for dq in maps[r][1]:
+            dq.close()
+        maps[r][0].close()
+    dm0, dqs0 = maps[0]
+    comp = comps[0]
+
+    class Emulated(D.ShardedLocalizer):
+        """rank 0 of N; the collectives replaced by device copies of what the other ranks would have sent"""
+
+        def _all_gather(self, send):
+            stored = keys if send.dtype == torch.int64 else parts
+            out = torch.empty((N,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+            comm = self._comm_stream()
+            with torch.cuda.stream(comm):
+                out[0].copy_(send)
+                for r in range(1, N):
+                    assert stored[r].shape == send.shape, "the stored parts were made for another batch / budget"
+                    out[r].copy_(stored[r])
+                ev = comm.record_event()
+            return out, ev
+
+    loc = Emulated(comp, rank=0, world=N, n_views_global=a.views)
+    if a.gang:
+        comp.gang = a.gang
+    batch = [dqs0[i] for i in batch_ids]
+
+    # ---- the emulated exchange is the real one: rank 0's queries against the unsharded path --------------------------
+    res = loc.localize_batch(batch, gather_results=False, bow_knn=a.bow_knn)
+    assert loc.counters()["batches_exchanged_again_with_a_larger_budget"] == 0, "budget grew: stored parts are stale"
+    full, fq = shard(0, 1)
+    same = 0
+    checked = sorted(res)[:16]
+    for i in checked:
+        pose, pq, pl = full.localize_bow(fq[batch_ids[i]], qbow[batch_ids[i]], a.bow_knn)
+        r = res[i]
+        same += int(bool(pose.ok) == r["ok"] and int(pose.n_inliers) == r["n_inliers"]
+                    and np.array_equal(np.array(pose.P).reshape(3, 4), r["P"]))
+    for dq in fq:
+        dq.close()
+    full.close()
+    n_ok_check = sum(int(r["ok"]) for r in res.values())
+
+    # ---- the rate ---------------------------------------------------------------------------------------------------
+    def run(n):
+        ok = 0
+        for r in loc.localize_stream([batch] * n, gather_results=False, bow_knn=a.bow_knn):
+            ok += sum(int(x["ok"]) for x in r.values())
+        torch.cuda.synchronize()
+        return ok
+
+    run(a.warmup)
+    t0 = time.perf_counter()
+    ok = run(a.steps)
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "emulated": f"rank 0 of {N}", "batch": B, "steps": a.steps, "contexts_per_slot": a.in_flight,
+        "queries_per_launch_stage1": getattr(comp, "gang", 1),
+        "ms_per_batch": dt / a.steps * 1e3,
+        "rank_rate_queries_per_s": a.steps * B / dt,
+        "note": "all ranks work in lock step, so this is also the predicted whole-job rate of N ranks, collectives' "
+                "latency excluded",
+        "stage2_queries_per_batch": len(res), "localised_of_own": f"{ok}/{a.steps * len(res)}",
+        "same_as_unsharded": f"{same}/{len(checked)}", "first_batch_ok": n_ok_check,
+        "redo": loc.counters()["batches_exchanged_again_with_a_larger_budget"]}), flush=True)
+    comp.close()
+    for dq in dqs0:
+        dq.close()
+    dm0.close()
+
+
+if __name__ == "__main__":
+    main()

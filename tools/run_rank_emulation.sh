@@ -1,0 +1,8 @@
+# per-rank batch rate of the sharded path for N = 2, 4, 8, measured on one GPU (tools/rank_emulation.py)
+mkdir -p gpurun_out
+out=gpurun_out/rank_emulation${TAG:+_$TAG}.jsonl
+rm -f $out
+for n in ${WORLDS:-2 4 8}; do
+  timeout -k 10 400 python tools/rank_emulation.py --of $n $EXTRA > gpurun_out/re.log 2>&1 || { tail -30 gpurun_out/re.log; exit 1; }
+  tail -1 gpurun_out/re.log | tee -a $out
+done
