@@ -325,6 +325,23 @@ int sfmloc_context_sync(sfmloc_context *ctx);
  * hip_stream is a hipStream_t of the same device (NULL = the default stream). */
 int sfmloc_context_signal(sfmloc_context *ctx, void *hip_stream);
 int sfmloc_context_wait(sfmloc_context *ctx, void *hip_stream);
+/* Gang sessions: up to 32 contexts of one map take one query each through the same asynchronous calls
+ * (sfmloc_shard_bow_keys, sfmloc_shard_begin[_bow] + sfmloc_shard_export_packed, sfmloc_localize[_bow]_begin), and every
+ * kernel of the chain is launched once for all of them (or for as many as its kernel arguments hold: 8 to 32).  Between _begin and _end the calls on these contexts only record
+ * their launches; _end issues them -- one launch per kernel, the members side by side in gridDim.z -- on the first
+ * context's stream and orders the other members' streams after it.  Results are those of the same calls made one context
+ * at a time, bit for bit: a member's arithmetic does not change, only the number of launches (a rank of an N-rank run
+ * scans 1/N of the map per query but still issues every query's launches, and the device completes only so many
+ * dependent launches per second).  One host thread drives a session; with params.profile != 0 a session records
+ * nothing and the members run one after the other.
+ *   _counters: launches issued by this leader's sessions so far, and how many of them carried more than one member. */
+int sfmloc_gang_begin(sfmloc_context *const *ctxs, uint32_t n);
+/* a context (workspace) WITHOUT a stream of its own: its work is queued on `lender`'s stream, which must outlive it.  For
+ * the members of a gang other than the first -- a device serves only so many hardware queues well, and a context that
+ * only ever works inside gang sessions needs none. */
+int sfmloc_context_create_sharing(sfmloc_map *map, sfmloc_context *lender, sfmloc_context **out);
+int sfmloc_gang_end(sfmloc_context *const *ctxs, uint32_t n);
+int sfmloc_gang_counters(sfmloc_context *lead_ctx, uint64_t *launches, uint64_t *gang_launches);
 /* Sharded BoW shortlist (selectViewByBoF over a map split by view).  _shard_bow_keys ranks this shard's
  * views against the query's BoW vector (query_bow, or NULL for the resident one) and writes its knn best to keys_dev
  * [knn] as sortable 64-bit keys (float32 distance bits << 32 | view id; ~0 = padding).  The caller all-gathers the key

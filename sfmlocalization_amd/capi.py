@@ -119,9 +119,36 @@ SYMBOLS = [
     "sfmloc_undistorter_apply",
     "sfmloc_query_set_bow", "sfmloc_context_signal", "sfmloc_context_wait", "sfmloc_shard_bow_keys",
     "sfmloc_geometric_read_pairs", "sfmloc_shard_begin_bow", "sfmloc_packed_bytes", "sfmloc_shard_export_packed", "sfmloc_merge_begin_packed",
+    "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing",
 ]
 
 _bound = False
+
+GANG_MAX = 32
+
+
+class gang:
+    """`with gang(ctxs):` -- sfmloc_gang_begin / _end: the asynchronous calls made on these contexts (<= GANG_MAX, one
+    map) inside the block record their launches, and leaving it issues them as ONE launch per kernel for all members."""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+        self._arr = (C.c_void_p * len(self.ctxs))(*[c._h for c in self.ctxs])
+
+    def __enter__(self):
+        _check(_L().sfmloc_gang_begin(self._arr, len(self.ctxs)))
+        return self
+
+    def __exit__(self, *exc):
+        _check(_L().sfmloc_gang_end(self._arr, len(self.ctxs)))
+        return False
+
+
+def gang_counters(lead_ctx):
+    """(launches issued by this leader's sessions, of which gang launches with more than one member)"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    _check(_L().sfmloc_gang_counters(lead_ctx._h, C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
 
 
 def _L():
@@ -696,8 +723,8 @@ class Map:
         k = pose.n_inliers if pose.ok else 0
         return pose, pq[:k].copy(), pl[:k].copy()
 
-    def context(self):
-        return Context(self)
+    def context(self, share=None):
+        return Context(self, share)
 
     def bow_select(self, query_bow, k, cand_views=None):
         """sfmloc_bow_select (selectViewByBoF): -> ascending view-table indices of the k nearest .bow vectors."""
@@ -869,11 +896,15 @@ class Akaze:
 class Context:
     """sfmloc_context: one in-flight query (stream + workspace) on a map; begin() is asynchronous."""
 
-    def __init__(self, m):
+    def __init__(self, m, share=None):
         self._h = None
         self.map = m
         h = C.c_void_p()
-        _check(_L().sfmloc_context_create(m._h, C.byref(h)))
+        if share is None:
+            _check(_L().sfmloc_context_create(m._h, C.byref(h)))
+        else:       # sfmloc_context_create_sharing: no stream of its own, work goes to `share`'s
+            _check(_L().sfmloc_context_create_sharing(m._h, share._h, C.byref(h)))
+            self._lender = share
         self._h = h
         m._children.add(self)
 

@@ -710,24 +710,30 @@ __device__ bool fmatrix_filter_view(const FFilterArgs &A, uint32_t v, Store st, 
   return true;
 }
 
-__global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
-  extern __shared__ unsigned char smem_raw[];
-  FShared &S = *reinterpret_cast<FShared *>(smem_raw);
-  const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
-  const int m = (int)A.put_count[v];
-  if (m <= A.skip_le) return;
-  if (!fmatrix_filter_view(A, v, FStoreLds{&S}, S.small, kFMaxM)) {
-    // more matches than the LDS form holds: queue the view for k_fmatrix_large
-    if (threadIdx.x == 0) {
-      A.geo_count[v] = 0;
-      if (A.large_list) {
-        const uint32_t slot = atomicAdd(A.large_count, 1u);
-        A.large_list[slot] = v;
-      } else {
-        atomicOr(A.status, 1);
+struct FmatrixFilterBody {
+  static constexpr int kGangThreads = kThreads;
+  static __device__ __forceinline__ void run(FFilterArgs A) {
+    extern __shared__ unsigned char smem_raw[];
+    FShared &S = *reinterpret_cast<FShared *>(smem_raw);
+    const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
+    const int m = (int)A.put_count[v];
+    if (m <= A.skip_le) return;
+    if (!fmatrix_filter_view(A, v, FStoreLds{&S}, S.small, kFMaxM)) {
+      // more matches than the LDS form holds: queue the view for k_fmatrix_large
+      if (threadIdx.x == 0) {
+        A.geo_count[v] = 0;
+        if (A.large_list) {
+          const uint32_t slot = atomicAdd(A.large_count, 1u);
+          A.large_list[slot] = v;
+        } else {
+          atomicOr(A.status, 1);
+        }
       }
     }
   }
+};
+__global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
+  FmatrixFilterBody::run(A);
 }
 
 // The views k_fmatrix_filter queued (more than kFMaxM putative matches): kFLargeSlots persistent workgroups, each
@@ -740,20 +746,26 @@ struct FLargeArgs {
   float *logc_n, *logc_k;
   int slot_m;  // matches one slot holds: a power of two >= the map's longest view, at most kFLargeMaxM
 };
-__global__ __launch_bounds__(kThreads) void k_fmatrix_large(FFilterArgs A, FLargeArgs W) {
-  __shared__ FSmall S;
-  const uint32_t n = *A.large_count;
-  const size_t o = (size_t)blockIdx.x * W.slot_m;
-  FStoreGlobal st{W.key + o, W.idx + o, W.vec_index + o, W.best_inl + o, W.logc_n + (size_t)blockIdx.x * (W.slot_m + 1),
-                  W.logc_k + (size_t)blockIdx.x * (W.slot_m + 1)};
-  for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
-    const uint32_t v = A.large_list[t];
-    if (!fmatrix_filter_view(A, v, st, S, W.slot_m) && threadIdx.x == 0) {
-      A.geo_count[v] = 0;
-      atomicOr(A.status, 1);  // more than 65 536 matches in one view
+struct FmatrixLargeBody {
+  static constexpr int kGangThreads = kThreads;
+  static __device__ __forceinline__ void run(FFilterArgs A, FLargeArgs W) {
+    __shared__ FSmall S;
+    const uint32_t n = *A.large_count;
+    const size_t o = (size_t)blockIdx.x * W.slot_m;
+    FStoreGlobal st{W.key + o, W.idx + o, W.vec_index + o, W.best_inl + o, W.logc_n + (size_t)blockIdx.x * (W.slot_m + 1),
+                    W.logc_k + (size_t)blockIdx.x * (W.slot_m + 1)};
+    for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+      const uint32_t v = A.large_list[t];
+      if (!fmatrix_filter_view(A, v, st, S, W.slot_m) && threadIdx.x == 0) {
+        A.geo_count[v] = 0;
+        atomicOr(A.status, 1);  // more than 65 536 matches in one view
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
+};
+__global__ __launch_bounds__(kThreads) void k_fmatrix_large(FFilterArgs A, FLargeArgs W) {
+  FmatrixLargeBody::run(A, W);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -820,290 +832,296 @@ __device__ void bitonic_sort_wave(uint64_t *kw, uint32_t *iw, int P) {
   }
 }
 
-__global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
-  extern __shared__ unsigned char smem_raw[];
-  F2Shared &S = *reinterpret_cast<F2Shared *>(smem_raw);
-  const int tid = threadIdx.x;
-  const int wv = tid >> 6, lane = tid & 63;
-  STAMP_F_DECL;
-  STAMP_F(1);
-  const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
-  if (A.merge.enabled) {  // K2 for this view (chain_device.h), by one wave; the others wait for its lists
-    if (wv == 0) merge_ratio_masked_view(A.merge, blockIdx.x, (uint32_t)lane);
-    __syncthreads();
-  }
-  const int m = (int)A.put_count[v];
-  const uint32_t off = A.view_off[v];
-  constexpr int s = 7;
-  if (m > kF2MaxM) return;  // k_fmatrix_filter handles this view
-  if (m < A.min_putative || m <= s) {  // localization.cpp:408-415 ; ACRANSAC: nData <= sizeSample
-    if (tid == 0) A.geo_count[v] = 0;
-    return;
-  }
-  // NormalizePoints(x, w, h) for both images
-  const int w1 = (int)A.view_wh[2 * v], h1 = (int)A.view_wh[2 * v + 1];
-  const int w2 = (int)A.qw, h2 = (int)A.qh;
-  const double s1 = 1.0 / sqrt((double)(w1 * h1)), s2 = 1.0 / sqrt((double)(w2 * h2));
-  const double t1x = -0.5 * (double)w1 * s1, t1y = -0.5 * (double)h1 * s1;
-  const double t2x = -0.5 * (double)w2 * s2, t2y = -0.5 * (double)h2 * s2;
-  const double Dg = sqrt((double)w2 * (double)w2 + (double)h2 * (double)h2);
-  const double Ar = (double)w2 * (double)h2;
-  const double logalpha0 = det_log10(2.0 * Dg / Ar / s2);
-  const double max_thr = (A.precision * A.precision) * s2 * s2;
-  const double loge0 = det_log10(3.0 * (double)(m - s));
-  const uint32_t stream = A.view_id[v];
-  const int P = next_pow2(m);
-
-  for (int p = tid; p < m; p += kF2Threads) {
-    const uint32_t i = A.match_i[off + p];
-    const uint32_t j = A.match_key[off + p] & 0xFFFFu;
-    const float2 a = A.map_kpt[off + i];
-    const float2 b = A.q_kpt6[j];
-    S.pts[0][p] = s1 * (double)a.x + t1x;
-    S.pts[1][p] = s1 * (double)a.y + t1y;
-    S.pts[2][p] = s2 * (double)b.x + t2x;
-    S.pts[3][p] = s2 * (double)b.y + t2y;
-  }
-  // logcombi tables (logcombi_tables_block is written for 256 threads); pre_models is free until the first batch
-  logc_n_block(m, A.L10, &S.pre_models[0][0], S.logc_n, kF2Threads);
-  for (int q = tid; q <= m; q += kF2Threads) {
-    float val = 0.0f;
-    if (s < q) {
-      int k = s;
-      if (q - k < k) k = q - k;
-      double r = 0.0;
-      for (int i = 1; i <= k; ++i) r += A.L10[q - i + 1] - A.L10[i];
-      val = (float)r;
-    }
-    S.logc_k[q] = val;
-  }
-  __syncthreads();
-  STAMP_F(2);  // prelude done (value: m in the low bits is not needed; the tool reads put_count)
-
-  // (the lambdas below must not capture the kernel-argument struct: that would put all of it on the stack)
-  const uint64_t seed = A.seed;
-  F2Shared *const Sp = &S;
-  // this wave: sample iteration `it`, solve, store the models at `models` / the count at *nm_out
-  auto wave_solve = [Sp, seed, stream, lane](const int32_t *vec_index, int n_index, long it, double *models,
-                                             int *nm_out) {
-    F2Shared &S = *Sp;
-    int32_t smp[7];
-    ac_sample<7>(vec_index, n_index, seed, STAGE_FMATRIX, stream, (uint32_t)it, smp);
-    const int r = lane / 9;
-    int pidx = smp[0];
-#pragma unroll
-    for (int q = 1; q < 7; ++q)
-      if (r == q) pidx = smp[q];
-    double f = 0.0;
-    const int nm = wave_seven_point(S.pts[0][pidx], S.pts[1][pidx], S.pts[2][pidx], S.pts[3][pidx], &f);
-    if (lane < 9 * nm) models[lane] = f;
-    if (lane == 0) *nm_out = nm;
-  };
-  // this wave: residuals of model M over all matches, sorted in registers, bestNFA; the sorted match indices go
-  // to the wave's LDS segment (S.idx[wv]) for whoever needs the inlier list afterwards
-  auto eval_e = [Sp, lane, wv, m, max_thr, logalpha0, loge0](const double *Mp, auto e_tag) -> NfaBest {
-    constexpr int E = decltype(e_tag)::value;
-    F2Shared &S = *Sp;
-    double M[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) M[q] = Mp[q];
-    uint64_t key[E];
-    uint32_t idx[E];
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-      const int p = (r << 6) + lane;
-      uint64_t kv = ~0ull;
-      if (p < m) kv = d2u(err_fmatrix(M, S.pts[0][p], S.pts[1][p], S.pts[2][p], S.pts[3][p]));
-      key[r] = kv;
-      idx[r] = (uint32_t)p;
-    }
-    uint32_t *iw = S.idx[wv];
-    wave_sort_fast<E>(key, idx, iw);
-#pragma unroll
-    for (int r = 0; r < E; ++r) iw[(r << 6) + lane] = idx[r];
-    return best_nfa_regs<E>(key, m, 7, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k);
-  };
-  auto wave_eval = [&eval_e, P](const double *Mp) -> NfaBest {
-    switch (P >> 6) {
-      case 1: return eval_e(Mp, std::integral_constant<int, 1>{});
-      case 2: return eval_e(Mp, std::integral_constant<int, 2>{});
-      case 4: return eval_e(Mp, std::integral_constant<int, 4>{});
-      default: return eval_e(Mp, std::integral_constant<int, 8>{});
-    }
-  };
-
-  // replicated scalar state (every thread holds the same values)
-  double min_nfa = pos_inf();
-  int n_in = 0;
-  long n_iter = A.n_iter;
-  long n_reserve = n_iter / 10;
-  n_iter -= n_reserve;
-  bool identity = true;
-  bool inl_valid = true;  // S.best_inl holds the inliers of the best model (vacuously: n_in == 0)
-  int n_index = m;
-  long iter = 0;
-
-  // wave 0 rebuilds the inlier list of S.best_model into best_inl (and vec_index when `to_index`)
-  auto rebuild_inliers = [&wave_eval, Sp, wv, lane, &n_in](bool to_index) {
-    F2Shared &S = *Sp;
-    __syncthreads();
-    if (wv == 0) {
-      (void)wave_eval(S.best_model);
-      wave_lds_sync();
-      for (int p = lane; p < n_in; p += 64) {
-        const int32_t q = (int32_t)S.idx[0][p];
-        S.best_inl[p] = q;
-        if (to_index) S.vec_index[p] = q;
-      }
-    }
-    __syncthreads();
-  };
-
-  while (iter < n_iter) {
-    if (identity) {
-      const int B = (int)((n_iter - iter < (long)kF2Batch) ? (n_iter - iter) : (long)kF2Batch);
-      __syncthreads();  // pre_* / res_* of the previous batch are no longer read
-      for (int b = wv; b < B; b += kF2Waves) wave_solve(nullptr, m, iter + b, S.pre_models[b], &S.pre_nm[b]);
+struct FmatrixFastBody {
+  static constexpr int kGangThreads = kF2Threads;
+  static __device__ __forceinline__ void run(FFilterArgs A) {
+    extern __shared__ unsigned char smem_raw[];
+    F2Shared &S = *reinterpret_cast<F2Shared *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, lane = tid & 63;
+    STAMP_F_DECL;
+    STAMP_F(1);
+    const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
+    if (A.merge.enabled) {  // K2 for this view (chain_device.h), by one wave; the others wait for its lists
+      if (wv == 0) merge_ratio_masked_view(A.merge, blockIdx.x, (uint32_t)lane);
       __syncthreads();
-      STAMP_F(3);  // speculative solves done
-      // flattened model list in iteration order
-      if (tid == 0) {
-        int n = 0;
-        for (int b = 0; b < B; ++b) {
-          for (int k = 0; k < S.pre_nm[b]; ++k) {
-            S.flat_b[n] = (uint8_t)b;
-            S.flat_k[n] = (uint8_t)k;
-            ++n;
-          }
-          S.iter_end[b] = n;
+    }
+    const int m = (int)A.put_count[v];
+    const uint32_t off = A.view_off[v];
+    constexpr int s = 7;
+    if (m > kF2MaxM) return;  // k_fmatrix_filter handles this view
+    if (m < A.min_putative || m <= s) {  // localization.cpp:408-415 ; ACRANSAC: nData <= sizeSample
+      if (tid == 0) A.geo_count[v] = 0;
+      return;
+    }
+    // NormalizePoints(x, w, h) for both images
+    const int w1 = (int)A.view_wh[2 * v], h1 = (int)A.view_wh[2 * v + 1];
+    const int w2 = (int)A.qw, h2 = (int)A.qh;
+    const double s1 = 1.0 / sqrt((double)(w1 * h1)), s2 = 1.0 / sqrt((double)(w2 * h2));
+    const double t1x = -0.5 * (double)w1 * s1, t1y = -0.5 * (double)h1 * s1;
+    const double t2x = -0.5 * (double)w2 * s2, t2y = -0.5 * (double)h2 * s2;
+    const double Dg = sqrt((double)w2 * (double)w2 + (double)h2 * (double)h2);
+    const double Ar = (double)w2 * (double)h2;
+    const double logalpha0 = det_log10(2.0 * Dg / Ar / s2);
+    const double max_thr = (A.precision * A.precision) * s2 * s2;
+    const double loge0 = det_log10(3.0 * (double)(m - s));
+    const uint32_t stream = A.view_id[v];
+    const int P = next_pow2(m);
+
+    for (int p = tid; p < m; p += kF2Threads) {
+      const uint32_t i = A.match_i[off + p];
+      const uint32_t j = A.match_key[off + p] & 0xFFFFu;
+      const float2 a = A.map_kpt[off + i];
+      const float2 b = A.q_kpt6[j];
+      S.pts[0][p] = s1 * (double)a.x + t1x;
+      S.pts[1][p] = s1 * (double)a.y + t1y;
+      S.pts[2][p] = s2 * (double)b.x + t2x;
+      S.pts[3][p] = s2 * (double)b.y + t2y;
+    }
+    // logcombi tables (logcombi_tables_block is written for 256 threads); pre_models is free until the first batch
+    logc_n_block(m, A.L10, &S.pre_models[0][0], S.logc_n, kF2Threads);
+    for (int q = tid; q <= m; q += kF2Threads) {
+      float val = 0.0f;
+      if (s < q) {
+        int k = s;
+        if (q - k < k) k = q - k;
+        double r = 0.0;
+        for (int i = 1; i <= k; ++i) r += A.L10[q - i + 1] - A.L10[i];
+        val = (float)r;
+      }
+      S.logc_k[q] = val;
+    }
+    __syncthreads();
+    STAMP_F(2);  // prelude done (value: m in the low bits is not needed; the tool reads put_count)
+
+    // (the lambdas below must not capture the kernel-argument struct: that would put all of it on the stack)
+    const uint64_t seed = A.seed;
+    F2Shared *const Sp = &S;
+    // this wave: sample iteration `it`, solve, store the models at `models` / the count at *nm_out
+    auto wave_solve = [Sp, seed, stream, lane](const int32_t *vec_index, int n_index, long it, double *models,
+                                               int *nm_out) {
+      F2Shared &S = *Sp;
+      int32_t smp[7];
+      ac_sample<7>(vec_index, n_index, seed, STAGE_FMATRIX, stream, (uint32_t)it, smp);
+      const int r = lane / 9;
+      int pidx = smp[0];
+#pragma unroll
+      for (int q = 1; q < 7; ++q)
+        if (r == q) pidx = smp[q];
+      double f = 0.0;
+      const int nm = wave_seven_point(S.pts[0][pidx], S.pts[1][pidx], S.pts[2][pidx], S.pts[3][pidx], &f);
+      if (lane < 9 * nm) models[lane] = f;
+      if (lane == 0) *nm_out = nm;
+    };
+    // this wave: residuals of model M over all matches, sorted in registers, bestNFA; the sorted match indices go
+    // to the wave's LDS segment (S.idx[wv]) for whoever needs the inlier list afterwards
+    auto eval_e = [Sp, lane, wv, m, max_thr, logalpha0, loge0](const double *Mp, auto e_tag) -> NfaBest {
+      constexpr int E = decltype(e_tag)::value;
+      F2Shared &S = *Sp;
+      double M[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) M[q] = Mp[q];
+      uint64_t key[E];
+      uint32_t idx[E];
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const int p = (r << 6) + lane;
+        uint64_t kv = ~0ull;
+        if (p < m) kv = d2u(err_fmatrix(M, S.pts[0][p], S.pts[1][p], S.pts[2][p], S.pts[3][p]));
+        key[r] = kv;
+        idx[r] = (uint32_t)p;
+      }
+      uint32_t *iw = S.idx[wv];
+      wave_sort_fast<E>(key, idx, iw);
+#pragma unroll
+      for (int r = 0; r < E; ++r) iw[(r << 6) + lane] = idx[r];
+      return best_nfa_regs<E>(key, m, 7, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k);
+    };
+    auto wave_eval = [&eval_e, P](const double *Mp) -> NfaBest {
+      switch (P >> 6) {
+        case 1: return eval_e(Mp, std::integral_constant<int, 1>{});
+        case 2: return eval_e(Mp, std::integral_constant<int, 2>{});
+        case 4: return eval_e(Mp, std::integral_constant<int, 4>{});
+        default: return eval_e(Mp, std::integral_constant<int, 8>{});
+      }
+    };
+
+    // replicated scalar state (every thread holds the same values)
+    double min_nfa = pos_inf();
+    int n_in = 0;
+    long n_iter = A.n_iter;
+    long n_reserve = n_iter / 10;
+    n_iter -= n_reserve;
+    bool identity = true;
+    bool inl_valid = true;  // S.best_inl holds the inliers of the best model (vacuously: n_in == 0)
+    int n_index = m;
+    long iter = 0;
+
+    // wave 0 rebuilds the inlier list of S.best_model into best_inl (and vec_index when `to_index`)
+    auto rebuild_inliers = [&wave_eval, Sp, wv, lane, &n_in](bool to_index) {
+      F2Shared &S = *Sp;
+      __syncthreads();
+      if (wv == 0) {
+        (void)wave_eval(S.best_model);
+        wave_lds_sync();
+        for (int p = lane; p < n_in; p += 64) {
+          const int32_t q = (int32_t)S.idx[0][p];
+          S.best_inl[p] = q;
+          if (to_index) S.vec_index[p] = q;
         }
       }
       __syncthreads();
-      const int total = S.iter_end[B - 1];
-      // evaluate the models eight per round; before each round replay the iterations whose models are all done,
-      // and stop as soon as one of them ends the uniform phase
-      int done = 0;    // models evaluated so far
-      int b_done = 0;  // iterations replayed so far
-      bool stop = false;
-      for (;;) {
-        while (b_done < B && S.iter_end[b_done] <= done) {
-          const int b = b_done;
-          bool better = false;
-          int bk = -1;
-          for (int k = 0; k < S.pre_nm[b]; ++k)
-            if (S.res_nfa[b][k] < min_nfa) {
-              better = true;
-              min_nfa = S.res_nfa[b][k];
-              n_in = S.res_k[b][k];
-              bk = k;
+    };
+
+    while (iter < n_iter) {
+      if (identity) {
+        const int B = (int)((n_iter - iter < (long)kF2Batch) ? (n_iter - iter) : (long)kF2Batch);
+        __syncthreads();  // pre_* / res_* of the previous batch are no longer read
+        for (int b = wv; b < B; b += kF2Waves) wave_solve(nullptr, m, iter + b, S.pre_models[b], &S.pre_nm[b]);
+        __syncthreads();
+        STAMP_F(3);  // speculative solves done
+        // flattened model list in iteration order
+        if (tid == 0) {
+          int n = 0;
+          for (int b = 0; b < B; ++b) {
+            for (int k = 0; k < S.pre_nm[b]; ++k) {
+              S.flat_b[n] = (uint8_t)b;
+              S.flat_k[n] = (uint8_t)k;
+              ++n;
             }
-          if (better) {
-            inl_valid = false;
-            if (tid < 9) S.best_model[tid] = S.pre_models[b][9 * bk + tid];
-          }
-          ++b_done;
-          const long it = iter + b;
-          if ((better && min_nfa < 0.0) || (it + 1 == n_iter && n_reserve)) {
-            if (n_in == 0) {
-              n_iter++;
-              n_reserve--;  // the iteration budget moved: close this batch here
-            } else {
-              rebuild_inliers(true);
-              inl_valid = true;
-              n_index = n_in;
-              identity = false;
-              if (n_reserve) {
-                n_iter = it + 1 + n_reserve;
-                n_reserve = 0;
-              }
-            }
-            stop = true;
-            break;
-          }
-        }
-        if (stop || b_done >= B) break;
-        const int mi = done + wv;
-        if (mi < total) {
-          const int bb = S.flat_b[mi], kk = S.flat_k[mi];
-          const NfaBest r = wave_eval(&S.pre_models[bb][9 * kk]);
-          if (lane == 0) {
-            S.res_nfa[bb][kk] = r.nfa;
-            S.res_k[bb][kk] = r.k;
+            S.iter_end[b] = n;
           }
         }
         __syncthreads();
-        STAMP_F(4);  // one evaluation round done
-        done = (done + kF2Waves < total) ? done + kF2Waves : total;
-      }
-      STAMP_F(5);  // uniform batch closed (incl. the inlier rebuild when the phase ended)
-      iter += b_done;
-    } else {
-      __syncthreads();
-      if (wv == 0) wave_solve(S.vec_index, n_index, iter, S.pre_models[0], &S.pre_nm[0]);
-      __syncthreads();
-      STAMP_F(6);  // sequential iteration: solved
-      const int nm = S.pre_nm[0];
-      if (wv < nm) {
-        const NfaBest r = wave_eval(&S.pre_models[0][9 * wv]);
-        if (lane == 0) {
-          S.res_nfa[0][wv] = r.nfa;
-          S.res_k[0][wv] = r.k;
-        }
-      }
-      __syncthreads();
-      bool better = false;
-      int bk = -1;
-      for (int k = 0; k < nm; ++k)
-        if (S.res_nfa[0][k] < min_nfa) {
-          better = true;
-          min_nfa = S.res_nfa[0][k];
-          n_in = S.res_k[0][k];
-          bk = k;
-        }
-      if (better) {
-        for (int p = tid; p < n_in; p += kF2Threads) S.best_inl[p] = (int32_t)S.idx[bk][p];
-        inl_valid = true;
-        if (tid < 9) S.best_model[tid] = S.pre_models[0][9 * bk + tid];  // read again only behind a barrier
-      }
-      if ((better && min_nfa < 0.0) || (iter + 1 == n_iter && n_reserve)) {
-        if (n_in == 0) {
-          n_iter++;
-          n_reserve--;
-        } else {
+        const int total = S.iter_end[B - 1];
+        // evaluate the models eight per round; before each round replay the iterations whose models are all done,
+        // and stop as soon as one of them ends the uniform phase
+        int done = 0;    // models evaluated so far
+        int b_done = 0;  // iterations replayed so far
+        bool stop = false;
+        for (;;) {
+          while (b_done < B && S.iter_end[b_done] <= done) {
+            const int b = b_done;
+            bool better = false;
+            int bk = -1;
+            for (int k = 0; k < S.pre_nm[b]; ++k)
+              if (S.res_nfa[b][k] < min_nfa) {
+                better = true;
+                min_nfa = S.res_nfa[b][k];
+                n_in = S.res_k[b][k];
+                bk = k;
+              }
+            if (better) {
+              inl_valid = false;
+              if (tid < 9) S.best_model[tid] = S.pre_models[b][9 * bk + tid];
+            }
+            ++b_done;
+            const long it = iter + b;
+            if ((better && min_nfa < 0.0) || (it + 1 == n_iter && n_reserve)) {
+              if (n_in == 0) {
+                n_iter++;
+                n_reserve--;  // the iteration budget moved: close this batch here
+              } else {
+                rebuild_inliers(true);
+                inl_valid = true;
+                n_index = n_in;
+                identity = false;
+                if (n_reserve) {
+                  n_iter = it + 1 + n_reserve;
+                  n_reserve = 0;
+                }
+              }
+              stop = true;
+              break;
+            }
+          }
+          if (stop || b_done >= B) break;
+          const int mi = done + wv;
+          if (mi < total) {
+            const int bb = S.flat_b[mi], kk = S.flat_k[mi];
+            const NfaBest r = wave_eval(&S.pre_models[bb][9 * kk]);
+            if (lane == 0) {
+              S.res_nfa[bb][kk] = r.nfa;
+              S.res_k[bb][kk] = r.k;
+            }
+          }
           __syncthreads();
-          for (int p = tid; p < n_in; p += kF2Threads) S.vec_index[p] = S.best_inl[p];
-          n_index = n_in;
-          identity = false;
-          if (n_reserve) {
-            n_iter = iter + 1 + n_reserve;
-            n_reserve = 0;
+          STAMP_F(4);  // one evaluation round done
+          done = (done + kF2Waves < total) ? done + kF2Waves : total;
+        }
+        STAMP_F(5);  // uniform batch closed (incl. the inlier rebuild when the phase ended)
+        iter += b_done;
+      } else {
+        __syncthreads();
+        if (wv == 0) wave_solve(S.vec_index, n_index, iter, S.pre_models[0], &S.pre_nm[0]);
+        __syncthreads();
+        STAMP_F(6);  // sequential iteration: solved
+        const int nm = S.pre_nm[0];
+        if (wv < nm) {
+          const NfaBest r = wave_eval(&S.pre_models[0][9 * wv]);
+          if (lane == 0) {
+            S.res_nfa[0][wv] = r.nfa;
+            S.res_k[0][wv] = r.k;
           }
         }
+        __syncthreads();
+        bool better = false;
+        int bk = -1;
+        for (int k = 0; k < nm; ++k)
+          if (S.res_nfa[0][k] < min_nfa) {
+            better = true;
+            min_nfa = S.res_nfa[0][k];
+            n_in = S.res_k[0][k];
+            bk = k;
+          }
+        if (better) {
+          for (int p = tid; p < n_in; p += kF2Threads) S.best_inl[p] = (int32_t)S.idx[bk][p];
+          inl_valid = true;
+          if (tid < 9) S.best_model[tid] = S.pre_models[0][9 * bk + tid];  // read again only behind a barrier
+        }
+        if ((better && min_nfa < 0.0) || (iter + 1 == n_iter && n_reserve)) {
+          if (n_in == 0) {
+            n_iter++;
+            n_reserve--;
+          } else {
+            __syncthreads();
+            for (int p = tid; p < n_in; p += kF2Threads) S.vec_index[p] = S.best_inl[p];
+            n_index = n_in;
+            identity = false;
+            if (n_reserve) {
+              n_iter = iter + 1 + n_reserve;
+              n_reserve = 0;
+            }
+          }
+        }
+        ++iter;
+        STAMP_F(7);  // sequential iteration: evaluated + replayed
       }
-      ++iter;
-      STAMP_F(7);  // sequential iteration: evaluated + replayed
     }
-  }
-  __syncthreads();
-  STAMP_F(8);
-  if (min_nfa >= 0.0) n_in = 0;
-  if ((double)n_in > 7 * 2.5) {
-    if (!inl_valid) rebuild_inliers(false);
-    for (int p = tid; p < n_in; p += kF2Threads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
-    if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
     __syncthreads();
-    if (A.geo_model && tid == 0) {  // errorMax = the residual of the last inlier (the list ascends by residual)
-      const int pl = S.best_inl[n_in - 1];
-      double Mb[9];
-      for (int q = 0; q < 9; ++q) Mb[q] = S.best_model[q];
-      double *gm = A.geo_model + 10 * (size_t)v;
-      for (int q = 0; q < 9; ++q) gm[q] = Mb[q];
-      gm[9] = err_fmatrix(Mb, S.pts[0][pl], S.pts[1][pl], S.pts[2][pl], S.pts[3][pl]);
+    STAMP_F(8);
+    if (min_nfa >= 0.0) n_in = 0;
+    if ((double)n_in > 7 * 2.5) {
+      if (!inl_valid) rebuild_inliers(false);
+      for (int p = tid; p < n_in; p += kF2Threads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
+      if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
+      __syncthreads();
+      if (A.geo_model && tid == 0) {  // errorMax = the residual of the last inlier (the list ascends by residual)
+        const int pl = S.best_inl[n_in - 1];
+        double Mb[9];
+        for (int q = 0; q < 9; ++q) Mb[q] = S.best_model[q];
+        double *gm = A.geo_model + 10 * (size_t)v;
+        for (int q = 0; q < 9; ++q) gm[q] = Mb[q];
+        gm[9] = err_fmatrix(Mb, S.pts[0][pl], S.pts[1][pl], S.pts[2][pl], S.pts[3][pl]);
+      }
+    } else if (tid == 0) {
+      A.geo_count[v] = 0;
     }
-  } else if (tid == 0) {
-    A.geo_count[v] = 0;
+    STAMP_F(9);
   }
-  STAMP_F(9);
+};
+__global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
+  FmatrixFastBody::run(A);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1120,125 +1138,153 @@ __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
 // have, and a shard's exchange shrinks to its winners.
 constexpr uint16_t kNoDist = 0xFFFFu;
 
-__global__ __launch_bounds__(256) void k_emit_min(const uint32_t *view_sel, uint32_t n_sel, const uint32_t *view_off,
-                                                  const uint32_t *view_id, const uint32_t *put_count,
-                                                  const uint32_t *match_i, const uint32_t *match_key,
-                                                  const uint32_t *geo_count, const uint32_t *geo_idx,
-                                                  const uint32_t *geo_j /*null: geo_idx indexes the putative list; else
-                                                                          (geo_idx, geo_j) = (map feature, query feature)
-                                                                          of a guided match*/,
-                                                  const int32_t *row_landmark, unsigned long long *best64,
-                                                  uint16_t *geo_dist, uint32_t min_putative, uint32_t *view_stats) {
-  // one workgroup (four waves) per selected view: the stage is a chain of dependent loads per candidate, so the waves
-  // take 64 candidates each side by side instead of one wave walking them 64 at a time
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gw = blockIdx.x;
-  if (gw >= n_sel) return;
-  const uint32_t v = view_sel ? view_sel[gw] : gw;
-  const uint32_t ng = geo_count[v];
-  if (threadIdx.x == 0) {  // the counts the reference prints (localization.cpp:416,458)
-    if (put_count[v] >= min_putative) atomicAdd(&view_stats[0], 1u);
-    if (ng > 0) atomicAdd(&view_stats[1], 1u);
-  }
-  if (ng == 0) return;
-  const uint32_t off = view_off[v];
-  const uint32_t np = put_count[v];
-  // the view's putative keys in LDS (one segment per wave): the "last match with the same query feature" search
-  // below is a dependent backward scan, far too slow against L2
-  __shared__ uint32_t keys[kFMaxM];
-  const bool staged = np <= (uint32_t)kFMaxM;
-  if (staged) {
-    for (uint32_t k = threadIdx.x; k < np; k += 256) keys[k] = match_key[off + k];
-    __syncthreads();
-  }
-  const uint64_t vkey = (uint64_t)(view_id[v] & 0xFFFFFFu) << 24;
-  for (uint32_t p0 = (threadIdx.x >> 6) * 64; p0 < ng; p0 += 256) {
-    const uint32_t p = p0 + lane;
-    if (p >= ng) continue;
-    uint32_t i, j;
-    if (geo_j) {
-      i = geo_idx[off + p];
-      j = geo_j[off + p];
-    } else {
-      const uint32_t pp = geo_idx[off + p];
-      i = match_i[off + pp];
-      j = match_key[off + pp] & 0xFFFFu;
+struct EmitMinBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const uint32_t *view_sel, uint32_t n_sel, const uint32_t *view_off,
+                                          const uint32_t *view_id, const uint32_t *put_count,
+                                          const uint32_t *match_i, const uint32_t *match_key,
+                                          const uint32_t *geo_count, const uint32_t *geo_idx,
+                                          const uint32_t *geo_j /*null: geo_idx indexes the putative list; else
+                                                                  (geo_idx, geo_j) = (map feature, query feature)
+                                                                  of a guided match*/,
+                                          const int32_t *row_landmark, unsigned long long *best64,
+                                          uint16_t *geo_dist, uint32_t min_putative, uint32_t *view_stats) {
+    // one workgroup (four waves) per selected view: the stage is a chain of dependent loads per candidate, so the waves
+    // take 64 candidates each side by side instead of one wave walking them 64 at a time
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x;
+    if (gw >= n_sel) return;
+    const uint32_t v = view_sel ? view_sel[gw] : gw;
+    const uint32_t ng = geo_count[v];
+    if (threadIdx.x == 0) {  // the counts the reference prints (localization.cpp:416,458)
+      if (put_count[v] >= min_putative) atomicAdd(&view_stats[0], 1u);
+      if (ng > 0) atomicAdd(&view_stats[1], 1u);
     }
-    uint16_t dist16 = kNoDist;
-    if (row_landmark[off + i] >= 0) {
-      for (int32_t k = (int32_t)np - 1; k >= 0; --k) {  // last putative match with the same query feature
-        const uint32_t kk = staged ? keys[k] : match_key[off + k];
-        if ((kk & 0xFFFFu) == j) {
-          dist16 = (uint16_t)(kk >> 16);
-          break;
-        }
+    if (ng == 0) return;
+    const uint32_t off = view_off[v];
+    const uint32_t np = put_count[v];
+    // the view's putative keys in LDS (one segment per wave): the "last match with the same query feature" search
+    // below is a dependent backward scan, far too slow against L2
+    __shared__ uint32_t keys[kFMaxM];
+    const bool staged = np <= (uint32_t)kFMaxM;
+    if (staged) {
+      for (uint32_t k = threadIdx.x; k < np; k += 256) keys[k] = match_key[off + k];
+      __syncthreads();
+    }
+    const uint64_t vkey = (uint64_t)(view_id[v] & 0xFFFFFFu) << 24;
+    for (uint32_t p0 = (threadIdx.x >> 6) * 64; p0 < ng; p0 += 256) {
+      const uint32_t p = p0 + lane;
+      if (p >= ng) continue;
+      uint32_t i, j;
+      if (geo_j) {
+        i = geo_idx[off + p];
+        j = geo_j[off + p];
+      } else {
+        const uint32_t pp = geo_idx[off + p];
+        i = match_i[off + pp];
+        j = match_key[off + pp] & 0xFFFFu;
       }
-      // featDist has no entry for a query feature no putative match of this view hit (only possible for guided
-      // matches): matchProviderToMatchSet then skips the match (SfMDataUtils.cpp:105-106) -> dist16 stays kNoDist
+      uint16_t dist16 = kNoDist;
+      if (row_landmark[off + i] >= 0) {
+        for (int32_t k = (int32_t)np - 1; k >= 0; --k) {  // last putative match with the same query feature
+          const uint32_t kk = staged ? keys[k] : match_key[off + k];
+          if ((kk & 0xFFFFu) == j) {
+            dist16 = (uint16_t)(kk >> 16);
+            break;
+          }
+        }
+        // featDist has no entry for a query feature no putative match of this view hit (only possible for guided
+        // matches): matchProviderToMatchSet then skips the match (SfMDataUtils.cpp:105-106) -> dist16 stays kNoDist
+      }
+      geo_dist[off + p] = dist16;
+      if (dist16 != kNoDist)
+        atomicMin(&best64[j], ((unsigned long long)dist16 << 48) | vkey | (unsigned long long)(p & 0xFFFFFFu));
     }
-    geo_dist[off + p] = dist16;
-    if (dist16 != kNoDist)
-      atomicMin(&best64[j], ((unsigned long long)dist16 << 48) | vkey | (unsigned long long)(p & 0xFFFFFFu));
   }
+};
+__global__ __launch_bounds__(256) void k_emit_min(const uint32_t *view_sel, uint32_t n_sel, const uint32_t *view_off,
+                                          const uint32_t *view_id, const uint32_t *put_count,
+                                          const uint32_t *match_i, const uint32_t *match_key,
+                                          const uint32_t *geo_count, const uint32_t *geo_idx,
+                                          const uint32_t *geo_j /*null: geo_idx indexes the putative list; else
+                                                                  (geo_idx, geo_j) = (map feature, query feature)
+                                                                  of a guided match*/,
+                                          const int32_t *row_landmark, unsigned long long *best64,
+                                          uint16_t *geo_dist, uint32_t min_putative, uint32_t *view_stats) {
+  EmitMinBody::run(view_sel, n_sel, view_off, view_id, put_count, match_i, match_key, geo_count, geo_idx, geo_j, row_landmark,
+                   best64, geo_dist, min_putative, view_stats);
 }
 
-__global__ __launch_bounds__(256) void k_emit_win(const uint32_t *view_sel, uint32_t n_sel, const uint32_t *view_off,
-                                                  const uint32_t *view_id, const uint32_t *match_i,
-                                                  const uint32_t *match_key, const uint32_t *geo_count,
-                                                  const uint32_t *geo_idx, const uint32_t *geo_j,
-                                                  const int32_t *row_landmark, const uint32_t *landmark_id,
-                                                  const double *landmark_X, const unsigned long long *best64,
-                                                  const uint16_t *geo_dist, Candidate *cand, uint32_t cap,
-                                                  uint32_t *n_cand, int *status) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gw = blockIdx.x;
-  if (gw >= n_sel) return;
-  const uint32_t v = view_sel ? view_sel[gw] : gw;
-  const uint32_t ng = geo_count[v];
-  if (ng == 0) return;
-  const uint32_t off = view_off[v];
-  const uint64_t vkey = (uint64_t)(view_id[v] & 0xFFFFFFu) << 24;
-  for (uint32_t p0 = (threadIdx.x >> 6) * 64; p0 < ng; p0 += 256) {
-    const uint32_t p = p0 + lane;
-    bool has = false;
-    uint32_t i = 0, j = 0;
-    unsigned long long order = 0;
-    if (p < ng) {
-      const uint16_t d = geo_dist[off + p];
-      if (d != kNoDist) {
-        if (geo_j) {
-          i = geo_idx[off + p];
-          j = geo_j[off + p];
-        } else {
-          const uint32_t pp = geo_idx[off + p];
-          i = match_i[off + pp];
-          j = match_key[off + pp] & 0xFFFFu;
+struct EmitWinBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const uint32_t *view_sel, uint32_t n_sel, const uint32_t *view_off,
+                                          const uint32_t *view_id, const uint32_t *match_i,
+                                          const uint32_t *match_key, const uint32_t *geo_count,
+                                          const uint32_t *geo_idx, const uint32_t *geo_j,
+                                          const int32_t *row_landmark, const uint32_t *landmark_id,
+                                          const double *landmark_X, const unsigned long long *best64,
+                                          const uint16_t *geo_dist, Candidate *cand, uint32_t cap,
+                                          uint32_t *n_cand, int *status) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x;
+    if (gw >= n_sel) return;
+    const uint32_t v = view_sel ? view_sel[gw] : gw;
+    const uint32_t ng = geo_count[v];
+    if (ng == 0) return;
+    const uint32_t off = view_off[v];
+    const uint64_t vkey = (uint64_t)(view_id[v] & 0xFFFFFFu) << 24;
+    for (uint32_t p0 = (threadIdx.x >> 6) * 64; p0 < ng; p0 += 256) {
+      const uint32_t p = p0 + lane;
+      bool has = false;
+      uint32_t i = 0, j = 0;
+      unsigned long long order = 0;
+      if (p < ng) {
+        const uint16_t d = geo_dist[off + p];
+        if (d != kNoDist) {
+          if (geo_j) {
+            i = geo_idx[off + p];
+            j = geo_j[off + p];
+          } else {
+            const uint32_t pp = geo_idx[off + p];
+            i = match_i[off + pp];
+            j = match_key[off + pp] & 0xFFFFu;
+          }
+          order = ((unsigned long long)d << 48) | vkey | (unsigned long long)(p & 0xFFFFFFu);
+          has = best64[j] == order;
         }
-        order = ((unsigned long long)d << 48) | vkey | (unsigned long long)(p & 0xFFFFFFu);
-        has = best64[j] == order;
       }
+      // one atomic per wave step instead of one per winner
+      const unsigned long long mask = __ballot(has);
+      uint32_t slot0 = 0;
+      if (lane == 0 && mask) slot0 = atomicAdd(n_cand, (uint32_t)__popcll(mask));
+      slot0 = __shfl(slot0, 0, 64);
+      if (!has) continue;
+      const uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (slot >= cap) {  // cannot happen: at most one winner per query feature and cap >= SFMLOC_MAX_QUERY_ROWS
+        atomicOr(status, 2);
+        continue;
+      }
+      const int32_t lm = row_landmark[off + i];
+      Candidate c;
+      c.order = order;
+      c.qfeat = j;
+      c.landmark_id = landmark_id[lm];
+      c.X[0] = landmark_X[3 * lm];
+      c.X[1] = landmark_X[3 * lm + 1];
+      c.X[2] = landmark_X[3 * lm + 2];
+      cand[slot] = c;
     }
-    // one atomic per wave step instead of one per winner
-    const unsigned long long mask = __ballot(has);
-    uint32_t slot0 = 0;
-    if (lane == 0 && mask) slot0 = atomicAdd(n_cand, (uint32_t)__popcll(mask));
-    slot0 = __shfl(slot0, 0, 64);
-    if (!has) continue;
-    const uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (slot >= cap) {  // cannot happen: at most one winner per query feature and cap >= SFMLOC_MAX_QUERY_ROWS
-      atomicOr(status, 2);
-      continue;
-    }
-    const int32_t lm = row_landmark[off + i];
-    Candidate c;
-    c.order = order;
-    c.qfeat = j;
-    c.landmark_id = landmark_id[lm];
-    c.X[0] = landmark_X[3 * lm];
-    c.X[1] = landmark_X[3 * lm + 1];
-    c.X[2] = landmark_X[3 * lm + 2];
-    cand[slot] = c;
   }
+};
+__global__ __launch_bounds__(256) void k_emit_win(const uint32_t *view_sel, uint32_t n_sel, const uint32_t *view_off,
+                                          const uint32_t *view_id, const uint32_t *match_i,
+                                          const uint32_t *match_key, const uint32_t *geo_count,
+                                          const uint32_t *geo_idx, const uint32_t *geo_j,
+                                          const int32_t *row_landmark, const uint32_t *landmark_id,
+                                          const double *landmark_X, const unsigned long long *best64,
+                                          const uint16_t *geo_dist, Candidate *cand, uint32_t cap,
+                                          uint32_t *n_cand, int *status) {
+  EmitWinBody::run(view_sel, n_sel, view_off, view_id, match_i, match_key, geo_count, geo_idx, geo_j, row_landmark, landmark_id, landmark_X, best64, geo_dist, cand, cap, n_cand, status);
 }
 
 // A "part" is what one shard contributes for one query: 16-byte header {u32 n_cand, pad} + cap candidates.
@@ -1276,86 +1322,108 @@ __device__ __forceinline__ void part_range(const unsigned char *parts, uint64_t 
   }
 }
 
-__global__ __launch_bounds__(256) void k_candidates_min(const unsigned char *parts, uint32_t n_parts,
-                                                        uint64_t part_bytes, uint32_t cap, uint32_t nq,
-                                                        unsigned long long *best, int *status, PartLayout L) {
-  for (uint32_t p = blockIdx.y; p < n_parts; p += gridDim.y) {
-    const Candidate *cand = part_cands(parts, part_bytes, p, L);
-    uint32_t c0, c1;
-    part_range(parts, part_bytes, p, cap, L, &c0, &c1);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const uint32_t *h = reinterpret_cast<const uint32_t *>(parts + (uint64_t)p * part_bytes);
-      // a shard produced more candidates than its part holds (packed: than the batch's budget, or than a context holds)
-      if (L.packed_b ? (h[0] > cap || h[3] != 0) : (h[0] > cap)) atomicOr(status, 2);
+struct CandidatesMinBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const unsigned char *parts, uint32_t n_parts,
+                                                uint64_t part_bytes, uint32_t cap, uint32_t nq,
+                                                unsigned long long *best, int *status, PartLayout L) {
+    for (uint32_t p = blockIdx.y; p < n_parts; p += gridDim.y) {
+      const Candidate *cand = part_cands(parts, part_bytes, p, L);
+      uint32_t c0, c1;
+      part_range(parts, part_bytes, p, cap, L, &c0, &c1);
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t *h = reinterpret_cast<const uint32_t *>(parts + (uint64_t)p * part_bytes);
+        // a shard produced more candidates than its part holds (packed: than the batch's budget, or than a context holds)
+        if (L.packed_b ? (h[0] > cap || h[3] != 0) : (h[0] > cap)) atomicOr(status, 2);
+      }
+      for (uint32_t c = c0 + blockIdx.x * blockDim.x + threadIdx.x; c < c1; c += gridDim.x * blockDim.x)
+        if (cand[c].qfeat < nq) atomicMin(&best[cand[c].qfeat], (unsigned long long)cand[c].order);
     }
-    for (uint32_t c = c0 + blockIdx.x * blockDim.x + threadIdx.x; c < c1; c += gridDim.x * blockDim.x)
-      if (cand[c].qfeat < nq) atomicMin(&best[cand[c].qfeat], (unsigned long long)cand[c].order);
   }
+};
+__global__ __launch_bounds__(256) void k_candidates_min(const unsigned char *parts, uint32_t n_parts,
+                                                uint64_t part_bytes, uint32_t cap, uint32_t nq,
+                                                unsigned long long *best, int *status, PartLayout L) {
+  CandidatesMinBody::run(parts, n_parts, part_bytes, cap, nq, best, status, L);
 }
 
 __device__ void p3p_init_block(const P3pArgs &A, int n, int n_threads, double *s_terms);  // K5's start, below
 
+struct MatchSetFinishBody {
+  static constexpr int kGangThreads = 1024;
+  static __device__ __forceinline__ void run(const unsigned char *parts, uint32_t n_parts,
+                                                  uint64_t part_bytes,
+                                                  uint32_t cap, const unsigned long long *best,
+                                                  uint32_t *winner, uint32_t nq, const float2 *q_kpt,
+                                                  uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
+                                                  double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
+                                                  double ppy, double k1, double k2, double k3, PartLayout L,
+                                                  P3pArgs init /*K5's start, by this workgroup: one launch less*/) {
+    // one workgroup; winners are compacted in query-feature order, 1024 features per pass (a pass is a chain of
+    // dependent loads, so fewer, wider passes)
+    __shared__ uint32_t wave_cnt[16];
+    __shared__ uint32_t base_s;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    // which candidate holds each query feature's minimum (the parts hold winners only -- a few
+    // hundred candidates each --, so the one workgroup that compacts them can also find them: one launch less)
+    for (uint32_t p = 0; p < n_parts; ++p) {
+      const Candidate *cand = part_cands(parts, part_bytes, p, L);
+      uint32_t c0, c1;
+      part_range(parts, part_bytes, p, cap, L, &c0, &c1);
+      for (uint32_t c = c0 + threadIdx.x; c < c1; c += 1024)
+        if (cand[c].qfeat < nq && best[cand[c].qfeat] == (unsigned long long)cand[c].order)
+          winner[cand[c].qfeat] = p * cap + c;
+    }
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < nq; j0 += 1024) {
+      const uint32_t j = j0 + threadIdx.x;
+      const bool has = j < nq && best[j] != ~0ull;
+      const unsigned long long mask = __ballot(has);
+      if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
+      __syncthreads();
+      uint32_t pre = base_s;
+      for (uint32_t w = 0; w < wave; ++w) pre += wave_cnt[w];
+      if (has) {
+        const uint32_t pos = pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        const uint32_t w = winner[j];
+        const Candidate c = part_cands(parts, part_bytes, w / cap, L)[w % cap];
+        ms_qfeat[pos] = j;
+        ms_landmark[pos] = c.landmark_id;
+        const float2 kp = q_kpt[j];
+        double ux = (double)kp.x, uy = (double)kp.y;  // cam_I->get_ud_pixel(qFeatLoc[j])   localization.cpp:484-487
+        if (radial_k3) ud_pixel_k3(f, ppx, ppy, k1, k2, k3, ux, uy, &ux, &uy);
+        pt2d[2 * pos] = ux;
+        pt2d[2 * pos + 1] = uy;
+        pt3d[3 * pos] = c.X[0];
+        pt3d[3 * pos + 1] = c.X[1];
+        pt3d[3 * pos + 2] = c.X[2];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < 16; ++w) t += wave_cnt[w];
+        base_s += t;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *ms_n = base_s;
+    // K5's initial state, normalised points and logcombi tables for the base_s correspondences just written
+    __shared__ double s_terms[kP3pMaxN / 2 + 1];
+    __syncthreads();
+    p3p_init_block(init, (int)base_s, 1024, s_terms);
+  }
+};
 __global__ __launch_bounds__(1024) void k_match_set_finish(const unsigned char *parts, uint32_t n_parts,
-                                                          uint64_t part_bytes,
-                                                          uint32_t cap, const unsigned long long *best,
-                                                          uint32_t *winner, uint32_t nq, const float2 *q_kpt,
-                                                          uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
-                                                          double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
-                                                          double ppy, double k1, double k2, double k3, PartLayout L,
-                                                          P3pArgs init /*K5's start, by this workgroup: one launch less*/) {
-  // one workgroup; winners are compacted in query-feature order, 1024 features per pass (a pass is a chain of
-  // dependent loads, so fewer, wider passes)
-  __shared__ uint32_t wave_cnt[16];
-  __shared__ uint32_t base_s;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) base_s = 0;
-  // which candidate holds each query feature's minimum (the parts hold winners only -- a few
-  // hundred candidates each --, so the one workgroup that compacts them can also find them: one launch less)
-  for (uint32_t p = 0; p < n_parts; ++p) {
-    const Candidate *cand = part_cands(parts, part_bytes, p, L);
-    uint32_t c0, c1;
-    part_range(parts, part_bytes, p, cap, L, &c0, &c1);
-    for (uint32_t c = c0 + threadIdx.x; c < c1; c += 1024)
-      if (cand[c].qfeat < nq && best[cand[c].qfeat] == (unsigned long long)cand[c].order)
-        winner[cand[c].qfeat] = p * cap + c;
-  }
-  __syncthreads();
-  for (uint32_t j0 = 0; j0 < nq; j0 += 1024) {
-    const uint32_t j = j0 + threadIdx.x;
-    const bool has = j < nq && best[j] != ~0ull;
-    const unsigned long long mask = __ballot(has);
-    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    uint32_t pre = base_s;
-    for (uint32_t w = 0; w < wave; ++w) pre += wave_cnt[w];
-    if (has) {
-      const uint32_t pos = pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      const uint32_t w = winner[j];
-      const Candidate c = part_cands(parts, part_bytes, w / cap, L)[w % cap];
-      ms_qfeat[pos] = j;
-      ms_landmark[pos] = c.landmark_id;
-      const float2 kp = q_kpt[j];
-      double ux = (double)kp.x, uy = (double)kp.y;  // cam_I->get_ud_pixel(qFeatLoc[j])   localization.cpp:484-487
-      if (radial_k3) ud_pixel_k3(f, ppx, ppy, k1, k2, k3, ux, uy, &ux, &uy);
-      pt2d[2 * pos] = ux;
-      pt2d[2 * pos + 1] = uy;
-      pt3d[3 * pos] = c.X[0];
-      pt3d[3 * pos + 1] = c.X[1];
-      pt3d[3 * pos + 2] = c.X[2];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t t = 0;
-      for (uint32_t w = 0; w < 16; ++w) t += wave_cnt[w];
-      base_s += t;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *ms_n = base_s;
-  // K5's initial state, normalised points and logcombi tables for the base_s correspondences just written
-  __shared__ double s_terms[kP3pMaxN / 2 + 1];
-  __syncthreads();
-  p3p_init_block(init, (int)base_s, 1024, s_terms);
+                                                  uint64_t part_bytes,
+                                                  uint32_t cap, const unsigned long long *best,
+                                                  uint32_t *winner, uint32_t nq, const float2 *q_kpt,
+                                                  uint32_t *ms_n, uint32_t *ms_qfeat, uint32_t *ms_landmark,
+                                                  double *pt2d, double *pt3d, int radial_k3, double f, double ppx,
+                                                  double ppy, double k1, double k2, double k3, PartLayout L,
+                                                  P3pArgs init /*K5's start, by this workgroup: one launch less*/) {
+  MatchSetFinishBody::run(parts, n_parts, part_bytes, cap, best, winner, nq, q_kpt, ms_n, ms_qfeat, ms_landmark, pt2d, pt3d,
+                          radial_k3, f, ppx, ppy, k1, k2, k3, L, init);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1416,9 +1484,15 @@ __device__ void p3p_init_block(const P3pArgs &A, int n, int n_threads, double *s
   // (the table pass wants n / 2 + 1 doubles of scratch: LDS up to kP3pMaxN correspondences, global beyond)
   logcombi_tables_block(3, n, A.L10, n > kP3pMaxN ? A.ws_terms : s_terms, A.logc_n, A.logc_k, n_threads);
 }
+struct P3pInitBody {
+  static constexpr int kGangThreads = kThreads;
+  static __device__ __forceinline__ void run(P3pArgs A) {
+    __shared__ double s_terms[kP3pMaxN / 2 + 1];
+    p3p_init_block(A, (int)*A.ms_n, kThreads, s_terms);
+  }
+};
 __global__ __launch_bounds__(kThreads) void k_p3p_init(P3pArgs A) {
-  __shared__ double s_terms[kP3pMaxN / 2 + 1];
-  p3p_init_block(A, (int)*A.ms_n, kThreads, s_terms);
+  P3pInitBody::run(A);
 }
 
 constexpr int kP3pWaveSeg = kP3pMaxN / 4;  // elements one wave sorts when the four models run side by side
@@ -1926,18 +2000,24 @@ __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pRepla
 // writes the state of the next round.  Nobody waits for anybody, so there is no co-residency requirement; workgroups
 // without a hypothesis (past the batch or the budget) only count themselves in.  A launch on a finished state returns at
 // once (st.done is written by the previous launch's last workgroup, i.e. before this launch starts).
+struct P3pRoundBody {
+  static constexpr int kGangThreads = kThreads;
+  static __device__ __forceinline__ void run(P3pArgs A, int batch) {
+    P3pState &st = *A.state;
+    if (st.done) return;
+    extern __shared__ unsigned char smem_raw[];
+    p3p_eval_hypothesis(A, batch, smem_raw);
+    __shared__ unsigned s_ticket;
+    __syncthreads();  // this workgroup's write-through stores have completed (and its LDS is free)
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&st.arrive, 1u);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing cached here predates the other workgroups' results
+    p3p_replay(A, batch, *reinterpret_cast<P3pReplayShared *>(smem_raw));
+  }
+};
 __global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch) {
-  P3pState &st = *A.state;
-  if (st.done) return;
-  extern __shared__ unsigned char smem_raw[];
-  p3p_eval_hypothesis(A, batch, smem_raw);
-  __shared__ unsigned s_ticket;
-  __syncthreads();  // this workgroup's write-through stores have completed (and its LDS is free)
-  if (threadIdx.x == 0) s_ticket = atomicAdd(&st.arrive, 1u);
-  __syncthreads();
-  if (s_ticket != gridDim.x - 1) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing cached here predates the other workgroups' results
-  p3p_replay(A, batch, *reinterpret_cast<P3pReplayShared *>(smem_raw));
+  P3pRoundBody::run(A, batch);
 }
 
 // ACRANSAC's epilogue + SfM_Localizer::Localize + localization.cpp:511-547, once per query after the last round
@@ -1960,92 +2040,98 @@ __device__ void p3p_publish(const P3pArgs &A) {
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_p3p_finish(P3pArgs A) {
-  P3pState &st = *A.state;
-  if (!st.done || st.finished) {  // rounds still to come, or nothing to estimate (k_p3p_init's verdict): just report
-    p3p_publish(A);
-    return;
-  }
-  const int tid = threadIdx.x;
-  const double min_nfa = st.min_nfa, errmax = st.errmax;
-  const int n_in = st.n_in;
+struct P3pFinishBody {
+  static constexpr int kGangThreads = kThreads;
+  static __device__ __forceinline__ void run(P3pArgs A) {
+    P3pState &st = *A.state;
+    if (!st.done || st.finished) {  // rounds still to come, or nothing to estimate (k_p3p_init's verdict): just report
+      p3p_publish(A);
+      return;
+    }
+    const int tid = threadIdx.x;
+    const double min_nfa = st.min_nfa, errmax = st.errmax;
+    const int n_in = st.n_in;
 #ifdef SFMLOC_STAMPS
-  const int stamp_round = st.rounds;
+    const int stamp_round = st.rounds;
 #endif
 
-  __shared__ double Msh[12];
-  if (tid < 12) Msh[tid] = st.model[tid];
-  __syncthreads();
-  int n_final = n_in;
-  if (min_nfa >= 0.0) n_final = 0;
-  const bool resection = (double)n_final > 2.5 * 3;
-  const bool ok = resection && n_final > A.min_inliers;
-  Pose &R = *A.result;
-  if (ok)
-    for (int p = tid; p < n_final; p += kThreads) {
-      const int32_t c = A.best_inl[p];
-      A.pair_qfeat[p] = A.ms_qfeat[c];
-      A.pair_landmark[p] = A.ms_landmark[c];
-      A.inlier_idx[p] = c;
-    }
-  // every thread computes the (tiny) pose epilogue redundantly so that the refinement can use block barriers
-  const double inv_f = 1.0 / A.focal;
-  double Pm[12];
-  for (int j = 0; j < 4; ++j) {  // P = K * [R|t]
-    Pm[j] = A.focal * Msh[j] + A.ppx * Msh[8 + j];
-    Pm[4 + j] = A.focal * Msh[4 + j] + A.ppy * Msh[8 + j];
-    Pm[8 + j] = Msh[8 + j];
-  }
-  if (n_final == 0)
-    for (int j = 0; j < 12; ++j) Pm[j] = 0.0;
-  double Kq[9], Rq[9], tq[3], cq[3];
-  double refine_cost = 0.0;
-  int refine_iters = 0;
-  if (ok) {
-    krt_from_p(Pm, Kq, Rq, tq);
-    if (A.refine_pose) {
-      __syncthreads();  // inlier_idx written above by all threads
-      refine_cost = refine_pose_block(A.pt2d, A.pt3d, A.best_inl, n_final, A.focal, A.ppx, A.ppy, Rq, tq, 20,
-                                      &refine_iters);
-      for (int r = 0; r < 3; ++r) {  // P = K [R|t] of the refined pose
-        for (int j = 0; j < 3; ++j) {
-          Pm[4 * r + j] = (r == 0) ? A.focal * Rq[j] + A.ppx * Rq[6 + j]
-                        : (r == 1) ? A.focal * Rq[3 + j] + A.ppy * Rq[6 + j]
-                                   : Rq[6 + j];
-        }
-        Pm[4 * r + 3] = (r == 0) ? A.focal * tq[0] + A.ppx * tq[2] : (r == 1) ? A.focal * tq[1] + A.ppy * tq[2] : tq[2];
+    __shared__ double Msh[12];
+    if (tid < 12) Msh[tid] = st.model[tid];
+    __syncthreads();
+    int n_final = n_in;
+    if (min_nfa >= 0.0) n_final = 0;
+    const bool resection = (double)n_final > 2.5 * 3;
+    const bool ok = resection && n_final > A.min_inliers;
+    Pose &R = *A.result;
+    if (ok)
+      for (int p = tid; p < n_final; p += kThreads) {
+        const int32_t c = A.best_inl[p];
+        A.pair_qfeat[p] = A.ms_qfeat[c];
+        A.pair_landmark[p] = A.ms_landmark[c];
+        A.inlier_idx[p] = c;
       }
-      Kq[0] = A.focal; Kq[1] = 0.0; Kq[2] = A.ppx; Kq[3] = 0.0; Kq[4] = A.focal; Kq[5] = A.ppy;
-      Kq[6] = 0.0; Kq[7] = 0.0; Kq[8] = 1.0;
+    // every thread computes the (tiny) pose epilogue redundantly so that the refinement can use block barriers
+    const double inv_f = 1.0 / A.focal;
+    double Pm[12];
+    for (int j = 0; j < 4; ++j) {  // P = K * [R|t]
+      Pm[j] = A.focal * Msh[j] + A.ppx * Msh[8 + j];
+      Pm[4 + j] = A.focal * Msh[4 + j] + A.ppy * Msh[8 + j];
+      Pm[8 + j] = Msh[8 + j];
     }
-    center_from_rt(Rq, tq, cq);
-  }
-  if (tid == 0) {
-    R.ok = ok ? 1 : 0;
-    R.n_inliers = n_final;
-    R.n_matches_2d3d = st.n;
-    R.iterations = st.iter;
-    R.nfa = min_nfa;
-    R.status = st.status;
-    R.reserved = refine_iters;
-    R.error_max = (n_final > 0) ? sqrt(errmax) / inv_f : errmax;
-    for (int j = 0; j < 12; ++j) R.P[j] = Pm[j];
+    if (n_final == 0)
+      for (int j = 0; j < 12; ++j) Pm[j] = 0.0;
+    double Kq[9], Rq[9], tq[3], cq[3];
+    double refine_cost = 0.0;
+    int refine_iters = 0;
     if (ok) {
-      for (int j = 0; j < 9; ++j) {
-        R.K[j] = Kq[j];
-        R.R[j] = Rq[j];
+      krt_from_p(Pm, Kq, Rq, tq);
+      if (A.refine_pose) {
+        __syncthreads();  // inlier_idx written above by all threads
+        refine_cost = refine_pose_block(A.pt2d, A.pt3d, A.best_inl, n_final, A.focal, A.ppx, A.ppy, Rq, tq, 20,
+                                        &refine_iters);
+        for (int r = 0; r < 3; ++r) {  // P = K [R|t] of the refined pose
+          for (int j = 0; j < 3; ++j) {
+            Pm[4 * r + j] = (r == 0) ? A.focal * Rq[j] + A.ppx * Rq[6 + j]
+                          : (r == 1) ? A.focal * Rq[3 + j] + A.ppy * Rq[6 + j]
+                                     : Rq[6 + j];
+          }
+          Pm[4 * r + 3] = (r == 0) ? A.focal * tq[0] + A.ppx * tq[2] : (r == 1) ? A.focal * tq[1] + A.ppy * tq[2] : tq[2];
+        }
+        Kq[0] = A.focal; Kq[1] = 0.0; Kq[2] = A.ppx; Kq[3] = 0.0; Kq[4] = A.focal; Kq[5] = A.ppy;
+        Kq[6] = 0.0; Kq[7] = 0.0; Kq[8] = 1.0;
       }
-      for (int j = 0; j < 3; ++j) {
-        R.t[j] = tq[j];
-        R.center[j] = cq[j];
-      }
-      if (A.refine_pose) R.stage_seconds[0] = refine_cost;  // overwritten by the host; kept for sfmloc_pose_read
+      center_from_rt(Rq, tq, cq);
     }
-    st.finished = 1;
+    if (tid == 0) {
+      R.ok = ok ? 1 : 0;
+      R.n_inliers = n_final;
+      R.n_matches_2d3d = st.n;
+      R.iterations = st.iter;
+      R.nfa = min_nfa;
+      R.status = st.status;
+      R.reserved = refine_iters;
+      R.error_max = (n_final > 0) ? sqrt(errmax) / inv_f : errmax;
+      for (int j = 0; j < 12; ++j) R.P[j] = Pm[j];
+      if (ok) {
+        for (int j = 0; j < 9; ++j) {
+          R.K[j] = Kq[j];
+          R.R[j] = Rq[j];
+        }
+        for (int j = 0; j < 3; ++j) {
+          R.t[j] = tq[j];
+          R.center[j] = cq[j];
+        }
+        if (A.refine_pose) R.stage_seconds[0] = refine_cost;  // overwritten by the host; kept for sfmloc_pose_read
+      }
+      st.finished = 1;
+    }
+    __syncthreads();  // the record is complete
+    p3p_publish(A);
+    STAMP_SEL(stamp_round, 3);
   }
-  __syncthreads();  // the record is complete
-  p3p_publish(A);
-  STAMP_SEL(stamp_round, 3);
+};
+__global__ __launch_bounds__(kThreads) void k_p3p_finish(P3pArgs A) {
+  P3pFinishBody::run(A);
 }
 
 // L10[i] = log10(i) for the logcombi tables, computed once per map on the device
@@ -2251,7 +2337,7 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
     static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(F2Shared));
     SFM_HIP(attr2);
-    hipLaunchKernelGGL(k_fmatrix_fast, dim3(n_sel), dim3(kF2Threads), lds2, c->stream, A);
+    sfm_launch<FmatrixFastBody>(c, k_fmatrix_fast, dim3(n_sel), dim3(kF2Threads), (uint32_t)lds2, A);
     SFM_HIP(hipGetLastError());
   }
   const size_t lds = sizeof(FShared);
@@ -2259,7 +2345,7 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FShared));
   SFM_HIP(attr1);
   A.merge.enabled = 0;  // (the lists exist by now)
-  hipLaunchKernelGGL(k_fmatrix_filter, dim3(n_sel), dim3(kThreads), lds, c->stream, A);
+  sfm_launch<FmatrixFilterBody>(c, k_fmatrix_filter, dim3(n_sel), dim3(kThreads), (uint32_t)lds, A);
   SFM_HIP(hipGetLastError());
   if (A.large_list) {  // some view of this map can have more than kFMaxM matches: the queue's consumer
     FLargeArgs W;
@@ -2270,7 +2356,7 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
     W.logc_n = c->fl_logc_n;
     W.logc_k = c->fl_logc_k;
     W.slot_m = c->fl_slot_m;
-    hipLaunchKernelGGL(k_fmatrix_large, dim3(kFLargeSlots), dim3(kThreads), 0, c->stream, A, W);
+    sfm_launch<FmatrixLargeBody>(c, k_fmatrix_large, dim3(kFLargeSlots), dim3(kThreads), 0, A, W);
     SFM_HIP(hipGetLastError());
   }
   return SFMLOC_OK;
@@ -2286,33 +2372,40 @@ int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_view
   if (n_sel == 0 || q->n == 0) return SFMLOC_OK;
   const uint32_t *sel = all_views ? nullptr : c->d_view_sel;
   const uint32_t *gj = c->geo_is_pairs ? c->d_geo_j : nullptr;
-  hipLaunchKernelGGL(k_emit_min, dim3(n_sel), dim3(256), 0, c->stream, sel, n_sel, m->d_view_off, m->d_view_id,
-                     c->d_view_count, c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, gj, m->d_row_landmark,
-                     c->d_best64, c->d_geo_dist, (uint32_t)m->params.min_putative, c->d_view_stats);
+  sfm_launch<EmitMinBody>(c, k_emit_min, dim3(n_sel), dim3(256), 0, sel, n_sel, m->d_view_off, m->d_view_id,
+                          c->d_view_count, c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, gj,
+                          m->d_row_landmark, c->d_best64, c->d_geo_dist, (uint32_t)m->params.min_putative, c->d_view_stats);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_emit_win, dim3(n_sel), dim3(256), 0, c->stream, sel, n_sel, m->d_view_off, m->d_view_id,
-                     c->d_match_i, c->d_match_key, c->d_geo_count, c->d_geo_idx, gj, m->d_row_landmark, m->d_landmark_id,
-                     m->d_landmark_X, c->d_best64, c->d_geo_dist,
-                     reinterpret_cast<Candidate *>(c->d_cand_part + kPartHeaderBytes), c->cand_cap,
-                     reinterpret_cast<uint32_t *>(c->d_cand_part), c->d_status);
+  sfm_launch<EmitWinBody>(c, k_emit_win, dim3(n_sel), dim3(256), 0, sel, n_sel, m->d_view_off, m->d_view_id, c->d_match_i,
+                          c->d_match_key, c->d_geo_count, c->d_geo_idx, gj, m->d_row_landmark, m->d_landmark_id,
+                          m->d_landmark_X, c->d_best64, c->d_geo_dist,
+                          reinterpret_cast<Candidate *>(c->d_cand_part + kPartHeaderBytes), c->cand_cap,
+                          reinterpret_cast<uint32_t *>(c->d_cand_part), c->d_status);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
 // a context's candidate part -> a caller's buffer: the 16-byte header (true count) and the candidates that exist, at
 // most cap of them (a fixed-size copy would move cap * 40 bytes for a few hundred candidates)
+struct ExportPartBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
+                                             uint32_t cap) {
+    const uint32_t n = min(*reinterpret_cast<const uint32_t *>(src), cap);
+    const uint64_t words = (kPartHeaderBytes + (uint64_t)n * sizeof(Candidate)) / 8;  // both multiples of 8
+    const uint2 *s8 = reinterpret_cast<const uint2 *>(src);
+    uint2 *d8 = reinterpret_cast<uint2 *>(dst);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x)
+      d8[i] = s8[i];
+  }
+};
 __global__ __launch_bounds__(256) void k_export_part(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
-                                                     uint32_t cap) {
-  const uint32_t n = min(*reinterpret_cast<const uint32_t *>(src), cap);
-  const uint64_t words = (kPartHeaderBytes + (uint64_t)n * sizeof(Candidate)) / 8;  // both multiples of 8
-  const uint2 *s8 = reinterpret_cast<const uint2 *>(src);
-  uint2 *d8 = reinterpret_cast<uint2 *>(dst);
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x)
-    d8[i] = s8[i];
+                                             uint32_t cap) {
+  ExportPartBody::run(src, dst, cap);
 }
 
 int launch_export_part(Ctx *c, void *dst_dev, uint32_t cap) {
-  hipLaunchKernelGGL(k_export_part, dim3(8), dim3(256), 0, c->stream, c->d_cand_part,
+  sfm_launch<ExportPartBody>(c, k_export_part, dim3(8), dim3(256), 0, c->d_cand_part,
                      reinterpret_cast<unsigned char *>(dst_dev), cap);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
@@ -2320,30 +2413,38 @@ int launch_export_part(Ctx *c, void *dst_dev, uint32_t cap) {
 
 // a context's candidates appended to a batch's packed part (layout: PartLayout above).  One workgroup: lane 0 claims
 // [off, off + n) of the candidate area with one atomic on the header's running total, then everybody copies.
-__global__ __launch_bounds__(256) void k_export_packed(const unsigned char *__restrict__ src, uint32_t src_cap,
-                                                       unsigned char *__restrict__ dst, uint32_t n_queries,
-                                                       uint32_t budget, uint32_t qi) {
-  __shared__ uint32_t s_off, s_n;
-  uint32_t *h = reinterpret_cast<uint32_t *>(dst);
-  if (threadIdx.x == 0) {
-    const uint32_t n_true = *reinterpret_cast<const uint32_t *>(src);
-    const uint32_t n = min(n_true, src_cap);
-    if (n_true > src_cap) atomicOr(&h[3], 2u);      // the context itself overflowed: candidates are lost
-    const uint32_t off = atomicAdd(&h[0], n);       // the total keeps counting past the budget: every rank sees by how much
-    const bool fits = (uint64_t)off + n <= budget;
-    if (!fits) atomicOr(&h[3], 1u);
-    h[1] = n_queries;
-    h[2] = budget;
-    h[4 + qi] = fits ? n : 0u;
-    h[4 + n_queries + qi] = fits ? off : 0u;
-    s_off = off;
-    s_n = fits ? n : 0u;
+struct ExportPackedBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const unsigned char *__restrict__ src, uint32_t src_cap,
+                                               unsigned char *__restrict__ dst, uint32_t n_queries,
+                                               uint32_t budget, uint32_t qi) {
+    __shared__ uint32_t s_off, s_n;
+    uint32_t *h = reinterpret_cast<uint32_t *>(dst);
+    if (threadIdx.x == 0) {
+      const uint32_t n_true = *reinterpret_cast<const uint32_t *>(src);
+      const uint32_t n = min(n_true, src_cap);
+      if (n_true > src_cap) atomicOr(&h[3], 2u);      // the context itself overflowed: candidates are lost
+      const uint32_t off = atomicAdd(&h[0], n);       // the total keeps counting past the budget: every rank sees by how much
+      const bool fits = (uint64_t)off + n <= budget;
+      if (!fits) atomicOr(&h[3], 1u);
+      h[1] = n_queries;
+      h[2] = budget;
+      h[4 + qi] = fits ? n : 0u;
+      h[4 + n_queries + qi] = fits ? off : 0u;
+      s_off = off;
+      s_n = fits ? n : 0u;
+    }
+    __syncthreads();
+    const uint2 *s8 = reinterpret_cast<const uint2 *>(src + kPartHeaderBytes);
+    uint2 *d8 = reinterpret_cast<uint2 *>(dst + packed_cands_offset(n_queries) + (uint64_t)s_off * sizeof(Candidate));
+    const uint64_t words = (uint64_t)s_n * (sizeof(Candidate) / 8);
+    for (uint64_t i = threadIdx.x; i < words; i += blockDim.x) d8[i] = s8[i];
   }
-  __syncthreads();
-  const uint2 *s8 = reinterpret_cast<const uint2 *>(src + kPartHeaderBytes);
-  uint2 *d8 = reinterpret_cast<uint2 *>(dst + packed_cands_offset(n_queries) + (uint64_t)s_off * sizeof(Candidate));
-  const uint64_t words = (uint64_t)s_n * (sizeof(Candidate) / 8);
-  for (uint64_t i = threadIdx.x; i < words; i += blockDim.x) d8[i] = s8[i];
+};
+__global__ __launch_bounds__(256) void k_export_packed(const unsigned char *__restrict__ src, uint32_t src_cap,
+                                               unsigned char *__restrict__ dst, uint32_t n_queries,
+                                               uint32_t budget, uint32_t qi) {
+  ExportPackedBody::run(src, src_cap, dst, n_queries, budget, qi);
 }
 
 uint64_t packed_part_bytes(uint32_t n_queries, uint32_t budget) {
@@ -2351,22 +2452,42 @@ uint64_t packed_part_bytes(uint32_t n_queries, uint32_t budget) {
 }
 
 int launch_export_packed(Ctx *c, void *dst_dev, uint32_t n_queries, uint32_t budget, uint32_t qi) {
-  hipLaunchKernelGGL(k_export_packed, dim3(1), dim3(256), 0, c->stream, c->d_cand_part, c->cand_cap,
-                     reinterpret_cast<unsigned char *>(dst_dev), n_queries, budget, qi);
+  sfm_launch<ExportPackedBody>(c, k_export_packed, dim3(1), dim3(256), 0, c->d_cand_part, c->cand_cap,
+                               reinterpret_cast<unsigned char *>(dst_dev), n_queries, budget, qi);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
 static P3pArgs make_p3p_args(Ctx *c);
 
+// what a query's 2D-3D selection starts from when no k_query_reset ran for it (sfmloc_merge_begin, the staged API)
+struct SelectResetBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(unsigned long long *__restrict__ best64, uint32_t nq, uint32_t *__restrict__ ms_n,
+                                             int *__restrict__ status) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nq) best64[i] = ~0ull;
+    if (i == 0) {
+      *ms_n = 0;
+      if (status) *status = 0;
+    }
+  }
+};
+__global__ __launch_bounds__(256) void k_select_reset(unsigned long long *__restrict__ best64, uint32_t nq,
+                                                      uint32_t *__restrict__ ms_n, int *__restrict__ status) {
+  SelectResetBody::run(best64, nq, ms_n, status);
+}
+
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
-                             uint64_t part_bytes, uint32_t cap, uint32_t packed_b, uint32_t packed_qi) {
+                             uint64_t part_bytes, uint32_t cap, uint32_t packed_b, uint32_t packed_qi, bool reset_status) {
   PartLayout L;
   L.packed_b = packed_b;
   L.qi = packed_qi;
-  if (!c->cleared) {
-    SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
-    SFM_HIP(hipMemsetAsync(c->d_ms_n, 0, sizeof(uint32_t), c->stream));
+  if (!c->cleared) {  // (one launch, and one that a gang session can carry, instead of three memsets)
+    const uint32_t nq1 = q->n ? q->n : 1;
+    sfm_launch<SelectResetBody>(c, k_select_reset, dim3((nq1 + 255) / 256), dim3(256), 0, c->d_best64, nq1, c->d_ms_n,
+                                reset_status ? c->d_status : (int *)nullptr);
+    SFM_HIP(hipGetLastError());
   }
   if (q->n == 0 || n_parts == 0) return SFMLOC_OK;
   const dim3 grid(16, n_parts < 64 ? n_parts : 64);
@@ -2374,14 +2495,14 @@ int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts,
   // d_best64 their keys, so the minimum pass would change nothing
   const bool own_part = (parts == c->d_cand_part && n_parts == 1 && packed_b == 0 && c->cleared);
   if (!own_part) {
-    hipLaunchKernelGGL(k_candidates_min, grid, dim3(256), 0, c->stream, parts, n_parts, part_bytes, cap, q->n,
-                       c->d_best64, c->d_status, L);
+    sfm_launch<CandidatesMinBody>(c, k_candidates_min, grid, dim3(256), 0, parts, n_parts, part_bytes, cap, q->n,
+                                  c->d_best64, c->d_status, L);
     SFM_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_match_set_finish, dim3(1), dim3(1024), 0, c->stream, parts, n_parts, part_bytes, cap, c->d_best64,
-                     c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark, c->d_pt2d, c->d_pt3d,
-                     c->map->intrinsic_type == 3 ? 1 : 0, c->map->focal, c->map->ppx, c->map->ppy, c->map->k1, c->map->k2,
-                     c->map->k3, L, make_p3p_args(c));
+  sfm_launch<MatchSetFinishBody>(c, k_match_set_finish, dim3(1), dim3(1024), 0, parts, n_parts, part_bytes, cap,
+                                 c->d_best64, c->d_winner, q->n, q->d_kpt, c->d_ms_n, c->d_ms_qfeat, c->d_ms_landmark,
+                                 c->d_pt2d, c->d_pt3d, c->map->intrinsic_type == 3 ? 1 : 0, c->map->focal, c->map->ppx,
+                                 c->map->ppy, c->map->k1, c->map->k2, c->map->k3, L, make_p3p_args(c));
   SFM_HIP(hipGetLastError());
   c->p3p_init_fused = true;  // launch_p3p_init is then a no-op for this query
   return SFMLOC_OK;
@@ -2453,7 +2574,7 @@ int launch_p3p_init(Ctx *c) {
     return SFMLOC_OK;
   }
   P3pArgs A = make_p3p_args(c);
-  hipLaunchKernelGGL(k_p3p_init, dim3(1), dim3(kThreads), 0, c->stream, A);
+  sfm_launch<P3pInitBody>(c, k_p3p_init, dim3(1), dim3(kThreads), 0, A);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
@@ -2466,14 +2587,14 @@ int launch_p3p_round(Ctx *c, int batch) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p3p_round),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(P3pShared));
   SFM_HIP(attr);
-  hipLaunchKernelGGL(k_p3p_round, dim3(batch), dim3(kThreads), lds, c->stream, A, batch);
+  sfm_launch<P3pRoundBody>(c, k_p3p_round, dim3(batch), dim3(kThreads), (uint32_t)lds, A, batch);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
 int launch_p3p_finish(Ctx *c) {
   P3pArgs A = make_p3p_args(c);
-  hipLaunchKernelGGL(k_p3p_finish, dim3(1), dim3(kThreads), 0, c->stream, A);
+  sfm_launch<P3pFinishBody>(c, k_p3p_finish, dim3(1), dim3(kThreads), 0, A);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -16,22 +16,30 @@
 namespace sfmloc {
 namespace {
 
-__global__ __launch_bounds__(256) void k_bow_dist(const float *__restrict__ bow, uint32_t dim,
-                                                  const uint32_t *__restrict__ cand, uint32_t n_cand,
-                                                  const float *__restrict__ query, uint32_t *__restrict__ dist_bits) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= n_cand) return;
-  const uint32_t v = cand ? cand[p] : p;
-  const float *row = bow + (size_t)v * dim;
-  float s = 0.0f;
-  for (uint32_t i = lane; i < dim; i += 64) {
-    const float d = row[i] - query[i];
-    const float d2 = d * d;
-    s = s + d2;
+struct BowDistBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ bow, uint32_t dim,
+                                          const uint32_t *__restrict__ cand, uint32_t n_cand,
+                                          const float *__restrict__ query, uint32_t *__restrict__ dist_bits) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_cand) return;
+    const uint32_t v = cand ? cand[p] : p;
+    const float *row = bow + (size_t)v * dim;
+    float s = 0.0f;
+    for (uint32_t i = lane; i < dim; i += 64) {
+      const float d = row[i] - query[i];
+      const float d2 = d * d;
+      s = s + d2;
+    }
+    for (int stride = 32; stride >= 1; stride >>= 1) s = s + __shfl_xor(s, stride, 64);
+    if (lane == 0) dist_bits[p] = __float_as_uint(s);
   }
-  for (int stride = 32; stride >= 1; stride >>= 1) s = s + __shfl_xor(s, stride, 64);
-  if (lane == 0) dist_bits[p] = __float_as_uint(s);
+};
+__global__ __launch_bounds__(256) void k_bow_dist(const float *__restrict__ bow, uint32_t dim,
+                                          const uint32_t *__restrict__ cand, uint32_t n_cand,
+                                          const float *__restrict__ query, uint32_t *__restrict__ dist_bits) {
+  BowDistBody::run(bow, dim, cand, n_cand, query, dist_bits);
 }
 
 // exclusive prefix sum of one value per thread over a 1024-thread workgroup (wave shuffles + one LDS hop); every
@@ -62,88 +70,96 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 // (11+11+10), then an order-preserving compaction of {dist < T} plus the first (k - #less) of {dist == T}.
 // Every search over the histogram and every scan over the per-thread counts is a block-wide scan: the first version
 // left them to thread 0 and spent 130 us on 10 000 views, most of it in those loops.
-__global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ dist_bits, uint32_t n,
-                                                   const uint32_t *__restrict__ cand, uint32_t k,
-                                                   uint32_t *__restrict__ out_sel, ChainArgs chain) {
-  __shared__ uint32_t hist[2048];
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t sh_prefix, sh_rank;
-  const uint32_t tid = threadIdx.x;
-  if (k > n) k = n;
-  if (k == 0) return;  // (the launcher never chains an empty shortlist)
-  const uint32_t k_sel = k;
-  uint32_t prefix = 0, rank = k;  // the k-th smallest (1-based) within the elements matching `prefix`
-  const int shifts[3] = {21, 10, 0};
-  const uint32_t widths[3] = {11, 11, 10};
-  for (int pass = 0; pass < 3; ++pass) {
-    const uint32_t bins = 1u << widths[pass];
-    for (uint32_t b = tid; b < bins; b += 1024) hist[b] = 0;
-    __syncthreads();
-    const uint32_t hi_shift = shifts[pass] + widths[pass];
-    for (uint32_t i = tid; i < n; i += 1024) {
-      const uint32_t x = dist_bits[i];
-      const bool match = (pass == 0) || ((x >> hi_shift) == (prefix >> hi_shift));
-      if (match) atomicAdd(&hist[(x >> shifts[pass]) & (bins - 1)], 1u);
+struct BowTopkBody {
+  static constexpr int kGangThreads = 1024;
+  static __device__ __forceinline__ void run(const uint32_t *__restrict__ dist_bits, uint32_t n,
+                                           const uint32_t *__restrict__ cand, uint32_t k,
+                                           uint32_t *__restrict__ out_sel, ChainArgs chain) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t sh_prefix, sh_rank;
+    const uint32_t tid = threadIdx.x;
+    if (k > n) k = n;
+    if (k == 0) return;  // (the launcher never chains an empty shortlist)
+    const uint32_t k_sel = k;
+    uint32_t prefix = 0, rank = k;  // the k-th smallest (1-based) within the elements matching `prefix`
+    const int shifts[3] = {21, 10, 0};
+    const uint32_t widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+      const uint32_t bins = 1u << widths[pass];
+      for (uint32_t b = tid; b < bins; b += 1024) hist[b] = 0;
+      __syncthreads();
+      const uint32_t hi_shift = shifts[pass] + widths[pass];
+      for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t x = dist_bits[i];
+        const bool match = (pass == 0) || ((x >> hi_shift) == (prefix >> hi_shift));
+        if (match) atomicAdd(&hist[(x >> shifts[pass]) & (bins - 1)], 1u);
+      }
+      __syncthreads();
+      // the bin holding the rank-th element: thread t owns bins 2t, 2t+1 (1024 bins in the last pass: bin t, and 0)
+      const uint32_t per = bins / 1024;  // 2 or 1
+      const uint32_t h0 = hist[tid * per], h1 = per == 2 ? hist[tid * per + 1] : 0u;
+      uint32_t total;
+      const uint32_t before = block_exclusive_scan_1024(h0 + h1, wave_tot, &total);
+      if (before < rank && rank <= before + h0 + h1) {  // exactly one thread (total >= rank by construction)
+        const bool second = rank > before + h0;
+        sh_prefix = prefix | ((tid * per + (second ? 1u : 0u)) << shifts[pass]);
+        sh_rank = rank - before - (second ? h0 : 0u);
+      }
+      __syncthreads();
+      prefix = sh_prefix;
+      rank = sh_rank;
+      __syncthreads();
     }
-    __syncthreads();
-    // the bin holding the rank-th element: thread t owns bins 2t, 2t+1 (1024 bins in the last pass: bin t, and 0)
-    const uint32_t per = bins / 1024;  // 2 or 1
-    const uint32_t h0 = hist[tid * per], h1 = per == 2 ? hist[tid * per + 1] : 0u;
+    const uint32_t T = prefix;  // bit pattern of the k-th smallest distance; `rank` of the equal ones are taken
+    // contiguous chunk per thread keeps index order
+    const uint32_t chunk = (n + 1023) / 1024;
+    const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+    uint32_t c_eq = 0;
+    for (uint32_t i = lo; i < hi; ++i) c_eq += (dist_bits[i] == T);
     uint32_t total;
-    const uint32_t before = block_exclusive_scan_1024(h0 + h1, wave_tot, &total);
-    if (before < rank && rank <= before + h0 + h1) {  // exactly one thread (total >= rank by construction)
-      const bool second = rank > before + h0;
-      sh_prefix = prefix | ((tid * per + (second ? 1u : 0u)) << shifts[pass]);
-      sh_rank = rank - before - (second ? h0 : 0u);
+    const uint32_t eq_before = block_exclusive_scan_1024(c_eq, wave_tot, &total);
+    uint32_t c_sel = 0;
+    {
+      uint32_t e = eq_before;
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t x = dist_bits[i];
+        if (x < T) ++c_sel;
+        else if (x == T) {
+          if (e < rank) ++c_sel;
+          ++e;
+        }
+      }
     }
-    __syncthreads();
-    prefix = sh_prefix;
-    rank = sh_rank;
-    __syncthreads();
-  }
-  const uint32_t T = prefix;  // bit pattern of the k-th smallest distance; `rank` of the equal ones are taken
-  // contiguous chunk per thread keeps index order
-  const uint32_t chunk = (n + 1023) / 1024;
-  const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
-  uint32_t c_eq = 0;
-  for (uint32_t i = lo; i < hi; ++i) c_eq += (dist_bits[i] == T);
-  uint32_t total;
-  const uint32_t eq_before = block_exclusive_scan_1024(c_eq, wave_tot, &total);
-  uint32_t c_sel = 0;
-  {
+    uint32_t pos = block_exclusive_scan_1024(c_sel, wave_tot, &total);
     uint32_t e = eq_before;
     for (uint32_t i = lo; i < hi; ++i) {
       const uint32_t x = dist_bits[i];
-      if (x < T) ++c_sel;
-      else if (x == T) {
-        if (e < rank) ++c_sel;
+      bool take = x < T;
+      if (x == T) {
+        take = e < rank;
         ++e;
       }
+      if (take) out_sel[pos++] = cand ? cand[i] : i;
     }
-  }
-  uint32_t pos = block_exclusive_scan_1024(c_sel, wave_tot, &total);
-  uint32_t e = eq_before;
-  for (uint32_t i = lo; i < hi; ++i) {
-    const uint32_t x = dist_bits[i];
-    bool take = x < T;
-    if (x == T) {
-      take = e < rank;
-      ++e;
-    }
-    if (take) out_sel[pos++] = cand ? cand[i] : i;
-  }
-  if (chain.keys_out) {  // sharded shortlist: the selection as (distance bits << 32 | global view id), padded
-    __syncthreads();
-    for (uint32_t i = tid; i < chain.k_out; i += 1024) {
-      unsigned long long key = ~0ull;
-      if (i < k_sel) {
-        const uint32_t v = out_sel[i];
-        key = ((unsigned long long)dist_bits[v] << 32) | (unsigned long long)chain.key_view_id[v];
+    if (chain.keys_out) {  // sharded shortlist: the selection as (distance bits << 32 | global view id), padded
+      __syncthreads();
+      for (uint32_t i = tid; i < chain.k_out; i += 1024) {
+        unsigned long long key = ~0ull;
+        if (i < k_sel) {
+          const uint32_t v = out_sel[i];
+          key = ((unsigned long long)dist_bits[v] << 32) | (unsigned long long)chain.key_view_id[v];
+        }
+        chain.keys_out[i] = key;
       }
-      chain.keys_out[i] = key;
     }
+    chain_after_shortlist(chain);  // the query's counters and the block list of the k views (chain_device.h)
   }
-  chain_after_shortlist(chain);  // the query's counters and the block list of the k views (chain_device.h)
+};
+__global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ dist_bits, uint32_t n,
+                                           const uint32_t *__restrict__ cand, uint32_t k,
+                                           uint32_t *__restrict__ out_sel, ChainArgs chain) {
+  BowTopkBody::run(dist_bits, n, cand, k, out_sel, chain);
 }
 
 // ----- sharded shortlist -----------------------------------------------------------------------------
@@ -152,68 +168,86 @@ __global__ __launch_bounds__(1024) void k_bow_topk(const uint32_t *__restrict__ 
 // (non-negative floats order like their bit patterns; equal distances fall to the lower view id, which is how the
 // unsharded k_bow_topk breaks ties because view ids ascend with the view index).  Lists shorter than k are padded
 // with ~0.
-__global__ __launch_bounds__(256) void k_bow_keys(const uint32_t *__restrict__ dist_bits, const uint32_t *__restrict__ sel,
-                                                  uint32_t n_sel, const uint32_t *__restrict__ view_id, uint32_t k,
-                                                  unsigned long long *__restrict__ keys) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= k) return;
-  unsigned long long key = ~0ull;
-  if (i < n_sel) {
-    const uint32_t v = sel[i];
-    key = ((unsigned long long)dist_bits[v] << 32) | (unsigned long long)view_id[v];
+struct BowKeysBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const uint32_t *__restrict__ dist_bits, const uint32_t *__restrict__ sel,
+                                          uint32_t n_sel, const uint32_t *__restrict__ view_id, uint32_t k,
+                                          unsigned long long *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    unsigned long long key = ~0ull;
+    if (i < n_sel) {
+      const uint32_t v = sel[i];
+      key = ((unsigned long long)dist_bits[v] << 32) | (unsigned long long)view_id[v];
+    }
+    keys[i] = key;
   }
-  keys[i] = key;
+};
+__global__ __launch_bounds__(256) void k_bow_keys(const uint32_t *__restrict__ dist_bits, const uint32_t *__restrict__ sel,
+                                          uint32_t n_sel, const uint32_t *__restrict__ view_id, uint32_t k,
+                                          unsigned long long *__restrict__ keys) {
+  BowKeysBody::run(dist_bits, sel, n_sel, view_id, k, keys);
 }
 
 // One 1024-thread workgroup per query: the k smallest of the n_parts x k gathered keys (rank by counting: the keys
 // are distinct), then those whose view id belongs to this shard (binary search in the ascending local id table) as
 // ASCENDING local view indices, padded with the phantom view (index n_views) up to n_pad entries.
 constexpr uint32_t kBowMergeMaxKeys = 8192;
+struct BowMergeSelectBody {
+  static constexpr int kGangThreads = 1024;
+  static __device__ __forceinline__ void run(const unsigned long long *__restrict__ keys, uint32_t n_parts,
+                                                   uint64_t part_stride, uint32_t k,
+                                                   const uint32_t *__restrict__ view_id, uint32_t n_views,
+                                                   uint32_t n_pad, uint32_t *__restrict__ sel_out,
+                                                   ChainArgs chain) {
+    // all scratch in the dynamic region (16-byte aligned base): keys [n_parts * k] u64, then this shard's winners'
+    // local indices [1024] (unordered), then their count
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = n_parts * k;
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(s_raw);
+    uint32_t *s_mine = reinterpret_cast<uint32_t *>(s_raw + (size_t)((n + 1) & ~1u) * 8);
+    uint32_t &s_n_mine = s_mine[1024];
+    if (tid == 0) s_n_mine = 0;
+    for (uint32_t i = tid; i < n; i += 1024) s_keys[i] = keys[(uint64_t)(i / k) * part_stride + (i % k)];
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) {
+      const unsigned long long mine = s_keys[i];
+      if (mine == ~0ull) continue;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n; ++j) rank += (s_keys[j] < mine);
+      if (rank >= k) continue;
+      const uint32_t id = (uint32_t)mine;
+      uint32_t lo = 0, hi = n_views;  // first local view with id >= the key's
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (view_id[mid] < id) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < n_views && view_id[lo] == id) {
+        const uint32_t slot = atomicAdd(&s_n_mine, 1u);
+        if (slot < 1024) s_mine[slot] = lo;
+      }
+    }
+    __syncthreads();
+    const uint32_t n_mine = min(min(s_n_mine, 1024u), n_pad);
+    for (uint32_t i = tid; i < n_pad; i += 1024) sel_out[i] = n_views;  // phantom padding
+    __syncthreads();
+    if (tid < n_mine) {
+      const uint32_t v = s_mine[tid];
+      uint32_t pos = 0;
+      for (uint32_t j = 0; j < n_mine; ++j) pos += (s_mine[j] < v);
+      sel_out[pos] = v;
+    }
+    chain_after_shortlist(chain);
+  }
+};
 __global__ __launch_bounds__(1024) void k_bow_merge_select(const unsigned long long *__restrict__ keys, uint32_t n_parts,
-                                                           uint64_t part_stride, uint32_t k,
-                                                           const uint32_t *__restrict__ view_id, uint32_t n_views,
-                                                           uint32_t n_pad, uint32_t *__restrict__ sel_out,
-                                                           ChainArgs chain) {
-  // all scratch in the dynamic region (16-byte aligned base): keys [n_parts * k] u64, then this shard's winners'
-  // local indices [1024] (unordered), then their count
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t n = n_parts * k;
-  unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(s_raw);
-  uint32_t *s_mine = reinterpret_cast<uint32_t *>(s_raw + (size_t)((n + 1) & ~1u) * 8);
-  uint32_t &s_n_mine = s_mine[1024];
-  if (tid == 0) s_n_mine = 0;
-  for (uint32_t i = tid; i < n; i += 1024) s_keys[i] = keys[(uint64_t)(i / k) * part_stride + (i % k)];
-  __syncthreads();
-  for (uint32_t i = tid; i < n; i += 1024) {
-    const unsigned long long mine = s_keys[i];
-    if (mine == ~0ull) continue;
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < n; ++j) rank += (s_keys[j] < mine);
-    if (rank >= k) continue;
-    const uint32_t id = (uint32_t)mine;
-    uint32_t lo = 0, hi = n_views;  // first local view with id >= the key's
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (view_id[mid] < id) lo = mid + 1;
-      else hi = mid;
-    }
-    if (lo < n_views && view_id[lo] == id) {
-      const uint32_t slot = atomicAdd(&s_n_mine, 1u);
-      if (slot < 1024) s_mine[slot] = lo;
-    }
-  }
-  __syncthreads();
-  const uint32_t n_mine = min(min(s_n_mine, 1024u), n_pad);
-  for (uint32_t i = tid; i < n_pad; i += 1024) sel_out[i] = n_views;  // phantom padding
-  __syncthreads();
-  if (tid < n_mine) {
-    const uint32_t v = s_mine[tid];
-    uint32_t pos = 0;
-    for (uint32_t j = 0; j < n_mine; ++j) pos += (s_mine[j] < v);
-    sel_out[pos] = v;
-  }
-  chain_after_shortlist(chain);
+                                                   uint64_t part_stride, uint32_t k,
+                                                   const uint32_t *__restrict__ view_id, uint32_t n_views,
+                                                   uint32_t n_pad, uint32_t *__restrict__ sel_out,
+                                                   ChainArgs chain) {
+  BowMergeSelectBody::run(keys, n_parts, part_stride, k, view_id, n_views, n_pad, sel_out, chain);
 }
 
 __global__ __launch_bounds__(256) void k_bof_assign(const float *__restrict__ desc, const float *__restrict__ kxy,
@@ -300,46 +334,49 @@ __global__ void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, 
 
 }  // namespace
 
-int launch_bow_select(Map *m, hipStream_t s, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
+int launch_bow_select(Ctx *c, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
                       uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel, const ChainArgs *chain) {
   SFM_CHECK(!chain || (n_cand > 0 && k > 0 && k <= n_cand), SFMLOC_EINVAL, "shortlist chain on an empty shortlist");
   if (n_cand == 0 || k == 0) return SFMLOC_OK;
+  Map *m = c->map;
   ChainArgs C{};
   if (chain) C = *chain;
-  hipLaunchKernelGGL(k_bow_dist, dim3((n_cand + 3) / 4), dim3(256), 0, s, m->d_bow, m->bow_dim, d_cand, n_cand,
-                     d_query, d_dist_bits);
+  sfm_launch<BowDistBody>(c, k_bow_dist, dim3((n_cand + 3) / 4), dim3(256), 0, m->d_bow, m->bow_dim, d_cand, n_cand, d_query,
+                          d_dist_bits);
   SFM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, s, d_dist_bits, n_cand, d_cand, k, d_out_sel, C);
+  sfm_launch<BowTopkBody>(c, k_bow_topk, dim3(1), dim3(1024), 0, d_dist_bits, n_cand, d_cand, k, d_out_sel, C);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
-int launch_bow_keys(Map *m, hipStream_t s, const float *d_query, uint32_t k, uint32_t *d_dist_bits, uint32_t *d_sel_tmp,
+int launch_bow_keys(Ctx *c, const float *d_query, uint32_t k, uint32_t *d_dist_bits, uint32_t *d_sel_tmp,
                     unsigned long long *d_keys_out) {
   if (k == 0) return SFMLOC_OK;
+  Map *m = c->map;
   const uint32_t kk = k < m->n_views ? k : m->n_views;
   if (kk) {  // the keys come out of the selection's own workgroup (no third launch)
     ChainArgs C{};
     C.keys_out = d_keys_out;
     C.key_view_id = m->d_view_id;
     C.k_out = k;
-    hipLaunchKernelGGL(k_bow_dist, dim3((m->n_views + 3) / 4), dim3(256), 0, s, m->d_bow, m->bow_dim,
-                       (const uint32_t *)nullptr, m->n_views, d_query, d_dist_bits);
+    sfm_launch<BowDistBody>(c, k_bow_dist, dim3((m->n_views + 3) / 4), dim3(256), 0, m->d_bow, m->bow_dim,
+                            (const uint32_t *)nullptr, m->n_views, d_query, d_dist_bits);
     SFM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_bow_topk, dim3(1), dim3(1024), 0, s, d_dist_bits, m->n_views, (const uint32_t *)nullptr, kk,
-                       d_sel_tmp, C);
+    sfm_launch<BowTopkBody>(c, k_bow_topk, dim3(1), dim3(1024), 0, d_dist_bits, m->n_views, (const uint32_t *)nullptr, kk,
+                            d_sel_tmp, C);
     SFM_HIP(hipGetLastError());
     return SFMLOC_OK;
   }
-  hipLaunchKernelGGL(k_bow_keys, dim3((k + 255) / 256), dim3(256), 0, s, d_dist_bits, d_sel_tmp, kk, m->d_view_id, k,
-                     d_keys_out);
+  sfm_launch<BowKeysBody>(c, k_bow_keys, dim3((k + 255) / 256), dim3(256), 0, d_dist_bits, d_sel_tmp, kk, m->d_view_id,
+                     k, d_keys_out);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
-int launch_bow_merge_select(Map *m, hipStream_t s, const unsigned long long *d_keys, uint32_t n_parts,
+int launch_bow_merge_select(Ctx *c, const unsigned long long *d_keys, uint32_t n_parts,
                             uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out,
                             const ChainArgs *chain) {
+  Map *m = c->map;
   ChainArgs C{};
   if (chain) C = *chain;
   const uint64_t n = (uint64_t)n_parts * k;
@@ -350,8 +387,8 @@ int launch_bow_merge_select(Map *m, hipStream_t s, const unsigned long long *d_k
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)(kBowMergeMaxKeys * 8 + 1024 * 4 + 16));
   SFM_HIP(attr);
-  hipLaunchKernelGGL(k_bow_merge_select, dim3(1), dim3(1024), lds, s, d_keys, n_parts, part_stride_keys, k, m->d_view_id,
-                     m->n_views, n_pad, d_sel_out, C);
+  sfm_launch<BowMergeSelectBody>(c, k_bow_merge_select, dim3(1), dim3(1024), (uint32_t)lds, d_keys, n_parts, part_stride_keys,
+                                 k, m->d_view_id, m->n_views, n_pad, d_sel_out, C);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

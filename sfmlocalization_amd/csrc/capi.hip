@@ -112,7 +112,7 @@ int drain_events(Ctx *c, double *per_kind_ms = nullptr) {
 
 void free_ctx(Ctx *c) {
   if (!c) return;
-  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->stream.own) hipStreamSynchronize(c->stream.own);
   for (auto &pe : c->pending_events) {
     hipEventDestroy(pe.second.first);
     hipEventDestroy(pe.second.second);
@@ -138,11 +138,16 @@ void free_ctx(Ctx *c) {
   if (c->pinned_busy) hipEventDestroy(c->pinned_busy);
   if (c->xev_out) hipEventDestroy(c->xev_out);
   if (c->xev_in) hipEventDestroy(c->xev_in);
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->gang_ev) hipEventDestroy(c->gang_ev);
+  if (c->gang_owned) {
+    if (c->gang_owned->done) hipEventDestroy(c->gang_owned->done);
+    delete c->gang_owned;
+  }
+  if (c->stream.own && !c->stream_borrowed) hipStreamDestroy(c->stream.own);
   delete c;
 }
 
-int make_ctx(Map *m, Ctx **out) {
+int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr) {
   *out = nullptr;
   Ctx *c = new (std::nothrow) Ctx();
   SFM_CHECK(c, SFMLOC_ENOMEM, "out of host memory");
@@ -165,7 +170,12 @@ int make_ctx(Map *m, Ctx **out) {
       return e_ == hipErrorOutOfMemory ? SFMLOC_ENOMEM : SFMLOC_EHIP; \
     }                                                           \
   } while (0)
-  CTX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (share) {  // no stream (hardware queue) of its own: work is queued on the lender's
+    c->stream.own = share->stream.own;
+    c->stream_borrowed = true;
+  } else {
+    CTX_HIP(hipStreamCreateWithFlags(&c->stream.own, hipStreamNonBlocking));
+  }
   const uint64_t n_pad = (uint64_t)m->n_blocks * kBlockRows;
   uint64_t *acct = &c->hbm_bytes;
   CTX_TRY(dev_alloc(acct, &c->d_part, (size_t)n_pad));
@@ -262,8 +272,14 @@ void free_map(Map *m) {
 // Every counter / flag the stages of one query start from, cleared by ONE launch instead of eight memsets (each a
 // separate ~5 us dispatch on the query's critical path).  The stage functions keep their own memsets for callers
 // that drive them one at a time (Ctx::cleared says which applies).
+struct QueryResetBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(QueryResetArgs R) {
+    query_reset_items(R, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);  // chain_device.h
+  }
+};
 __global__ __launch_bounds__(256) void k_query_reset(QueryResetArgs R) {
-  query_reset_items(R, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);  // chain_device.h
+  QueryResetBody::run(R);
 }
 
 QueryResetArgs make_reset_args(Ctx *c, const Query *q) {
@@ -289,7 +305,7 @@ int ctx_reset_for_query(Ctx *c, const Query *q) {
   }
   const uint32_t nq = q->n ? q->n : 1;
   const uint32_t n = m->n_views + 1 > nq ? m->n_views + 1 : nq;
-  hipLaunchKernelGGL(k_query_reset, dim3((n + 255) / 256), dim3(256), 0, c->stream, make_reset_args(c, q));
+  sfm_launch<QueryResetBody>(c, k_query_reset, dim3((n + 255) / 256), dim3(256), 0, make_reset_args(c, q));
   SFM_HIP(hipGetLastError());
   c->cleared = true;
   return SFMLOC_OK;
@@ -549,6 +565,7 @@ int ctx_resection_wait(Ctx *c) {
   HostResult *h = reinterpret_cast<HostResult *>(c->h_result);
   for (int guard = 0; guard < 64; ++guard) {
     SFM_HIP(hipStreamSynchronize(c->stream));
+    c->stream.dirty = false;
     if (h->state.done) return SFMLOC_OK;
     int rc;
     {
@@ -672,6 +689,56 @@ int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *p
 }
 
 }  // namespace
+
+// gang.h: issue what the members of a gang session have recorded -- the heads of their lists that are the same kernel
+// on the same grid as ONE launch, a head without a partner as a plain launch
+int gang_flush(GangState *g) {
+  int rc = SFMLOC_OK;
+  for (;;) {
+    // the members advance in step: always the earliest position any member still has to issue, and there every member
+    // whose record is the same kernel on the same grid in ONE launch (dynamic LDS: the largest request serves all)
+    size_t pos = SIZE_MAX;
+    for (Ctx *m : g->members)
+      if (m->gang_head < m->gang_recs.size() && m->gang_head < pos) pos = m->gang_head;
+    if (pos == SIZE_MAX) break;
+    GangRec *grp[kGangMembers];
+    int n = 0;
+    GangRec *lead = nullptr;
+    uint32_t shmem = 0;
+    for (Ctx *m : g->members) {
+      if (m->gang_head != pos || pos >= m->gang_recs.size()) continue;
+      GangRec *r = &m->gang_recs[pos];
+      if (lead && !(r->key == lead->key && r->grid.x == lead->grid.x && r->grid.y == lead->grid.y &&
+                    r->grid.z == lead->grid.z && r->block.x == lead->block.x))
+        continue;
+      if (!lead) lead = r;
+      grp[n++] = r;
+      shmem = r->shmem > shmem ? r->shmem : shmem;
+      ++m->gang_head;
+      if (n == lead->cap) break;
+    }
+    const bool together = n > 1 && lead->grid.z == 1;
+    if (together) {
+      lead->shmem = shmem;
+      lead->launch_many(grp, n, g->stream);
+    } else {
+      for (int i = 0; i < n; ++i) grp[i]->launch_one(*grp[i], g->stream);
+    }
+    g->launches += together ? 1 : n;
+    g->gang_launches += together ? 1 : 0;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      set_error("gang launch (%d members, grid %u x %u, %u threads, %u B LDS): %s", n, lead->grid.x, lead->grid.y,
+                lead->block.x, lead->shmem, hipGetErrorString(e));
+      rc = SFMLOC_EHIP;
+    }
+  }
+  for (Ctx *m : g->members) {
+    m->gang_recs.clear();
+    m->gang_head = 0;
+  }
+  return rc;
+}
 
 int match_putative_on(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel) {
   return ctx_match_putative(c, q, view_sel, n_sel);
@@ -907,6 +974,21 @@ int sfmloc_context_create(sfmloc_map *map, sfmloc_context **out) {
   SFM_HIP(hipSetDevice(m->device));
   Ctx *c = nullptr;
   int rc = make_ctx(m, &c);
+  if (rc) return rc;
+  m->pool.push_back(c);
+  m->hbm_bytes += c->hbm_bytes;
+  *out = reinterpret_cast<sfmloc_context *>(c);
+  return SFMLOC_OK;
+}
+
+int sfmloc_context_create_sharing(sfmloc_map *map, sfmloc_context *lender, sfmloc_context **out) {
+  SFM_CHECK(map && lender && out, SFMLOC_EINVAL, "sfmloc_context_create_sharing: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  Ctx *l = reinterpret_cast<Ctx *>(lender);
+  SFM_CHECK(l->map == m, SFMLOC_EINVAL, "sfmloc_context_create_sharing: the lender belongs to another map");
+  SFM_HIP(hipSetDevice(m->device));
+  Ctx *c = nullptr;
+  int rc = make_ctx(m, &c, l);
   if (rc) return rc;
   m->pool.push_back(c);
   m->hbm_bytes += c->hbm_bytes;
@@ -1293,7 +1375,7 @@ int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const fl
     EventScope ev(c, SFMLOC_K_BOW);
     // the workgroup that finishes the shortlist also clears the query's counters and builds the block list
     const ChainArgs chain = make_chain_args(c, q, c->d_bow_sel, knn);
-    rc = launch_bow_select(m, c->stream, query_bow ? c->d_bow_query : q->d_bow, cand_views ? c->d_bow_cand : nullptr,
+    rc = launch_bow_select(c, query_bow ? c->d_bow_query : q->d_bow, cand_views ? c->d_bow_cand : nullptr,
                            n_cand, knn, c->d_bow_dist, c->d_bow_sel, &chain);
   }
   if (rc) return rc;
@@ -1364,7 +1446,7 @@ int sfmloc_shard_bow_keys(sfmloc_context *ctx, sfmloc_query *query, const float 
   if (query_bow)
     SFM_HIP(hipMemcpyAsync(c->d_bow_query, query_bow, m->bow_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
   EventScope ev(c, SFMLOC_K_BOW);
-  return launch_bow_keys(m, c->stream, query_bow ? c->d_bow_query : q->d_bow, knn, c->d_bow_dist, c->d_bow_cand,
+  return launch_bow_keys(c, query_bow ? c->d_bow_query : q->d_bow, knn, c->d_bow_dist, c->d_bow_cand,
                          reinterpret_cast<unsigned long long *>(keys_dev));
 }
 
@@ -1389,7 +1471,7 @@ int sfmloc_shard_begin_bow(sfmloc_context *ctx, sfmloc_query *query, const void 
     EventScope ev(c, SFMLOC_K_BOW);
     // the workgroup that merges the key lists also clears the query's counters and builds the block list
     const ChainArgs chain = make_chain_args(c, q, c->d_bow_sel, n_pad);
-    rc = launch_bow_merge_select(m, c->stream, reinterpret_cast<const unsigned long long *>(keys_dev), n_parts,
+    rc = launch_bow_merge_select(c, reinterpret_cast<const unsigned long long *>(keys_dev), n_parts,
                                  part_stride_keys, knn, n_pad, c->d_bow_sel, n_pad ? &chain : nullptr);
   }
   if (rc) return rc;
@@ -1427,11 +1509,77 @@ int sfmloc_context_wait(sfmloc_context *ctx, void *hip_stream) {
   return SFMLOC_OK;
 }
 
+int sfmloc_gang_begin(sfmloc_context *const *ctxs, uint32_t n) {
+  SFM_CHECK(ctxs && n >= 1 && n <= (uint32_t)kGangMembers, SFMLOC_EINVAL, "sfmloc_gang_begin: 1..%d contexts", kGangMembers);
+  Ctx *lead = reinterpret_cast<Ctx *>(ctxs[0]);
+  SFM_CHECK(lead, SFMLOC_EINVAL, "sfmloc_gang_begin: null context");
+  for (uint32_t i = 0; i < n; ++i) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctxs[i]);
+    SFM_CHECK(c && c->map == lead->map, SFMLOC_EINVAL, "sfmloc_gang_begin: the contexts belong to different maps");
+    SFM_CHECK(c->stream.gang == nullptr, SFMLOC_EINVAL, "sfmloc_gang_begin: context %u is already in a gang session", i);
+    for (uint32_t j = 0; j < i; ++j) SFM_CHECK(ctxs[j] != ctxs[i], SFMLOC_EINVAL, "sfmloc_gang_begin: context listed twice");
+  }
+  // (stage brackets are events on the stream around every launch: with profiling on, the session records nothing and the
+  // members simply run one after the other)
+  if (n == 1 || lead->map->params.profile != 0) return SFMLOC_OK;
+  SFM_HIP(hipSetDevice(lead->map->device));
+  if (!lead->gang_owned) {
+    lead->gang_owned = new (std::nothrow) GangState();
+    SFM_CHECK(lead->gang_owned, SFMLOC_ENOMEM, "out of host memory");
+    lead->gang_owned->stream = lead->stream.own;
+    SFM_HIP(hipEventCreateWithFlags(&lead->gang_owned->done, hipEventDisableTiming));
+  }
+  GangState *g = lead->gang_owned;
+  g->members.clear();
+  for (uint32_t i = 0; i < n; ++i) {
+    Ctx *c = reinterpret_cast<Ctx *>(ctxs[i]);
+    if (i > 0 && c->stream.dirty && c->stream.own != g->stream) {  // the member's own earlier work comes first
+      if (!c->gang_ev) SFM_HIP(hipEventCreateWithFlags(&c->gang_ev, hipEventDisableTiming));
+      SFM_HIP(hipEventRecord(c->gang_ev, c->stream.own));
+      SFM_HIP(hipStreamWaitEvent(g->stream, c->gang_ev, 0));
+      c->stream.dirty = false;
+    }
+    g->members.push_back(c);
+  }
+  for (Ctx *c : g->members) c->stream.gang = g;
+  return SFMLOC_OK;
+}
+
+int sfmloc_gang_end(sfmloc_context *const *ctxs, uint32_t n) {
+  SFM_CHECK(ctxs && n >= 1 && n <= (uint32_t)kGangMembers && ctxs[0], SFMLOC_EINVAL, "sfmloc_gang_end: 1..%d contexts", kGangMembers);
+  Ctx *lead = reinterpret_cast<Ctx *>(ctxs[0]);
+  GangState *g = lead->stream.gang;
+  if (!g) return SFMLOC_OK;  // the session recorded nothing (one member, or profiling)
+  SFM_CHECK(g == lead->gang_owned && g->members.size() == n, SFMLOC_EINVAL, "sfmloc_gang_end: not the contexts of the session");
+  SFM_HIP(hipSetDevice(lead->map->device));
+  const int rc = gang_flush(g);
+  for (Ctx *c : g->members) c->stream.gang = nullptr;
+  lead->stream.dirty = true;
+  // the members' own streams continue after the gang's work
+  bool any_own = false;
+  for (size_t i = 1; i < g->members.size(); ++i) any_own |= g->members[i]->stream.own != g->stream;
+  if (any_own) {
+    SFM_HIP(hipEventRecord(g->done, g->stream));
+    for (size_t i = 1; i < g->members.size(); ++i)
+      if (g->members[i]->stream.own != g->stream) SFM_HIP(hipStreamWaitEvent(g->members[i]->stream.own, g->done, 0));
+  }
+  return rc;  // (gang_flush has set the message)
+}
+
+int sfmloc_gang_counters(sfmloc_context *lead_ctx, uint64_t *launches, uint64_t *gang_launches) {
+  SFM_CHECK(lead_ctx, SFMLOC_EINVAL, "sfmloc_gang_counters: null context");
+  Ctx *c = reinterpret_cast<Ctx *>(lead_ctx);
+  if (launches) *launches = c->gang_owned ? c->gang_owned->launches : 0;
+  if (gang_launches) *gang_launches = c->gang_owned ? c->gang_owned->gang_launches : 0;
+  return SFMLOC_OK;
+}
+
 int sfmloc_context_sync(sfmloc_context *ctx) {
   SFM_CHECK(ctx, SFMLOC_EINVAL, "sfmloc_context_sync: null context");
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   SFM_HIP(hipSetDevice(c->map->device));
   SFM_HIP(hipStreamSynchronize(c->stream));
+  c->stream.dirty = false;
   if (c->in_flight == nullptr) ctx_mark_idle(c);
   return SFMLOC_OK;
 }
@@ -1482,14 +1630,13 @@ static int merge_begin_impl(sfmloc_context *ctx, sfmloc_query *query, const void
     const int rcr = ctx_p3p_reserve(c, q->n);
     if (rcr) return rcr;
   }
-  SFM_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
   int rc;
   {
     EventScope ev(c, SFMLOC_K_MATCHSET);
     if (part_stride == 0) part_stride = sfmloc_part_bytes(cap);
     SFM_CHECK(packed_b || part_stride >= sfmloc_part_bytes(cap), SFMLOC_EINVAL, "sfmloc_merge_begin: part_stride too small");
     rc = launch_select_candidates(c, q, reinterpret_cast<const unsigned char *>(parts_dev), n_parts, part_stride, cap,
-                                  packed_b, packed_qi);
+                                  packed_b, packed_qi, /*reset_status=*/true);
   }
   if (rc) return rc;
   {
@@ -1598,7 +1745,7 @@ int sfmloc_bow_select(sfmloc_map *map, const float *query_bow, const uint32_t *c
   int rc;
   {
     EventScope ev(c, SFMLOC_K_BOW);
-    rc = launch_bow_select(m, c->stream, c->d_bow_query, cand_views ? c->d_bow_cand : nullptr, n_cand, k,
+    rc = launch_bow_select(c, c->d_bow_query, cand_views ? c->d_bow_cand : nullptr, n_cand, k,
                            c->d_bow_dist, c->d_bow_sel);
   }
   if (rc) return rc;
@@ -1619,7 +1766,7 @@ int sfmloc_bow_distances(sfmloc_map *map, const float *query_bow, float *out_dis
   int rc;
   {
     EventScope ev(c, SFMLOC_K_BOW);
-    rc = launch_bow_select(m, c->stream, c->d_bow_query, nullptr, m->n_views, 1, c->d_bow_dist, c->d_bow_sel);
+    rc = launch_bow_select(c, c->d_bow_query, nullptr, m->n_views, 1, c->d_bow_dist, c->d_bow_sel);
   }
   if (rc) return rc;
   // the kernel stores the float32 distance's bit pattern (non-negative floats order like their bits)

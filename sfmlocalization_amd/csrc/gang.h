@@ -1,0 +1,133 @@
+// Gang launches: several contexts of one map take one query each through the same chain of kernels, and every kernel
+// of the chain is launched ONCE for all of them (gridDim.z = member), the members' argument lists side by side in the
+// kernel arguments.  The arithmetic of a member is untouched -- a kernel's body is the same device function whether it
+// is launched alone or in a gang -- only the number of launches changes: a rank of an 8-rank run has 1/8 of the scan
+// per query but every query's launches, and the device completes only so many dependent launches per second
+// (Concurrency).
+//
+// How: between sfmloc_gang_begin and sfmloc_gang_end the members' launchers RECORD their launches (sfm_launch below)
+// instead of issuing them; sfmloc_gang_end walks the members' lists in step and issues, on the gang's stream (the
+// first member's), one gang kernel for every set of heads that are the same kernel with the same grid, and a plain
+// launch for a head that has no partner.  Any other use of a member's stream while recording (a copy, an event, a
+// kernel that has no gang form) first issues what has been recorded, so the order on the stream is always the order
+// of the calls.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <atomic>
+#include <new>
+#include <utility>
+#include <vector>
+
+namespace sfmloc {
+
+constexpr int kGangMembers = 32;      // contexts per session at most
+constexpr int kGangArgBytes = 1008;   // one member's argument list at most
+constexpr int kGangKernargBytes = 3968;  // the members' lists of one launch together (the kernarg segment holds 4 KB)
+
+// a trivially copyable tuple (std::tuple is neither that nor usable in a kernel signature)
+template <size_t I, class T>
+struct TupLeaf {
+  T v;
+};
+template <class Seq, class... Ts>
+struct TupImpl;
+template <size_t... Is, class... Ts>
+struct TupImpl<std::index_sequence<Is...>, Ts...> : TupLeaf<Is, Ts>... {};
+template <class... Ts>
+using Tup = TupImpl<std::index_sequence_for<Ts...>, Ts...>;
+template <size_t I, class T>
+__host__ __device__ __forceinline__ const T &tup_get(const TupLeaf<I, T> &l) {
+  return l.v;
+}
+
+// members one launch of a kernel with these arguments can carry: as many as fit the kernel arguments
+template <class... Ts>
+constexpr int gang_cap() {
+  return (int)(kGangKernargBytes / sizeof(Tup<Ts...>)) < kGangMembers ? (int)(kGangKernargBytes / sizeof(Tup<Ts...>)) : kGangMembers;
+}
+template <int Cap, class... Ts>
+struct GangArgs {
+  Tup<Ts...> a[Cap];
+};
+
+template <class Body, class... Ts, size_t... Is>
+__device__ __forceinline__ void gang_call(const Tup<Ts...> &t, std::index_sequence<Is...>) {
+  Body::run(tup_get<Is>(t)...);
+}
+
+// Body: struct { static constexpr int kGangThreads; __device__ static void run(Ts...); } -- the kernel's body
+template <class Body, int Cap, class... Ts>
+__global__ __launch_bounds__(Body::kGangThreads) void k_gang(GangArgs<Cap, Ts...> g) {
+  gang_call<Body, Ts...>(g.a[blockIdx.z], std::index_sequence_for<Ts...>{});
+}
+
+struct GangRec {
+  const void *key;  // the gang kernel: same key = same body and argument types
+  const void *single;
+  void (*launch_one)(const GangRec &, hipStream_t);
+  void (*launch_many)(GangRec *const *, int, hipStream_t);
+  dim3 grid, block;
+  uint32_t shmem;
+  int cap;  // members one launch of this kernel carries
+  alignas(16) unsigned char args[kGangArgBytes];
+};
+
+struct Ctx;
+struct GangState {
+  hipStream_t stream = nullptr;  // the first member's own stream
+  hipEvent_t done = nullptr;
+  std::vector<Ctx *> members;
+  uint64_t launches = 0, gang_launches = 0;  // issued by flushes (all kinds / with more than one member)
+};
+
+int gang_flush(GangState *g);  // capi.hip
+
+// A context's stream.  Reading it (every hipXxx(..., c->stream) of the launchers) gives the stream work has to be
+// queued on NOW: the context's own, or -- while the context records for a gang -- the gang's, after everything
+// recorded so far has been issued.
+struct CtxStream {
+  hipStream_t own = nullptr;
+  GangState *gang = nullptr;  // non-null while recording
+  bool dirty = false;         // work was queued on `own` since the host last waited for it
+  operator hipStream_t() {
+    if (gang) {
+      gang_flush(gang);
+      return gang->stream;
+    }
+    dirty = true;
+    return own;
+  }
+};
+
+template <class Body, class... Ts>
+struct GangLaunch {
+  using T = Tup<Ts...>;
+  static_assert(sizeof(T) <= kGangArgBytes, "argument list too long for a gang record");
+  static constexpr int kCap = gang_cap<Ts...>();
+  static_assert(kCap >= 2, "argument list too long for a gang launch");
+  static const void *key() { return reinterpret_cast<const void *>(&k_gang<Body, kCap, Ts...>); }
+  template <size_t... Is>
+  static void one_impl(const GangRec &r, hipStream_t s, std::index_sequence<Is...>) {
+    const T &t = *reinterpret_cast<const T *>(r.args);
+    auto k = reinterpret_cast<void (*)(Ts...)>(const_cast<void *>(r.single));
+    hipLaunchKernelGGL(k, r.grid, r.block, r.shmem, s, tup_get<Is>(t)...);
+  }
+  static void one(const GangRec &r, hipStream_t s) { one_impl(r, s, std::index_sequence_for<Ts...>{}); }
+  static void many(GangRec *const *rs, int n, hipStream_t s) {
+    const GangRec &r = *rs[0];
+    static std::atomic<uint32_t> lds_allowed{48 * 1024};  // (dynamic LDS beyond the default needs the attribute)
+    if (r.shmem > lds_allowed.load(std::memory_order_relaxed)) {
+      if (hipFuncSetAttribute(key(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r.shmem) != hipSuccess)
+        return;  // (the error stays for the caller's hipGetLastError)
+      lds_allowed.store(r.shmem, std::memory_order_relaxed);
+    }
+    GangArgs<kCap, Ts...> g;
+    for (int i = 0; i < n; ++i) g.a[i] = *reinterpret_cast<const T *>(rs[i]->args);
+    for (int i = n; i < kCap; ++i) g.a[i] = g.a[0];
+    hipLaunchKernelGGL((k_gang<Body, kCap, Ts...>), dim3(r.grid.x, r.grid.y, n), r.block, r.shmem, s, g);
+  }
+};
+
+}  // namespace sfmloc

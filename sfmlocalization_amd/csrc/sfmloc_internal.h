@@ -11,6 +11,7 @@
 
 #include "../../include/sfmloc.h"
 #include "chain_device.h"
+#include "gang.h"
 
 namespace sfmloc {
 
@@ -160,7 +161,12 @@ struct Map {
 // Hamming kernel of another).
 struct Ctx {
   Map *map = nullptr;
-  hipStream_t stream = nullptr;
+  CtxStream stream;  // gang.h: reads as the stream to queue on now (the context's own, or its gang's while recording)
+  bool stream_borrowed = false;    // stream.own belongs to another context (sfmloc_context_create_sharing)
+  std::vector<GangRec> gang_recs;  // launches recorded for the gang session in progress
+  size_t gang_head = 0;
+  GangState *gang_owned = nullptr;  // this context has led a gang: its state (stream = this context's own)
+  hipEvent_t gang_ev = nullptr;     // orders the gang's stream after this member's own earlier work
   uint64_t hbm_bytes = 0;
 
   // --- putative stage ---
@@ -261,6 +267,31 @@ struct Ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
 };
 
+// A launch of a kernel that has a gang form (Body: the kernel's body, gang.h): issued at once on the context's stream,
+// or recorded when the context is a member of a gang session.  `single` is the kernel itself.
+template <class... Ts, size_t... Is, class... As>
+inline void gang_store_args(void *dst, std::index_sequence<Is...>, As &&...as) {
+  new (dst) Tup<Ts...>{TupLeaf<Is, Ts>{static_cast<Ts>(as)}...};
+}
+template <class Body, class... Ts, class... As>
+inline void sfm_launch(Ctx *c, void (*single)(Ts...), dim3 grid, dim3 block, uint32_t shmem, As &&...as) {
+  if (!c->stream.gang) {
+    hipLaunchKernelGGL(single, grid, block, shmem, (hipStream_t)c->stream, static_cast<Ts>(as)...);
+    return;
+  }
+  c->gang_recs.emplace_back();
+  GangRec &r = c->gang_recs.back();
+  r.key = GangLaunch<Body, Ts...>::key();
+  r.cap = GangLaunch<Body, Ts...>::kCap;
+  r.single = reinterpret_cast<const void *>(single);
+  r.launch_one = &GangLaunch<Body, Ts...>::one;
+  r.launch_many = &GangLaunch<Body, Ts...>::many;
+  r.grid = grid;
+  r.block = block;
+  r.shmem = shmem;
+  gang_store_args<Ts...>(r.args, std::index_sequence_for<Ts...>{}, as...);
+}
+
 struct Query {
   Map *map = nullptr;
   uint32_t n = 0, width = 0, height = 0;
@@ -295,13 +326,13 @@ struct BofModel {
   hipStream_t stream = nullptr;
 };
 struct ChainArgs;  // chain_device.h: what the shortlist's workgroup does on top of the shortlist (may be null)
-int launch_bow_select(Map *m, hipStream_t s, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
+int launch_bow_select(Ctx *c, const float *d_query, const uint32_t *d_cand, uint32_t n_cand,
                       uint32_t k, uint32_t *d_dist_bits, uint32_t *d_out_sel, const ChainArgs *chain = nullptr);
 // sharded shortlist: this shard's k best as sortable keys (distance bits << 32 | global view id), and
 // the shard's part of the global k best among n_parts key lists
-int launch_bow_keys(Map *m, hipStream_t s, const float *d_query, uint32_t k, uint32_t *d_dist_bits, uint32_t *d_sel_tmp,
+int launch_bow_keys(Ctx *c, const float *d_query, uint32_t k, uint32_t *d_dist_bits, uint32_t *d_sel_tmp,
                     unsigned long long *d_keys_out);
-int launch_bow_merge_select(Map *m, hipStream_t s, const unsigned long long *d_keys, uint32_t n_parts,
+int launch_bow_merge_select(Ctx *c, const unsigned long long *d_keys, uint32_t n_parts,
                             uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out,
                             const ChainArgs *chain = nullptr);
 int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const float *d_kxy, int n, uint32_t *d_counts,
@@ -322,7 +353,8 @@ int launch_export_part(Ctx *c, void *dst_dev, uint32_t cap);
 // packed_b > 0: `parts` are packed batch parts of packed_b queries (acransac.hip PartLayout), cap = their budget,
 // and this query is number packed_qi of the batch
 int launch_select_candidates(Ctx *c, const Query *q, const unsigned char *parts, uint32_t n_parts,
-                             uint64_t part_bytes, uint32_t cap, uint32_t packed_b = 0, uint32_t packed_qi = 0);
+                             uint64_t part_bytes, uint32_t cap, uint32_t packed_b = 0, uint32_t packed_qi = 0,
+                             bool reset_status = false);  // (also clear the context's status word: sfmloc_merge_begin)
 int launch_export_packed(Ctx *c, void *dst_dev, uint32_t n_queries, uint32_t budget, uint32_t qi);
 uint64_t packed_part_bytes(uint32_t n_queries, uint32_t budget);
 int ctx_p3p_reserve(Ctx *c, uint32_t n_query_rows);  // capi.hip: grow the P3P workspace to a query's feature count

@@ -342,19 +342,39 @@ class HipShardCompute:
 
     n_slots = 2
 
-    def __init__(self, shard_map, cap=None, n_contexts=4, device=None):
+    def __init__(self, shard_map, cap=None, n_contexts=4, device=None, gang=None):
+        import os
         import torch
+        from . import capi
+        # stage 1 of `gang` queries per launch (sfmloc_gang_begin/_end): a rank has 1/N of the scan per query but every
+        # query's launches, so with more ranks the launches are what is left.  SFMLOC_GANG=1 turns it off.
+        g = int(os.environ.get("SFMLOC_GANG", "0")) if gang is None else int(gang)
+        self.gang = max(1, min(capi.GANG_MAX, g if g > 0 else 1))
+        self.n_stage2 = 8 if self.gang == 1 else capi.GANG_MAX   # queries in stage 2 at a time
         self.map = shard_map
         self.device = torch.device("cuda", shard_map.params.device) if device is None else device
         self.comm = torch.cuda.Stream(self.device)
-        self.ctxs = [[shard_map.context() for _ in range(n_contexts)] for _ in range(self.n_slots)]
+        self.ctxs = []
+        for _ in range(self.n_slots):
+            cs = []
+            for k in range(n_contexts):     # a gang's first context owns the stream the whole gang works on
+                cs.append(shard_map.context(share=None if k % self.gang == 0 else cs[k - k % self.gang]))
+            self.ctxs.append(cs)
+        # stage 2 is one chain of launches per query: it wants a stream per query in flight, which the gangs' members
+        # do not have -- contexts of its own then, shared by the slots (a batch's stage 2 ends before the next one's begins)
+        self.ctx2 = None
+        if self.gang > 1:
+            self.ctx2 = [shard_map.context()]
+            self.ctx2 += [shard_map.context(share=self.ctx2[0]) for _ in range(self.n_stage2 - 1)]
         self._buf = {}
         self._queries = [None] * self.n_slots
 
     def close(self):
         for cs in self.ctxs:
-            for c in cs:
+            for c in reversed(cs):          # (a gang's members before the context whose stream they borrow)
                 c.close()
+        for c in reversed(self.ctx2 or []):
+            c.close()
 
     def _tensor(self, name, slot, shape, dtype):
         """persistent per (name, slot, shape): the C ABI writes every byte that is read back, so no clearing (and a
@@ -368,22 +388,51 @@ class HipShardCompute:
             self._buf[key] = t
         return t
 
+    def _streams(self, slot):
+        """one context per stream of the slot (a gang's members work on its first context's stream)"""
+        return self.ctxs[slot][::self.gang]
+
     def before_collective(self, slot=0):
-        for c in self.ctxs[slot]:
+        for c in self._streams(slot):
             c.signal(self.comm.cuda_stream)       # the collective waits for the slot's queued work
 
     def after_collective(self, slot=0):
-        for c in self.ctxs[slot]:
+        for c in self._streams(slot):
             c.wait(self.comm.cuda_stream)         # the slot's later work waits for the collective
+
+    def _gangs(self, slot, n_queries):
+        """the slot's contexts in gangs of `self.gang`, and for each gang the rounds of (context, query index) it runs:
+        query i goes to context i mod n as before; a round of a gang is one gang session"""
+        from . import capi
+        cs = self.ctxs[slot]
+        n = len(cs)
+        for g0 in range(0, n, self.gang):
+            members = list(range(g0, min(n, g0 + self.gang)))
+            for base in range(0, n_queries, n):
+                work = [(cs[k], base + k) for k in members if base + k < n_queries]
+                if work:
+                    yield capi.gang([c for c, _ in work]), work
+
+    def _rounds(self, slot, n_queries):
+        """every (session, work) in an order that keeps the gangs' streams equally loaded"""
+        per_gang = {}
+        for sess, work in self._gangs(slot, n_queries):
+            per_gang.setdefault(id(work[0][0]), []).append((sess, work))
+        lists = list(per_gang.values())
+        for r in range(max((len(x) for x in lists), default=0)):
+            for x in lists:
+                if r < len(x):
+                    yield x[r]
 
     def bow_keys(self, queries, knn, slot=0):
         import torch
         B = len(queries)
         keys = self._tensor("keys", slot, (B, knn), torch.int64)
-        cs = self.ctxs[slot]
         base = keys.data_ptr()
-        for i, q in enumerate(queries):
-            cs[i % len(cs)].shard_bow_keys(q, knn, base + i * knn * 8)
+        for sess, work in self._rounds(slot, B):
+            with sess:
+                for c, i in work:
+                    c.shard_bow_keys(queries[i], knn, base + i * knn * 8)
         return keys
 
     def _packed(self, slot, B, budget):
@@ -402,12 +451,12 @@ class HipShardCompute:
         world = keys_all.shape[0]
         part = self._packed(slot, B, budget)
         base, kbase = part.data_ptr(), keys_all.data_ptr()
-        cs = self.ctxs[slot]
-        for i, q in enumerate(queries):
-            c = cs[i % len(cs)]
-            # query i's key lists: keys_all[r, i, :] for r in range(world) -> stride B*knn keys
-            c.shard_begin_bow(q, kbase + i * knn * 8, world, knn, part_stride_keys=B * knn)
-            c.shard_export_packed(base, B, budget, i)
+        for sess, work in self._rounds(slot, B):
+            with sess:
+                for c, i in work:
+                    # query i's key lists: keys_all[r, i, :] for r in range(world) -> stride B*knn keys
+                    c.shard_begin_bow(queries[i], kbase + i * knn * 8, world, knn, part_stride_keys=B * knn)
+                    c.shard_export_packed(base, B, budget, i)
         self._queries[slot] = queries
         return part
 
@@ -415,12 +464,12 @@ class HipShardCompute:
         B = len(queries)
         part = self._packed(slot, B, budget)
         base = part.data_ptr()
-        cs = self.ctxs[slot]
-        for i, q in enumerate(queries):
-            c = cs[i % len(cs)]
-            # K1..K3 + candidate emission, asynchronous; view_sels[i]: this shard's views to scan
-            c.shard_begin(q, None if view_sels is None else view_sels[i])
-            c.shard_export_packed(base, B, budget, i)  # on the same stream
+        for sess, work in self._rounds(slot, B):
+            with sess:
+                for c, i in work:
+                    # K1..K3 + candidate emission, asynchronous; view_sels[i]: this shard's views to scan
+                    c.shard_begin(queries[i], None if view_sels is None else view_sels[i])
+                    c.shard_export_packed(base, B, budget, i)  # on the same stream
         self._queries[slot] = queries
         return part
 
@@ -428,10 +477,22 @@ class HipShardCompute:
         world, pb = gathered.shape
         base = gathered.data_ptr()
         out = {}
-        cs = self.ctxs[slot]
-        n = len(cs)
         queries = self._queries[slot]
         B = len(queries)
+        if self.ctx2 is not None:
+            # gang sessions: the 2D-3D selection and every P3P round of up to len(ctx2) queries per launch
+            from . import capi
+            cs = self.ctx2
+            for k0 in range(0, len(indices), len(cs)):
+                chunk = indices[k0:k0 + len(cs)]
+                with capi.gang(cs[:len(chunk)]):
+                    for c, i in zip(cs, chunk):
+                        c.merge_begin_packed(queries[i], base, world, B, budget, i, part_stride=pb)
+                for c, i in zip(cs, chunk):
+                    out[i] = _pose_tuple(c.end())
+            return out
+        cs = self.ctxs[slot]
+        n = len(cs)
         pending = []
         for k, i in enumerate(indices):
             c = cs[k % n]

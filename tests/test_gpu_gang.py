@@ -1,0 +1,142 @@
+"""GPU: gang sessions (sfmloc_gang_begin / _end, include/sfmloc.h) -- several contexts taken through the same chain
+with ONE launch per kernel.  A member's arithmetic is the kernel's own body, so every result must be what the same calls
+give one context at a time, bit for bit."""
+import numpy as np
+import pytest
+
+import sfmlocalization_amd as S
+import synthdata as synth
+from sfmlocalization_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def scene(seed, n_views=60):
+    m = synth.make_map(seed, n_views=n_views, desc_per_view=400, views_per_place=10, landmarks_per_place=300,
+                       obs_per_view=140)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    place_bow = rng.uniform(0, 1, (len(m.place_center), 64)).astype(np.float32)
+    bow = (place_bow[m.view_place] + rng.normal(0, 0.05, (m.n_views, 64))).astype(np.float32)
+    return m, bow, place_bow
+
+
+def device_map(m, bow, v0=0, v1=None, **params):
+    v1 = m.n_views if v1 is None else v1
+    r0, r1 = int(m.view_off[v0]), int(m.view_off[v1])
+    return S.Map(m.view_id[v0:v1], m.view_off[v0:v1 + 1] - m.view_off[v0], m.desc[r0:r1],
+                 params=S.default_params(ransac_round=25, **params), view_wh=m.view_wh[v0:v1], kpt_xy=m.kpt_xy[r0:r1],
+                 row_landmark=m.row_landmark[r0:r1], landmark_id=m.landmark_id, landmark_X=m.landmark_X,
+                 intrinsic=m.intrinsic, bow=bow[v0:v1])
+
+
+def same(a, b):
+    assert a[0].ok == b[0].ok and a[0].n_inliers == b[0].n_inliers
+    assert a[0].n_putative_views == b[0].n_putative_views and a[0].n_geometric_views == b[0].n_geometric_views
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(bits(np.array(a[0].P)), bits(np.array(b[0].P)))
+    np.testing.assert_array_equal(bits(np.array(a[0].center)), bits(np.array(b[0].center)))
+
+
+@pytest.mark.parametrize("own_streams", [False, True])
+def test_whole_path_in_a_gang_equals_one_at_a_time(own_streams):
+    """sfmloc_localize_bow_begin on 5 contexts inside one session (members with and without a stream of their own), and
+    again with a member left out and different queries: the poses, inlier pairs and view counts of the plain calls."""
+    m, bow, place_bow = scene(41)
+    rng = np.random.Generator(np.random.PCG64(7))
+    with device_map(m, bow) as dm:
+        qs = [synth.make_query(m, 500 + k, n_feat=700 + 37 * k, n_copies=200, outlier_frac=0.3) for k in range(9)]
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in qs]
+        qbow = [(place_bow[q.place] + rng.normal(0, 0.05, 64)).astype(np.float32) for q in qs]
+        for dq, b in zip(dqs, qbow):
+            dq.set_bow(b)
+        ref = [dm.localize_bow(dq, b, 20) for dq, b in zip(dqs, qbow)]
+        assert sum(int(r[0].ok) for r in ref) >= 6
+        lead = dm.context()
+        ctxs = [lead] + [dm.context(share=None if own_streams else lead) for _ in range(4)]
+        for first in (0, 4):
+            part = list(zip(ctxs, range(first, first + 5)))
+            if first:
+                part = part[:2] + part[3:]                      # a session need not use every context it could
+            with capi.gang([c for c, _ in part]):
+                for c, i in part:
+                    c.begin_bow(dqs[i], None, 20)
+            for c, i in part:
+                same(c.end(), ref[i])
+        launches, ganged = capi.gang_counters(lead)
+        assert ganged >= 15 and launches < 3 * ganged           # the chain went out as gang launches
+        # a plain call on a member right after a session sees the session's work as done (stream order)
+        ctxs[1].begin_bow(dqs[0], None, 20)
+        same(ctxs[1].end(), ref[0])
+        # misuse
+        with pytest.raises(S.SfmlocError):
+            with capi.gang([lead, lead]):
+                pass
+        with capi.gang([lead, ctxs[1]]):
+            with pytest.raises(S.SfmlocError):
+                capi._check(capi._L().sfmloc_gang_begin((capi.C.c_void_p * 1)(ctxs[1]._h), 1))
+        for c in reversed(ctxs):
+            c.close()
+        for dq in dqs:
+            dq.close()
+
+
+def test_profiled_sessions_and_single_members_run_plainly():
+    """params.profile = 1 (stage brackets are events on the stream): a session records nothing, results unchanged."""
+    m, bow, place_bow = scene(42, n_views=40)
+    with device_map(m, bow, profile=1) as dm:
+        qs = [synth.make_query(m, 600 + k, n_feat=600, n_copies=200, outlier_frac=0.3) for k in range(3)]
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in qs]
+        for dq, q in zip(dqs, qs):
+            dq.set_bow(place_bow[q.place])
+        ref = [dm.localize_bow(dq, place_bow[q.place], 10) for dq, q in zip(dqs, qs)]
+        ctxs = [dm.context() for _ in range(3)]
+        with capi.gang(ctxs):
+            for c, dq in zip(ctxs, dqs):
+                c.begin_bow(dq, None, 10)
+        for c, r in zip(ctxs, ref):
+            got = c.end()
+            same(got, r)
+            assert sum(got[0].stage_seconds[:6]) > 0.0            # the brackets were taken
+        assert capi.gang_counters(ctxs[0]) == (0, 0)
+        for c in ctxs:
+            c.close()
+        for dq in dqs:
+            dq.close()
+
+
+@pytest.mark.parametrize("gang", [3, 16])
+def test_sharded_layer_with_gangs_equals_without(gang):
+    """dist.HipShardCompute with stage 1 and stage 2 in gang sessions (stream-less members, stage-2 contexts of its own)
+    against the same layer one query per launch, through the sharded BoW shortlist and the packed exchange; world 1
+    and an emulated second shard's keys / parts are not needed for this: the compute object is what changes."""
+    import torch
+    from sfmlocalization_amd import dist as D
+    m, bow, place_bow = scene(43)
+    dev = torch.device("cuda", 0)
+    with device_map(m, bow) as dm:
+        qs = [synth.make_query(m, 700 + k, n_feat=650, n_copies=200, outlier_frac=0.3) for k in range(11)]
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in qs]
+        for dq, q in zip(dqs, qs):
+            dq.set_bow(place_bow[q.place])
+        out = {}
+        for g in (1, gang):
+            comp = D.HipShardCompute(dm, n_contexts=2 * g if g > 1 else 4, device=dev, gang=g)
+            loc = D.ShardedLocalizer(comp, rank=0, world=1, n_views_global=m.n_views)
+            batches = [dqs[:7], dqs[7:], dqs[2:9]]
+            out[g] = list(loc.localize_stream(batches, bow_knn=15))
+            comp.close()
+        for a, b in zip(out[1], out[gang]):
+            assert sorted(a) == sorted(b)
+            for i in a:
+                assert a[i]["ok"] == b[i]["ok"] and a[i]["n_inliers"] == b[i]["n_inliers"]
+                np.testing.assert_array_equal(a[i]["pair_qfeat"], b[i]["pair_qfeat"])
+                np.testing.assert_array_equal(a[i]["pair_landmark"], b[i]["pair_landmark"])
+                np.testing.assert_array_equal(bits(a[i]["P"].ravel()), bits(b[i]["P"].ravel()))
+        assert sum(int(r["ok"]) for r in out[1][0].values()) >= 4
+        for dq in dqs:
+            dq.close()

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--in-flight", type=int, default=8, help="contexts per slot (the sharded path keeps two slots)")
     ap.add_argument("--gang", type=int, default=0, help="queries per launch in stage 1 (0 = the library's default)")
+    ap.add_argument("--only-stage1", action="store_true", help="diagnosis: no query is owned here (stage 2 never runs)")
     a = ap.parse_args()
     N, B = a.of, a.batch
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, 2 * a.in_flight + 2))))
@@ -65,7 +66,8 @@ def main():
     budget = B * 256
     # ---- the other ranks' halves of the two exchanges, once --------------------------------------------------------
     maps = [shard(r, N) for r in range(N)]
-    comps = [D.HipShardCompute(dm, n_contexts=(a.in_flight if r == 0 else 2), device=dev) for r, (dm, _) in enumerate(maps)]
+    comps = [D.HipShardCompute(dm, n_contexts=(a.in_flight if r == 0 else 2), device=dev, gang=(a.gang or None) if r == 0 else 1)
+             for r, (dm, _) in enumerate(maps)]
     keys = []
     for comp, (dm, dqs) in zip(comps, maps):
         k = comp.bow_keys([dqs[i] for i in batch_ids], a.bow_knn, 0)
@@ -105,8 +107,19 @@ def main():
             return out, ev
 
     loc = Emulated(comp, rank=0, world=N, n_views_global=a.views)
-    if a.gang:
-        comp.gang = a.gang
+    host = {}                                   # host seconds inside each of the compute object's calls
+
+    def timed(name):
+        f = getattr(comp, name)
+
+        def g(*x, **k):
+            t = time.perf_counter()
+            r = f(*x, **k)
+            host[name] = host.get(name, 0.0) + time.perf_counter() - t
+            return r
+        setattr(comp, name, g)
+    for name in ("bow_keys", "stage1_bow", "stage2"):
+        timed(name)
     batch = [dqs0[i] for i in batch_ids]
 
     # ---- the emulated exchange is the real one: rank 0's queries against the unsharded path --------------------------
@@ -133,7 +146,10 @@ def main():
         torch.cuda.synchronize()
         return ok
 
+    if a.only_stage1:
+        loc.owner = lambda i: -1
     run(a.warmup)
+    host.clear()
     t0 = time.perf_counter()
     ok = run(a.steps)
     dt = time.perf_counter() - t0
@@ -141,6 +157,7 @@ def main():
         "emulated": f"rank 0 of {N}", "batch": B, "steps": a.steps, "contexts_per_slot": a.in_flight,
         "queries_per_launch_stage1": getattr(comp, "gang", 1),
         "ms_per_batch": dt / a.steps * 1e3,
+        "host_ms_per_batch_in": {k: v / a.steps * 1e3 for k, v in host.items()},
         "rank_rate_queries_per_s": a.steps * B / dt,
         "note": "all ranks work in lock step, so this is also the predicted whole-job rate of N ranks, collectives' "
                 "latency excluded",
