@@ -63,6 +63,9 @@ def parse(argv=None):
                          "640x480 image on the GPU (sfmloc_akaze_detect_and_compute, its own stream); --in-flight worker "
                          "threads, one extractor and one context each.  The map is synthetic, so the localised descriptors "
                          "are the synthetic query's, not the image's: the point is the cost of extraction sharing the GPU")
+    ap.add_argument("--gang", type=int, default=0,
+                    help="--gpus > 1: queries per launch in both stages of the sharded path (gang sessions, "
+                         "sfmloc_gang_begin/_end); 0 = 16 with more than one rank, 1 = one query per launch")
     ap.add_argument("--threads", type=int, default=0,
                     help="host threads driving the contexts (1 GPU, no shortlist collective): 0/1 = one thread round-robins "
                          "all contexts; N > 1 = N threads, each with its share of the contexts (the C ABI calls release the "
@@ -272,13 +275,20 @@ def main():
     # longer get a hardware queue each and the rate drops by 40 %, profiles/r02_sharded_inflight_sweep.txt)
     # (images in: a worker thread owns an extractor stream and a context; 4 workers = 8 streams is the measured optimum,
     # 12 workers -- 24 streams -- run at a third of it, profiles/r02_image_in_sweep.txt)
-    nctx = a.in_flight if a.in_flight > 0 else (4 if a.from_images else ((8 if sharded_mode else 12) if shortlist else 4))
+    # (N ranks: a rank scans 1/N of the map per query but issues every query's launches, and a device serves few
+    # hardware queues well -- 16 queries per launch on 2 streams per slot instead of 8 streams with a query each:
+    # tools/rank_emulation.py, profiles/r02_rank_emulation.jsonl)
+    gang = a.gang if a.gang > 0 else (16 if world > 1 else int(os.environ.get("SFMLOC_GANG", "1")))
+    gang = gang if sharded_mode else 1
+    nctx = a.in_flight if a.in_flight > 0 else (4 if a.from_images else
+                                                (((32 if gang > 1 else 8) if sharded_mode else 12) if shortlist else 4))
     if a.threads == 0 and shortlist and nctx >= 8 and not a.from_images and not sharded_mode:
         a.threads = 4
     # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
     # (so does the image-in mode: a context and an extractor stream per worker)
     # (+2: the map's own stream and torch's; measured: 8 contexts on 8 queues lose 20 % to two streams sharing one)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, (2 * nctx if sharded_mode else nctx) + 2))))
+    n_streams = (2 * -(-nctx // gang) + 1) if gang > 1 else (2 * nctx if sharded_mode else nctx)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, n_streams + 2))))
 
     import numpy as np
     sys.path.insert(0, ROOT)
@@ -334,7 +344,7 @@ def main():
     xchg = {}
     if sharded_mode:
         from sfmlocalization_amd import dist as D
-        comp = D.HipShardCompute(dev_map, n_contexts=nctx, device=torch.device("cuda", local_rank))
+        comp = D.HipShardCompute(dev_map, n_contexts=nctx, device=torch.device("cuda", local_rank), gang=gang)
         sharded = D.ShardedLocalizer(comp, rank=rank, world=world, always_gather=forced and dist is not None,
                                      n_views_global=a.views)
     ctxs = [dev_map.context() for _ in range(nctx)] if sharded is None else []
@@ -549,6 +559,7 @@ def main():
                        "views": a.views, "rows": int(m.n_rows), "nq": a.nq, "bow_knn": a.bow_knn, "batch": a.batch,
                        "queries_per_step": a.batch, "queries_timed": n_timed, "in_flight_per_gpu": nctx,
                        "host_threads": max(1, a.threads) if sharded is None else 1,
+                       **({"queries_per_launch": gang} if sharded is not None else {}),
                        "parallelism": (f"bank + .bow sharded by view x{world}; per {a.batch}-query batch one all-gather of "
                                        "per-shard k-best BoW keys and ONE all-gather of candidate parts (RCCL), P3P of "
                                        "query i on rank i mod N" if world > 1 else "1 GPU, whole bank"),

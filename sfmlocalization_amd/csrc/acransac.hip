@@ -835,293 +835,11 @@ __device__ void bitonic_sort_wave(uint64_t *kw, uint32_t *iw, int P) {
 struct FmatrixFastBody {
   static constexpr int kGangThreads = kF2Threads;
   static __device__ __forceinline__ void run(FFilterArgs A) {
-    extern __shared__ unsigned char smem_raw[];
-    F2Shared &S = *reinterpret_cast<F2Shared *>(smem_raw);
-    const int tid = threadIdx.x;
-    const int wv = tid >> 6, lane = tid & 63;
-    STAMP_F_DECL;
-    STAMP_F(1);
-    const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
-    if (A.merge.enabled) {  // K2 for this view (chain_device.h), by one wave; the others wait for its lists
-      if (wv == 0) merge_ratio_masked_view(A.merge, blockIdx.x, (uint32_t)lane);
-      __syncthreads();
-    }
-    const int m = (int)A.put_count[v];
-    const uint32_t off = A.view_off[v];
-    constexpr int s = 7;
-    if (m > kF2MaxM) return;  // k_fmatrix_filter handles this view
-    if (m < A.min_putative || m <= s) {  // localization.cpp:408-415 ; ACRANSAC: nData <= sizeSample
-      if (tid == 0) A.geo_count[v] = 0;
-      return;
-    }
-    // NormalizePoints(x, w, h) for both images
-    const int w1 = (int)A.view_wh[2 * v], h1 = (int)A.view_wh[2 * v + 1];
-    const int w2 = (int)A.qw, h2 = (int)A.qh;
-    const double s1 = 1.0 / sqrt((double)(w1 * h1)), s2 = 1.0 / sqrt((double)(w2 * h2));
-    const double t1x = -0.5 * (double)w1 * s1, t1y = -0.5 * (double)h1 * s1;
-    const double t2x = -0.5 * (double)w2 * s2, t2y = -0.5 * (double)h2 * s2;
-    const double Dg = sqrt((double)w2 * (double)w2 + (double)h2 * (double)h2);
-    const double Ar = (double)w2 * (double)h2;
-    const double logalpha0 = det_log10(2.0 * Dg / Ar / s2);
-    const double max_thr = (A.precision * A.precision) * s2 * s2;
-    const double loge0 = det_log10(3.0 * (double)(m - s));
-    const uint32_t stream = A.view_id[v];
-    const int P = next_pow2(m);
-
-    for (int p = tid; p < m; p += kF2Threads) {
-      const uint32_t i = A.match_i[off + p];
-      const uint32_t j = A.match_key[off + p] & 0xFFFFu;
-      const float2 a = A.map_kpt[off + i];
-      const float2 b = A.q_kpt6[j];
-      S.pts[0][p] = s1 * (double)a.x + t1x;
-      S.pts[1][p] = s1 * (double)a.y + t1y;
-      S.pts[2][p] = s2 * (double)b.x + t2x;
-      S.pts[3][p] = s2 * (double)b.y + t2y;
-    }
-    // logcombi tables (logcombi_tables_block is written for 256 threads); pre_models is free until the first batch
-    logc_n_block(m, A.L10, &S.pre_models[0][0], S.logc_n, kF2Threads);
-    for (int q = tid; q <= m; q += kF2Threads) {
-      float val = 0.0f;
-      if (s < q) {
-        int k = s;
-        if (q - k < k) k = q - k;
-        double r = 0.0;
-        for (int i = 1; i <= k; ++i) r += A.L10[q - i + 1] - A.L10[i];
-        val = (float)r;
-      }
-      S.logc_k[q] = val;
-    }
-    __syncthreads();
-    STAMP_F(2);  // prelude done (value: m in the low bits is not needed; the tool reads put_count)
-
-    // (the lambdas below must not capture the kernel-argument struct: that would put all of it on the stack)
-    const uint64_t seed = A.seed;
-    F2Shared *const Sp = &S;
-    // this wave: sample iteration `it`, solve, store the models at `models` / the count at *nm_out
-    auto wave_solve = [Sp, seed, stream, lane](const int32_t *vec_index, int n_index, long it, double *models,
-                                               int *nm_out) {
-      F2Shared &S = *Sp;
-      int32_t smp[7];
-      ac_sample<7>(vec_index, n_index, seed, STAGE_FMATRIX, stream, (uint32_t)it, smp);
-      const int r = lane / 9;
-      int pidx = smp[0];
-#pragma unroll
-      for (int q = 1; q < 7; ++q)
-        if (r == q) pidx = smp[q];
-      double f = 0.0;
-      const int nm = wave_seven_point(S.pts[0][pidx], S.pts[1][pidx], S.pts[2][pidx], S.pts[3][pidx], &f);
-      if (lane < 9 * nm) models[lane] = f;
-      if (lane == 0) *nm_out = nm;
-    };
-    // this wave: residuals of model M over all matches, sorted in registers, bestNFA; the sorted match indices go
-    // to the wave's LDS segment (S.idx[wv]) for whoever needs the inlier list afterwards
-    auto eval_e = [Sp, lane, wv, m, max_thr, logalpha0, loge0](const double *Mp, auto e_tag) -> NfaBest {
-      constexpr int E = decltype(e_tag)::value;
-      F2Shared &S = *Sp;
-      double M[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) M[q] = Mp[q];
-      uint64_t key[E];
-      uint32_t idx[E];
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const int p = (r << 6) + lane;
-        uint64_t kv = ~0ull;
-        if (p < m) kv = d2u(err_fmatrix(M, S.pts[0][p], S.pts[1][p], S.pts[2][p], S.pts[3][p]));
-        key[r] = kv;
-        idx[r] = (uint32_t)p;
-      }
-      uint32_t *iw = S.idx[wv];
-      wave_sort_fast<E>(key, idx, iw);
-#pragma unroll
-      for (int r = 0; r < E; ++r) iw[(r << 6) + lane] = idx[r];
-      return best_nfa_regs<E>(key, m, 7, max_thr, logalpha0, 0.5, loge0, S.logc_n, S.logc_k);
-    };
-    auto wave_eval = [&eval_e, P](const double *Mp) -> NfaBest {
-      switch (P >> 6) {
-        case 1: return eval_e(Mp, std::integral_constant<int, 1>{});
-        case 2: return eval_e(Mp, std::integral_constant<int, 2>{});
-        case 4: return eval_e(Mp, std::integral_constant<int, 4>{});
-        default: return eval_e(Mp, std::integral_constant<int, 8>{});
-      }
-    };
-
-    // replicated scalar state (every thread holds the same values)
-    double min_nfa = pos_inf();
-    int n_in = 0;
-    long n_iter = A.n_iter;
-    long n_reserve = n_iter / 10;
-    n_iter -= n_reserve;
-    bool identity = true;
-    bool inl_valid = true;  // S.best_inl holds the inliers of the best model (vacuously: n_in == 0)
-    int n_index = m;
-    long iter = 0;
-
-    // wave 0 rebuilds the inlier list of S.best_model into best_inl (and vec_index when `to_index`)
-    auto rebuild_inliers = [&wave_eval, Sp, wv, lane, &n_in](bool to_index) {
-      F2Shared &S = *Sp;
-      __syncthreads();
-      if (wv == 0) {
-        (void)wave_eval(S.best_model);
-        wave_lds_sync();
-        for (int p = lane; p < n_in; p += 64) {
-          const int32_t q = (int32_t)S.idx[0][p];
-          S.best_inl[p] = q;
-          if (to_index) S.vec_index[p] = q;
-        }
-      }
-      __syncthreads();
-    };
-
-    while (iter < n_iter) {
-      if (identity) {
-        const int B = (int)((n_iter - iter < (long)kF2Batch) ? (n_iter - iter) : (long)kF2Batch);
-        __syncthreads();  // pre_* / res_* of the previous batch are no longer read
-        for (int b = wv; b < B; b += kF2Waves) wave_solve(nullptr, m, iter + b, S.pre_models[b], &S.pre_nm[b]);
-        __syncthreads();
-        STAMP_F(3);  // speculative solves done
-        // flattened model list in iteration order
-        if (tid == 0) {
-          int n = 0;
-          for (int b = 0; b < B; ++b) {
-            for (int k = 0; k < S.pre_nm[b]; ++k) {
-              S.flat_b[n] = (uint8_t)b;
-              S.flat_k[n] = (uint8_t)k;
-              ++n;
-            }
-            S.iter_end[b] = n;
-          }
-        }
-        __syncthreads();
-        const int total = S.iter_end[B - 1];
-        // evaluate the models eight per round; before each round replay the iterations whose models are all done,
-        // and stop as soon as one of them ends the uniform phase
-        int done = 0;    // models evaluated so far
-        int b_done = 0;  // iterations replayed so far
-        bool stop = false;
-        for (;;) {
-          while (b_done < B && S.iter_end[b_done] <= done) {
-            const int b = b_done;
-            bool better = false;
-            int bk = -1;
-            for (int k = 0; k < S.pre_nm[b]; ++k)
-              if (S.res_nfa[b][k] < min_nfa) {
-                better = true;
-                min_nfa = S.res_nfa[b][k];
-                n_in = S.res_k[b][k];
-                bk = k;
-              }
-            if (better) {
-              inl_valid = false;
-              if (tid < 9) S.best_model[tid] = S.pre_models[b][9 * bk + tid];
-            }
-            ++b_done;
-            const long it = iter + b;
-            if ((better && min_nfa < 0.0) || (it + 1 == n_iter && n_reserve)) {
-              if (n_in == 0) {
-                n_iter++;
-                n_reserve--;  // the iteration budget moved: close this batch here
-              } else {
-                rebuild_inliers(true);
-                inl_valid = true;
-                n_index = n_in;
-                identity = false;
-                if (n_reserve) {
-                  n_iter = it + 1 + n_reserve;
-                  n_reserve = 0;
-                }
-              }
-              stop = true;
-              break;
-            }
-          }
-          if (stop || b_done >= B) break;
-          const int mi = done + wv;
-          if (mi < total) {
-            const int bb = S.flat_b[mi], kk = S.flat_k[mi];
-            const NfaBest r = wave_eval(&S.pre_models[bb][9 * kk]);
-            if (lane == 0) {
-              S.res_nfa[bb][kk] = r.nfa;
-              S.res_k[bb][kk] = r.k;
-            }
-          }
-          __syncthreads();
-          STAMP_F(4);  // one evaluation round done
-          done = (done + kF2Waves < total) ? done + kF2Waves : total;
-        }
-        STAMP_F(5);  // uniform batch closed (incl. the inlier rebuild when the phase ended)
-        iter += b_done;
-      } else {
-        __syncthreads();
-        if (wv == 0) wave_solve(S.vec_index, n_index, iter, S.pre_models[0], &S.pre_nm[0]);
-        __syncthreads();
-        STAMP_F(6);  // sequential iteration: solved
-        const int nm = S.pre_nm[0];
-        if (wv < nm) {
-          const NfaBest r = wave_eval(&S.pre_models[0][9 * wv]);
-          if (lane == 0) {
-            S.res_nfa[0][wv] = r.nfa;
-            S.res_k[0][wv] = r.k;
-          }
-        }
-        __syncthreads();
-        bool better = false;
-        int bk = -1;
-        for (int k = 0; k < nm; ++k)
-          if (S.res_nfa[0][k] < min_nfa) {
-            better = true;
-            min_nfa = S.res_nfa[0][k];
-            n_in = S.res_k[0][k];
-            bk = k;
-          }
-        if (better) {
-          for (int p = tid; p < n_in; p += kF2Threads) S.best_inl[p] = (int32_t)S.idx[bk][p];
-          inl_valid = true;
-          if (tid < 9) S.best_model[tid] = S.pre_models[0][9 * bk + tid];  // read again only behind a barrier
-        }
-        if ((better && min_nfa < 0.0) || (iter + 1 == n_iter && n_reserve)) {
-          if (n_in == 0) {
-            n_iter++;
-            n_reserve--;
-          } else {
-            __syncthreads();
-            for (int p = tid; p < n_in; p += kF2Threads) S.vec_index[p] = S.best_inl[p];
-            n_index = n_in;
-            identity = false;
-            if (n_reserve) {
-              n_iter = iter + 1 + n_reserve;
-              n_reserve = 0;
-            }
-          }
-        }
-        ++iter;
-        STAMP_F(7);  // sequential iteration: evaluated + replayed
-      }
-    }
-    __syncthreads();
-    STAMP_F(8);
-    if (min_nfa >= 0.0) n_in = 0;
-    if ((double)n_in > 7 * 2.5) {
-      if (!inl_valid) rebuild_inliers(false);
-      for (int p = tid; p < n_in; p += kF2Threads) A.geo_idx[off + p] = (uint32_t)S.best_inl[p];
-      if (tid == 0) A.geo_count[v] = (uint32_t)n_in;
-      __syncthreads();
-      if (A.geo_model && tid == 0) {  // errorMax = the residual of the last inlier (the list ascends by residual)
-        const int pl = S.best_inl[n_in - 1];
-        double Mb[9];
-        for (int q = 0; q < 9; ++q) Mb[q] = S.best_model[q];
-        double *gm = A.geo_model + 10 * (size_t)v;
-        for (int q = 0; q < 9; ++q) gm[q] = Mb[q];
-        gm[9] = err_fmatrix(Mb, S.pts[0][pl], S.pts[1][pl], S.pts[2][pl], S.pts[3][pl]);
-      }
-    } else if (tid == 0) {
-      A.geo_count[v] = 0;
-    }
-    STAMP_F(9);
+#include "fmatrix_fast.body.inc"
   }
 };
 __global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
-  FmatrixFastBody::run(A);
+#include "fmatrix_fast.body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2003,21 +1721,11 @@ __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pRepla
 struct P3pRoundBody {
   static constexpr int kGangThreads = kThreads;
   static __device__ __forceinline__ void run(P3pArgs A, int batch) {
-    P3pState &st = *A.state;
-    if (st.done) return;
-    extern __shared__ unsigned char smem_raw[];
-    p3p_eval_hypothesis(A, batch, smem_raw);
-    __shared__ unsigned s_ticket;
-    __syncthreads();  // this workgroup's write-through stores have completed (and its LDS is free)
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&st.arrive, 1u);
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing cached here predates the other workgroups' results
-    p3p_replay(A, batch, *reinterpret_cast<P3pReplayShared *>(smem_raw));
+#include "p3p_round.body.inc"
   }
 };
 __global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch) {
-  P3pRoundBody::run(A, batch);
+#include "p3p_round.body.inc"
 }
 
 // ACRANSAC's epilogue + SfM_Localizer::Localize + localization.cpp:511-547, once per query after the last round

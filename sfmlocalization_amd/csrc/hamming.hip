@@ -56,70 +56,7 @@ struct HammingTop2Body {
     const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
     const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t q_chunk, uint32_t lds_rows,
     uint2 *__restrict__ part) {
-    extern __shared__ uint4 qs[];  // lds_rows x 4 uint4: a slice of the query block, row major
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t j_begin = blockIdx.y * q_chunk;
-    const uint32_t j_end = min(nq, j_begin + q_chunk);
-
-    // The R bank blocks of this wave; lane l owns row l of each.
-    const uint32_t w0 = (blockIdx.x * WAVES + wave) * R;
-    uint32_t blk[R];
-    uint32_t b[R][16];
-    uint32_t best0[R], best1[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint32_t widx = w0 + r;
-      blk[r] = (widx < n_work_blocks) ? (block_list ? block_list[widx] : widx) : kNoBlock;
-      const bool valid = blk[r] != kNoBlock;  // padding of a device-built list (k_blocks_from_views)
-      best0[r] = best1[r] = SFMLOC_NOMATCH;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (valid) v = bank[((uint64_t)blk[r] * 4 + c) * 64 + lane];
-        b[r][4 * c + 0] = v.x;
-        b[r][4 * c + 1] = v.y;
-        b[r][4 * c + 2] = v.z;
-        b[r][4 * c + 3] = v.w;
-      }
-    }
-    bool wave_has_work = false;  // wave uniform
-#pragma unroll
-    for (int r = 0; r < R; ++r) wave_has_work = wave_has_work || blk[r] != kNoBlock;
-
-    for (uint32_t j0 = j_begin; j0 < j_end; j0 += lds_rows) {
-      const uint32_t cnt = min(lds_rows, j_end - j0);
-      __syncthreads();  // the previous slice has been consumed by every wave
-      for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
-      __syncthreads();
-      if (wave_has_work) {
-#pragma unroll 2
-        for (uint32_t jj = 0; jj < cnt; ++jj) {
-          const uint4 q0 = qs[jj * 4 + 0];
-          const uint4 q1 = qs[jj * 4 + 1];
-          const uint4 q2 = qs[jj * 4 + 2];
-          const uint4 q3 = qs[jj * 4 + 3];
-          const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                  q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-          const uint32_t j = j0 + jj;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[r][k] ^ q[k]);
-            top2_push(best0[r], best1[r], (acc << 16) | j);
-          }
-        }
-      }
-    }
-
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      // partials are indexed by WORK block (position in the block list), split-major
-      if (blk[r] != 0xFFFFFFFFu)
-        part[((uint64_t)blockIdx.y * n_work_blocks + (w0 + r)) * 64 + lane] = make_uint2(best0[r], best1[r]);
-    }
+#include "hamming_top2.body.inc"
   }
 };
 template <int R, int WAVES>
@@ -127,7 +64,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_top2(
     const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
     const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t q_chunk, uint32_t lds_rows,
     uint2 *__restrict__ part) {
-  HammingTop2Body<R, WAVES>::run(bank, block_list, n_work_blocks, qdesc, nq, q_chunk, lds_rows, part);
+#include "hamming_top2.body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -156,164 +93,7 @@ struct HammingScreenBody {
     const uint2 *__restrict__ head_part /*null, or [work block][lane]: the exact top-2 over the first `head` query rows,
                                   computed once by k_hamming_top2 -- the slices then start from it instead of each
                                   scanning a head of its own*/) {
-    extern __shared__ uint4 qs[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t w0 = blockIdx.x * WAVES + wave;
-    const uint32_t blk = (w0 < n_work_blocks) ? (block_list ? block_list[w0] : w0) : kNoBlock;
-    const bool valid = blk != kNoBlock;  // false also for the padding of a device-built list
-    if (!__syncthreads_or(valid)) return;
-    uint32_t b[16];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (valid) v = bank[((uint64_t)blk * 4 + c) * 64 + lane];
-      b[4 * c + 0] = v.x;
-      b[4 * c + 1] = v.y;
-      b[4 * c + 2] = v.z;
-      b[4 * c + 3] = v.w;
-    }
-    __shared__ uint16_t cnt_s[520];
-    for (uint32_t i = threadIdx.x; i < 513; i += WAVES * 64) cnt_s[i] = ratio_cnt[i];
-    uint32_t best0 = SFMLOC_NOMATCH, best1 = SFMLOC_NOMATCH;  // exact top-2 over the pairs finished so far
-    uint32_t T = 0;                                            // accept needs (nearest distance) < T
-    bool flag = false;
-    uint32_t n_finished = 0;
-    // gridDim.y > 1 (short block lists): this workgroup screens the query rows [j_begin, j_end) only, with its own exact
-    // head and threshold.  A bank row that the whole query would accept is accepted by the slice holding its nearest row
-    // (the slice's second-nearest is no nearer than the global one), so the union of the slices' flags still covers
-    // every accepted row; k_hamming_rows then recomputes the flagged rows against ALL query rows, as before.
-    // With a shared head the slices divide the rows AFTER it and start from its (best0, best1): any upper bound of the
-    // second-nearest distance gives a valid threshold, so every slice may use the head's.
-    const uint32_t base = head_part ? min(head, nq) : 0u;
-    const uint32_t per = (nq - base + gridDim.y - 1) / gridDim.y;
-    const uint32_t j_begin = base + blockIdx.y * per, j_end = min(nq, j_begin + per);
-    const uint32_t head_end = head_part ? j_begin : j_begin + head;
-    if (head_part && valid) {
-      const uint2 hp = head_part[(uint64_t)w0 * 64 + lane];
-      best0 = hp.x;
-      best1 = hp.y;
-      T = (best1 != SFMLOC_NOMATCH) ? (uint32_t)ratio_cnt[best1 >> 16] : 0u;
-      flag = (best0 >> 16) < T;
-    }
-    for (uint32_t j0 = j_begin; j0 < j_end; j0 += lds_rows) {
-      const uint32_t cnt = min(lds_rows, j_end - j0);
-      __syncthreads();
-      for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
-      __syncthreads();
-      if (!valid) continue;
-      uint32_t jj = 0;
-      // (a) exact head
-      for (; jj < cnt && j0 + jj < head_end; ++jj) {
-        const uint4 q0 = qs[jj * 4 + 0], q1 = qs[jj * 4 + 1], q2 = qs[jj * 4 + 2], q3 = qs[jj * 4 + 3];
-        const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
-        top2_push(best0, best1, (acc << 16) | (j0 + jj));
-        if (j0 + jj + 1 == head_end || j0 + jj + 1 == j_end) {
-          T = (best1 != SFMLOC_NOMATCH) ? (uint32_t)cnt_s[best1 >> 16] : 0u;
-          flag = (best0 >> 16) < T;
-        }
-      }
-      // (b) screened tail.  A finished pair is exact, so it also tightens (best0, best1) and with them T: the
-      // threshold only ever shrinks towards ratio_cnt[d1], which keeps every earlier decision valid.
-      // kScreenBatch > 1 (short block lists, e.g. a BoW shortlist, where a SIMD holds two to four waves and the latency
-      // of one xor -> bcnt chain is exposed): that many query rows per step, their prefix sums as independent chains;
-      // the votes then see the threshold as of the start of the step -- a larger one, so still valid.  With the chip
-      // full (kScreenBatch = 1) the plain loop below is 1 % faster.
-      if constexpr (kScreenBatch > 1)
-      for (; jj + kScreenBatch <= cnt; jj += kScreenBatch) {
-        uint32_t acc[kScreenBatch];
-#pragma unroll
-        for (int u = 0; u < kScreenBatch; ++u) {
-          uint32_t q[4 * ((NW + 3) / 4)];
-#pragma unroll
-          for (int c = 0; c < (NW + 3) / 4; ++c) {
-            const uint4 v = qs[(jj + u) * 4 + c];
-            q[4 * c + 0] = v.x, q[4 * c + 1] = v.y, q[4 * c + 2] = v.z, q[4 * c + 3] = v.w;
-          }
-          uint32_t a = 0;
-#pragma unroll
-          for (int k = 0; k < NW; ++k) a += __builtin_popcount(b[k] ^ q[k]);
-          acc[u] = a;
-        }
-#pragma unroll
-        for (int u = 0; u < kScreenBatch; ++u) {
-          if (__any(acc[u] < T)) {
-            ++n_finished;
-            uint32_t a = acc[u];
-#pragma unroll
-            for (int c = NW / 4; c < 4; ++c) {
-              const uint4 v = qs[(jj + u) * 4 + c];
-              const uint32_t q[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-              for (int k = 0; k < 4; ++k)
-                if (4 * c + k >= NW) a += __builtin_popcount(b[4 * c + k] ^ q[k]);
-            }
-            flag = flag || (a < T);
-            top2_push(best0, best1, (a << 16) | (j0 + jj + u));
-            T = (uint32_t)cnt_s[best1 >> 16];
-          }
-        }
-      }
-#pragma unroll 2
-      for (; jj < cnt; ++jj) {  // kScreenBatch = 1: every row; else the rows left over at the end of a slice
-        uint32_t q[16];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint4 v = qs[jj * 4 + c];
-          q[4 * c + 0] = v.x, q[4 * c + 1] = v.y, q[4 * c + 2] = v.z, q[4 * c + 3] = v.w;
-        }
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
-        if (__any(acc < T)) {
-          ++n_finished;
-#pragma unroll
-          for (int k = NW; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
-          flag = flag || (acc < T);
-          top2_push(best0, best1, (acc << 16) | (j0 + jj));
-          T = (uint32_t)cnt_s[best1 >> 16];
-        }
-      }
-    }
-    if (!valid) return;
-    const uint32_t pidx = w0 * 64 + lane;
-    // unflagged rows are rejected: K2 reads the mask and never touches their (stale) partial-result slots, so the
-    // only per-row bytes this kernel writes are 8 per 64 rows
-    unsigned long long mask = __ballot(flag);
-    if (gridDim.y == 1) {
-      if (lane == 0) flagmask[w0] = mask;
-    } else {  // the mask was cleared before the launch; only rows no other slice has flagged yet join the list
-      unsigned long long old = 0;
-      if (lane == 0 && mask) old = atomicOr(&flagmask[w0], mask);
-      old = __shfl(old, 0, 64);
-      mask &= ~old;
-      flag = (mask >> lane) & 1ull;
-    }
-    if (lane == 0) {
-      atomicAdd(&counters[0], (unsigned long long)n_finished);
-      if (mask) atomicAdd(&counters[1], (unsigned long long)__popcll(mask));
-    }
-    if (mask) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(n_flagged, (uint32_t)__popcll(mask));
-      base = __shfl(base, 0, 64);
-      if (flag) {
-        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        flagged[slot] = make_uint2(pidx, blk * 64 + lane);
-        // the exact pass reads the row again, SLICES times: hand it over compactly instead of as 4 x 128-byte lines
-        // of the bank per reader (the row is in registers here)
-        if (slot < flagged_desc_cap) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            flagged_desc[((uint64_t)(slot >> 6) * 4 + c) * 64 + (slot & 63u)] =
-                make_uint4(b[4 * c + 0], b[4 * c + 1], b[4 * c + 2], b[4 * c + 3]);
-        }
-      }
-    }
+#include "hamming_screen.body.inc"
   }
 };
 template <int WAVES, int NW, int kScreenBatch>
@@ -328,8 +108,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
     const uint2 *__restrict__ head_part /*null, or [work block][lane]: the exact top-2 over the first `head` query rows,
                                   computed once by k_hamming_top2 -- the slices then start from it instead of each
                                   scanning a head of its own*/) {
-  HammingScreenBody<WAVES, NW, kScreenBatch>::run(bank, block_list, n_work_blocks, qdesc, nq, lds_rows, ratio_cnt, flagmask,
-                                                  flagged, n_flagged, counters, head, flagged_desc, flagged_desc_cap, head_part);
+#include "hamming_screen.body.inc"
 }
 
 // Exact top-2 of the flagged rows.  64 flagged rows x all query rows is ~130 k pairs: on ONE compute unit that is
@@ -349,121 +128,7 @@ struct HammingRowsBody {
                                                      uint32_t chunk_cap, uint32_t lds_rows,
                                                      const uint4 *__restrict__ flagged_desc,
                                                      uint2 *__restrict__ part) {
-    extern __shared__ uint4 qs[];
-    __shared__ uint2 merge[WAVES][64];
-    __shared__ uint32_t s_last;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t slice = blockIdx.x % SLICES;
-    const uint32_t n = *n_flagged;
-    const uint32_t per = (nq + SLICES - 1) / SLICES;
-    const uint32_t j_lo = slice * per, j_hi = min(nq, j_lo + per);
-    const uint32_t cnt = j_hi > j_lo ? j_hi - j_lo : 0;
-    // this workgroup's query slice (the same for every chunk it handles); chunk_cap == 0 <=> the slice does not fit
-    if (chunk_cap && (uint64_t)(blockIdx.x / SLICES) * 64 < n)  // (only workgroups that own a chunk need it)
-      for (uint32_t i = threadIdx.x; i < cnt * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j_lo * 4 + i];
-    __syncthreads();
-    for (uint32_t chunk = blockIdx.x / SLICES; chunk * 64 < n && chunk < chunk_cap; chunk += gridDim.x / SLICES) {
-      const uint32_t e = chunk * 64 + lane;
-      const bool valid = e < n;
-      const uint2 ent = valid ? flagged[e] : make_uint2(0, 0);
-      uint32_t b[16];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (valid) v = flagged_desc[((uint64_t)chunk * 4 + c) * 64 + lane];  // written by k_hamming_screen
-        b[4 * c + 0] = v.x;
-        b[4 * c + 1] = v.y;
-        b[4 * c + 2] = v.z;
-        b[4 * c + 3] = v.w;
-      }
-      uint32_t best0 = SFMLOC_NOMATCH, best1 = SFMLOC_NOMATCH;
-      for (uint32_t jj = wave; jj < cnt; jj += WAVES) {
-        const uint4 q0 = qs[jj * 4 + 0], q1 = qs[jj * 4 + 1], q2 = qs[jj * 4 + 2], q3 = qs[jj * 4 + 3];
-        const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
-        top2_push(best0, best1, (acc << 16) | (j_lo + jj));
-      }
-      merge[wave][lane] = make_uint2(best0, best1);
-      __syncthreads();
-      if (wave == 0) {
-        uint32_t m0 = SFMLOC_NOMATCH, m1 = SFMLOC_NOMATCH;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-          top2_push(m0, m1, merge[w][lane].x);
-          top2_push(m0, m1, merge[w][lane].y);
-        }
-        scratch[((uint64_t)chunk * SLICES + slice) * 64 + lane] = make_uint2(m0, m1);
-      }
-      // publish the partial, count the arrival; the last of the chunk's SLICES workgroups merges
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __threadfence();
-        const uint32_t prev = atomicAdd(&arrivals[chunk], 1u);
-        s_last = (prev == SLICES - 1) ? 1u : 0u;
-        if (s_last) arrivals[chunk] = 0;  // every arrival of this query is in: ready for the next query
-        __threadfence();
-      }
-      __syncthreads();
-      if (s_last && wave == 0 && valid) {
-        uint32_t m0 = SFMLOC_NOMATCH, m1 = SFMLOC_NOMATCH;
-        for (int sl = 0; sl < SLICES; ++sl) {
-          const uint2 p = scratch[((uint64_t)chunk * SLICES + sl) * 64 + lane];
-          top2_push(m0, m1, p.x);
-          top2_push(m0, m1, p.y);
-        }
-        part[ent.x] = make_uint2(m0, m1);
-      }
-      __syncthreads();  // merge[] and s_last are reused by the next chunk
-    }
-    // more flagged rows than the scratch has chunks for (pathological inputs): one workgroup per remaining chunk walks
-    // all the query slices itself
-    for (uint32_t chunk = chunk_cap + blockIdx.x; chunk * 64 < n; chunk += gridDim.x) {
-      const uint32_t e = chunk * 64 + lane;
-      const bool valid = e < n;
-      const uint2 ent = valid ? flagged[e] : make_uint2(0, 0);
-      uint32_t b[16];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (valid) v = bank[((uint64_t)(ent.y >> 6) * 4 + c) * 64 + (ent.y & 63u)];
-        b[4 * c + 0] = v.x;
-        b[4 * c + 1] = v.y;
-        b[4 * c + 2] = v.z;
-        b[4 * c + 3] = v.w;
-      }
-      uint32_t best0 = SFMLOC_NOMATCH, best1 = SFMLOC_NOMATCH;
-      for (uint32_t j0 = 0; j0 < nq; j0 += lds_rows) {
-        const uint32_t c2 = min(lds_rows, nq - j0);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < c2 * 4; i += WAVES * 64) qs[i] = qdesc[(uint64_t)j0 * 4 + i];
-        __syncthreads();
-        for (uint32_t jj = wave; jj < c2; jj += WAVES) {
-          const uint4 q0 = qs[jj * 4 + 0], q1 = qs[jj * 4 + 1], q2 = qs[jj * 4 + 2], q3 = qs[jj * 4 + 3];
-          const uint32_t q[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                  q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-          uint32_t acc = 0;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) acc += __builtin_popcount(b[k] ^ q[k]);
-          top2_push(best0, best1, (acc << 16) | (j0 + jj));
-        }
-      }
-      __syncthreads();
-      merge[wave][lane] = make_uint2(best0, best1);
-      __syncthreads();
-      if (wave == 0 && valid) {
-        uint32_t m0 = SFMLOC_NOMATCH, m1 = SFMLOC_NOMATCH;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-          top2_push(m0, m1, merge[w][lane].x);
-          top2_push(m0, m1, merge[w][lane].y);
-        }
-        part[ent.x] = make_uint2(m0, m1);
-      }
-    }
+#include "hamming_rows.body.inc"
   }
 };
 template <int WAVES, int SLICES>
@@ -476,8 +141,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_rows(const uint4 *__rest
                                                      uint32_t chunk_cap, uint32_t lds_rows,
                                                      const uint4 *__restrict__ flagged_desc,
                                                      uint2 *__restrict__ part) {
-  HammingRowsBody<WAVES, SLICES>::run(bank, qdesc, nq, flagged, n_flagged, scratch, arrivals, chunk_cap, lds_rows, flagged_desc,
-                                      part);
+#include "hamming_rows.body.inc"
 }
 
 // One wave per selected view.  Merges the per-split partial top-2, applies the ratio test through a

@@ -2,7 +2,9 @@
 """Randomised parity campaign for the multi-GPU path on one GPU: the map's views split into 2..5 shards (separate
 sfmloc_map objects), sfmloc_shard_begin / _export per shard, the parts concatenated as the all-gather would,
 sfmloc_merge_begin on one of them -- against the oracle's UNSHARDED result, bit for bit.
-usage: fuzz_sharded.py [n_scenes] [first_seed]"""
+usage: fuzz_sharded.py [n_scenes] [first_seed]
+SFMLOC_FUZZ_GANG=1: a scene's two queries go through every shard, and through the merge, TOGETHER in gang sessions
+(sfmloc_gang_begin / _end, the second context without a stream of its own) -- same expectation."""
 import os
 import sys
 import time
@@ -50,6 +52,13 @@ def one(seed):
                             landmark_id=m.landmark_id, landmark_X=m.landmark_X, intrinsic=m.intrinsic))
     pb = D.part_bytes(cap)
     n = 0
+    if os.environ.get("SFMLOC_FUZZ_GANG") == "1":
+        try:
+            return one_ganged(m, rng, seed, shards, world, cap, pb, nq, ratio, rounds)
+        finally:
+            for sm in shards:
+                if sm is not None:
+                    sm.close()
     try:
         for k in range(2):
             q = synth.make_query(m, seed * 10 + k, n_feat=nq, n_copies=int(rng.integers(0, min(nq, 400))),
@@ -86,6 +95,53 @@ def one(seed):
             if sm is not None:
                 sm.close()
     return n
+
+
+def one_ganged(m, rng, seed, shards, world, cap, pb, nq, ratio, rounds):
+    from sfmlocalization_amd import capi
+    qs, exps = [], []
+    for k in range(2):
+        q = synth.make_query(m, seed * 10 + k, n_feat=nq, n_copies=int(rng.integers(0, min(nq, 400))),
+                             outlier_frac=float(rng.uniform(0.0, 0.6)))
+        qs.append(q)
+        exps.append(opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), ratio=ratio, ransac_round=rounds))
+    parts = torch.zeros((2, world, pb), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    sq = [[None] * world for _ in range(2)]
+    for s, sm in enumerate(shards):
+        if sm is None:
+            continue
+        lead = sm.context()
+        cs = [lead, sm.context(share=lead)]
+        for k in range(2):
+            sq[k][s] = sm.query(qs[k].desc, qs[k].kpt_xy, qs[k].width, qs[k].height)
+        with capi.gang(cs):
+            for k in range(2):
+                cs[k].shard_begin(sq[k][s])
+                cs[k].shard_export(parts[k, s].data_ptr(), cap)
+        lead.sync()
+        cs[1].close()
+        lead.close()
+    owner = int(rng.choice([i for i, sm in enumerate(shards) if sm is not None]))
+    lead = shards[owner].context()
+    cs = [lead, shards[owner].context(share=lead)]
+    with capi.gang(cs):
+        for k in range(2):
+            cs[k].merge_begin(sq[k][owner], parts[k].data_ptr(), world, cap)
+    for k in range(2):
+        pose, pq, pl = cs[k].end()
+        exp = exps[k]
+        assert bool(pose.ok) == exp["ok"], "ok flag"
+        if exp["ok"]:
+            assert np.array_equal(pq, exp["pair_qfeat"]) and np.array_equal(pl, exp["pair_landmark"]), "pairs"
+            assert np.array_equal(bits(np.array(pose.P)), bits(exp["P"].ravel())), "P"
+    cs[1].close()
+    lead.close()
+    for k in range(2):
+        for x in sq[k]:
+            if x is not None:
+                x.close()
+    return 2
 
 
 def main():
