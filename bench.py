@@ -8,8 +8,8 @@ N = 1  : BASELINE.json configs[2] -- 10 k-image / 20 M-descriptor synthetic map,
          shortlists k = 100 views by exact L2 over the 10 000 x 500 .bow matrix, then runs the whole path on them
 N > 1  : the same map and workload with the bank (and the .bow matrix) sharded by view across the N ranks
          (BASELINE configs[3]/[4]): sharded shortlist (one small all-gather of per-shard k best), shard
-         local K1..K3, ONE all-gather of candidate parts per batch over RCCL, P3P of query i on rank i mod N.
-         Strong scaling on a fixed map.
+         local K1..K3, ONE all-gather of candidate parts per batch over RCCL, P3P of query i on rank i mod N; both
+         stages in gang sessions (--gang: 16 queries per kernel launch).  Strong scaling on a fixed map.
 
 `python bench.py --gpus N` without a launcher starts the N ranks itself (before any GPU call) through
 torch.distributed.run and relays rank 0's JSON line; under a launcher a rank insists on WORLD_SIZE == --gpus.

@@ -1,16 +1,18 @@
 // Gang launches: several contexts of one map take one query each through the same chain of kernels, and every kernel
 // of the chain is launched ONCE for all of them (gridDim.z = member), the members' argument lists side by side in the
 // kernel arguments.  The arithmetic of a member is untouched -- a kernel's body is the same device function whether it
-// is launched alone or in a gang -- only the number of launches changes: a rank of an 8-rank run has 1/8 of the scan
-// per query but every query's launches, and the device completes only so many dependent launches per second
-// (Concurrency).
+// is launched alone or in a gang -- only the number of launches and of busy streams changes: a rank of an 8-rank run has
+// 1/8 of the scan per query but every query's launches, and a dependent launch costs the more the more hardware queues
+// are busy (Concurrency; 6: a rank of 8 goes from 7.6 k to 14.7 k queries/s).
 //
-// How: between sfmloc_gang_begin and sfmloc_gang_end the members' launchers RECORD their launches (sfm_launch below)
-// instead of issuing them; sfmloc_gang_end walks the members' lists in step and issues, on the gang's stream (the
-// first member's), one gang kernel for every set of heads that are the same kernel with the same grid, and a plain
-// launch for a head that has no partner.  Any other use of a member's stream while recording (a copy, an event, a
-// kernel that has no gang form) first issues what has been recorded, so the order on the stream is always the order
-// of the calls.
+// How: between sfmloc_gang_begin and sfmloc_gang_end the members' launchers RECORD their launches (sfm_launch,
+// sfmloc_internal.h) instead of issuing them; sfmloc_gang_end (gang_flush, capi.hip) walks the members' lists in step
+// and issues, on the gang's stream (the first member's), per position ONE gang kernel for the members whose record is
+// the same kernel on the same grid -- as many of them as the kernel arguments hold, the rest in further launches -- and a
+// plain launch for a record without a partner.  Any other use of a member's stream while recording (a copy, an event)
+// first issues what has been recorded, so the order on the stream is always the order of the calls.
+// The five hot kernels keep their text in *.body.inc files included by the kernel and by its Body::run: compiled as an
+// inlined call the scan's loop is unrolled and scheduled before the inlining and runs 20 % slower.
 #pragma once
 
 #include <hip/hip_runtime.h>
