@@ -336,7 +336,8 @@ int sfmloc_context_wait(sfmloc_context *ctx, void *hip_stream);
  * nothing and the members run one after the other.
  *   _counters: launches issued by this leader's sessions so far, and how many of them carried more than one member. */
 int sfmloc_gang_begin(sfmloc_context *const *ctxs, uint32_t n);
-/* a context (workspace) WITHOUT a stream of its own: its work is queued on `lender`'s stream, which must outlive it.  For
+/* a context (workspace) WITHOUT a stream of its own: its work is queued on `lender`'s stream (a lender destroyed first
+ * stops being usable but its stream lives until the last borrower is destroyed).  For
  * the members of a gang other than the first -- a device serves only so many hardware queues well, and a context that
  * only ever works inside gang sessions needs none. */
 int sfmloc_context_create_sharing(sfmloc_map *map, sfmloc_context *lender, sfmloc_context **out);

@@ -112,6 +112,10 @@ int drain_events(Ctx *c, double *per_kind_ms = nullptr) {
 
 void free_ctx(Ctx *c) {
   if (!c) return;
+  if (c->borrowers > 0) {  // its stream is lent out: the last borrower to go frees it (sfmloc_context_create_sharing)
+    c->zombie = true;
+    return;
+  }
   if (c->stream.own) hipStreamSynchronize(c->stream.own);
   for (auto &pe : c->pending_events) {
     hipEventDestroy(pe.second.first);
@@ -144,7 +148,9 @@ void free_ctx(Ctx *c) {
     delete c->gang_owned;
   }
   if (c->stream.own && !c->stream_borrowed) hipStreamDestroy(c->stream.own);
+  Ctx *lender = c->lender;
   delete c;
+  if (lender && --lender->borrowers == 0 && lender->zombie) free_ctx(lender);
 }
 
 int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr) {
@@ -173,6 +179,8 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr) {
   if (share) {  // no stream (hardware queue) of its own: work is queued on the lender's
     c->stream.own = share->stream.own;
     c->stream_borrowed = true;
+    c->lender = share;
+    ++share->borrowers;
   } else {
     CTX_HIP(hipStreamCreateWithFlags(&c->stream.own, hipStreamNonBlocking));
   }
@@ -1626,9 +1634,15 @@ static int merge_begin_impl(sfmloc_context *ctx, sfmloc_query *query, const void
   SFM_CHECK(q->n == 0 || q->d_kpt, SFMLOC_EINVAL, "sfmloc_merge_begin: the query was created without keypoints");
   SFM_HIP(hipSetDevice(m->device));
   c->t_begin = now_s();
+  // (counted like a begun localisation: with other contexts' work queued -- the next batch's stage 1, always, in the
+  // pipeline of dist.py -- K5 takes its shared-GPU round sizes; sfmloc_localize_end uncounts)
+  ctx_mark_busy(c);
   {
     const int rcr = ctx_p3p_reserve(c, q->n);
-    if (rcr) return rcr;
+    if (rcr) {
+      ctx_mark_idle(c);
+      return rcr;
+    }
   }
   int rc;
   {
@@ -1638,14 +1652,15 @@ static int merge_begin_impl(sfmloc_context *ctx, sfmloc_query *query, const void
     rc = launch_select_candidates(c, q, reinterpret_cast<const unsigned char *>(parts_dev), n_parts, part_stride, cap,
                                   packed_b, packed_qi, /*reset_status=*/true);
   }
-  if (rc) return rc;
-  {
+  if (!rc) {
     EventScope ev(c, SFMLOC_K_P3P);
     rc = ctx_resection_enqueue(c, true);
   }
-  if (rc) return rc;
-  rc = ctx_fetch_result(c);
-  if (rc) return rc;
+  if (!rc) rc = ctx_fetch_result(c);
+  if (rc) {
+    ctx_mark_idle(c);
+    return rc;
+  }
   c->in_flight = q;
   return SFMLOC_OK;
 }

@@ -162,7 +162,10 @@ struct Map {
 struct Ctx {
   Map *map = nullptr;
   CtxStream stream;  // gang.h: reads as the stream to queue on now (the context's own, or its gang's while recording)
-  bool stream_borrowed = false;    // stream.own belongs to another context (sfmloc_context_create_sharing)
+  bool stream_borrowed = false;    // stream.own belongs to `lender` (sfmloc_context_create_sharing)
+  Ctx *lender = nullptr;
+  int borrowers = 0;               // contexts working on this one's stream
+  bool zombie = false;             // destroyed while lent out: freed with its last borrower
   std::vector<GangRec> gang_recs;  // launches recorded for the gang session in progress
   size_t gang_head = 0;
   GangState *gang_owned = nullptr;  // this context has led a gang: its state (stream = this context's own)
