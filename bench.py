@@ -287,7 +287,7 @@ def main():
     # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
     # (so does the image-in mode: a context and an extractor stream per worker)
     # (+2: the map's own stream and torch's; measured: 8 contexts on 8 queues lose 20 % to two streams sharing one)
-    n_streams = (2 * -(-nctx // gang) + 1) if gang > 1 else (2 * nctx if sharded_mode else nctx)
+    n_streams = (2 * -(-nctx // gang) + 2) if gang > 1 else (2 * nctx if sharded_mode else nctx)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, n_streams + 2))))
 
     import numpy as np

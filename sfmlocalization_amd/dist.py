@@ -364,8 +364,10 @@ class HipShardCompute:
         # do not have -- contexts of its own then, shared by the slots (a batch's stage 2 ends before the next one's begins)
         self.ctx2 = None
         if self.gang > 1:
-            self.ctx2 = [shard_map.context()]
-            self.ctx2 += [shard_map.context(share=self.ctx2[0]) for _ in range(self.n_stage2 - 1)]
+            self.ctx2 = []
+            for _ in range(2):
+                lead = shard_map.context()
+                self.ctx2.append([lead] + [shard_map.context(share=lead) for _ in range(self.n_stage2 - 1)])
         self._buf = {}
         self._queries = [None] * self.n_slots
 
@@ -373,8 +375,9 @@ class HipShardCompute:
         for cs in self.ctxs:
             for c in reversed(cs):          # (a gang's members before the context whose stream they borrow)
                 c.close()
-        for c in reversed(self.ctx2 or []):
-            c.close()
+        for group in self.ctx2 or []:
+            for c in reversed(group):
+                c.close()
 
     def _tensor(self, name, slot, shape, dtype):
         """persistent per (name, slot, shape): the C ABI writes every byte that is read back, so no clearing (and a
@@ -481,15 +484,22 @@ class HipShardCompute:
         B = len(queries)
         if self.ctx2 is not None:
             # gang sessions: the 2D-3D selection and every P3P round of up to len(ctx2) queries per launch
+            # (two groups of contexts take turns, so that a session is queued while the one before it is awaited)
             from . import capi
-            cs = self.ctx2
-            for k0 in range(0, len(indices), len(cs)):
-                chunk = indices[k0:k0 + len(cs)]
+            n = len(self.ctx2[0])
+            pending = None
+            for t, k0 in enumerate(range(0, len(indices), n)):
+                cs = self.ctx2[t % len(self.ctx2)]
+                chunk = indices[k0:k0 + n]
                 with capi.gang(cs[:len(chunk)]):
                     for c, i in zip(cs, chunk):
                         c.merge_begin_packed(queries[i], base, world, B, budget, i, part_stride=pb)
-                for c, i in zip(cs, chunk):
-                    out[i] = _pose_tuple(c.end())
+                if pending is not None:
+                    for c, i in pending:
+                        out[i] = _pose_tuple(c.end())
+                pending = list(zip(cs, chunk))
+            for c, i in pending or []:
+                out[i] = _pose_tuple(c.end())
             return out
         cs = self.ctxs[slot]
         n = len(cs)

@@ -23,8 +23,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--of", type=int, default=8, help="N: the emulated world size (this process is rank 0 of N)")
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--views", type=int, default=10000)
     ap.add_argument("--desc-per-view", type=int, default=2000)
