@@ -403,29 +403,18 @@ class HipShardCompute:
         for c in self._streams(slot):
             c.wait(self.comm.cuda_stream)         # the slot's later work waits for the collective
 
-    def _gangs(self, slot, n_queries):
-        """the slot's contexts in gangs of `self.gang`, and for each gang the rounds of (context, query index) it runs:
-        query i goes to context i mod n as before; a round of a gang is one gang session"""
+    def _rounds(self, slot, n_queries):
+        """(session, [(context, query index)]) in the order they are queued: query i goes to context i mod n as ever; the
+        contexts are cut into gangs of `self.gang`, a gang takes its share of every n consecutive queries in ONE session,
+        and the gangs take turns so that their streams stay equally loaded"""
         from . import capi
         cs = self.ctxs[slot]
         n = len(cs)
-        for g0 in range(0, n, self.gang):
-            members = list(range(g0, min(n, g0 + self.gang)))
-            for base in range(0, n_queries, n):
-                work = [(cs[k], base + k) for k in members if base + k < n_queries]
+        for base in range(0, n_queries, n):
+            for g0 in range(0, n, self.gang):
+                work = [(cs[k], base + k) for k in range(g0, min(n, g0 + self.gang)) if base + k < n_queries]
                 if work:
                     yield capi.gang([c for c, _ in work]), work
-
-    def _rounds(self, slot, n_queries):
-        """every (session, work) in an order that keeps the gangs' streams equally loaded"""
-        per_gang = {}
-        for sess, work in self._gangs(slot, n_queries):
-            per_gang.setdefault(id(work[0][0]), []).append((sess, work))
-        lists = list(per_gang.values())
-        for r in range(max((len(x) for x in lists), default=0)):
-            for x in lists:
-                if r < len(x):
-                    yield x[r]
 
     def bow_keys(self, queries, knn, slot=0):
         import torch

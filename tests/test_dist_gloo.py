@@ -86,6 +86,32 @@ def test_merge_bow_shortlists_equals_global_selection():
         assert got == glob
 
 
+def test_gang_sessions_cover_every_query_once_on_its_context():
+    """HipShardCompute._rounds (host logic only): query i stays on context i mod n, a session holds distinct contexts of
+    ONE gang, and consecutive sessions alternate between the gangs."""
+    class FakeCtx:
+        _h = None
+
+    for n_ctx, gang, n_q in ((8, 1, 13), (8, 4, 13), (32, 16, 256), (6, 4, 5), (30, 15, 31)):
+        comp = object.__new__(D.HipShardCompute)
+        comp.ctxs = [[FakeCtx() for _ in range(n_ctx)]]
+        comp.gang = gang
+        seen = {}
+        last_gang = None
+        for sess, work in comp._rounds(0, n_q):
+            cs = [c for c, _ in work]
+            assert 1 <= len(cs) <= gang and len(set(map(id, cs))) == len(cs) and sess.ctxs == cs
+            gangs = {comp.ctxs[0].index(c) // gang for c in cs}
+            assert len(gangs) == 1
+            if n_ctx // gang > 1 and n_q > n_ctx:
+                assert gangs != last_gang or len(cs) < gang       # the gangs take turns
+            last_gang = gangs
+            for c, i in work:
+                assert i not in seen and comp.ctxs[0].index(c) == i % n_ctx
+                seen[i] = c
+        assert sorted(seen) == list(range(n_q))
+
+
 def test_k_best_equals_full_sort():
     """dist._k_best (partition + tie handling) against the full (distance, id) sort it replaces."""
     rng = np.random.Generator(np.random.PCG64(16))
