@@ -341,6 +341,11 @@ int sfmloc_gang_begin(sfmloc_context *const *ctxs, uint32_t n);
  * the members of a gang other than the first -- a device serves only so many hardware queues well, and a context that
  * only ever works inside gang sessions needs none. */
 int sfmloc_context_create_sharing(sfmloc_map *map, sfmloc_context *lender, sfmloc_context **out);
+/* a context for sfmloc_merge_begin[_packed] + sfmloc_localize_end ONLY (the owner's stage of a sharded query): none of the
+ * per-bank-row workspace of the matching stages (30 B per descriptor of the map and 32 MB), so a rank can afford one per
+ * query of a gang.  lender: NULL = a stream of its own, else as sfmloc_context_create_sharing.  Every other asynchronous
+ * call on it fails with SFMLOC_EINVAL. */
+int sfmloc_context_create_merge(sfmloc_map *map, sfmloc_context *lender, sfmloc_context **out);
 int sfmloc_gang_end(sfmloc_context *const *ctxs, uint32_t n);
 int sfmloc_gang_counters(sfmloc_context *lead_ctx, uint64_t *launches, uint64_t *gang_launches);
 /* Sharded BoW shortlist (selectViewByBoF over a map split by view).  _shard_bow_keys ranks this shard's

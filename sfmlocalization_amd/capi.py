@@ -119,7 +119,7 @@ SYMBOLS = [
     "sfmloc_undistorter_apply",
     "sfmloc_query_set_bow", "sfmloc_context_signal", "sfmloc_context_wait", "sfmloc_shard_bow_keys",
     "sfmloc_geometric_read_pairs", "sfmloc_shard_begin_bow", "sfmloc_packed_bytes", "sfmloc_shard_export_packed", "sfmloc_merge_begin_packed",
-    "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing",
+    "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing", "sfmloc_context_create_merge",
 ]
 
 _bound = False
@@ -723,8 +723,8 @@ class Map:
         k = pose.n_inliers if pose.ok else 0
         return pose, pq[:k].copy(), pl[:k].copy()
 
-    def context(self, share=None):
-        return Context(self, share)
+    def context(self, share=None, merge_only=False):
+        return Context(self, share, merge_only)
 
     def bow_select(self, query_bow, k, cand_views=None):
         """sfmloc_bow_select (selectViewByBoF): -> ascending view-table indices of the k nearest .bow vectors."""
@@ -896,11 +896,14 @@ class Akaze:
 class Context:
     """sfmloc_context: one in-flight query (stream + workspace) on a map; begin() is asynchronous."""
 
-    def __init__(self, m, share=None):
+    def __init__(self, m, share=None, merge_only=False):
         self._h = None
         self.map = m
         h = C.c_void_p()
-        if share is None:
+        if merge_only:  # sfmloc_context_create_merge: for merge_begin[_packed] + end only, no matching workspace
+            _check(_L().sfmloc_context_create_merge(m._h, None if share is None else share._h, C.byref(h)))
+            self._lender = share
+        elif share is None:
             _check(_L().sfmloc_context_create(m._h, C.byref(h)))
         else:       # sfmloc_context_create_sharing: no stream of its own, work goes to `share`'s
             _check(_L().sfmloc_context_create_sharing(m._h, share._h, C.byref(h)))

@@ -153,7 +153,7 @@ void free_ctx(Ctx *c) {
   if (lender && --lender->borrowers == 0 && lender->zombie) free_ctx(lender);
 }
 
-int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr) {
+int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr, bool merge_only = false) {
   *out = nullptr;
   Ctx *c = new (std::nothrow) Ctx();
   SFM_CHECK(c, SFMLOC_ENOMEM, "out of host memory");
@@ -186,25 +186,31 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr) {
   }
   const uint64_t n_pad = (uint64_t)m->n_blocks * kBlockRows;
   uint64_t *acct = &c->hbm_bytes;
-  CTX_TRY(dev_alloc(acct, &c->d_part, (size_t)n_pad));
+  c->merge_only = merge_only;
+  // a context that only ever merges candidate parts and runs P3P (sfmloc_context_create_merge) has no use for the
+  // per-bank-row arrays of the matching stages: 30 B per row and the 32 MB of the flagged-row pass
+  const bool full = !merge_only;
+  if (full) CTX_TRY(dev_alloc(acct, &c->d_part, (size_t)n_pad));
   CTX_TRY(dev_alloc(acct, &c->d_view_sel, (size_t)m->n_views + 1));
   CTX_TRY(dev_alloc(acct, &c->d_view_widx0, (size_t)m->n_views + 1));
-  CTX_TRY(dev_alloc(acct, &c->d_block_list, (size_t)m->n_blocks));
+  if (full) CTX_TRY(dev_alloc(acct, &c->d_block_list, (size_t)m->n_blocks));
   CTX_TRY(dev_alloc(acct, &c->d_view_count, (size_t)m->n_views + 1));  // + the phantom view (sfmloc_internal.h)
-  CTX_TRY(dev_alloc(acct, &c->d_match_i, (size_t)m->n_rows));
-  CTX_TRY(dev_alloc(acct, &c->d_match_key, (size_t)m->n_rows));
-  CTX_TRY(dev_alloc(acct, &c->d_flagged, (size_t)n_pad));
+  if (full) CTX_TRY(dev_alloc(acct, &c->d_match_i, (size_t)m->n_rows));
+  if (full) CTX_TRY(dev_alloc(acct, &c->d_match_key, (size_t)m->n_rows));
+  if (full) CTX_TRY(dev_alloc(acct, &c->d_flagged, (size_t)n_pad));
   CTX_TRY(dev_alloc(acct, &c->d_n_flagged, (size_t)1));
-  CTX_TRY(dev_alloc(acct, &c->d_flagmask, (size_t)m->n_blocks + 1));
+  if (full) CTX_TRY(dev_alloc(acct, &c->d_flagmask, (size_t)m->n_blocks + 1));
   c->rows_chunk_cap = m->n_blocks < 4096 ? (m->n_blocks ? m->n_blocks : 1) : 4096;  // 4096 chunks = 262 k flagged rows, 16 MB
-  CTX_TRY(dev_alloc(acct, &c->d_rows_scratch, (size_t)c->rows_chunk_cap * 8 * 64));
-  CTX_TRY(dev_alloc(acct, &c->d_rows_arrivals, (size_t)c->rows_chunk_cap));
-  CTX_TRY(dev_alloc(acct, &c->d_flagged_desc, (size_t)c->rows_chunk_cap * 4 * 64));
-  CTX_HIP(hipMemset(c->d_rows_arrivals, 0, (size_t)c->rows_chunk_cap * sizeof(uint32_t)));
+  if (full) {
+    CTX_TRY(dev_alloc(acct, &c->d_rows_scratch, (size_t)c->rows_chunk_cap * 8 * 64));
+    CTX_TRY(dev_alloc(acct, &c->d_rows_arrivals, (size_t)c->rows_chunk_cap));
+    CTX_TRY(dev_alloc(acct, &c->d_flagged_desc, (size_t)c->rows_chunk_cap * 4 * 64));
+    CTX_HIP(hipMemset(c->d_rows_arrivals, 0, (size_t)c->rows_chunk_cap * sizeof(uint32_t)));
+  }
   CTX_TRY(dev_alloc(acct, &c->d_k1_counters, (size_t)2));
   CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
   CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views + 1));
-  CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
+  if (full) CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_geo_model, ((size_t)m->n_views + 1) * 10));
   // everything a finished query reports lives in ONE device record laid out as HostResult: one D2H copy per query
   CTX_TRY(dev_alloc(acct, &c->d_result, sizeof(HostResult)));
@@ -218,7 +224,7 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr) {
     c->d_pair_landmark = r->pair_landmark;
   }
   CTX_TRY(dev_alloc(acct, &c->d_cand_part, (size_t)kPartHeaderBytes + (size_t)c->cand_cap * sizeof(Candidate)));
-  CTX_TRY(dev_alloc(acct, &c->d_geo_dist, (size_t)m->n_rows));
+  if (full) CTX_TRY(dev_alloc(acct, &c->d_geo_dist, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_best64, (size_t)65536));
   CTX_TRY(dev_alloc(acct, &c->d_winner, (size_t)65536));
   CTX_TRY(dev_alloc(acct, &c->d_ms_n, (size_t)1));
@@ -365,6 +371,7 @@ int ctx_localize_begin(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_se
 // sfmloc_localize_bow_begin) -- the block list is then built by a kernel and the host never sees the views
 int ctx_match_putative(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel, const uint32_t *d_sel) {
   Map *m = c->map;
+  SFM_CHECK(!c->merge_only, SFMLOC_EINVAL, "this context was created for sfmloc_merge_begin only (sfmloc_context_create_merge)");
   const bool all_views = (view_sel == nullptr && d_sel == nullptr);
   if (all_views) n_sel = m->n_views;
   SFM_CHECK(n_sel <= m->n_views, SFMLOC_EINVAL, "view selection: n_sel %u > n_views %u", n_sel, m->n_views);
@@ -1004,6 +1011,21 @@ int sfmloc_context_create_sharing(sfmloc_map *map, sfmloc_context *lender, sfmlo
   return SFMLOC_OK;
 }
 
+int sfmloc_context_create_merge(sfmloc_map *map, sfmloc_context *lender, sfmloc_context **out) {
+  SFM_CHECK(map && out, SFMLOC_EINVAL, "sfmloc_context_create_merge: null argument");
+  Map *m = reinterpret_cast<Map *>(map);
+  Ctx *l = reinterpret_cast<Ctx *>(lender);
+  SFM_CHECK(!l || l->map == m, SFMLOC_EINVAL, "sfmloc_context_create_merge: the lender belongs to another map");
+  SFM_HIP(hipSetDevice(m->device));
+  Ctx *c = nullptr;
+  int rc = make_ctx(m, &c, l, /*merge_only=*/true);
+  if (rc) return rc;
+  m->pool.push_back(c);
+  m->hbm_bytes += c->hbm_bytes;
+  *out = reinterpret_cast<sfmloc_context *>(c);
+  return SFMLOC_OK;
+}
+
 void sfmloc_context_destroy(sfmloc_context *ctx) {
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   if (!c) return;
@@ -1362,6 +1384,7 @@ int sfmloc_localize_bow_begin(sfmloc_context *ctx, sfmloc_query *query, const fl
   SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: query belongs to another map");
   SFM_CHECK(m->bow_dim > 0 && m->d_bow, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: the map has no .bow vectors");
   SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: context already has a query in flight");
+  SFM_CHECK(!c->merge_only, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: this context was created for sfmloc_merge_begin only");
   if (!cand_views) n_cand = m->n_views;
   SFM_CHECK(n_cand <= m->n_views, SFMLOC_EINVAL, "sfmloc_localize_bow_begin: n_cand > n_views");
   SFM_HIP(hipSetDevice(m->device));
@@ -1466,6 +1489,7 @@ int sfmloc_shard_begin_bow(sfmloc_context *ctx, sfmloc_query *query, const void 
   Map *m = c->map;
   SFM_CHECK(q->map == m, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: query belongs to another map");
   SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: context has a query in flight");
+  SFM_CHECK(!c->merge_only, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: this context was created for sfmloc_merge_begin only");
   if (part_stride_keys == 0) part_stride_keys = knn;
   SFM_CHECK(part_stride_keys >= knn, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: part_stride_keys < knn");
   SFM_HIP(hipSetDevice(m->device));

@@ -164,6 +164,7 @@ struct Ctx {
   CtxStream stream;  // gang.h: reads as the stream to queue on now (the context's own, or its gang's while recording)
   bool stream_borrowed = false;    // stream.own belongs to `lender` (sfmloc_context_create_sharing)
   Ctx *lender = nullptr;
+  bool merge_only = false;         // no workspace of the matching stages (sfmloc_context_create_merge)
   int borrowers = 0;               // contexts working on this one's stream
   bool zombie = false;             // destroyed while lent out: freed with its last borrower
   std::vector<GangRec> gang_recs;  // launches recorded for the gang session in progress

@@ -366,8 +366,9 @@ class HipShardCompute:
         if self.gang > 1:
             self.ctx2 = []
             for _ in range(2):
-                lead = shard_map.context()
-                self.ctx2.append([lead] + [shard_map.context(share=lead) for _ in range(self.n_stage2 - 1)])
+                lead = shard_map.context(merge_only=True)
+                self.ctx2.append([lead] + [shard_map.context(share=lead, merge_only=True)
+                                           for _ in range(self.n_stage2 - 1)])
         self._buf = {}
         self._queries = [None] * self.n_slots
 

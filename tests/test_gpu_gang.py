@@ -79,6 +79,13 @@ def test_whole_path_in_a_gang_equals_one_at_a_time(own_streams):
         with capi.gang([lead, ctxs[1]]):
             with pytest.raises(S.SfmlocError):
                 capi._check(capi._L().sfmloc_gang_begin((capi.C.c_void_p * 1)(ctxs[1]._h), 1))
+        # a merge-only context (no matching workspace) refuses everything but the merge
+        mc = dm.context(merge_only=True)
+        with pytest.raises(S.SfmlocError):
+            mc.begin_bow(dqs[0], None, 20)
+        with pytest.raises(S.SfmlocError):
+            mc.begin(dqs[0])
+        mc.close()
         # a lender destroyed before its borrowers: its stream lives on until the last of them goes
         lead.close()
         ctxs[2].begin_bow(dqs[1], None, 20)
