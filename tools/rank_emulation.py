@@ -154,7 +154,8 @@ def main():
     ok = run(a.steps)
     dt = time.perf_counter() - t0
     print(json.dumps({
-        "emulated": f"rank 0 of {N}", "batch": B, "steps": a.steps, "contexts_per_slot": a.in_flight,
+        "emulated": f"rank 0 of {N}", "map_views": a.views, "map_rows": int(m.n_rows), "shard_rows": int(m.view_off[a.views // N]),
+        "bow_knn": a.bow_knn, "batch": B, "steps": a.steps, "contexts_per_slot": a.in_flight,
         "queries_per_launch_stage1": getattr(comp, "gang", 1),
         "ms_per_batch": dt / a.steps * 1e3,
         "host_ms_per_batch_in": {k: v / a.steps * 1e3 for k, v in host.items()},
