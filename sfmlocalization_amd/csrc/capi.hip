@@ -517,7 +517,9 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
     const int v = e ? atoi(e) : 0;
     return (v >= 1 && v <= 64) ? v : 9;
   }();
-  const int rounds = first_call ? env_rounds : 6;
+  // (in a gang session a surplus round costs a fraction of a launch, and a member that needs more than were queued gets
+  // them alone on the gang's stream: three more up front)
+  const int rounds = first_call ? (c->stream.gang ? std::max(env_rounds, 12) : env_rounds) : 6;
   for (int r = 0; r < rounds && rc == SFMLOC_OK; ++r)
     rc = launch_p3p_round(c, (first_call && r == 0) ? 64 : env_batch);
   if (rc == SFMLOC_OK) rc = launch_p3p_finish(c);  // pose + inlier pairs once the state says "done"; a no-op before
