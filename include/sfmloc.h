@@ -183,6 +183,17 @@ void sfmloc_query_destroy(sfmloc_query *q);
  * LocalizeEngine.cc:337-340): sfmloc_localize_bow_begin / sfmloc_shard_bow_keys then take query_bow = NULL and no
  * per-call upload happens.  Synchronous. */
 int sfmloc_query_set_bow(sfmloc_query *q, const float *query_bow);
+/* A query over arrays that already ARE in device memory and stay the caller's -- e.g. slices of the buffer an all-gather
+ * of extracted features wrote (images in on several ranks: the rank that owns a query extracts it, every rank matches
+ * it).  Nothing is allocated or copied; the arrays must stay valid and unchanged while the query is in use.
+ *   desc_dev  uint8 [n_pad * 64], row major, n_pad = n rounded up to a multiple of 64, the rows beyond n ZERO; 16-byte aligned
+ *   kpt_dev   float [n * 2] as extracted;  kpt6_dev  float [n * 2] after sfmloc_feat_round_trip;  8-byte aligned
+ *   bow_dev   float [bow_dim of the map], or NULL (then the calls that need one take a host pointer as usual)
+ * sfmloc_feat_round_trip: host helper, the `.feat` text round trip of the keypoints (6 significant digits,
+ * AKAZEOpenCV.cpp:80-81 / :106-111) that sfmloc_query_create applies itself. */
+int sfmloc_query_create_view(sfmloc_map *map, const void *desc_dev, const void *kpt_dev, const void *kpt6_dev,
+                             const void *bow_dev, uint32_t n, uint32_t width, uint32_t height, sfmloc_query **out);
+void sfmloc_feat_round_trip(const float *kpt_xy, uint64_t n_values, float *out);
 
 /* ------------------------------------------------------------------------- */
 /* Stage A6+A7: putative matching.                                             */

@@ -120,6 +120,7 @@ SYMBOLS = [
     "sfmloc_query_set_bow", "sfmloc_context_signal", "sfmloc_context_wait", "sfmloc_shard_bow_keys",
     "sfmloc_geometric_read_pairs", "sfmloc_shard_begin_bow", "sfmloc_packed_bytes", "sfmloc_shard_export_packed", "sfmloc_merge_begin_packed",
     "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing", "sfmloc_context_create_merge",
+    "sfmloc_query_create_view", "sfmloc_feat_round_trip",
 ]
 
 _bound = False
@@ -142,6 +143,17 @@ class gang:
     def __exit__(self, *exc):
         _check(_L().sfmloc_gang_end(self._arr, len(self.ctxs)))
         return False
+
+
+def feat_round_trip(kpt_xy):
+    """sfmloc_feat_round_trip: the keypoints after the reference's `.feat` text round trip (6 significant digits)."""
+    k = np.ascontiguousarray(kpt_xy, dtype=np.float32)
+    out = np.empty_like(k)
+    L = _L()
+    L.sfmloc_feat_round_trip.restype = None
+    L.sfmloc_feat_round_trip.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_float)]
+    L.sfmloc_feat_round_trip(_ptr(k, C.c_float), k.size, _ptr(out, C.c_float))
+    return out
 
 
 def gang_counters(lead_ctx):
@@ -579,6 +591,10 @@ class Map:
         _check(_L().sfmloc_sync(self._h))
 
     # ----- map-side matching (matchAKAZE / trackAKAZE, MatchUtils.cpp:73-277) -----
+    def query_view(self, desc_ptr, kpt_ptr, kpt6_ptr, bow_ptr, n, width, height):
+        """sfmloc_query_create_view: a query over device arrays that stay the caller's (integers = device pointers)."""
+        return Query._over_device_arrays(self, desc_ptr, kpt_ptr, kpt6_ptr, bow_ptr, n, width, height)
+
     def query_from_view(self, view_index):
         """sfmloc_query_from_view: one map image's descriptors as a Query (rebuilt from the bank on the device)."""
         return Query._from_view(self, int(view_index))
@@ -1016,6 +1032,20 @@ class Query:
         """sfmloc_query_set_bow: the query's BoW vector becomes resident with it."""
         b = np.ascontiguousarray(bow, dtype=np.float32).ravel()
         _check(_L().sfmloc_query_set_bow(self._h, _ptr(b, C.c_float)))
+
+    @classmethod
+    def _over_device_arrays(cls, m, desc_ptr, kpt_ptr, kpt6_ptr, bow_ptr, n, width, height):
+        self = cls.__new__(cls)
+        self._h = None
+        self.map = m
+        self.n = int(n)
+        h = C.c_void_p()
+        _check(_L().sfmloc_query_create_view(m._h, C.c_void_p(desc_ptr), C.c_void_p(kpt_ptr), C.c_void_p(kpt6_ptr),
+                                             C.c_void_p(bow_ptr) if bow_ptr else None, int(n), int(width), int(height),
+                                             C.byref(h)))
+        self._h = h
+        m._children.add(self)
+        return self
 
     @classmethod
     def _from_view(cls, m, view_index):

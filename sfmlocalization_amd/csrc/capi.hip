@@ -1096,6 +1096,39 @@ int sfmloc_query_create(sfmloc_map *map, const uint8_t *desc, const float *kpt_x
   return SFMLOC_OK;
 }
 
+void sfmloc_feat_round_trip(const float *kpt_xy, uint64_t n_values, float *out) {
+  char buf[64];
+  for (uint64_t i = 0; i < n_values; ++i) {  // (the same two lines as in sfmloc_query_create)
+    snprintf(buf, sizeof(buf), "%.6g", (double)kpt_xy[i]);
+    out[i] = strtof(buf, nullptr);
+  }
+}
+
+int sfmloc_query_create_view(sfmloc_map *map, const void *desc_dev, const void *kpt_dev, const void *kpt6_dev,
+                             const void *bow_dev, uint32_t n, uint32_t width, uint32_t height, sfmloc_query **out) {
+  SFM_CHECK(map && out, SFMLOC_EINVAL, "sfmloc_query_create_view: null argument");
+  *out = nullptr;
+  SFM_CHECK(n == 0 || (desc_dev && kpt_dev && kpt6_dev), SFMLOC_EINVAL, "sfmloc_query_create_view: null device pointer");
+  SFM_CHECK(n <= SFMLOC_MAX_QUERY_ROWS, SFMLOC_EINVAL, "sfmloc_query_create_view: %u query descriptors > %u", n,
+            SFMLOC_MAX_QUERY_ROWS);
+  SFM_CHECK(((uintptr_t)desc_dev & 15) == 0 && ((uintptr_t)kpt_dev & 7) == 0 && ((uintptr_t)kpt6_dev & 7) == 0 &&
+                ((uintptr_t)bow_dev & 3) == 0,
+            SFMLOC_EINVAL, "sfmloc_query_create_view: misaligned device pointer (descriptors 16, keypoints 8, bow 4 bytes)");
+  Query *q = new (std::nothrow) Query();
+  SFM_CHECK(q, SFMLOC_ENOMEM, "out of host memory");
+  q->map = reinterpret_cast<Map *>(map);
+  q->n = n;
+  q->width = width;
+  q->height = height;
+  q->is_view = true;
+  q->d_desc = reinterpret_cast<uint4 *>(const_cast<void *>(desc_dev));
+  q->d_kpt = reinterpret_cast<float2 *>(const_cast<void *>(kpt_dev));
+  q->d_kpt6 = reinterpret_cast<float2 *>(const_cast<void *>(kpt6_dev));
+  q->d_bow = reinterpret_cast<float *>(const_cast<void *>(bow_dev));
+  *out = reinterpret_cast<sfmloc_query *>(q);
+  return SFMLOC_OK;
+}
+
 void sfmloc_query_destroy(sfmloc_query *query) {
   Query *q = reinterpret_cast<Query *>(query);
   if (!q) return;
@@ -1111,10 +1144,12 @@ void sfmloc_query_destroy(sfmloc_query *query) {
         if (c->last_query == q) c->last_query = nullptr;
       }
   }
-  if (q->d_desc) hipFree(q->d_desc);
-  if (q->d_kpt) hipFree(q->d_kpt);
-  if (q->d_kpt6) hipFree(q->d_kpt6);
-  if (q->d_bow) hipFree(q->d_bow);
+  if (!q->is_view) {  // (a view's arrays are the caller's)
+    if (q->d_desc) hipFree(q->d_desc);
+    if (q->d_kpt) hipFree(q->d_kpt);
+    if (q->d_kpt6) hipFree(q->d_kpt6);
+    if (q->d_bow) hipFree(q->d_bow);
+  }
   delete q;
 }
 
@@ -1123,6 +1158,7 @@ int sfmloc_query_set_bow(sfmloc_query *query, const float *query_bow) {
   Query *q = reinterpret_cast<Query *>(query);
   Map *m = q->map;
   SFM_CHECK(m && m->bow_dim > 0, SFMLOC_EINVAL, "sfmloc_query_set_bow: the map has no .bow vectors");
+  SFM_CHECK(!q->is_view, SFMLOC_EINVAL, "sfmloc_query_set_bow: a view's BoW vector is given to sfmloc_query_create_view");
   SFM_HIP(hipSetDevice(m->device));
   if (!q->d_bow) SFM_HIP(hipMalloc((void **)&q->d_bow, (size_t)m->bow_dim * sizeof(float)));
   SFM_HIP(hipMemcpy(q->d_bow, query_bow, (size_t)m->bow_dim * sizeof(float), hipMemcpyHostToDevice));

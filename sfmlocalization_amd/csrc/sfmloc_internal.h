@@ -304,6 +304,7 @@ struct Query {
   float2 *d_kpt6 = nullptr;  // after the .feat text round trip (6 significant digits): used by the F-matrix filter
   float *d_bow = nullptr;    // the query's BoW vector, resident (sfmloc_query_set_bow), [bow_dim] or null
   std::vector<float> h_kpt;
+  bool is_view = false;  // the device arrays belong to the caller (sfmloc_query_create_view)
 };
 
 // capi.hip: K1 + K2 of the selected views against q on context c (sfmloc_match_putative's body)

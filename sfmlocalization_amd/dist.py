@@ -160,6 +160,54 @@ def unpack_batch(buf, qi):
     return np.frombuffer(buf[base + off * 40: base + (off + n) * 40].tobytes(), CANDIDATE_DTYPE)
 
 
+# ----- images in on several ranks: the extracted features of a batch, exchanged like the candidates ------------------
+# The rank that owns query i (i mod world) extracts it; ONE all-gather per batch hands every rank every query as a
+# fixed-capacity block {u32 n, width, height, 0 | desc [cap x 64] (rows beyond n zero) | kpt [cap x 2 f32] |
+# kpt after the .feat round trip [cap x 2 f32] | BoW vector [bow_dim f32]}, and the queries of the batch are VIEWS
+# into the gathered buffer (sfmloc_query_create_view): nothing is copied or allocated per query.
+FEATURE_HEADER_BYTES = 16
+
+
+def feature_block_layout(cap, bow_dim):
+    """-> (offset of desc, kpt, kpt6, bow, block bytes); cap must be a multiple of 64 (the bank's row blocks)"""
+    assert cap % 64 == 0 and cap > 0
+    o_desc = FEATURE_HEADER_BYTES
+    o_kpt = o_desc + cap * 64
+    o_kpt6 = o_kpt + cap * 8
+    o_bow = o_kpt6 + cap * 8
+    total = (o_bow + bow_dim * 4 + 15) // 16 * 16
+    return o_desc, o_kpt, o_kpt6, o_bow, total
+
+
+def pack_features(desc, kpt_xy, kpt6_xy, width, height, bow, cap, bow_dim):
+    """one query's block (uint8 [block bytes]); kpt6_xy = capi.feat_round_trip(kpt_xy)"""
+    o_desc, o_kpt, o_kpt6, o_bow, total = feature_block_layout(cap, bow_dim)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 64)
+    n = desc.shape[0]
+    if n > cap:
+        raise OverflowError(f"{n} features > the exchange's capacity of {cap} per query")
+    b = np.zeros(total, np.uint8)
+    b[:16].view(np.uint32)[:3] = (n, width, height)
+    b[o_desc:o_desc + n * 64] = desc.ravel()
+    b[o_kpt:o_kpt + n * 8] = np.ascontiguousarray(kpt_xy, np.float32).reshape(-1).view(np.uint8)
+    b[o_kpt6:o_kpt6 + n * 8] = np.ascontiguousarray(kpt6_xy, np.float32).reshape(-1).view(np.uint8)
+    if bow_dim:
+        b[o_bow:o_bow + bow_dim * 4] = np.ascontiguousarray(bow, np.float32).reshape(-1)[:bow_dim].view(np.uint8)
+    return b
+
+
+def unpack_features(block, cap, bow_dim):
+    """-> (desc [n, 64], kpt [n, 2], kpt6 [n, 2], width, height, bow [bow_dim])  (host side of the layout: tests,
+    stand-in compute objects)"""
+    o_desc, o_kpt, o_kpt6, o_bow, total = feature_block_layout(cap, bow_dim)
+    block = np.ascontiguousarray(block, np.uint8)
+    n, w, h = (int(x) for x in block[:16].view(np.uint32)[:3])
+    return (block[o_desc:o_desc + n * 64].reshape(n, 64).copy(),
+            block[o_kpt:o_kpt + n * 8].view(np.float32).reshape(n, 2).copy(),
+            block[o_kpt6:o_kpt6 + n * 8].view(np.float32).reshape(n, 2).copy(), w, h,
+            block[o_bow:o_bow + bow_dim * 4].view(np.float32).copy())
+
+
 class ShardedLocalizer:
     """One batch = (optional) sharded BoW shortlist -> stage 1 on every shard -> ONE all-gather of the shards' packed
     candidate parts -> stage 2 (2D-3D selection + P3P) of query i on rank i mod world.
@@ -193,7 +241,7 @@ class ShardedLocalizer:
 
     def reset_counters(self):
         self._n_batches = self._n_queries = self._n_redo = 0
-        self._bytes_parts = self._bytes_keys = 0
+        self._bytes_parts = self._bytes_keys = self._bytes_feats = 0
         self._max_total = 0
 
     def counters(self):
@@ -201,6 +249,7 @@ class ShardedLocalizer:
         return {"batches": self._n_batches, "queries": self._n_queries,
                 "candidate_allgather_bytes_per_batch_per_rank": self._bytes_parts / nb,
                 "bow_key_allgather_bytes_per_batch_per_rank": self._bytes_keys / nb,
+                **({"feature_allgather_bytes_per_batch_per_rank": self._bytes_feats / nb} if self._bytes_feats else {}),
                 "budget_candidates_per_query": self.budget_per_query,
                 "max_candidates_of_one_shard_for_one_batch": int(self._max_total),
                 "batches_exchanged_again_with_a_larger_budget": self._n_redo}
@@ -244,6 +293,32 @@ class ShardedLocalizer:
     def _after(self, slot):
         if hasattr(self.compute, "after_collective"):
             self.compute.after_collective(slot)
+
+    # ----- images in: the batch's features ------------------------------------------------------------------------
+    def gather_queries(self, own_blocks, n_queries, cap, bow_dim, slot=0):
+        """own_blocks {i: uint8 block (pack_features)} for the queries i of the batch that this rank owns and has
+        extracted -> the batch's n_queries queries, as the compute object makes them over the gathered buffer
+        (compute.query_views(gathered [world, per_rank, block], cap, bow_dim, n_queries)); every rank gets the same
+        list.  One all-gather of per_rank x block bytes per rank."""
+        import torch
+        per = -(-n_queries // self.world)
+        total = feature_block_layout(cap, bow_dim)[4]
+        send = np.zeros((per, total), np.uint8)
+        for i, b in own_blocks.items():
+            assert self.owner(i) == self.rank and 0 <= i < n_queries
+            send[i // self.world] = b
+        import contextlib
+        dev = getattr(self.compute, "device", None)
+        t = torch.from_numpy(send)
+        if dev is not None and dev.type == "cuda":
+            comm = self._comm_stream()     # (the upload on the stream the collective runs on: ordered before it)
+            with (torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()):
+                t = t.pin_memory().to(dev, non_blocking=True)
+        gathered, ev = self._all_gather(t)
+        if ev is not None:
+            ev.synchronize()
+        self._bytes_feats += t.numel()
+        return self.compute.query_views(gathered, cap, bow_dim, n_queries, slot)
 
     # ----- one batch ----------------------------------------------------------------------------------------------
     def _use_bow(self, bow_knn):
@@ -370,9 +445,16 @@ class HipShardCompute:
                 self.ctx2.append([lead] + [shard_map.context(share=lead, merge_only=True)
                                            for _ in range(self.n_stage2 - 1)])
         self._buf = {}
+        self._views = {}       # slot -> the query views of its last image batch, and the buffer they point into
+        self._feat_keep = {}
         self._queries = [None] * self.n_slots
 
     def close(self):
+        for qs in self._views.values():
+            for q in qs:
+                q.close()
+        self._views = {}
+        self._feat_keep = {}
         for cs in self.ctxs:
             for c in reversed(cs):          # (a gang's members before the context whose stream they borrow)
                 c.close()
@@ -427,6 +509,27 @@ class HipShardCompute:
                 for c, i in work:
                     c.shard_bow_keys(queries[i], knn, base + i * knn * 8)
         return keys
+
+    def query_views(self, gathered, cap, bow_dim, n_queries, slot=0):
+        """the batch's queries as views into the gathered feature blocks (query i: rank i mod world, block i // world);
+        the buffer is kept until the slot's next batch"""
+        import torch
+        world, per, total = gathered.shape
+        o_desc, o_kpt, o_kpt6, o_bow, tot = feature_block_layout(cap, bow_dim)
+        assert tot == total and gathered.is_contiguous() and gathered.data_ptr() % 16 == 0
+        hdr = gathered[:, :, :16].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        for q in self._views.get(slot, ()):
+            q.close()
+        self._views[slot] = []
+        self._feat_keep[slot] = gathered
+        base = gathered.data_ptr()
+        for i in range(n_queries):
+            r, j = i % world, i // world
+            p = base + (r * per + j) * total
+            n, w, h = (int(x) for x in hdr[r, j, :3])
+            self._views[slot].append(self.map.query_view(p + o_desc, p + o_kpt, p + o_kpt6, p + o_bow if bow_dim else 0,
+                                                         n, w, h))
+        return list(self._views[slot])
 
     def _packed(self, slot, B, budget):
         """the slot's packed part with its header zeroed on the collective's stream, which the slot's contexts then

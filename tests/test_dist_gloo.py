@@ -112,6 +112,24 @@ def test_gang_sessions_cover_every_query_once_on_its_context():
         assert sorted(seen) == list(range(n_q))
 
 
+def test_feature_block_roundtrip_and_capacity():
+    rng = np.random.Generator(np.random.PCG64(3))
+    for n, cap, bow_dim in ((0, 64, 0), (1, 64, 4), (64, 64, 500), (200, 256, 500)):
+        desc = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+        kpt = rng.uniform(0, 2000, (n, 2)).astype(np.float32)
+        k6 = kpt + 0.5
+        bow = rng.random(bow_dim).astype(np.float32)
+        b = D.pack_features(desc, kpt, k6, 1920, 1080, bow, cap, bow_dim)
+        o_desc, o_kpt, o_kpt6, o_bow, total = D.feature_block_layout(cap, bow_dim)
+        assert b.shape == (total,) and total % 16 == 0 and o_desc % 16 == 0 and o_kpt % 8 == 0 and o_bow % 4 == 0
+        assert not b[o_desc + n * 64:o_kpt].any()                  # the rows beyond n are zero (the kernels rely on it)
+        d2, k2, k62, w, h, bow2 = D.unpack_features(b, cap, bow_dim)
+        assert np.array_equal(d2, desc) and np.array_equal(k2, kpt) and np.array_equal(k62, k6)
+        assert (w, h) == (1920, 1080) and np.array_equal(bow2, bow)
+    with pytest.raises(OverflowError):
+        D.pack_features(np.zeros((65, 64), np.uint8), np.zeros((65, 2)), np.zeros((65, 2)), 1, 1, None, 64, 0)
+
+
 def test_k_best_equals_full_sort():
     """dist._k_best (partition + tie handling) against the full (distance, id) sort it replaces."""
     rng = np.random.Generator(np.random.PCG64(16))
@@ -162,6 +180,18 @@ class OracleShardCompute:
         sels = [self.v0 + D.select_from_keys(ka[:, i, :], knn, ids) for i in range(len(queries))]
         return self._parts(queries, slot, budget, sels)
 
+    def query_views(self, gathered, cap, bow_dim, n_queries, slot=0):
+        """images in: the batch's queries out of the gathered feature blocks (host copies here; HipShardCompute makes
+        views into the device buffer)"""
+        import types
+        g = gathered.numpy()
+        world = g.shape[0]
+        out = []
+        for i in range(n_queries):
+            desc, kpt, kpt6, w, h, bow = D.unpack_features(g[i % world, i // world], cap, bow_dim)
+            out.append(types.SimpleNamespace(desc=desc, kpt_xy=kpt, kpt6_xy=kpt6, width=w, height=h, bow=bow))
+        return out
+
     def stage2(self, indices, gathered, slot=0, budget=0):
         from oracle import pipeline as opipe
         g = gathered.numpy()
@@ -211,6 +241,24 @@ def _worker(rank, world, port, q):
                 if out[i]["ok"]:
                     assert np.array_equal(np.asarray(out[i]["pair_qfeat"]), np.asarray(res[k]["pair_qfeat"]))
                     assert np.array_equal(np.asarray(out[i]["P"]), np.asarray(res[k]["P"]))
+        # images in: every rank "extracts" only the queries it owns, one all-gather of feature blocks hands every rank
+        # the whole batch, and the batch localises as before
+        from sfmlocalization_amd import capi
+        cap, bow_dim = 320, 12
+        own = {i: D.pack_features(qq.desc, qq.kpt_xy, capi.feat_round_trip(qq.kpt_xy), qq.width, qq.height, qq.bow, cap,
+                                  bow_dim)
+               for i, qq in enumerate(queries) if i % world == rank}
+        imgloc = D.ShardedLocalizer(OracleShardCompute(m, v0, v1, cap=2048), budget_per_query=2048)
+        got_q = imgloc.gather_queries(own, len(queries), cap, bow_dim)
+        for a, b in zip(got_q, queries):
+            assert np.array_equal(a.desc, b.desc) and np.array_equal(a.kpt_xy, b.kpt_xy.astype(np.float32))
+            assert np.array_equal(a.kpt6_xy, capi.feat_round_trip(b.kpt_xy)) and (a.width, a.height) == (b.width, b.height)
+            assert np.array_equal(a.bow, b.bow)
+        res_img = imgloc.localize_batch(got_q)
+        assert (imgloc.counters()["feature_allgather_bytes_per_batch_per_rank"]
+                == -(-len(queries) // world) * D.feature_block_layout(cap, bow_dim)[4])
+        for k in res:
+            assert res_img[k]["ok"] == res[k]["ok"] and np.array_equal(res_img[k]["ms_qfeat"], res[k]["ms_qfeat"])
         if rank == 0:
             pack = lambda rr: {i: {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()}  # noqa: E731
                                for i, r in rr.items()}

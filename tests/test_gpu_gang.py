@@ -151,3 +151,43 @@ def test_sharded_layer_with_gangs_equals_without(gang):
         assert sum(int(r["ok"]) for r in out[1][0].values()) >= 4
         for dq in dqs:
             dq.close()
+
+
+@pytest.mark.parametrize("gang", [1, 4])
+def test_queries_as_views_into_the_gathered_feature_blocks(gang):
+    """images in on several ranks (dist.gather_queries): the owner packs a query's extracted features, the all-gather's
+    buffer holds every query of the batch, and the queries are views into it (sfmloc_query_create_view) -- same poses as
+    queries uploaded the usual way, through the sharded shortlist and both stages, with and without gangs."""
+    import torch
+    from sfmlocalization_amd import dist as D
+    m, bow, place_bow = scene(44)
+    dev = torch.device("cuda", 0)
+    with device_map(m, bow) as dm:
+        qs = [synth.make_query(m, 800 + k, n_feat=300 + 90 * k, n_copies=150, outlier_frac=0.3) for k in range(6)]
+        qbow = [place_bow[q.place] for q in qs]
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in qs]
+        for dq, b in zip(dqs, qbow):
+            dq.set_bow(b)
+        comp = D.HipShardCompute(dm, n_contexts=2 * gang if gang > 1 else 4, device=dev, gang=gang)
+        loc = D.ShardedLocalizer(comp, rank=0, world=1, n_views_global=m.n_views)
+        ref = loc.localize_batch(dqs, bow_knn=15)
+        cap, bow_dim = 832, 64
+        own = {i: D.pack_features(q.desc, q.kpt_xy, capi.feat_round_trip(q.kpt_xy), q.width, q.height, b, cap, bow_dim)
+               for i, (q, b) in enumerate(zip(qs, qbow))}
+        for _ in range(2):                                        # the second batch replaces the first one's views
+            views = loc.gather_queries(own, len(qs), cap, bow_dim)
+            assert [v.n for v in views] == [q.desc.shape[0] for q in qs]
+            got = loc.localize_batch(views, bow_knn=15)
+            for i in ref:
+                assert got[i]["ok"] == ref[i]["ok"] and got[i]["n_inliers"] == ref[i]["n_inliers"]
+                np.testing.assert_array_equal(got[i]["pair_qfeat"], ref[i]["pair_qfeat"])
+                np.testing.assert_array_equal(bits(got[i]["P"].ravel()), bits(ref[i]["P"].ravel()))
+        assert sum(int(r["ok"]) for r in ref.values()) >= 3
+        assert loc.counters()["feature_allgather_bytes_per_batch_per_rank"] > 0
+        with pytest.raises(S.SfmlocError):                        # a view's BoW vector is part of the view
+            views[0].set_bow(qbow[0])
+        with pytest.raises(OverflowError):
+            D.pack_features(qs[5].desc, qs[5].kpt_xy, qs[5].kpt_xy, 1, 1, qbow[5], 64, bow_dim)
+        comp.close()
+        for dq in dqs:
+            dq.close()

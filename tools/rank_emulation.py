@@ -34,6 +34,11 @@ def main():
     ap.add_argument("--in-flight", type=int, default=8, help="contexts per slot (the sharded path keeps two slots)")
     ap.add_argument("--gang", type=int, default=0, help="queries per launch in stage 1 (0 = the library's default)")
     ap.add_argument("--only-stage1", action="store_true", help="diagnosis: no query is owned here (stage 2 never runs)")
+    ap.add_argument("--images", choices=["", "vga", "1080p"], default="",
+                    help="images in: rank 0 extracts AKAZE + M-LDB features of one synthetic frame per query it owns "
+                         "(cost only: the map is synthetic, so the localised features stay the synthetic query's), packs "
+                         "them, and the batch's queries are views into the gathered feature blocks (dist.gather_queries)")
+    ap.add_argument("--extract-workers", type=int, default=4, help="host threads (one extractor and stream each)")
     a = ap.parse_args()
     N, B = a.of, a.batch
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, 2 * a.in_flight + 2))))
@@ -95,7 +100,7 @@ def main():
         """rank 0 of N; the collectives replaced by device copies of what the other ranks would have sent"""
 
         def _all_gather(self, send):
-            stored = keys if send.dtype == torch.int64 else parts
+            stored = keys if send.dtype == torch.int64 else (parts if send.dim() == 1 else feats)
             out = torch.empty((N,) + tuple(send.shape), dtype=send.dtype, device=send.device)
             comm = self._comm_stream()
             with torch.cuda.stream(comm):
@@ -105,6 +110,45 @@ def main():
                     out[r].copy_(stored[r])
                 ev = comm.record_event()
             return out, ev
+
+    # ---- images in: the other ranks' feature blocks, once; extractors for this rank's share --------------------------
+    feats = [None] * N
+    extract = None
+    if a.images:
+        from concurrent.futures import ThreadPoolExecutor
+        from sfmlocalization_amd import capi
+        hw = (480, 640) if a.images == "vga" else (1080, 1920)
+        cap_f, bow_dim = (a.nq + 63) // 64 * 64, bow.shape[1]
+        per = -(-B // N)
+        block = D.feature_block_layout(cap_f, bow_dim)[4]
+        packed = {}
+
+        def pack(i):
+            k = batch_ids[i]
+            if k not in packed:
+                q = queries[k]
+                packed[k] = D.pack_features(q.desc, q.kpt_xy, capi.feat_round_trip(q.kpt_xy), q.width, q.height, qbow[k],
+                                            cap_f, bow_dim)
+            return packed[k]
+        for r in range(1, N):
+            blk = np.zeros((per, block), np.uint8)
+            for i in range(r, B, N):
+                blk[i // N] = pack(i)
+            feats[r] = torch.from_numpy(blk).to(dev)
+        frames = [synth.texture_image(900 + k, hw[0], hw[1]) for k in range(4)]
+        extractors = [S.Akaze(hw[1], hw[0], device=0) for _ in range(a.extract_workers)]
+        pool = ThreadPoolExecutor(a.extract_workers)
+        mine_i = list(range(0, B, N))
+        n_kp = [0]
+
+        def extract():
+            """this rank's share of a batch: one frame through AKAZE + M-LDB per owned query (W workers), then the blocks"""
+            def work(w):
+                for j in range(w, len(mine_i), a.extract_workers):
+                    kp, _ = extractors[w].detect_and_compute(frames[j % len(frames)])
+                    n_kp[0] = len(kp)
+            list(pool.map(work, range(a.extract_workers)))
+            return {i: pack(i) for i in mine_i}
 
     loc = Emulated(comp, rank=0, world=N, n_views_global=a.views)
     host = {}                                   # host seconds inside each of the compute object's calls
@@ -139,9 +183,23 @@ def main():
     n_ok_check = sum(int(r["ok"]) for r in res.values())
 
     # ---- the rate ---------------------------------------------------------------------------------------------------
+    t_extract = [0.0]
+
+    def batches(n):
+        """descriptors in: the same resident queries every time; images in: extraction, exchange and views per batch
+        (slots alternate as in localize_stream)"""
+        for b in range(n):
+            if extract is None:
+                yield batch
+                continue
+            t = time.perf_counter()
+            own = extract()
+            t_extract[0] += time.perf_counter() - t
+            yield loc.gather_queries(own, B, cap_f, bow_dim, slot=b % 2)
+
     def run(n):
         ok = 0
-        for r in loc.localize_stream([batch] * n, gather_results=False, bow_knn=a.bow_knn):
+        for r in loc.localize_stream(batches(n), gather_results=False, bow_knn=a.bow_knn):
             ok += sum(int(x["ok"]) for x in r.values())
         torch.cuda.synchronize()
         return ok
@@ -150,6 +208,7 @@ def main():
         loc.owner = lambda i: -1
     run(a.warmup)
     host.clear()
+    t_extract[0] = 0.0
     t0 = time.perf_counter()
     ok = run(a.steps)
     dt = time.perf_counter() - t0
@@ -159,6 +218,10 @@ def main():
         "queries_per_launch_stage1": getattr(comp, "gang", 1),
         "ms_per_batch": dt / a.steps * 1e3,
         "host_ms_per_batch_in": {k: v / a.steps * 1e3 for k, v in host.items()},
+        **({"images_in": {"frame": a.images, "keypoints_per_frame": n_kp[0], "frames_extracted_per_batch": len(mine_i),
+                          "extract_workers": a.extract_workers, "extract_ms_per_batch": t_extract[0] / a.steps * 1e3,
+                          "feature_block_bytes": block, "feature_allgather_bytes_per_batch_per_rank": per * block}}
+           if a.images else {}),
         "rank_rate_queries_per_s": a.steps * B / dt,
         "note": "all ranks work in lock step, so this is also the predicted whole-job rate of N ranks, collectives' "
                 "latency excluded",
