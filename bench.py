@@ -63,6 +63,10 @@ def parse(argv=None):
                          "640x480 image on the GPU (sfmloc_akaze_detect_and_compute, its own stream); --in-flight worker "
                          "threads, one extractor and one context each.  The map is synthetic, so the localised descriptors "
                          "are the synthetic query's, not the image's: the point is the cost of extraction sharing the GPU")
+    ap.add_argument("--image-batch", type=int, default=4,
+                    help="--from-images: frames a worker takes at a time -- extracted together "
+                         "(sfmloc_akaze_detect_and_compute_batch: one launch per kernel for all of them) and localised in one "
+                         "gang session on the worker's one stream; 1 = a frame at a time")
     ap.add_argument("--gang", type=int, default=0,
                     help="--gpus > 1: queries per launch in both stages of the sharded path (gang sessions, "
                          "sfmloc_gang_begin/_end); 0 = 16 with more than one rank, 1 = one query per launch")
@@ -444,24 +448,45 @@ def main():
         if sharded is not None:
             raise SystemExit("--from-images is a single-GPU mode")
         import threading
+        from sfmlocalization_amd import capi
         imgs = [synth.texture_image(900 + k, 480, 640) for k in range(4)]
-        extractors = [S.Akaze(640, 480, device=local_rank) for _ in range(nctx)]
-        if os.environ.get("SFMLOC_BENCH_SHARE_STREAM", "1") != "0":
-            for e, c in zip(extractors, ctxs):      # a worker's extractor and context take turns: one stream, one queue
-                e.share_stream(c)
+        G = max(1, min(a.image_batch, capi.GANG_MAX))
+        # a worker = ONE stream: its G extractors and G contexts all queue on the first context's (the frames of a turn
+        # are extracted together and localised in one gang session)
+        groups = []
+        for k in range(nctx):
+            cs = [ctxs[k]] + [dev_map.context(share=ctxs[k]) for _ in range(G - 1)]
+            es = [S.Akaze(640, 480, device=local_rank) for _ in range(G)]
+            if os.environ.get("SFMLOC_BENCH_SHARE_STREAM", "1") != "0":
+                for e in es:
+                    e.share_stream(ctxs[k])
+            groups.append((cs, es))
+        extractors = [e for _, es in groups for e in es]
         n_feat = [0]
         lock = threading.Lock()
 
         def worker(k, first, count):
-            for i in range(first + k, first + count, nctx):
+            cs, es = groups[k]
+            mine = list(range(first + k * G, first + count, nctx * G))
+            for i0 in mine:
+                idx = [i for i in range(i0, min(i0 + G, first + count))]
                 t1 = time.perf_counter()
-                kp, _ = extractors[k].detect_and_compute(imgs[i % len(imgs)])
-                begin(k, i)
-                pose, _, _ = ctxs[k].end()
+                if len(idx) == 1:
+                    feats = [es[0].detect_and_compute(imgs[idx[0] % len(imgs)])]
+                else:
+                    feats = S.Akaze.detect_and_compute_batch(es[:len(idx)], [imgs[i % len(imgs)] for i in idx])
+                with capi.gang(cs[:len(idx)]):
+                    for c, i in zip(cs, idx):
+                        dq = dqs[i % len(dqs)]
+                        if shortlist:
+                            c.begin_bow(dq, None, a.bow_knn)
+                        else:
+                            c.begin(dq)
+                oks = [int(c.end()[0].ok) for c in cs[:len(idx)]]
                 with lock:
-                    lat.append(time.perf_counter() - t1)
-                    n_ok[0] += int(pose.ok)
-                    n_feat[0] = len(kp)
+                    lat.extend([time.perf_counter() - t1] * len(idx))
+                    n_ok[0] += sum(oks)
+                    n_feat[0] = len(feats[0][0])
 
         def run_images(first, count):
             ts = [threading.Thread(target=worker, args=(k, first, count)) for k in range(nctx)]
@@ -471,7 +496,8 @@ def main():
                 t.join()
 
         run = run_images  # noqa: F811
-        img_mode = {"extractors": extractors, "n_feat": n_feat}
+        img_mode = {"extractors": extractors, "n_feat": n_feat, "frames_per_turn": G,
+                    "member_contexts": [c for cs, _ in groups for c in cs[1:]]}
 
     n_timed = a.steps * a.batch
     run(0, a.warmup * a.batch)
@@ -630,7 +656,8 @@ def main():
                     "note": "side note only: brackets of overlapping launches contain queue wait"}
         if img_mode is not None:
             out["config"]["workload"] += ("; image-in mode: each query first runs AKAZE + M-LDB extraction of a 640x480 "
-                                          f"synthetic image on the GPU ({img_mode['n_feat'][0]} keypoints)")
+                                          f"synthetic image on the GPU ({img_mode['n_feat'][0]} keypoints), "
+                                          f"{img_mode['frames_per_turn']} frames per worker turn")
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = (cpu_baseline_shortlist(m, queries, bow, qbow, a.bow_knn, a.cpu_seconds)
                                    if shortlist else cpu_baseline(m, queries, a.cpu_seconds))
@@ -638,6 +665,8 @@ def main():
     if img_mode is not None:
         for e in img_mode["extractors"]:
             e.close()
+        for c in img_mode["member_contexts"]:
+            c.close()
     for c in ctxs:
         c.close()
     if sharded is not None:

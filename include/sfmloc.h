@@ -447,6 +447,12 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
 void sfmloc_akaze_destroy(sfmloc_akaze *ak);
 int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float *kpts, uint8_t *desc64, uint32_t cap,
                                     uint32_t *n_out);
+/* n images of ONE size at once, extractor i taking image i (1 <= n <= 32): the scale spaces, determinants and extrema of
+ * all of them go out as one launch per kernel (a gang session on the first extractor's stream) -- these are launch-bound
+ * kernels on small images, eight frames cost little more than one --, the candidates' refinement on the host and the
+ * orientation + M-LDB launch follow per image.  kpts[i] / descs[i] / n_out[i] as in the single call; same results. */
+int sfmloc_akaze_detect_and_compute_batch(sfmloc_akaze *const *aks, const uint8_t *const *grays, uint32_t n,
+                                          float *const *kpts, uint8_t *const *descs, uint32_t cap, uint32_t *n_out);
 /* kin [n*4]: x, y, size, class_id */
 int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin, uint32_t n, uint8_t *desc64,
                          float *angle_out);

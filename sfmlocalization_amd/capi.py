@@ -111,7 +111,7 @@ SYMBOLS = [
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
     "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
-    "sfmloc_akaze_share_stream",
+    "sfmloc_akaze_share_stream", "sfmloc_akaze_detect_and_compute_batch",
     "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
     "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close", "sfmloc_localize_bow_begin", "sfmloc_localize_bow",
     "sfmloc_pack", "sfmloc_scan_packed", "sfmloc_open_packed",
@@ -880,6 +880,27 @@ class Akaze:
         _check(_L().sfmloc_akaze_detect_and_compute(self._h, _ptr(gray, C.c_uint8), _ptr(kp, C.c_float),
                                                     _ptr(desc, C.c_uint8), cap, C.byref(n)))
         return kp[:n.value].copy(), desc[:n.value].copy()
+
+    @staticmethod
+    def detect_and_compute_batch(extractors, grays, cap=65536):
+        """sfmloc_akaze_detect_and_compute_batch: extractors[i] takes grays[i] (all of one size), the device side of
+        detection as ONE launch per kernel for all of them -> [(kpts, desc)] as detect_and_compute gives."""
+        n = len(extractors)
+        assert n == len(grays) and n >= 1
+        imgs = [np.ascontiguousarray(g, np.uint8) for g in grays]
+        for e, g in zip(extractors, imgs):
+            assert g.shape == (e.height, e.width)
+            if getattr(e, "_out_cap", 0) != cap:
+                e._out_kp = np.zeros((cap, 6), np.float32)
+                e._out_desc = np.zeros((cap, 64), np.uint8)
+                e._out_cap = cap
+        aks = (C.c_void_p * n)(*[e._h for e in extractors])
+        gp = (C.POINTER(C.c_uint8) * n)(*[_ptr(g, C.c_uint8) for g in imgs])
+        kp = (C.POINTER(C.c_float) * n)(*[_ptr(e._out_kp, C.c_float) for e in extractors])
+        dp = (C.POINTER(C.c_uint8) * n)(*[_ptr(e._out_desc, C.c_uint8) for e in extractors])
+        n_out = (C.c_uint32 * n)()
+        _check(_L().sfmloc_akaze_detect_and_compute_batch(aks, gp, n, kp, dp, cap, n_out))
+        return [(e._out_kp[:n_out[i]].copy(), e._out_desc[:n_out[i]].copy()) for i, e in enumerate(extractors)]
 
     def compute(self, gray, kin):
         gray = np.ascontiguousarray(gray, np.uint8)

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "sfmloc_internal.h"
@@ -248,23 +249,29 @@ __global__ void k_scharr(const float *__restrict__ src, float *__restrict__ dst,
   dst[(size_t)y * w + x] = d;
 }
 
-__global__ void k_halfsample(const float *__restrict__ src, int sw, int sh, float *__restrict__ dst, int dw, int dh) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= dw) return;
-  const double sx = (double)sw / dw, sy = (double)sh / dh;
-  const double fx0 = x * sx, fx1 = (x + 1) * sx, fy0 = y * sy, fy1 = (y + 1) * sy;
-  const int ix0 = (int)floor(fx0), iy0 = (int)floor(fy0);
-  const int ix1 = (int)ceil(fx1), iy1 = (int)ceil(fy1);
-  float acc = 0.0f;
-  for (int yy = iy0; yy < iy1 && yy < sh; ++yy) {
-    const double wy = fmin(fy1, yy + 1.0) - fmax(fy0, (double)yy);
-    for (int xx = ix0; xx < ix1 && xx < sw; ++xx) {
-      const double wx = fmin(fx1, xx + 1.0) - fmax(fx0, (double)xx);
-      const float wgt = (float)(wx * wy / (sx * sy));
-      acc = acc + wgt * src[(size_t)yy * sw + xx];
+struct HalfsampleBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ src, int sw, int sh, float *__restrict__ dst, int dw, int dh) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    const double sx = (double)sw / dw, sy = (double)sh / dh;
+    const double fx0 = x * sx, fx1 = (x + 1) * sx, fy0 = y * sy, fy1 = (y + 1) * sy;
+    const int ix0 = (int)floor(fx0), iy0 = (int)floor(fy0);
+    const int ix1 = (int)ceil(fx1), iy1 = (int)ceil(fy1);
+    float acc = 0.0f;
+    for (int yy = iy0; yy < iy1 && yy < sh; ++yy) {
+      const double wy = fmin(fy1, yy + 1.0) - fmax(fy0, (double)yy);
+      for (int xx = ix0; xx < ix1 && xx < sw; ++xx) {
+        const double wx = fmin(fx1, xx + 1.0) - fmax(fx0, (double)xx);
+        const float wgt = (float)(wx * wy / (sx * sy));
+        acc = acc + wgt * src[(size_t)yy * sw + xx];
+      }
     }
+    dst[(size_t)y * dw + x] = acc;
   }
-  dst[(size_t)y * dw + x] = acc;
+};
+__global__ void k_halfsample(const float *__restrict__ src, int sw, int sh, float *__restrict__ dst, int dw, int dh) {
+  HalfsampleBody::run(src, sw, sh, dst, dw, dh);
 }
 
 // compute_k_percentile: maximum gradient magnitude over the interior, then its 300-bin histogram.
@@ -322,95 +329,124 @@ struct Taps2 {
 };
 __device__ __forceinline__ float scharr_at(const float *__restrict__ src, int w, int h, int x, int y, int xorder,
                                            int scale, float ws, float wm);
+struct PreRowsBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const uint8_t *__restrict__ src, float *__restrict__ rows9, float *__restrict__ rows5, int w,
+                   int h, const Taps2 &t, unsigned int *hist /*[304]*/) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+      for (int i = threadIdx.x; i < 304; i += blockDim.x) hist[i] = 0u;
+    if (x >= w) return;
+    float v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = (float)src[(size_t)y * w + clampi(x + i - 4, 0, w - 1)] / 255.0f;
+    float a9 = 0.0f, a5 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a9 = a9 + t.k9[i] * v[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a5 = a5 + t.k5[i] * v[i + 2];
+    rows9[(size_t)y * w + x] = a9;
+    rows5[(size_t)y * w + x] = a5;
+  }
+};
 __global__ void k_pre_rows(const uint8_t *__restrict__ src, float *__restrict__ rows9, float *__restrict__ rows5, int w,
-                           int h, Taps2 t, unsigned int *hist /*[304]*/) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (blockIdx.x == 0 && blockIdx.y == 0)
-    for (int i = threadIdx.x; i < 304; i += blockDim.x) hist[i] = 0u;
-  if (x >= w) return;
-  float v[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) v[i] = (float)src[(size_t)y * w + clampi(x + i - 4, 0, w - 1)] / 255.0f;
-  float a9 = 0.0f, a5 = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) a9 = a9 + t.k9[i] * v[i];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) a5 = a5 + t.k5[i] * v[i + 2];
-  rows9[(size_t)y * w + x] = a9;
-  rows5[(size_t)y * w + x] = a5;
+                   int h, Taps2 t, unsigned int *hist /*[304]*/) {
+  PreRowsBody::run(src, rows9, rows5, w, h, t, hist);
 }
+struct PreColsBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ rows9, const float *__restrict__ rows5, float *__restrict__ lt0,
+                   float *__restrict__ lsmooth0, float *__restrict__ sm5, int w, int h, const Taps2 &t) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    float a9 = 0.0f, a5 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a9 = a9 + t.k9[i] * rows9[(size_t)clampi(y + i - 4, 0, h - 1) * w + x];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a5 = a5 + t.k5[i] * rows5[(size_t)clampi(y + i - 2, 0, h - 1) * w + x];
+    lt0[(size_t)y * w + x] = a9;
+    lsmooth0[(size_t)y * w + x] = a9;
+    sm5[(size_t)y * w + x] = a5;
+  }
+};
 __global__ void k_pre_cols(const float *__restrict__ rows9, const float *__restrict__ rows5, float *__restrict__ lt0,
-                           float *__restrict__ lsmooth0, float *__restrict__ sm5, int w, int h, Taps2 t) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  float a9 = 0.0f, a5 = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) a9 = a9 + t.k9[i] * rows9[(size_t)clampi(y + i - 4, 0, h - 1) * w + x];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) a5 = a5 + t.k5[i] * rows5[(size_t)clampi(y + i - 2, 0, h - 1) * w + x];
-  lt0[(size_t)y * w + x] = a9;
-  lsmooth0[(size_t)y * w + x] = a9;
-  sm5[(size_t)y * w + x] = a5;
+                   float *__restrict__ lsmooth0, float *__restrict__ sm5, int w, int h, Taps2 t) {
+  PreColsBody::run(rows9, rows5, lt0, lsmooth0, sm5, w, h, t);
 }
-__global__ __launch_bounds__(128) void k_pre_grad(const float *__restrict__ sm5, float *__restrict__ mag, int w, int h,
-                                                  unsigned int *hmax_bits) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  float m = 0.0f;
-  for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y) {
-    if (x >= w) continue;
-    float g = 0.0f;
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-      const float a = scharr_at(sm5, w, h, x, y, 1, 1, 3.0f, 10.0f);
-      const float b = scharr_at(sm5, w, h, x, y, 0, 1, 3.0f, 10.0f);
-      g = sqrtf(a * a + b * b);
-      m = fmaxf(m, g);
-    }
-    mag[(size_t)y * w + x] = g;
-  }
-  unsigned int bits = __float_as_uint(m);  // non-negative floats order like their bit patterns
-  for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off, 64));
-  if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(hmax_bits, bits);
-}
-__global__ __launch_bounds__(128) void k_pre_hist(const float *__restrict__ mag, int w, int h,
-                                                  unsigned int *hist_all /*[0] hmax bits, [1..301] bins + npoints, [302] arrivals*/,
-                                                  float *kcontrast) {
-  __shared__ unsigned int lh[301];
-  __shared__ unsigned int ticket;
-  for (int i = threadIdx.x; i < 301; i += blockDim.x) lh[i] = 0;
-  __syncthreads();
-  unsigned int *hist = hist_all + 1;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const float hmax = __uint_as_float(hist_all[0]);
-  unsigned int mine = 0;
-  for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y)
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-      const float m = mag[(size_t)y * w + x];
-      if (m != 0.0f) {
-        int nbin = (int)floorf(300.0f * (m / hmax));
-        if (nbin == 300) nbin--;
-        atomicAdd(&lh[nbin], 1u);
-        ++mine;
+struct PreGradBody {
+  static constexpr int kGangThreads = 128;
+  static __device__ __forceinline__ void run(const float *__restrict__ sm5, float *__restrict__ mag, int w, int h,
+                                          unsigned int *hmax_bits) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y) {
+      if (x >= w) continue;
+      float g = 0.0f;
+      if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+        const float a = scharr_at(sm5, w, h, x, y, 1, 1, 3.0f, 10.0f);
+        const float b = scharr_at(sm5, w, h, x, y, 0, 1, 3.0f, 10.0f);
+        g = sqrtf(a * a + b * b);
+        m = fmaxf(m, g);
       }
+      mag[(size_t)y * w + x] = g;
     }
-  if (mine) atomicAdd(&lh[300], mine);
-  __syncthreads();
-  for (int i = threadIdx.x; i < 301; i += blockDim.x)
-    if (lh[i]) atomicAdd(&hist[i], lh[i]);
-  __syncthreads();  // this workgroup's atomics are issued ...
-  if (threadIdx.x == 0) {
-    __threadfence();  // ... and performed before it counts itself in
-    ticket = atomicAdd(&hist_all[302], 1u);
+    unsigned int bits = __float_as_uint(m);  // non-negative floats order like their bit patterns
+    for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off, 64));
+    if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(hmax_bits, bits);
   }
-  __syncthreads();
-  if (ticket != gridDim.x * gridDim.y - 1 || threadIdx.x != 0) return;
-  __threadfence();
-  // compute_k_percentile's tail (k_kcontrast), by the last workgroup; the histogram is read through atomics so that no
-  // stale cached word is used
-  const int npoints = (int)atomicAdd(&hist[300], 0u);
-  const int nthreshold = (int)((float)npoints * 0.7f);
-  int nelements = 0, k = 0;
-  for (k = 0; nelements < nthreshold && k < 300; k++) nelements += (int)atomicAdd(&hist[k], 0u);
-  *kcontrast = (nelements < nthreshold) ? 0.03f : hmax * ((float)k / 300.0f);
+};
+__global__ __launch_bounds__(128) void k_pre_grad(const float *__restrict__ sm5, float *__restrict__ mag, int w, int h,
+                                          unsigned int *hmax_bits) {
+  PreGradBody::run(sm5, mag, w, h, hmax_bits);
+}
+struct PreHistBody {
+  static constexpr int kGangThreads = 128;
+  static __device__ __forceinline__ void run(const float *__restrict__ mag, int w, int h,
+                                          unsigned int *hist_all /*[0] hmax bits, [1..301] bins + npoints, [302] arrivals*/,
+                                          float *kcontrast) {
+    __shared__ unsigned int lh[301];
+    __shared__ unsigned int ticket;
+    for (int i = threadIdx.x; i < 301; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    unsigned int *hist = hist_all + 1;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const float hmax = __uint_as_float(hist_all[0]);
+    unsigned int mine = 0;
+    for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y)
+      if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+        const float m = mag[(size_t)y * w + x];
+        if (m != 0.0f) {
+          int nbin = (int)floorf(300.0f * (m / hmax));
+          if (nbin == 300) nbin--;
+          atomicAdd(&lh[nbin], 1u);
+          ++mine;
+        }
+      }
+    if (mine) atomicAdd(&lh[300], mine);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 301; i += blockDim.x)
+      if (lh[i]) atomicAdd(&hist[i], lh[i]);
+    __syncthreads();  // this workgroup's atomics are issued ...
+    if (threadIdx.x == 0) {
+      __threadfence();  // ... and performed before it counts itself in
+      ticket = atomicAdd(&hist_all[302], 1u);
+    }
+    __syncthreads();
+    if (ticket != gridDim.x * gridDim.y - 1 || threadIdx.x != 0) return;
+    __threadfence();
+    // compute_k_percentile's tail (k_kcontrast), by the last workgroup; the histogram is read through atomics so that no
+    // stale cached word is used
+    const int npoints = (int)atomicAdd(&hist[300], 0u);
+    const int nthreshold = (int)((float)npoints * 0.7f);
+    int nelements = 0, k = 0;
+    for (k = 0; nelements < nthreshold && k < 300; k++) nelements += (int)atomicAdd(&hist[k], 0u);
+    *kcontrast = (nelements < nthreshold) ? 0.03f : hmax * ((float)k / 300.0f);
+  }
+};
+__global__ __launch_bounds__(128) void k_pre_hist(const float *__restrict__ mag, int w, int h,
+                                          unsigned int *hist_all /*[0] hmax bits, [1..301] bins + npoints, [302] arrivals*/,
+                                          float *kcontrast) {
+  PreHistBody::run(mag, w, h, hist_all, kcontrast);
 }
 
 __global__ void k_kcontrast(const unsigned int *hmax_bits, const unsigned int *hist, float *kcontrast) {
@@ -434,43 +470,51 @@ struct NldSteps {
 constexpr int kNldTileX = 32, kNldTileY = 8;  // one output pixel per thread of a 256-thread workgroup
 
 template <int K>
-__global__ __launch_bounds__(256) void k_nld_steps(const float *__restrict__ Ld, const float *__restrict__ c,
-                                                   float *__restrict__ Ld_out, int w, int h, NldSteps hs, int nsteps) {
-  constexpr int TX = kNldTileX, TY = kNldTileY, RX = TX + 2 * K, RY = TY + 2 * K;
-  __shared__ float sL[2][RY][RX + 1];
-  __shared__ float sC[RY][RX + 1];
-  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;  // 32 x 8 threads
-  const int x0 = blockIdx.x * TX - K, y0 = blockIdx.y * TY - K;
-  for (int ly = ty; ly < RY; ly += TY)
-    for (int lx = tx; lx < RX; lx += TX) {
-      const int gx = x0 + lx, gy = y0 + ly;
-      const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
-      sL[0][ly][lx] = in ? Ld[(size_t)gy * w + gx] : 0.0f;
-      sC[ly][lx] = in ? c[(size_t)gy * w + gx] : 0.0f;
-    }
-  __syncthreads();
-  int cur = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    const int m = K - (nsteps - 1 - s);  // margin of the region this step still needs: the last step has m = K
-    const float half_step = hs.half_step[s];
-    for (int ly = m + ty; ly < RY - m; ly += TY)
-      for (int lx = m + tx; lx < RX - m; lx += TX) {
+struct NldStepsBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ Ld, const float *__restrict__ c,
+                                           float *__restrict__ Ld_out, int w, int h, const NldSteps &hs, int nsteps) {
+    constexpr int TX = kNldTileX, TY = kNldTileY, RX = TX + 2 * K, RY = TY + 2 * K;
+    __shared__ float sL[2][RY][RX + 1];
+    __shared__ float sC[RY][RX + 1];
+    const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;  // 32 x 8 threads
+    const int x0 = blockIdx.x * TX - K, y0 = blockIdx.y * TY - K;
+    for (int ly = ty; ly < RY; ly += TY)
+      for (int lx = tx; lx < RX; lx += TX) {
         const int gx = x0 + lx, gy = y0 + ly;
-        if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
-        const float cc = sC[ly][lx], v = sL[cur][ly][lx];
-        float xpos = 0.0f, xneg = 0.0f, ypos = 0.0f, yneg = 0.0f;
-        if (gx + 1 < w) xpos = (cc + sC[ly][lx + 1]) * (sL[cur][ly][lx + 1] - v);
-        if (gx > 0) xneg = (sC[ly][lx - 1] + cc) * (v - sL[cur][ly][lx - 1]);
-        if (gy + 1 < h) ypos = (cc + sC[ly + 1][lx]) * (sL[cur][ly + 1][lx] - v);
-        if (gy > 0) yneg = (sC[ly - 1][lx] + cc) * (v - sL[cur][ly - 1][lx]);
-        const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
-        sL[cur ^ 1][ly][lx] = v + stp;
+        const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+        sL[0][ly][lx] = in ? Ld[(size_t)gy * w + gx] : 0.0f;
+        sC[ly][lx] = in ? c[(size_t)gy * w + gx] : 0.0f;
       }
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const int m = K - (nsteps - 1 - s);  // margin of the region this step still needs: the last step has m = K
+      const float half_step = hs.half_step[s];
+      for (int ly = m + ty; ly < RY - m; ly += TY)
+        for (int lx = m + tx; lx < RX - m; lx += TX) {
+          const int gx = x0 + lx, gy = y0 + ly;
+          if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+          const float cc = sC[ly][lx], v = sL[cur][ly][lx];
+          float xpos = 0.0f, xneg = 0.0f, ypos = 0.0f, yneg = 0.0f;
+          if (gx + 1 < w) xpos = (cc + sC[ly][lx + 1]) * (sL[cur][ly][lx + 1] - v);
+          if (gx > 0) xneg = (sC[ly][lx - 1] + cc) * (v - sL[cur][ly][lx - 1]);
+          if (gy + 1 < h) ypos = (cc + sC[ly + 1][lx]) * (sL[cur][ly + 1][lx] - v);
+          if (gy > 0) yneg = (sC[ly - 1][lx] + cc) * (v - sL[cur][ly - 1][lx]);
+          const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
+          sL[cur ^ 1][ly][lx] = v + stp;
+        }
+      __syncthreads();
+      cur ^= 1;
+    }
+    const int gx = x0 + K + tx, gy = y0 + K + ty;
+    if (gx < w && gy < h) Ld_out[(size_t)gy * w + gx] = sL[cur][K + ty][K + tx];
   }
-  const int gx = x0 + K + tx, gy = y0 + K + ty;
-  if (gx < w && gy < h) Ld_out[(size_t)gy * w + gx] = sL[cur][K + ty][K + tx];
+};
+template <int K>
+__global__ __launch_bounds__(256) void k_nld_steps(const float *__restrict__ Ld, const float *__restrict__ c,
+                                           float *__restrict__ Ld_out, int w, int h, NldSteps hs, int nsteps) {
+  NldStepsBody<K>::run(Ld, c, Ld_out, w, h, hs, nsteps);
 }
 
 // Compute_Multiscale_Derivatives + Compute_Determinant_Hessian_Response, fused.  The reference runs five Scharr
@@ -499,61 +543,69 @@ __device__ __forceinline__ float scharr_at(const float *__restrict__ src, int w,
 // tile with the source halo in LDS (3 px: 2 for the taps of the column pass's rows / the row pass's columns, 1 for the
 // Scharr stencil on Lsmooth).  The row pass, the column pass and the Scharr sums run in the order a kernel per pass
 // would use, so the images are the same bit for bit.
+struct SmoothFlowBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ src, float *__restrict__ lsmooth,
+                                             float *__restrict__ g2, int w, int h, const Taps &t,
+                                             const float *kcontrast, int octave) {
+    constexpr int TX = 32, TY = 8;
+    constexpr int SX = TX + 6, SY = TY + 6;  // source region
+    constexpr int MX = TX + 2, MY = TY + 6;  // row-pass region: Lsmooth's columns, the column pass's rows
+    constexpr int LX = TX + 2, LY = TY + 2;  // Lsmooth region
+    __shared__ float sS[SY][SX + 1];
+    __shared__ float sM[MY][MX + 1];
+    __shared__ float sL[LY][LX + 1];
+    const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int ly = ty; ly < SY; ly += TY)
+      for (int lx = tx; lx < SX; lx += TX) {
+        const int gx = X0 - 3 + lx, gy = Y0 - 3 + ly;
+        sS[ly][lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? src[(size_t)gy * w + gx] : 0.0f;
+      }
+    __syncthreads();
+    for (int ly = ty; ly < MY; ly += TY)  // row pass at (X0 - 1 + lx, Y0 - 3 + ly)
+      for (int lx = tx; lx < MX; lx += TX) {
+        const int gx = X0 - 1 + lx, gy = Y0 - 3 + ly;
+        if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+        float acc = 0.0f;
+        for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * sS[ly][clampi(gx + i - 2, 0, w - 1) - (X0 - 3)];
+        sM[ly][lx] = acc;
+      }
+    __syncthreads();
+    for (int ly = ty; ly < LY; ly += TY)  // column pass at (X0 - 1 + lx, Y0 - 1 + ly)
+      for (int lx = tx; lx < LX; lx += TX) {
+        const int gx = X0 - 1 + lx, gy = Y0 - 1 + ly;
+        if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+        float acc = 0.0f;
+        for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * sM[clampi(gy + i - 2, 0, h - 1) - (Y0 - 3)][lx];
+        sL[ly][lx] = acc;
+        if (lx >= 1 && lx <= TX && ly >= 1 && ly <= TY) lsmooth[(size_t)gy * w + gx] = acc;
+      }
+    __syncthreads();
+    const int x = X0 + tx, y = Y0 + ty;
+    if (x >= w || y >= h) return;
+    const int xm = reflect101(x - 1, w) - (X0 - 1), xp = reflect101(x + 1, w) - (X0 - 1), xc = tx + 1;
+    const int ym = reflect101(y - 1, h) - (Y0 - 1), yp = reflect101(y + 1, h) - (Y0 - 1), yc = ty + 1;
+    const float ws = 3.0f, wm = 10.0f;
+    float lx_, ly_;
+    {
+      const float r0 = sL[yc][xp] - sL[yc][xm], rm = sL[ym][xp] - sL[ym][xm], rp = sL[yp][xp] - sL[yp][xm];
+      lx_ = wm * r0 + ws * (rm + rp);
+    }
+    {
+      const float r0 = sL[yp][xc] - sL[ym][xc], rm = sL[yp][xm] - sL[ym][xm], rp = sL[yp][xp] - sL[ym][xp];
+      ly_ = wm * r0 + ws * (rm + rp);
+    }
+    float kc = *kcontrast;
+    for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
+    const float inv_k = 1.0f / (kc * kc);
+    g2[(size_t)y * w + x] = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
+  }
+};
 __global__ __launch_bounds__(256) void k_smooth_flow(const float *__restrict__ src, float *__restrict__ lsmooth,
-                                                     float *__restrict__ g2, int w, int h, Taps t,
-                                                     const float *kcontrast, int octave) {
-  constexpr int TX = 32, TY = 8;
-  constexpr int SX = TX + 6, SY = TY + 6;  // source region
-  constexpr int MX = TX + 2, MY = TY + 6;  // row-pass region: Lsmooth's columns, the column pass's rows
-  constexpr int LX = TX + 2, LY = TY + 2;  // Lsmooth region
-  __shared__ float sS[SY][SX + 1];
-  __shared__ float sM[MY][MX + 1];
-  __shared__ float sL[LY][LX + 1];
-  const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int ly = ty; ly < SY; ly += TY)
-    for (int lx = tx; lx < SX; lx += TX) {
-      const int gx = X0 - 3 + lx, gy = Y0 - 3 + ly;
-      sS[ly][lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? src[(size_t)gy * w + gx] : 0.0f;
-    }
-  __syncthreads();
-  for (int ly = ty; ly < MY; ly += TY)  // row pass at (X0 - 1 + lx, Y0 - 3 + ly)
-    for (int lx = tx; lx < MX; lx += TX) {
-      const int gx = X0 - 1 + lx, gy = Y0 - 3 + ly;
-      if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
-      float acc = 0.0f;
-      for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * sS[ly][clampi(gx + i - 2, 0, w - 1) - (X0 - 3)];
-      sM[ly][lx] = acc;
-    }
-  __syncthreads();
-  for (int ly = ty; ly < LY; ly += TY)  // column pass at (X0 - 1 + lx, Y0 - 1 + ly)
-    for (int lx = tx; lx < LX; lx += TX) {
-      const int gx = X0 - 1 + lx, gy = Y0 - 1 + ly;
-      if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
-      float acc = 0.0f;
-      for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * sM[clampi(gy + i - 2, 0, h - 1) - (Y0 - 3)][lx];
-      sL[ly][lx] = acc;
-      if (lx >= 1 && lx <= TX && ly >= 1 && ly <= TY) lsmooth[(size_t)gy * w + gx] = acc;
-    }
-  __syncthreads();
-  const int x = X0 + tx, y = Y0 + ty;
-  if (x >= w || y >= h) return;
-  const int xm = reflect101(x - 1, w) - (X0 - 1), xp = reflect101(x + 1, w) - (X0 - 1), xc = tx + 1;
-  const int ym = reflect101(y - 1, h) - (Y0 - 1), yp = reflect101(y + 1, h) - (Y0 - 1), yc = ty + 1;
-  const float ws = 3.0f, wm = 10.0f;
-  float lx_, ly_;
-  {
-    const float r0 = sL[yc][xp] - sL[yc][xm], rm = sL[ym][xp] - sL[ym][xm], rp = sL[yp][xp] - sL[yp][xm];
-    lx_ = wm * r0 + ws * (rm + rp);
-  }
-  {
-    const float r0 = sL[yp][xc] - sL[ym][xc], rm = sL[yp][xm] - sL[ym][xm], rp = sL[yp][xp] - sL[ym][xp];
-    ly_ = wm * r0 + ws * (rm + rp);
-  }
-  float kc = *kcontrast;
-  for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
-  const float inv_k = 1.0f / (kc * kc);
-  g2[(size_t)y * w + x] = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
+                                             float *__restrict__ g2, int w, int h, Taps t,
+                                             const float *kcontrast, int octave) {
+  SmoothFlowBody::run(src, lsmooth, g2, w, h, t, kcontrast, octave);
 }
 
 // k_smooth_flow and the level's first k_nld_steps in ONE launch: a 32 x 8 tile computes Lsmooth and the conductivity on
@@ -563,102 +615,111 @@ __global__ __launch_bounds__(256) void k_smooth_flow(const float *__restrict__ s
 // the conductivity of the tile proper go to global memory as before (derivatives later; further step launches of the
 // level).  Per pixel the arithmetic is that of the two kernels, in the same order: the images are the same bit for bit.
 template <int K>
-__global__ __launch_bounds__(256) void k_smooth_nld(const float *__restrict__ src, float *__restrict__ lsmooth,
-                                                    float *__restrict__ g2, float *__restrict__ Ld_out, int w, int h,
-                                                    Taps t, const float *kcontrast, int octave, NldSteps hs, int nsteps) {
-  constexpr int TX = kNldTileX, TY = kNldTileY;
-  constexpr int CX = TX + 2 * K, CY = TY + 2 * K;              // conductivity / evolving image: tile + K
-  constexpr int LX = CX + 2, LY = CY + 2;                      // Lsmooth: + 1 (Scharr)
-  constexpr int MX = LX, MY = LY + 4;                          // row pass: Lsmooth's columns, + 2 rows (column taps)
-  constexpr int SX = MX + 4, SY = MY;                          // source: + 2 columns (row taps)
-  __shared__ float sS[SY][SX + 1];
-  __shared__ float sM[MY][MX + 1];
-  __shared__ float sLs[LY][LX + 1];
-  __shared__ float sC[CY][CX + 1];
-  __shared__ float sL[2][CY][CX + 1];
-  const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY;        // the tile
-  const int sx0 = X0 - K - 3, sy0 = Y0 - K - 3;                // origins of the regions in the image
-  const int mx0 = X0 - K - 1, my0 = sy0;
-  const int lx0 = mx0, ly0 = Y0 - K - 1;
-  const int cx0 = X0 - K, cy0 = Y0 - K;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < SX * SY; i += 256) {
-    const int ly = i / SX, lx = i - ly * SX;
-    const int gx = sx0 + lx, gy = sy0 + ly;
-    sS[ly][lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? src[(size_t)gy * w + gx] : 0.0f;
-  }
-  __syncthreads();
-  for (int i = tid; i < MX * MY; i += 256) {  // row pass
-    const int ly = i / MX, lx = i - ly * MX;
-    const int gx = mx0 + lx, gy = my0 + ly;
-    if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
-    float acc = 0.0f;
-    for (int q = 0; q < 5; ++q) acc = acc + t.k[q] * sS[ly][clampi(gx + q - 2, 0, w - 1) - sx0];
-    sM[ly][lx] = acc;
-  }
-  __syncthreads();
-  for (int i = tid; i < LX * LY; i += 256) {  // column pass
-    const int ly = i / LX, lx = i - ly * LX;
-    const int gx = lx0 + lx, gy = ly0 + ly;
-    if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
-    float acc = 0.0f;
-    for (int q = 0; q < 5; ++q) acc = acc + t.k[q] * sM[clampi(gy + q - 2, 0, h - 1) - my0][lx];
-    sLs[ly][lx] = acc;
-    if (gx >= X0 && gx < X0 + TX && gy >= Y0 && gy < Y0 + TY) lsmooth[(size_t)gy * w + gx] = acc;
-  }
-  __syncthreads();
-  float kc = *kcontrast;
-  for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
-  const float inv_k = 1.0f / (kc * kc);
-  for (int i = tid; i < CX * CY; i += 256) {  // conductivity, and the evolving image's start
-    const int ly = i / CX, lx = i - ly * CX;
-    const int x = cx0 + lx, y = cy0 + ly;
-    const bool in = x >= 0 && x < w && y >= 0 && y < h;
-    sL[0][ly][lx] = in ? sS[y - sy0][x - sx0] : 0.0f;
-    float c = 0.0f;
-    if (in) {
-      const int xm = reflect101(x - 1, w) - lx0, xp = reflect101(x + 1, w) - lx0, xc = x - lx0;
-      const int ym = reflect101(y - 1, h) - ly0, yp = reflect101(y + 1, h) - ly0, yc = y - ly0;
-      const float ws = 3.0f, wm = 10.0f;
-      float lx_, ly_;
-      {
-        const float r0 = sLs[yc][xp] - sLs[yc][xm], rm = sLs[ym][xp] - sLs[ym][xm], rp = sLs[yp][xp] - sLs[yp][xm];
-        lx_ = wm * r0 + ws * (rm + rp);
-      }
-      {
-        const float r0 = sLs[yp][xc] - sLs[ym][xc], rm = sLs[yp][xm] - sLs[ym][xm], rp = sLs[yp][xp] - sLs[ym][xp];
-        ly_ = wm * r0 + ws * (rm + rp);
-      }
-      c = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
-      if (x >= X0 && x < X0 + TX && y >= Y0 && y < Y0 + TY) g2[(size_t)y * w + x] = c;
+struct SmoothNldBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ src, float *__restrict__ lsmooth,
+                                            float *__restrict__ g2, float *__restrict__ Ld_out, int w, int h,
+                                            const Taps &t, const float *kcontrast, int octave, const NldSteps &hs, int nsteps) {
+    constexpr int TX = kNldTileX, TY = kNldTileY;
+    constexpr int CX = TX + 2 * K, CY = TY + 2 * K;              // conductivity / evolving image: tile + K
+    constexpr int LX = CX + 2, LY = CY + 2;                      // Lsmooth: + 1 (Scharr)
+    constexpr int MX = LX, MY = LY + 4;                          // row pass: Lsmooth's columns, + 2 rows (column taps)
+    constexpr int SX = MX + 4, SY = MY;                          // source: + 2 columns (row taps)
+    __shared__ float sS[SY][SX + 1];
+    __shared__ float sM[MY][MX + 1];
+    __shared__ float sLs[LY][LX + 1];
+    __shared__ float sC[CY][CX + 1];
+    __shared__ float sL[2][CY][CX + 1];
+    const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY;        // the tile
+    const int sx0 = X0 - K - 3, sy0 = Y0 - K - 3;                // origins of the regions in the image
+    const int mx0 = X0 - K - 1, my0 = sy0;
+    const int lx0 = mx0, ly0 = Y0 - K - 1;
+    const int cx0 = X0 - K, cy0 = Y0 - K;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SX * SY; i += 256) {
+      const int ly = i / SX, lx = i - ly * SX;
+      const int gx = sx0 + lx, gy = sy0 + ly;
+      sS[ly][lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? src[(size_t)gy * w + gx] : 0.0f;
     }
-    sC[ly][lx] = c;
-  }
-  __syncthreads();
-  // the steps, as in k_nld_steps (region of step s: the tile grown by K - 1 - s ... of the steps still to come)
-  const int tx = tid & (TX - 1), ty = tid / TX;
-  int cur = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    const int m = K - (nsteps - 1 - s);
-    const float half_step = hs.half_step[s];
-    for (int ly = m + ty; ly < CY - m; ly += TY)
-      for (int lx = m + tx; lx < CX - m; lx += TX) {
-        const int gx = cx0 + lx, gy = cy0 + ly;
-        if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
-        const float cc = sC[ly][lx], v = sL[cur][ly][lx];
-        float xpos = 0.0f, xneg = 0.0f, ypos = 0.0f, yneg = 0.0f;
-        if (gx + 1 < w) xpos = (cc + sC[ly][lx + 1]) * (sL[cur][ly][lx + 1] - v);
-        if (gx > 0) xneg = (sC[ly][lx - 1] + cc) * (v - sL[cur][ly][lx - 1]);
-        if (gy + 1 < h) ypos = (cc + sC[ly + 1][lx]) * (sL[cur][ly + 1][lx] - v);
-        if (gy > 0) yneg = (sC[ly - 1][lx] + cc) * (v - sL[cur][ly - 1][lx]);
-        const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
-        sL[cur ^ 1][ly][lx] = v + stp;
-      }
     __syncthreads();
-    cur ^= 1;
+    for (int i = tid; i < MX * MY; i += 256) {  // row pass
+      const int ly = i / MX, lx = i - ly * MX;
+      const int gx = mx0 + lx, gy = my0 + ly;
+      if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+      float acc = 0.0f;
+      for (int q = 0; q < 5; ++q) acc = acc + t.k[q] * sS[ly][clampi(gx + q - 2, 0, w - 1) - sx0];
+      sM[ly][lx] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < LX * LY; i += 256) {  // column pass
+      const int ly = i / LX, lx = i - ly * LX;
+      const int gx = lx0 + lx, gy = ly0 + ly;
+      if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+      float acc = 0.0f;
+      for (int q = 0; q < 5; ++q) acc = acc + t.k[q] * sM[clampi(gy + q - 2, 0, h - 1) - my0][lx];
+      sLs[ly][lx] = acc;
+      if (gx >= X0 && gx < X0 + TX && gy >= Y0 && gy < Y0 + TY) lsmooth[(size_t)gy * w + gx] = acc;
+    }
+    __syncthreads();
+    float kc = *kcontrast;
+    for (int o = 0; o < octave; ++o) kc = kc * 0.75f;
+    const float inv_k = 1.0f / (kc * kc);
+    for (int i = tid; i < CX * CY; i += 256) {  // conductivity, and the evolving image's start
+      const int ly = i / CX, lx = i - ly * CX;
+      const int x = cx0 + lx, y = cy0 + ly;
+      const bool in = x >= 0 && x < w && y >= 0 && y < h;
+      sL[0][ly][lx] = in ? sS[y - sy0][x - sx0] : 0.0f;
+      float c = 0.0f;
+      if (in) {
+        const int xm = reflect101(x - 1, w) - lx0, xp = reflect101(x + 1, w) - lx0, xc = x - lx0;
+        const int ym = reflect101(y - 1, h) - ly0, yp = reflect101(y + 1, h) - ly0, yc = y - ly0;
+        const float ws = 3.0f, wm = 10.0f;
+        float lx_, ly_;
+        {
+          const float r0 = sLs[yc][xp] - sLs[yc][xm], rm = sLs[ym][xp] - sLs[ym][xm], rp = sLs[yp][xp] - sLs[yp][xm];
+          lx_ = wm * r0 + ws * (rm + rp);
+        }
+        {
+          const float r0 = sLs[yp][xc] - sLs[ym][xc], rm = sLs[yp][xm] - sLs[ym][xm], rp = sLs[yp][xp] - sLs[ym][xp];
+          ly_ = wm * r0 + ws * (rm + rp);
+        }
+        c = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
+        if (x >= X0 && x < X0 + TX && y >= Y0 && y < Y0 + TY) g2[(size_t)y * w + x] = c;
+      }
+      sC[ly][lx] = c;
+    }
+    __syncthreads();
+    // the steps, as in k_nld_steps (region of step s: the tile grown by K - 1 - s ... of the steps still to come)
+    const int tx = tid & (TX - 1), ty = tid / TX;
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const int m = K - (nsteps - 1 - s);
+      const float half_step = hs.half_step[s];
+      for (int ly = m + ty; ly < CY - m; ly += TY)
+        for (int lx = m + tx; lx < CX - m; lx += TX) {
+          const int gx = cx0 + lx, gy = cy0 + ly;
+          if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+          const float cc = sC[ly][lx], v = sL[cur][ly][lx];
+          float xpos = 0.0f, xneg = 0.0f, ypos = 0.0f, yneg = 0.0f;
+          if (gx + 1 < w) xpos = (cc + sC[ly][lx + 1]) * (sL[cur][ly][lx + 1] - v);
+          if (gx > 0) xneg = (sC[ly][lx - 1] + cc) * (v - sL[cur][ly][lx - 1]);
+          if (gy + 1 < h) ypos = (cc + sC[ly + 1][lx]) * (sL[cur][ly + 1][lx] - v);
+          if (gy > 0) yneg = (sC[ly - 1][lx] + cc) * (v - sL[cur][ly - 1][lx]);
+          const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
+          sL[cur ^ 1][ly][lx] = v + stp;
+        }
+      __syncthreads();
+      cur ^= 1;
+    }
+    const int gx = X0 + tx, gy = Y0 + ty;
+    if (gx < w && gy < h) Ld_out[(size_t)gy * w + gx] = sL[cur][K + ty][K + tx];
   }
-  const int gx = X0 + tx, gy = Y0 + ty;
-  if (gx < w && gy < h) Ld_out[(size_t)gy * w + gx] = sL[cur][K + ty][K + tx];
+};
+template <int K>
+__global__ __launch_bounds__(256) void k_smooth_nld(const float *__restrict__ src, float *__restrict__ lsmooth,
+                                            float *__restrict__ g2, float *__restrict__ Ld_out, int w, int h,
+                                            Taps t, const float *kcontrast, int octave, NldSteps hs, int nsteps) {
+  SmoothNldBody<K>::run(src, lsmooth, g2, Ld_out, w, h, t, kcontrast, octave, hs, nsteps);
 }
 
 // A whole octave in ONE launch when its image fits in LDS three times (VGA: the 80 x 60 octave -- 4 800 pixels, but 99 of
@@ -676,107 +737,116 @@ struct OctaveRun {
   int step0[kOctaveRunMax];         // index of the level's first half step in the table
 };
 
-__global__ __launch_bounds__(1024) void k_octave_resident(const float *__restrict__ start, float *__restrict__ Lt_all,
-                                                          float *__restrict__ Lsmooth_all, Taps t,
-                                                          const float *__restrict__ kcontrast,
-                                                          const float *__restrict__ half_steps, OctaveRun R) {
-  extern __shared__ float lds_f[];
-  const int w = R.w, h = R.h, n = w * h;
-  float *A = lds_f, *B = lds_f + n, *C = lds_f + 2 * n;
-  const int tid = threadIdx.x;
-  for (int p = tid; p < n; p += 1024) A[p] = start[p];
-  float kc = *kcontrast;
-  for (int o = 0; o < R.octave; ++o) kc = kc * 0.75f;
-  const float inv_k = 1.0f / (kc * kc);
-  __syncthreads();
-  for (int lv = 0; lv < R.n_levels; ++lv) {
-    // row pass A -> B, column pass B -> C (= Lsmooth)
-    for (int p = tid; p < n; p += 1024) {
-      const int y = p / w, x = p - y * w;
-      float acc = 0.0f;
-      for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * A[y * w + clampi(x + i - 2, 0, w - 1)];
-      B[p] = acc;
-    }
+struct OctaveResidentBody {
+  static constexpr int kGangThreads = 1024;
+  static __device__ __forceinline__ void run(const float *__restrict__ start, float *__restrict__ Lt_all,
+                                                  float *__restrict__ Lsmooth_all, const Taps &t,
+                                                  const float *__restrict__ kcontrast,
+                                                  const float *__restrict__ half_steps, const OctaveRun &R) {
+    extern __shared__ float lds_f[];
+    const int w = R.w, h = R.h, n = w * h;
+    float *A = lds_f, *B = lds_f + n, *C = lds_f + 2 * n;
+    const int tid = threadIdx.x;
+    for (int p = tid; p < n; p += 1024) A[p] = start[p];
+    float kc = *kcontrast;
+    for (int o = 0; o < R.octave; ++o) kc = kc * 0.75f;
+    const float inv_k = 1.0f / (kc * kc);
     __syncthreads();
-    float *const lsm = Lsmooth_all + R.off[lv];
-    for (int p = tid; p < n; p += 1024) {
-      const int y = p / w, x = p - y * w;
-      float acc = 0.0f;
-      for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * B[clampi(y + i - 2, 0, h - 1) * w + x];
-      C[p] = acc;
-      lsm[p] = acc;
-    }
-    __syncthreads();
-    // conductivity from Lsmooth (C) -> B
-    for (int p = tid; p < n; p += 1024) {
-      const int y = p / w, x = p - y * w;
-      const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
-      const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
-      const float ws = 3.0f, wm = 10.0f;
-      float lx_, ly_;
-      {
-        const float r0 = C[y * w + xp] - C[y * w + xm], rm = C[ym * w + xp] - C[ym * w + xm],
-                    rp = C[yp * w + xp] - C[yp * w + xm];
-        lx_ = wm * r0 + ws * (rm + rp);
-      }
-      {
-        const float r0 = C[yp * w + x] - C[ym * w + x], rm = C[yp * w + xm] - C[ym * w + xm],
-                    rp = C[yp * w + xp] - C[ym * w + xp];
-        ly_ = wm * r0 + ws * (rm + rp);
-      }
-      B[p] = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
-    }
-    __syncthreads();
-    // FED steps: A -> C -> A ...  The conductivity does not change within a level, so a thread keeps the four sums
-    // (c + c_neighbour) of each of its pixels in registers; a neighbour outside the image is replaced by the pixel
-    // itself, whose difference is +0 and gives the +0 flux the per-launch kernel writes there.
-    float cxp[kResidentPix], cxn[kResidentPix], cyp[kResidentPix], cyn[kResidentPix];
-    int nb[kResidentPix];  // bit 0..3: neighbour x+1 / x-1 / y+1 / y-1 exists
-#pragma unroll
-    for (int k = 0; k < kResidentPix; ++k) {
-      const int p = tid + k * 1024;
-      cxp[k] = cxn[k] = cyp[k] = cyn[k] = 0.0f;
-      nb[k] = 0;
-      if (p < n) {
+    for (int lv = 0; lv < R.n_levels; ++lv) {
+      // row pass A -> B, column pass B -> C (= Lsmooth)
+      for (int p = tid; p < n; p += 1024) {
         const int y = p / w, x = p - y * w;
-        const float cc = B[p];
-        int f = 0;
-        if (x + 1 < w) { cxp[k] = cc + B[p + 1]; f |= 1; }
-        if (x > 0) { cxn[k] = B[p - 1] + cc; f |= 2; }
-        if (y + 1 < h) { cyp[k] = cc + B[p + w]; f |= 4; }
-        if (y > 0) { cyn[k] = B[p - w] + cc; f |= 8; }
-        nb[k] = f;
+        float acc = 0.0f;
+        for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * A[y * w + clampi(x + i - 2, 0, w - 1)];
+        B[p] = acc;
       }
-    }
-    float *cur = A, *nxt = C;
-    for (int s = 0; s < R.nsteps[lv]; ++s) {
-      const float half_step = half_steps[R.step0[lv] + s];
+      __syncthreads();
+      float *const lsm = Lsmooth_all + R.off[lv];
+      for (int p = tid; p < n; p += 1024) {
+        const int y = p / w, x = p - y * w;
+        float acc = 0.0f;
+        for (int i = 0; i < 5; ++i) acc = acc + t.k[i] * B[clampi(y + i - 2, 0, h - 1) * w + x];
+        C[p] = acc;
+        lsm[p] = acc;
+      }
+      __syncthreads();
+      // conductivity from Lsmooth (C) -> B
+      for (int p = tid; p < n; p += 1024) {
+        const int y = p / w, x = p - y * w;
+        const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+        const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+        const float ws = 3.0f, wm = 10.0f;
+        float lx_, ly_;
+        {
+          const float r0 = C[y * w + xp] - C[y * w + xm], rm = C[ym * w + xp] - C[ym * w + xm],
+                      rp = C[yp * w + xp] - C[yp * w + xm];
+          lx_ = wm * r0 + ws * (rm + rp);
+        }
+        {
+          const float r0 = C[yp * w + x] - C[ym * w + x], rm = C[yp * w + xm] - C[ym * w + xm],
+                      rp = C[yp * w + xp] - C[ym * w + xp];
+          ly_ = wm * r0 + ws * (rm + rp);
+        }
+        B[p] = 1.0f / (1.0f + inv_k * (lx_ * lx_ + ly_ * ly_));
+      }
+      __syncthreads();
+      // FED steps: A -> C -> A ...  The conductivity does not change within a level, so a thread keeps the four sums
+      // (c + c_neighbour) of each of its pixels in registers; a neighbour outside the image is replaced by the pixel
+      // itself, whose difference is +0 and gives the +0 flux the per-launch kernel writes there.
+      float cxp[kResidentPix], cxn[kResidentPix], cyp[kResidentPix], cyn[kResidentPix];
+      int nb[kResidentPix];  // bit 0..3: neighbour x+1 / x-1 / y+1 / y-1 exists
 #pragma unroll
       for (int k = 0; k < kResidentPix; ++k) {
         const int p = tid + k * 1024;
+        cxp[k] = cxn[k] = cyp[k] = cyn[k] = 0.0f;
+        nb[k] = 0;
         if (p < n) {
-          const int f = nb[k];
-          const float v = cur[p];
-          const float xpos = cxp[k] * (cur[(f & 1) ? p + 1 : p] - v);
-          const float xneg = cxn[k] * (v - cur[(f & 2) ? p - 1 : p]);
-          const float ypos = cyp[k] * (cur[(f & 4) ? p + w : p] - v);
-          const float yneg = cyn[k] * (v - cur[(f & 8) ? p - w : p]);
-          const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
-          nxt[p] = v + stp;
+          const int y = p / w, x = p - y * w;
+          const float cc = B[p];
+          int f = 0;
+          if (x + 1 < w) { cxp[k] = cc + B[p + 1]; f |= 1; }
+          if (x > 0) { cxn[k] = B[p - 1] + cc; f |= 2; }
+          if (y + 1 < h) { cyp[k] = cc + B[p + w]; f |= 4; }
+          if (y > 0) { cyn[k] = B[p - w] + cc; f |= 8; }
+          nb[k] = f;
         }
       }
+      float *cur = A, *nxt = C;
+      for (int s = 0; s < R.nsteps[lv]; ++s) {
+        const float half_step = half_steps[R.step0[lv] + s];
+#pragma unroll
+        for (int k = 0; k < kResidentPix; ++k) {
+          const int p = tid + k * 1024;
+          if (p < n) {
+            const int f = nb[k];
+            const float v = cur[p];
+            const float xpos = cxp[k] * (cur[(f & 1) ? p + 1 : p] - v);
+            const float xneg = cxn[k] * (v - cur[(f & 2) ? p - 1 : p]);
+            const float ypos = cyp[k] * (cur[(f & 4) ? p + w : p] - v);
+            const float yneg = cyn[k] * (v - cur[(f & 8) ? p - w : p]);
+            const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
+            nxt[p] = v + stp;
+          }
+        }
+        __syncthreads();
+        float *const tswap = cur;
+        cur = nxt;
+        nxt = tswap;
+      }
+      float *const lt = Lt_all + R.off[lv];
+      for (int p = tid; p < n; p += 1024) lt[p] = cur[p];
+      // the next level starts from `cur`; its scratch is the other image
+      A = cur;
+      C = nxt;
       __syncthreads();
-      float *const tswap = cur;
-      cur = nxt;
-      nxt = tswap;
     }
-    float *const lt = Lt_all + R.off[lv];
-    for (int p = tid; p < n; p += 1024) lt[p] = cur[p];
-    // the next level starts from `cur`; its scratch is the other image
-    A = cur;
-    C = nxt;
-    __syncthreads();
   }
+};
+__global__ __launch_bounds__(1024) void k_octave_resident(const float *__restrict__ start, float *__restrict__ Lt_all,
+                                                  float *__restrict__ Lsmooth_all, Taps t,
+                                                  const float *__restrict__ kcontrast,
+                                                  const float *__restrict__ half_steps, OctaveRun R) {
+  OctaveResidentBody::run(start, Lt_all, Lsmooth_all, t, kcontrast, half_steps, R);
 }
 
 // Compute_Multiscale_Derivatives, Compute_Determinant_Hessian_Response and the candidate pass of
@@ -796,28 +866,41 @@ __device__ __forceinline__ int level_of_row(const LevelTab &T, int row) {
   return i;
 }
 
+struct ScharrXyAllBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly, const LevelTab &T) {
+    const int i = level_of_row(T, blockIdx.y);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
+    if (x >= w) return;
+    const float *src = ls + T.off[i];
+    lx[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 1, T.sc[i], T.ws[i], T.wm[i]);
+    ly[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 0, T.sc[i], T.ws[i], T.wm[i]);
+  }
+};
 __global__ void k_scharr_xy_all(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly, LevelTab T) {
-  const int i = level_of_row(T, blockIdx.y);
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
-  if (x >= w) return;
-  const float *src = ls + T.off[i];
-  lx[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 1, T.sc[i], T.ws[i], T.wm[i]);
-  ly[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 0, T.sc[i], T.ws[i], T.wm[i]);
+  ScharrXyAllBody::run(ls, lx, ly, T);
 }
 
+struct HessianDetAllBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ lx_all, const float *__restrict__ ly_all,
+                          float *__restrict__ ldet, const LevelTab &T) {
+    const int i = level_of_row(T, blockIdx.y);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
+    if (x >= w) return;
+    const float *lx = lx_all + T.off[i], *ly = ly_all + T.off[i];
+    const int scale = T.sc[i];
+    const float ws = T.ws[i], wm = T.wm[i], sf2 = (float)(scale * scale);
+    const float lxx = scharr_at(lx, w, h, x, y, 1, scale, ws, wm);
+    const float lyy = scharr_at(ly, w, h, x, y, 0, scale, ws, wm);
+    const float lxy = scharr_at(lx, w, h, x, y, 0, scale, ws, wm);
+    const float a = lxx * sf2, b = lxy * sf2, c = lyy * sf2;
+    ldet[T.off[i] + (size_t)y * w + x] = a * c - b * b;
+  }
+};
 __global__ void k_hessian_det_all(const float *__restrict__ lx_all, const float *__restrict__ ly_all,
-                                  float *__restrict__ ldet, LevelTab T) {
-  const int i = level_of_row(T, blockIdx.y);
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
-  if (x >= w) return;
-  const float *lx = lx_all + T.off[i], *ly = ly_all + T.off[i];
-  const int scale = T.sc[i];
-  const float ws = T.ws[i], wm = T.wm[i], sf2 = (float)(scale * scale);
-  const float lxx = scharr_at(lx, w, h, x, y, 1, scale, ws, wm);
-  const float lyy = scharr_at(ly, w, h, x, y, 0, scale, ws, wm);
-  const float lxy = scharr_at(lx, w, h, x, y, 0, scale, ws, wm);
-  const float a = lxx * sf2, b = lxy * sf2, c = lyy * sf2;
-  ldet[T.off[i] + (size_t)y * w + x] = a * c - b * b;
+                          float *__restrict__ ldet, LevelTab T) {
+  HessianDetAllBody::run(lx_all, ly_all, ldet, T);
 }
 
 struct Candidate9 {
@@ -826,33 +909,40 @@ struct Candidate9 {
   float pad2[3];
 };
 
+struct ExtremaAllBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ ldet_all, const LevelTab &T, float dthreshold, Candidate9 *out,
+                      unsigned int cap, unsigned int *n_out) {
+    const int i = level_of_row(T, blockIdx.y);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+    const float *D = ldet_all + T.off[i];
+    const float v = D[(size_t)y * w + x];
+    if (!(v > dthreshold && v >= 0.00001f)) return;
+    float p[9];
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) p[(dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
+    if (!(v > p[3] && v > p[5] && v > p[0] && v > p[1] && v > p[2] && v > p[6] && v > p[7] && v > p[8])) return;
+    const float smax = 10.0f * sqrtf(2.0f);
+    const int sigma_size_ = T.sigma_size[i];
+    const int left_x = fround_d((float)x - smax * sigma_size_) - 1, right_x = fround_d((float)x + smax * sigma_size_) + 1;
+    const int up_y = fround_d((float)y - smax * sigma_size_) - 1, down_y = fround_d((float)y + smax * sigma_size_) + 1;
+    if (left_x < 0 || right_x >= w || up_y < 0 || down_y >= h) return;
+    const unsigned int slot = atomicAdd(n_out, 1u);
+    if (slot >= cap) return;
+    Candidate9 c;
+    c.level = i;
+    c.x = x;
+    c.y = y;
+    c.pad = 0;
+    for (int k = 0; k < 9; ++k) c.patch[k] = p[k];
+    c.pad2[0] = c.pad2[1] = c.pad2[2] = 0.0f;
+    out[slot] = c;
+  }
+};
 __global__ void k_extrema_all(const float *__restrict__ ldet_all, LevelTab T, float dthreshold, Candidate9 *out,
-                              unsigned int cap, unsigned int *n_out) {
-  const int i = level_of_row(T, blockIdx.y);
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
-  if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
-  const float *D = ldet_all + T.off[i];
-  const float v = D[(size_t)y * w + x];
-  if (!(v > dthreshold && v >= 0.00001f)) return;
-  float p[9];
-  for (int dy = -1; dy <= 1; ++dy)
-    for (int dx = -1; dx <= 1; ++dx) p[(dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
-  if (!(v > p[3] && v > p[5] && v > p[0] && v > p[1] && v > p[2] && v > p[6] && v > p[7] && v > p[8])) return;
-  const float smax = 10.0f * sqrtf(2.0f);
-  const int sigma_size_ = T.sigma_size[i];
-  const int left_x = fround_d((float)x - smax * sigma_size_) - 1, right_x = fround_d((float)x + smax * sigma_size_) + 1;
-  const int up_y = fround_d((float)y - smax * sigma_size_) - 1, down_y = fround_d((float)y + smax * sigma_size_) + 1;
-  if (left_x < 0 || right_x >= w || up_y < 0 || down_y >= h) return;
-  const unsigned int slot = atomicAdd(n_out, 1u);
-  if (slot >= cap) return;
-  Candidate9 c;
-  c.level = i;
-  c.x = x;
-  c.y = y;
-  c.pad = 0;
-  for (int k = 0; k < 9; ++k) c.patch[k] = p[k];
-  c.pad2[0] = c.pad2[1] = c.pad2[2] = 0.0f;
-  out[slot] = c;
+                      unsigned int cap, unsigned int *n_out) {
+  ExtremaAllBody::run(ldet_all, T, dthreshold, out, cap, n_out);
 }
 
 struct DevLevel {
@@ -871,10 +961,10 @@ __device__ __forceinline__ float at_clamped(const float *img, int w, int h, int 
 // Compute_Main_Orientation + Get_MLDB_Full_Descriptor: one wave per keypoint
 // kp [n x 4] = x, y, size (diameter), class_id ; angle_out [n] ; desc [n x 64] (61 bytes + 3 zero bytes = .desc row)
 __global__ __launch_bounds__(64) void k_orient_describe(DevLevels LV, const float *__restrict__ kp, int n,
-                                                        const float *__restrict__ gauss25,
-                                                        const float *__restrict__ win_ang1, int n_win,
-                                                        const uint16_t *__restrict__ pair_tab,
-                                                        float *__restrict__ angle_out, uint8_t *__restrict__ desc) {
+                                                const float *__restrict__ gauss25,
+                                                const float *__restrict__ win_ang1, int n_win,
+                                                const uint16_t *__restrict__ pair_tab,
+                                                float *__restrict__ angle_out, uint8_t *__restrict__ desc) {
   __shared__ float resX[109], resY[109], Ang[109];
   __shared__ float vals[29 * 3];
   const int kidx = blockIdx.x;
@@ -1002,12 +1092,11 @@ static double now_s() {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-struct Akaze {
+struct Akaze : GangMember {  // (gang.h: `stream` reads as the stream to queue on now; an extractor can record for a gang)
   int device = 0;
   int w = 0, h = 0, omax = 4, nsub = 4;
   float thres = 0.001f;
   AkPlan plan;
-  hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;  // the one created with the extractor (stream may be a context's, see _share_stream)
   uint8_t *d_gray = nullptr;
   float *d_img = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr;
@@ -1082,8 +1171,9 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
   const AkPlan &P = a->plan;
   const int w = a->w, h = a->h;
   const size_t n0 = (size_t)w * h;
-  hipStream_t s = a->stream;
-  AK_HIP(hipMemcpyAsync(a->d_gray, gray, n0, hipMemcpyHostToDevice, s));
+  // (nothing recorded for this image touches d_gray before the upload: it need not wait for a gang session's launches)
+  AK_HIP(hipMemcpyAsync(a->d_gray, gray, n0, hipMemcpyHostToDevice, a->stream.unordered()));
+#define s ((hipStream_t)a->stream) /* the few launches below that have no gang form (comparison paths) */
   int rc = SFMLOC_OK;
   static const bool kFusedPre = [] {  // SFMLOC_AKAZE_FUSED_PRE=0: the thirteen separate launches (comparison runs)
     const char *e = getenv("SFMLOC_AKAZE_FUSED_PRE");
@@ -1094,10 +1184,10 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
     Taps2 t2;
     for (int k = 0; k < 9; ++k) t2.k9[k] = P.g16[k];
     for (int k = 0; k < 5; ++k) t2.k5[k] = P.g10[k];
-    hipLaunchKernelGGL(k_pre_rows, grid2(w, h), dim3(128), 0, s, a->d_gray, a->d_t3, a->d_t1, w, h, t2, a->d_hist);
-    hipLaunchKernelGGL(k_pre_cols, grid2(w, h), dim3(128), 0, s, a->d_t3, a->d_t1, a->d_Lt, a->d_Lsmooth, a->d_t0, w, h, t2);
-    hipLaunchKernelGGL(k_pre_grad, ggrid, dim3(128), 0, s, a->d_t0, a->d_t2, w, h, a->d_hist);
-    hipLaunchKernelGGL(k_pre_hist, ggrid, dim3(128), 0, s, a->d_t2, w, h, a->d_hist, a->d_kcontrast);
+    sfm_launch<PreRowsBody>(a, k_pre_rows, grid2(w, h), dim3(128), (uint32_t)0, a->d_gray, a->d_t3, a->d_t1, w, h, t2, a->d_hist);
+    sfm_launch<PreColsBody>(a, k_pre_cols, grid2(w, h), dim3(128), (uint32_t)0, a->d_t3, a->d_t1, a->d_Lt, a->d_Lsmooth, a->d_t0, w, h, t2);
+    sfm_launch<PreGradBody>(a, k_pre_grad, ggrid, dim3(128), (uint32_t)0, a->d_t0, a->d_t2, w, h, a->d_hist);
+    sfm_launch<PreHistBody>(a, k_pre_hist, ggrid, dim3(128), (uint32_t)0, a->d_t2, w, h, a->d_hist, a->d_kcontrast);
     AK_HIP(hipGetLastError());
   } else {
   hipLaunchKernelGGL(k_u8_to_f32, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, a->d_gray, a->d_img, n0);
@@ -1131,7 +1221,7 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
       if (kResident && whole && lds <= 150u * 1024u && j - i + 1 <= kOctaveRunMax && a->d_half_steps) {
         const float *start = a->d_Lt + Lp.off;
         if (L.octave > Lp.octave) {
-          hipLaunchKernelGGL(k_halfsample, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lt + Lp.off, Lp.w, Lp.h, a->d_t3, L.w, L.h);
+          sfm_launch<HalfsampleBody>(a, k_halfsample, grid2(L.w, L.h), dim3(128), (uint32_t)0, a->d_Lt + Lp.off, Lp.w, Lp.h, a->d_t3, L.w, L.h);
           start = a->d_t3;
         }
         OctaveRun R{};
@@ -1150,7 +1240,7 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octave_resident),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         AK_HIP(attr);
-        hipLaunchKernelGGL(k_octave_resident, dim3(1), dim3(1024), lds, s, start, a->d_Lt, a->d_Lsmooth, t5,
+        sfm_launch<OctaveResidentBody>(a, k_octave_resident, dim3(1), dim3(1024), (uint32_t)lds, start, a->d_Lt, a->d_Lsmooth, t5,
                            a->d_kcontrast, a->d_half_steps, R);
         AK_HIP(hipGetLastError());
         i = j;
@@ -1177,7 +1267,7 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
     const int n_launch = (L.nsteps + kFuse - 1) / kFuse;
     if (L.octave > Lp.octave) {
       float *half = (n_launch % 2 == 0) ? Lt : a->d_t3;  // even number of launches: start (and end) in Lt
-      hipLaunchKernelGGL(k_halfsample, grid2(L.w, L.h), dim3(128), 0, s, a->d_Lt + Lp.off, Lp.w, Lp.h, half, L.w, L.h);
+      sfm_launch<HalfsampleBody>(a, k_halfsample, grid2(L.w, L.h), dim3(128), (uint32_t)0, a->d_Lt + Lp.off, Lp.w, Lp.h, half, L.w, L.h);
       start = half;
     }
     Taps t5;
@@ -1188,7 +1278,7 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
     }();
     const bool fuse_smooth = kFuseSmooth && L.nsteps > 0;
     if (!fuse_smooth)
-      hipLaunchKernelGGL(k_smooth_flow, dim3((L.w + 31) / 32, (L.h + 7) / 8), dim3(256), 0, s, start,
+      sfm_launch<SmoothFlowBody>(a, k_smooth_flow, dim3((L.w + 31) / 32, (L.h + 7) / 8), dim3(256), (uint32_t)0, start,
                          a->d_Lsmooth + L.off, a->d_t2, L.w, L.h, t5, a->d_kcontrast, L.octave);
     const float *cur = start;
     // destination of step st: alternate so that step nsteps-1 writes Lt; `start` is never written
@@ -1202,7 +1292,7 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
       if (j == 0 && fuse_smooth) {  // the level's smoothing + conductivity + first steps in one launch
 #define SNLD_CASE(KK)                                                                                                  \
   case KK:                                                                                                             \
-    hipLaunchKernelGGL(k_smooth_nld<KK>, tgrid, dim3(256), 0, s, cur, a->d_Lsmooth + L.off, a->d_t2, dst, L.w, L.h, t5, \
+    sfm_launch<SmoothNldBody<KK>>(a, k_smooth_nld<KK>, tgrid, dim3(256), 0, cur, a->d_Lsmooth + L.off, a->d_t2, dst, L.w, L.h, t5, \
                        a->d_kcontrast, L.octave, hs, n);                                                               \
     break;
         switch (n) {
@@ -1215,7 +1305,7 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
         continue;
       }
 #define NLD_CASE(KK) \
-  case KK: hipLaunchKernelGGL(k_nld_steps<KK>, tgrid, dim3(256), 0, s, cur, a->d_t2, dst, L.w, L.h, hs, n); break;
+  case KK: sfm_launch<NldStepsBody<KK>>(a, k_nld_steps<KK>, tgrid, dim3(256), 0, cur, a->d_t2, dst, L.w, L.h, hs, n); break;
       switch (n) {
         NLD_CASE(1) NLD_CASE(2) NLD_CASE(3) NLD_CASE(4) NLD_CASE(5) NLD_CASE(6) NLD_CASE(7) NLD_CASE(8)
         NLD_CASE(9) NLD_CASE(10) NLD_CASE(11) NLD_CASE(12) NLD_CASE(13) NLD_CASE(14) NLD_CASE(15) NLD_CASE(16)
@@ -1230,10 +1320,11 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
   }
   const LevelTab T = level_tab(a);
   const dim3 agrid((a->w + 127) / 128, T.row0[T.n]);
-  hipLaunchKernelGGL(k_scharr_xy_all, agrid, dim3(128), 0, s, a->d_Lsmooth, a->d_Lx, a->d_Ly, T);
-  hipLaunchKernelGGL(k_hessian_det_all, agrid, dim3(128), 0, s, a->d_Lx, a->d_Ly, a->d_Ldet, T);
+  sfm_launch<ScharrXyAllBody>(a, k_scharr_xy_all, agrid, dim3(128), (uint32_t)0, a->d_Lsmooth, a->d_Lx, a->d_Ly, T);
+  sfm_launch<HessianDetAllBody>(a, k_hessian_det_all, agrid, dim3(128), (uint32_t)0, a->d_Lx, a->d_Ly, a->d_Ldet, T);
   AK_HIP(hipGetLastError());
   return SFMLOC_OK;
+#undef s
 }
 
 struct HostKpt {
@@ -1257,7 +1348,10 @@ int ensure_kp_cap(Akaze *a, unsigned int n) {
   return SFMLOC_OK;
 }
 
-int orient_describe(Akaze *a, const std::vector<float> &kin, unsigned int n, float *angle_out, uint8_t *desc64) {
+// phase 0: upload + kernel + downloads; 1: upload + kernel only; 2: the downloads only (a batch queues every image's kernel
+// before the first download, which blocks the host when the destination is pageable memory)
+int orient_describe_enqueue(Akaze *a, const std::vector<float> &kin, unsigned int n, float *angle_out, uint8_t *desc64,
+                            int phase) {
   if (n == 0) return SFMLOC_OK;
   int rc = ensure_kp_cap(a, n);
   if (rc) return rc;
@@ -1273,12 +1367,22 @@ int orient_describe(Akaze *a, const std::vector<float> &kin, unsigned int n, flo
     LV.l[i].octave = L.octave;
     LV.l[i].sf = (float)L.sigma_size;
   }
-  AK_HIP(hipMemcpyAsync(a->d_kp, kin.data(), (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, a->stream));
-  hipLaunchKernelGGL(k_orient_describe, dim3(n), dim3(64), 0, a->stream, LV, a->d_kp, (int)n, a->d_gauss25, a->d_win,
-                     a->plan.n_win, a->d_pair, a->d_angle, a->d_desc);
-  AK_HIP(hipGetLastError());
-  if (angle_out) AK_HIP(hipMemcpyAsync(angle_out, a->d_angle, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, a->stream));
-  if (desc64) AK_HIP(hipMemcpyAsync(desc64, a->d_desc, (size_t)n * 64, hipMemcpyDeviceToHost, a->stream));
+  if (phase != 2) {
+    AK_HIP(hipMemcpyAsync(a->d_kp, kin.data(), (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, a->stream));
+    hipLaunchKernelGGL(k_orient_describe, dim3(n), dim3(64), 0, a->stream, LV, a->d_kp, (int)n, a->d_gauss25, a->d_win,
+                       a->plan.n_win, a->d_pair, a->d_angle, a->d_desc);
+    AK_HIP(hipGetLastError());
+  }
+  if (phase != 1) {
+    if (angle_out) AK_HIP(hipMemcpyAsync(angle_out, a->d_angle, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, a->stream));
+    if (desc64) AK_HIP(hipMemcpyAsync(desc64, a->d_desc, (size_t)n * 64, hipMemcpyDeviceToHost, a->stream));
+  }
+  return SFMLOC_OK;
+}
+
+int orient_describe(Akaze *a, const std::vector<float> &kin, unsigned int n, float *angle_out, uint8_t *desc64) {
+  int rc = orient_describe_enqueue(a, kin, n, angle_out, desc64, 0);
+  if (rc) return rc;
   AK_HIP(hipStreamSynchronize(a->stream));
   return SFMLOC_OK;
 }
@@ -1294,7 +1398,8 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   Akaze *a = reinterpret_cast<Akaze *>(ak);
   if (!a) return;
   hipSetDevice(a->device);
-  if (a->stream) hipStreamSynchronize(a->stream);
+  if (a->stream.own) hipStreamSynchronize(a->stream.own);
+  gang_member_free(a);
   void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
                   a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_cand, a->d_ncand,
                   a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc};
@@ -1327,7 +1432,7 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   make_plan(width, height, n_octaves, n_sublevels, a->plan);
   const size_t n0 = (size_t)width * height, tot = a->plan.total;
   hipError_t he = hipStreamCreateWithFlags(&a->own_stream, hipStreamNonBlocking);
-  a->stream = a->own_stream;
+  a->stream.own = a->own_stream;
   auto A = [&](void **p, size_t bytes) {
     if (he == hipSuccess) he = hipMalloc(p, bytes);
   };
@@ -1372,7 +1477,7 @@ int sfmloc_akaze_share_stream(sfmloc_akaze *ak, sfmloc_context *ctx) {
   SFM_CHECK(!c || c->map->device == a->device, SFMLOC_EINVAL, "sfmloc_akaze_share_stream: extractor and context on different devices");
   hipSetDevice(a->device);
   if (a->stream) hipStreamSynchronize(a->stream);
-  a->stream = c ? c->stream : a->own_stream;
+  a->stream.own = c ? c->stream.own : a->own_stream;
   return SFMLOC_OK;
 }
 
@@ -1398,31 +1503,63 @@ int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt) {
   return SFMLOC_OK;
 }
 
+// The device side of detection up to the extrema candidates of every level: launches only (an extractor that records for
+// a gang session takes part in ONE launch per kernel with the other images of the batch), no host synchronisation.
+static int akaze_detect_enqueue(Akaze *a, const uint8_t *gray) {
+  // (the counter is not touched by anything the scale space launches: it need not wait for recorded launches)
+  SFM_HIP(hipMemsetAsync(a->d_ncand, 0, sizeof(unsigned int), a->stream.unordered()));
+  int rc = build_scale_space(a, gray);
+  if (rc) return rc;
+  const LevelTab T = level_tab(a);
+  sfm_launch<ExtremaAllBody>(a, k_extrema_all, dim3((a->w + 127) / 128, T.row0[T.n]), dim3(128), 0, a->d_Ldet, T, a->thres,
+                             a->d_cand, a->cand_cap, a->d_ncand);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+static int akaze_detect_finish(Akaze *a, float *kpts, uint8_t *desc64, uint32_t cap, uint32_t *n_out, double t_0);
+
 int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float *kpts /*[cap*6]*/,
                                     uint8_t *desc64 /*[cap*64]*/, uint32_t cap, uint32_t *n_out) {
   SFM_CHECK(ak && gray && n_out, SFMLOC_EINVAL, "sfmloc_akaze_detect_and_compute: null argument");
   Akaze *a = reinterpret_cast<Akaze *>(ak);
-  const AkPlan &P = a->plan;
   SFM_HIP(hipSetDevice(a->device));
   static const bool timing = getenv("SFMLOC_AKAZE_TIMING") != nullptr;
   const double t_0 = timing ? now_s() : 0.0;
-  int rc = build_scale_space(a, gray);
+  int rc = akaze_detect_enqueue(a, gray);
   if (rc) return rc;
-  // candidates of every level
-  SFM_HIP(hipMemsetAsync(a->d_ncand, 0, sizeof(unsigned int), a->stream));
-  {
-    const LevelTab T = level_tab(a);
-    hipLaunchKernelGGL(k_extrema_all, dim3((a->w + 127) / 128, T.row0[T.n]), dim3(128), 0, a->stream, a->d_Ldet, T, a->thres,
-                       a->d_cand, a->cand_cap, a->d_ncand);
-  }
-  SFM_HIP(hipGetLastError());
+  return akaze_detect_finish(a, kpts, desc64, cap, n_out, t_0);
+}
+
+// One image's detection after the device has produced the extrema candidates, in stages so that a batch of images can
+// take each stage together (one host synchronisation per stage instead of three per image, the host's refinement of the
+// images in parallel): count -> candidates -> host refinement -> orientation + descriptors -> outputs.
+struct DetectState {
   unsigned int nc = 0;
-  SFM_HIP(hipMemcpyAsync(&nc, a->d_ncand, sizeof(nc), hipMemcpyDeviceToHost, a->stream));
-  SFM_HIP(hipStreamSynchronize(a->stream));
-  SFM_CHECK(nc <= a->cand_cap, SFMLOC_ECAP, "AKAZE: %u extrema candidates exceed the workspace (%u)", nc, a->cand_cap);
-  std::vector<Candidate9> cand(nc);
-  if (nc) SFM_HIP(hipMemcpy(cand.data(), a->d_cand, (size_t)nc * sizeof(Candidate9), hipMemcpyDeviceToHost));
-  const double t_1 = timing ? now_s() : 0.0;
+  std::vector<Candidate9> cand;
+  std::vector<HostKpt> fin;
+  std::vector<float> kin, ang;
+  uint32_t n = 0;
+};
+
+// (a) the candidate count, asynchronously on stream s; the caller synchronises
+static int detect_count_enqueue(Akaze *a, DetectState &st, hipStream_t s) {
+  SFM_HIP(hipMemcpyAsync(&st.nc, a->d_ncand, sizeof(st.nc), hipMemcpyDeviceToHost, s));
+  return SFMLOC_OK;
+}
+// (b) the candidates themselves
+static int detect_candidates_read(Akaze *a, DetectState &st) {
+  SFM_CHECK(st.nc <= a->cand_cap, SFMLOC_ECAP, "AKAZE: %u extrema candidates exceed the workspace (%u)", st.nc, a->cand_cap);
+  st.cand.resize(st.nc);
+  if (st.nc) SFM_HIP(hipMemcpy(st.cand.data(), a->d_cand, (size_t)st.nc * sizeof(Candidate9), hipMemcpyDeviceToHost));
+  return SFMLOC_OK;
+}
+// (c) host only (no HIP call, no shared state: images can take it in parallel threads)
+static void detect_refine_host(const Akaze *a, DetectState &st) {
+  const AkPlan &P = a->plan;
+  std::vector<Candidate9> &cand = st.cand;
+  const unsigned int nc = st.nc;
+  std::vector<HostKpt> &fin = st.fin;
   std::sort(cand.begin(), cand.end(), [](const Candidate9 &p, const Candidate9 &q) {
     if (p.level != q.level) return p.level < q.level;
     if (p.y != q.y) return p.y < q.y;
@@ -1512,7 +1649,7 @@ int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float
     if (!rep) kept.push_back(aux[i]);
   }
   // Do_Subpixel_Refinement on the carried 3x3 patch
-  std::vector<HostKpt> fin;
+  fin.clear();
   fin.reserve(kept.size());
   for (HostKpt k : kept) {
     const float ratio = (float)(1 << k.octave);
@@ -1535,33 +1672,121 @@ int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float
     }
   }
   const uint32_t n = (uint32_t)fin.size();
-  *n_out = n;
-  SFM_CHECK(n <= cap, SFMLOC_ECAP, "AKAZE: %u keypoints, caller buffers hold %u", n, cap);
-  std::vector<float> kin((size_t)n * 4), ang(n);
+  st.n = n;
+  st.kin.resize((size_t)n * 4);
+  st.ang.assign(n, 0.0f);
   for (uint32_t i = 0; i < n; ++i) {
-    kin[4 * i] = fin[i].x;
-    kin[4 * i + 1] = fin[i].y;
-    kin[4 * i + 2] = fin[i].size;
-    kin[4 * i + 3] = (float)fin[i].class_id;
+    st.kin[4 * i] = fin[i].x;
+    st.kin[4 * i + 1] = fin[i].y;
+    st.kin[4 * i + 2] = fin[i].size;
+    st.kin[4 * i + 3] = (float)fin[i].class_id;
   }
-  const double t_2 = timing ? now_s() : 0.0;
-  rc = orient_describe(a, kin, n, ang.data(), desc64);
+}
+// (e) the keypoint records
+static void detect_outputs(const DetectState &st, float *kpts) {
+  if (!kpts) return;
+  for (uint32_t i = 0; i < st.n; ++i) {
+    kpts[6 * i] = st.fin[i].x;
+    kpts[6 * i + 1] = st.fin[i].y;
+    kpts[6 * i + 2] = st.fin[i].size;
+    kpts[6 * i + 3] = st.ang[i];
+    kpts[6 * i + 4] = st.fin[i].response;
+    kpts[6 * i + 5] = (float)st.fin[i].class_id;
+  }
+}
+
+static int akaze_detect_finish(Akaze *a, float *kpts, uint8_t *desc64, uint32_t cap, uint32_t *n_out, double t_0) {
+  static const bool timing = getenv("SFMLOC_AKAZE_TIMING") != nullptr;
+  DetectState st;
+  int rc = detect_count_enqueue(a, st, a->stream);
   if (rc) return rc;
+  SFM_HIP(hipStreamSynchronize(a->stream));
+  rc = detect_candidates_read(a, st);
+  if (rc) return rc;
+  const double t_1 = timing ? now_s() : 0.0;
+  detect_refine_host(a, st);
+  *n_out = st.n;
+  SFM_CHECK(st.n <= cap, SFMLOC_ECAP, "AKAZE: %u keypoints, caller buffers hold %u", st.n, cap);
+  const double t_2 = timing ? now_s() : 0.0;
+  rc = orient_describe_enqueue(a, st.kin, st.n, st.ang.data(), desc64, 0);
+  if (rc) return rc;
+  SFM_HIP(hipStreamSynchronize(a->stream));
   if (timing)
     fprintf(stderr, "akaze %dx%d: scale space + extrema %.3f ms, host suppression + subpixel %.3f ms (%u candidates -> %u), "
-                    "orientation + M-LDB %.3f ms\n", a->w, a->h, (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, nc, n,
+                    "orientation + M-LDB %.3f ms\n", a->w, a->h, (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, st.nc, st.n,
             (now_s() - t_2) * 1e3);
-  if (kpts)
-    for (uint32_t i = 0; i < n; ++i) {
-      kpts[6 * i] = fin[i].x;
-      kpts[6 * i + 1] = fin[i].y;
-      kpts[6 * i + 2] = fin[i].size;
-      kpts[6 * i + 3] = ang[i];
-      kpts[6 * i + 4] = fin[i].response;
-      kpts[6 * i + 5] = (float)fin[i].class_id;
-    }
+  detect_outputs(st, kpts);
   return SFMLOC_OK;
 }
+
+// Several images of one size at once: extractor i takes image i; the scale spaces, determinants and extrema of all of them
+// go out as ONE launch per kernel (a gang session on the first extractor's stream); the candidates' refinement on the
+// host and the orientation + M-LDB launch follow per image.  Results are those of n separate calls.
+int sfmloc_akaze_detect_and_compute_batch(sfmloc_akaze *const *aks, const uint8_t *const *grays, uint32_t n,
+                                          float *const *kpts, uint8_t *const *descs, uint32_t cap, uint32_t *n_out) {
+  SFM_CHECK(aks && grays && kpts && n_out && n >= 1 && n <= (uint32_t)kGangMembers, SFMLOC_EINVAL,
+            "sfmloc_akaze_detect_and_compute_batch: 1..%d images", kGangMembers);
+  GangMember *ms[kGangMembers];
+  Akaze *first = reinterpret_cast<Akaze *>(aks[0]);
+  for (uint32_t i = 0; i < n; ++i) {
+    Akaze *a = reinterpret_cast<Akaze *>(aks[i]);
+    SFM_CHECK(a && grays[i] && kpts[i], SFMLOC_EINVAL, "sfmloc_akaze_detect_and_compute_batch: null argument (image %u)", i);
+    SFM_CHECK(a->device == first->device && a->w == first->w && a->h == first->h, SFMLOC_EINVAL,
+              "sfmloc_akaze_detect_and_compute_batch: the extractors differ in device or image size");
+    SFM_CHECK(a->stream.gang == nullptr, SFMLOC_EINVAL, "sfmloc_akaze_detect_and_compute_batch: extractor %u is in a session", i);
+    for (uint32_t j = 0; j < i; ++j) SFM_CHECK(aks[j] != aks[i], SFMLOC_EINVAL, "extractor listed twice");
+    ms[i] = a;
+  }
+  SFM_HIP(hipSetDevice(first->device));
+  static const bool timing = getenv("SFMLOC_AKAZE_TIMING") != nullptr;
+  const double t_0 = timing ? now_s() : 0.0;
+  int rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
+  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = akaze_detect_enqueue(reinterpret_cast<Akaze *>(aks[i]), grays[i]);
+  const int rc_close = gang_close(first);
+  if (rc == SFMLOC_OK) rc = rc_close;
+  if (rc) return rc;
+  double t_s[6] = {t_0, 0, 0, 0, 0, 0};
+  if (timing) t_s[1] = now_s();
+  // every stage for all the images, one host synchronisation per stage
+  std::vector<DetectState> st(n);
+  hipStream_t s0 = first->stream;  // (the gang's stream: the candidates of every image were produced on it)
+  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = detect_count_enqueue(reinterpret_cast<Akaze *>(aks[i]), st[i], s0);
+  if (rc) return rc;
+  SFM_HIP(hipStreamSynchronize(s0));
+  if (timing) t_s[2] = now_s();
+  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = detect_candidates_read(reinterpret_cast<Akaze *>(aks[i]), st[i]);
+  if (rc) return rc;
+  if (timing) t_s[3] = now_s();
+  {  // the host's refinement: images are independent
+    const unsigned nthr = n < 8 ? n : 8;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthr; ++t)
+      th.emplace_back([&, t] {
+        for (uint32_t i = t; i < n; i += nthr) detect_refine_host(reinterpret_cast<const Akaze *>(aks[i]), st[i]);
+      });
+    for (uint32_t i = 0; i < n; i += nthr) detect_refine_host(reinterpret_cast<const Akaze *>(aks[i]), st[i]);
+    for (auto &t : th) t.join();
+  }
+  if (timing) t_s[4] = now_s();
+  for (uint32_t i = 0; i < n; ++i) {
+    n_out[i] = st[i].n;
+    SFM_CHECK(st[i].n <= cap, SFMLOC_ECAP, "AKAZE: %u keypoints, caller buffers hold %u", st[i].n, cap);
+  }
+  for (int phase = 1; phase <= 2; ++phase)
+    for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i)
+      rc = orient_describe_enqueue(reinterpret_cast<Akaze *>(aks[i]), st[i].kin, st[i].n, st[i].ang.data(),
+                                   descs ? descs[i] : nullptr, phase);
+  if (rc) return rc;
+  for (uint32_t i = 0; i < n; ++i) SFM_HIP(hipStreamSynchronize(reinterpret_cast<Akaze *>(aks[i])->stream));
+  for (uint32_t i = 0; i < n; ++i) detect_outputs(st[i], kpts[i]);
+  if (timing)
+    fprintf(stderr, "akaze batch of %u (%dx%d): launches queued %.3f ms, scale spaces + extrema done %.3f, candidates read "
+                    "%.3f, host refinement %.3f, orientation + M-LDB + outputs %.3f\n", n, first->w, first->h,
+            (t_s[1] - t_s[0]) * 1e3, (t_s[2] - t_s[1]) * 1e3, (t_s[3] - t_s[2]) * 1e3, (t_s[4] - t_s[3]) * 1e3,
+            (now_s() - t_s[4]) * 1e3);
+  return SFMLOC_OK;
+}
+
 
 int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin, uint32_t n, uint8_t *desc64,
                          float *angle_out) {

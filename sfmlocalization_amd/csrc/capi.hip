@@ -142,11 +142,7 @@ void free_ctx(Ctx *c) {
   if (c->pinned_busy) hipEventDestroy(c->pinned_busy);
   if (c->xev_out) hipEventDestroy(c->xev_out);
   if (c->xev_in) hipEventDestroy(c->xev_in);
-  if (c->gang_ev) hipEventDestroy(c->gang_ev);
-  if (c->gang_owned) {
-    if (c->gang_owned->done) hipEventDestroy(c->gang_owned->done);
-    delete c->gang_owned;
-  }
+  gang_member_free(c);
   if (c->stream.own && !c->stream_borrowed) hipStreamDestroy(c->stream.own);
   Ctx *lender = c->lender;
   delete c;
@@ -715,14 +711,14 @@ int gang_flush(GangState *g) {
     // the members advance in step: always the earliest position any member still has to issue, and there every member
     // whose record is the same kernel on the same grid in ONE launch (dynamic LDS: the largest request serves all)
     size_t pos = SIZE_MAX;
-    for (Ctx *m : g->members)
+    for (GangMember *m : g->members)
       if (m->gang_head < m->gang_recs.size() && m->gang_head < pos) pos = m->gang_head;
     if (pos == SIZE_MAX) break;
     GangRec *grp[kGangMembers];
     int n = 0;
     GangRec *lead = nullptr;
     uint32_t shmem = 0;
-    for (Ctx *m : g->members) {
+    for (GangMember *m : g->members) {
       if (m->gang_head != pos || pos >= m->gang_recs.size()) continue;
       GangRec *r = &m->gang_recs[pos];
       if (lead && !(r->key == lead->key && r->grid.x == lead->grid.x && r->grid.y == lead->grid.y &&
@@ -750,11 +746,62 @@ int gang_flush(GangState *g) {
       rc = SFMLOC_EHIP;
     }
   }
-  for (Ctx *m : g->members) {
+  for (GangMember *m : g->members) {
     m->gang_recs.clear();
     m->gang_head = 0;
   }
   return rc;
+}
+
+int gang_open(GangMember *const *members, int n) {
+  GangMember *lead = members[0];
+  if (!lead->gang_owned) {
+    lead->gang_owned = new (std::nothrow) GangState();
+    SFM_CHECK(lead->gang_owned, SFMLOC_ENOMEM, "out of host memory");
+    SFM_HIP(hipEventCreateWithFlags(&lead->gang_owned->done, hipEventDisableTiming));
+  }
+  GangState *g = lead->gang_owned;
+  g->stream = lead->stream.own;
+  g->members.clear();
+  for (int i = 0; i < n; ++i) {
+    GangMember *c = members[i];
+    if (i > 0 && c->stream.dirty && c->stream.own != g->stream) {  // the member's own earlier work comes first
+      if (!c->gang_ev) SFM_HIP(hipEventCreateWithFlags(&c->gang_ev, hipEventDisableTiming));
+      SFM_HIP(hipEventRecord(c->gang_ev, c->stream.own));
+      SFM_HIP(hipStreamWaitEvent(g->stream, c->gang_ev, 0));
+      c->stream.dirty = false;
+    }
+    g->members.push_back(c);
+  }
+  for (GangMember *c : g->members) c->stream.gang = g;
+  return SFMLOC_OK;
+}
+
+int gang_close(GangMember *lead) {
+  GangState *g = lead->stream.gang;
+  if (!g) return SFMLOC_OK;
+  const int rc = gang_flush(g);
+  for (GangMember *c : g->members) c->stream.gang = nullptr;
+  lead->stream.dirty = true;
+  // the members' own streams continue after the gang's work
+  bool any_own = false;
+  for (size_t i = 1; i < g->members.size(); ++i) any_own |= g->members[i]->stream.own != g->stream;
+  if (any_own) {
+    SFM_HIP(hipEventRecord(g->done, g->stream));
+    for (size_t i = 1; i < g->members.size(); ++i)
+      if (g->members[i]->stream.own != g->stream) SFM_HIP(hipStreamWaitEvent(g->members[i]->stream.own, g->done, 0));
+  }
+  return rc;  // (gang_flush has set the message)
+}
+
+void gang_member_free(GangMember *m) {
+  if (m->gang_ev) hipEventDestroy(m->gang_ev);
+  if (m->gang_owned) {
+    if (m->gang_owned->done) hipEventDestroy(m->gang_owned->done);
+    delete m->gang_owned;
+  }
+  m->gang_ev = nullptr;
+  m->gang_owned = nullptr;
 }
 
 int match_putative_on(Ctx *c, Query *q, const uint32_t *view_sel, uint32_t n_sel) {
@@ -1593,26 +1640,9 @@ int sfmloc_gang_begin(sfmloc_context *const *ctxs, uint32_t n) {
   // members simply run one after the other)
   if (n == 1 || lead->map->params.profile != 0) return SFMLOC_OK;
   SFM_HIP(hipSetDevice(lead->map->device));
-  if (!lead->gang_owned) {
-    lead->gang_owned = new (std::nothrow) GangState();
-    SFM_CHECK(lead->gang_owned, SFMLOC_ENOMEM, "out of host memory");
-    lead->gang_owned->stream = lead->stream.own;
-    SFM_HIP(hipEventCreateWithFlags(&lead->gang_owned->done, hipEventDisableTiming));
-  }
-  GangState *g = lead->gang_owned;
-  g->members.clear();
-  for (uint32_t i = 0; i < n; ++i) {
-    Ctx *c = reinterpret_cast<Ctx *>(ctxs[i]);
-    if (i > 0 && c->stream.dirty && c->stream.own != g->stream) {  // the member's own earlier work comes first
-      if (!c->gang_ev) SFM_HIP(hipEventCreateWithFlags(&c->gang_ev, hipEventDisableTiming));
-      SFM_HIP(hipEventRecord(c->gang_ev, c->stream.own));
-      SFM_HIP(hipStreamWaitEvent(g->stream, c->gang_ev, 0));
-      c->stream.dirty = false;
-    }
-    g->members.push_back(c);
-  }
-  for (Ctx *c : g->members) c->stream.gang = g;
-  return SFMLOC_OK;
+  GangMember *ms[kGangMembers];
+  for (uint32_t i = 0; i < n; ++i) ms[i] = reinterpret_cast<Ctx *>(ctxs[i]);
+  return gang_open(ms, (int)n);
 }
 
 int sfmloc_gang_end(sfmloc_context *const *ctxs, uint32_t n) {
@@ -1622,18 +1652,7 @@ int sfmloc_gang_end(sfmloc_context *const *ctxs, uint32_t n) {
   if (!g) return SFMLOC_OK;  // the session recorded nothing (one member, or profiling)
   SFM_CHECK(g == lead->gang_owned && g->members.size() == n, SFMLOC_EINVAL, "sfmloc_gang_end: not the contexts of the session");
   SFM_HIP(hipSetDevice(lead->map->device));
-  const int rc = gang_flush(g);
-  for (Ctx *c : g->members) c->stream.gang = nullptr;
-  lead->stream.dirty = true;
-  // the members' own streams continue after the gang's work
-  bool any_own = false;
-  for (size_t i = 1; i < g->members.size(); ++i) any_own |= g->members[i]->stream.own != g->stream;
-  if (any_own) {
-    SFM_HIP(hipEventRecord(g->done, g->stream));
-    for (size_t i = 1; i < g->members.size(); ++i)
-      if (g->members[i]->stream.own != g->stream) SFM_HIP(hipStreamWaitEvent(g->members[i]->stream.own, g->done, 0));
-  }
-  return rc;  // (gang_flush has set the message)
+  return gang_close(lead);
 }
 
 int sfmloc_gang_counters(sfmloc_context *lead_ctx, uint64_t *launches, uint64_t *gang_launches) {

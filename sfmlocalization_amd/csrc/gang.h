@@ -25,7 +25,7 @@
 namespace sfmloc {
 
 constexpr int kGangMembers = 32;      // contexts per session at most
-constexpr int kGangArgBytes = 1008;   // one member's argument list at most
+constexpr int kGangArgBytes = 2032;   // one member's argument list at most (the AKAZE level tables are 1 KB)
 constexpr int kGangKernargBytes = 3968;  // the members' lists of one launch together (the kernarg segment holds 4 KB)
 
 // a trivially copyable tuple (std::tuple is neither that nor usable in a kernel signature)
@@ -76,11 +76,11 @@ struct GangRec {
   alignas(16) unsigned char args[kGangArgBytes];
 };
 
-struct Ctx;
+struct GangMember;
 struct GangState {
   hipStream_t stream = nullptr;  // the first member's own stream
   hipEvent_t done = nullptr;
-  std::vector<Ctx *> members;
+  std::vector<GangMember *> members;
   uint64_t launches = 0, gang_launches = 0;  // issued by flushes (all kinds / with more than one member)
 };
 
@@ -101,7 +101,30 @@ struct CtxStream {
     dirty = true;
     return own;
   }
+  // the stream for work that depends on NOTHING this member has recorded in the session so far (an upload into a buffer
+  // the recorded kernels do not touch before it): queued at once, ahead of the recorded launches, without issuing them
+  hipStream_t unordered() {
+    if (gang) return gang->stream;
+    dirty = true;
+    return own;
+  }
 };
+
+// what takes part in gang sessions: a context (sfmloc_internal.h) or an AKAZE extractor (akaze.hip)
+struct GangMember {
+  CtxStream stream;  // reads as the stream to queue on now (the member's own, or its gang's while recording)
+  std::vector<GangRec> gang_recs;  // launches recorded for the gang session in progress
+  size_t gang_head = 0;
+  GangState *gang_owned = nullptr;  // this member has led a gang: its state (stream = this member's own)
+  hipEvent_t gang_ev = nullptr;     // orders the gang's stream after this member's own earlier work
+};
+
+// capi.hip.  gang_open: the members (the first leads: its stream carries the session) start recording; the gang's stream
+// first waits for whatever a member still has queued on a stream of its own.  gang_close: everything recorded is issued
+// and the members' own streams continue after it.  gang_member_free: the events / state a member may own.
+int gang_open(GangMember *const *members, int n);
+int gang_close(GangMember *lead);
+void gang_member_free(GangMember *m);
 
 template <class Body, class... Ts>
 struct GangLaunch {

@@ -159,18 +159,13 @@ struct Map {
 // Everything one in-flight query needs: a stream and the workspace of every stage.  Several contexts
 // of one map run concurrently (the latency-bound RANSAC stages of one query overlap the VALU-bound
 // Hamming kernel of another).
-struct Ctx {
+struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   Map *map = nullptr;
-  CtxStream stream;  // gang.h: reads as the stream to queue on now (the context's own, or its gang's while recording)
   bool stream_borrowed = false;    // stream.own belongs to `lender` (sfmloc_context_create_sharing)
   Ctx *lender = nullptr;
   bool merge_only = false;         // no workspace of the matching stages (sfmloc_context_create_merge)
   int borrowers = 0;               // contexts working on this one's stream
   bool zombie = false;             // destroyed while lent out: freed with its last borrower
-  std::vector<GangRec> gang_recs;  // launches recorded for the gang session in progress
-  size_t gang_head = 0;
-  GangState *gang_owned = nullptr;  // this context has led a gang: its state (stream = this context's own)
-  hipEvent_t gang_ev = nullptr;     // orders the gang's stream after this member's own earlier work
   uint64_t hbm_bytes = 0;
 
   // --- putative stage ---
@@ -278,7 +273,7 @@ inline void gang_store_args(void *dst, std::index_sequence<Is...>, As &&...as) {
   new (dst) Tup<Ts...>{TupLeaf<Is, Ts>{static_cast<Ts>(as)}...};
 }
 template <class Body, class... Ts, class... As>
-inline void sfm_launch(Ctx *c, void (*single)(Ts...), dim3 grid, dim3 block, uint32_t shmem, As &&...as) {
+inline void sfm_launch(GangMember *c, void (*single)(Ts...), dim3 grid, dim3 block, uint32_t shmem, As &&...as) {
   if (!c->stream.gang) {
     hipLaunchKernelGGL(single, grid, block, shmem, (hipStream_t)c->stream, static_cast<Ts>(as)...);
     return;

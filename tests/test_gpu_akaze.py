@@ -29,6 +29,47 @@ def test_detect_and_compute_matches_oracle(oracle_c, shape, seed):
     ak.close()
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (270, 481)])
+def test_batch_of_images_equals_one_at_a_time(shape):
+    """sfmloc_akaze_detect_and_compute_batch (one launch per kernel for all the frames, the stages after the extrema taken
+    together): keypoints, descriptors and the scale space of every extractor as from separate calls -- with extractors on
+    streams of their own and with all of them on one context's stream."""
+    imgs = [synth.texture_image(40 + k, *shape) for k in range(7)]
+    one = S.Akaze(shape[1], shape[0])
+    ref = [one.detect_and_compute(g) for g in imgs]
+    ref_levels = one.read_levels()                                   # (of the last image)
+    exs = [S.Akaze(shape[1], shape[0]) for _ in range(7)]
+    for n in (1, 2, 7):
+        got = S.Akaze.detect_and_compute_batch(exs[:n], imgs[:n])
+        for (kp, d), (rkp, rd) in zip(got, ref):
+            np.testing.assert_array_equal(bits32(kp), bits32(rkp))
+            np.testing.assert_array_equal(d, rd)
+    ldet, lt = exs[6].read_levels()
+    np.testing.assert_array_equal(bits32(lt), bits32(ref_levels[1]))
+    np.testing.assert_array_equal(bits32(ldet), bits32(ref_levels[0]))
+    assert sum(len(kp) for kp, _ in ref) > 50
+    # a worker's extractors and context on ONE stream (bench.py --from-images)
+    m = synth.make_map(1, n_views=6, desc_per_view=50, views_per_place=3, landmarks_per_place=40, obs_per_view=20)
+    with S.Map(m.view_id, m.view_off, m.desc) as dm:
+        c = dm.context()
+        for e in exs[:3]:
+            e.share_stream(c)
+        got = S.Akaze.detect_and_compute_batch(exs[:3], imgs[2:5])
+        for (kp, d), (rkp, rd) in zip(got, ref[2:5]):
+            np.testing.assert_array_equal(bits32(kp), bits32(rkp))
+            np.testing.assert_array_equal(d, rd)
+        for e in exs[:3]:
+            e.share_stream(None)
+        c.close()
+    other = S.Akaze(shape[1] + 16, shape[0])
+    with pytest.raises(S.SfmlocError):                                # one size per batch
+        S.Akaze.detect_and_compute_batch([exs[0], other], [imgs[0], synth.texture_image(9, shape[0], shape[1] + 16)])
+    with pytest.raises(S.SfmlocError):                                # an extractor takes one image of a batch
+        S.Akaze.detect_and_compute_batch([exs[0], exs[0]], imgs[:2])
+    for e in exs + [one, other]:
+        e.close()
+
+
 def test_dense_compute_matches_oracle(oracle_c):
     g = synth.texture_image(4, 300, 300)
     xs = np.arange(0, 300, 6, dtype=np.float32)
