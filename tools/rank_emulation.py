@@ -136,7 +136,12 @@ def main():
                 blk[i // N] = pack(i)
             feats[r] = torch.from_numpy(blk).to(dev)
         frames = [synth.texture_image(900 + k, hw[0], hw[1]) for k in range(4)]
-        extractors = [S.Akaze(hw[1], hw[0], device=0) for _ in range(a.extract_workers)]
+        G_ex = 8                                            # frames per extraction call (detect_and_compute_batch)
+        extractors = [[S.Akaze(hw[1], hw[0], device=0) for _ in range(G_ex)] for _ in range(a.extract_workers)]
+        lenders = [maps[0][0].context(merge_only=True) for _ in range(a.extract_workers)]
+        for es, c in zip(extractors, lenders):              # a worker's extractors on ONE stream (a small context lends it)
+            for e in es:
+                e.share_stream(c)
         pool = ThreadPoolExecutor(a.extract_workers)
         mine_i = list(range(0, B, N))
         n_kp = [0]
@@ -144,9 +149,11 @@ def main():
         def extract():
             """this rank's share of a batch: one frame through AKAZE + M-LDB per owned query (W workers), then the blocks"""
             def work(w):
-                for j in range(w, len(mine_i), a.extract_workers):
-                    kp, _ = extractors[w].detect_and_compute(frames[j % len(frames)])
-                    n_kp[0] = len(kp)
+                js = list(range(w, len(mine_i), a.extract_workers))
+                for k0 in range(0, len(js), G_ex):
+                    part = js[k0:k0 + G_ex]
+                    got = S.Akaze.detect_and_compute_batch(extractors[w][:len(part)], [frames[j % len(frames)] for j in part])
+                    n_kp[0] = len(got[0][0])
             list(pool.map(work, range(a.extract_workers)))
             return {i: pack(i) for i in mine_i}
 
