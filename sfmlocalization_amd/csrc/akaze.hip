@@ -868,7 +868,8 @@ __device__ __forceinline__ int level_of_row(const LevelTab &T, int row) {
 
 struct ScharrXyAllBody {
   static constexpr int kGangThreads = 256;
-  static __device__ __forceinline__ void run(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly, const LevelTab &T) {
+  static __device__ __forceinline__ void run(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly, const LevelTab *__restrict__ Tp) {
+    const LevelTab &T = *Tp;  // (in device memory, one per extractor: a gang launch carries a pointer per frame, not a table)
     const int i = level_of_row(T, blockIdx.y);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
     if (x >= w) return;
@@ -877,14 +878,16 @@ struct ScharrXyAllBody {
     ly[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 0, T.sc[i], T.ws[i], T.wm[i]);
   }
 };
-__global__ void k_scharr_xy_all(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly, LevelTab T) {
-  ScharrXyAllBody::run(ls, lx, ly, T);
+__global__ void k_scharr_xy_all(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly,
+                                const LevelTab *__restrict__ Tp) {
+  ScharrXyAllBody::run(ls, lx, ly, Tp);
 }
 
 struct HessianDetAllBody {
   static constexpr int kGangThreads = 256;
   static __device__ __forceinline__ void run(const float *__restrict__ lx_all, const float *__restrict__ ly_all,
-                          float *__restrict__ ldet, const LevelTab &T) {
+                          float *__restrict__ ldet, const LevelTab *__restrict__ Tp) {
+    const LevelTab &T = *Tp;
     const int i = level_of_row(T, blockIdx.y);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
     if (x >= w) return;
@@ -899,8 +902,8 @@ struct HessianDetAllBody {
   }
 };
 __global__ void k_hessian_det_all(const float *__restrict__ lx_all, const float *__restrict__ ly_all,
-                          float *__restrict__ ldet, LevelTab T) {
-  HessianDetAllBody::run(lx_all, ly_all, ldet, T);
+                          float *__restrict__ ldet, const LevelTab *__restrict__ Tp) {
+  HessianDetAllBody::run(lx_all, ly_all, ldet, Tp);
 }
 
 struct Candidate9 {
@@ -911,8 +914,9 @@ struct Candidate9 {
 
 struct ExtremaAllBody {
   static constexpr int kGangThreads = 256;
-  static __device__ __forceinline__ void run(const float *__restrict__ ldet_all, const LevelTab &T, float dthreshold, Candidate9 *out,
+  static __device__ __forceinline__ void run(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp, float dthreshold, Candidate9 *out,
                       unsigned int cap, unsigned int *n_out) {
+    const LevelTab &T = *Tp;
     const int i = level_of_row(T, blockIdx.y);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
     if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
@@ -940,9 +944,9 @@ struct ExtremaAllBody {
     out[slot] = c;
   }
 };
-__global__ void k_extrema_all(const float *__restrict__ ldet_all, LevelTab T, float dthreshold, Candidate9 *out,
+__global__ void k_extrema_all(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp, float dthreshold, Candidate9 *out,
                       unsigned int cap, unsigned int *n_out) {
-  ExtremaAllBody::run(ldet_all, T, dthreshold, out, cap, n_out);
+  ExtremaAllBody::run(ldet_all, Tp, dthreshold, out, cap, n_out);
 }
 
 struct DevLevel {
@@ -1104,6 +1108,7 @@ struct Akaze : GangMember {  // (gang.h: `stream` reads as the stream to queue o
   unsigned int *d_hist = nullptr;             // [0] hmax bits, [1..301] histogram + npoints
   float *d_kcontrast = nullptr;
   float *d_half_steps = nullptr;              // [level][64]: 0.5 * tsteps, for k_octave_resident
+  void *d_level_tab = nullptr;                // the LevelTab of this image size (the all-level kernels read it by pointer)
   Candidate9 *d_cand = nullptr;
   unsigned int *d_ncand = nullptr;
   unsigned int cand_cap = 1u << 16;
@@ -1320,8 +1325,8 @@ int build_scale_space(Akaze *a, const uint8_t *gray) {
   }
   const LevelTab T = level_tab(a);
   const dim3 agrid((a->w + 127) / 128, T.row0[T.n]);
-  sfm_launch<ScharrXyAllBody>(a, k_scharr_xy_all, agrid, dim3(128), (uint32_t)0, a->d_Lsmooth, a->d_Lx, a->d_Ly, T);
-  sfm_launch<HessianDetAllBody>(a, k_hessian_det_all, agrid, dim3(128), (uint32_t)0, a->d_Lx, a->d_Ly, a->d_Ldet, T);
+  sfm_launch<ScharrXyAllBody>(a, k_scharr_xy_all, agrid, dim3(128), (uint32_t)0, a->d_Lsmooth, a->d_Lx, a->d_Ly, reinterpret_cast<const LevelTab *>(a->d_level_tab));
+  sfm_launch<HessianDetAllBody>(a, k_hessian_det_all, agrid, dim3(128), (uint32_t)0, a->d_Lx, a->d_Ly, a->d_Ldet, reinterpret_cast<const LevelTab *>(a->d_level_tab));
   AK_HIP(hipGetLastError());
   return SFMLOC_OK;
 #undef s
@@ -1401,7 +1406,7 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   if (a->stream.own) hipStreamSynchronize(a->stream.own);
   gang_member_free(a);
   void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
-                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_cand, a->d_ncand,
+                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_level_tab, a->d_cand, a->d_ncand,
                   a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -1447,6 +1452,7 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   A((void **)&a->d_hist, 304 * 4);
   A((void **)&a->d_kcontrast, 4);
   A((void **)&a->d_half_steps, (size_t)kMaxLevels * 64 * 4);
+  A((void **)&a->d_level_tab, sizeof(LevelTab));
   A((void **)&a->d_cand, (size_t)a->cand_cap * sizeof(Candidate9));
   A((void **)&a->d_ncand, 4);
   A((void **)&a->d_gauss25, 49 * 4);
@@ -1457,6 +1463,10 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
     for (int i = 0; i < a->plan.nlev; ++i)
       for (int k = 0; k < a->plan.lev[i].nsteps && k < 64; ++k) hs[(size_t)i * 64 + k] = 0.5f * a->plan.lev[i].tsteps[k];
     he = hipMemcpy(a->d_half_steps, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
+  }
+  if (he == hipSuccess) {
+    const LevelTab T = level_tab(a);
+    he = hipMemcpy(a->d_level_tab, &T, sizeof(T), hipMemcpyHostToDevice);
   }
   if (he == hipSuccess) he = hipMemcpy(a->d_gauss25, a->plan.gauss25, 49 * 4, hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipMemcpy(a->d_win, a->plan.win_ang1, 64 * 4, hipMemcpyHostToDevice);
@@ -1511,7 +1521,7 @@ static int akaze_detect_enqueue(Akaze *a, const uint8_t *gray) {
   int rc = build_scale_space(a, gray);
   if (rc) return rc;
   const LevelTab T = level_tab(a);
-  sfm_launch<ExtremaAllBody>(a, k_extrema_all, dim3((a->w + 127) / 128, T.row0[T.n]), dim3(128), 0, a->d_Ldet, T, a->thres,
+  sfm_launch<ExtremaAllBody>(a, k_extrema_all, dim3((a->w + 127) / 128, T.row0[T.n]), dim3(128), 0, a->d_Ldet, reinterpret_cast<const LevelTab *>(a->d_level_tab), a->thres,
                              a->d_cand, a->cand_cap, a->d_ncand);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
