@@ -964,128 +964,138 @@ __device__ __forceinline__ float at_clamped(const float *img, int w, int h, int 
 
 // Compute_Main_Orientation + Get_MLDB_Full_Descriptor: one wave per keypoint
 // kp [n x 4] = x, y, size (diameter), class_id ; angle_out [n] ; desc [n x 64] (61 bytes + 3 zero bytes = .desc row)
-__global__ __launch_bounds__(64) void k_orient_describe(DevLevels LV, const float *__restrict__ kp, int n,
-                                                const float *__restrict__ gauss25,
-                                                const float *__restrict__ win_ang1, int n_win,
-                                                const uint16_t *__restrict__ pair_tab,
-                                                float *__restrict__ angle_out, uint8_t *__restrict__ desc) {
-  __shared__ float resX[109], resY[109], Ang[109];
-  __shared__ float vals[29 * 3];
-  const int kidx = blockIdx.x;
-  if (kidx >= n) return;
-  const int lane = threadIdx.x;
-  const float kx = kp[4 * kidx], ky = kp[4 * kidx + 1], ksize = kp[4 * kidx + 2];
-  const int level = (int)kp[4 * kidx + 3];
-  const DevLevel L = LV.l[level];
-  const float ratio = (float)(1 << L.octave);
-  const int s = fround_d(0.5f * ksize / ratio);
-  const float xf = kx / ratio, yf = ky / ratio;
-  // --- orientation: 109 samples of the disc of radius 6 s ---
-  for (int q = lane; q < 109; q += 64) {
-    // q-th (i, j) of the double loop i = -6..6, j = -6..6 with i*i + j*j < 36
-    int cnt = 0, ii = 0, jj = 0;
-    for (int i = -6; i <= 6; ++i)
-      for (int j = -6; j <= 6; ++j)
-        if (i * i + j * j < 36) {
-          if (cnt == q) {
-            ii = i;
-            jj = j;
+struct OrientDescribeBody {
+  static constexpr int kGangThreads = 64;
+  static __device__ __forceinline__ void run(const DevLevels *__restrict__ LVp, const float *__restrict__ kp, int n,
+                                        const float *__restrict__ gauss25,
+                                        const float *__restrict__ win_ang1, int n_win,
+                                        const uint16_t *__restrict__ pair_tab,
+                                        float *__restrict__ angle_out, uint8_t *__restrict__ desc) {
+    __shared__ float resX[109], resY[109], Ang[109];
+    __shared__ float vals[29 * 3];
+    const int kidx = blockIdx.x;
+    if (kidx >= n) return;
+    const int lane = threadIdx.x;
+    const float kx = kp[4 * kidx], ky = kp[4 * kidx + 1], ksize = kp[4 * kidx + 2];
+    const int level = (int)kp[4 * kidx + 3];
+    const DevLevel L = LVp->l[level];
+    const float ratio = (float)(1 << L.octave);
+    const int s = fround_d(0.5f * ksize / ratio);
+    const float xf = kx / ratio, yf = ky / ratio;
+    // --- orientation: 109 samples of the disc of radius 6 s ---
+    for (int q = lane; q < 109; q += 64) {
+      // q-th (i, j) of the double loop i = -6..6, j = -6..6 with i*i + j*j < 36
+      int cnt = 0, ii = 0, jj = 0;
+      for (int i = -6; i <= 6; ++i)
+        for (int j = -6; j <= 6; ++j)
+          if (i * i + j * j < 36) {
+            if (cnt == q) {
+              ii = i;
+              jj = j;
+            }
+            ++cnt;
           }
-          ++cnt;
+      const int iy = fround_d(yf + (float)(jj * s)), ix = fround_d(xf + (float)(ii * s));
+      const int a = ii < 0 ? -ii : ii, b = jj < 0 ? -jj : jj;  // id[] = |.| mirrored table index
+      const float g = gauss25[7 * a + b];
+      const float rx = g * (at_clamped(L.Lx, L.w, L.h, iy, ix) * L.sf);
+      const float ry = g * (at_clamped(L.Ly, L.w, L.h, iy, ix) * L.sf);
+      resX[q] = rx;
+      resY[q] = ry;
+      Ang[q] = get_angle(rx, ry);
+    }
+    __syncthreads();
+    const float two_pi = 2.0f * kPiF;
+    float mag = -1.0f, sumX = 0.0f, sumY = 0.0f;
+    if (lane < n_win) {
+      const float ang1 = win_ang1[lane];
+      const float ang2 = (ang1 + kPiF / 3.0f > two_pi) ? ang1 - 5.0f * kPiF / 3.0f : ang1 + kPiF / 3.0f;
+      for (int q = 0; q < 109; ++q) {
+        const float ang = Ang[q];
+        if (ang1 < ang2 && ang1 < ang && ang < ang2) {
+          sumX += resX[q];
+          sumY += resY[q];
+        } else if (ang2 < ang1 && ((ang > 0 && ang < ang2) || (ang > ang1 && ang < two_pi))) {
+          sumX += resX[q];
+          sumY += resY[q];
         }
-    const int iy = fround_d(yf + (float)(jj * s)), ix = fround_d(xf + (float)(ii * s));
-    const int a = ii < 0 ? -ii : ii, b = jj < 0 ? -jj : jj;  // id[] = |.| mirrored table index
-    const float g = gauss25[7 * a + b];
-    const float rx = g * (at_clamped(L.Lx, L.w, L.h, iy, ix) * L.sf);
-    const float ry = g * (at_clamped(L.Ly, L.w, L.h, iy, ix) * L.sf);
-    resX[q] = rx;
-    resY[q] = ry;
-    Ang[q] = get_angle(rx, ry);
-  }
-  __syncthreads();
-  const float two_pi = 2.0f * kPiF;
-  float mag = -1.0f, sumX = 0.0f, sumY = 0.0f;
-  if (lane < n_win) {
-    const float ang1 = win_ang1[lane];
-    const float ang2 = (ang1 + kPiF / 3.0f > two_pi) ? ang1 - 5.0f * kPiF / 3.0f : ang1 + kPiF / 3.0f;
-    for (int q = 0; q < 109; ++q) {
-      const float ang = Ang[q];
-      if (ang1 < ang2 && ang1 < ang && ang < ang2) {
-        sumX += resX[q];
-        sumY += resY[q];
-      } else if (ang2 < ang1 && ((ang > 0 && ang < ang2) || (ang > ang1 && ang < two_pi))) {
-        sumX += resX[q];
-        sumY += resY[q];
+      }
+      mag = sumX * sumX + sumY * sumY;
+    }
+    // first window (in sweep order) with the strictly largest magnitude; "max" starts at 0, so an all-zero sweep keeps angle 0
+    float best = mag;
+    int best_lane = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off, 64);
+      const int ol = __shfl_xor(best_lane, off, 64);
+      if (ob > best || (ob == best && ol < best_lane)) {
+        best = ob;
+        best_lane = ol;
       }
     }
-    mag = sumX * sumX + sumY * sumY;
-  }
-  // first window (in sweep order) with the strictly largest magnitude; "max" starts at 0, so an all-zero sweep keeps angle 0
-  float best = mag;
-  int best_lane = lane;
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ob = __shfl_xor(best, off, 64);
-    const int ol = __shfl_xor(best_lane, off, 64);
-    if (ob > best || (ob == best && ol < best_lane)) {
-      best = ob;
-      best_lane = ol;
-    }
-  }
-  const float wx = __shfl(sumX, best_lane, 64), wy = __shfl(sumY, best_lane, 64);
-  const float angle = (best > 0.0f) ? get_angle(wx, wy) : 0.0f;
-  if (lane == 0) angle_out[kidx] = angle;
-  // --- M-LDB: 4 + 9 + 16 grid cells, one lane per cell, samples summed in (k, l) order ---
-  float si, co;
-  det_sincosf(angle, &si, &co);
-  const int scale = s;
-  if (lane < 29) {
-    int lvl, cell;
-    if (lane < 4) {
-      lvl = 0;
-      cell = lane;
-    } else if (lane < 13) {
-      lvl = 1;
-      cell = lane - 4;
-    } else {
-      lvl = 2;
-      cell = lane - 13;
-    }
-    const int pattern = 10;
-    const int step = lvl == 0 ? 10 : (lvl == 1 ? 7 : 5);
-    const int per = lvl + 2;               // cells per side
-    const int i0 = -pattern + (cell / per) * step, j0 = -pattern + (cell % per) * step;
-    float di = 0.0f, dx = 0.0f, dy = 0.0f;
-    int ns = 0;
-    for (int kk = i0; kk < i0 + step; ++kk)
-      for (int l = j0; l < j0 + step; ++l) {
-        const float sample_y = yf + ((float)l * co * (float)scale + (float)kk * si * (float)scale);
-        const float sample_x = xf + (-(float)l * si * (float)scale + (float)kk * co * (float)scale);
-        const int y1 = fround_d(sample_y), x1 = fround_d(sample_x);
-        const float ri = at_clamped(L.Lt, L.w, L.h, y1, x1);
-        const float rx = at_clamped(L.Lx, L.w, L.h, y1, x1) * L.sf;
-        const float ry = at_clamped(L.Ly, L.w, L.h, y1, x1) * L.sf;
-        di += ri;
-        const float rry = rx * co + ry * si;
-        const float rrx = -rx * si + ry * co;
-        dx += rrx;
-        dy += rry;
-        ns++;
+    const float wx = __shfl(sumX, best_lane, 64), wy = __shfl(sumY, best_lane, 64);
+    const float angle = (best > 0.0f) ? get_angle(wx, wy) : 0.0f;
+    if (lane == 0) angle_out[kidx] = angle;
+    // --- M-LDB: 4 + 9 + 16 grid cells, one lane per cell, samples summed in (k, l) order ---
+    float si, co;
+    det_sincosf(angle, &si, &co);
+    const int scale = s;
+    if (lane < 29) {
+      int lvl, cell;
+      if (lane < 4) {
+        lvl = 0;
+        cell = lane;
+      } else if (lane < 13) {
+        lvl = 1;
+        cell = lane - 4;
+      } else {
+        lvl = 2;
+        cell = lane - 13;
       }
-    vals[lane * 3 + 0] = di / (float)ns;
-    vals[lane * 3 + 1] = dx / (float)ns;
-    vals[lane * 3 + 2] = dy / (float)ns;
-  }
-  __syncthreads();
-  {
-    uint8_t byte = 0;
-    if (lane < 61) {
-      for (int b = 0; b < 8; ++b) {
-        const int dpos = 8 * lane + b;
-        if (dpos < 486 && vals[pair_tab[2 * dpos]] > vals[pair_tab[2 * dpos + 1]]) byte |= (uint8_t)(1 << b);
-      }
+      const int pattern = 10;
+      const int step = lvl == 0 ? 10 : (lvl == 1 ? 7 : 5);
+      const int per = lvl + 2;               // cells per side
+      const int i0 = -pattern + (cell / per) * step, j0 = -pattern + (cell % per) * step;
+      float di = 0.0f, dx = 0.0f, dy = 0.0f;
+      int ns = 0;
+      for (int kk = i0; kk < i0 + step; ++kk)
+        for (int l = j0; l < j0 + step; ++l) {
+          const float sample_y = yf + ((float)l * co * (float)scale + (float)kk * si * (float)scale);
+          const float sample_x = xf + (-(float)l * si * (float)scale + (float)kk * co * (float)scale);
+          const int y1 = fround_d(sample_y), x1 = fround_d(sample_x);
+          const float ri = at_clamped(L.Lt, L.w, L.h, y1, x1);
+          const float rx = at_clamped(L.Lx, L.w, L.h, y1, x1) * L.sf;
+          const float ry = at_clamped(L.Ly, L.w, L.h, y1, x1) * L.sf;
+          di += ri;
+          const float rry = rx * co + ry * si;
+          const float rrx = -rx * si + ry * co;
+          dx += rrx;
+          dy += rry;
+          ns++;
+        }
+      vals[lane * 3 + 0] = di / (float)ns;
+      vals[lane * 3 + 1] = dx / (float)ns;
+      vals[lane * 3 + 2] = dy / (float)ns;
     }
-    desc[(size_t)kidx * 64 + lane] = byte;  // lanes 61..63 write the zero padding of the .desc row
+    __syncthreads();
+    {
+      uint8_t byte = 0;
+      if (lane < 61) {
+        for (int b = 0; b < 8; ++b) {
+          const int dpos = 8 * lane + b;
+          if (dpos < 486 && vals[pair_tab[2 * dpos]] > vals[pair_tab[2 * dpos + 1]]) byte |= (uint8_t)(1 << b);
+        }
+      }
+      desc[(size_t)kidx * 64 + lane] = byte;  // lanes 61..63 write the zero padding of the .desc row
+    }
   }
+};
+__global__ __launch_bounds__(64) void k_orient_describe(const DevLevels *__restrict__ LVp, const float *__restrict__ kp, int n,
+                                        const float *__restrict__ gauss25,
+                                        const float *__restrict__ win_ang1, int n_win,
+                                        const uint16_t *__restrict__ pair_tab,
+                                        float *__restrict__ angle_out, uint8_t *__restrict__ desc) {
+  OrientDescribeBody::run(LVp, kp, n, gauss25, win_ang1, n_win, pair_tab, angle_out, desc);
 }
 
 }  // namespace
@@ -1109,6 +1119,7 @@ struct Akaze : GangMember {  // (gang.h: `stream` reads as the stream to queue o
   float *d_kcontrast = nullptr;
   float *d_half_steps = nullptr;              // [level][64]: 0.5 * tsteps, for k_octave_resident
   void *d_level_tab = nullptr;                // the LevelTab of this image size (the all-level kernels read it by pointer)
+  void *d_dev_levels = nullptr;               // the DevLevels of this extractor (k_orient_describe reads it by pointer)
   Candidate9 *d_cand = nullptr;
   unsigned int *d_ncand = nullptr;
   unsigned int cand_cap = 1u << 16;
@@ -1338,6 +1349,23 @@ struct HostKpt {
   float patch[9];
 };
 
+// the per-level image pointers and sizes k_orient_describe works on (constant for an extractor: uploaded once)
+DevLevels dev_levels(const Akaze *a) {
+  DevLevels LV;
+  memset(&LV, 0, sizeof(LV));
+  for (int i = 0; i < a->plan.nlev; ++i) {
+    const AkLevel &L = a->plan.lev[i];
+    LV.l[i].Lt = a->d_Lt + L.off;
+    LV.l[i].Lx = a->d_Lx + L.off;
+    LV.l[i].Ly = a->d_Ly + L.off;
+    LV.l[i].w = L.w;
+    LV.l[i].h = L.h;
+    LV.l[i].octave = L.octave;
+    LV.l[i].sf = (float)L.sigma_size;
+  }
+  return LV;
+}
+
 int ensure_kp_cap(Akaze *a, unsigned int n) {
   if (n <= a->kp_cap) return SFMLOC_OK;
   if (a->d_kp) hipFree(a->d_kp);
@@ -1356,29 +1384,20 @@ int ensure_kp_cap(Akaze *a, unsigned int n) {
 // phase 0: upload + kernel + downloads; 1: upload + kernel only; 2: the downloads only (a batch queues every image's kernel
 // before the first download, which blocks the host when the destination is pageable memory)
 int orient_describe_enqueue(Akaze *a, const std::vector<float> &kin, unsigned int n, float *angle_out, uint8_t *desc64,
-                            int phase) {
-  if (n == 0) return SFMLOC_OK;
+                            int phase, unsigned int grid_n = 0 /*workgroups to launch (>= n; a batch launches its largest)*/) {
+  if (n == 0 && grid_n == 0) return SFMLOC_OK;
+  if (grid_n < n) grid_n = n;
   int rc = ensure_kp_cap(a, n);
   if (rc) return rc;
-  DevLevels LV;
-  memset(&LV, 0, sizeof(LV));
-  for (int i = 0; i < a->plan.nlev; ++i) {
-    const AkLevel &L = a->plan.lev[i];
-    LV.l[i].Lt = a->d_Lt + L.off;
-    LV.l[i].Lx = a->d_Lx + L.off;
-    LV.l[i].Ly = a->d_Ly + L.off;
-    LV.l[i].w = L.w;
-    LV.l[i].h = L.h;
-    LV.l[i].octave = L.octave;
-    LV.l[i].sf = (float)L.sigma_size;
-  }
   if (phase != 2) {
-    AK_HIP(hipMemcpyAsync(a->d_kp, kin.data(), (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, a->stream));
-    hipLaunchKernelGGL(k_orient_describe, dim3(n), dim3(64), 0, a->stream, LV, a->d_kp, (int)n, a->d_gauss25, a->d_win,
-                       a->plan.n_win, a->d_pair, a->d_angle, a->d_desc);
+    // (the keypoints go up ahead of anything recorded: nothing recorded for this extractor in the session reads d_kp)
+    if (n) AK_HIP(hipMemcpyAsync(a->d_kp, kin.data(), (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, a->stream.unordered()));
+    sfm_launch<OrientDescribeBody>(a, k_orient_describe, dim3(grid_n), dim3(64), 0,
+                                   reinterpret_cast<const DevLevels *>(a->d_dev_levels), a->d_kp, (int)n, a->d_gauss25, a->d_win,
+                                   a->plan.n_win, a->d_pair, a->d_angle, a->d_desc);
     AK_HIP(hipGetLastError());
   }
-  if (phase != 1) {
+  if (phase != 1 && n) {
     if (angle_out) AK_HIP(hipMemcpyAsync(angle_out, a->d_angle, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, a->stream));
     if (desc64) AK_HIP(hipMemcpyAsync(desc64, a->d_desc, (size_t)n * 64, hipMemcpyDeviceToHost, a->stream));
   }
@@ -1406,7 +1425,7 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   if (a->stream.own) hipStreamSynchronize(a->stream.own);
   gang_member_free(a);
   void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
-                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_level_tab, a->d_cand, a->d_ncand,
+                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_level_tab, a->d_dev_levels, a->d_cand, a->d_ncand,
                   a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -1453,6 +1472,7 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   A((void **)&a->d_kcontrast, 4);
   A((void **)&a->d_half_steps, (size_t)kMaxLevels * 64 * 4);
   A((void **)&a->d_level_tab, sizeof(LevelTab));
+  A((void **)&a->d_dev_levels, sizeof(DevLevels));
   A((void **)&a->d_cand, (size_t)a->cand_cap * sizeof(Candidate9));
   A((void **)&a->d_ncand, 4);
   A((void **)&a->d_gauss25, 49 * 4);
@@ -1467,6 +1487,10 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   if (he == hipSuccess) {
     const LevelTab T = level_tab(a);
     he = hipMemcpy(a->d_level_tab, &T, sizeof(T), hipMemcpyHostToDevice);
+  }
+  if (he == hipSuccess) {
+    const DevLevels LV = dev_levels(a);
+    he = hipMemcpy(a->d_dev_levels, &LV, sizeof(LV), hipMemcpyHostToDevice);
   }
   if (he == hipSuccess) he = hipMemcpy(a->d_gauss25, a->plan.gauss25, 49 * 4, hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipMemcpy(a->d_win, a->plan.win_ang1, 64 * 4, hipMemcpyHostToDevice);
@@ -1782,10 +1806,20 @@ int sfmloc_akaze_detect_and_compute_batch(sfmloc_akaze *const *aks, const uint8_
     n_out[i] = st[i].n;
     SFM_CHECK(st[i].n <= cap, SFMLOC_ECAP, "AKAZE: %u keypoints, caller buffers hold %u", st[i].n, cap);
   }
-  for (int phase = 1; phase <= 2; ++phase)
+  // orientation + M-LDB of every frame in ONE launch (a second session; the launch is as large as the frame with most
+  // keypoints needs, a workgroup beyond a frame's own count leaves at once), then the downloads
+  unsigned int most = 0;
+  for (uint32_t i = 0; i < n; ++i) most = st[i].n > most ? st[i].n : most;
+  if (most) {
+    rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
+    for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i)
+      rc = orient_describe_enqueue(reinterpret_cast<Akaze *>(aks[i]), st[i].kin, st[i].n, nullptr, nullptr, 1, most);
+    const int rc2 = gang_close(first);
+    if (rc == SFMLOC_OK) rc = rc2;
     for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i)
       rc = orient_describe_enqueue(reinterpret_cast<Akaze *>(aks[i]), st[i].kin, st[i].n, st[i].ang.data(),
-                                   descs ? descs[i] : nullptr, phase);
+                                   descs ? descs[i] : nullptr, 2);
+  }
   if (rc) return rc;
   for (uint32_t i = 0; i < n; ++i) SFM_HIP(hipStreamSynchronize(reinterpret_cast<Akaze *>(aks[i])->stream));
   for (uint32_t i = 0; i < n; ++i) detect_outputs(st[i], kpts[i]);
