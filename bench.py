@@ -275,10 +275,11 @@ def main():
     # the chip with 4
     forced = os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1"
     sharded_mode = world > 1 or forced
-    # (the sharded path keeps two slots of contexts: 8 per slot -- with 12 the 24 contexts and the collective's stream no
-    # longer get a hardware queue each and the rate drops by 40 %, profiles/r02_sharded_inflight_sweep.txt)
-    # (images in: a worker thread owns an extractor stream and a context; 4 workers = 8 streams is the measured optimum,
-    # 12 workers -- 24 streams -- run at a third of it, profiles/r02_image_in_sweep.txt)
+    # (the sharded path keeps two slots of contexts; one query per launch: 8 per slot -- with 12 the 24 contexts and the
+    # collective's stream no longer get a hardware queue each and the rate drops by 40 %,
+    # profiles/r02_sharded_inflight_sweep.txt)
+    # (images in: a worker thread is ONE stream -- its extractors and contexts queue on the first context's; 4 workers
+    # are the measured optimum, profiles/r02_image_in_sweep.txt)
     # (N ranks: a rank scans 1/N of the map per query but issues every query's launches, and a device serves few
     # hardware queues well -- 16 queries per launch on 2 streams per slot instead of 8 streams with a query each:
     # tools/rank_emulation.py, profiles/r02_rank_emulation.jsonl)
@@ -288,8 +289,8 @@ def main():
                                                 (((32 if gang > 1 else 8) if sharded_mode else 12) if shortlist else 4))
     if a.threads == 0 and shortlist and nctx >= 8 and not a.from_images and not sharded_mode:
         a.threads = 4
-    # one HW queue per in-flight context (sfmlocalization_amd/_lib.py); the sharded path keeps two slots of contexts
-    # (so does the image-in mode: a context and an extractor stream per worker)
+    # one HW queue per stream that carries work (sfmlocalization_amd/_lib.py): a context each without gangs, a gang's
+    # first context with them (two slots + the two stage-2 groups)
     # (+2: the map's own stream and torch's; measured: 8 contexts on 8 queues lose 20 % to two streams sharing one)
     n_streams = (2 * -(-nctx // gang) + 2) if gang > 1 else (2 * nctx if sharded_mode else nctx)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, n_streams + 2))))
