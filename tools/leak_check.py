@@ -35,11 +35,33 @@ for it in range(60):
         dm.match_one_to_one(qv, np.array([1], np.uint32))
         dm.track(3)
         qv.close()
+        # gang sessions: members without a stream, a merge-only context, a session's events and records
+        from sfmlocalization_amd import capi
+        members = [dm.context(share=ctxs[0]) for _ in range(2)]
+        mo = dm.context(merge_only=True)
+        dq.set_bow(np.random.rand(16).astype(np.float32))
+        with capi.gang([ctxs[0]] + members):
+            for c in [ctxs[0]] + members:
+                c.begin_bow(dq, None, 5)
+        for c in [ctxs[0]] + members:
+            c.end()
+        with capi.gang([ctxs[1], ctxs[2]]):          # members with streams of their own
+            ctxs[1].begin(dq)
+            ctxs[2].begin(dq)
+        ctxs[1].end()
+        ctxs[2].end()
+        mo.close()
+        for c in members:
+            c.close()
         for c in ctxs:
             c.close()
         dq.close()
     ak = S.Akaze(320, 240)
     ak.detect_and_compute(img)
+    ak2 = [S.Akaze(320, 240) for _ in range(3)]
+    S.Akaze.detect_and_compute_batch(ak2, [img, img, img])
+    for e in ak2:
+        e.close()
     ak.close()
     S.dense_gray(bgr, 64)
     with S.Undistorter(np.array([[300.0, 0, 160], [0, 300, 120], [0, 0, 1]]), [-0.2, 0.05, 0, 0], 320, 240) as ud:
