@@ -191,3 +191,30 @@ def test_queries_as_views_into_the_gathered_feature_blocks(gang):
         comp.close()
         for dq in dqs:
             dq.close()
+
+
+@pytest.mark.parametrize("world,images", [(4, ""), (8, "vga")])
+def test_one_rank_of_n_on_this_gpu(world, images):
+    """tools/rank_emulation.py at test size: rank 0 of N through the whole sharded pipeline in gang sessions (the other
+    ranks' halves of the exchanges computed beforehand from their shards) -- its poses are the unsharded path's and every
+    owned query localises; with `images`, the batch's queries are views into the gathered feature blocks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "rank_emulation.py"), "--of", str(world), "--views", "1600",
+           "--desc-per-view", "600", "--nq", "700", "--bow-knn", "40", "--batch", "64", "--queries", "32", "--steps", "2",
+           "--warmup", "1", "--gang", "8", "--in-flight", "16"]
+    if images:
+        cmd += ["--images", images, "--extract-workers", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    n_checked = int(d["same_as_unsharded"].split("/")[1])
+    assert d["same_as_unsharded"] == f"{n_checked}/{n_checked}" and n_checked >= 64 // world
+    own, total = (int(x) for x in d["localised_of_own"].split("/"))
+    assert own == total == 2 * (64 // world) and d["redo"] == 0
+    assert d["queries_per_launch_stage1"] == 8
+    if images:
+        assert d["images_in"]["frames_extracted_per_batch"] == 64 // world
