@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised AKAZE + M-LDB parity campaign: random textures at random sizes (odd widths, tile edges of the fused
 kernels), random thresholds and octave / sub-level counts, GPU against the CPU restatement -- scale space, determinant
-response, keypoints and descriptors bit for bit.  usage: fuzz_akaze.py [n_images] [first_seed]"""
+response, keypoints and descriptors bit for bit.  usage: fuzz_akaze.py [n_images] [first_seed]
+SFMLOC_FUZZ_BATCH=1: every seed is a BATCH of 2..6 textures of one random size taken by
+sfmloc_akaze_detect_and_compute_batch (one launch per kernel for the batch), each frame against the oracle."""
 import os
 import sys
 import time
@@ -41,7 +43,35 @@ def one(seed):
     return len(kp)
 
 
+def one_batch(seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    h = int(rng.integers(64, 420))
+    w = int(rng.integers(64, 560))
+    k = int(rng.integers(2, 7))
+    imgs = [synth.texture_image(seed * 8 + j, h, w, n_blobs=int(rng.integers(20, 400)), n_rects=int(rng.integers(5, 80)))
+            for j in range(k)]
+    exs = [S.Akaze(w, h) for _ in range(k)]
+    try:
+        got = S.Akaze.detect_and_compute_batch(exs, imgs)
+        total = 0
+        for j, (g, e, (kp, desc)) in enumerate(zip(imgs, exs, got)):
+            ekp, edesc, eldet, elt = oracle_c.akaze_detect_and_compute(g, want_levels=True)
+            ldet, lt = e.read_levels()
+            assert np.array_equal(bits32(lt), bits32(elt)), f"scale space (frame {j} of {k})"
+            assert np.array_equal(bits32(ldet), bits32(eldet)), f"determinant response (frame {j} of {k})"
+            assert len(kp) == len(ekp) and np.array_equal(bits32(kp), bits32(ekp)), f"keypoints (frame {j} of {k})"
+            assert np.array_equal(desc[:, :61], edesc), f"descriptors (frame {j} of {k})"
+            total += len(kp)
+    finally:
+        for e in exs:
+            e.close()
+    return total
+
+
 def main():
+    global one
+    if os.environ.get("SFMLOC_FUZZ_BATCH") == "1":
+        one = one_batch
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     oracle_c.build()
