@@ -3,7 +3,7 @@
 // kernel arguments.  The arithmetic of a member is untouched -- a kernel's body is the same device function whether it
 // is launched alone or in a gang -- only the number of launches and of busy streams changes: a rank of an 8-rank run has
 // 1/8 of the scan per query but every query's launches, and a dependent launch costs the more the more hardware queues
-// are busy (Concurrency; 6: a rank of 8 goes from 7.6 k to 14.9 k queries/s).
+// are busy (Concurrency; 6: a rank of 8 goes from 7.5 k to 15.0 k queries/s).
 //
 // How: between sfmloc_gang_begin and sfmloc_gang_end the members' launchers RECORD their launches (sfm_launch,
 // sfmloc_internal.h) instead of issuing them; sfmloc_gang_end (gang_flush, capi.hip) walks the members' lists in step
