@@ -109,6 +109,12 @@ def pmc_traffic(match):
     return d[k]["hbm_bytes_per_dispatch"]["total"], os.path.relpath(PMC_SUMMARY, ROOT)
 
 
+def fingerprint(pose, pq, pl):
+    """capi.result_fingerprint: every bit of a query's result except the stage timings, as 8 bytes."""
+    from sfmlocalization_amd import capi
+    return capi.result_fingerprint(pose, pq, pl)
+
+
 def cpu_baseline(m, queries, seconds):
     """The C oracle's restatement of the whole per-query path on this host's cores (OpenMP), on a bounded
     sample of the full-scan workload: exact 2-NN + ratio on a sample of views (scaled to the full bank: that stage is
@@ -345,6 +351,7 @@ def main():
             dq.set_bow(qb)          # the query's BoW vector is an input: resident before the timed region
     lat = []
     n_ok = [0]
+    fps = []            # (query index, fingerprint) of every query localised since the last clear
     sharded = None
     xchg = {}
     if sharded_mode:
@@ -356,10 +363,13 @@ def main():
     t_begin = [0.0] * nctx
     busy = [False] * nctx
 
+    q_of = [0] * nctx
+
     def finish(k):
-        pose, _, _ = ctxs[k].end()
+        pose, pq, pl = ctxs[k].end()
         lat.append(time.perf_counter() - t_begin[k])
         n_ok[0] += int(pose.ok)
+        fps.append((q_of[k], fingerprint(pose, pq, pl)))
         busy[k] = False
 
     def begin(k, i):
@@ -382,6 +392,7 @@ def main():
             lat.extend([now - t_mark[0]] * len(b))          # a query's latency in batch mode = its batch's wall time
             t_mark = [t_mark[1], now]
             n_ok[0] += sum(int(r["ok"]) for r in res.values())
+            fps.extend((b[j] % len(dqs), r["fingerprint"]) for j, r in res.items())
 
     def run_threads(first, count):
         import threading
@@ -392,24 +403,30 @@ def main():
             mine = list(range(t, nctx, nthr))          # this thread's contexts
             tb = {k: 0.0 for k in mine}
             bz = {k: False for k in mine}
-            lat_l, ok_l = [], 0
+            qi = {k: 0 for k in mine}
+            lat_l, ok_l, fp_l = [], 0, []
+
+            def fin(k):
+                pose, pq, pl = ctxs[k].end()
+                lat_l.append(time.perf_counter() - tb[k])
+                fp_l.append((qi[k], fingerprint(pose, pq, pl)))
+                return int(pose.ok)
+
             for n, i in enumerate(range(first + t, first + count, nthr)):
                 k = mine[n % len(mine)]
                 if bz[k]:
-                    pose, _, _ = ctxs[k].end()
-                    lat_l.append(time.perf_counter() - tb[k])
-                    ok_l += int(pose.ok)
+                    ok_l += fin(k)
                 tb[k] = time.perf_counter()
                 begin(k, i)
+                qi[k] = i % len(dqs)
                 bz[k] = True
             for k in mine:
                 if bz[k]:
-                    pose, _, _ = ctxs[k].end()
-                    lat_l.append(time.perf_counter() - tb[k])
-                    ok_l += int(pose.ok)
+                    ok_l += fin(k)
             with lock:
                 lat.extend(lat_l)
                 n_ok[0] += ok_l
+                fps.extend(fp_l)
 
         ts = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
         for t in ts:
@@ -430,6 +447,7 @@ def main():
                 finish(k)
             t_begin[k] = time.perf_counter()
             begin(k, i)
+            q_of[k] = i % len(dqs)
             busy[k] = True
 
     def drain():
@@ -483,10 +501,12 @@ def main():
                             c.begin_bow(dq, None, a.bow_knn)
                         else:
                             c.begin(dq)
-                oks = [int(c.end()[0].ok) for c in cs[:len(idx)]]
+                ends = [c.end() for c in cs[:len(idx)]]
+                oks = [int(e[0].ok) for e in ends]
                 with lock:
                     lat.extend([time.perf_counter() - t1] * len(idx))
                     n_ok[0] += sum(oks)
+                    fps.extend((i % len(dqs), fingerprint(*e)) for i, e in zip(idx, ends))
                     n_feat[0] = len(feats[0][0])
 
         def run_images(first, count):
@@ -507,12 +527,14 @@ def main():
     if sharded is not None:
         sharded.reset_counters()
     lat.clear()
+    fps.clear()
     n_ok[0] = 0
     fence()
     t0 = time.perf_counter()
     run(0, n_timed)
     fence()
     dt = time.perf_counter() - t0
+    fps_timed = list(fps)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -536,15 +558,35 @@ def main():
     fence()
     st = dev_map.stats()
     # (b) per-query latency proper: one query in flight (with several in flight a query's wall time is mostly queueing)
+    #     and, from the same pass, what every timed query is compared with: each distinct query's result when it is
+    #     alone on the GPU.  A query localised under load must give the same bits (status, P, K, R, t, inlier pairs).
     lat_single = []
+    ref_fp = {}
     if sharded is None:
         dev_map.set_profile(0)
-        for i in range(min(n_timed, 64)):
+        dev_map.sync()
+        for i in range(max(min(n_timed, 64), len(dqs))):
             t1 = time.perf_counter()
             begin(0, i)
-            pose = ctxs[0].end()[0]
+            pose, pq, pl = ctxs[0].end()
             lat_single.append(time.perf_counter() - t1)
+            ref_fp.setdefault(i % len(dqs), fingerprint(pose, pq, pl))
+        # the reference's `times` buckets of one query alone, from HIP events (profile = 1)
+        dev_map.set_profile(1)
+        begin(0, 0)
+        pose = ctxs[0].end()[0]
         stage_seconds = [float(x) for x in pose.stage_seconds]
+        dev_map.set_profile(0)
+    else:
+        for i in range(len(dqs)):     # a batch of one query through the same sharded path, every rank gets the result
+            res = sharded.localize_batch([dqs[i]], gather_results=True, bow_knn=a.bow_knn if shortlist else 0)
+            ref_fp[i] = res[0]["fingerprint"]
+    n_same = sum(1 for i, f in fps_timed if ref_fp.get(i) == f)
+    n_cmp = len(fps_timed)
+    if world > 1:
+        c_t = torch.tensor([n_same, n_cmp], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(c_t)
+        n_same, n_cmp = int(c_t[0].item()), int(c_t[1].item())
     # (c) the roofline kernel: full-bank scan of this rank's bank, one launch in flight
     roof = sweep = None
     rows_rank = r1 - r0
@@ -592,6 +634,7 @@ def main():
                                        "query i on rank i mod N" if world > 1 else "1 GPU, whole bank"),
                        "queries_localised": f"{n_ok_timed}/{n_timed}",
                        "map_generation_s": round(t_gen, 1), **({"DIAGNOSTIC_OVERRIDES_NOT_THE_METRIC": diag} if diag else {})},
+            "identical_to_single_flight": f"{n_same}/{n_cmp}",
             "latency_ms": {"p50": float(np.percentile(lat_single or lat_throughput, 50) * 1e3),
                            "p95": float(np.percentile(lat_single or lat_throughput, 95) * 1e3),
                            "mode": "one query in flight" if lat_single else f"{a.batch}-query batches",

@@ -145,6 +145,24 @@ class gang:
         return False
 
 
+def result_fingerprint(pose, pair_qfeat, pair_landmark, view_counts=True):
+    """Every bit of a query's result -- ok, status, counts, iterations, NFA, error_max, P, K, R, t, centre and the
+    inlier pairs (localization.cpp:504-547: what the result file is written from) -- except the stage timings, as 8
+    bytes.  Two runs of a query agree bit for bit iff their fingerprints do (bench.py `identical_to_single_flight`,
+    tests/test_gpu_load.py).  view_counts=False leaves out n_putative_views / n_geometric_views, which a shard of a
+    sharded map counts for its own views only."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    raw = C.string_at(C.addressof(pose), Pose.stage_seconds.offset)
+    if not view_counts:
+        o = Pose.n_putative_views.offset
+        raw = raw[:o] + raw[o + 8:]
+    h.update(raw)
+    h.update(np.ascontiguousarray(pair_qfeat).tobytes())
+    h.update(np.ascontiguousarray(pair_landmark).tobytes())
+    return h.digest()
+
+
 def feat_round_trip(kpt_xy):
     """sfmloc_feat_round_trip: the keypoints after the reference's `.feat` text round trip (6 significant digits)."""
     k = np.ascontiguousarray(kpt_xy, dtype=np.float32)

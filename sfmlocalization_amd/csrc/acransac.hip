@@ -1252,7 +1252,9 @@ struct P3pShared {
 
 // A round's results go from the workgroup that computed them to the one that replays the round, which may sit on
 // another XCD (another L2): they are written through (agent-scope stores), so that delivering them needs no L2
-// write-back -- only the stores' completion, which the workgroup barrier in front of the counter waits for.
+// write-back -- only the stores' completion: every storing wave runs s_waitcnt vmcnt(0) after its last store and the
+// workgroup's barrier then orders all of those waits in front of the one lane that adds to the counter
+// (p3p_round.body.inc; the barrier alone does not wait on vmcnt).
 template <typename T>
 __device__ __forceinline__ void store_through(T *p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -426,11 +426,11 @@ struct PreHistBody {
     __syncthreads();
     for (int i = threadIdx.x; i < 301; i += blockDim.x)
       if (lh[i]) atomicAdd(&hist[i], lh[i]);
-    __syncthreads();  // this workgroup's atomics are issued ...
-    if (threadIdx.x == 0) {
-      __threadfence();  // ... and performed before it counts itself in
-      ticket = atomicAdd(&hist_all[302], 1u);
-    }
+    // every wave waits for its OWN histogram adds to have been performed (__syncthreads() does not wait on vmcnt on
+    // gfx950); behind the barrier one lane counts the workgroup in (MI355X_MICROARCH.md, hand-over table, producer rule)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(&hist_all[302], 1u);
     __syncthreads();
     if (ticket != gridDim.x * gridDim.y - 1 || threadIdx.x != 0) return;
     __threadfence();

@@ -612,4 +612,10 @@ class HipShardCompute:
 def _pose_tuple(res):
     pose, pq, pl = res
     return {"ok": bool(pose.ok), "n_inliers": int(pose.n_inliers), "R": np.array(pose.R).reshape(3, 3),
-            "center": np.array(pose.center), "P": np.array(pose.P).reshape(3, 4), "pair_qfeat": pq, "pair_landmark": pl}
+            "center": np.array(pose.center), "P": np.array(pose.P).reshape(3, 4), "pair_qfeat": pq, "pair_landmark": pl,
+            "fingerprint": _fingerprint(pose, pq, pl)}
+
+
+def _fingerprint(pose, pq, pl):
+    from . import capi
+    return capi.result_fingerprint(pose, pq, pl, view_counts=False)
