@@ -80,6 +80,17 @@ def parse(argv=None):
                     help="skip the side measurement on M-LDB-like descriptors (its scans run the same kernel on another "
                          "bank: leave it out of a rocprofv3 run whose averages are meant for the 20 M-row scan)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-image-in", action="store_true",
+                    help="skip the image-in leg (frame -> AKAZE + M-LDB -> BoW vector from the image -> shortlist -> path -> "
+                         "pose on a map whose bank was extracted from rendered views)")
+    ap.add_argument("--image-in-only", action="store_true", help="run only the image-in leg (development)")
+    ap.add_argument("--image-tiles", type=int, default=8,
+                    help="image-in leg: the plane is tiles x tiles places of 16 m x 16 m with a texture each")
+    ap.add_argument("--image-views", type=int, default=1000,
+                    help="image-in leg: map views rendered and extracted on the GPU (the rest of --views are padding views "
+                         "of random descriptors)")
+    ap.add_argument("--image-steps", type=int, default=6, help="image-in leg: timed batches of --batch frames")
+    ap.add_argument("--image-workers", type=int, default=4, help="image-in leg: worker threads (one stream each)")
     return ap.parse_args(argv)
 
 
@@ -265,6 +276,249 @@ def real_statistics_phase(S, synth, device):
     return out
 
 
+def oracle_image_chain(world, frame, bow_model, knn):
+    """The whole image-in chain on the host, by the oracle: AKAZE + M-LDB of the frame, the BoW vector of the frame
+    (dense gray -> dense-grid descriptors -> PCA / eigenvalue -> BoF), exact L2 shortlist, then the path on the
+    shortlisted views.  -> dict with kp, desc, bow, shortlist and pipeline.localize's result."""
+    import numpy as np
+    from oracle import oracle_c, pipeline as opipe
+    from sfmlocalization_amd import engine
+    m = world.m
+    kp, desc = oracle_c.akaze_detect_and_compute(frame)[:2]
+    desc64 = np.zeros((len(desc), 64), np.uint8)
+    desc64[:, :desc.shape[1]] = desc
+    pca, bowm = bow_model
+    gray = oracle_c.dense_gray(np.stack([frame, frame, frame], 2), 300)
+    grid = engine.dense_grid_keypoints(300)
+    dd, _ = oracle_c.akaze_compute(gray, grid)
+    bow = oracle_c.bof(dd[:, :61].astype(np.float32), grid[:, :2].copy(), bowm["Centers"], 300, 2, 2,
+                       pca["MeanPCA"], pca["EigenVectorsPCA"], pca["EigenValuesPCA"], int(pca["DimPCA"]))
+    sel = np.sort(oracle_c.bow_select(world.bow, bow.astype(np.float32), knn)).astype(np.uint32)
+    r = opipe.localize(m, desc64, kp[:, :2].copy(), (m.width, m.height), view_sel=sel, ransac_round=25,
+                       threads=max(1, min(16, os.cpu_count() or 1)))
+    return {"kp": kp, "desc": desc64, "bow": bow, "sel": sel, "res": r}
+
+
+def image_in_phase(a, S, local_rank, log):
+    """frame -> AKAZE + M-LDB (K9) -> the frame's BoW vector (A5a dense gray + dense-grid descriptors, A5b PCA, A5c BoF)
+    -> shortlist (A5d) -> Hamming 2-NN + ratio -> F-matrix AC-RANSAC -> 2D-3D -> P3P -> pose, measured live on a map whose
+    bank was EXTRACTED: --image-views views rendered from a textured plane and put through the product's own extraction
+    (every keypoint a landmark), padded with views of random descriptors up to --views, the .bow vector of every real
+    view computed by the same chain.  What is localised is what was extracted from the frame
+    (localization.cpp:323,346-368; DenseLocalFeatureWrapper.cpp:83-183; PcaWrapper.cpp:67-89;
+    BoFSpatialPyramids.cpp:108-302).  Frames are gray VGA images in host memory (PCIe inclusive)."""
+    import tempfile
+    import threading
+    import numpy as np
+    import imageworld as iw
+    from sfmlocalization_amd import capi, engine, fileio
+    t_build = time.perf_counter()
+    W, H, knn = 640, 480, a.bow_knn if a.bow_knn > 0 else 100
+    n_real = min(a.image_views, a.views)
+    rng = np.random.Generator(np.random.PCG64(77))
+    # a BoW model of the reference's shapes, trained on dense features of a few rendered frames (training is offline)
+    import torch
+    tdev = torch.device("cuda", local_rank)
+    atlas0 = iw.make_atlas(901, 1, 1600, tdev)
+    Rs, Cs = iw.cameras(rng, 12, (0.0, 0.0), 16.0)
+    train_imgs = iw.render(atlas0, 100.0, Rs, Cs, 800.0, W, H)
+    del atlas0
+    grid = engine.dense_grid_keypoints(300)
+    ak300 = S.Akaze(300, 300, 4, 4, 0.001, device=local_rank)
+    feats = []
+    for g in train_imgs:
+        gray = capi.dense_gray(np.stack([g, g, g], 2), 300, device=local_rank)
+        feats.append(ak300.compute(gray, grid)[0][:, :61].astype(np.float32))
+    ak300.close()
+    pca, bowm = iw.train_bow_model(np.concatenate(feats)[::3], rng)
+    tmp = tempfile.TemporaryDirectory()
+    bow_file, pca_file = os.path.join(tmp.name, "BOWfile.yml"), os.path.join(tmp.name, "PCAfile.yml")
+    fileio.write_cv_yaml(pca_file, pca)
+    fileio.write_cv_yaml(bow_file, bowm)
+    dense0 = engine.DenseBow(bow_file, pca_file, device=local_rank)
+    world = iw.build(S, 31, n_real, a.queries, tiles=a.image_tiles, device=local_rank, n_pad_views=a.views - n_real,
+                     pad_desc_per_view=a.desc_per_view, dense_bow=dense0, progress=log)
+    m = world.m
+    params = S.default_params(device=local_rank, profile=0, ransac_round=25)
+    dev_map = S.Map(m.view_id, m.view_off, m.desc, params=params, view_wh=m.view_wh, kpt_xy=m.kpt_xy,
+                    row_landmark=m.row_landmark, landmark_id=m.landmark_id, landmark_X=m.landmark_X,
+                    intrinsic=m.intrinsic, bow=world.bow)
+    t_build = time.perf_counter() - t_build
+    log(f"image-in world: {n_real} extracted views ({world.extra['rows_real']} rows) + {a.views - n_real} padding views, "
+        f"{m.n_rows} rows, built in {t_build:.1f} s")
+    frames = [np.ascontiguousarray(f) for f in world.frames]
+    bgrs = [np.ascontiguousarray(np.stack([f, f, f], 2)) for f in frames]
+    nf = len(frames)
+    nw, G = a.image_workers, max(1, min(a.image_batch, capi.GANG_MAX))
+    groups = []
+    for k in range(nw):
+        lead = dev_map.context()
+        cs = [lead] + [dev_map.context(share=lead) for _ in range(G - 1)]
+        es = [S.Akaze(W, H, device=local_rank) for _ in range(G)]
+        for e in es:
+            e.share_stream(lead)
+        groups.append((cs, es, dense0 if k == 0 else engine.DenseBow(bow_file, pca_file, device=local_rank)))
+    stage_t = {"extract(K9)": 0.0, "query_upload": 0.0, "bow_vector(A5a-c)": 0.0, "shortlist+path(A5d..A12)": 0.0}
+    lock = threading.Lock()
+    lat, fps, n_ok, n_feat, err_c = [], [], [0], [0, 0], []
+
+    def localise_frames(k, idx, record=True):
+        cs, es, dense = groups[k]
+        n = len(idx)
+        t0 = time.perf_counter()
+        if n == 1:
+            fe = [es[0].detect_and_compute(frames[idx[0] % nf])]
+        else:
+            fe = S.Akaze.detect_and_compute_batch(es[:n], [frames[i % nf] for i in idx])
+        t1 = time.perf_counter()
+        qs = [dev_map.query(d, kp[:, :2], W, H) for kp, d in fe]
+        t2 = time.perf_counter()
+        for dq, i in zip(qs, idx):
+            dq.set_bow(dense.compute(bgrs[i % nf]).astype(np.float32))
+        t3 = time.perf_counter()
+        with capi.gang(cs[:n]):
+            for c, dq in zip(cs, qs):
+                c.begin_bow(dq, None, knn)
+        ends = [c.end() for c in cs[:n]]
+        t4 = time.perf_counter()
+        for dq in qs:
+            dq.close()
+        if record:
+            with lock:
+                lat.extend([t4 - t0] * n)
+                n_ok[0] += sum(int(e[0].ok) for e in ends)
+                fps.extend((i % nf, fingerprint(*e)) for i, e in zip(idx, ends))
+                n_feat[0] += sum(len(d) for _, d in fe)
+                n_feat[1] += n
+                for key, dt in zip(stage_t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                    stage_t[key] += dt
+                for i, e in zip(idx, ends):
+                    if e[0].ok:
+                        err_c.append(float(np.abs(np.array(e[0].center) - world.frame_C[i % nf]).max()))
+        return fe, ends
+
+    def run(first, count):
+        def worker(k):
+            for i0 in range(first + k * G, first + count, nw * G):
+                localise_frames(k, list(range(i0, min(i0 + G, first + count))))
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(nw)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    run(0, a.batch)                         # warm-up
+    dev_map.sync()
+    with lock:
+        lat.clear(); fps.clear(); err_c.clear()
+        n_ok[0] = 0; n_feat[0] = n_feat[1] = 0
+        for key in stage_t:
+            stage_t[key] = 0.0
+    n_timed = a.image_steps * a.batch
+    t0 = time.perf_counter()
+    run(0, n_timed)
+    dev_map.sync()
+    dt = time.perf_counter() - t0
+    fps_timed, lat_load, n_ok_timed = list(fps), list(lat), n_ok[0]
+    stage_load = {k: v / max(1, n_timed) * 1e3 for k, v in stage_t.items()}
+    feat_mean = n_feat[0] / max(1, n_feat[1])
+    err_timed = list(err_c)
+    # one frame at a time: latency, the stage split of a frame alone, and the results every timed frame is compared with
+    with lock:
+        lat.clear(); fps.clear()
+        for key in stage_t:
+            stage_t[key] = 0.0
+    ref_fp = {}
+    for i in range(nf):
+        _, ends = localise_frames(0, [i])
+        ref_fp[i] = fingerprint(*ends[0])
+    lat_single = list(lat)
+    stage_single = {k: v / nf * 1e3 for k, v in stage_t.items()}
+    # the BoW chain's own split (three synchronous calls and the host glue between them)
+    dense = groups[0][2]
+    bow_split = {"dense_gray(A5a resize+gray+minmax)": 0.0, "dense_descriptors(A5a AKAZE compute, 10000 kpts)": 0.0,
+                 "pca+bof(A5b,A5c)": 0.0}
+    for i in range(min(nf, 32)):
+        t1 = time.perf_counter()
+        gray = capi.dense_gray(bgrs[i], dense.size, device=local_rank)
+        t2 = time.perf_counter()
+        dd, _ = dense.akaze.compute(gray, dense.grid)
+        ff = dd[:, :61].astype(np.float32)
+        t3 = time.perf_counter()
+        dense.bof.compute(ff, dense.grid[:, :2].copy())
+        t4 = time.perf_counter()
+        for key, d in zip(bow_split, (t2 - t1, t3 - t2, t4 - t3)):
+            bow_split[key] += d / min(nf, 32) * 1e3
+    n_same = sum(1 for i, f in fps_timed if ref_fp.get(i) == f)
+    # the path's own stages for a frame alone (HIP-event brackets, the reference's `times` buckets) and what the
+    # frames look like to the path: views with >= 16 putative matches, views that pass the F-matrix filter
+    dev_map.set_profile(1)
+    path_split = {"selectBow": 0.0, "putMatch": 0.0, "geoMatch": 0.0, "PnP": 0.0, "others": 0.0}
+    n_put_v = n_geo_v = n_23 = n_inl = 0
+    n_ps = min(nf, 32)
+    for i in range(n_ps):
+        _, ends = localise_frames(0, [i], record=False)
+        ss = ends[0][0].stage_seconds
+        for key, v in zip(path_split, (ss[1], ss[3], ss[4], ss[5], ss[6])):
+            path_split[key] += v / n_ps * 1e3
+        n_put_v += ends[0][0].n_putative_views
+        n_geo_v += ends[0][0].n_geometric_views
+        n_23 += ends[0][0].n_matches_2d3d
+        n_inl += ends[0][0].n_inliers
+    dev_map.set_profile(0)
+    path_shape = {"views_with_16_or_more_putative_matches": n_put_v / n_ps, "views_passing_the_F_matrix_filter": n_geo_v / n_ps,
+                  "correspondences_2d3d": n_23 / n_ps, "inliers": n_inl / n_ps}
+    # a sample of the frames against the oracle, end to end
+    checked, agree = 0, 0
+    oracle_note = []
+    for i in range(0, nf, max(1, nf // 3))[:3]:
+        fe, ends = localise_frames(0, [i], record=False)
+        o = oracle_image_chain(world, frames[i], (pca, bowm), knn)
+        kp, d = fe[0]
+        pose, pq, pl = ends[0]
+        same = (len(kp) == len(o["kp"]) and np.array_equal(kp.view(np.uint32), o["kp"].astype(np.float32).view(np.uint32))
+                and np.array_equal(d, o["desc"]))
+        same_bow = np.array_equal(dense.compute(bgrs[i]).view(np.uint64), o["bow"].view(np.uint64))
+        same_sel = np.array_equal(np.sort(dev_map.bow_select(o["bow"].astype(np.float32), knn)), o["sel"])
+        r = o["res"]
+        same_pose = bool(pose.ok) == bool(r["ok"]) and (not r["ok"] or (
+            np.array_equal(pq, r["pair_qfeat"]) and np.array_equal(pl, r["pair_landmark"])
+            and np.array_equal(np.array(pose.P).view(np.uint64), np.ascontiguousarray(r["P"]).ravel().view(np.uint64))))
+        checked += 1
+        agree += int(same and same_bow and same_sel and same_pose)
+        oracle_note.append({"frame": i, "features": int(len(kp)), "features_equal": bool(same), "bow_equal": bool(same_bow),
+                            "shortlist_equal": bool(same_sel), "pose_and_inliers_equal": bool(same_pose),
+                            "localised": bool(r["ok"])})
+    out = {
+        "metric": "query images localized/sec, image in", "value": n_timed / dt, "unit": "images/s",
+        "frames_timed": n_timed, "frames_localised": f"{n_ok_timed}/{n_timed}",
+        "identical_to_single_flight": f"{n_same}/{len(fps_timed)}",
+        "oracle_end_to_end": {"frames_checked": checked, "frames_identical": agree, "detail": oracle_note},
+        "workload": f"{W}x{H} gray frames in host memory -> AKAZE + M-LDB (K9) -> BoW vector of the frame (dense gray, "
+                    f"10 000 dense-grid descriptors, PCA-32 / eigenvalue, BoF 5 x 100) -> shortlist of {knn} of {m.n_views} "
+                    f"views -> whole path -> pose; map: {n_real} views rendered from a textured plane and EXTRACTED by K9 "
+                    f"({world.extra['rows_real']} descriptors, one landmark each) + {m.n_views - n_real} padding views of random "
+                    f"descriptors = {m.n_rows} rows; {nw} workers x {G} frames per turn",
+        "features_per_frame": feat_mean,
+        "latency_ms": {"p50": float(np.percentile(lat_single, 50) * 1e3), "p95": float(np.percentile(lat_single, 95) * 1e3),
+                       "mode": "one frame in flight", "p50_at_throughput": float(np.percentile(lat_load, 50) * 1e3)},
+        "stage_ms_one_frame_alone": stage_single, "stage_ms_per_frame_under_load": stage_load,
+        "bow_vector_split_ms": bow_split, "path_stage_ms_one_frame_alone": path_split, "path_shape_per_frame": path_shape,
+        "centre_error_m": {"median": float(np.median(err_timed)) if err_timed else None,
+                           "max": float(np.max(err_timed)) if err_timed else None},
+        "world_build_s": round(t_build, 1),
+    }
+    for cs, es, dense in groups:
+        for e in es:
+            e.close()
+        for c in reversed(cs):
+            c.close()
+        dense.close()
+    dev_map.close()
+    tmp.cleanup()
+    return out
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -322,6 +576,10 @@ def main():
     import sfmlocalization_amd as S
     import synthdata as synth
 
+    if a.image_in_only:
+        out = {"image_in": image_in_phase(a, S, local_rank, lambda msg: print("[bench] " + msg, file=sys.stderr, flush=True))}
+        print(json.dumps(out), flush=True)
+        return
     # every rank builds the same seeded map and keeps its shard of views (contiguous view ranges)
     t_gen = time.perf_counter()
     m = synth.make_map(2, n_views=a.views, desc_per_view=a.desc_per_view)
@@ -705,7 +963,6 @@ def main():
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = (cpu_baseline_shortlist(m, queries, bow, qbow, a.bow_knn, a.cpu_seconds)
                                    if shortlist else cpu_baseline(m, queries, a.cpu_seconds))
-        print(json.dumps(out), flush=True)
     if img_mode is not None:
         for e in img_mode["extractors"]:
             e.close()
@@ -718,6 +975,12 @@ def main():
     for dq in dqs:
         dq.close()
     dev_map.close()
+    if rank == 0:
+        # the image in front of the path, on a map of its own (the headline's map and contexts are gone by now)
+        if world == 1 and not a.no_image_in and not a.from_images and shortlist:
+            del m, queries, bow, qbow
+            out["image_in"] = image_in_phase(a, S, local_rank, lambda msg: print("[bench] " + msg, file=sys.stderr, flush=True))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -833,6 +833,7 @@ class BofModel:
         self._h = h
         self.dim = int(_L().sfmloc_bof_dim(h))
         self.resized = int(resized)
+        self.K = int(centers.shape[0])
 
     @classmethod
     def from_files(cls, bow_file, pca_file=None, in_dim=61, device=0):

@@ -239,6 +239,9 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr, bool merge_only = false) {
   CTX_TRY(dev_alloc(acct, &c->d_hyp_k, (size_t)kP3pBatchMax));
   CTX_TRY(dev_alloc(acct, &c->d_hyp_inl, (size_t)kP3pBatchMax * kP3pMaxN));
   CTX_TRY(dev_alloc(acct, &c->d_inlier_idx, (size_t)kP3pMaxN));
+  // the regrowable P3P set as allocated above (ctx_p3p_reserve replaces it and keeps the accounts)
+  c->p3p_bytes = (uint64_t)kP3pMaxN * (2 * sizeof(double) + 3 * sizeof(int32_t)) + 2 * ((uint64_t)kP3pMaxN + 1) * sizeof(float) +
+                 (uint64_t)kP3pBatchMax * kP3pMaxN * sizeof(int32_t);
   if (m->bow_dim) {
     CTX_TRY(dev_alloc(acct, &c->d_bow_query, (size_t)m->bow_dim));
     CTX_TRY(dev_alloc(acct, &c->d_bow_dist, (size_t)m->n_views));
@@ -525,40 +528,67 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
 }  // namespace
 
 // Grows the P3P workspace of a context to hold `n` correspondences (a query has at most one per feature).  Rare: only a
-// query with more than kP3pMaxN features gets here; the stream is drained first because the arrays are replaced.
+// query with more than kP3pMaxN features gets here.  The new set is allocated first and swapped in only when every
+// allocation has succeeded: on failure the context keeps its old arrays and capacity and the caller gets SFMLOC_ENOMEM
+// (the old code freed first and left null pointers behind a stale p3p_cap).  The stream is drained before
+// the old arrays are freed (kernels of the previous query may still read them); a context that is recording for a gang
+// session never gets here with work recorded -- the reserve is the first thing a query's stage does -- but if it does,
+// reading c->stream issues what was recorded first (gang.h), so stream order is still call order.
+namespace {
+int g_test_fail_alloc = -1;  // test hook (SFMLOC_TEST_FAIL_P3P_ALLOC=k): the k-th allocation of the next reserve fails
+}
 int ctx_p3p_reserve(Ctx *c, uint32_t n) {
   if (n <= c->p3p_cap) return SFMLOC_OK;
   uint32_t cap = c->p3p_cap;
   while (cap < n) cap <<= 1;
-  SFM_HIP(hipStreamSynchronize(c->stream));
-  void *old[] = {c->d_xn, c->d_logc_n, c->d_logc_k, c->d_vec_index, c->d_best_inl, c->d_hyp_inl, c->d_inlier_idx,
-                 c->d_pair_qfeat_big, c->d_pair_landmark_big, c->d_p3p_ws_key, c->d_p3p_ws_idx, c->d_p3p_terms};
-  for (void *p : old)
-    if (p) hipFree(p);
-  c->d_xn = nullptr;
-  c->d_logc_n = c->d_logc_k = nullptr;
-  c->d_vec_index = c->d_best_inl = c->d_hyp_inl = nullptr;
-  c->d_inlier_idx = c->d_pair_qfeat_big = c->d_pair_landmark_big = nullptr;
-  c->d_p3p_ws_key = nullptr;
-  c->d_p3p_ws_idx = nullptr;
-  c->d_p3p_terms = nullptr;
   // hypothesis inlier lists: kP3pBatchMax lists of kP3pMaxN, or (more correspondences) kP3pLargeBatch lists of cap
   const size_t large_batch = 64;  // acransac.hip kP3pLargeBatch
   const size_t hyp = std::max<size_t>((size_t)kP3pBatchMax * kP3pMaxN, large_batch * cap);
-  SFM_HIP(hipMalloc((void **)&c->d_xn, (size_t)cap * 2 * sizeof(double)));
-  SFM_HIP(hipMalloc((void **)&c->d_logc_n, ((size_t)cap + 1) * sizeof(float)));
-  SFM_HIP(hipMalloc((void **)&c->d_logc_k, ((size_t)cap + 1) * sizeof(float)));
-  SFM_HIP(hipMalloc((void **)&c->d_vec_index, (size_t)cap * sizeof(int32_t)));
-  SFM_HIP(hipMalloc((void **)&c->d_best_inl, (size_t)cap * sizeof(int32_t)));
-  SFM_HIP(hipMalloc((void **)&c->d_hyp_inl, hyp * sizeof(int32_t)));
-  SFM_HIP(hipMalloc((void **)&c->d_inlier_idx, (size_t)cap * sizeof(uint32_t)));
-  SFM_HIP(hipMalloc((void **)&c->d_pair_qfeat_big, (size_t)cap * sizeof(uint32_t)));
-  SFM_HIP(hipMalloc((void **)&c->d_pair_landmark_big, (size_t)cap * sizeof(uint32_t)));
-  SFM_HIP(hipMalloc((void **)&c->d_p3p_ws_key, large_batch * cap * sizeof(uint64_t)));
-  SFM_HIP(hipMalloc((void **)&c->d_p3p_ws_idx, large_batch * cap * sizeof(uint32_t)));
-  SFM_HIP(hipMalloc((void **)&c->d_p3p_terms, ((size_t)cap / 2 + 2) * sizeof(double)));
+  const size_t bytes[12] = {(size_t)cap * 2 * sizeof(double),      ((size_t)cap + 1) * sizeof(float),
+                            ((size_t)cap + 1) * sizeof(float),     (size_t)cap * sizeof(int32_t),
+                            (size_t)cap * sizeof(int32_t),         hyp * sizeof(int32_t),
+                            (size_t)cap * sizeof(uint32_t),        (size_t)cap * sizeof(uint32_t),
+                            (size_t)cap * sizeof(uint32_t),        large_batch * cap * sizeof(uint64_t),
+                            large_batch * cap * sizeof(uint32_t),  ((size_t)cap / 2 + 2) * sizeof(double)};
+  const char *e_fail = getenv("SFMLOC_TEST_FAIL_P3P_ALLOC");
+  g_test_fail_alloc = e_fail ? atoi(e_fail) : -1;
+  void *fresh[12] = {nullptr};
+  uint64_t total = 0;
+  for (int i = 0; i < 12; ++i) {
+    hipError_t err = (i == g_test_fail_alloc) ? hipErrorOutOfMemory : hipMalloc(&fresh[i], bytes[i]);
+    if (err != hipSuccess) {
+      if (i != g_test_fail_alloc) (void)hipGetLastError();
+      for (int k = 0; k < i; ++k) (void)hipFree(fresh[k]);
+      set_error("P3P workspace for %u correspondences: allocation %d of 12 (%zu bytes) failed: %s", cap, i, bytes[i],
+                hipGetErrorString(err));
+      return SFMLOC_ENOMEM;
+    }
+    total += bytes[i];
+  }
+  SFM_HIP(hipStreamSynchronize(c->stream));
+  void *old[12] = {c->d_xn,        c->d_logc_n,        c->d_logc_k,           c->d_vec_index,  c->d_best_inl,   c->d_hyp_inl,
+                   c->d_inlier_idx, c->d_pair_qfeat_big, c->d_pair_landmark_big, c->d_p3p_ws_key, c->d_p3p_ws_idx, c->d_p3p_terms};
+  for (void *p : old)
+    if (p) (void)hipFree(p);
+  c->d_xn = (double *)fresh[0];
+  c->d_logc_n = (float *)fresh[1];
+  c->d_logc_k = (float *)fresh[2];
+  c->d_vec_index = (int32_t *)fresh[3];
+  c->d_best_inl = (int32_t *)fresh[4];
+  c->d_hyp_inl = (int32_t *)fresh[5];
+  c->d_inlier_idx = (uint32_t *)fresh[6];
+  c->d_pair_qfeat_big = (uint32_t *)fresh[7];
+  c->d_pair_landmark_big = (uint32_t *)fresh[8];
+  c->d_p3p_ws_key = (uint64_t *)fresh[9];
+  c->d_p3p_ws_idx = (uint32_t *)fresh[10];
+  c->d_p3p_terms = (double *)fresh[11];
   c->d_pair_qfeat = c->d_pair_qfeat_big;  // no longer inside the HostResult record
   c->d_pair_landmark = c->d_pair_landmark_big;
+  // accounting: the regrown set replaces the previous one (the first set was counted by make_ctx through dev_alloc)
+  const uint64_t before = c->p3p_bytes;
+  c->p3p_bytes = total;
+  c->hbm_bytes += total - before;
+  if (c->map) c->map->hbm_bytes += total - before;
   c->p3p_cap = cap;
   return SFMLOC_OK;
 }
@@ -707,6 +737,17 @@ int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *p
 // on the same grid as ONE launch, a head without a partner as a plain launch
 int gang_flush(GangState *g) {
   int rc = SFMLOC_OK;
+  bool oom = false;
+  for (GangMember *m : g->members) oom |= m->gang_oom;
+  if (oom) {  // a chain with a launch missing must not run at all: drop the session's records
+    for (GangMember *m : g->members) {
+      m->gang_recs.clear();
+      m->gang_head = 0;
+      m->gang_oom = false;
+    }
+    set_error("gang session: out of host memory while recording launches; the launches still recorded were dropped");
+    return SFMLOC_ENOMEM;
+  }
   for (;;) {
     // the members advance in step: always the earliest position any member still has to issue, and there every member
     // whose record is the same kernel on the same grid in ONE launch (dynamic LDS: the largest request serves all)
@@ -722,7 +763,8 @@ int gang_flush(GangState *g) {
       if (m->gang_head != pos || pos >= m->gang_recs.size()) continue;
       GangRec *r = &m->gang_recs[pos];
       if (lead && !(r->key == lead->key && r->grid.x == lead->grid.x && r->grid.y == lead->grid.y &&
-                    r->grid.z == lead->grid.z && r->block.x == lead->block.x))
+                    r->grid.z == lead->grid.z && r->block.x == lead->block.x && r->block.y == lead->block.y &&
+                    r->block.z == lead->block.z))
         continue;
       if (!lead) lead = r;
       grp[n++] = r;
@@ -789,7 +831,12 @@ int gang_close(GangMember *lead) {
   if (any_own) {
     SFM_HIP(hipEventRecord(g->done, g->stream));
     for (size_t i = 1; i < g->members.size(); ++i)
-      if (g->members[i]->stream.own != g->stream) SFM_HIP(hipStreamWaitEvent(g->members[i]->stream.own, g->done, 0));
+      if (g->members[i]->stream.own != g->stream) {
+        SFM_HIP(hipStreamWaitEvent(g->members[i]->stream.own, g->done, 0));
+        // the member's stream now carries a dependency on the session's work: a later session under ANOTHER leader
+        // must order itself after it (gang_open records and waits only for dirty members) -- ADVICE r02
+        g->members[i]->stream.dirty = true;
+      }
   }
   return rc;  // (gang_flush has set the message)
 }
@@ -1577,6 +1624,7 @@ int sfmloc_shard_begin_bow(sfmloc_context *ctx, sfmloc_query *query, const void 
   SFM_CHECK(!c->merge_only, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: this context was created for sfmloc_merge_begin only");
   if (part_stride_keys == 0) part_stride_keys = knn;
   SFM_CHECK(part_stride_keys >= knn, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: part_stride_keys < knn");
+  SFM_CHECK(m->bow_dim > 0 && c->d_bow_sel, SFMLOC_EINVAL, "sfmloc_shard_begin_bow: the map has no BoW vectors");
   SFM_HIP(hipSetDevice(m->device));
   ctx_mark_busy(c);  // until sfmloc_context_sync
   ClearedScope cs{c};
@@ -1713,6 +1761,8 @@ static int merge_begin_impl(sfmloc_context *ctx, sfmloc_query *query, const void
   SFM_CHECK(c->in_flight == nullptr, SFMLOC_EINVAL, "sfmloc_merge_begin: context has a query in flight");
   SFM_CHECK(m->focal > 0.0, SFMLOC_EINVAL, "sfmloc_merge_begin: the map has no intrinsic");
   SFM_CHECK(q->n == 0 || q->d_kpt, SFMLOC_EINVAL, "sfmloc_merge_begin: the query was created without keypoints");
+  if (part_stride == 0) part_stride = sfmloc_part_bytes(cap);
+  SFM_CHECK(packed_b || part_stride >= sfmloc_part_bytes(cap), SFMLOC_EINVAL, "sfmloc_merge_begin: part_stride too small");
   SFM_HIP(hipSetDevice(m->device));
   c->t_begin = now_s();
   // (counted like a begun localisation: with other contexts' work queued -- the next batch's stage 1, always, in the
@@ -1728,8 +1778,6 @@ static int merge_begin_impl(sfmloc_context *ctx, sfmloc_query *query, const void
   int rc;
   {
     EventScope ev(c, SFMLOC_K_MATCHSET);
-    if (part_stride == 0) part_stride = sfmloc_part_bytes(cap);
-    SFM_CHECK(packed_b || part_stride >= sfmloc_part_bytes(cap), SFMLOC_EINVAL, "sfmloc_merge_begin: part_stride too small");
     rc = launch_select_candidates(c, q, reinterpret_cast<const unsigned char *>(parts_dev), n_parts, part_stride, cap,
                                   packed_b, packed_qi, /*reset_status=*/true);
   }

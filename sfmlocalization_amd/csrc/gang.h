@@ -115,6 +115,7 @@ struct GangMember {
   CtxStream stream;  // reads as the stream to queue on now (the member's own, or its gang's while recording)
   std::vector<GangRec> gang_recs;  // launches recorded for the gang session in progress
   size_t gang_head = 0;
+  bool gang_oom = false;            // a record could not be stored (host memory): the session's flush returns ENOMEM
   GangState *gang_owned = nullptr;  // this member has led a gang: its state (stream = this member's own)
   hipEvent_t gang_ev = nullptr;     // orders the gang's stream after this member's own earlier work
 };

@@ -223,6 +223,7 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   // more features arrives; beyond kP3pMaxN the pair lists leave HostResult for buffers of their own and the sort of a
   // hypothesis gets a global-memory segment
   uint32_t p3p_cap = kP3pMaxN;
+  uint64_t p3p_bytes = 0;  // bytes of the regrowable P3P arrays currently held (part of hbm_bytes)
   uint32_t *d_pair_qfeat_big = nullptr, *d_pair_landmark_big = nullptr;
   uint64_t *d_p3p_ws_key = nullptr;
   uint32_t *d_p3p_ws_idx = nullptr;
@@ -278,7 +279,12 @@ inline void sfm_launch(GangMember *c, void (*single)(Ts...), dim3 grid, dim3 blo
     hipLaunchKernelGGL(single, grid, block, shmem, (hipStream_t)c->stream, static_cast<Ts>(as)...);
     return;
   }
-  c->gang_recs.emplace_back();
+  try {  // (a record is ~2 KB; no exception may cross the C ABI: the session's end reports it -- gang_flush)
+    c->gang_recs.emplace_back();
+  } catch (const std::bad_alloc &) {
+    c->gang_oom = true;
+    return;
+  }
   GangRec &r = c->gang_recs.back();
   r.key = GangLaunch<Body, Ts...>::key();
   r.cap = GangLaunch<Body, Ts...>::kCap;

@@ -246,7 +246,7 @@ def format_result_json(query_path, sfm_data_path, matches_dir, K=None, R=None, c
     s += '\t"K": ' + _eigen_format(np.asarray(K).reshape(3, 3), "[", "]") + ",\n"
     s += '\t"R": ' + _eigen_format(np.asarray(R).reshape(3, 3), "[", "]") + ",\n"
     s += '\t"t": ' + _eigen_format(np.asarray(center).reshape(3, 1), "", "") + ",\n"
-    s += '\t"pair": [' + ",".join(f"[{int(a)},{int(b)}]" for a, b in (pairs or [])) + "]\n"
+    s += '\t"pair": [' + ",".join(f"[{int(a)},{int(b)}]" for a, b in ([] if pairs is None else pairs)) + "]\n"
     s += "}\n"
     return s
 

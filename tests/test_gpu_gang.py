@@ -120,6 +120,61 @@ def test_profiled_sessions_and_single_members_run_plainly():
             dq.close()
 
 
+def test_consecutive_sessions_under_different_leaders():
+    """Members with streams of their own, no host synchronisation between sessions, the leader changing every time: a
+    member's stream carries a dependency on the previous session's work (gang_close), so the next leader's stream must
+    order itself after it (gang_open) -- the shard stage of dist.py queues batch after batch like this.  The packed
+    parts of every session are the ones the same calls give one context at a time."""
+    import torch
+    m, bow, place_bow = scene(44)
+    dev = torch.device("cuda", 0)
+    with device_map(m, bow) as dm:
+        qs = [synth.make_query(m, 800 + k, n_feat=500 + 150 * k, n_copies=180, outlier_frac=0.3) for k in range(6)]
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in qs]
+        B, budget = 3, 3 * 256
+        nbytes = capi.packed_bytes(B, budget)
+        ctxs = [dm.context() for _ in range(3)]                 # three streams
+        plan = [((0, 1, 2), (0, 1, 2)), ((2, 1, 0), (3, 4, 5)), ((1, 0, 2), (5, 0, 3)), ((2, 0, 1), (1, 2, 4)),
+                ((0, 2), (4, 5))]
+
+        def run(session):
+            parts = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in plan]
+            torch.cuda.synchronize()
+            for part, (order, queries) in zip(parts, plan):
+                cs = [ctxs[k] for k in order]
+                work = list(zip(cs, queries))
+                if session:
+                    with capi.gang(cs):
+                        for slot, (c, qi) in enumerate(work):
+                            c.shard_begin(dqs[qi])
+                            c.shard_export_packed(part.data_ptr(), B, budget, slot)
+                else:
+                    for slot, (c, qi) in enumerate(work):
+                        c.shard_begin(dqs[qi])
+                        c.shard_export_packed(part.data_ptr(), B, budget, slot)
+                        c.sync()
+            for c in ctxs:
+                c.sync()
+            return [p.cpu().numpy() for p in parts]
+
+        def canon(buf):
+            """each query's candidates (where a query's block sits inside the part depends on the order the exports ran
+            in, which differs between the two forms; the candidates themselves do not)"""
+            from sfmlocalization_amd import dist as D
+            return [np.sort(D.unpack_batch(buf, qi).view(np.dtype((np.void, 40))).ravel()).tobytes() for qi in range(B)]
+
+        one = run(False)
+        for _ in range(3):
+            many = run(True)
+            for a, b in zip(one, many):
+                assert canon(a) == canon(b)
+        assert sum(len(x) for x in canon(one[0])) > 50 * 40
+        for c in ctxs:
+            c.close()
+        for dq in dqs:
+            dq.close()
+
+
 @pytest.mark.parametrize("gang", [3, 16])
 def test_sharded_layer_with_gangs_equals_without(gang):
     """dist.HipShardCompute with stage 1 and stage 2 in gang sessions (stream-less members, stage-2 contexts of its own)

@@ -7,6 +7,7 @@ import pytest
 
 import sfmlocalization_amd as S
 import synthdata as synth
+from sfmlocalization_amd import capi
 from oracle import pipeline as opipe
 
 pytestmark = pytest.mark.gpu
@@ -407,6 +408,46 @@ def test_no_size_limits_near_duplicate_of_a_large_frame(oracle_c):
     ctx.close()
     dq.close()
     dqs.close()
+    dm.close()
+
+
+def test_failed_regrowth_of_the_p3p_workspace_leaves_the_context_usable(monkeypatch):
+    """ctx_p3p_reserve allocates the larger set before it lets go of the old one: when an allocation fails (injected:
+    SFMLOC_TEST_FAIL_P3P_ALLOC = index of the allocation that fails) the query gets SFMLOC_ENOMEM, the context keeps its
+    arrays and capacity, an ordinary query on it gives its usual result, the large query succeeds once memory is there,
+    and the map's memory account grows only then."""
+    m = synth.make_map(72, n_views=5, desc_per_view=1500, views_per_place=5, landmarks_per_place=1800, obs_per_view=1400)
+    dm = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, p3p_max_iteration=200),
+               view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+               landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    small = synth.make_query(m, 721, n_feat=700, n_copies=300)
+    big = synth.make_query(m, 722, n_feat=4500, n_copies=1200)      # > kP3pMaxN = 4 096 features: the workspace regrows
+    dqs = dm.query(small.desc, small.kpt_xy, small.width, small.height)
+    dqb = dm.query(big.desc, big.kpt_xy, big.width, big.height)
+    ctx = dm.context()
+    ctx.begin(dqs)
+    ref = ctx.end()
+    assert ref[0].ok
+    bytes_before = dm.info()["hbm_bytes"]
+    for k in (0, 5, 11):
+        monkeypatch.setenv("SFMLOC_TEST_FAIL_P3P_ALLOC", str(k))
+        with pytest.raises(S.SfmlocError) as ei:
+            ctx.begin(dqb)
+        assert ei.value.code == capi.ENOMEM, ei.value
+        assert dm.info()["hbm_bytes"] == bytes_before
+        monkeypatch.delenv("SFMLOC_TEST_FAIL_P3P_ALLOC")
+        ctx.begin(dqs)
+        got = ctx.end()
+        assert capi.result_fingerprint(*got) == capi.result_fingerprint(*ref)
+    ctx.begin(dqb)
+    pb = ctx.end()
+    assert pb[0].ok
+    assert dm.info()["hbm_bytes"] > bytes_before
+    ctx.begin(dqs)
+    assert capi.result_fingerprint(*ctx.end()) == capi.result_fingerprint(*ref)
+    ctx.close()
+    dqs.close()
+    dqb.close()
     dm.close()
 
 
