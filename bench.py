@@ -36,6 +36,18 @@ HBM_COPY_GBS = 6290.0
 # SIMD over-reads the SIMD's rate by ~1.6x -- that is where round 1's "51 T from the stamps" came from.
 VALU_PEAK_TOPS = 41.3
 OPS_PER_PAIR = 35  # 16 xor + 16 bcnt + lshl_or + med3 + min (hamming.hip)
+# Issue rates per instruction class at 8 waves per SIMD on the balanced grid (profiles/r02_valu_rates.jsonl, lane-ops over
+# wall time): VOP2-encoded integer ops (v_xor_b32 58.96 T; v_cmp / v_min issue at that rate) and the VOP3-only ones
+# (v_bcnt_u32_b32 36.70, v_med3_u32 37.16, v_lshl_or_b32 likewise).  A kernel's ceiling is the HARMONIC combination of
+# the two for its own class counts -- time = vop2 / R2 + vop3 / R3 -- so a fraction against it cannot exceed 1
+# (the 1:1 "mix" figure above lost 8 % to alternation and K1 read 1.03 of it).
+VOP2_TOPS, VOP3_TOPS = 58.96, 36.93
+# lane-ops per (bank row, query row) pair by class, from hamming.hip's own accounting (hamming.hip:341-347):
+#   exact head pair (first 64 query rows): 16 xor + min | 16 bcnt + lshl_or + med3
+#   screened pair (10 of 16 dwords):        10 xor + cmp | 10 bcnt
+#   a pair that is finished (counted on the device): + 6 xor + min + 2 | + 6 bcnt + lshl_or + med3
+K1_CLASS_OPS = {"head": (17, 18), "screened": (11, 10), "finished_extra": (9, 8)}
+K1_HEAD_ROWS = 64
 
 # HBM bytes per launch of the roofline kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
 # runs of this command, corrected as MI355X_MICROARCH.md prescribes; tools/run_profile.sh + tools/pmc_summary.py).
@@ -187,7 +199,35 @@ def cpu_baseline_shortlist(m, queries, bow, qbow, knn, seconds):
         ok += int(bool(r["ok"]))
         done += 1
     dt = time.perf_counter() - t0
+    # the two further rows SURVEY 8(d) asks for: the same port on ONE core, and the reference's I/O pattern -- it re-reads
+    # the .bow file of EVERY candidate view (BoFUtils.cpp:33-42) and the .desc file of every shortlisted view
+    # (MatchUtils.cpp:328-332) for every query
+    q = queries[0]
+    d0 = ((bow - qbow[0][None, :]) ** 2).sum(1)
+    sel0 = np.sort(np.argsort(d0, kind="stable")[:knn]).astype(np.uint32)
+    t1 = time.perf_counter()
+    opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=sel0, ransac_round=25, threads=1)
+    t_one = time.perf_counter() - t1 + t_bow / done
+    import tempfile
+    from sfmlocalization_amd import fileio
+    n_io = max(8, min(m.n_views, 200))
+    with tempfile.TemporaryDirectory() as td:
+        for v in range(n_io):
+            fileio.write_mat_bin(os.path.join(td, f"v{v}.bow"), bow[v].astype(np.float64).reshape(-1, 1))
+        for v in sel0[:n_io]:
+            fileio.write_desc(os.path.join(td, f"v{int(v)}.desc"), m.desc[int(m.view_off[v]):int(m.view_off[v + 1])])
+        t1 = time.perf_counter()
+        for v in range(n_io):
+            fileio.read_mat_bin(os.path.join(td, f"v{v}.bow"))
+        t_bow_io = (time.perf_counter() - t1) / n_io * m.n_views
+        t1 = time.perf_counter()
+        for v in sel0[:n_io]:
+            fileio.read_desc(os.path.join(td, f"v{int(v)}.desc"))
+        t_desc_io = (time.perf_counter() - t1) / min(n_io, len(sel0)) * len(sel0)
     return {"value": done / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+            "single_core_value": 1.0 / t_one,
+            "with_per_query_bow_and_desc_reread_value": 1.0 / (dt / done + t_bow_io + t_desc_io),
+            "reread_seconds_per_query": {"bow_files_of_every_view": t_bow_io, "desc_files_of_the_shortlist": t_desc_io},
             "sample": f"{done} whole queries ({queries[0].desc.shape[0]} feats): exact BoW shortlist k={knn} of {m.n_views} "
                       f"views in NumPy ({t_bow / done * 1e3:.1f} ms/query) + the C oracle's path on the shortlisted views "
                       f"(exact 2-NN + ratio, F-matrix AC-RANSAC, 2D-3D set, P3P AC-RANSAC; localised {ok}/{done}); "
@@ -357,8 +397,10 @@ def image_in_phase(a, S, local_rank, log):
         es = [S.Akaze(W, H, device=local_rank) for _ in range(G)]
         for e in es:
             e.share_stream(lead)
-        groups.append((cs, es, dense0 if k == 0 else engine.DenseBow(bow_file, pca_file, device=local_rank)))
-    stage_t = {"extract(K9)": 0.0, "query_upload": 0.0, "bow_vector(A5a-c)": 0.0, "shortlist+path(A5d..A12)": 0.0}
+        ib = S.ImgBow.from_files(bow_file, pca_file, W, H, 1, device=local_rank)   # gray frames: one channel
+        ib.share_stream(lead)
+        groups.append((cs, es, ib))
+    stage_t = {"extract(K9)": 0.0, "query_upload": 0.0, "bow_vector(A5a-c, queued)": 0.0, "shortlist+path(A5d..A12)": 0.0}
     lock = threading.Lock()
     lat, fps, n_ok, n_feat, err_c = [], [], [0], [0, 0], []
 
@@ -374,7 +416,7 @@ def image_in_phase(a, S, local_rank, log):
         qs = [dev_map.query(d, kp[:, :2], W, H) for kp, d in fe]
         t2 = time.perf_counter()
         for dq, i in zip(qs, idx):
-            dq.set_bow(dense.compute(bgrs[i % nf]).astype(np.float32))
+            dense.compute(frames[i % nf], dq)       # queued on the worker's stream, lands in the query's BoW slot
         t3 = time.perf_counter()
         with capi.gang(cs[:n]):
             for c, dq in zip(cs, qs):
@@ -435,7 +477,12 @@ def image_in_phase(a, S, local_rank, log):
     lat_single = list(lat)
     stage_single = {k: v / nf * 1e3 for k, v in stage_t.items()}
     # the BoW chain's own split (three synchronous calls and the host glue between them)
-    dense = groups[0][2]
+    dense = dense0
+    ib0 = groups[0][2]
+    t1 = time.perf_counter()
+    for i in range(min(nf, 32)):
+        ib0.compute(frames[i], None, want_vector=True)
+    bow_resident_ms = (time.perf_counter() - t1) / min(nf, 32) * 1e3
     bow_split = {"dense_gray(A5a resize+gray+minmax)": 0.0, "dense_descriptors(A5a AKAZE compute, 10000 kpts)": 0.0,
                  "pca+bof(A5b,A5c)": 0.0}
     for i in range(min(nf, 32)):
@@ -478,7 +525,7 @@ def image_in_phase(a, S, local_rank, log):
         pose, pq, pl = ends[0]
         same = (len(kp) == len(o["kp"]) and np.array_equal(kp.view(np.uint32), o["kp"].astype(np.float32).view(np.uint32))
                 and np.array_equal(d, o["desc"]))
-        same_bow = np.array_equal(dense.compute(bgrs[i]).view(np.uint64), o["bow"].view(np.uint64))
+        same_bow = np.array_equal(ib0.compute(frames[i], None, want_vector=True).view(np.uint64), o["bow"].view(np.uint64))
         same_sel = np.array_equal(np.sort(dev_map.bow_select(o["bow"].astype(np.float32), knn)), o["sel"])
         r = o["res"]
         same_pose = bool(pose.ok) == bool(r["ok"]) and (not r["ok"] or (
@@ -503,17 +550,20 @@ def image_in_phase(a, S, local_rank, log):
         "latency_ms": {"p50": float(np.percentile(lat_single, 50) * 1e3), "p95": float(np.percentile(lat_single, 95) * 1e3),
                        "mode": "one frame in flight", "p50_at_throughput": float(np.percentile(lat_load, 50) * 1e3)},
         "stage_ms_one_frame_alone": stage_single, "stage_ms_per_frame_under_load": stage_load,
-        "bow_vector_split_ms": bow_split, "path_stage_ms_one_frame_alone": path_split, "path_shape_per_frame": path_shape,
+        "bow_vector_ms": {"resident_chain_alone(sfmloc_imgbow, incl. upload + D2H of the vector)": bow_resident_ms,
+                          "three_staged_calls_alone(dense_gray, akaze_compute, bof_compute)": bow_split},
+        "path_stage_ms_one_frame_alone": path_split, "path_shape_per_frame": path_shape,
         "centre_error_m": {"median": float(np.median(err_timed)) if err_timed else None,
                            "max": float(np.max(err_timed)) if err_timed else None},
         "world_build_s": round(t_build, 1),
     }
-    for cs, es, dense in groups:
+    for cs, es, ib in groups:
+        ib.close()
         for e in es:
             e.close()
         for c in reversed(cs):
             c.close()
-        dense.close()
+    dense0.close()
     dev_map.close()
     tmp.cleanup()
     return out
@@ -915,6 +965,19 @@ def main():
             achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
             valu = lane_ops / (k1_ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic(world == 1 and (a.views, a.desc_per_view, a.nq) == (10000, 2000, 2000))
+            # K1's own ceiling: the harmonic combination of the two issue rates for its class counts
+            n_head = rows_rank * min(K1_HEAD_ROWS, a.nq)
+            n_scr = rows_rank * max(0, a.nq - K1_HEAD_ROWS)
+            n_fin = st_roof.hamming_pairs_finished / max(1, st_roof.launches[0])
+            vop2 = (K1_CLASS_OPS["head"][0] * n_head + K1_CLASS_OPS["screened"][0] * n_scr
+                    + K1_CLASS_OPS["finished_extra"][0] * n_fin)
+            vop3 = (K1_CLASS_OPS["head"][1] * n_head + K1_CLASS_OPS["screened"][1] * n_scr
+                    + K1_CLASS_OPS["finished_extra"][1] * n_fin)
+            floor_ms = (vop2 / (VOP2_TOPS * 1e12) + vop3 / (VOP3_TOPS * 1e12)) * 1e3
+            sq_insts = None
+            if traffic is not None:
+                with open(PMC_SUMMARY) as fh:
+                    sq_insts = json.load(fh).get("k_hamming_screen<8, 10, 1>", {}).get("SQ_INSTS_VALU", {}).get("mean_per_dispatch")
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -928,10 +991,17 @@ def main():
                 "note": "SURVEY F7: at N_q=2000 the kernel is VALU-bound (intensity N_q/2 lane-ops per bank byte against "
                         "a machine balance of ~6): frac against HBM is <1 % whatever the kernel; `valu` is the bound "
                         "that applies, `hbm_bound_regime` the same kernel family where HBM is the bound",
-                "valu": {"achieved": valu, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": valu / VALU_PEAK_TOPS,
-                         "peak_source": "profiles/r02_valu_rates.jsonl (xor+bcnt mix, 8 waves/SIMD, exactly balanced grid, "
-                                        "lane-ops over wall time; K1 also issues cheaper v_cmp / v_xor, so it can read "
-                                        "a little above the pure mix)",
+                "valu": {"achieved": valu, "peak": (vop2 + vop3) / (floor_ms * 1e-3) / 1e12, "unit": "T lane-ops/s",
+                         "frac": floor_ms / k1_ms,
+                         "peak_source": "harmonic combination of the measured issue rates of the kernel's two instruction "
+                                        f"classes (VOP2-rate {VOP2_TOPS} T, VOP3-only {VOP3_TOPS} T lane-ops/s at 8 waves per "
+                                        "SIMD, profiles/r02_valu_rates.jsonl) for ITS class counts: floor = vop2 / R2 + "
+                                        "vop3 / R3; frac = floor time / measured time",
+                         "floor_ms": floor_ms, "vop2_rate_lane_ops_per_launch": vop2, "vop3_only_lane_ops_per_launch": vop3,
+                         "counted_lane_ops_per_launch": lane_ops,
+                         "SQ_INSTS_VALU_x64_per_launch(PMC pass, incl. addressing and loop instructions)":
+                             None if sq_insts is None else sq_insts * 64,
+                         "frac_of_1to1_mix_ceiling_41.3T(round 2's figure)": valu / VALU_PEAK_TOPS,
                          "ops_per_pair_exact": OPS_PER_PAIR, "ops_per_pair_issued": lane_ops / max(1, pairs),
                          "pairs_per_s": pairs / (k1_ms * 1e-3),
                          "pairs_finished_frac": st_roof.hamming_pairs_finished / max(1, st_roof.hamming_pairs),

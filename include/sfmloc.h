@@ -499,6 +499,28 @@ int sfmloc_undistorter_apply(sfmloc_undistorter *u, const uint8_t *src, uint32_t
 int sfmloc_dense_gray(int device, const uint8_t *bgr, uint32_t width, uint32_t height, uint32_t size,
                       uint8_t *gray_out);
 
+/* The query-side BoW vector from the IMAGE as one resident, asynchronous chain: replaces, per
+ * query, DenseLocalFeatureWrapper::calcDenseLocalFeature (BoWCommon/src/DenseLocalFeatureWrapper.cpp:83-183) ->
+ * PcaWrapper::calcPcaProject (VisionLocalizeCommon/src/PcaWrapper.cpp:67-89) -> BoFSpatialPyramids::calcBoF
+ * (BoWCommon/src/BoFSpatialPyramids.cpp:108-302) as localization.cpp:346-361 / LocalizeEngine.cc:205-232 call them.
+ * _create: everything an image of this size needs is allocated once (model = the BOWfile.yml / PCAfile.yml contents as
+ * for sfmloc_bof_create; in_dim must be 61; channels 3 = BGR as imread(IMREAD_COLOR) returns it, 1 = a gray image,
+ * whose colour read has three equal channels).  _compute: image [height x width x channels] in host memory -> the
+ * vector; nothing is allocated, nothing crosses PCIe but the image (and the result when out_bow is given).
+ *   query   non-NULL: the float32 vector (what BoFUtils.cpp:51-54 hands the matcher) is written into the query's
+ *           resident BoW slot, as sfmloc_query_set_bow would, ASYNCHRONOUSLY on the extractor's stream: share that
+ *           stream with the context that will localise the query (sfmloc_imgbow_share_stream) so that
+ *           sfmloc_localize_bow_begin(ctx, query, NULL, knn) is ordered after it, or pass out_bow (which synchronises).
+ *   out_bow non-NULL: the reference's float64 vector [sfmloc_imgbow_dim], after a stream synchronisation.
+ * Same kernels as sfmloc_dense_gray + sfmloc_akaze_compute + sfmloc_bof_compute: the same bits. */
+typedef struct sfmloc_imgbow sfmloc_imgbow;
+int sfmloc_imgbow_create(const sfmloc_bof_desc *model, int device, uint32_t width, uint32_t height, uint32_t channels,
+                         sfmloc_imgbow **out);
+void sfmloc_imgbow_destroy(sfmloc_imgbow *ib);
+int sfmloc_imgbow_dim(const sfmloc_imgbow *ib);
+int sfmloc_imgbow_share_stream(sfmloc_imgbow *ib, sfmloc_context *ctx); /* NULL: back on its own stream */
+int sfmloc_imgbow_compute(sfmloc_imgbow *ib, const uint8_t *image, sfmloc_query *query, double *out_bow);
+
 /* ------------------------------------------------------------------------- */
 /* Map-side matching: the reference's matchAKAZE /         */
 /* trackAKAZE on the same kernels.  Views are addressed by their index in the  */

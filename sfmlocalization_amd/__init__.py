@@ -6,10 +6,10 @@ reference's interface for that path.  There is no CPU fallback.
 """
 from . import _lib  # noqa: F401
 from .capi import (  # noqa: F401
-    SfmlocError, Params, MapDesc, Map, Query, Context, BofModel, Akaze, KernelStats, Pose, default_params, device_count, NOMATCH, debug_math, dense_gray,
+    SfmlocError, Params, MapDesc, Map, Query, Context, BofModel, ImgBow, Akaze, KernelStats, Pose, default_params, device_count, NOMATCH, debug_math, dense_gray,
     Undistorter, image_read, image_decode, image_size,
 )
 
-__all__ = ["SfmlocError", "Params", "MapDesc", "Map", "Query", "Context", "BofModel", "Akaze", "KernelStats", "default_params",
+__all__ = ["SfmlocError", "Params", "MapDesc", "Map", "Query", "Context", "BofModel", "ImgBow", "Akaze", "KernelStats", "default_params",
            "device_count", "NOMATCH", "Pose", "debug_math", "dense_gray", "Undistorter", "image_read", "image_decode",
            "image_size"]

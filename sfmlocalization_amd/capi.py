@@ -121,6 +121,7 @@ SYMBOLS = [
     "sfmloc_geometric_read_pairs", "sfmloc_shard_begin_bow", "sfmloc_packed_bytes", "sfmloc_shard_export_packed", "sfmloc_merge_begin_packed",
     "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing", "sfmloc_context_create_merge",
     "sfmloc_query_create_view", "sfmloc_feat_round_trip",
+    "sfmloc_imgbow_create", "sfmloc_imgbow_destroy", "sfmloc_imgbow_dim", "sfmloc_imgbow_share_stream", "sfmloc_imgbow_compute",
 ]
 
 _bound = False
@@ -275,6 +276,12 @@ def _L():
         L.sfmloc_shard_export_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.sfmloc_merge_begin_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32,
                                                 C.c_uint32, C.c_uint32]
+        L.sfmloc_imgbow_create.argtypes = [C.POINTER(BofDesc), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sfmloc_imgbow_destroy.restype = None
+        L.sfmloc_imgbow_destroy.argtypes = [C.c_void_p]
+        L.sfmloc_imgbow_dim.argtypes = [C.c_void_p]
+        L.sfmloc_imgbow_share_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.sfmloc_imgbow_compute.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_void_p, F64P]
         _bound = True
     return L
 
@@ -809,25 +816,90 @@ class Map:
 NORM_TYPES = {"NONE": 0, "L2": 1, "L1": 2}
 
 
+def _bof_desc(centers, in_dim, resized=300, use_pyramid=True, pyramid_level=2, norm="L1", pca_mean=None,
+              pca_eigvec=None, pca_eigval=None, n_pca=0):
+    """-> (BofDesc, the arrays it points into)"""
+    centers = np.ascontiguousarray(centers, np.float32)
+    d = BofDesc()
+    d.K, d.in_dim = centers.shape[0], int(in_dim)
+    d.centers = _ptr(centers, C.c_float)
+    d.resized_image_size, d.use_spatial_pyramid, d.pyramid_level = int(resized), int(bool(use_pyramid)), int(pyramid_level)
+    d.norm_type = NORM_TYPES[norm] if isinstance(norm, str) else int(norm)
+    keep = [centers]
+    if n_pca:
+        pm = np.ascontiguousarray(pca_mean, np.float32).ravel()
+        pe = np.ascontiguousarray(np.asarray(pca_eigvec, np.float32)[:n_pca])
+        pv = np.ascontiguousarray(np.asarray(pca_eigval, np.float32).ravel()[:n_pca])
+        keep += [pm, pe, pv]
+        d.n_pca, d.pca_mean, d.pca_eigvec, d.pca_eigval = int(n_pca), _ptr(pm, C.c_float), _ptr(pe, C.c_float), _ptr(pv, C.c_float)
+    return d, keep
+
+
+def _bof_desc_from_files(bow_file, pca_file=None, in_dim=61):
+    from . import fileio
+    b = fileio.read_cv_yaml(bow_file)
+    kw = {}
+    if pca_file:
+        p = fileio.read_cv_yaml(pca_file)
+        kw = dict(pca_mean=p["MeanPCA"], pca_eigvec=p["EigenVectorsPCA"], pca_eigval=p["EigenValuesPCA"],
+                  n_pca=int(p["DimPCA"]))
+    return dict(centers=b["Centers"], in_dim=in_dim, resized=int(b["ResizedImageSize"]),
+                use_pyramid=bool(b["UseSpatialPyramid"]), pyramid_level=int(b["PyramidLevel"]),
+                norm=b["NormBofFeatureType"], **kw)
+
+
+class ImgBow:
+    """sfmloc_imgbow: the query-side BoW vector from the image as one resident, asynchronous chain
+    (DenseLocalFeatureWrapper::calcDenseLocalFeature -> PcaWrapper::calcPcaProject -> BoFSpatialPyramids::calcBoF)."""
+
+    def __init__(self, width, height, channels=3, device=0, **model):
+        self._h = None
+        d, keep = _bof_desc(**model)
+        h = C.c_void_p()
+        _check(_L().sfmloc_imgbow_create(C.byref(d), device, int(width), int(height), int(channels), C.byref(h)))
+        self._h = h
+        self.width, self.height, self.channels = int(width), int(height), int(channels)
+        self.dim = int(_L().sfmloc_imgbow_dim(h))
+
+    @classmethod
+    def from_files(cls, bow_file, pca_file, width, height, channels=3, device=0):
+        return cls(width, height, channels, device, **_bof_desc_from_files(bow_file, pca_file))
+
+    def share_stream(self, ctx):
+        _check(_L().sfmloc_imgbow_share_stream(self._h, None if ctx is None else ctx._h))
+
+    def compute(self, image, query=None, want_vector=None):
+        """image [h, w, channels] (or [h, w] for channels = 1) u8.  query: its resident BoW slot is filled
+        (asynchronously: share the stream with the context that localises it).  want_vector (default: when no query is
+        given): also return the float64 vector, which synchronises."""
+        img = np.ascontiguousarray(image, np.uint8)
+        assert img.size == self.width * self.height * self.channels, img.shape
+        want = (query is None) if want_vector is None else want_vector
+        out = np.zeros(self.dim, np.float64) if want else None
+        _check(_L().sfmloc_imgbow_compute(self._h, _ptr(img, C.c_uint8), None if query is None else query._h,
+                                          _ptr(out, C.c_double)))
+        return out
+
+    def close(self):
+        if self._h is not None:
+            _L().sfmloc_imgbow_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BofModel:
     """sfmloc_bof: BOWfile.yml (+ PCAfile.yml) on the GPU; compute() = calcPcaProject + calcBoF."""
 
     def __init__(self, centers, in_dim, resized=300, use_pyramid=True, pyramid_level=2, norm="L1", pca_mean=None,
                  pca_eigvec=None, pca_eigval=None, n_pca=0, device=0):
         self._h = None
-        centers = np.ascontiguousarray(centers, np.float32)
-        d = BofDesc()
-        d.K, d.in_dim = centers.shape[0], int(in_dim)
-        d.centers = _ptr(centers, C.c_float)
-        d.resized_image_size, d.use_spatial_pyramid, d.pyramid_level = int(resized), int(bool(use_pyramid)), int(pyramid_level)
-        d.norm_type = NORM_TYPES[norm] if isinstance(norm, str) else int(norm)
-        keep = [centers]
-        if n_pca:
-            pm = np.ascontiguousarray(pca_mean, np.float32).ravel()
-            pe = np.ascontiguousarray(np.asarray(pca_eigvec, np.float32)[:n_pca])
-            pv = np.ascontiguousarray(np.asarray(pca_eigval, np.float32).ravel()[:n_pca])
-            keep += [pm, pe, pv]
-            d.n_pca, d.pca_mean, d.pca_eigvec, d.pca_eigval = int(n_pca), _ptr(pm, C.c_float), _ptr(pe, C.c_float), _ptr(pv, C.c_float)
+        d, keep = _bof_desc(centers, in_dim, resized, use_pyramid, pyramid_level, norm, pca_mean, pca_eigvec, pca_eigval, n_pca)
+        centers = keep[0]
         h = C.c_void_p()
         _check(_L().sfmloc_bof_create(C.byref(d), device, C.byref(h)))
         self._h = h
@@ -837,15 +909,7 @@ class BofModel:
 
     @classmethod
     def from_files(cls, bow_file, pca_file=None, in_dim=61, device=0):
-        from . import fileio
-        b = fileio.read_cv_yaml(bow_file)
-        kw = {}
-        if pca_file:
-            p = fileio.read_cv_yaml(pca_file)
-            kw = dict(pca_mean=p["MeanPCA"], pca_eigvec=p["EigenVectorsPCA"], pca_eigval=p["EigenValuesPCA"],
-                      n_pca=int(p["DimPCA"]))
-        return cls(b["Centers"], in_dim, resized=int(b["ResizedImageSize"]), use_pyramid=bool(b["UseSpatialPyramid"]),
-                   pyramid_level=int(b["PyramidLevel"]), norm=b["NormBofFeatureType"], device=device, **kw)
+        return cls(device=device, **_bof_desc_from_files(bow_file, pca_file, in_dim))
 
     def compute(self, desc, kpt_xy):
         desc = np.ascontiguousarray(desc, np.float32)

@@ -1260,6 +1260,159 @@ __device__ __forceinline__ void store_through(T *p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The NFA filter.  A model of this round can only matter to the replay if its NFA is below the best NFA the round
+// started from (st.min_nfa = B: the running minimum only goes down), and finding a model's NFA means sorting its n
+// residuals -- 4 us for 256 correspondences in a wave's registers, 100 us for 2 000 in LDS, per model.  Whether a model
+// CAN beat B is decided without sorting: with e_(k) the k-th smallest residual,
+//     NFA(k) = loge0 + (logalpha0 + log10(e_(k) + eps)) (k - s) + logc_n[k] + logc_k[k]  <  B
+//         <=>  e_(k) + eps  <  T_k := 10 ^ ((B - loge0 - logc_n[k] - logc_k[k]) / (k - s) - logalpha0)
+//         <=>  #{ i : e_i + eps < T_k }  >=  k,
+// so a model beats B only if SOME k has at least k residuals below T_k.  With T'_k = max_{j <= k} T_j (monotone, >= T_k:
+// a weaker, still necessary condition) every residual is binned by binary search in the table, the bins are counted and
+// prefix-summed, and the model passes iff some bin's running count reaches the bin's lowest k.  A model that fails
+// reports NFA = +inf (exactly what the replay does with any NFA >= its running minimum: nothing); a model that passes
+// is evaluated exactly as before, so every result the replay acts on has the bits it always had.  The table is
+// computed with a safety margin of 1e-7 in the exponent (the exact test's rounding is ~1e-12), i.e. the filter never
+// rejects a model whose exactly computed NFA is below B.  For n > 1024 the bins are 2 or 4 values of k wide (threshold
+// of the bin's upper end against the bin's lowest k: weaker again, still necessary), which keeps the table at 8 KB.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kP3pFilterBins = 1024;
+struct P3pFilterLds {  // lives in P3pShared::key (32 KB), which is idle until a model is sorted in LDS
+  double T[kP3pFilterBins];            // T' at each bin's upper end
+  uint32_t hist[4][kP3pFilterBins + 4];
+  double wave_max[kThreads / 64];
+  int pass[4];
+};
+static_assert(sizeof(P3pFilterLds) <= sizeof(uint64_t) * kP3pMaxN, "the filter's tables live in the sort's key array");
+
+__device__ __forceinline__ int p3p_filter_shift(int n) { return n <= kP3pFilterBins ? 0 : (n <= 2 * kP3pFilterBins ? 1 : 2); }
+
+// raw thresholds: the maximum of T_k over the k of each bin, bins owned by the calling threads (any subset of the
+// workgroup: thread `t` of `nt` takes bins t, t + nt, ...)
+__device__ __forceinline__ void p3p_filter_raw(P3pFilterLds &F, int n, int s, double B, double logalpha0, double loge0,
+                                               const float *__restrict__ logc_n, const float *__restrict__ logc_k, int t,
+                                               int nt) {
+  const int sh = p3p_filter_shift(n), w = 1 << sh;
+  const int nb = (n >> sh) + 1;
+  for (int j = t; j < nb; j += nt) {
+    double m = 0.0;
+    for (int k = j << sh; k < (j << sh) + w; ++k)
+      if (k > s && k <= n) {
+        const double x = (B - loge0 - (double)logc_n[k] - (double)logc_k[k]) / (double)(k - s) - logalpha0 + 1e-7;
+        const double T = x > 300.0 ? pos_inf() : exp10(x);
+        m = T > m ? T : m;
+      }
+    F.T[j] = m;
+  }
+}
+
+// T' = running maximum over the bins; every thread of the workgroup calls it (two barriers inside)
+__device__ __forceinline__ void p3p_filter_scan(P3pFilterLds &F, int n) {
+  const int sh = p3p_filter_shift(n);
+  const int nb = (n >> sh) + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int per = (kP3pFilterBins + 4 + kThreads - 1) / kThreads;  // bins per thread, contiguous
+  double v[per];
+  double run = 0.0;
+#pragma unroll
+  for (int i = 0; i < per; ++i) {
+    const int j = tid * per + i;
+    const double x = j < nb ? F.T[j] : 0.0;
+    run = x > run ? x : run;
+    v[i] = run;
+  }
+  double inc = run;  // inclusive running maximum across the wave's lanes
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc = o > inc ? o : inc;
+  }
+  double before = __shfl_up(inc, 1, 64);
+  if (lane == 0) before = 0.0;
+  if (lane == 63) F.wave_max[wv] = inc;
+  __syncthreads();
+  for (int q = 0; q < wv; ++q) before = F.wave_max[q] > before ? F.wave_max[q] : before;
+#pragma unroll
+  for (int i = 0; i < per; ++i) {
+    const int j = tid * per + i;
+    if (j < nb) F.T[j] = v[i] > before ? v[i] : before;
+  }
+  __syncthreads();
+}
+
+// one wave, one model: can it beat B?  (every lane returns the verdict)
+__device__ __forceinline__ bool p3p_filter_model(P3pFilterLds &F, int wv, const double (&M)[12], int n, int s,
+                                                 const double *__restrict__ pt3d, const double *__restrict__ xn) {
+  const int lane = threadIdx.x & 63;
+  const int sh = p3p_filter_shift(n);
+  const int nb = (n >> sh) + 1;
+  uint32_t *h = F.hist[wv];
+  for (int j = lane; j < nb; j += 64) h[j] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int steps = 0;
+  while ((1 << steps) < nb + 1) ++steps;
+  // four elements of a lane at a time: their residuals (two f64 divisions each) and their searches (dependent LDS reads)
+  // interleave
+  constexpr int U = 4;
+  for (int p0 = 0; p0 < n; p0 += 64 * U) {
+    double r[U];
+    int lo[U], hi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + 64 * u + lane;
+      const int pc = p < n ? p : n - 1;
+      const double e = err_resection(M, pt3d[3 * pc], pt3d[3 * pc + 1], pt3d[3 * pc + 2], xn[2 * pc], xn[2 * pc + 1]);
+      r[u] = e + (double)FLT_EPSILON;
+      lo[u] = 0;
+      hi[u] = nb;
+    }
+    // first bin whose threshold exceeds r (nb: none); T is non-decreasing
+    for (int it = 0; it < steps; ++it) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int mid = (lo[u] + hi[u]) >> 1;
+        const bool below = mid < nb && r[u] < F.T[mid < nb ? mid : nb - 1];
+        const bool open = lo[u] < hi[u];
+        hi[u] = (open && below) ? mid : hi[u];
+        lo[u] = (open && !below) ? mid + 1 : lo[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (p0 + 64 * u + lane < n && lo[u] < nb) atomicAdd(&h[lo[u]], 1u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // running counts: each lane a contiguous run of bins, then across the lanes
+  constexpr int per = (kP3pFilterBins + 4 + 63) / 64;
+  uint32_t c[per];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < per; ++i) {
+    const int j = lane * per + i;
+    sum += j < nb ? h[j] : 0u;
+    c[i] = sum;
+  }
+  uint32_t inc = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  const uint32_t before = inc - sum;
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < per; ++i) {
+    const int j = lane * per + i;
+    const int k_lo = (j << sh) > s + 1 ? (j << sh) : s + 1;          // lowest k of the bin that NFA ranges over
+    const int k_hi = (j << sh) + (1 << sh) - 1;
+    if (j < nb && k_hi > s && k_lo <= n && before + c[i] >= (uint32_t)k_lo) any = true;
+  }
+  return __ballot(any) != 0ull;
+}
+
 // one hypothesis: sample, solve, evaluate the (up to 4) models, leave the best one's NFA / inliers / model in the
 // round's result arrays.  Executed by one workgroup of k_p3p_round.
 __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch, unsigned char *smem_raw) {
@@ -1282,6 +1435,15 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   constexpr int s = 3;
   const int P = next_pow2(n);
   const bool fast = P <= kP3pWaveSeg;
+  const double logalpha0 = det_log10(3.14159265358979323846);
+  const double loge0 = det_log10(4.0 * (double)(n - s));
+  // the NFA filter (above): only once a model exists, only while its tables fit the idle part of the LDS
+  const double nfa_to_beat = st.min_nfa;
+  // (from 257 correspondences on: below that a model's register sort costs about what the filter does)
+  const bool filter = A.nfa_filter && nfa_to_beat < pos_inf() && n <= kP3pMaxN && P >= A.nfa_filter_min_p;
+  P3pFilterLds &F = *reinterpret_cast<P3pFilterLds *>(S.key);
+  if (filter && tid >= 64)  // (wave 0 is busy: its lane 0 solves the P3P below)
+    p3p_filter_raw(F, n, s, nfa_to_beat, logalpha0, loge0, A.logc_n, A.logc_k, tid - 64, kThreads - 64);
   if (tid == 0) {
     int32_t smp[3];
     ac_sample<3>(st.identity ? nullptr : A.vec_index, st.n_index, A.seed, STAGE_P3P, A.stream, (uint32_t)it, smp);
@@ -1300,10 +1462,33 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   STAMP_P3P(stamp_round, b, 2);
   const int nm = S.nm;
   if (tid < nm) p3p_kneip_model(S.prep, tid, S.models + 12 * tid);  // the four roots' models side by side
-  __syncthreads();
+  if (filter) p3p_filter_scan(F, n);  // (two barriers inside: the models are visible behind them too)
+  else __syncthreads();
   STAMP_P3P(stamp_round, b, 3);
-  const double logalpha0 = det_log10(3.14159265358979323846);
-  const double loge0 = det_log10(4.0 * (double)(n - s));
+  if (!fast) {
+    STAMP_P3P(stamp_round, b, 6);   // (the register path stamps 6 / 7 around its sort)
+  }
+  bool pass_mine = true;   // fast path: this wave's model; LDS path: read from F.pass
+  if (filter) {
+    const int wv = tid >> 6;
+    if (wv < nm) {
+      double M[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) M[q] = S.models[12 * wv + q];
+      pass_mine = p3p_filter_model(F, wv, M, n, s, A.pt3d, A.xn);
+    }
+    if ((tid & 63) == 0) F.pass[wv] = (wv < nm && pass_mine) ? 1 : 0;
+    __syncthreads();
+  }
+  int pass_mask = 0xF;
+  if (filter) {
+    pass_mask = 0;
+    for (int k = 0; k < 4; ++k) pass_mask |= F.pass[k] << k;
+    __syncthreads();  // F (in S.key) is dead from here on: the LDS sort may overwrite it
+  }
+  if (!fast) {
+    STAMP_P3P(stamp_round, b, 7);   // LDS path: 3 -> 6 = table scan, 6 -> 7 = the filter, 7 -> 4 = the models that passed
+  }
   double best = pos_inf();
   int best_k = 0, best_m = -1;
   double best_err = pos_inf();
@@ -1314,7 +1499,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     uint32_t *iw = S.idx + (size_t)wv * kP3pWaveSeg;
     NfaBest r{pos_inf(), 0x7FFFFFFF};
     double r_err = pos_inf();
-    if (wv < nm) {
+    if (wv < nm && ((pass_mask >> wv) & 1)) {
       double M[12];
 #pragma unroll
       for (int q = 0; q < 12; ++q) M[q] = S.models[12 * wv + q];
@@ -1378,6 +1563,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     }
   } else
   for (int k = 0; k < nm; ++k) {
+    if (!((pass_mask >> k) & 1)) continue;  // (uniform over the workgroup)
     double M[12];
     for (int q = 0; q < 12; ++q) M[q] = S.models[12 * k + q];
     __syncthreads();
@@ -1400,6 +1586,9 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
       int32_t *dst = A.hyp_inl + (size_t)b * inl_stride;
       for (int p = tid; p < best_k; p += kThreads) store_through(dst + p, (int32_t)sidx[p]);
     }
+  }
+  if (!fast) {
+    STAMP_P3P(stamp_round, b, 4);
   }
   if (tid == 0) {
     store_through(A.hyp_nfa + b, best);
@@ -2268,6 +2457,10 @@ static P3pArgs make_p3p_args(Ctx *c) {
     const char *e = getenv("SFMLOC_P3P_ADAPTIVE");
     return e ? atoi(e) : -1;
   }();
+  static const int env_filter = [] { const char *e = getenv("SFMLOC_P3P_FILTER"); return e ? atoi(e) : 1; }();
+  A.nfa_filter = env_filter;  // (0: every model is sorted, as before round 3 -- comparison runs and tests)
+  static const int env_filter_p = [] { const char *e = getenv("SFMLOC_P3P_FILTER_MIN_P"); return e ? atoi(e) : 512; }();
+  A.nfa_filter_min_p = env_filter_p;
   A.adaptive_batch = env_adaptive >= 0 ? env_adaptive : (c->k1_may_slice ? 0 : 1);
   static const int env_quarters = [] { const char *e = getenv("SFMLOC_P3P_ADAPT_QUARTERS"); return e ? atoi(e) : 12; }();
   static const int env_floor = [] { const char *e = getenv("SFMLOC_P3P_ADAPT_FLOOR"); return e ? atoi(e) : 64; }();

@@ -1183,12 +1183,12 @@ LevelTab level_tab(const Akaze *a) {
 }
 
 // Create_Nonlinear_Scale_Space + Compute_Multiscale_Derivatives + Compute_Determinant_Hessian_Response
-int build_scale_space(Akaze *a, const uint8_t *gray) {
+int build_scale_space(Akaze *a, const uint8_t *gray /*host; null: the image is already in d_gray, written on a->stream*/) {
   const AkPlan &P = a->plan;
   const int w = a->w, h = a->h;
   const size_t n0 = (size_t)w * h;
   // (nothing recorded for this image touches d_gray before the upload: it need not wait for a gang session's launches)
-  AK_HIP(hipMemcpyAsync(a->d_gray, gray, n0, hipMemcpyHostToDevice, a->stream.unordered()));
+  if (gray) AK_HIP(hipMemcpyAsync(a->d_gray, gray, n0, hipMemcpyHostToDevice, a->stream.unordered()));
 #define s ((hipStream_t)a->stream) /* the few launches below that have no gang form (comparison paths) */
   int rc = SFMLOC_OK;
   static const bool kFusedPre = [] {  // SFMLOC_AKAZE_FUSED_PRE=0: the thirteen separate launches (comparison runs)
@@ -1412,6 +1412,23 @@ int orient_describe(Akaze *a, const std::vector<float> &kin, unsigned int n, flo
 }
 
 }  // namespace
+
+// for callers inside the library (imgbow.hip): see sfmloc_internal.h
+uint8_t *akaze_gray_dev(Akaze *a) { return a->d_gray; }
+uint8_t *akaze_desc_dev(Akaze *a) { return a->d_desc; }
+hipStream_t akaze_stream_now(Akaze *a) { return a->stream; }
+int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n) {
+  int rc = ensure_kp_cap(a, n);  // (before anything is queued: it may free and allocate)
+  if (rc) return rc;
+  rc = build_scale_space(a, nullptr);
+  if (rc || n == 0) return rc;
+  sfm_launch<OrientDescribeBody>(a, k_orient_describe, dim3(n), dim3(64), 0,
+                                 reinterpret_cast<const DevLevels *>(a->d_dev_levels), d_kin, (int)n, a->d_gauss25, a->d_win,
+                                 a->plan.n_win, a->d_pair, a->d_angle, a->d_desc);
+  AK_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
 }  // namespace sfmloc
 
 using namespace sfmloc;

@@ -255,10 +255,19 @@ __global__ __launch_bounds__(256) void k_bof_assign(const float *__restrict__ de
                                                     const float *__restrict__ pca_evec,
                                                     const float *__restrict__ pca_eval, int n_pca,
                                                     const float *__restrict__ centers, int K, int resized, int levels,
-                                                    uint32_t *__restrict__ counts) {
+                                                    uint32_t *__restrict__ counts,
+                                                    const uint8_t *__restrict__ desc8 /*or null: rows of 64 bytes*/) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  const float *x = desc + (size_t)r * in_dim;
+  // the descriptor as floats: given so, or the bytes of a .desc row converted (convertTo(CV_32FC1),
+  // DenseLocalFeatureWrapper.cpp:176-181: byte values 0..255 as floats)
+  float xin[128];
+  if (desc8) {
+    for (int i = 0; i < in_dim; ++i) xin[i] = (float)desc8[(size_t)r * 64 + i];
+  } else {
+    for (int i = 0; i < in_dim; ++i) xin[i] = desc[(size_t)r * in_dim + i];
+  }
+  const float *x = xin;
   const int cdim = n_pca > 0 ? n_pca : in_dim;
   float y[128];
   if (n_pca > 0) {
@@ -394,12 +403,12 @@ int launch_bow_merge_select(Ctx *c, const unsigned long long *d_keys, uint32_t n
 }
 
 int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const float *d_kxy, int n, uint32_t *d_counts,
-               double *d_out, float *d_out_f32) {
+               double *d_out, float *d_out_f32, const uint8_t *d_desc8) {
   const int cells = b->cells;
   SFM_HIP(hipMemsetAsync(d_counts, 0, (size_t)b->K * cells * sizeof(uint32_t), s));
   if (n > 0) {
     hipLaunchKernelGGL(k_bof_assign, dim3((n + 255) / 256), dim3(256), 0, s, d_desc, d_kxy, n, b->in_dim, b->d_pca_mean,
-                       b->d_pca_evec, b->d_pca_eval, b->n_pca, b->d_centers, b->K, b->resized, b->levels, d_counts);
+                       b->d_pca_evec, b->d_pca_eval, b->n_pca, b->d_centers, b->K, b->resized, b->levels, d_counts, d_desc8);
     SFM_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_bof_finish, dim3(1), dim3(64), 0, s, d_counts, n > 0 ? n : 1, b->K, cells, b->norm_type, d_out,

@@ -570,9 +570,12 @@ int main(int argc, char **argv) {
       }
       sfmloc_query *q = nullptr;
       if (sfmloc_query_create(map, desc.data(), xy.data(), nq, (uint32_t)w, (uint32_t)h, &q)) {
-        fprintf(stderr, "%s\n", sfmloc_last_error());
+        // as for any error on ONE image: this image gets the failure form, the run goes on (the reference writes a
+        // result file for every image, localization.cpp:441,530)
+        fprintf(stderr, "%s: %s\n", img.c_str(), sfmloc_last_error());
         rc_all = 1;
-        break;
+        write_result_json(out_dir, img, sfm_json, match_dir, nullptr, nullptr, nullptr);
+        continue;
       }
       // with a BoW vector: shortlist (when more than knn views remain, localization.cpp:346) + path in one call, the
       // shortlist staying on the device

@@ -95,6 +95,8 @@ struct P3pArgs {
   double *ws_terms;  // [max_n / 2 + 1]
   double focal, ppx, ppy;
   int max_iteration, min_resection_points, min_inliers, max_n, refine_pose;
+  int nfa_filter;      // 1 = models that cannot beat the round's starting NFA are not sorted (acransac.hip, "The NFA filter")
+  int nfa_filter_min_p;  // ... for next_pow2(n) >= this
   int adaptive_batch;  // other queries share the GPU: trade rounds for fewer speculative hypotheses
   int adapt_quarters, adapt_floor;  // next batch = max(floor, quarters/4 * iterations since the switch)
   uint64_t seed;
@@ -341,8 +343,31 @@ int launch_bow_keys(Ctx *c, const float *d_query, uint32_t k, uint32_t *d_dist_b
 int launch_bow_merge_select(Ctx *c, const unsigned long long *d_keys, uint32_t n_parts,
                             uint64_t part_stride_keys, uint32_t k, uint32_t n_pad, uint32_t *d_sel_out,
                             const ChainArgs *chain = nullptr);
+// d_desc8 non-null: the descriptors are rows of 64 bytes (a .desc row, the first in_dim bytes used) instead of floats
 int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const float *d_kxy, int n, uint32_t *d_counts,
-               double *d_out, float *d_out_f32);
+               double *d_out, float *d_out_f32, const uint8_t *d_desc8 = nullptr);
+
+// dense.hip: the resize + gray + min-max front end with its tables resident (sfmloc_imgbow; sfmloc_dense_gray builds a
+// temporary one).  src: h x w x channels (3 = BGR, 1 = gray: a colour read of a gray file has three equal channels,
+// for which BGR2GRAY is the identity, so one channel is resized).
+struct DenseGrayPlan {
+  int w = 0, h = 0, channels = 3, size = 300;
+  int *d_xo = nullptr, *d_yo = nullptr;
+  short *d_xa = nullptr, *d_ya = nullptr;
+  unsigned int *d_mm = nullptr;
+};
+int dense_gray_plan_create(DenseGrayPlan *p, int w, int h, int channels, int size);
+void dense_gray_plan_destroy(DenseGrayPlan *p);
+int dense_gray_enqueue(const DenseGrayPlan *p, hipStream_t s, const uint8_t *d_src, uint8_t *d_gray_out);
+
+// akaze.hip: an extractor's device-resident pieces, for callers inside the library (imgbow.hip)
+struct Akaze;
+uint8_t *akaze_gray_dev(Akaze *a);           // [h*w] the image build_scale_space works on
+uint8_t *akaze_desc_dev(Akaze *a);           // [n x 64] descriptors of the last describe
+hipStream_t akaze_stream_now(Akaze *a);      // the stream its work is queued on (its own or a context's)
+// scale space of the image ALREADY in akaze_gray_dev (written on akaze_stream_now) + orientation and M-LDB at the
+// device-resident keypoints d_kin [n x 4] (x, y, size, class_id); asynchronous
+int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n);
 
 // acransac.hip
 int launch_fill_log10(double *d_L10, int n, hipStream_t s);

@@ -22,6 +22,7 @@ def test_cpu_baseline_legs_report_the_contract_fields():
     qbow = [(proto[q.place] + rng.normal(0, 0.05, 500)).astype(np.float32) for q in queries]
     cs = bench.cpu_baseline_shortlist(m, queries, bow, qbow, 10, 1.0)
     assert cs["unit"] == "queries/s" and cs["value"] > 0 and "shortlist k=10" in cs["sample"]
+    assert cs["single_core_value"] > 0 and 0 < cs["with_per_query_bow_and_desc_reread_value"] <= cs["value"]
 
 
 def test_committed_evidence_parses():
