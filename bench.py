@@ -397,26 +397,37 @@ def image_in_phase(a, S, local_rank, log):
         es = [S.Akaze(W, H, device=local_rank) for _ in range(G)]
         for e in es:
             e.share_stream(lead)
-        ib = S.ImgBow.from_files(bow_file, pca_file, W, H, 1, device=local_rank)   # gray frames: one channel
-        ib.share_stream(lead)
-        groups.append((cs, es, ib))
-    stage_t = {"extract(K9)": 0.0, "query_upload": 0.0, "bow_vector(A5a-c, queued)": 0.0, "shortlist+path(A5d..A12)": 0.0}
+        ibs = [S.ImgBow.from_files(bow_file, pca_file, W, H, 1, device=local_rank) for _ in range(G)]  # gray: one channel
+        for ib in ibs:
+            ib.share_stream(lead)
+        groups.append((cs, es, ibs))
+    stage_t = {"extract(K9, incl. the count's synchronisation)": 0.0, "bow_vector(A5a-c, queued)": 0.0, "query_view": 0.0,
+               "shortlist+path(A5d..A12, incl. waiting for the BoW chain)": 0.0}
     lock = threading.Lock()
     lat, fps, n_ok, n_feat, err_c = [], [], [0], [0, 0], []
 
-    def localise_frames(k, idx, record=True):
-        cs, es, dense = groups[k]
+    def localise_frames(k, idx, record=True, staged=False):
+        cs, es, ibs = groups[k]
         n = len(idx)
         t0 = time.perf_counter()
-        if n == 1:
-            fe = [es[0].detect_and_compute(frames[idx[0] % nf])]
-        else:
-            fe = S.Akaze.detect_and_compute_batch(es[:n], [frames[i % nf] for i in idx])
-        t1 = time.perf_counter()
-        qs = [dev_map.query(d, kp[:, :2], W, H) for kp, d in fe]
-        t2 = time.perf_counter()
-        for dq, i in zip(qs, idx):
-            dense.compute(frames[i % nf], dq)       # queued on the worker's stream, lands in the query's BoW slot
+        if staged:      # everything through the host: features downloaded, query uploaded (round 2's route)
+            if n == 1:
+                fe = [es[0].detect_and_compute(frames[idx[0] % nf])]
+            else:
+                fe = S.Akaze.detect_and_compute_batch(es[:n], [frames[i % nf] for i in idx])
+            t1 = time.perf_counter()
+            qs = [dev_map.query(d, kp[:, :2], W, H) for kp, d in fe]
+            t2 = time.perf_counter()
+            for dq, i, ib in zip(qs, idx, ibs):
+                ib.compute(frames[i % nf], dq)      # queued on the worker's stream, lands in the query's BoW slot
+        else:           # resident: features and BoW vector stay on the device, the query is a view over them
+            ns = S.Akaze.detect_resident_batch(es[:n], [frames[i % nf] for i in idx])
+            fe = [(None, range(c)) for c in ns]
+            t1 = time.perf_counter()
+            for i, ib in zip(idx, ibs):
+                ib.compute(frames[i % nf], None, want_vector=False)
+            t2 = time.perf_counter()
+            qs = [e.query_view(dev_map, c, ib.vector_dev()) for e, c, ib in zip(es, ns, ibs)]
         t3 = time.perf_counter()
         with capi.gang(cs[:n]):
             for c, dq in zip(cs, qs):
@@ -430,7 +441,7 @@ def image_in_phase(a, S, local_rank, log):
                 lat.extend([t4 - t0] * n)
                 n_ok[0] += sum(int(e[0].ok) for e in ends)
                 fps.extend((i % nf, fingerprint(*e)) for i, e in zip(idx, ends))
-                n_feat[0] += sum(len(d) for _, d in fe)
+                n_feat[0] += sum(len(d) for _, d in fe)     # (resident route: d is range(count))
                 n_feat[1] += n
                 for key, dt in zip(stage_t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                     stage_t[key] += dt
@@ -478,7 +489,7 @@ def image_in_phase(a, S, local_rank, log):
     stage_single = {k: v / nf * 1e3 for k, v in stage_t.items()}
     # the BoW chain's own split (three synchronous calls and the host glue between them)
     dense = dense0
-    ib0 = groups[0][2]
+    ib0 = groups[0][2][0]
     t1 = time.perf_counter()
     for i in range(min(nf, 32)):
         ib0.compute(frames[i], None, want_vector=True)
@@ -519,7 +530,9 @@ def image_in_phase(a, S, local_rank, log):
     checked, agree = 0, 0
     oracle_note = []
     for i in range(0, nf, max(1, nf // 3))[:3]:
-        fe, ends = localise_frames(0, [i], record=False)
+        fe, ends = localise_frames(0, [i], record=False, staged=True)
+        if capi.result_fingerprint(*ends[0]) != ref_fp[i]:
+            raise SystemExit(f"image-in: frame {i}: the staged route and the resident route give different results")
         o = oracle_image_chain(world, frames[i], (pca, bowm), knn)
         kp, d = fe[0]
         pose, pq, pl = ends[0]
@@ -541,7 +554,8 @@ def image_in_phase(a, S, local_rank, log):
         "frames_timed": n_timed, "frames_localised": f"{n_ok_timed}/{n_timed}",
         "identical_to_single_flight": f"{n_same}/{len(fps_timed)}",
         "oracle_end_to_end": {"frames_checked": checked, "frames_identical": agree, "detail": oracle_note},
-        "workload": f"{W}x{H} gray frames in host memory -> AKAZE + M-LDB (K9) -> BoW vector of the frame (dense gray, "
+        "workload": f"{W}x{H} gray frames in host memory -> AKAZE + M-LDB (K9, outputs resident: only the keypoint count is read "
+                    f"back) -> BoW vector of the frame (sfmloc_imgbow: dense gray, "
                     f"10 000 dense-grid descriptors, PCA-32 / eigenvalue, BoF 5 x 100) -> shortlist of {knn} of {m.n_views} "
                     f"views -> whole path -> pose; map: {n_real} views rendered from a textured plane and EXTRACTED by K9 "
                     f"({world.extra['rows_real']} descriptors, one landmark each) + {m.n_views - n_real} padding views of random "
@@ -557,8 +571,9 @@ def image_in_phase(a, S, local_rank, log):
                            "max": float(np.max(err_timed)) if err_timed else None},
         "world_build_s": round(t_build, 1),
     }
-    for cs, es, ib in groups:
-        ib.close()
+    for cs, es, ibs in groups:
+        for ib in ibs:
+            ib.close()
         for e in es:
             e.close()
         for c in reversed(cs):

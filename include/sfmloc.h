@@ -454,6 +454,17 @@ int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float
 int sfmloc_akaze_detect_and_compute_batch(sfmloc_akaze *const *aks, const uint8_t *const *grays, uint32_t n,
                                           float *const *kpts, uint8_t *const *descs, uint32_t cap, uint32_t *n_out);
 /* kin [n*4]: x, y, size, class_id */
+/* detectAndCompute whose outputs stay on the device, laid out as a query block (what extractAKAZESingleImg hands
+ * matchAKAZEToQuery, AKAZEOpenCV.cpp:37-113, without the .feat / .desc files in between): descriptor rows [n x 64]
+ * followed by zero rows up to a multiple of 64, keypoints (x, y) float2 [n], the keypoints after the .feat text round
+ * trip (6 significant digits, AKAZEOpenCV.cpp:80-81,106-111) float2 [n], and the six-float records [n x 6].  Only the
+ * counts come back: ONE host synchronisation per call, nothing else crosses PCIe.  _resident_arrays: the device addresses
+ * (valid until the extractor's next call) -- sfmloc_query_create_view(map, desc, kpt, kpt6, bow, n, w, h) makes the query;
+ * queue its localisation on the extractor's stream (sfmloc_akaze_share_stream) or synchronise in between. */
+int sfmloc_akaze_detect_resident(sfmloc_akaze *ak, const uint8_t *gray, uint32_t *n_out);
+int sfmloc_akaze_detect_resident_batch(sfmloc_akaze *const *aks, const uint8_t *const *grays, uint32_t n, uint32_t *n_out);
+int sfmloc_akaze_resident_arrays(sfmloc_akaze *ak, const void **desc_dev, const void **kpt_dev, const void **kpt6_dev,
+                                 const void **kp6_dev);
 int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin, uint32_t n, uint8_t *desc64,
                          float *angle_out);
 /* scale-space introspection for parity tests: level sizes, and the stacked Ldet / Lt images of the last call */
@@ -520,6 +531,9 @@ void sfmloc_imgbow_destroy(sfmloc_imgbow *ib);
 int sfmloc_imgbow_dim(const sfmloc_imgbow *ib);
 int sfmloc_imgbow_share_stream(sfmloc_imgbow *ib, sfmloc_context *ctx); /* NULL: back on its own stream */
 int sfmloc_imgbow_compute(sfmloc_imgbow *ib, const uint8_t *image, sfmloc_query *query, double *out_bow);
+/* where the float32 vector of a call WITHOUT a query lands (device memory, [sfmloc_imgbow_dim] floats): the bow_dev of a
+ * query view (sfmloc_query_create_view) over an extractor's resident outputs */
+const void *sfmloc_imgbow_vector_dev(const sfmloc_imgbow *ib);
 
 /* ------------------------------------------------------------------------- */
 /* Map-side matching: the reference's matchAKAZE /         */

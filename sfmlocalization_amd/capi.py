@@ -122,6 +122,7 @@ SYMBOLS = [
     "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing", "sfmloc_context_create_merge",
     "sfmloc_query_create_view", "sfmloc_feat_round_trip",
     "sfmloc_imgbow_create", "sfmloc_imgbow_destroy", "sfmloc_imgbow_dim", "sfmloc_imgbow_share_stream", "sfmloc_imgbow_compute",
+    "sfmloc_imgbow_vector_dev", "sfmloc_akaze_detect_resident", "sfmloc_akaze_detect_resident_batch", "sfmloc_akaze_resident_arrays",
 ]
 
 _bound = False
@@ -282,6 +283,11 @@ def _L():
         L.sfmloc_imgbow_dim.argtypes = [C.c_void_p]
         L.sfmloc_imgbow_share_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_imgbow_compute.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_void_p, F64P]
+        L.sfmloc_imgbow_vector_dev.restype = C.c_void_p
+        L.sfmloc_imgbow_vector_dev.argtypes = [C.c_void_p]
+        L.sfmloc_akaze_detect_resident.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), U32P]
+        L.sfmloc_akaze_detect_resident_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_uint8)), C.c_uint32, U32P]
+        L.sfmloc_akaze_resident_arrays.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4
         _bound = True
     return L
 
@@ -868,6 +874,10 @@ class ImgBow:
     def share_stream(self, ctx):
         _check(_L().sfmloc_imgbow_share_stream(self._h, None if ctx is None else ctx._h))
 
+    def vector_dev(self):
+        """device address of the float32 vector a compute() without a query writes (a query view's bow_dev)"""
+        return int(_L().sfmloc_imgbow_vector_dev(self._h) or 0)
+
     def compute(self, image, query=None, want_vector=None):
         """image [h, w, channels] (or [h, w] for channels = 1) u8.  query: its resident BoW slot is filled
         (asynchronously: share the stream with the context that localises it).  want_vector (default: when no query is
@@ -984,6 +994,35 @@ class Akaze:
         n_out = (C.c_uint32 * n)()
         _check(_L().sfmloc_akaze_detect_and_compute_batch(aks, gp, n, kp, dp, cap, n_out))
         return [(e._out_kp[:n_out[i]].copy(), e._out_desc[:n_out[i]].copy()) for i, e in enumerate(extractors)]
+
+    def resident_arrays(self):
+        """sfmloc_akaze_resident_arrays -> device addresses (desc, kpt, kpt6, kp6) of the last resident detection"""
+        p = [C.c_void_p() for _ in range(4)]
+        _check(_L().sfmloc_akaze_resident_arrays(self._h, *[C.byref(x) for x in p]))
+        return tuple(int(x.value or 0) for x in p)
+
+    def detect_resident(self, gray):
+        """sfmloc_akaze_detect_resident: outputs stay on the device as a query block -> number of keypoints"""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        assert gray.shape == (self.height, self.width)
+        n = C.c_uint32()
+        _check(_L().sfmloc_akaze_detect_resident(self._h, _ptr(gray, C.c_uint8), C.byref(n)))
+        return int(n.value)
+
+    @staticmethod
+    def detect_resident_batch(extractors, grays):
+        n = len(extractors)
+        imgs = [np.ascontiguousarray(g, np.uint8) for g in grays]
+        aks = (C.c_void_p * n)(*[e._h for e in extractors])
+        gp = (C.POINTER(C.c_uint8) * n)(*[_ptr(g, C.c_uint8) for g in imgs])
+        n_out = (C.c_uint32 * n)()
+        _check(_L().sfmloc_akaze_detect_resident_batch(aks, gp, n, n_out))
+        return [int(x) for x in n_out]
+
+    def query_view(self, m, n, bow_dev=0):
+        """the last resident detection as a query of map m (sfmloc_query_create_view over the extractor's arrays)"""
+        desc, kpt, kpt6, _ = self.resident_arrays()
+        return m.query_view(desc, kpt, kpt6, bow_dev, n, self.width, self.height)
 
     def compute(self, gray, kin):
         gray = np.ascontiguousarray(gray, np.uint8)

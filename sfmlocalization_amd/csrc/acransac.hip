@@ -2078,6 +2078,7 @@ __global__ void k_debug_math(int op, const double *in, int n, int in_stride, dou
       ac_sample<7>(nullptr, (int)x[2], seed, (uint32_t)x[3], (uint32_t)x[4], (uint32_t)x[5], smp);
       for (int k = 0; k < 7; ++k) o[k] = (double)smp[k];
     } break;
+    case 10: o[0] = (double)round6_dev((float)x[0]); break;  // the .feat round trip of a coordinate
     default: break;
   }
 }

@@ -18,10 +18,10 @@
 
 #include <algorithm>
 #include <new>
-#include <thread>
 #include <vector>
 
 #include "sfmloc_internal.h"
+#include "geom_device.h"
 
 namespace sfmloc {
 namespace {
@@ -858,6 +858,8 @@ struct LevelTab {
   int w[kMaxLevels], h[kMaxLevels], sc[kMaxLevels], sigma_size[kMaxLevels];
   unsigned int off[kMaxLevels];
   float ws[kMaxLevels], wm[kMaxLevels];
+  float ksize[kMaxLevels];  // esigma * 1.5: the radius of the duplicate tests (the keypoint's size is twice that)
+  int octave[kMaxLevels];
 };
 
 __device__ __forceinline__ int level_of_row(const LevelTab &T, int row) {
@@ -906,48 +908,500 @@ __global__ void k_hessian_det_all(const float *__restrict__ lx_all, const float 
   HessianDetAllBody::run(lx_all, ly_all, ldet, Tp);
 }
 
-struct Candidate9 {
-  int level, x, y, pad;
-  float patch[9];  // Ldet(y-1..y+1, x-1..x+1), row major
-  float pad2[3];
-};
+// ---------------------------------------------------------------------------------------------------------------------
+// The rest of Find_Scale_Space_Extrema + Do_Subpixel_Refinement on the device (round 3; it ran on the host before, behind
+// a D2H of the candidates and two host synchronisations per image).
+//
+// OpenCV walks the candidates in raster order, level by level, and keeps a list of accepted points: a candidate looks
+// for the FIRST accepted point (in acceptance order) of its own or the previous level within its radius; if there is one
+// the stronger of the two keeps that point's place in the list, otherwise the candidate is appended; a second pass drops
+// every point that has a stronger point of the next level within its radius further down the list; the survivors are
+// refined to sub-pixel positions in list order.  The first pass is order dependent, but only LOCALLY: a candidate's
+// outcome depends on the accepted points within its radius r, and an earlier candidate can change those only if it lies
+// within 2 r (it sits there itself, or it took over a point that did).  So the candidates of a level are decided in
+// ROUNDS by one workgroup: a candidate is ready when every earlier candidate of its level within 2 r (a box, slightly
+// larger: conservative) has been decided, all ready candidates of a round decide at once -- two of them are never within
+// 2 r of each other, so they touch disjoint points -- and a level takes as many rounds as its longest chain of such
+// dependencies (a handful).  A point's place in the list is carried as a key: the raster index of the candidate that
+// was appended there (appends happen in raster order, so ascending key IS acceptance order; the candidate that takes a
+// point over inherits its key).  The survivors leave in ascending key order, which is the reference's output order.
+//   k_extrema_seg    per 64-pixel segment of every level row: the extrema's x offsets, in order (ballot) + their count
+//   k_seg_scan       exclusive sum over the segments -> where each segment's candidates start in the raster-ordered list
+//   k_extrema_place  the candidates (level, x, y, response, 3x3 patch) into that list
+//   k_suppress       the two passes + sub-pixel refinement + ordered compaction, one workgroup per image
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSegPx = 64;          // a segment = what one wave of the extrema kernels covers
+constexpr int kSegMax = kSegPx / 2; // strict 3x3 maxima are never horizontal neighbours
 
-struct ExtremaAllBody {
-  static constexpr int kGangThreads = 256;
-  static __device__ __forceinline__ void run(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp, float dthreshold, Candidate9 *out,
-                      unsigned int cap, unsigned int *n_out) {
+__device__ __forceinline__ bool extremum_at(const float *__restrict__ D, int w, int h, int x, int y, float dthreshold,
+                                            int sigma_size_, float (&p)[9]) {
+  if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return false;
+  const float v = D[(size_t)y * w + x];
+  if (!(v > dthreshold && v >= 0.00001f)) return false;
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) p[(dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
+  if (!(v > p[3] && v > p[5] && v > p[0] && v > p[1] && v > p[2] && v > p[6] && v > p[7] && v > p[8])) return false;
+  const float smax = 10.0f * sqrtf(2.0f);
+  const int left_x = fround_d((float)x - smax * sigma_size_) - 1, right_x = fround_d((float)x + smax * sigma_size_) + 1;
+  const int up_y = fround_d((float)y - smax * sigma_size_) - 1, down_y = fround_d((float)y + smax * sigma_size_) + 1;
+  return !(left_x < 0 || right_x >= w || up_y < 0 || down_y >= h);
+}
+
+struct ExtremaSegBody {
+  static constexpr int kGangThreads = 128;
+  static __device__ __forceinline__ void run(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp,
+                                             float dthreshold, uint8_t *__restrict__ seg_x, unsigned int *__restrict__ seg_cnt) {
     const LevelTab &T = *Tp;
     const int i = level_of_row(T, blockIdx.y);
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
-    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
-    const float *D = ldet_all + T.off[i];
-    const float v = D[(size_t)y * w + x];
-    if (!(v > dthreshold && v >= 0.00001f)) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i];
     float p[9];
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) p[(dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
-    if (!(v > p[3] && v > p[5] && v > p[0] && v > p[1] && v > p[2] && v > p[6] && v > p[7] && v > p[8])) return;
-    const float smax = 10.0f * sqrtf(2.0f);
-    const int sigma_size_ = T.sigma_size[i];
-    const int left_x = fround_d((float)x - smax * sigma_size_) - 1, right_x = fround_d((float)x + smax * sigma_size_) + 1;
-    const int up_y = fround_d((float)y - smax * sigma_size_) - 1, down_y = fround_d((float)y + smax * sigma_size_) + 1;
-    if (left_x < 0 || right_x >= w || up_y < 0 || down_y >= h) return;
-    const unsigned int slot = atomicAdd(n_out, 1u);
-    if (slot >= cap) return;
-    Candidate9 c;
-    c.level = i;
-    c.x = x;
-    c.y = y;
-    c.pad = 0;
-    for (int k = 0; k < 9; ++k) c.patch[k] = p[k];
-    c.pad2[0] = c.pad2[1] = c.pad2[2] = 0.0f;
-    out[slot] = c;
+    const bool is = extremum_at(ldet_all + T.off[i], T.w[i], T.h[i], x, y, dthreshold, T.sigma_size[i], p);
+    const unsigned long long m = __ballot(is);
+    const int lane = threadIdx.x & 63;
+    const unsigned int seg = blockIdx.y * (gridDim.x * 2) + blockIdx.x * 2 + (threadIdx.x >> 6);
+    if (is) seg_x[(size_t)seg * kSegMax + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    if (lane == 0) seg_cnt[seg] = (unsigned int)__popcll(m);
   }
 };
-__global__ void k_extrema_all(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp, float dthreshold, Candidate9 *out,
-                      unsigned int cap, unsigned int *n_out) {
-  ExtremaAllBody::run(ldet_all, Tp, dthreshold, out, cap, n_out);
+__global__ __launch_bounds__(128) void k_extrema_seg(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp,
+                                                     float dthreshold, uint8_t *__restrict__ seg_x,
+                                                     unsigned int *__restrict__ seg_cnt) {
+  ExtremaSegBody::run(ldet_all, Tp, dthreshold, seg_x, seg_cnt);
 }
+
+// exclusive sum of seg_cnt[0 .. n_seg) in place, the total in seg_cnt[n_seg] and in *n_out.  Each of the 16 waves owns a
+// contiguous chunk: it sums it with coalesced loads, the 16 totals meet in LDS, then the wave walks its chunk again with a
+// shuffle scan and a running carry (no block barrier inside the walks).
+struct SegScanBody {
+  static constexpr int kGangThreads = 1024;
+  static __device__ __forceinline__ void run(unsigned int *__restrict__ seg_cnt, unsigned int n_seg, unsigned int cap,
+                                             unsigned int *__restrict__ n_out) {
+    __shared__ unsigned int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned int chunk = ((n_seg + 15u) / 16u + 63u) & ~63u;
+    const unsigned int lo = min(n_seg, (unsigned int)wv * chunk), hi = min(n_seg, lo + chunk);
+    unsigned int sum = 0;
+    for (unsigned int k = lo + lane; k < hi; k += 64) sum += seg_cnt[k];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) wsum[wv] = sum;
+    __syncthreads();
+    unsigned int carry = 0;
+    for (int q = 0; q < wv; ++q) carry += wsum[q];
+    for (unsigned int k0 = lo; k0 < hi; k0 += 64) {
+      const unsigned int k = k0 + lane;
+      const unsigned int c = k < hi ? seg_cnt[k] : 0u;
+      unsigned int inc = c;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+      }
+      if (k < hi) seg_cnt[k] = carry + inc - c;
+      carry += __shfl(inc, 63, 64);
+    }
+    if (tid == 0) {
+      unsigned int total = 0;
+      for (int q = 0; q < 16; ++q) total += wsum[q];
+      seg_cnt[n_seg] = total;
+      *n_out = total;
+    }
+    (void)cap;
+  }
+};
+__global__ __launch_bounds__(1024) void k_seg_scan(unsigned int *__restrict__ seg_cnt, unsigned int n_seg, unsigned int cap,
+                                                   unsigned int *__restrict__ n_out) {
+  SegScanBody::run(seg_cnt, n_seg, cap, n_out);
+}
+
+struct CandArrays {
+  uint32_t *xy;           // level coordinates: x | y << 16
+  uint8_t *level;
+  float *resp;            // |Ldet| at the candidate
+  float *patch;           // [n x 9] the 3 x 3 neighbourhood
+};
+
+struct ExtremaPlaceBody {
+  static constexpr int kGangThreads = 128;
+  static __device__ __forceinline__ void run(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp,
+                                             const uint8_t *__restrict__ seg_x, const unsigned int *__restrict__ seg_base,
+                                             unsigned int cap, CandArrays C) {
+    const LevelTab &T = *Tp;
+    const int i = level_of_row(T, blockIdx.y);
+    const int y = blockIdx.y - T.row0[i], w = T.w[i];
+    const int lane = threadIdx.x & 63;
+    const unsigned int seg = blockIdx.y * (gridDim.x * 2) + blockIdx.x * 2 + (threadIdx.x >> 6);
+    const unsigned int base = seg_base[seg], cnt = seg_base[seg + 1] - base;
+    if ((unsigned int)lane >= cnt || base + lane >= cap) return;
+    const int x = blockIdx.x * blockDim.x + (threadIdx.x & ~63) + seg_x[(size_t)seg * kSegMax + lane];
+    const float *D = ldet_all + T.off[i];
+    const unsigned int g = base + lane;
+    C.xy[g] = (uint32_t)x | ((uint32_t)y << 16);
+    C.level[g] = (uint8_t)i;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) C.patch[(size_t)g * 9 + (dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
+    C.resp[g] = fabsf(D[(size_t)y * w + x]);
+  }
+};
+__global__ __launch_bounds__(128) void k_extrema_place(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp,
+                                                       const uint8_t *__restrict__ seg_x,
+                                                       const unsigned int *__restrict__ seg_base, unsigned int cap,
+                                                       CandArrays C) {
+  ExtremaPlaceBody::run(ldet_all, Tp, seg_x, seg_base, cap, C);
+}
+
+struct SuppressArgs {
+  const LevelTab *T;
+  const unsigned int *seg_base;  // [n_seg + 1]
+  unsigned int segs_per_row;     // 2 x the extrema kernels' gridDim.x
+  unsigned int cap;
+  CandArrays C;
+  uint8_t *status;               // per candidate: 0 undecided, 1 holds a point of the list, 2 dropped, 3 taken over
+  uint8_t *ready;
+  unsigned int *key;             // the list position a candidate holds (raster index of the candidate appended there)
+  int *slot;                     // [cap] key -> the candidate that holds it at the end (-1: nobody), then output positions
+  float *kp;                     // out [n x 4]: x, y, size, class_id
+  float *resp_out;               // out [n]
+  unsigned int *n_kp;            // out
+  unsigned int *n_cand;          // in (k_seg_scan)
+  unsigned int *rounds_out;      // diagnostics: rounds the first pass took over all levels
+};
+
+enum : uint8_t { kUndecided = 0, kHolds = 1, kDropped = 2, kTakenOver = 3 };
+
+// The first pass works out of LDS: per level the row starts (raster index of a row's first candidate), the packed
+// coordinates and the status bytes of the level and of the one before it; a band of rows is ONE contiguous index range.
+// A level with more candidates than the LDS arrays hold works on the global arrays through the same pointers.
+constexpr int kSupMaxRows = 4096 + 1;  // level rows the row-start tables hold (sfmloc_akaze_create: height <= 4096)
+constexpr int kSupLevelCap = 4096;     // candidates of one level kept in LDS
+struct SuppressLds {
+  unsigned int row[2][kSupMaxRows];
+  uint32_t xy[2][kSupLevelCap];
+  unsigned int key[2][kSupLevelCap];
+  float resp[2][kSupLevelCap];
+  uint8_t st[2][kSupLevelCap];
+  uint8_t ready[kSupLevelCap];
+  unsigned int lvl[kMaxLevels + 1];   // where each level starts in the raster-ordered list
+  unsigned int left[2];
+  unsigned int wsum[16];
+};
+
+struct SuppressBody {
+  static constexpr int kGangThreads = 1024;
+
+  // One level of the first pass.  CL / PL: this level's / the previous level's coordinates and status bytes are in LDS
+  // (slot b / b ^ 1, indexed by raster index minus c0 / p0) or in the global arrays -- compile-time, so that the LDS form
+  // is ds_read / ds_write and not a generic (flat) access, which costs a global-memory round trip even when it lands in LDS.
+  template <bool CL, bool PL>
+  static __device__ __forceinline__ void level(const SuppressArgs &A, const LevelTab &T, SuppressLds &L, int l, int b,
+                                               unsigned int c0, unsigned int c1, unsigned int p0, unsigned int &rounds) {
+    const int tid = threadIdx.x;
+    const int h = T.h[l];
+    const unsigned int *R = L.row[b], *Rp = L.row[b ^ 1];
+    auto xy_c = [&](unsigned int g) -> uint32_t { return CL ? L.xy[b][g - c0] : A.C.xy[g]; };
+    auto st_c = [&](unsigned int g) -> uint8_t & { return CL ? L.st[b][g - c0] : A.status[g]; };
+    auto rd_c = [&](unsigned int g) -> uint8_t & { return CL ? L.ready[g - c0] : A.ready[g]; };
+    auto xy_p = [&](unsigned int g) -> uint32_t { return PL ? L.xy[b ^ 1][g - p0] : A.C.xy[g]; };
+    auto st_p = [&](unsigned int g) -> uint8_t & { return PL ? L.st[b ^ 1][g - p0] : A.status[g]; };
+    auto key_c = [&](unsigned int g) -> unsigned int & { return CL ? L.key[b][g - c0] : A.key[g]; };
+    auto key_p = [&](unsigned int g) -> unsigned int { return PL ? L.key[b ^ 1][g - p0] : A.key[g]; };
+    auto rsp_c = [&](unsigned int g) -> float { return CL ? L.resp[b][g - c0] : A.C.resp[g]; };
+    auto rsp_p = [&](unsigned int g) -> float { return PL ? L.resp[b ^ 1][g - p0] : A.C.resp[g]; };
+    const float size = T.ksize[l];
+    const float ratio = (float)(1 << T.octave[l]);
+    const float dep2 = 4.0f * size * size * 1.0001f + 0.01f;   // (2 r)^2 with slack: conservative
+    const int dep = (int)ceilf(2.0f * size / ratio) + 1;
+    const int hit = (int)ceilf(size / ratio) + 1;
+    const float r1 = l > 0 ? (float)(1 << T.octave[l - 1]) : 1.0f;
+    for (; c0 != c1;) {
+      // (a) who is ready: no earlier undecided candidate of this level within 2 r; how many are undecided at all
+      unsigned int undecided = 0;
+      for (unsigned int g = c0 + tid; g < c1; g += 1024) {
+        if (st_c(g) != kUndecided) continue;
+        ++undecided;
+        const uint32_t me = xy_c(g);
+        const int x = (int)(me & 0xFFFFu), y = (int)(me >> 16);
+        bool blocked = false;
+        // earlier in raster order: the rows above within reach, and this row up to the candidate itself
+        const unsigned int from = R[max(y - dep, 0)];
+        // (four neighbours per step, their loads issued together: the scan is a chain of LDS latencies otherwise)
+        for (unsigned int o4 = from; o4 < g && !blocked; o4 += 4) {
+          uint32_t q[4];
+          uint8_t sv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned int o = min(o4 + u, g - 1);
+            q[u] = xy_c(o);
+            sv[u] = st_c(o);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (o4 + u >= g) continue;
+            const int ddx = x - (int)(q[u] & 0xFFFFu), ddy = y - (int)(q[u] >> 16);
+            if (ddx > dep || ddx < -dep || sv[u] != kUndecided) continue;
+            const float dx = (float)ddx * ratio, dy = (float)ddy * ratio;
+            if (dx * dx + dy * dy <= dep2) blocked = true;
+          }
+        }
+        rd_c(g) = blocked ? 0 : 1;
+      }
+      if (undecided) atomicAdd(&L.left[rounds & 1], undecided);
+      if (tid == 0) L.left[(rounds + 1) & 1] = 0u;
+      __syncthreads();
+      if (L.left[rounds & 1] == 0u) {
+        ++rounds;
+        break;
+      }
+      // (b) the ready ones decide
+      for (unsigned int g = c0 + tid; g < c1; g += 1024) {
+        if (st_c(g) != kUndecided || !rd_c(g)) continue;
+        const uint32_t me = xy_c(g);
+        const int x = (int)(me & 0xFFFFu), y = (int)(me >> 16);
+        const float px = (float)x * ratio, py = (float)y * ratio;
+        unsigned int first = 0xFFFFFFFFu, first_key = 0xFFFFFFFFu;
+        {  // this level: the band of rows within r
+          const unsigned int from = R[max(y - hit, 0)], to = R[min(y + hit, h - 1) + 1];
+          for (unsigned int o4 = from; o4 < to; o4 += 4) {
+            uint32_t q[4];
+            uint8_t sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const unsigned int o = min(o4 + u, to - 1);
+              q[u] = xy_c(o);
+              sv[u] = st_c(o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const unsigned int o = o4 + u;
+              const int ddx = x - (int)(q[u] & 0xFFFFu);
+              if (o >= to || ddx > hit || ddx < -hit || o == g || sv[u] != kHolds) continue;
+              const float dx = px - (float)(q[u] & 0xFFFFu) * ratio, dy = py - (float)(q[u] >> 16) * ratio;
+              if (dx * dx + dy * dy <= size * size) {
+                const unsigned int ko = key_c(o);
+                if (ko < first_key) {
+                  first_key = ko;
+                  first = o;
+                }
+              }
+            }
+          }
+        }
+        if (l > 0) {  // the level before
+          const int wp = T.w[l - 1], hp = T.h[l - 1];
+          const int x0 = max((int)floorf((px - size) / r1) - 1, 0), x1 = min((int)ceilf((px + size) / r1) + 1, wp - 1);
+          const int y0 = max((int)floorf((py - size) / r1) - 1, 0), y1 = min((int)ceilf((py + size) / r1) + 1, hp - 1);
+          if (x0 <= x1 && y0 <= y1) {
+            const unsigned int from = Rp[y0], to = Rp[y1 + 1];
+            for (unsigned int o4 = from; o4 < to; o4 += 4) {
+              uint32_t q[4];
+              uint8_t sv[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const unsigned int o = min(o4 + u, to - 1);
+                q[u] = xy_p(o);
+                sv[u] = st_p(o);
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const unsigned int o = o4 + u;
+                const int xo = (int)(q[u] & 0xFFFFu);
+                if (o >= to || xo < x0 || xo > x1 || sv[u] != kHolds) continue;
+                const float dx = px - (float)xo * r1, dy = py - (float)(q[u] >> 16) * r1;
+                if (dx * dx + dy * dy <= size * size) {
+                  const unsigned int ko = key_p(o);
+                  if (ko < first_key) {
+                    first_key = ko;
+                    first = o;
+                  }
+                }
+              }
+            }
+          }
+        }
+        if (first == 0xFFFFFFFFu) {
+          st_c(g) = kHolds;  // appended: its own raster index is its place
+        } else if (rsp_c(g) > (first >= c0 ? rsp_c(first) : rsp_p(first))) {
+          key_c(g) = first_key;  // takes the point over, keeps its place
+          st_c(g) = kHolds;
+          if (first >= c0) st_c(first) = kTakenOver;
+          else st_p(first) = kTakenOver;
+        } else {
+          st_c(g) = kDropped;
+        }
+      }
+      ++rounds;
+      __syncthreads();
+    }
+  }
+
+  static __device__ __forceinline__ void run(SuppressArgs A) {
+    const LevelTab &T = *A.T;
+    extern __shared__ unsigned char sup_smem[];
+    SuppressLds &L = *reinterpret_cast<SuppressLds *>(sup_smem);
+    const int tid = threadIdx.x;
+    const unsigned int N = min(*A.n_cand, A.cap);
+    for (unsigned int g = tid; g < N; g += 1024) {
+      A.status[g] = kUndecided;
+      A.key[g] = g;
+      A.slot[g] = -1;
+    }
+    unsigned int rounds = 0;
+    const unsigned long long t_start = wall_clock64();
+    if (tid < 2) L.left[tid] = 0u;
+    if (tid <= T.n) L.lvl[tid] = min(A.seg_base[(unsigned int)T.row0[tid] * A.segs_per_row], N);
+    // level l's tables sit in slot l & 1 of the LDS arrays (or, a level with more than kSupLevelCap candidates, in the
+    // global arrays); the previous level's stay where they are while level l is decided
+    bool prev_lds = false;
+    unsigned int p0 = 0, p1 = 0;
+    __syncthreads();
+    // ---- first pass, level by level ----
+    for (int l = 0; l < T.n; ++l) {
+      const int b = l & 1;
+      const int h = T.h[l];
+      // the level's extent straight from the segment table (every thread the same two loads: no barrier in front of the
+      // fills), then row starts and coordinates under ONE barrier
+      const unsigned long long t_l0 = wall_clock64();
+      const unsigned int rounds_before = rounds;
+      const unsigned int c0 = L.lvl[l], c1 = L.lvl[l + 1];
+      for (int y = tid; y <= h; y += 1024) L.row[b][y] = min(A.seg_base[(unsigned int)(T.row0[l] + y) * A.segs_per_row], N);
+      const bool in_lds = c1 - c0 <= (unsigned int)kSupLevelCap;
+      if (in_lds)
+        for (unsigned int g = c0 + tid; g < c1; g += 1024) {
+          L.xy[b][g - c0] = A.C.xy[g];
+          L.resp[b][g - c0] = A.C.resp[g];
+          L.key[b][g - c0] = g;
+          L.st[b][g - c0] = kUndecided;
+        }
+      __syncthreads();
+      const unsigned long long t_l1 = wall_clock64();
+      if (in_lds) {
+        if (prev_lds) level<true, true>(A, T, L, l, b, c0, c1, p0, rounds);
+        else level<true, false>(A, T, L, l, b, c0, c1, p0, rounds);
+      } else {
+        if (prev_lds) level<false, true>(A, T, L, l, b, c0, c1, p0, rounds);
+        else level<false, false>(A, T, L, l, b, c0, c1, p0, rounds);
+      }
+      // the previous level is final now: its statuses go back to the global array (the second pass reads them there)
+      if (prev_lds)
+        for (unsigned int g = p0 + tid; g < p1; g += 1024) {
+          A.status[g] = L.st[b ^ 1][g - p0];
+          A.key[g] = L.key[b ^ 1][g - p0];
+        }
+      const unsigned long long t_l2 = wall_clock64();
+      prev_lds = in_lds;
+      p0 = c0;
+      p1 = c1;
+      __syncthreads();
+      if (tid == 0 && A.rounds_out) {  // diagnostics: per level candidates, rounds, 10 ns ticks of the fill and of the rounds
+        unsigned int *dbg = A.rounds_out + 8 + 4 * l;
+        dbg[0] = c1 - c0;
+        dbg[1] = rounds - rounds_before;
+        dbg[2] = (unsigned int)(t_l1 - t_l0);
+        dbg[3] = (unsigned int)(t_l2 - t_l1);
+      }
+    }
+    if (prev_lds)  // ... and the last level's
+      for (unsigned int g = p0 + tid; g < p1; g += 1024) {
+        A.status[g] = L.st[(T.n - 1) & 1][g - p0];
+        A.key[g] = L.key[(T.n - 1) & 1][g - p0];
+      }
+    __syncthreads();
+    const unsigned long long t_pass1 = wall_clock64();
+    // ---- second pass: a point with a stronger point of the NEXT level within its radius, further down the list ----
+    for (unsigned int g = tid; g < N; g += 1024) {
+      if (A.status[g] != kHolds) continue;
+      const int l = A.C.level[g];
+      bool rep = false;
+      if (l + 1 < T.n) {
+        const uint32_t me = A.C.xy[g];
+        const float size = T.ksize[l], ratio = (float)(1 << T.octave[l]);
+        const float px = (float)(me & 0xFFFFu) * ratio, py = (float)(me >> 16) * ratio, rsp = A.C.resp[g];
+        const unsigned int kg = A.key[g];
+        const float rn = (float)(1 << T.octave[l + 1]);
+        const int wn = T.w[l + 1], hn = T.h[l + 1];
+        const int x0 = max((int)floorf((px - size) / rn) - 1, 0), x1 = min((int)ceilf((px + size) / rn) + 1, wn - 1);
+        const int y0 = max((int)floorf((py - size) / rn) - 1, 0), y1 = min((int)ceilf((py + size) / rn) + 1, hn - 1);
+        if (x0 <= x1 && y0 <= y1) {
+          const unsigned int from = min(A.seg_base[(unsigned int)(T.row0[l + 1] + y0) * A.segs_per_row], N);
+          const unsigned int to = min(A.seg_base[(unsigned int)(T.row0[l + 1] + y1 + 1) * A.segs_per_row], N);
+          for (unsigned int o = from; o < to; ++o) {
+            const uint32_t q = A.C.xy[o];
+            const int xo = (int)(q & 0xFFFFu);
+            if (xo < x0 || xo > x1 || A.status[o] != kHolds || A.key[o] <= kg) continue;
+            const float dx = px - (float)xo * rn, dy = py - (float)(q >> 16) * rn;
+            if (dx * dx + dy * dy <= size * size && rsp < A.C.resp[o]) rep = true;
+          }
+        }
+      }
+      A.ready[g] = rep ? 1 : 0;  // (reused: "repeated")
+    }
+    __syncthreads();
+    const unsigned long long t_pass2 = wall_clock64();
+    // ---- Do_Subpixel_Refinement on the survivors; slot[key] = the candidate, or -1 ----
+    for (unsigned int g = tid; g < N; g += 1024) {
+      if (A.status[g] != kHolds || A.ready[g]) continue;
+      const float *p = A.C.patch + (size_t)g * 9;
+      const float Dx = 0.5f * (p[5] - p[3]);
+      const float Dy = 0.5f * (p[7] - p[1]);
+      const float Dxx = (p[5] + p[3]) - 2.0f * p[4];
+      const float Dyy = (p[7] + p[1]) - 2.0f * p[4];
+      const float Dxy = 0.25f * (p[8] + p[0]) - 0.25f * (p[2] + p[6]);
+      const float det = Dxx * Dyy - Dxy * Dxy;
+      if (det == 0.0f) continue;
+      const float d0 = (-Dx * Dyy + Dy * Dxy) / det;
+      const float d1 = (-Dy * Dxx + Dx * Dxy) / det;
+      if (fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f) A.slot[A.key[g]] = (int)g;
+    }
+    __syncthreads();
+    // ---- ordered compaction over the keys: a wave per contiguous chunk, as k_seg_scan ----
+    const int lane = tid & 63, wv = tid >> 6;
+    const unsigned int chunk = ((N + 15u) / 16u + 63u) & ~63u;
+    const unsigned int lo = min(N, (unsigned int)wv * chunk), hi = min(N, lo + chunk);
+    unsigned int sum = 0;
+    for (unsigned int k = lo + lane; k < hi; k += 64) sum += A.slot[k] >= 0 ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) L.wsum[wv] = sum;
+    __syncthreads();
+    unsigned int carry = 0;
+    for (int q = 0; q < wv; ++q) carry += L.wsum[q];
+    for (unsigned int k0 = lo; k0 < hi; k0 += 64) {
+      const unsigned int k = k0 + lane;
+      const int g = k < hi ? A.slot[k] : -1;
+      const unsigned long long m = __ballot(g >= 0);
+      if (g >= 0) {
+        const unsigned int pos = carry + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        const int l = A.C.level[g];
+        const uint32_t me = A.C.xy[g];
+        const float ratio = (float)(1 << T.octave[l]);
+        const float *p = A.C.patch + (size_t)g * 9;
+        const float Dx = 0.5f * (p[5] - p[3]);
+        const float Dy = 0.5f * (p[7] - p[1]);
+        const float Dxx = (p[5] + p[3]) - 2.0f * p[4];
+        const float Dyy = (p[7] + p[1]) - 2.0f * p[4];
+        const float Dxy = 0.25f * (p[8] + p[0]) - 0.25f * (p[2] + p[6]);
+        const float det = Dxx * Dyy - Dxy * Dxy;
+        const float d0 = (-Dx * Dyy + Dy * Dxy) / det;
+        const float d1 = (-Dy * Dxx + Dx * Dxy) / det;
+        A.kp[4 * pos] = ((float)(me & 0xFFFFu) + d0) * ratio;
+        A.kp[4 * pos + 1] = ((float)(me >> 16) + d1) * ratio;
+        A.kp[4 * pos + 2] = T.ksize[l] * 2.0f;
+        A.kp[4 * pos + 3] = (float)l;
+        A.resp_out[pos] = A.C.resp[g];
+      }
+      carry += (unsigned int)__popcll(m);
+    }
+    if (tid == 0) {
+      unsigned int total = 0;
+      for (int q = 0; q < 16; ++q) total += L.wsum[q];
+      *A.n_kp = total;
+      if (A.rounds_out) {  // diagnostics (SFMLOC_AKAZE_TIMING): rounds, then 10 ns ticks of the first pass, the second, the rest
+        A.rounds_out[0] = rounds;
+        A.rounds_out[1] = (unsigned int)(t_pass1 - t_start);
+        A.rounds_out[2] = (unsigned int)(t_pass2 - t_pass1);
+        A.rounds_out[3] = (unsigned int)(wall_clock64() - t_pass2);
+      }
+    }
+  }
+};
+__global__ __launch_bounds__(1024) void k_suppress(SuppressArgs A) { SuppressBody::run(A); }
 
 struct DevLevel {
   const float *Lt, *Lx, *Ly;  // Lx, Ly unscaled: multiply by sf (= sigma_size) on use
@@ -970,12 +1424,21 @@ struct OrientDescribeBody {
                                         const float *__restrict__ gauss25,
                                         const float *__restrict__ win_ang1, int n_win,
                                         const uint16_t *__restrict__ pair_tab,
-                                        float *__restrict__ angle_out, uint8_t *__restrict__ desc) {
+                                        float *__restrict__ angle_out, uint8_t *__restrict__ desc,
+                                        const unsigned int *__restrict__ n_dev /*or null: the count, on the device*/,
+                                        const float *__restrict__ resp /*with kp6: the responses*/,
+                                        float *__restrict__ kp6 /*or null: out [n x 6] x, y, size, angle, response, class*/,
+                                        float2 *__restrict__ qkpt /*or null: out [n] (x, y): a query's keypoints ...*/,
+                                        float2 *__restrict__ qkpt6 /*... and the same after the .feat text round trip*/) {
     __shared__ float resX[109], resY[109], Ang[109];
     __shared__ float vals[29 * 3];
-    const int kidx = blockIdx.x;
-    if (kidx >= n) return;
+    if (n_dev) n = (int)*n_dev;
     const int lane = threadIdx.x;
+    // rows n .. the next multiple of 64 are zeroed: the descriptor array then IS a query block (sfmloc_query_create_view)
+    if (qkpt)
+      for (int kidx = n + blockIdx.x; kidx < ((n + 63) & ~63); kidx += gridDim.x) desc[(size_t)kidx * 64 + lane] = 0;
+    // (a launch sized before the count is known covers any count: workgroup b takes keypoints b, b + gridDim.x, ...)
+    for (int kidx = blockIdx.x; kidx < n; kidx += gridDim.x) {
     const float kx = kp[4 * kidx], ky = kp[4 * kidx + 1], ksize = kp[4 * kidx + 2];
     const int level = (int)kp[4 * kidx + 3];
     const DevLevel L = LVp->l[level];
@@ -1035,7 +1498,21 @@ struct OrientDescribeBody {
     }
     const float wx = __shfl(sumX, best_lane, 64), wy = __shfl(sumY, best_lane, 64);
     const float angle = (best > 0.0f) ? get_angle(wx, wy) : 0.0f;
-    if (lane == 0) angle_out[kidx] = angle;
+    if (lane == 0) {
+      angle_out[kidx] = angle;
+      if (kp6) {
+        kp6[6 * kidx] = kx;
+        kp6[6 * kidx + 1] = ky;
+        kp6[6 * kidx + 2] = ksize;
+        kp6[6 * kidx + 3] = angle;
+        kp6[6 * kidx + 4] = resp[kidx];
+        kp6[6 * kidx + 5] = (float)level;
+      }
+      if (qkpt) {
+        qkpt[kidx] = make_float2(kx, ky);
+        qkpt6[kidx] = make_float2(geom::round6_dev(kx), geom::round6_dev(ky));
+      }
+    }
     // --- M-LDB: 4 + 9 + 16 grid cells, one lane per cell, samples summed in (k, l) order ---
     float si, co;
     det_sincosf(angle, &si, &co);
@@ -1088,14 +1565,18 @@ struct OrientDescribeBody {
       }
       desc[(size_t)kidx * 64 + lane] = byte;  // lanes 61..63 write the zero padding of the .desc row
     }
+    __syncthreads();  // the LDS arrays serve the next keypoint of this workgroup
+    }
   }
 };
 __global__ __launch_bounds__(64) void k_orient_describe(const DevLevels *__restrict__ LVp, const float *__restrict__ kp, int n,
                                         const float *__restrict__ gauss25,
                                         const float *__restrict__ win_ang1, int n_win,
                                         const uint16_t *__restrict__ pair_tab,
-                                        float *__restrict__ angle_out, uint8_t *__restrict__ desc) {
-  OrientDescribeBody::run(LVp, kp, n, gauss25, win_ang1, n_win, pair_tab, angle_out, desc);
+                                        float *__restrict__ angle_out, uint8_t *__restrict__ desc,
+                                        const unsigned int *__restrict__ n_dev, const float *__restrict__ resp,
+                                        float *__restrict__ kp6, float2 *__restrict__ qkpt, float2 *__restrict__ qkpt6) {
+  OrientDescribeBody::run(LVp, kp, n, gauss25, win_ang1, n_win, pair_tab, angle_out, desc, n_dev, resp, kp6, qkpt, qkpt6);
 }
 
 }  // namespace
@@ -1120,9 +1601,20 @@ struct Akaze : GangMember {  // (gang.h: `stream` reads as the stream to queue o
   float *d_half_steps = nullptr;              // [level][64]: 0.5 * tsteps, for k_octave_resident
   void *d_level_tab = nullptr;                // the LevelTab of this image size (the all-level kernels read it by pointer)
   void *d_dev_levels = nullptr;               // the DevLevels of this extractor (k_orient_describe reads it by pointer)
-  Candidate9 *d_cand = nullptr;
-  unsigned int *d_ncand = nullptr;
+  // detection tail (k_extrema_seg .. k_suppress): the raster-ordered candidate list and the suppression's state
+  unsigned int *d_ncand = nullptr;            // [0] candidates, [1] keypoints, [2] rounds of the first pass
   unsigned int cand_cap = 1u << 16;
+  unsigned int n_seg = 0, segs_per_row = 0;
+  unsigned int *d_seg = nullptr;              // [n_seg + 1] counts, then (k_seg_scan) where each segment starts
+  uint8_t *d_seg_x = nullptr;                 // [n_seg x kSegMax]
+  uint32_t *d_cxy = nullptr;
+  uint8_t *d_clevel = nullptr, *d_cstatus = nullptr, *d_cready = nullptr;
+  float *d_cresp = nullptr, *d_cpatch = nullptr;
+  unsigned int *d_ckey = nullptr;
+  int *d_cslot = nullptr;
+  float *d_resp = nullptr, *d_kp6 = nullptr;  // per keypoint: response; the six-float records of the C ABI
+  float2 *d_qkpt = nullptr, *d_qkpt6 = nullptr;  // the keypoints as a query holds them: (x, y), and after the .feat round trip
+  unsigned int *h_counts = nullptr;           // pinned copy of d_ncand
   float *d_gauss25 = nullptr, *d_win = nullptr;
   uint16_t *d_pair = nullptr;
   float *d_kp = nullptr, *d_angle = nullptr;
@@ -1176,6 +1668,8 @@ LevelTab level_tab(const Akaze *a) {
     T.ws[i] = norm;
     T.wm[i] = wgt * norm;
     T.sigma_size[i] = fround_h(L.esigma * 1.5f / (float)(1 << L.octave));  // the extrema pass's border test
+    T.ksize[i] = L.esigma * 1.5f;
+    T.octave[i] = L.octave;
     row += L.h;
   }
   T.row0[P.nlev] = row;
@@ -1343,12 +1837,6 @@ int build_scale_space(Akaze *a, const uint8_t *gray /*host; null: the image is a
 #undef s
 }
 
-struct HostKpt {
-  float x, y, size, angle, response;
-  int octave, class_id;
-  float patch[9];
-};
-
 // the per-level image pointers and sizes k_orient_describe works on (constant for an extractor: uploaded once)
 DevLevels dev_levels(const Akaze *a) {
   DevLevels LV;
@@ -1374,9 +1862,19 @@ int ensure_kp_cap(Akaze *a, unsigned int n) {
   a->d_kp = a->d_angle = nullptr;
   a->d_desc = nullptr;
   const unsigned int cap = std::max(n, 4096u);
+  if (a->d_resp) hipFree(a->d_resp);
+  if (a->d_kp6) hipFree(a->d_kp6);
+  a->d_resp = a->d_kp6 = nullptr;
+  if (a->d_qkpt) hipFree(a->d_qkpt);
+  if (a->d_qkpt6) hipFree(a->d_qkpt6);
+  a->d_qkpt = a->d_qkpt6 = nullptr;
+  AK_HIP(hipMalloc((void **)&a->d_qkpt, (size_t)cap * sizeof(float2)));
+  AK_HIP(hipMalloc((void **)&a->d_qkpt6, (size_t)cap * sizeof(float2)));
   AK_HIP(hipMalloc((void **)&a->d_kp, (size_t)cap * 4 * sizeof(float)));
   AK_HIP(hipMalloc((void **)&a->d_angle, (size_t)cap * sizeof(float)));
-  AK_HIP(hipMalloc((void **)&a->d_desc, (size_t)cap * 64));
+  AK_HIP(hipMalloc((void **)&a->d_desc, ((size_t)cap + 64) * 64));  // (+ the zero rows up to a multiple of 64)
+  AK_HIP(hipMalloc((void **)&a->d_resp, (size_t)cap * sizeof(float)));
+  AK_HIP(hipMalloc((void **)&a->d_kp6, (size_t)cap * 6 * sizeof(float)));
   a->kp_cap = cap;
   return SFMLOC_OK;
 }
@@ -1394,7 +1892,9 @@ int orient_describe_enqueue(Akaze *a, const std::vector<float> &kin, unsigned in
     if (n) AK_HIP(hipMemcpyAsync(a->d_kp, kin.data(), (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, a->stream.unordered()));
     sfm_launch<OrientDescribeBody>(a, k_orient_describe, dim3(grid_n), dim3(64), 0,
                                    reinterpret_cast<const DevLevels *>(a->d_dev_levels), a->d_kp, (int)n, a->d_gauss25, a->d_win,
-                                   a->plan.n_win, a->d_pair, a->d_angle, a->d_desc);
+                                   a->plan.n_win, a->d_pair, a->d_angle, a->d_desc,
+                                   (const unsigned int *)nullptr, (const float *)nullptr, (float *)nullptr,
+                                   (float2 *)nullptr, (float2 *)nullptr);
     AK_HIP(hipGetLastError());
   }
   if (phase != 1 && n) {
@@ -1424,7 +1924,9 @@ int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n) {
   if (rc || n == 0) return rc;
   sfm_launch<OrientDescribeBody>(a, k_orient_describe, dim3(n), dim3(64), 0,
                                  reinterpret_cast<const DevLevels *>(a->d_dev_levels), d_kin, (int)n, a->d_gauss25, a->d_win,
-                                 a->plan.n_win, a->d_pair, a->d_angle, a->d_desc);
+                                 a->plan.n_win, a->d_pair, a->d_angle, a->d_desc,
+                                   (const unsigned int *)nullptr, (const float *)nullptr, (float *)nullptr,
+                                   (float2 *)nullptr, (float2 *)nullptr);
   AK_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
@@ -1442,10 +1944,12 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   if (a->stream.own) hipStreamSynchronize(a->stream.own);
   gang_member_free(a);
   void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
-                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_level_tab, a->d_dev_levels, a->d_cand, a->d_ncand,
-                  a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc};
+                  a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_level_tab, a->d_dev_levels, a->d_ncand,
+                  a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc, a->d_seg, a->d_seg_x, a->d_cxy,
+                  a->d_clevel, a->d_cstatus, a->d_cready, a->d_cresp, a->d_cpatch, a->d_ckey, a->d_cslot, a->d_resp, a->d_kp6, a->d_qkpt, a->d_qkpt6};
   for (void *p : ptrs)
     if (p) hipFree(p);
+  if (a->h_counts) hipHostFree(a->h_counts);
   if (a->own_stream) hipStreamDestroy(a->own_stream);
   delete a;
 }
@@ -1454,8 +1958,8 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
                         sfmloc_akaze **out) {
   SFM_CHECK(out, SFMLOC_EINVAL, "sfmloc_akaze_create: null argument");
   *out = nullptr;
-  SFM_CHECK(width >= 16 && height >= 16 && width <= 16384 && height <= 16384, SFMLOC_EINVAL,
-            "sfmloc_akaze_create: image size %dx%d", width, height);
+  SFM_CHECK(width >= 16 && height >= 16 && width <= 16384 && height <= kSupMaxRows - 1, SFMLOC_EINVAL,
+            "sfmloc_akaze_create: image size %dx%d (at most 16384 x %d)", width, height, kSupMaxRows - 1);
   SFM_CHECK(n_octaves >= 1 && n_octaves <= 8 && n_sublevels >= 1 && n_octaves * n_sublevels <= kMaxLevels,
             SFMLOC_EINVAL, "sfmloc_akaze_create: nOct %d nOctLay %d", n_octaves, n_sublevels);
   int ndev = 0;
@@ -1490,8 +1994,30 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   A((void **)&a->d_half_steps, (size_t)kMaxLevels * 64 * 4);
   A((void **)&a->d_level_tab, sizeof(LevelTab));
   A((void **)&a->d_dev_levels, sizeof(DevLevels));
-  A((void **)&a->d_cand, (size_t)a->cand_cap * sizeof(Candidate9));
-  A((void **)&a->d_ncand, 4);
+  {
+    const LevelTab T0 = level_tab(a);
+    a->segs_per_row = 2u * (unsigned int)((width + 127) / 128);
+    a->n_seg = (unsigned int)T0.row0[T0.n] * a->segs_per_row;
+  }
+  const size_t cc = a->cand_cap;
+  A((void **)&a->d_ncand, 160 * sizeof(unsigned int));
+  A((void **)&a->d_seg, ((size_t)a->n_seg + 1) * sizeof(unsigned int));
+  A((void **)&a->d_seg_x, (size_t)a->n_seg * kSegMax);
+  A((void **)&a->d_cxy, cc * sizeof(uint32_t));
+  A((void **)&a->d_clevel, cc);
+  A((void **)&a->d_cstatus, cc);
+  A((void **)&a->d_cready, cc);
+  A((void **)&a->d_cresp, cc * sizeof(float));
+  A((void **)&a->d_cpatch, cc * 9 * sizeof(float));
+  A((void **)&a->d_ckey, cc * sizeof(unsigned int));
+  A((void **)&a->d_cslot, cc * sizeof(int));
+  if (he == hipSuccess) he = hipHostMalloc((void **)&a->h_counts, 160 * sizeof(unsigned int), hipHostMallocDefault);
+  if (he == hipSuccess && ensure_kp_cap(a, a->cand_cap) != SFMLOC_OK) he = hipErrorOutOfMemory;  // (never regrown later)
+  if (he == hipSuccess) {  // (k_suppress keeps two levels' candidates in LDS: more than the default 64 KB per workgroup)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_suppress),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SuppressLds));
+    he = attr;
+  }
   A((void **)&a->d_gauss25, 49 * 4);
   A((void **)&a->d_win, 64 * 4);
   A((void **)&a->d_pair, 486 * 2 * 2);
@@ -1554,21 +2080,63 @@ int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt) {
   return SFMLOC_OK;
 }
 
-// The device side of detection up to the extrema candidates of every level: launches only (an extractor that records for
-// a gang session takes part in ONE launch per kernel with the other images of the batch), no host synchronisation.
+// The whole of detectAndCompute on the device, launches only (an extractor that records for a gang session takes part in
+// ONE launch per kernel with the other images of the batch): scale space -> extrema, raster ordered -> duplicate
+// suppression + sub-pixel refinement (k_suppress) -> orientation + M-LDB of however many keypoints that left (the launch
+// is sized before the count is known: its workgroups stride over the keypoints).  No host synchronisation, nothing
+// leaves the device: d_ncand[1] keypoints, d_kp6 their six-float records, d_desc their .desc rows.
 static int akaze_detect_enqueue(Akaze *a, const uint8_t *gray) {
-  // (the counter is not touched by anything the scale space launches: it need not wait for recorded launches)
-  SFM_HIP(hipMemsetAsync(a->d_ncand, 0, sizeof(unsigned int), a->stream.unordered()));
   int rc = build_scale_space(a, gray);
   if (rc) return rc;
   const LevelTab T = level_tab(a);
-  sfm_launch<ExtremaAllBody>(a, k_extrema_all, dim3((a->w + 127) / 128, T.row0[T.n]), dim3(128), 0, a->d_Ldet, reinterpret_cast<const LevelTab *>(a->d_level_tab), a->thres,
-                             a->d_cand, a->cand_cap, a->d_ncand);
+  const dim3 egrid((a->w + 127) / 128, T.row0[T.n]);
+  const LevelTab *dT = reinterpret_cast<const LevelTab *>(a->d_level_tab);
+  CandArrays C{a->d_cxy, a->d_clevel, a->d_cresp, a->d_cpatch};
+  sfm_launch<ExtremaSegBody>(a, k_extrema_seg, egrid, dim3(128), 0, a->d_Ldet, dT, a->thres, a->d_seg_x, a->d_seg);
+  sfm_launch<SegScanBody>(a, k_seg_scan, dim3(1), dim3(1024), 0, a->d_seg, a->n_seg, a->cand_cap, a->d_ncand);
+  sfm_launch<ExtremaPlaceBody>(a, k_extrema_place, egrid, dim3(128), 0, a->d_Ldet, dT, a->d_seg_x, a->d_seg, a->cand_cap, C);
+  SuppressArgs S;
+  S.T = dT;
+  S.seg_base = a->d_seg;
+  S.segs_per_row = a->segs_per_row;
+  S.cap = a->cand_cap;
+  S.C = C;
+  S.status = a->d_cstatus;
+  S.ready = a->d_cready;
+  S.key = a->d_ckey;
+  S.slot = a->d_cslot;
+  S.kp = a->d_kp;
+  S.resp_out = a->d_resp;
+  S.n_kp = a->d_ncand + 1;
+  S.n_cand = a->d_ncand;
+  S.rounds_out = a->d_ncand + 2;
+  sfm_launch<SuppressBody>(a, k_suppress, dim3(1), dim3(1024), (uint32_t)sizeof(SuppressLds), S);
+  // orientation + M-LDB: a fixed grid that strides over the keypoints (their number is on the device)
+  unsigned int dgrid = (unsigned int)((size_t)a->w * a->h / 96);
+  dgrid = dgrid < 1024u ? 1024u : (dgrid > 16384u ? 16384u : dgrid);
+  sfm_launch<OrientDescribeBody>(a, k_orient_describe, dim3(dgrid), dim3(64), 0,
+                                 reinterpret_cast<const DevLevels *>(a->d_dev_levels), a->d_kp, 0, a->d_gauss25, a->d_win,
+                                 a->plan.n_win, a->d_pair, a->d_angle, a->d_desc, (const unsigned int *)(a->d_ncand + 1),
+                                 (const float *)a->d_resp, a->d_kp6, a->d_qkpt, a->d_qkpt6);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
 
-static int akaze_detect_finish(Akaze *a, float *kpts, uint8_t *desc64, uint32_t cap, uint32_t *n_out, double t_0);
+// the counts of one or more extractions (asynchronous on stream s; the caller synchronises), then their outputs
+static int akaze_counts_enqueue(Akaze *a, hipStream_t s) {
+  static const bool timing_counts = getenv("SFMLOC_AKAZE_TIMING") != nullptr;
+  SFM_HIP(hipMemcpyAsync(a->h_counts, a->d_ncand, (timing_counts ? 160 : 6) * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  return SFMLOC_OK;
+}
+static int akaze_outputs_enqueue(Akaze *a, float *kpts, uint8_t *desc64, uint32_t cap, uint32_t *n_out, hipStream_t s) {
+  const unsigned int nc = a->h_counts[0], n = a->h_counts[1];
+  SFM_CHECK(nc <= a->cand_cap, SFMLOC_ECAP, "AKAZE: %u extrema candidates exceed the workspace (%u)", nc, a->cand_cap);
+  *n_out = n;
+  SFM_CHECK(n <= cap, SFMLOC_ECAP, "AKAZE: %u keypoints, caller buffers hold %u", n, cap);
+  if (n && kpts) SFM_HIP(hipMemcpyAsync(kpts, a->d_kp6, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (n && desc64) SFM_HIP(hipMemcpyAsync(desc64, a->d_desc, (size_t)n * 64, hipMemcpyDeviceToHost, s));
+  return SFMLOC_OK;
+}
 
 int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float *kpts /*[cap*6]*/,
                                     uint8_t *desc64 /*[cap*64]*/, uint32_t cap, uint32_t *n_out) {
@@ -1579,200 +2147,30 @@ int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float
   const double t_0 = timing ? now_s() : 0.0;
   int rc = akaze_detect_enqueue(a, gray);
   if (rc) return rc;
-  return akaze_detect_finish(a, kpts, desc64, cap, n_out, t_0);
-}
-
-// One image's detection after the device has produced the extrema candidates, in stages so that a batch of images can
-// take each stage together (one host synchronisation per stage instead of three per image, the host's refinement of the
-// images in parallel): count -> candidates -> host refinement -> orientation + descriptors -> outputs.
-struct DetectState {
-  unsigned int nc = 0;
-  std::vector<Candidate9> cand;
-  std::vector<HostKpt> fin;
-  std::vector<float> kin, ang;
-  uint32_t n = 0;
-};
-
-// (a) the candidate count, asynchronously on stream s; the caller synchronises
-static int detect_count_enqueue(Akaze *a, DetectState &st, hipStream_t s) {
-  SFM_HIP(hipMemcpyAsync(&st.nc, a->d_ncand, sizeof(st.nc), hipMemcpyDeviceToHost, s));
-  return SFMLOC_OK;
-}
-// (b) the candidates themselves
-static int detect_candidates_read(Akaze *a, DetectState &st) {
-  SFM_CHECK(st.nc <= a->cand_cap, SFMLOC_ECAP, "AKAZE: %u extrema candidates exceed the workspace (%u)", st.nc, a->cand_cap);
-  st.cand.resize(st.nc);
-  if (st.nc) SFM_HIP(hipMemcpy(st.cand.data(), a->d_cand, (size_t)st.nc * sizeof(Candidate9), hipMemcpyDeviceToHost));
-  return SFMLOC_OK;
-}
-// (c) host only (no HIP call, no shared state: images can take it in parallel threads)
-static void detect_refine_host(const Akaze *a, DetectState &st) {
-  const AkPlan &P = a->plan;
-  std::vector<Candidate9> &cand = st.cand;
-  const unsigned int nc = st.nc;
-  std::vector<HostKpt> &fin = st.fin;
-  std::sort(cand.begin(), cand.end(), [](const Candidate9 &p, const Candidate9 &q) {
-    if (p.level != q.level) return p.level < q.level;
-    if (p.y != q.y) return p.y < q.y;
-    return p.x < q.x;
-  });
-  // OpenCV's sequential duplicate suppression (same / previous level while scanning, then against the upper level).
-  // The reference scans every accepted point for every candidate (quadratic: 2.1 ms for a 1080p frame); a uniform grid
-  // over the accepted points finds the same one -- "the first accepted point, in acceptance order, of this or the
-  // previous level within the candidate's radius" is the minimum index among the grid hits -- in 0.1 ms.
-  std::vector<HostKpt> aux;
-  aux.reserve(nc);
-  constexpr float kCell = 32.0f;
-  const int gw = (int)(a->w / kCell) + 2, gh = (int)(a->h / kCell) + 2;
-  std::vector<std::vector<uint32_t>> grid((size_t)gw * gh);
-  auto cell_of = [&](float v, int n) {
-    int c = (int)floorf(v / kCell);
-    return c < 0 ? 0 : (c >= n ? n - 1 : c);
-  };
-  for (const Candidate9 &c : cand) {
-    const AkLevel &L = P.lev[c.level];
-    HostKpt pt;
-    pt.response = fabsf(c.patch[4]);
-    pt.size = L.esigma * 1.5f;
-    pt.octave = L.octave;
-    pt.class_id = c.level;
-    pt.angle = 0.0f;
-    memcpy(pt.patch, c.patch, sizeof(pt.patch));
-    const float ratio = (float)(1 << L.octave);
-    pt.x = (float)c.x;
-    pt.y = (float)c.y;
-    bool is_extremum = true, is_repeated = false;
-    size_t id_repeated = 0;
-    {
-      const float px = pt.x * ratio, py = pt.y * ratio;
-      const int cx0 = cell_of(px - pt.size, gw), cx1 = cell_of(px + pt.size, gw);
-      const int cy0 = cell_of(py - pt.size, gh), cy1 = cell_of(py + pt.size, gh);
-      size_t first = (size_t)-1;
-      for (int cy = cy0; cy <= cy1; ++cy)
-        for (int cx = cx0; cx <= cx1; ++cx)
-          for (uint32_t ik : grid[(size_t)cy * gw + cx]) {
-            if (ik >= first) continue;
-            if (pt.class_id - 1 == aux[ik].class_id || pt.class_id == aux[ik].class_id) {
-              const float dx = pt.x * ratio - aux[ik].x, dy = pt.y * ratio - aux[ik].y;
-              const float dist = dx * dx + dy * dy;
-              if (dist <= pt.size * pt.size) first = ik;
-            }
-          }
-      if (first != (size_t)-1) {
-        if (pt.response > aux[first].response) {
-          id_repeated = first;
-          is_repeated = true;
-        } else {
-          is_extremum = false;
-        }
-      }
-    }
-    if (!is_extremum) continue;
-    pt.x = pt.x * ratio;
-    pt.y = pt.y * ratio;
-    const size_t dst_cell = (size_t)cell_of(pt.y, gh) * gw + cell_of(pt.x, gw);
-    if (!is_repeated) {
-      grid[dst_cell].push_back((uint32_t)aux.size());
-      aux.push_back(pt);
-    } else {
-      std::vector<uint32_t> &old = grid[(size_t)cell_of(aux[id_repeated].y, gh) * gw + cell_of(aux[id_repeated].x, gw)];
-      old.erase(std::find(old.begin(), old.end(), (uint32_t)id_repeated));
-      grid[dst_cell].push_back((uint32_t)id_repeated);
-      aux[id_repeated] = pt;
-    }
-  }
-  std::vector<HostKpt> kept;
-  kept.reserve(aux.size());
-  for (size_t i = 0; i < aux.size(); ++i) {
-    bool rep = false;
-    const int cx0 = cell_of(aux[i].x - aux[i].size, gw), cx1 = cell_of(aux[i].x + aux[i].size, gw);
-    const int cy0 = cell_of(aux[i].y - aux[i].size, gh), cy1 = cell_of(aux[i].y + aux[i].size, gh);
-    for (int cy = cy0; cy <= cy1 && !rep; ++cy)
-      for (int cx = cx0; cx <= cx1 && !rep; ++cx)
-        for (uint32_t j : grid[(size_t)cy * gw + cx])
-          if (j > i && aux[i].class_id + 1 == aux[j].class_id) {
-            const float dx = aux[i].x - aux[j].x, dy = aux[i].y - aux[j].y;
-            if (dx * dx + dy * dy <= aux[i].size * aux[i].size && aux[i].response < aux[j].response) {
-              rep = true;
-              break;
-            }
-          }
-    if (!rep) kept.push_back(aux[i]);
-  }
-  // Do_Subpixel_Refinement on the carried 3x3 patch
-  fin.clear();
-  fin.reserve(kept.size());
-  for (HostKpt k : kept) {
-    const float ratio = (float)(1 << k.octave);
-    const int x = fround_h(k.x / ratio), y = fround_h(k.y / ratio);
-    const float *p = k.patch;  // p[(dy+1)*3 + dx+1]
-    const float Dx = 0.5f * (p[5] - p[3]);
-    const float Dy = 0.5f * (p[7] - p[1]);
-    const float Dxx = (p[5] + p[3]) - 2.0f * p[4];
-    const float Dyy = (p[7] + p[1]) - 2.0f * p[4];
-    const float Dxy = 0.25f * (p[8] + p[0]) - 0.25f * (p[2] + p[6]);
-    const float det = Dxx * Dyy - Dxy * Dxy;
-    if (det == 0.0f) continue;
-    const float d0 = (-Dx * Dyy + Dy * Dxy) / det;
-    const float d1 = (-Dy * Dxx + Dx * Dxy) / det;
-    if (fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f) {
-      k.x = ((float)x + d0) * ratio;
-      k.y = ((float)y + d1) * ratio;
-      k.size = k.size * 2.0f;
-      fin.push_back(k);
-    }
-  }
-  const uint32_t n = (uint32_t)fin.size();
-  st.n = n;
-  st.kin.resize((size_t)n * 4);
-  st.ang.assign(n, 0.0f);
-  for (uint32_t i = 0; i < n; ++i) {
-    st.kin[4 * i] = fin[i].x;
-    st.kin[4 * i + 1] = fin[i].y;
-    st.kin[4 * i + 2] = fin[i].size;
-    st.kin[4 * i + 3] = (float)fin[i].class_id;
-  }
-}
-// (e) the keypoint records
-static void detect_outputs(const DetectState &st, float *kpts) {
-  if (!kpts) return;
-  for (uint32_t i = 0; i < st.n; ++i) {
-    kpts[6 * i] = st.fin[i].x;
-    kpts[6 * i + 1] = st.fin[i].y;
-    kpts[6 * i + 2] = st.fin[i].size;
-    kpts[6 * i + 3] = st.ang[i];
-    kpts[6 * i + 4] = st.fin[i].response;
-    kpts[6 * i + 5] = (float)st.fin[i].class_id;
-  }
-}
-
-static int akaze_detect_finish(Akaze *a, float *kpts, uint8_t *desc64, uint32_t cap, uint32_t *n_out, double t_0) {
-  static const bool timing = getenv("SFMLOC_AKAZE_TIMING") != nullptr;
-  DetectState st;
-  int rc = detect_count_enqueue(a, st, a->stream);
+  hipStream_t s = a->stream;
+  rc = akaze_counts_enqueue(a, s);
   if (rc) return rc;
-  SFM_HIP(hipStreamSynchronize(a->stream));
-  rc = detect_candidates_read(a, st);
-  if (rc) return rc;
+  SFM_HIP(hipStreamSynchronize(s));
   const double t_1 = timing ? now_s() : 0.0;
-  detect_refine_host(a, st);
-  *n_out = st.n;
-  SFM_CHECK(st.n <= cap, SFMLOC_ECAP, "AKAZE: %u keypoints, caller buffers hold %u", st.n, cap);
-  const double t_2 = timing ? now_s() : 0.0;
-  rc = orient_describe_enqueue(a, st.kin, st.n, st.ang.data(), desc64, 0);
+  rc = akaze_outputs_enqueue(a, kpts, desc64, cap, n_out, s);
   if (rc) return rc;
-  SFM_HIP(hipStreamSynchronize(a->stream));
+  SFM_HIP(hipStreamSynchronize(s));
   if (timing)
-    fprintf(stderr, "akaze %dx%d: scale space + extrema %.3f ms, host suppression + subpixel %.3f ms (%u candidates -> %u), "
-                    "orientation + M-LDB %.3f ms\n", a->w, a->h, (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, st.nc, st.n,
-            (now_s() - t_2) * 1e3);
-  detect_outputs(st, kpts);
+    fprintf(stderr, "akaze %dx%d: device (scale space .. descriptors) %.3f ms, outputs %.3f ms (%u candidates -> %u keypoints, "
+                    "%u suppression rounds: first pass %.1f us, second %.1f, sub-pixel + compaction %.1f)\n", a->w, a->h,
+            (t_1 - t_0) * 1e3, (now_s() - t_1) * 1e3, a->h_counts[0], a->h_counts[1], a->h_counts[2], a->h_counts[3] * 0.01,
+            a->h_counts[4] * 0.01, a->h_counts[5] * 0.01);
+  if (timing) {
+    for (int l = 0; l < a->plan.nlev; ++l)
+      fprintf(stderr, "  level %2d: %5u candidates, %2u rounds, fill %.1f us, rounds %.1f us\n", l, a->h_counts[10 + 4 * l],
+              a->h_counts[11 + 4 * l], a->h_counts[12 + 4 * l] * 0.01, a->h_counts[13 + 4 * l] * 0.01);
+  }
   return SFMLOC_OK;
 }
 
-// Several images of one size at once: extractor i takes image i; the scale spaces, determinants and extrema of all of them
-// go out as ONE launch per kernel (a gang session on the first extractor's stream); the candidates' refinement on the
-// host and the orientation + M-LDB launch follow per image.  Results are those of n separate calls.
+// Several images of one size at once: extractor i takes image i; every kernel of the chain goes out as ONE launch for all
+// of them (a gang session on the first extractor's stream), then one synchronisation for the counts and one for the
+// outputs.  Results are those of n separate calls.
 int sfmloc_akaze_detect_and_compute_batch(sfmloc_akaze *const *aks, const uint8_t *const *grays, uint32_t n,
                                           float *const *kpts, uint8_t *const *descs, uint32_t cap, uint32_t *n_out) {
   SFM_CHECK(aks && grays && kpts && n_out && n >= 1 && n <= (uint32_t)kGangMembers, SFMLOC_EINVAL,
@@ -1796,58 +2194,74 @@ int sfmloc_akaze_detect_and_compute_batch(sfmloc_akaze *const *aks, const uint8_
   const int rc_close = gang_close(first);
   if (rc == SFMLOC_OK) rc = rc_close;
   if (rc) return rc;
-  double t_s[6] = {t_0, 0, 0, 0, 0, 0};
-  if (timing) t_s[1] = now_s();
-  // every stage for all the images, one host synchronisation per stage
-  std::vector<DetectState> st(n);
-  hipStream_t s0 = first->stream;  // (the gang's stream: the candidates of every image were produced on it)
-  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = detect_count_enqueue(reinterpret_cast<Akaze *>(aks[i]), st[i], s0);
+  const double t_1 = timing ? now_s() : 0.0;
+  hipStream_t s0 = first->stream;  // (the gang's stream: everything of every image was produced on it)
+  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = akaze_counts_enqueue(reinterpret_cast<Akaze *>(aks[i]), s0);
   if (rc) return rc;
   SFM_HIP(hipStreamSynchronize(s0));
-  if (timing) t_s[2] = now_s();
-  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = detect_candidates_read(reinterpret_cast<Akaze *>(aks[i]), st[i]);
+  const double t_2 = timing ? now_s() : 0.0;
+  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i)
+    rc = akaze_outputs_enqueue(reinterpret_cast<Akaze *>(aks[i]), kpts[i], descs ? descs[i] : nullptr, cap, &n_out[i], s0);
   if (rc) return rc;
-  if (timing) t_s[3] = now_s();
-  {  // the host's refinement: images are independent
-    const unsigned nthr = n < 8 ? n : 8;
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nthr; ++t)
-      th.emplace_back([&, t] {
-        for (uint32_t i = t; i < n; i += nthr) detect_refine_host(reinterpret_cast<const Akaze *>(aks[i]), st[i]);
-      });
-    for (uint32_t i = 0; i < n; i += nthr) detect_refine_host(reinterpret_cast<const Akaze *>(aks[i]), st[i]);
-    for (auto &t : th) t.join();
-  }
-  if (timing) t_s[4] = now_s();
-  for (uint32_t i = 0; i < n; ++i) {
-    n_out[i] = st[i].n;
-    SFM_CHECK(st[i].n <= cap, SFMLOC_ECAP, "AKAZE: %u keypoints, caller buffers hold %u", st[i].n, cap);
-  }
-  // orientation + M-LDB of every frame in ONE launch (a second session; the launch is as large as the frame with most
-  // keypoints needs, a workgroup beyond a frame's own count leaves at once), then the downloads
-  unsigned int most = 0;
-  for (uint32_t i = 0; i < n; ++i) most = st[i].n > most ? st[i].n : most;
-  if (most) {
-    rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
-    for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i)
-      rc = orient_describe_enqueue(reinterpret_cast<Akaze *>(aks[i]), st[i].kin, st[i].n, nullptr, nullptr, 1, most);
-    const int rc2 = gang_close(first);
-    if (rc == SFMLOC_OK) rc = rc2;
-    for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i)
-      rc = orient_describe_enqueue(reinterpret_cast<Akaze *>(aks[i]), st[i].kin, st[i].n, st[i].ang.data(),
-                                   descs ? descs[i] : nullptr, 2);
-  }
-  if (rc) return rc;
-  for (uint32_t i = 0; i < n; ++i) SFM_HIP(hipStreamSynchronize(reinterpret_cast<Akaze *>(aks[i])->stream));
-  for (uint32_t i = 0; i < n; ++i) detect_outputs(st[i], kpts[i]);
+  SFM_HIP(hipStreamSynchronize(s0));
+  // the members' own streams were made to wait for the session (gang_close); nothing of theirs is pending beyond it
   if (timing)
-    fprintf(stderr, "akaze batch of %u (%dx%d): launches queued %.3f ms, scale spaces + extrema done %.3f, candidates read "
-                    "%.3f, host refinement %.3f, orientation + M-LDB + outputs %.3f\n", n, first->w, first->h,
-            (t_s[1] - t_s[0]) * 1e3, (t_s[2] - t_s[1]) * 1e3, (t_s[3] - t_s[2]) * 1e3, (t_s[4] - t_s[3]) * 1e3,
-            (now_s() - t_s[4]) * 1e3);
+    fprintf(stderr, "akaze batch of %u (%dx%d): launches queued %.3f ms, device %.3f, outputs %.3f\n", n, first->w, first->h,
+            (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (now_s() - t_2) * 1e3);
   return SFMLOC_OK;
 }
 
+
+// detectAndCompute whose outputs STAY on the device, laid out as a query block: descriptors [n x 64] followed by zero
+// rows up to a multiple of 64, keypoints (x, y) and the keypoints after the .feat text round trip -- what
+// sfmloc_query_create_view takes.  Only the count comes back (one 4-byte copy + one synchronisation per call).
+int sfmloc_akaze_detect_resident_batch(sfmloc_akaze *const *aks, const uint8_t *const *grays, uint32_t n, uint32_t *n_out) {
+  SFM_CHECK(aks && grays && n_out && n >= 1 && n <= (uint32_t)kGangMembers, SFMLOC_EINVAL,
+            "sfmloc_akaze_detect_resident_batch: 1..%d images", kGangMembers);
+  GangMember *ms[kGangMembers];
+  Akaze *first = reinterpret_cast<Akaze *>(aks[0]);
+  for (uint32_t i = 0; i < n; ++i) {
+    Akaze *a = reinterpret_cast<Akaze *>(aks[i]);
+    SFM_CHECK(a && grays[i], SFMLOC_EINVAL, "sfmloc_akaze_detect_resident_batch: null argument (image %u)", i);
+    SFM_CHECK(a->device == first->device && a->w == first->w && a->h == first->h, SFMLOC_EINVAL,
+              "sfmloc_akaze_detect_resident_batch: the extractors differ in device or image size");
+    SFM_CHECK(a->stream.gang == nullptr, SFMLOC_EINVAL, "sfmloc_akaze_detect_resident_batch: extractor %u is in a session", i);
+    for (uint32_t j = 0; j < i; ++j) SFM_CHECK(aks[j] != aks[i], SFMLOC_EINVAL, "extractor listed twice");
+    ms[i] = a;
+  }
+  SFM_HIP(hipSetDevice(first->device));
+  int rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
+  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = akaze_detect_enqueue(reinterpret_cast<Akaze *>(aks[i]), grays[i]);
+  const int rc_close = n > 1 ? gang_close(first) : SFMLOC_OK;
+  if (rc == SFMLOC_OK) rc = rc_close;
+  if (rc) return rc;
+  hipStream_t s0 = first->stream;
+  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = akaze_counts_enqueue(reinterpret_cast<Akaze *>(aks[i]), s0);
+  if (rc) return rc;
+  SFM_HIP(hipStreamSynchronize(s0));
+  for (uint32_t i = 0; i < n; ++i) {
+    Akaze *a = reinterpret_cast<Akaze *>(aks[i]);
+    SFM_CHECK(a->h_counts[0] <= a->cand_cap, SFMLOC_ECAP, "AKAZE: %u extrema candidates exceed the workspace (%u)",
+              a->h_counts[0], a->cand_cap);
+    n_out[i] = a->h_counts[1];
+  }
+  return SFMLOC_OK;
+}
+
+int sfmloc_akaze_detect_resident(sfmloc_akaze *ak, const uint8_t *gray, uint32_t *n_out) {
+  return sfmloc_akaze_detect_resident_batch(&ak, &gray, 1, n_out);
+}
+
+int sfmloc_akaze_resident_arrays(sfmloc_akaze *ak, const void **desc_dev, const void **kpt_dev, const void **kpt6_dev,
+                                 const void **kp6_dev) {
+  SFM_CHECK(ak, SFMLOC_EINVAL, "sfmloc_akaze_resident_arrays: null argument");
+  Akaze *a = reinterpret_cast<Akaze *>(ak);
+  if (desc_dev) *desc_dev = a->d_desc;
+  if (kpt_dev) *kpt_dev = a->d_qkpt;
+  if (kpt6_dev) *kpt6_dev = a->d_qkpt6;
+  if (kp6_dev) *kp6_dev = a->d_kp6;
+  return SFMLOC_OK;
+}
 
 int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin, uint32_t n, uint8_t *desc64,
                          float *angle_out) {

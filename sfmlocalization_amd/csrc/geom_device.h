@@ -24,6 +24,46 @@ GD double q_nan() { return u2d(0x7FF8000000000000ull); }
 GD double dabs(double x) { return x < 0.0 ? -x : x; }
 GD double dmax(double a, double b) { return a > b ? a : b; }
 
+// The .feat text round trip of a keypoint coordinate on the device: what `snprintf("%.6g", (double)v)` followed by
+// `strtof` returns (sfmloc_feat_round_trip, AKAZEOpenCV.cpp:80-81 / :106-111: the query's features are written to a
+// .feat file at the default stream precision and read back).  v is exact in double; it is scaled by an exact power of
+// ten to 6 significant digits before the decimal point, rounded half-to-even (printf rounds the exact binary value), and
+// the decimal r * 10^(e-5) is taken back to float through one correctly rounded division -- no float midpoint lies within
+// 2^-53 of such a quotient for |v| >= 1, so the double rounding is harmless there.  Values of 10^6 and more are rounded
+// in integer arithmetic.  Exact for 1e-10 <= |v| < 1e15 (a keypoint coordinate is a pixel position); outside that range
+// the value is returned as it is.
+GD float round6_dev(float vf) {
+  const double p10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+  if (!(vf == vf) || vf == 0.0f) return vf;
+  const bool neg = vf < 0.0f;
+  const double v = neg ? -(double)vf : (double)vf;
+  if (!(v >= 1e-10 && v < 1e15)) return vf;
+  double res;
+  if (v >= 1e6) {  // 6 digits end left of the decimal point: integer arithmetic
+    int e = 6;
+    while (e < 14 && v >= p10[e + 1]) ++e;
+    const long long D = (long long)p10[e - 5];
+    const long long iv = (long long)v;         // (truncation; v < 2^53)
+    const double frac = v - (double)iv;        // exact
+    long long q = iv / D;
+    const long long rem = iv % D;
+    const double twice = 2.0 * ((double)rem + frac);  // exact: rem < 1e9, frac a few bits
+    if (twice > (double)D || (twice == (double)D && (q & 1))) ++q;
+    res = (double)(q * D);
+  } else if (v >= 1.0) {
+    int e = 0;
+    while (e < 5 && v >= p10[e + 1]) ++e;
+    const double r = rint(v * p10[5 - e]);     // exact product, half-to-even
+    res = r / p10[5 - e];
+  } else {
+    int k = 1;
+    while (k < 10 && v * p10[k] < 1.0) ++k;    // 10^-k <= v < 10^-(k-1): e = -k
+    const double r = rint(v * p10[5 + k]);
+    res = r / p10[5 + k];
+  }
+  return (float)(neg ? -res : res);
+}
+
 // log10 by a fixed operation order: x = m 2^e, m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh((m-1)/(m+1))
 GDN double det_log10(double x) {
   if (is_nan(x) || x < 0.0) return q_nan();

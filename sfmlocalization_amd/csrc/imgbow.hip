@@ -141,6 +141,11 @@ int sfmloc_imgbow_dim(const sfmloc_imgbow *p) {
   return ib ? sfmloc_bof_dim(ib->bof) : 0;
 }
 
+const void *sfmloc_imgbow_vector_dev(const sfmloc_imgbow *p) {
+  const ImgBow *ib = reinterpret_cast<const ImgBow *>(p);
+  return ib ? ib->d_out_f32 : nullptr;
+}
+
 int sfmloc_imgbow_share_stream(sfmloc_imgbow *p, sfmloc_context *ctx) {
   SFM_CHECK(p, SFMLOC_EINVAL, "sfmloc_imgbow_share_stream: null argument");
   ImgBow *ib = reinterpret_cast<ImgBow *>(p);

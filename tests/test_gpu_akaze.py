@@ -12,7 +12,7 @@ def bits32(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("shape,seed", [((480, 640), 1), ((300, 300), 2), ((270, 481), 3)])
+@pytest.mark.parametrize("shape,seed", [((480, 640), 1), ((300, 300), 2), ((270, 481), 3), ((1080, 1920), 4)])
 def test_detect_and_compute_matches_oracle(oracle_c, shape, seed):
     g = synth.texture_image(seed, *shape)
     ekp, edesc, eldet, elt = oracle_c.akaze_detect_and_compute(g, want_levels=True)
