@@ -211,12 +211,16 @@ def build(S, seed, n_real_views, n_queries, tiles=4, tile_px=1600, px_per_m=100.
             pad[p0:p0 + len(src)] = src.reshape(len(src), cells, K)[:, :, perm].reshape(len(src), -1)
         bow = np.concatenate([real_bow, pad]) if n_pad_views else real_bow
     # query frames
-    q_place = rng.integers(0, n_places, n_queries)
+    # each from a new pose near one of the map views (within a metre of its centre, own height, tilt and roll): the
+    # frame overlaps what the map has seen, as a query taken where the map was recorded does
+    q_view = rng.integers(0, n_real_views, n_queries)
+    q_place = view_place[q_view]
     qR, qC = [], []
-    for p in q_place:
-        R, C = cameras(rng, 1, place_xy[p], tile_m, height=(9.0, 11.0), tilt=0.10, margin=5.0)
-        qR.append(R[0])
-        qC.append(C[0])
+    for v in q_view:
+        cxy = (Cs[v][0] + rng.uniform(-1.0, 1.0), Cs[v][1] + rng.uniform(-1.0, 1.0))
+        R, C = synth.plane_camera(rng, cxy, rng.uniform(9.0, 11.0), tilt=0.10)
+        qR.append(R)
+        qC.append(C)
     qR, qC = np.stack(qR), np.stack(qC)
     frames = render(atlas, px_per_m, qR, qC, focal, width, height)
     del atlas

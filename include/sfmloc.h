@@ -534,6 +534,9 @@ int sfmloc_imgbow_compute(sfmloc_imgbow *ib, const uint8_t *image, sfmloc_query 
 /* where the float32 vector of a call WITHOUT a query lands (device memory, [sfmloc_imgbow_dim] floats): the bow_dev of a
  * query view (sfmloc_query_create_view) over an extractor's resident outputs */
 const void *sfmloc_imgbow_vector_dev(const sfmloc_imgbow *ib);
+/* an extractor on a stream of its own (not shared) works beside the feature extraction of the same frame; this makes the
+ * context's stream wait for everything the extractor has queued so far (call it before sfmloc_localize_bow_begin) */
+int sfmloc_imgbow_order_before(sfmloc_imgbow *ib, sfmloc_context *ctx);
 
 /* ------------------------------------------------------------------------- */
 /* Map-side matching: the reference's matchAKAZE /         */

@@ -122,7 +122,7 @@ SYMBOLS = [
     "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing", "sfmloc_context_create_merge",
     "sfmloc_query_create_view", "sfmloc_feat_round_trip",
     "sfmloc_imgbow_create", "sfmloc_imgbow_destroy", "sfmloc_imgbow_dim", "sfmloc_imgbow_share_stream", "sfmloc_imgbow_compute",
-    "sfmloc_imgbow_vector_dev", "sfmloc_akaze_detect_resident", "sfmloc_akaze_detect_resident_batch", "sfmloc_akaze_resident_arrays",
+    "sfmloc_imgbow_vector_dev", "sfmloc_imgbow_order_before", "sfmloc_akaze_detect_resident", "sfmloc_akaze_detect_resident_batch", "sfmloc_akaze_resident_arrays",
 ]
 
 _bound = False
@@ -283,6 +283,7 @@ def _L():
         L.sfmloc_imgbow_dim.argtypes = [C.c_void_p]
         L.sfmloc_imgbow_share_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_imgbow_compute.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_void_p, F64P]
+        L.sfmloc_imgbow_order_before.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_imgbow_vector_dev.restype = C.c_void_p
         L.sfmloc_imgbow_vector_dev.argtypes = [C.c_void_p]
         L.sfmloc_akaze_detect_resident.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), U32P]
@@ -873,6 +874,10 @@ class ImgBow:
 
     def share_stream(self, ctx):
         _check(_L().sfmloc_imgbow_share_stream(self._h, None if ctx is None else ctx._h))
+
+    def order_before(self, ctx):
+        """the context's stream waits for what this extractor has queued (an extractor on a stream of its own)"""
+        _check(_L().sfmloc_imgbow_order_before(self._h, ctx._h))
 
     def vector_dev(self):
         """device address of the float32 vector a compute() without a query writes (a query view's bow_dev)"""

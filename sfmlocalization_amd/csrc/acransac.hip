@@ -1231,11 +1231,16 @@ __device__ __forceinline__ int p3p_round_batch(int n, int batch) {
 // evaluated for ~1.3x the rounds (+8 % queries per second at 12 in flight; the policy's constants hardly matter,
 // profiles/r02_p3p_adaptive_policy.txt).  A query alone on the GPU keeps full batches: rounds are what its latency is
 // made of.
-__device__ __forceinline__ int p3p_next_batch_limit(const P3pArgs &A, int identity, long iter, long switch_iter) {
-  if (!A.adaptive_batch || identity) return 1 << 30;
+__device__ __forceinline__ int p3p_next_batch_limit(const P3pArgs &A, int identity, long iter, long switch_iter, int n) {
+  // (more than 512 correspondences: a model that passes the NFA filter costs a block-wide sort, and right after the
+  // switch nearly every hypothesis passes -- its reference is the FIRST meaningful model -- while everything behind the
+  // round's first improvement is thrown away: small rounds first, also for a query alone on the GPU)
+  const bool costly = next_pow2(n) >= 1024;
+  if ((!A.adaptive_batch && !costly) || identity) return 1 << 30;
   const long t = iter - switch_iter;
   const long m = (A.adapt_quarters * t) / 4;
-  return (int)(m < A.adapt_floor ? A.adapt_floor : (m > kP3pBatchMax ? kP3pBatchMax : m));
+  const long floor_ = costly && !A.adaptive_batch ? 16 : A.adapt_floor;
+  return (int)(m < floor_ ? floor_ : (m > kP3pBatchMax ? kP3pBatchMax : m));
 }
 __device__ __forceinline__ size_t p3p_inl_stride(int n, int max_n) { return n > kP3pMaxN ? (size_t)max_n : (size_t)kP3pMaxN; }
 
@@ -1413,17 +1418,101 @@ __device__ __forceinline__ bool p3p_filter_model(P3pFilterLds &F, int wv, const 
   return __ballot(any) != 0ull;
 }
 
+// one model, the whole workgroup: can it beat B?  (p3p_filter_model with the four waves sharing the elements and ONE
+// table of counts; every thread returns the verdict; two barriers inside)
+__device__ __forceinline__ bool p3p_filter_model_block(P3pFilterLds &F, const double (&M)[12], int n, int s,
+                                                       const double *__restrict__ pt3d, const double *__restrict__ xn) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sh = p3p_filter_shift(n);
+  const int nb = (n >> sh) + 1;
+  uint32_t *h = F.hist[0];
+  for (int j = tid; j < nb; j += kThreads) h[j] = 0u;
+  __syncthreads();
+  int steps = 0;
+  while ((1 << steps) < nb + 1) ++steps;
+  constexpr int U = 4;
+  for (int p0 = 0; p0 < n; p0 += kThreads * U) {
+    double r[U];
+    int lo[U], hi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + kThreads * u + tid;
+      const int pc = p < n ? p : n - 1;
+      const double e = err_resection(M, pt3d[3 * pc], pt3d[3 * pc + 1], pt3d[3 * pc + 2], xn[2 * pc], xn[2 * pc + 1]);
+      r[u] = e + (double)FLT_EPSILON;
+      lo[u] = 0;
+      hi[u] = nb;
+    }
+    for (int it = 0; it < steps; ++it) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int mid = (lo[u] + hi[u]) >> 1;
+        const bool below = mid < nb && r[u] < F.T[mid < nb ? mid : nb - 1];
+        const bool open = lo[u] < hi[u];
+        hi[u] = (open && below) ? mid : hi[u];
+        lo[u] = (open && !below) ? mid + 1 : lo[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (p0 + kThreads * u + tid < n && lo[u] < nb) atomicAdd(&h[lo[u]], 1u);
+  }
+  __syncthreads();
+  // every wave walks the same table of counts and reaches the same verdict
+  constexpr int per = (kP3pFilterBins + 4 + 63) / 64;
+  uint32_t c[per];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < per; ++i) {
+    const int j = lane * per + i;
+    sum += j < nb ? h[j] : 0u;
+    c[i] = sum;
+  }
+  uint32_t inc = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  const uint32_t before = inc - sum;
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < per; ++i) {
+    const int j = lane * per + i;
+    const int k_lo = (j << sh) > s + 1 ? (j << sh) : s + 1;
+    const int k_hi = (j << sh) + (1 << sh) - 1;
+    if (j < nb && k_hi > s && k_lo <= n && before + c[i] >= (uint32_t)k_lo) any = true;
+  }
+  return __ballot(any) != 0ull;
+}
+
 // one hypothesis: sample, solve, evaluate the (up to 4) models, leave the best one's NFA / inliers / model in the
-// round's result arrays.  Executed by one workgroup of k_p3p_round.
-__device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch, unsigned char *smem_raw) {
+// round's result arrays.  Executed by one workgroup of k_p3p_round -- or, in a WIDE launch (four workgroups per
+// hypothesis: model m of hypothesis b is workgroup m * batch + b) and from 513 correspondences on, by four, one model each: a model's residuals are
+// two f64 divisions per correspondence and a lone wave issues one instruction every ~5 cycles, so with a wave per model
+// 2 000 correspondences are 32 per lane (45 us for the filter alone, 105 us for a model that has to be sorted), and a
+// hypothesis's models wait for each other; with a workgroup per model it is 8 per thread, four times as many waves on the
+// compute unit, and the four models of a hypothesis side by side.  Results go to slot 4 b + m; the replay takes the
+// best model of each hypothesis (the first on ties, as the sequential loop over a hypothesis's models does).
+__device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch, int wide, unsigned char *smem_raw) {
   const P3pState &st = *A.state;
-  const int b = blockIdx.x;
+  const int per_model = wide ? (int)(gridDim.x >> 2) : (int)gridDim.x;  // hypotheses of the launch
+  const int b = (int)blockIdx.x % per_model;
+  const int mdl = (int)blockIdx.x / per_model;
+  const int slot = wide ? 4 * b + mdl : b;
   const int n = st.n;
   if (b >= p3p_round_batch(n, batch) || b >= st.batch_limit) return;
   const long it = (long)st.iter + b;
   if (it >= st.n_iter) return;
   P3pShared &S = *reinterpret_cast<P3pShared *>(smem_raw);
   const int tid = threadIdx.x;
+  constexpr int s = 3;
+  const int P = next_pow2(n);
+  // one model per workgroup: a wide launch with enough correspondences (and the LDS forms: n <= kP3pMaxN)
+  const bool single = wide && P >= 1024 && n <= kP3pMaxN;
+  if (wide && !single && mdl != 0) {  // this hypothesis is workgroup 4 b's alone
+    if (tid == 0) store_through(A.hyp_nfa + slot, pos_inf());
+    return;
+  }
 #ifdef SFMLOC_STAMPS
   const int stamp_round = st.rounds;
 #endif
@@ -1432,8 +1521,6 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   // where the block-wide sort of this hypothesis runs
   uint64_t *const skey = n > kP3pMaxN ? A.ws_key + (size_t)b * A.max_n : S.key;
   uint32_t *const sidx = n > kP3pMaxN ? A.ws_idx + (size_t)b * A.max_n : S.idx;
-  constexpr int s = 3;
-  const int P = next_pow2(n);
   const bool fast = P <= kP3pWaveSeg;
   const double logalpha0 = det_log10(3.14159265358979323846);
   const double loge0 = det_log10(4.0 * (double)(n - s));
@@ -1461,48 +1548,61 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   __syncthreads();
   STAMP_P3P(stamp_round, b, 2);
   const int nm = S.nm;
+  if (single && mdl >= nm) {  // (uniform over the workgroup) no such root
+    if (tid == 0) store_through(A.hyp_nfa + slot, pos_inf());
+    return;
+  }
   if (tid < nm) p3p_kneip_model(S.prep, tid, S.models + 12 * tid);  // the four roots' models side by side
   if (filter) p3p_filter_scan(F, n);  // (two barriers inside: the models are visible behind them too)
   else __syncthreads();
   STAMP_P3P(stamp_round, b, 3);
-  if (!fast) {
+  if (!fast || single) {
     STAMP_P3P(stamp_round, b, 6);   // (the register path stamps 6 / 7 around its sort)
   }
-  bool pass_mine = true;   // fast path: this wave's model; LDS path: read from F.pass
+  // which models have to be evaluated: bit k = model k (one model per workgroup: bit mdl only)
+  int pass_mask = single ? (1 << mdl) : 0xF;
   if (filter) {
-    const int wv = tid >> 6;
-    if (wv < nm) {
+    if (single) {
       double M[12];
 #pragma unroll
-      for (int q = 0; q < 12; ++q) M[q] = S.models[12 * wv + q];
-      pass_mine = p3p_filter_model(F, wv, M, n, s, A.pt3d, A.xn);
+      for (int q = 0; q < 12; ++q) M[q] = S.models[12 * mdl + q];
+      pass_mask = p3p_filter_model_block(F, M, n, s, A.pt3d, A.xn) ? (1 << mdl) : 0;
+      __syncthreads();  // F (in S.key) is dead from here on
+    } else {
+      const int wv = tid >> 6;
+      bool pass_mine = false;
+      if (wv < nm) {
+        double M[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) M[q] = S.models[12 * wv + q];
+        pass_mine = p3p_filter_model(F, wv, M, n, s, A.pt3d, A.xn);
+      }
+      if ((tid & 63) == 0) F.pass[wv] = pass_mine ? 1 : 0;
+      __syncthreads();
+      pass_mask = 0;
+      for (int k = 0; k < 4; ++k) pass_mask |= F.pass[k] << k;
+      __syncthreads();  // F (in S.key) is dead from here on: the LDS sort may overwrite it
     }
-    if ((tid & 63) == 0) F.pass[wv] = (wv < nm && pass_mine) ? 1 : 0;
-    __syncthreads();
   }
-  int pass_mask = 0xF;
-  if (filter) {
-    pass_mask = 0;
-    for (int k = 0; k < 4; ++k) pass_mask |= F.pass[k] << k;
-    __syncthreads();  // F (in S.key) is dead from here on: the LDS sort may overwrite it
-  }
-  if (!fast) {
+  if (!fast || single) {
     STAMP_P3P(stamp_round, b, 7);   // LDS path: 3 -> 6 = table scan, 6 -> 7 = the filter, 7 -> 4 = the models that passed
   }
   double best = pos_inf();
   int best_k = 0, best_m = -1;
   double best_err = pos_inf();
   if (fast) {
-    // fast path: the (up to 4) models of the hypothesis are evaluated side by side, one wave each, residuals
-    // sorted in registers
+    // register path: a model is evaluated by ONE wave, residuals sorted in its registers; the (up to 4) models of the
+    // hypothesis side by side, one wave each -- or (one model per workgroup) wave 0 takes the workgroup's model
     const int wv = tid >> 6, lane = tid & 63;
+    const int my_model = single ? mdl : wv;
+    const bool mine = single ? (wv == 0) : (wv < nm);
     uint32_t *iw = S.idx + (size_t)wv * kP3pWaveSeg;
     NfaBest r{pos_inf(), 0x7FFFFFFF};
     double r_err = pos_inf();
-    if (wv < nm && ((pass_mask >> wv) & 1)) {
+    if (mine && ((pass_mask >> my_model) & 1)) {
       double M[12];
 #pragma unroll
-      for (int q = 0; q < 12; ++q) M[q] = S.models[12 * wv + q];
+      for (int q = 0; q < 12; ++q) M[q] = S.models[12 * my_model + q];
       // (the lambda must not capture the kernel-argument struct: that would put all of it on the stack)
       const double *pt3d = A.pt3d, *xn = A.xn;
       const float *logc_n = A.logc_n, *logc_k = A.logc_k;
@@ -1549,16 +1649,18 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     }
     __syncthreads();
     STAMP_P3P(stamp_round, b, 4);
-    for (int k = 0; k < nm; ++k)
+    // (one model per workgroup: wave 0 holds the model's result, the other waves +inf)
+    for (int k = 0; k < (single ? 1 : nm); ++k)
       if (S.red_nfa[k] < best) {  // strict: the first model of the hypothesis wins ties, as the sequential loop does
         best = S.red_nfa[k];
         best_k = S.red_k[k];
-        best_m = k;
+        best_m = single ? mdl : k;
       }
     if (best_m >= 0) {
-      best_err = S.red_err[best_m];
-      int32_t *dst = A.hyp_inl + (size_t)b * inl_stride;
-      const uint32_t *src = S.idx + (size_t)best_m * kP3pWaveSeg;
+      const int w_best = single ? 0 : best_m;
+      best_err = S.red_err[w_best];
+      int32_t *dst = A.hyp_inl + (size_t)slot * inl_stride;
+      const uint32_t *src = S.idx + (size_t)w_best * kP3pWaveSeg;
       for (int p = tid; p < best_k; p += kThreads) store_through(dst + p, (int32_t)src[p]);
     }
   } else
@@ -1583,7 +1685,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
       best_k = r.k;
       best_m = k;
       best_err = u2d(skey[r.k - 1]);
-      int32_t *dst = A.hyp_inl + (size_t)b * inl_stride;
+      int32_t *dst = A.hyp_inl + (size_t)slot * inl_stride;
       for (int p = tid; p < best_k; p += kThreads) store_through(dst + p, (int32_t)sidx[p]);
     }
   }
@@ -1591,11 +1693,11 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     STAMP_P3P(stamp_round, b, 4);
   }
   if (tid == 0) {
-    store_through(A.hyp_nfa + b, best);
-    store_through(A.hyp_k + b, best_k);
-    store_through(A.hyp_err + b, best_err);
+    store_through(A.hyp_nfa + slot, best);
+    store_through(A.hyp_k + slot, best_k);
+    store_through(A.hyp_err + slot, best_err);
     if (best_m >= 0)
-      for (int q = 0; q < 12; ++q) store_through(A.hyp_model + 12 * b + q, S.models[12 * best_m + q]);
+      for (int q = 0; q < 12; ++q) store_through(A.hyp_model + 12 * slot + q, S.models[12 * best_m + q]);
   }
   STAMP_P3P(stamp_round, b, 5);
 }
@@ -1775,9 +1877,18 @@ struct P3pReplayShared {
   double nfa[kP3pBatchMax];
   double err[kP3pBatchMax];
   int k[kP3pBatchMax];
+  unsigned char m[kP3pBatchMax];  // wide launches: which of a hypothesis's four slots holds its best model
   int first[kThreads / 64];
 };
-__device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pReplayShared &RS) {
+// wide4: the launch has four result slots per hypothesis (4 b + m) and all four were written (one model per workgroup);
+// a wide launch whose query turned out small wrote slot 4 b only, a plain launch slot b
+__device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int wide4, int slot_mul, P3pReplayShared &RS);
+__device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, int single_mode, P3pReplayShared &RS) {
+  // (gridDim.x is 4 x batch in a wide launch -- the kernel's `wide` argument -- and batch otherwise)
+  const int slot_mul = (int)gridDim.x == batch ? 1 : 4;
+  p3p_replay_impl(A, batch, single_mode, slot_mul, RS);
+}
+__device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int wide, int slot_mul, P3pReplayShared &RS) {
   P3pState &st = *A.state;
   const int tid = threadIdx.x;
 #ifdef SFMLOC_STAMPS
@@ -1802,9 +1913,23 @@ __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pRepla
   int *const s_k = RS.k;
   for (int b = tid; b < batch && b < kP3pBatchMax; b += kThreads) {
     const bool live = iter0 + b < n_iter;
-    s_nfa[b] = live ? A.hyp_nfa[b] : pos_inf();
-    s_err[b] = live ? A.hyp_err[b] : 0.0;
-    s_k[b] = live ? A.hyp_k[b] : 0;
+    int slot = slot_mul * b;
+    if (wide && live) {  // the hypothesis's best model: strictly smaller NFA, the first model on ties
+      slot = 4 * b;
+      double v = A.hyp_nfa[slot];
+      for (int mm = 1; mm < 4; ++mm) {
+        const double o = A.hyp_nfa[4 * b + mm];
+        if (o < v) {
+          v = o;
+          slot = 4 * b + mm;
+        }
+      }
+    }
+    RS.m[b] = (unsigned char)(slot & 3);
+    s_nfa[b] = live ? A.hyp_nfa[slot] : pos_inf();
+    // (a slot that reports +inf wrote nothing else)
+    s_err[b] = live && s_nfa[b] < pos_inf() ? A.hyp_err[slot] : 0.0;
+    s_k[b] = live && s_nfa[b] < pos_inf() ? A.hyp_k[slot] : 0;
   }
   __syncthreads();
   // The sequential rule only acts at two kinds of hypotheses: one whose NFA improves on the running minimum, and the
@@ -1872,8 +1997,9 @@ __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pRepla
     }
   }
   STAMP_SEL(stamp_round, 1);
+  const int best_slot = best_b < 0 ? 0 : (wide ? 4 * best_b + (int)RS.m[best_b] : slot_mul * best_b);
   if (best_b >= 0) {
-    const int32_t *src = A.hyp_inl + (size_t)best_b * inl_stride;
+    const int32_t *src = A.hyp_inl + (size_t)best_slot * inl_stride;
     for (int p = tid; p < n_in; p += kThreads) A.best_inl[p] = src[p];
     if (index_changed)
       for (int p = tid; p < n_in; p += kThreads) A.vec_index[p] = src[p];
@@ -1895,9 +2021,9 @@ __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pRepla
     st.rounds += 1;
     const long switch_iter = (index_changed && identity0) ? iter0 + processed : (long)st.switch_iter;
     st.switch_iter = (int)switch_iter;
-    st.batch_limit = p3p_next_batch_limit(A, identity, iter0 + processed, switch_iter);
+    st.batch_limit = p3p_next_batch_limit(A, identity, iter0 + processed, switch_iter, st.n);
     if (best_b >= 0)
-      for (int q = 0; q < 12; ++q) st.model[q] = A.hyp_model[12 * best_b + q];
+      for (int q = 0; q < 12; ++q) st.model[q] = A.hyp_model[12 * best_slot + q];
     if (done) st.done = 1;
     st.arrive = 0u;  // the next round counts from zero
   }
@@ -1911,11 +2037,11 @@ __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, P3pRepla
 // once (st.done is written by the previous launch's last workgroup, i.e. before this launch starts).
 struct P3pRoundBody {
   static constexpr int kGangThreads = kThreads;
-  static __device__ __forceinline__ void run(P3pArgs A, int batch) {
+  static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
 #include "p3p_round.body.inc"
   }
 };
-__global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch) {
+__global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch, int wide) {
 #include "p3p_round.body.inc"
 }
 
@@ -2491,7 +2617,14 @@ int launch_p3p_round(Ctx *c, int batch) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p3p_round),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(P3pShared));
   SFM_HIP(attr);
-  sfm_launch<P3pRoundBody>(c, k_p3p_round, dim3(batch), dim3(kThreads), (uint32_t)lds, A, batch);
+  // from 513 features on a query may have that many correspondences: four workgroups per hypothesis, one model each
+  // (p3p_eval_hypothesis); the result slots then are 4 b + m, of which there are kP3pSlots
+  // -- and only while queries of this map HAVE had that many lately (Map::p3p_wide_credit, refreshed by every finished
+  // query that did): the idle workgroups of a wide launch cost a small query ~15 us and 3 % of the throughput, and the
+  // host cannot know the match set's size when it queues the rounds.  Either launch shape gives the same bits.
+  const int wide = (c->p3p_query_n > 512 && c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) ? 1 : 0;
+  if (wide && batch > kP3pSlots / 4) batch = kP3pSlots / 4;
+  sfm_launch<P3pRoundBody>(c, k_p3p_round, dim3(wide ? 4 * batch : batch), dim3(kThreads), (uint32_t)lds, A, batch, wide);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -233,15 +233,15 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr, bool merge_only = false) {
   CTX_TRY(dev_alloc(acct, &c->d_logc_k, (size_t)kP3pMaxN + 1));
   CTX_TRY(dev_alloc(acct, &c->d_vec_index, (size_t)kP3pMaxN));
   CTX_TRY(dev_alloc(acct, &c->d_best_inl, (size_t)kP3pMaxN));
-  CTX_TRY(dev_alloc(acct, &c->d_hyp_nfa, (size_t)kP3pBatchMax));
-  CTX_TRY(dev_alloc(acct, &c->d_hyp_err, (size_t)kP3pBatchMax));
-  CTX_TRY(dev_alloc(acct, &c->d_hyp_model, (size_t)kP3pBatchMax * 12));
-  CTX_TRY(dev_alloc(acct, &c->d_hyp_k, (size_t)kP3pBatchMax));
-  CTX_TRY(dev_alloc(acct, &c->d_hyp_inl, (size_t)kP3pBatchMax * kP3pMaxN));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_nfa, (size_t)kP3pSlots));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_err, (size_t)kP3pSlots));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_model, (size_t)kP3pSlots * 12));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_k, (size_t)kP3pSlots));
+  CTX_TRY(dev_alloc(acct, &c->d_hyp_inl, (size_t)kP3pSlots * kP3pMaxN));
   CTX_TRY(dev_alloc(acct, &c->d_inlier_idx, (size_t)kP3pMaxN));
   // the regrowable P3P set as allocated above (ctx_p3p_reserve replaces it and keeps the accounts)
   c->p3p_bytes = (uint64_t)kP3pMaxN * (2 * sizeof(double) + 3 * sizeof(int32_t)) + 2 * ((uint64_t)kP3pMaxN + 1) * sizeof(float) +
-                 (uint64_t)kP3pBatchMax * kP3pMaxN * sizeof(int32_t);
+                 (uint64_t)kP3pSlots * kP3pMaxN * sizeof(int32_t);
   if (m->bow_dim) {
     CTX_TRY(dev_alloc(acct, &c->d_bow_query, (size_t)m->bow_dim));
     CTX_TRY(dev_alloc(acct, &c->d_bow_dist, (size_t)m->n_views));
@@ -538,12 +538,13 @@ namespace {
 int g_test_fail_alloc = -1;  // test hook (SFMLOC_TEST_FAIL_P3P_ALLOC=k): the k-th allocation of the next reserve fails
 }
 int ctx_p3p_reserve(Ctx *c, uint32_t n) {
+  c->p3p_query_n = n;
   if (n <= c->p3p_cap) return SFMLOC_OK;
   uint32_t cap = c->p3p_cap;
   while (cap < n) cap <<= 1;
   // hypothesis inlier lists: kP3pBatchMax lists of kP3pMaxN, or (more correspondences) kP3pLargeBatch lists of cap
   const size_t large_batch = 64;  // acransac.hip kP3pLargeBatch
-  const size_t hyp = std::max<size_t>((size_t)kP3pBatchMax * kP3pMaxN, large_batch * cap);
+  const size_t hyp = std::max<size_t>((size_t)kP3pSlots * kP3pMaxN, large_batch * cap);
   const size_t bytes[12] = {(size_t)cap * 2 * sizeof(double),      ((size_t)cap + 1) * sizeof(float),
                             ((size_t)cap + 1) * sizeof(float),     (size_t)cap * sizeof(int32_t),
                             (size_t)cap * sizeof(int32_t),         hyp * sizeof(int32_t),
@@ -609,7 +610,12 @@ int ctx_resection_wait(Ctx *c) {
   for (int guard = 0; guard < 64; ++guard) {
     SFM_HIP(hipStreamSynchronize(c->stream));
     c->stream.dirty = false;
-    if (h->state.done) return SFMLOC_OK;
+    if (h->state.done) {
+      // what the next queries' rounds look like (launch_p3p_round): this one's number of correspondences
+      if (h->state.n > 512) c->map->p3p_wide_credit.store(64, std::memory_order_relaxed);
+      else if (c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) c->map->p3p_wide_credit.fetch_sub(1, std::memory_order_relaxed);
+      return SFMLOC_OK;
+    }
     int rc;
     {
       EventScope ev(c, SFMLOC_K_P3P);

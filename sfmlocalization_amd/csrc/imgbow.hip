@@ -40,6 +40,7 @@ struct ImgBow {
   double *d_out = nullptr;         // [dim] the reference's float64 vector
   float *d_out_f32 = nullptr;      // [dim] as the shortlist reads it (BoFUtils.cpp:51-54 converts to CV_32F)
   double *h_out = nullptr;         // pinned [dim]
+  hipEvent_t ordered = nullptr;    // sfmloc_imgbow_order_before
   hipEvent_t staged = nullptr;     // the previous call's H2D out of h_src has completed
   bool staged_pending = false;
 };
@@ -65,6 +66,7 @@ void sfmloc_imgbow_destroy(sfmloc_imgbow *p) {
   if (ib->h_src) (void)hipHostFree(ib->h_src);
   if (ib->h_out) (void)hipHostFree(ib->h_out);
   if (ib->staged) (void)hipEventDestroy(ib->staged);
+  if (ib->ordered) (void)hipEventDestroy(ib->ordered);
   if (ib->ak) sfmloc_akaze_destroy(ib->ak);
   if (ib->bof) sfmloc_bof_destroy(ib->bof);
   delete ib;
@@ -144,6 +146,22 @@ int sfmloc_imgbow_dim(const sfmloc_imgbow *p) {
 const void *sfmloc_imgbow_vector_dev(const sfmloc_imgbow *p) {
   const ImgBow *ib = reinterpret_cast<const ImgBow *>(p);
   return ib ? ib->d_out_f32 : nullptr;
+}
+
+// the context's stream waits for what this extractor has queued so far (an extractor on a stream of its own runs beside
+// the feature extraction of the same frame; the localisation that reads its vector is ordered behind it by this)
+int sfmloc_imgbow_order_before(sfmloc_imgbow *p, sfmloc_context *ctx) {
+  SFM_CHECK(p && ctx, SFMLOC_EINVAL, "sfmloc_imgbow_order_before: null argument");
+  ImgBow *ib = reinterpret_cast<ImgBow *>(p);
+  Ctx *c = reinterpret_cast<Ctx *>(ctx);
+  SFM_HIP(hipSetDevice(ib->device));
+  hipStream_t s = akaze_stream_now(reinterpret_cast<Akaze *>(ib->ak));
+  hipStream_t cs = c->stream;
+  if (s == cs) return SFMLOC_OK;  // (shared: stream order already)
+  if (!ib->ordered) SFM_HIP(hipEventCreateWithFlags(&ib->ordered, hipEventDisableTiming));
+  SFM_HIP(hipEventRecord(ib->ordered, s));
+  SFM_HIP(hipStreamWaitEvent(cs, ib->ordered, 0));
+  return SFMLOC_OK;
 }
 
 int sfmloc_imgbow_share_stream(sfmloc_imgbow *p, sfmloc_context *ctx) {

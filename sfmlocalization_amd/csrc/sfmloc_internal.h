@@ -50,6 +50,7 @@ void set_error(const char *fmt, ...);
 constexpr uint32_t kBlockRows = 64;
 constexpr int kP3pMaxN = 4096;     // 2D-3D correspondences the P3P LDS sort holds
 constexpr int kP3pBatchMax = 512;  // hypotheses evaluated per round
+constexpr int kP3pSlots = 1024;    // result slots of a round: one per hypothesis, or (wide launches) four, one per model
 constexpr uint32_t kPartHeaderBytes = 16;  // candidate part: {u32 n_cand, pad[3]} then the candidates
 
 using Pose = sfmloc_pose;
@@ -127,6 +128,9 @@ struct Map {
   uint32_t max_view_blocks = 0;  // most 64-row blocks any one view overlaps (launch bound of a device-side selection)
   uint32_t max_view_rows = 0;    // most rows of any one view
   std::atomic<int> busy_ctx{0};  // contexts with work queued (begin .. end / sync): K1 slices a short scan only when alone
+  // > 0 while recent queries had more than 512 2D-3D correspondences: K5's rounds are then launched wide (four
+  // workgroups per hypothesis, acransac.hip).  Set to 64 by a finished query that had, counted down by the others.
+  std::atomic<int> p3p_wide_credit{0};
   uint32_t n_views = 0;
   uint32_t n_landmarks = 0;
   std::vector<uint32_t> h_view_id, h_view_off, h_view_wh;
@@ -226,6 +230,7 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   // hypothesis gets a global-memory segment
   uint32_t p3p_cap = kP3pMaxN;
   uint64_t p3p_bytes = 0;  // bytes of the regrowable P3P arrays currently held (part of hbm_bytes)
+  uint32_t p3p_query_n = 0;  // features of the query K5 is about to run for (ctx_p3p_reserve): launch shape of the rounds
   uint32_t *d_pair_qfeat_big = nullptr, *d_pair_landmark_big = nullptr;
   uint64_t *d_p3p_ws_key = nullptr;
   uint32_t *d_p3p_ws_idx = nullptr;
