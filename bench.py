@@ -86,6 +86,11 @@ def parse(argv=None):
                     help="host threads driving the contexts (1 GPU, no shortlist collective): 0/1 = one thread round-robins "
                          "all contexts; N > 1 = N threads, each with its share of the contexts (the C ABI calls release the "
                          "GIL, so the kernel launches of different queries are issued in parallel)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="--gpus N: every rank holds the WHOLE map and takes the queries i mod N of each batch, no collective "
+                         "(the map fits one GPU 45 times over: what sharding is compared with).  Without this flag a run on "
+                         "more than one GPU measures the sharded path and then this one, and prints it as `replicas`")
+    ap.add_argument("--no-replica-leg", action="store_true", help="--gpus N: skip the replicas comparison leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-phase", action="store_true", help="skip the full-bank scan and the N_q sweep")
     ap.add_argument("--no-real-stats", action="store_true",
@@ -597,22 +602,14 @@ def image_in_phase(a, S, local_rank, log):
     return out
 
 
-def main():
-    a = parse()
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        sys.exit(spawn_ranks(a))   # before torch / HIP are touched in this process
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches "
-              f"its own ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr)
-        sys.exit(2)
+def plan(a, world, replicas):
+    """The run's shape from its arguments: (shortlist, forced, sharded_mode, gang, nctx, hardware queues wanted); sets
+    a.threads.  replicas: every rank is a single-GPU run on the whole map."""
     shortlist = a.bow_knn > 0
     # measured (profiles/r02_inflight_sweep.txt): with the shortlist 12 contexts driven by 4 host threads; full scans fill
     # the chip with 4
     forced = os.environ.get("SFMLOC_BENCH_FORCE_SHARDED") == "1"
-    sharded_mode = world > 1 or forced
+    sharded_mode = (world > 1 or forced) and not replicas
     # (the sharded path keeps two slots of contexts; one query per launch: 8 per slot -- with 12 the 24 contexts and the
     # collective's stream no longer get a hardware queue each and the rate drops by 40 %,
     # profiles/r02_sharded_inflight_sweep.txt)
@@ -621,7 +618,7 @@ def main():
     # (N ranks: a rank scans 1/N of the map per query but issues every query's launches, and a device serves few
     # hardware queues well -- 16 queries per launch on 2 streams per slot instead of 8 streams with a query each:
     # tools/rank_emulation.py, profiles/r02_rank_emulation.jsonl)
-    gang = a.gang if a.gang > 0 else (16 if world > 1 else int(os.environ.get("SFMLOC_GANG", "1")))
+    gang = a.gang if a.gang > 0 else (16 if (world > 1 and not replicas) else int(os.environ.get("SFMLOC_GANG", "1")))
     gang = gang if sharded_mode else 1
     nctx = a.in_flight if a.in_flight > 0 else (4 if a.from_images else
                                                 (((32 if gang > 1 else 8) if sharded_mode else 12) if shortlist else 4))
@@ -631,33 +628,20 @@ def main():
     # first context with them (two slots + the two stage-2 groups)
     # (+2: the map's own stream and torch's; measured: 8 contexts on 8 queues lose 20 % to two streams sharing one)
     n_streams = (2 * -(-nctx // gang) + 2) if gang > 1 else (2 * nctx if sharded_mode else nctx)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, n_streams + 2))))
+    return shortlist, forced, sharded_mode, gang, nctx, min(24, max(8, n_streams + 2))
 
+
+
+def measure(a, rank, world, local_rank, dist, torch, replicas):
+    """One whole measurement in the mode `replicas` says; -> the JSON object (rank 0) or None."""
     import numpy as np
-    sys.path.insert(0, ROOT)
-    import torch
-    dist = None
-    if world > 1 or (forced and "RANK" in os.environ):
-        import torch.distributed as dist_
-        dist = dist_
-        # SFMLOC_BENCH_BACKEND=gloo: rehearse N ranks on fewer GPUs (ranks share devices, the exchange goes through the
-        # host); the measured configuration is always nccl = RCCL, one rank per GPU
-        backend = os.environ.get("SFMLOC_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-            local_rank = local_rank % max(1, torch.cuda.device_count())
-        assert dist.get_world_size() == a.gpus, "process group size differs from --gpus"
-    torch.cuda.set_device(local_rank)
-
+    shortlist, forced, sharded_mode, gang, nctx, _ = plan(a, world, replicas)
+    log = lambda msg: print("[bench] " + msg, file=sys.stderr, flush=True)  # noqa: E731
     import sfmlocalization_amd as S
     import synthdata as synth
 
     if a.image_in_only:
-        out = {"image_in": image_in_phase(a, S, local_rank, lambda msg: print("[bench] " + msg, file=sys.stderr, flush=True))}
-        print(json.dumps(out), flush=True)
-        return
+        return {"image_in": image_in_phase(a, S, local_rank, log)}
     # every rank builds the same seeded map and keeps its shard of views (contiguous view ranges)
     t_gen = time.perf_counter()
     m = synth.make_map(2, n_views=a.views, desc_per_view=a.desc_per_view)
@@ -666,8 +650,10 @@ def main():
     if shortlist:
         bow, qbow = synth_bow(m, queries)
     t_gen = time.perf_counter() - t_gen
-    v0 = (a.views * rank) // world
-    v1 = (a.views * (rank + 1)) // world
+    # (replicas: the whole map on every rank, and of every batch the queries i with i mod world == rank)
+    v0 = 0 if replicas else (a.views * rank) // world
+    v1 = a.views if replicas else (a.views * (rank + 1)) // world
+    stride, phase = (world, rank) if replicas else (1, 0)
     r0, r1 = int(m.view_off[v0]), int(m.view_off[v1])
     params = S.default_params(device=local_rank, profile=0, ransac_round=25)
     # diagnosis only (what each latency-bound stage costs the throughput); a line produced with these set is not the metric
@@ -748,7 +734,7 @@ def main():
                 fp_l.append((qi[k], fingerprint(pose, pq, pl)))
                 return int(pose.ok)
 
-            for n, i in enumerate(range(first + t, first + count, nthr)):
+            for n, i in enumerate(range(first + phase + t * stride, first + count, nthr * stride)):
                 k = mine[n % len(mine)]
                 if bz[k]:
                     ok_l += fin(k)
@@ -777,8 +763,8 @@ def main():
         if a.threads > 1:
             run_threads(first, count)
             return
-        for i in range(first, first + count):   # up to `nctx` queries overlap on the GPU
-            k = i % nctx
+        for n, i in enumerate(range(first + phase, first + count, stride)):   # up to `nctx` queries overlap on the GPU
+            k = n % nctx
             if busy[k]:
                 finish(k)
             t_begin[k] = time.perf_counter()
@@ -965,9 +951,11 @@ def main():
                        "queries_per_step": a.batch, "queries_timed": n_timed, "in_flight_per_gpu": nctx,
                        "host_threads": max(1, a.threads) if sharded is None else 1,
                        **({"queries_per_launch": gang} if sharded is not None else {}),
-                       "parallelism": (f"bank + .bow sharded by view x{world}; per {a.batch}-query batch one all-gather of "
-                                       "per-shard k-best BoW keys and ONE all-gather of candidate parts (RCCL), P3P of "
-                                       "query i on rank i mod N" if world > 1 else "1 GPU, whole bank"),
+                       "parallelism": ((f"replicas x{world}: every rank holds the whole bank, query i of a batch on rank i mod "
+                                        f"{world}, no collective") if (replicas and world > 1) else
+                                       (f"bank + .bow sharded by view x{world}; per {a.batch}-query batch one all-gather of "
+                                        "per-shard k-best BoW keys and ONE all-gather of candidate parts (RCCL), P3P of "
+                                        "query i on rank i mod N") if world > 1 else "1 GPU, whole bank"),
                        "queries_localised": f"{n_ok_timed}/{n_timed}",
                        "map_generation_s": round(t_gen, 1), **({"DIAGNOSTIC_OVERRIDES_NOT_THE_METRIC": diag} if diag else {})},
             "identical_to_single_flight": f"{n_same}/{n_cmp}",
@@ -1077,7 +1065,57 @@ def main():
         # the image in front of the path, on a map of its own (the headline's map and contexts are gone by now)
         if world == 1 and not a.no_image_in and not a.from_images and shortlist:
             del m, queries, bow, qbow
-            out["image_in"] = image_in_phase(a, S, local_rank, lambda msg: print("[bench] " + msg, file=sys.stderr, flush=True))
+            out["image_in"] = image_in_phase(a, S, local_rank, log)
+        return out
+    return None
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))   # before torch / HIP are touched in this process
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches "
+              f"its own ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr)
+        sys.exit(2)
+    _, forced, _, _, _, hwq = plan(argparse.Namespace(**vars(a)), world, a.replicas)
+    if world > 1:
+        hwq = 24     # (both legs of a multi-GPU run)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(hwq))
+
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import torch
+    dist = None
+    if world > 1 or (forced and "RANK" in os.environ):
+        import torch.distributed as dist_
+        dist = dist_
+        # SFMLOC_BENCH_BACKEND=gloo: rehearse N ranks on fewer GPUs (ranks share devices, the exchange goes through the
+        # host); the measured configuration is always nccl = RCCL, one rank per GPU
+        backend = os.environ.get("SFMLOC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+        assert dist.get_world_size() == a.gpus, "process group size differs from --gpus"
+    torch.cuda.set_device(local_rank)
+
+    out = measure(argparse.Namespace(**vars(a)), rank, world, local_rank, dist, torch, a.replicas)
+    if world > 1 and not a.replicas and not a.no_replica_leg and not a.image_in_only:
+        # the comparison SCALE runs need: N independent replicas of the whole map, same queries, no exchange
+        b = argparse.Namespace(**vars(a))
+        b.no_cpu_baseline = b.no_roofline_phase = b.no_image_in = True
+        b.threads = b.in_flight = 0
+        rep = measure(b, rank, world, local_rank, dist, torch, True)
+        if rank == 0:
+            out["replicas"] = {k: rep[k] for k in ("value", "unit", "ms_per_step", "identical_to_single_flight", "latency_ms")}
+            out["replicas"]["parallelism"] = rep["config"]["parallelism"]
+            out["replicas"]["queries_localised"] = rep["config"]["queries_localised"]
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

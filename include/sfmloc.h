@@ -389,6 +389,27 @@ int sfmloc_shard_export_packed(sfmloc_context *ctx, void *packed_dev, uint32_t n
                                uint32_t query_index);
 int sfmloc_merge_begin_packed(sfmloc_context *ctx, sfmloc_query *q, const void *packed_dev, uint32_t n_parts,
                               uint64_t part_stride, uint32_t n_queries, uint32_t budget, uint32_t query_index);
+/* A rank's whole batch per call: the per-query calls above for n_queries queries, in gang sessions of
+ * `gang` contexts (query i on context i mod n_ctx; the contexts [g, g + gang) of every n_ctx consecutive queries form one
+ * session) -- what a caller would otherwise issue as one foreign call per query and stage.  Asynchronous like the calls
+ * they stand for; same results.
+ *   _bow_keys      keys_dev [n_queries][knn] u64: every query's knn best views of this shard (resident BoW vectors)
+ *   _begin_bow     keys_all_dev [n_parts][n_queries][knn]: the all-gathered keys; stage 1 of every query on its part of
+ *                  the global shortlist + its candidates exported to packed_dev (sfmloc_packed_bytes(n_queries, budget))
+ *   _begin         the same without a shortlist (every view of the shard)
+ *   sfmloc_merge_batch_begin   stage 2 (2D-3D set + P3P) of n <= 32 queries in one session: context k takes query
+ *                  query_index[k] of the batch, whose parts lie in packed_all_dev (n_parts parts, part_stride bytes
+ *                  apart); finish each with sfmloc_localize_end */
+int sfmloc_shard_batch_bow_keys(sfmloc_context *const *ctxs, uint32_t n_ctx, uint32_t gang, sfmloc_query *const *queries,
+                                uint32_t n_queries, uint32_t knn, void *keys_dev);
+int sfmloc_shard_batch_begin_bow(sfmloc_context *const *ctxs, uint32_t n_ctx, uint32_t gang, sfmloc_query *const *queries,
+                                 uint32_t n_queries, const void *keys_all_dev, uint32_t n_parts, uint32_t knn,
+                                 void *packed_dev, uint32_t budget);
+int sfmloc_shard_batch_begin(sfmloc_context *const *ctxs, uint32_t n_ctx, uint32_t gang, sfmloc_query *const *queries,
+                             uint32_t n_queries, void *packed_dev, uint32_t budget);
+int sfmloc_merge_batch_begin(sfmloc_context *const *ctxs, uint32_t n, sfmloc_query *const *queries,
+                             const uint32_t *query_index, const void *packed_all_dev, uint32_t n_parts,
+                             uint64_t part_stride, uint32_t n_queries, uint32_t budget);
 
 /* ------------------------------------------------------------------------- */
 /* Stage A5: bag-of-words view shortlist.                                        */

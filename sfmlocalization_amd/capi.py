@@ -122,6 +122,7 @@ SYMBOLS = [
     "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing", "sfmloc_context_create_merge",
     "sfmloc_query_create_view", "sfmloc_feat_round_trip",
     "sfmloc_imgbow_create", "sfmloc_imgbow_destroy", "sfmloc_imgbow_dim", "sfmloc_imgbow_share_stream", "sfmloc_imgbow_compute",
+    "sfmloc_shard_batch_bow_keys", "sfmloc_shard_batch_begin_bow", "sfmloc_shard_batch_begin", "sfmloc_merge_batch_begin",
     "sfmloc_imgbow_vector_dev", "sfmloc_imgbow_order_before", "sfmloc_akaze_detect_resident", "sfmloc_akaze_detect_resident_batch", "sfmloc_akaze_resident_arrays",
 ]
 
@@ -163,6 +164,34 @@ def result_fingerprint(pose, pair_qfeat, pair_landmark, view_counts=True):
     h.update(np.ascontiguousarray(pair_qfeat).tobytes())
     h.update(np.ascontiguousarray(pair_landmark).tobytes())
     return h.digest()
+
+
+def _handles(objs):
+    return (C.c_void_p * len(objs))(*[o._h for o in objs])
+
+
+def shard_batch_bow_keys(ctxs, gang, queries, knn, keys_dev_ptr):
+    """sfmloc_shard_batch_bow_keys: every query's knn best views of this shard -> keys [len(queries)][knn] on the device"""
+    _check(_L().sfmloc_shard_batch_bow_keys(_handles(ctxs), len(ctxs), gang, _handles(queries), len(queries), knn,
+                                            C.c_void_p(keys_dev_ptr)))
+
+
+def shard_batch_begin_bow(ctxs, gang, queries, keys_all_dev_ptr, n_parts, knn, packed_dev_ptr, budget):
+    """sfmloc_shard_batch_begin_bow: stage 1 of a batch on the global shortlist + the packed export, one call"""
+    _check(_L().sfmloc_shard_batch_begin_bow(_handles(ctxs), len(ctxs), gang, _handles(queries), len(queries),
+                                             C.c_void_p(keys_all_dev_ptr), n_parts, knn, C.c_void_p(packed_dev_ptr), budget))
+
+
+def shard_batch_begin(ctxs, gang, queries, packed_dev_ptr, budget):
+    _check(_L().sfmloc_shard_batch_begin(_handles(ctxs), len(ctxs), gang, _handles(queries), len(queries),
+                                         C.c_void_p(packed_dev_ptr), budget))
+
+
+def merge_batch_begin(ctxs, queries, query_index, packed_all_dev_ptr, n_parts, part_stride, n_queries, budget):
+    """sfmloc_merge_batch_begin: stage 2 of len(ctxs) queries in one session (finish each with Context.end)"""
+    qi = np.ascontiguousarray(query_index, np.uint32)
+    _check(_L().sfmloc_merge_batch_begin(_handles(ctxs), len(ctxs), _handles(queries), _ptr(qi, C.c_uint32),
+                                         C.c_void_p(packed_all_dev_ptr), n_parts, part_stride, n_queries, budget))
 
 
 def feat_round_trip(kpt_xy):
@@ -283,6 +312,13 @@ def _L():
         L.sfmloc_imgbow_dim.argtypes = [C.c_void_p]
         L.sfmloc_imgbow_share_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_imgbow_compute.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_void_p, F64P]
+        VPP = C.POINTER(C.c_void_p)
+        L.sfmloc_shard_batch_bow_keys.argtypes = [VPP, C.c_uint32, C.c_uint32, VPP, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.sfmloc_shard_batch_begin_bow.argtypes = [VPP, C.c_uint32, C.c_uint32, VPP, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                   C.c_uint32, C.c_void_p, C.c_uint32]
+        L.sfmloc_shard_batch_begin.argtypes = [VPP, C.c_uint32, C.c_uint32, VPP, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.sfmloc_merge_batch_begin.argtypes = [VPP, C.c_uint32, VPP, U32P, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32,
+                                               C.c_uint32]
         L.sfmloc_imgbow_order_before.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_imgbow_vector_dev.restype = C.c_void_p
         L.sfmloc_imgbow_vector_dev.argtypes = [C.c_void_p]

@@ -2011,6 +2011,81 @@ int sfmloc_bof_compute(sfmloc_bof *bof, const float *desc, const float *kpt_xy, 
   return SFMLOC_OK;
 }
 
+// ----- a rank's whole batch per call --------------------------------------------
+// dist.py drove a batch with one ctypes call per query and stage (~2 ms of a 17 ms batch at N = 8); these take the
+// batch's arrays and run the same per-query calls in gang sessions of `gang` contexts: query i goes to context
+// i mod n_ctx, the contexts [g, g + gang) of every n_ctx consecutive queries form one session (the first of them leads),
+// the sessions take turns so that their streams stay equally loaded -- exactly the order dist.HipShardCompute._rounds
+// queued them in, so the results are the same bits.
+}  // extern "C"
+namespace {
+template <class PerQuery>
+int shard_batch_rounds(sfmloc_context *const *ctxs, uint32_t n_ctx, uint32_t gang, uint32_t n_queries, const char *who,
+                       PerQuery per_query) {
+  SFM_CHECK(ctxs && n_ctx > 0, SFMLOC_EINVAL, "%s: no contexts", who);
+  if (gang == 0) gang = 1;
+  if (gang > (uint32_t)kGangMembers) gang = kGangMembers;
+  for (uint32_t base = 0; base < n_queries; base += n_ctx)
+    for (uint32_t g0 = 0; g0 < n_ctx; g0 += gang) {
+      uint32_t m = 0;
+      for (uint32_t k = g0; k < n_ctx && k < g0 + gang && base + k < n_queries; ++k) ++m;
+      if (m == 0) continue;
+      int rc = m > 1 ? sfmloc_gang_begin(ctxs + g0, m) : SFMLOC_OK;
+      for (uint32_t k = 0; k < m && rc == SFMLOC_OK; ++k) rc = per_query(ctxs[g0 + k], base + g0 + k);
+      const int rc_end = m > 1 ? sfmloc_gang_end(ctxs + g0, m) : SFMLOC_OK;
+      if (rc == SFMLOC_OK) rc = rc_end;
+      if (rc) return rc;
+    }
+  return SFMLOC_OK;
+}
+}  // namespace
+extern "C" {
+
+int sfmloc_shard_batch_bow_keys(sfmloc_context *const *ctxs, uint32_t n_ctx, uint32_t gang, sfmloc_query *const *queries,
+                                uint32_t n_queries, uint32_t knn, void *keys_dev) {
+  SFM_CHECK(queries && keys_dev && knn > 0, SFMLOC_EINVAL, "sfmloc_shard_batch_bow_keys: bad argument");
+  return shard_batch_rounds(ctxs, n_ctx, gang, n_queries, "sfmloc_shard_batch_bow_keys", [&](sfmloc_context *c, uint32_t i) {
+    return sfmloc_shard_bow_keys(c, queries[i], nullptr, knn, static_cast<unsigned char *>(keys_dev) + (size_t)i * knn * 8);
+  });
+}
+
+int sfmloc_shard_batch_begin_bow(sfmloc_context *const *ctxs, uint32_t n_ctx, uint32_t gang, sfmloc_query *const *queries,
+                                 uint32_t n_queries, const void *keys_all_dev, uint32_t n_parts, uint32_t knn,
+                                 void *packed_dev, uint32_t budget) {
+  SFM_CHECK(queries && keys_all_dev && packed_dev && knn > 0 && n_parts > 0, SFMLOC_EINVAL,
+            "sfmloc_shard_batch_begin_bow: bad argument");
+  // keys_all [n_parts][n_queries][knn]: query i's lists start at i * knn keys, one part every n_queries * knn keys
+  return shard_batch_rounds(ctxs, n_ctx, gang, n_queries, "sfmloc_shard_batch_begin_bow", [&](sfmloc_context *c, uint32_t i) {
+    int rc = sfmloc_shard_begin_bow(c, queries[i], static_cast<const unsigned char *>(keys_all_dev) + (size_t)i * knn * 8,
+                                    n_parts, (uint64_t)n_queries * knn, knn);
+    if (!rc) rc = sfmloc_shard_export_packed(c, packed_dev, n_queries, budget, i);
+    return rc;
+  });
+}
+
+int sfmloc_shard_batch_begin(sfmloc_context *const *ctxs, uint32_t n_ctx, uint32_t gang, sfmloc_query *const *queries,
+                             uint32_t n_queries, void *packed_dev, uint32_t budget) {
+  SFM_CHECK(queries && packed_dev, SFMLOC_EINVAL, "sfmloc_shard_batch_begin: bad argument");
+  return shard_batch_rounds(ctxs, n_ctx, gang, n_queries, "sfmloc_shard_batch_begin", [&](sfmloc_context *c, uint32_t i) {
+    int rc = sfmloc_shard_begin(c, queries[i], nullptr, 0);
+    if (!rc) rc = sfmloc_shard_export_packed(c, packed_dev, n_queries, budget, i);
+    return rc;
+  });
+}
+
+// stage 2 of up to kGangMembers queries in ONE session: context k takes query query_index[k] of the batch
+int sfmloc_merge_batch_begin(sfmloc_context *const *ctxs, uint32_t n, sfmloc_query *const *queries, const uint32_t *query_index,
+                             const void *packed_all_dev, uint32_t n_parts, uint64_t part_stride, uint32_t n_queries,
+                             uint32_t budget) {
+  SFM_CHECK(ctxs && queries && query_index && packed_all_dev && n > 0 && n <= (uint32_t)kGangMembers, SFMLOC_EINVAL,
+            "sfmloc_merge_batch_begin: 1..%d contexts", kGangMembers);
+  int rc = n > 1 ? sfmloc_gang_begin(ctxs, n) : SFMLOC_OK;
+  for (uint32_t k = 0; k < n && rc == SFMLOC_OK; ++k)
+    rc = sfmloc_merge_begin_packed(ctxs[k], queries[k], packed_all_dev, n_parts, part_stride, n_queries, budget, query_index[k]);
+  const int rc_end = n > 1 ? sfmloc_gang_end(ctxs, n) : SFMLOC_OK;
+  return rc ? rc : rc_end;
+}
+
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride) {
   SFM_CHECK(in && out && n > 0 && in_stride > 0 && out_stride > 0, SFMLOC_EINVAL, "sfmloc_debug_math: bad argument");
   int ndev = 0;

@@ -240,13 +240,24 @@ class ShardedLocalizer:
         self.reset_counters()
 
     def reset_counters(self):
+        self._coll_events = []
         self._n_batches = self._n_queries = self._n_redo = 0
         self._bytes_parts = self._bytes_keys = self._bytes_feats = 0
         self._max_total = 0
 
     def counters(self):
         nb = max(1, self._n_batches)
+        coll = {}
+        for what, e0, e1 in self._coll_events:      # (every recorded collective has completed when this is read)
+            try:
+                e1.synchronize()
+                coll.setdefault(what, []).append(e0.elapsed_time(e1))
+            except Exception:  # noqa: BLE001
+                pass
+        coll_ms = {k: {"n": len(v), "mean_ms": float(np.mean(v)), "max_ms": float(np.max(v))} for k, v in coll.items()}
         return {"batches": self._n_batches, "queries": self._n_queries,
+                "process_group_size": int(self.dist.get_world_size(self.group)) if self.dist.is_initialized() else 1,
+                "collective_ms_on_the_comm_stream": coll_ms,
                 "candidate_allgather_bytes_per_batch_per_rank": self._bytes_parts / nb,
                 "bow_key_allgather_bytes_per_batch_per_rank": self._bytes_keys / nb,
                 **({"feature_allgather_bytes_per_batch_per_rank": self._bytes_feats / nb} if self._bytes_feats else {}),
@@ -261,7 +272,7 @@ class ShardedLocalizer:
     def _comm_stream(self):
         return getattr(self.compute, "comm", None)
 
-    def _all_gather(self, send):
+    def _all_gather(self, send, what="candidates"):
         """send [n, ...] -> ([world, n, ...] on send's device, event) -- on the compute object's collective stream (if
         any); the event marks the gather's completion on that stream (None without one)."""
         import contextlib
@@ -269,7 +280,11 @@ class ShardedLocalizer:
         out = torch.empty((self.world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
         comm = self._comm_stream()
         scope = torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()
+        timed = comm is not None and send.is_cuda
         with scope:
+            if timed:
+                t_start = torch.cuda.Event(enable_timing=True)
+                t_start.record(comm)
             if self.world > 1 or self.always_gather:
                 flat = out.view((self.world * send.shape[0],) + tuple(send.shape[1:]))
                 if send.is_cuda and self.dist.get_backend(self.group) == "gloo":
@@ -283,7 +298,12 @@ class ShardedLocalizer:
                     self.dist.all_gather_into_tensor(flat, send.contiguous(), group=self.group)
             else:
                 out[0].copy_(send)
-            ev = comm.record_event() if comm is not None else None
+            if timed:   # the collective's own duration on its stream (read in counters(), after the events completed)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(comm)
+                self._coll_events.append((what, t_start, ev))
+            else:
+                ev = comm.record_event() if comm is not None else None
         return out, ev
 
     def _before(self, slot):
@@ -314,7 +334,7 @@ class ShardedLocalizer:
             comm = self._comm_stream()     # (the upload on the stream the collective runs on: ordered before it)
             with (torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()):
                 t = t.pin_memory().to(dev, non_blocking=True)
-        gathered, ev = self._all_gather(t)
+        gathered, ev = self._all_gather(t, "features")
         if ev is not None:
             ev.synchronize()
         self._bytes_feats += t.numel()
@@ -332,7 +352,7 @@ class ShardedLocalizer:
             if keys_all is None:
                 keys = self.compute.bow_keys(queries, bow_knn, slot)
                 self._before(slot)
-                keys_all, _ = self._all_gather(keys)
+                keys_all, _ = self._all_gather(keys, "bow_keys")
                 self._after(slot)
                 self._bytes_keys += keys.numel() * keys.element_size()
             part = self.compute.stage1_bow(queries, keys_all, bow_knn, slot, budget)
@@ -503,11 +523,9 @@ class HipShardCompute:
         import torch
         B = len(queries)
         keys = self._tensor("keys", slot, (B, knn), torch.int64)
-        base = keys.data_ptr()
-        for sess, work in self._rounds(slot, B):
-            with sess:
-                for c, i in work:
-                    c.shard_bow_keys(queries[i], knn, base + i * knn * 8)
+        # ONE foreign call for the batch (sfmloc_shard_batch_bow_keys runs the sessions of _rounds in C)
+        from . import capi
+        capi.shard_batch_bow_keys(self.ctxs[slot], self.gang, queries, knn, keys.data_ptr())
         return keys
 
     def query_views(self, gathered, cap, bow_dim, n_queries, slot=0):
@@ -546,13 +564,10 @@ class HipShardCompute:
         B = len(queries)
         world = keys_all.shape[0]
         part = self._packed(slot, B, budget)
-        base, kbase = part.data_ptr(), keys_all.data_ptr()
-        for sess, work in self._rounds(slot, B):
-            with sess:
-                for c, i in work:
-                    # query i's key lists: keys_all[r, i, :] for r in range(world) -> stride B*knn keys
-                    c.shard_begin_bow(queries[i], kbase + i * knn * 8, world, knn, part_stride_keys=B * knn)
-                    c.shard_export_packed(base, B, budget, i)
+        # query i's key lists: keys_all[r, i, :] for r in range(world) -> one part every B*knn keys; one foreign call
+        from . import capi
+        assert keys_all.is_contiguous() and tuple(keys_all.shape) == (world, B, knn)
+        capi.shard_batch_begin_bow(self.ctxs[slot], self.gang, queries, keys_all.data_ptr(), world, knn, part.data_ptr(), budget)
         self._queries[slot] = queries
         return part
 
@@ -560,6 +575,11 @@ class HipShardCompute:
         B = len(queries)
         part = self._packed(slot, B, budget)
         base = part.data_ptr()
+        if view_sels is None:
+            from . import capi
+            capi.shard_batch_begin(self.ctxs[slot], self.gang, queries, base, budget)
+            self._queries[slot] = queries
+            return part
         for sess, work in self._rounds(slot, B):
             with sess:
                 for c, i in work:
@@ -584,9 +604,7 @@ class HipShardCompute:
             for t, k0 in enumerate(range(0, len(indices), n)):
                 cs = self.ctx2[t % len(self.ctx2)]
                 chunk = indices[k0:k0 + n]
-                with capi.gang(cs[:len(chunk)]):
-                    for c, i in zip(cs, chunk):
-                        c.merge_begin_packed(queries[i], base, world, B, budget, i, part_stride=pb)
+                capi.merge_batch_begin(cs[:len(chunk)], [queries[i] for i in chunk], chunk, base, world, pb, B, budget)
                 if pending is not None:
                     for c, i in pending:
                         out[i] = _pose_tuple(c.end())
