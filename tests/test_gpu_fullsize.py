@@ -4,7 +4,8 @@ disjoint view selections, idempotence, and planted matches whose answer is known
 configs[1]: 1 000 views / 2 M descriptors, every query scans the whole bank.
 configs[2]: 10 000 views / 20 M descriptors, BoW shortlist of 100 views, then the path on them.
 configs[3]: the same map split by view into 8 shards (here: 8 maps on the one GPU), candidate parts merged.
-configs[4]: 50 000 views / 100 M descriptors (6.4 GB) -- the scan alone, planted matches."""
+configs[4]: 50 000 views / 100 M descriptors (6.4 GB) -- the scan alone with planted matches, and the whole chain: BoW
+            shortlist over 50 000 .bow vectors, the map as 8 shards, 1080p-size queries (5 000 features), pose refinement."""
 import numpy as np
 import pytest
 
@@ -23,11 +24,11 @@ def bits(a):
     return u
 
 
-def make_dev_map(m, bow=None, lo=0, hi=None):
+def make_dev_map(m, bow=None, lo=0, hi=None, **params):
     hi = m.n_views if hi is None else hi
     r0, r1 = int(m.view_off[lo]), int(m.view_off[hi])
     return S.Map(m.view_id[lo:hi], m.view_off[lo:hi + 1] - m.view_off[lo], m.desc[r0:r1],
-                 params=S.default_params(ransac_round=25), view_wh=m.view_wh[lo:hi], kpt_xy=m.kpt_xy[r0:r1],
+                 params=S.default_params(ransac_round=25, **params), view_wh=m.view_wh[lo:hi], kpt_xy=m.kpt_xy[r0:r1],
                  row_landmark=m.row_landmark[r0:r1], landmark_id=m.landmark_id, landmark_X=m.landmark_X,
                  intrinsic=m.intrinsic, bow=None if bow is None else bow[lo:hi])
 
@@ -175,3 +176,78 @@ def test_config4_scan_of_one_hundred_million_rows(oracle_c):
     assert int(cnt[others].max()) < 16
     dq.close()
     dm.close()
+
+
+def test_config4_chain_fifty_thousand_views_in_eight_shards(oracle_c):
+    """BASELINE configs[4] as a chain on the one GPU: 50 000 views / 100 M descriptors with a .bow matrix of 50 000 x 500,
+    split by view into 8 shards (12.5 M rows each); 1080p-size queries (5 000 features); per query the device-side chain of
+    the multi-GPU path -- every shard's k-best keys -> global shortlist of 100 -> stage 1 on every shard's part of it ->
+    packed parts -> merge + P3P + pose refinement on the owner -- through the batch entry points
+    (sfmloc_shard_batch_*, sfmloc_merge_batch_begin).  Expected: the oracle's exact shortlist over all 50 000 vectors,
+    then the oracle's path on those 100 views, bit for bit (inlier pairs, unrefined P through a second, refine-less
+    merge), and the refined pose within 1e-7 of the oracle's Levenberg-Marquardt on the same inliers."""
+    import torch
+    import bench
+    from sfmlocalization_amd import capi
+    from sfmlocalization_amd import dist as D
+    V, n_sh, knn = 50000, 8, 100
+    m = synth.make_map(4, n_views=V, desc_per_view=2000)
+    assert m.n_rows == 100_000_000
+    queries = [synth.make_query(m, 4000 + i, n_feat=5000, n_copies=700) for i in range(3)]
+    bow, qbow = bench.synth_bow(m, queries)
+    f, ppx, ppy = m.intrinsic[:3]
+    bounds = [(V * r) // n_sh for r in range(n_sh + 1)]
+    B = len(queries)
+    budget = 512 * B
+    ppb = capi.packed_bytes(B, budget)
+    packed = torch.zeros((n_sh, ppb), dtype=torch.uint8, device="cuda")
+    keys_all = torch.zeros((n_sh, B, knn), dtype=torch.int64, device="cuda")
+    expected = []
+    for q, qb in zip(queries, qbow):
+        sel = oracle_c.bow_select(bow, qb, knn, None)
+        expected.append((opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), view_sel=sel, ransac_round=25, threads=8), sel))
+        assert expected[-1][0]["ok"]
+    poses = {}
+    for refine in (1, 0):
+        shards = [make_dev_map(m, bow, bounds[r], bounds[r + 1], refine_pose=refine) for r in range(n_sh)]
+        ctxs = [[s.context(), s.context(share=None)] for s in shards]     # two contexts per shard, a gang of 2
+        sqs = [[s.query(q.desc, q.kpt_xy, q.width, q.height) for q in queries] for s in shards]
+        for r in range(n_sh):
+            for dq, qb in zip(sqs[r], qbow):
+                dq.set_bow(qb)
+        packed.zero_()
+        torch.cuda.synchronize()
+        for r in range(n_sh):       # "all-gather" of the keys: every shard writes its slice of the gathered array
+            capi.shard_batch_bow_keys(ctxs[r], 2, sqs[r], knn, keys_all.data_ptr() + r * B * knn * 8)
+        for r in range(n_sh):
+            for c in ctxs[r]:
+                c.sync()
+        hk = keys_all.cpu().numpy().view(np.uint64)
+        for qi, (exp, sel) in enumerate(expected):
+            got = np.concatenate([bounds[r] + D.select_from_keys(hk[:, qi, :], knn, m.view_id[bounds[r]:bounds[r + 1]])
+                                  for r in range(n_sh)])
+            assert np.array_equal(np.sort(got), np.sort(sel)), "global shortlist of 100 of 50 000 views"
+        for r in range(n_sh):
+            capi.shard_batch_begin_bow(ctxs[r], 2, sqs[r], keys_all.data_ptr(), n_sh, knn, packed.data_ptr() + r * ppb, budget)
+        for r in range(n_sh):
+            for c in ctxs[r]:
+                c.sync()
+        for qi in range(B):
+            owner = qi % n_sh
+            capi.merge_batch_begin(ctxs[owner][:1], [sqs[owner][qi]], [qi], packed.data_ptr(), n_sh, ppb, B, budget)
+            poses[(refine, qi)] = ctxs[owner][0].end()
+        for r in range(n_sh):
+            for dq in sqs[r]:
+                dq.close()
+            for c in reversed(ctxs[r]):
+                c.close()
+            shards[r].close()
+    for qi, (exp, sel) in enumerate(expected):
+        check_pose(*poses[(0, qi)], exp)                                   # reference-equivalent output: the oracle's bits
+        p1, pq1, pl1 = poses[(1, qi)]
+        assert p1.ok and p1.n_inliers == exp["n_inliers"]
+        np.testing.assert_array_equal(pq1, exp["pair_qfeat"])
+        o = oracle_c.refine_pose(exp["pt2d"], exp["pt3d"], exp["inlier_idx"], f, ppx, ppy, exp["R"], exp["t"])
+        assert np.abs(np.array(p1.R).reshape(3, 3) - o["R"]).max() < 1e-7
+        assert np.abs(np.array(p1.center) - o["center"]).max() < 1e-7
+        assert len(exp["pair_qfeat"]) > 100
