@@ -52,7 +52,7 @@ K1_HEAD_ROWS = 64
 # HBM bytes per launch of the roofline kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
 # runs of this command, corrected as MI355X_MICROARCH.md prescribes; tools/run_profile.sh + tools/pmc_summary.py).
 # PMC cannot be collected from inside this process, so this one field is read from the committed summary.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary_fullscan.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary_fullscan.json")
 
 
 def parse(argv=None):
@@ -550,7 +550,14 @@ def image_in_phase(a, S, local_rank, log):
     for i in range(0, nf, max(1, nf // 3))[:3]:
         fe, ends = localise_frames(0, [i], record=False, staged=True)
         if capi.result_fingerprint(*ends[0]) != ref_fp[i]:
-            raise SystemExit(f"image-in: frame {i}: the staged route and the resident route give different results")
+            _, again = localise_frames(0, [i], record=False)
+            pa, pb = ends[0][0], again[0][0]
+            raise SystemExit(f"image-in: frame {i}: the staged route and the resident route give different results: staged "
+                             f"(ok {pa.ok}, 2d3d {pa.n_matches_2d3d}, inliers {pa.n_inliers}, iterations {pa.iterations}, views "
+                             f"{pa.n_putative_views}/{pa.n_geometric_views}, nfa {pa.nfa}) resident now (ok {pb.ok}, 2d3d "
+                             f"{pb.n_matches_2d3d}, inliers {pb.n_inliers}, iterations {pb.iterations}, views "
+                             f"{pb.n_putative_views}/{pb.n_geometric_views}, nfa {pb.nfa}); resident now == resident before: "
+                             f"{capi.result_fingerprint(*again[0]) == ref_fp[i]}")
         o = oracle_image_chain(world, frames[i], (pca, bowm), knn)
         kp, d = fe[0]
         pose, pq, pl = ends[0]

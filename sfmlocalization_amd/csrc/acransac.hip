@@ -1189,6 +1189,20 @@ __device__ void p3p_init_block(const P3pArgs &A, int n, int n_threads, double *s
     A.result->n_matches_2d3d = n;
     A.result->iterations = 0;
     A.result->status = st.status;
+    // a query that ends here (too few correspondences) must not report the PREVIOUS query's numbers: the record is the
+    // context's, and a result is a function of the query alone (bench.py / tests compare results bit for bit)
+    A.result->reserved = 0;
+    A.result->nfa = 0.0;
+    A.result->error_max = 0.0;
+    for (int i = 0; i < 12; ++i) A.result->P[i] = 0.0;
+    for (int i = 0; i < 9; ++i) {
+      A.result->K[i] = 0.0;
+      A.result->R[i] = 0.0;
+    }
+    for (int i = 0; i < 3; ++i) {
+      A.result->t[i] = 0.0;
+      A.result->center[i] = 0.0;
+    }
   }
   __syncthreads();
   if (!go) return;

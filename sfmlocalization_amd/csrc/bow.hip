@@ -318,6 +318,112 @@ __global__ __launch_bounds__(256) void k_bof_assign(const float *__restrict__ de
   }
 }
 
+// The same assignment with the work laid out for the machine (round 3: the one-thread-per-descriptor form above walks
+// 61 x 32 + 100 x 32 dependent operations per thread out of scratch arrays -- 616 us for the 10 000 descriptors of a
+// frame's dense grid, 13 % of the GPU time of the image-in path).  A workgroup takes kBofTile descriptors; every
+// (descriptor, PCA component) pair and every (descriptor, centre) pair is its own thread's chain -- the SAME chain of
+// float operations in the same order as above (and as the oracle), so the same bits -- with the descriptors, the PCA
+// basis, the projected vectors and the centres in LDS; the nearest centre of a descriptor is then the first minimum
+// over its row of distances.  Used when the model fits the LDS layout (the reference's: 61 -> 32, K = 100); any other
+// model takes the form above.
+constexpr int kBofTile = 32;
+struct BofTileLds {   // sized by the launcher: floats
+  static __host__ __device__ size_t floats(int in_dim, int n_pca, int cdim, int K) {
+    return (size_t)kBofTile * in_dim + (n_pca > 0 ? (size_t)in_dim + (size_t)n_pca * in_dim + n_pca : 0) +
+           (size_t)kBofTile * cdim + (size_t)K * cdim + (size_t)kBofTile * K;
+  }
+};
+__global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restrict__ desc, const float *__restrict__ kxy,
+                                                          int n, int in_dim, const float *__restrict__ pca_mean,
+                                                          const float *__restrict__ pca_evec,
+                                                          const float *__restrict__ pca_eval, int n_pca,
+                                                          const float *__restrict__ centers, int K, int resized,
+                                                          int levels, uint32_t *__restrict__ counts,
+                                                          const uint8_t *__restrict__ desc8) {
+  extern __shared__ float bof_lds[];
+  const int cdim = n_pca > 0 ? n_pca : in_dim;
+  float *sx = bof_lds;                                     // [tile][in_dim]
+  float *smean = sx + (size_t)kBofTile * in_dim;           // [in_dim]        } only with PCA
+  float *sevec = smean + (n_pca > 0 ? in_dim : 0);         // [n_pca][in_dim] }
+  float *seval = sevec + (n_pca > 0 ? (size_t)n_pca * in_dim : 0);  // [n_pca]
+  float *sy = seval + (n_pca > 0 ? n_pca : 0);             // [tile][cdim]
+  float *scen = sy + (size_t)kBofTile * cdim;              // [K][cdim]
+  float *sdist = scen + (size_t)K * cdim;                  // [tile][K]
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * kBofTile;
+  const int rows = min(kBofTile, n - r0);
+  for (int e = tid; e < rows * in_dim; e += 256) {
+    const int r = e / in_dim, i = e - r * in_dim;
+    sx[e] = desc8 ? (float)desc8[(size_t)(r0 + r) * 64 + i] : desc[(size_t)(r0 + r) * in_dim + i];
+  }
+  if (n_pca > 0) {
+    for (int e = tid; e < in_dim; e += 256) smean[e] = pca_mean[e];
+    for (int e = tid; e < n_pca * in_dim; e += 256) sevec[e] = pca_evec[e];
+    for (int e = tid; e < n_pca; e += 256) seval[e] = pca_eval[e];
+  }
+  for (int e = tid; e < K * cdim; e += 256) scen[e] = centers[e];
+  __syncthreads();
+  if (n_pca > 0) {
+    for (int e = tid; e < rows * n_pca; e += 256) {
+      const int r = e / n_pca, d = e - r * n_pca;
+      const float *x = sx + (size_t)r * in_dim, *ev = sevec + (size_t)d * in_dim;
+      float acc = 0.0f;
+      for (int i = 0; i < in_dim; ++i) {
+        const float c = x[i] - smean[i];
+        const float pr = c * ev[i];
+        acc = acc + pr;
+      }
+      sy[(size_t)r * cdim + d] = acc / seval[d];
+    }
+  } else {
+    for (int e = tid; e < rows * in_dim; e += 256) sy[e] = sx[e];
+  }
+  __syncthreads();
+  for (int e = tid; e < rows * K; e += 256) {
+    const int r = e / K, c = e - r * K;
+    const float *y = sy + (size_t)r * cdim, *cen = scen + (size_t)c * cdim;
+    float sacc = 0.0f;
+    for (int i = 0; i < cdim; ++i) {
+      const float d = y[i] - cen[i];
+      const float d2 = d * d;
+      sacc = sacc + d2;
+    }
+    sdist[e] = sacc;
+  }
+  __syncthreads();
+  if (tid < rows) {
+    const int r = r0 + tid;
+    int best = 0;
+    float bestd = INFINITY;
+    for (int c = 0; c < K; ++c) {
+      const float sacc = sdist[(size_t)tid * K + c];
+      if (sacc < bestd) {
+        bestd = sacc;
+        best = c;
+      }
+    }
+    const float px = kxy[2 * r], py = kxy[2 * r + 1];
+    int cell0 = 0;
+    for (int level = 0; level < levels; ++level) {
+      const int len = level + 1;
+      const int edge = resized / len;
+      if (level == 2) {
+        for (int cy = 0; cy < len; ++cy)
+          if (px >= 0 && px < (float)resized && py >= (float)(edge * cy) && py < (float)(edge * (cy + 1)))
+            atomicAdd(&counts[(size_t)K * (cell0 + cy) + best], 1u);
+        cell0 += 3;
+      } else {
+        for (int cx = 0; cx < len; ++cx)
+          for (int cy = 0; cy < len; ++cy)
+            if (px >= (float)(edge * cx) && px < (float)(edge * (cx + 1)) && py >= (float)(edge * cy) &&
+                py < (float)(edge * (cy + 1)))
+              atomicAdd(&counts[(size_t)K * (cell0 + cy * len + cx) + best], 1u);
+        cell0 += len * len;
+      }
+    }
+  }
+}
+
 // one thread per pyramid cell: counts -> /n -> per-cell normalisation, sequential in the reference's order
 __global__ void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, int cells, int norm_type,
                              double *__restrict__ out, float *__restrict__ out_f32) {
@@ -407,8 +513,16 @@ int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const floa
   const int cells = b->cells;
   SFM_HIP(hipMemsetAsync(d_counts, 0, (size_t)b->K * cells * sizeof(uint32_t), s));
   if (n > 0) {
-    hipLaunchKernelGGL(k_bof_assign, dim3((n + 255) / 256), dim3(256), 0, s, d_desc, d_kxy, n, b->in_dim, b->d_pca_mean,
-                       b->d_pca_evec, b->d_pca_eval, b->n_pca, b->d_centers, b->K, b->resized, b->levels, d_counts, d_desc8);
+    const size_t lds = BofTileLds::floats(b->in_dim, b->n_pca, b->cdim, b->K) * sizeof(float);
+    static const bool tiled_ok = [] { const char *e = getenv("SFMLOC_BOF_TILED"); return !(e && atoi(e) == 0); }();
+    if (tiled_ok && lds <= 60 * 1024) {  // the model fits the LDS layout (the reference's does: 45 KB)
+      hipLaunchKernelGGL(k_bof_assign_tiled, dim3((n + kBofTile - 1) / kBofTile), dim3(256), lds, s, d_desc, d_kxy, n,
+                         b->in_dim, b->d_pca_mean, b->d_pca_evec, b->d_pca_eval, b->n_pca, b->d_centers, b->K, b->resized,
+                         b->levels, d_counts, d_desc8);
+    } else {
+      hipLaunchKernelGGL(k_bof_assign, dim3((n + 255) / 256), dim3(256), 0, s, d_desc, d_kxy, n, b->in_dim, b->d_pca_mean,
+                         b->d_pca_evec, b->d_pca_eval, b->n_pca, b->d_centers, b->K, b->resized, b->levels, d_counts, d_desc8);
+    }
     SFM_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_bof_finish, dim3(1), dim3(64), 0, s, d_counts, n > 0 ? n : 1, b->K, cells, b->norm_type, d_out,

@@ -265,24 +265,24 @@ bool read_cv_yaml(const std::string &path, CvYaml *y) {
 }
 
 // The query-side BoW vector (DenseLocalFeatureWrapper -> PcaWrapper -> BoFSpatialPyramids, localization.cpp:346-361):
-// colour image -> 300x300 gray (sfmloc_dense_gray) -> AKAZE descriptors at the dense grid (sfmloc_akaze_compute,
-// cv::AKAZE::create() defaults) as floats -> PCA + BoF (sfmloc_bof_compute)
+// colour image -> 300x300 gray -> AKAZE descriptors at the dense grid (cv::AKAZE::create() defaults) as floats -> PCA +
+// BoF, as ONE resident chain on the device (sfmloc_imgbow: one extractor per image size, nothing but the image and the
+// vector crosses PCIe)
 struct DenseBow {
-  sfmloc_bof *bof = nullptr;
-  sfmloc_akaze *ak = nullptr;
-  int size = 300, device = 0;
-  std::vector<float> grid;  // x, y, size, class_id
+  CvYaml b, p;          // the model files' contents (the descriptor below points into them)
+  sfmloc_bof_desc d;
+  int device = 0;
+  bool ready = false;
+  std::map<std::pair<int, int>, sfmloc_imgbow *> by_size;
   bool init(const std::string &bow_file, const std::string &pca_file, int dev) {
     device = dev;
-    CvYaml b, p;
     if (!read_cv_yaml(bow_file, &b) || !b.mat.count("Centers")) return false;
-    sfmloc_bof_desc d;
     memset(&d, 0, sizeof(d));
     const CvYaml::Mat &cen = b.mat["Centers"];
     d.K = cen.rows;
     d.in_dim = 61;
     d.centers = cen.data.data();
-    size = d.resized_image_size = b.num.count("ResizedImageSize") ? (int)b.num["ResizedImageSize"] : 300;
+    d.resized_image_size = b.num.count("ResizedImageSize") ? (int)b.num["ResizedImageSize"] : 300;
     d.use_spatial_pyramid = b.num.count("UseSpatialPyramid") ? (int)b.num["UseSpatialPyramid"] : 1;
     d.pyramid_level = b.num.count("PyramidLevel") ? (int)b.num["PyramidLevel"] : 2;
     const std::string norm = b.str.count("NormBofFeatureType") ? b.str["NormBofFeatureType"] : "L1";
@@ -296,43 +296,24 @@ struct DenseBow {
       d.pca_eigvec = p.mat["EigenVectorsPCA"].data.data();  // first n_pca rows of [in_dim x in_dim]
       d.pca_eigval = p.mat["EigenValuesPCA"].data.data();
     }
-    if (sfmloc_bof_create(&d, device, &bof)) return false;
-    if (sfmloc_akaze_create(device, size, size, 4, 4, 0.001f, &ak)) return false;
-    float fs = 4.0f;  // DenseFeatureDetector.cpp:44-69 with DenseLocalFeatureWrapper.h:32-38
-    for (int s = 0; s < 4; ++s) {
-      for (int y = 0; y < size; y += 6)
-        for (int x = 0; x < size; x += 6) {
-          grid.push_back((float)x);
-          grid.push_back((float)y);
-          grid.push_back(fs);
-          grid.push_back((float)s);
-        }
-      fs = fs * 1.5f;
-    }
+    ready = true;
     return true;
   }
   bool compute(const std::vector<uint8_t> &bgr, int w, int h, std::vector<float> *out) {
-    std::vector<uint8_t> gray((size_t)size * size);
-    if (sfmloc_dense_gray(device, bgr.data(), (uint32_t)w, (uint32_t)h, (uint32_t)size, gray.data())) return false;
-    const uint32_t n = (uint32_t)(grid.size() / 4);
-    std::vector<uint8_t> desc((size_t)n * 64);
-    if (sfmloc_akaze_compute(ak, gray.data(), grid.data(), n, desc.data(), nullptr)) return false;
-    std::vector<float> feats((size_t)n * 61), kxy((size_t)n * 2);
-    for (uint32_t i = 0; i < n; ++i) {
-      for (int k = 0; k < 61; ++k) feats[(size_t)i * 61 + k] = (float)desc[(size_t)i * 64 + k];  // convertTo(CV_32FC1)
-      kxy[2 * i] = grid[4 * i];
-      kxy[2 * i + 1] = grid[4 * i + 1];
-    }
-    std::vector<double> bow(sfmloc_bof_dim(bof));
-    if (sfmloc_bof_compute(bof, feats.data(), kxy.data(), n, bow.data())) return false;
+    if (!ready) return false;
+    sfmloc_imgbow *&ib = by_size[std::make_pair(w, h)];
+    if (!ib && sfmloc_imgbow_create(&d, device, (uint32_t)w, (uint32_t)h, 3, &ib)) return false;
+    std::vector<double> bow((size_t)sfmloc_imgbow_dim(ib));
+    if (sfmloc_imgbow_compute(ib, bgr.data(), nullptr, bow.data())) return false;
     out->assign(bow.begin(), bow.end());
     return true;
   }
   ~DenseBow() {
-    if (ak) sfmloc_akaze_destroy(ak);
-    if (bof) sfmloc_bof_destroy(bof);
+    for (auto &kv : by_size)
+      if (kv.second) sfmloc_imgbow_destroy(kv.second);
   }
 };
+
 
 // Eigen IOFormat(6, 0, ",", ",\n", rowPrefix, rowSuffix, "[", "]"): 6 significant digits, columns aligned
 std::string eigen_format(const double *m, int rows, int cols, const char *row_prefix, const char *row_suffix) {
@@ -559,7 +540,7 @@ int main(int argc, char **argv) {
         // a precomputed <base>.bow next to the features if there is one, else from the colour image as the reference does
         have_bow = read_bow(join(fdir, base + ".bow"), &bow);
         if (!have_bow && have_img) {
-          if (!dense.bof && !dense.init(bow_model, pca_model, device)) {
+          if (!dense.ready && !dense.init(bow_model, pca_model, device)) {
             fprintf(stderr, "cannot load the BoW / PCA model (%s)\n", sfmloc_last_error());
             rc_all = 1;
             break;

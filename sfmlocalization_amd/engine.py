@@ -215,17 +215,31 @@ class DenseBow:
         self.device = device
         self.akaze = capi.Akaze(self.size, self.size, 4, 4, 0.001, device=device)   # cv::AKAZE::create() defaults
         self.grid = dense_grid_keypoints(self.size)
+        self._files = (bow_file, pca_file)
+        self._resident = {}     # (w, h): capi.ImgBow -- the same chain without the host round trips (sfmloc_imgbow)
 
     def local_features(self, bgr):
         gray = capi.dense_gray(bgr, self.size, device=self.device)
         desc, _ = self.akaze.compute(gray, self.grid)
         return desc[:, :61].astype(np.float32), self.grid[:, :2].copy(), gray      # convertTo(CV_32FC1)
 
-    def compute(self, bgr):
-        feats, kxy, _ = self.local_features(bgr)
-        return self.bof.compute(feats, kxy)
+    def compute(self, bgr, staged=False):
+        """-> the float64 BoF vector.  staged=True: the three stage-level calls (sfmloc_dense_gray, sfmloc_akaze_compute,
+        sfmloc_bof_compute); default: sfmloc_imgbow, one resident chain per image size -- the same bits."""
+        if staged:
+            feats, kxy, _ = self.local_features(bgr)
+            return self.bof.compute(feats, kxy)
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w = bgr.shape[:2]
+        ib = self._resident.get((w, h))
+        if ib is None:
+            ib = self._resident[(w, h)] = capi.ImgBow.from_files(self._files[0], self._files[1], w, h, 3, device=self.device)
+        return ib.compute(bgr)
 
     def close(self):
+        for ib in self._resident.values():
+            ib.close()
+        self._resident = {}
         self.akaze.close()
         self.bof.close()
 

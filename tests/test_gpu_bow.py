@@ -56,6 +56,29 @@ def test_bof_vector_matches_oracle(oracle_c):
     b2.close()
 
 
+@pytest.mark.parametrize("K,n_pca,n", [(100, 32, 9999), (100, 32, 31), (100, 32, 1), (37, 0, 5003), (400, 48, 3001), (7, 61, 650)])
+def test_bof_assignment_forms_match_oracle(oracle_c, K, n_pca, n):
+    """The LDS-tiled assignment (models that fit its layout: the reference's 61 -> 32, K = 100) and the
+    thread-per-descriptor one (anything larger: K = 400 x 48 does not fit) give the oracle's vector bit for bit: ragged
+    last tile, a single descriptor, no PCA, repeated centres (the first of equal distances wins: BoFSpatialPyramids.cpp:
+    230-243)."""
+    rng = np.random.Generator(np.random.PCG64(K * 1000 + n))
+    kxy = rng.uniform(0, 300, (n, 2)).astype(np.float32)
+    desc = rng.integers(0, 256, (n, 61)).astype(np.float32)
+    cdim = n_pca if n_pca else 61
+    pca = {}
+    if n_pca:
+        pca = dict(pca_mean=rng.uniform(0, 255, 61).astype(np.float32), pca_eigvec=rng.normal(size=(n_pca, 61)).astype(np.float32),
+                   pca_eigval=rng.uniform(0.5, 4.0, n_pca).astype(np.float32), n_pca=n_pca)
+    centers = (rng.normal(size=(K, cdim)) * (30 if n_pca else 1) + (0 if n_pca else 128)).astype(np.float32)
+    centers[K // 2] = centers[1]                                # a tie for every descriptor nearest to centre 1
+    b = S.BofModel(centers, 61, **pca)
+    got = b.compute(desc, kxy)
+    exp = oracle_c.bof(desc, kxy, centers, **pca)
+    np.testing.assert_array_equal(got.view(np.uint64), exp.view(np.uint64))
+    b.close()
+
+
 def test_sharded_shortlist_equals_unsharded(oracle_c):
     """sfmloc_bow_distances per shard + the (distance, view id) merge of dist.py = sfmloc_bow_select on the whole map;
     an empty local selection scans nothing (it must not fall back to "all views")."""

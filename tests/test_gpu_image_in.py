@@ -74,7 +74,7 @@ def test_frame_to_pose_on_the_device_equals_the_staged_route(world):
             # staged: everything through the host
             kp, desc = ak.detect_and_compute(frame)
             dq = dm.query(desc, kp[:, :2], W, H)
-            dq.set_bow(staged_bow.compute(np.stack([frame, frame, frame], 2)).astype(np.float32))
+            dq.set_bow(staged_bow.compute(np.stack([frame, frame, frame], 2), staged=True).astype(np.float32))
             ctx.begin_bow(dq, None, 12)
             want = ctx.end()
             dq.close()

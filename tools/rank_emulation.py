@@ -99,7 +99,7 @@ def main():
     class Emulated(D.ShardedLocalizer):
         """rank 0 of N; the collectives replaced by device copies of what the other ranks would have sent"""
 
-        def _all_gather(self, send):
+        def _all_gather(self, send, what="candidates"):
             stored = keys if send.dtype == torch.int64 else (parts if send.dim() == 1 else feats)
             out = torch.empty((N,) + tuple(send.shape), dtype=send.dtype, device=send.device)
             comm = self._comm_stream()
