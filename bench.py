@@ -628,7 +628,7 @@ def plan(a, world, replicas):
     gang = a.gang if a.gang > 0 else (16 if (world > 1 and not replicas) else int(os.environ.get("SFMLOC_GANG", "1")))
     gang = gang if sharded_mode else 1
     nctx = a.in_flight if a.in_flight > 0 else (4 if a.from_images else
-                                                (((32 if gang > 1 else 8) if sharded_mode else 12) if shortlist else 4))
+                                                (((32 if gang > 1 else 8) if sharded_mode else 20) if shortlist else 4))
     if a.threads == 0 and shortlist and nctx >= 8 and not a.from_images and not sharded_mode:
         a.threads = 4
     # one HW queue per stream that carries work (sfmlocalization_amd/_lib.py): a context each without gangs, a gang's

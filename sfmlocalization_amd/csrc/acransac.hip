@@ -780,13 +780,17 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_large(FFilterArgs A, FLarg
 //     evaluate the (up to 3) models side by side.
 // Results are bit-identical to k_fmatrix_filter (same samples, same arithmetic per value, same tie rules).
 // ---------------------------------------------------------------------------------------------------
-constexpr int kF2Waves = 16;
-constexpr int kF2Threads = kF2Waves * 64;
 constexpr int kF2MaxM = 512;   // putative matches per view (one wave sorts one model's residuals)
 constexpr int kF2Batch = 32;   // uniform iterations solved speculatively per batch
 
-struct F2Shared {
-  uint32_t idx[kF2Waves][kF2MaxM];  // sorted match indices of the model each wave evaluated last
+// (W = waves per view: 16 for a query alone on the GPU -- a view's latency --, 4 when the GPU is shared: a workgroup of 16
+// waves at 124 VGPRs is a compute unit's whole register file, i.e. it starts only on a compute unit nothing else runs on
+// and nothing else runs beside it; at 8 the Hamming scans of the other queries keep three of their waves per SIMD, at
+// 4 all of them.  Measured at 20 queries in flight: 16 / 8 / 4 waves 3 259 / 3 413 / 3 460 queries/s -- K3 costs the
+// others 13 us per query instead of 36.)
+template <int W>
+struct F2SharedT {
+  uint32_t idx[W][kF2MaxM];  // sorted match indices of the model each wave evaluated last
   double pts[4][kF2MaxM];  // normalised x, y of the map keypoint, u, w of the query keypoint (one plane each: a
                            // wave reading element p of 64 consecutive matches hits 64 different banks)
   int32_t vec_index[kF2MaxM];
@@ -832,13 +836,19 @@ __device__ void bitonic_sort_wave(uint64_t *kw, uint32_t *iw, int P) {
   }
 }
 
+template <int W>
 struct FmatrixFastBody {
-  static constexpr int kGangThreads = kF2Threads;
+  static constexpr int kGangThreads = W * 64;
   static __device__ __forceinline__ void run(FFilterArgs A) {
+    constexpr int kF2Waves = W, kF2Threads = W * 64;
+    using F2Shared = F2SharedT<W>;
 #include "fmatrix_fast.body.inc"
   }
 };
-__global__ __launch_bounds__(kF2Threads) void k_fmatrix_fast(FFilterArgs A) {
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_fmatrix_fast(FFilterArgs A) {
+  constexpr int kF2Waves = W, kF2Threads = W * 64;
+  using F2Shared = F2SharedT<W>;
 #include "fmatrix_fast.body.inc"
 }
 
@@ -1168,6 +1178,8 @@ __device__ void p3p_init_block(const P3pArgs &A, int n, int n_threads, double *s
     st.finished = 0;
     st.batch_limit = 1 << 30;
     st.switch_iter = 0;
+    st.prep_iter = -1;
+    st.prep_n = 0;
     st.min_nfa = pos_inf();
     st.errmax = pos_inf();
     for (int i = 0; i < 12; ++i) st.model[i] = 0.0;
@@ -1258,16 +1270,30 @@ __device__ __forceinline__ int p3p_next_batch_limit(const P3pArgs &A, int identi
 }
 __device__ __forceinline__ size_t p3p_inl_stride(int n, int max_n) { return n > kP3pMaxN ? (size_t)max_n : (size_t)kP3pMaxN; }
 
+// (the small members first, then idx, then key: the SMALL form of the round -- below -- allocates only kP3pSmallN entries
+// per wave of idx and nothing of key)
 struct P3pShared {
-  uint64_t key[kP3pMaxN];
-  uint32_t idx[kP3pMaxN];
   double models[48];
   P3pPrep prep;  // Kneip's intermediates + the quartic's roots (lane 0), read by the four model lanes
   int nm;
   double red_nfa[kThreads / 64];
   int red_k[kThreads / 64];
   double red_err[kThreads / 64];
+  uint32_t idx[kP3pMaxN];
+  uint64_t key[kP3pMaxN];
 };
+// The SMALL form of a round (k_p3p_round_small): match sets of at most kP3pSmallN correspondences, whose models are
+// sorted in at most kP3pSmallN / 64 registers per lane and never filtered.  k_p3p_round holds every form of the
+// evaluation -- up to 16 (key, index, two table values) per lane for the register sort, the LDS and global sorts, the
+// filter -- and the compiler gives it 248 VGPRs: ONE of its waves takes half a SIMD's register file, i.e. the place of
+// four waves of the Hamming scan (68 VGPRs) that other queries in flight are running, for the 30-90 us a round lasts,
+// and a round is 64-256 workgroups.  That, not K5's instructions (a tenth of the scan's) nor its LDS, is what K5 cost
+// the other queries.  The small form is the same code with the large cases compiled out.  The host queues a query's
+// rounds before it knows the set's size (Map::p3p_small_credit: the map's last queries were all small); a small round
+// that finds a larger set returns at once, state untouched -- as if it had not been launched --, and
+// ctx_resection_wait queues that query's rounds again in the full form.  The partition into rounds and the form of a
+// launch change nothing in the result.
+constexpr int kP3pSmallN = 512;
 
 // A round's results go from the workgroup that computed them to the one that replays the round, which may sit on
 // another XCD (another L2): they are written through (agent-scope stores), so that delivering them needs no L2
@@ -1499,6 +1525,36 @@ __device__ __forceinline__ bool p3p_filter_model_block(P3pFilterLds &F, const do
   return __ballot(any) != 0ull;
 }
 
+// one model evaluated by one wave in its registers: residuals of elements r * 64 + lane, register sort, NFA minimum;
+// the sorted indices go to iw[] (LDS).  -> r (NFA, k) and the k-th smallest residual.
+template <int E>
+__device__ __forceinline__ void p3p_eval_regs(const double (&M)[12], NfaBest &r, double &r_err, const double *__restrict__ pt3d,
+                                              const double *__restrict__ xn, const float *__restrict__ logc_n,
+                                              const float *__restrict__ logc_k, uint32_t *iw, int lane, int n, double logalpha0,
+                                              double loge0, int stamp_round, int b) {
+  uint64_t key[E];
+  uint32_t idx[E];
+  float cn[E], ck[E];
+  nfa_tables_fetch<E>(cn, ck, n, logc_n, logc_k);  // in flight during the residuals and the sort
+  // the wave is alone on its SIMD: the E residuals of a lane are computed without branches (clamped index, then a
+  // select) so that their dependent f64 chains -- two divisions each -- interleave
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) {
+    const int p = (rr << 6) + lane;
+    const int pc = p < n ? p : n - 1;
+    const double e = err_resection(M, pt3d[3 * pc], pt3d[3 * pc + 1], pt3d[3 * pc + 2], xn[2 * pc], xn[2 * pc + 1]);
+    key[rr] = p < n ? d2u(e) : ~0ull;
+    idx[rr] = (uint32_t)p;
+  }
+  STAMP_P3P(stamp_round, b, 6);
+  wave_sort_fast<E>(key, idx, iw);
+  STAMP_P3P(stamp_round, b, 7);
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) iw[(rr << 6) + lane] = idx[rr];
+  r = best_nfa_regs_ilp<E>(key, n, 3, pos_inf(), logalpha0, 1.0, loge0, cn, ck);
+  if (r.k != 0x7FFFFFFF) r_err = u2d(sorted_key_at<E>(key, r.k - 1));
+}
+
 // one hypothesis: sample, solve, evaluate the (up to 4) models, leave the best one's NFA / inliers / model in the
 // round's result arrays.  Executed by one workgroup of k_p3p_round -- or, in a WIDE launch (four workgroups per
 // hypothesis: model m of hypothesis b is workgroup m * batch + b) and from 513 correspondences on, by four, one model each: a model's residuals are
@@ -1507,6 +1563,7 @@ __device__ __forceinline__ bool p3p_filter_model_block(P3pFilterLds &F, const do
 // hypothesis's models wait for each other; with a workgroup per model it is 8 per thread, four times as many waves on the
 // compute unit, and the four models of a hypothesis side by side.  Results go to slot 4 b + m; the replay takes the
 // best model of each hypothesis (the first on ties, as the sequential loop over a hypothesis's models does).
+template <bool kSmall>
 __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch, int wide, unsigned char *smem_raw) {
   const P3pState &st = *A.state;
   const int per_model = wide ? (int)(gridDim.x >> 2) : (int)gridDim.x;  // hypotheses of the launch
@@ -1522,7 +1579,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   constexpr int s = 3;
   const int P = next_pow2(n);
   // one model per workgroup: a wide launch with enough correspondences (and the LDS forms: n <= kP3pMaxN)
-  const bool single = wide && P >= 1024 && n <= kP3pMaxN;
+  const bool single = !kSmall && wide && P >= 1024 && n <= kP3pMaxN;
   if (wide && !single && mdl != 0) {  // this hypothesis is workgroup 4 b's alone
     if (tid == 0) store_through(A.hyp_nfa + slot, pos_inf());
     return;
@@ -1535,17 +1592,27 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   // where the block-wide sort of this hypothesis runs
   uint64_t *const skey = n > kP3pMaxN ? A.ws_key + (size_t)b * A.max_n : S.key;
   uint32_t *const sidx = n > kP3pMaxN ? A.ws_idx + (size_t)b * A.max_n : S.idx;
-  const bool fast = P <= kP3pWaveSeg;
+  const bool fast = kSmall || P <= kP3pWaveSeg;
+  constexpr int wave_seg = kSmall ? kP3pSmallN : kP3pWaveSeg;  // entries of S.idx a wave owns
   const double logalpha0 = det_log10(3.14159265358979323846);
   const double loge0 = det_log10(4.0 * (double)(n - s));
   // the NFA filter (above): only once a model exists, only while its tables fit the idle part of the LDS
   const double nfa_to_beat = st.min_nfa;
   // (from 257 correspondences on: below that a model's register sort costs about what the filter does)
-  const bool filter = A.nfa_filter && nfa_to_beat < pos_inf() && n <= kP3pMaxN && P >= A.nfa_filter_min_p;
+  // (the small form has no LDS for the tables: its models are sorted, which gives the same result)
+  const bool filter = !kSmall && A.nfa_filter && nfa_to_beat < pos_inf() && n <= kP3pMaxN && P >= A.nfa_filter_min_p;
   P3pFilterLds &F = *reinterpret_cast<P3pFilterLds *>(S.key);
-  if (filter && tid >= 64)  // (wave 0 is busy: its lane 0 solves the P3P below)
-    p3p_filter_raw(F, n, s, nfa_to_beat, logalpha0, loge0, A.logc_n, A.logc_k, tid - 64, kThreads - 64);
-  if (tid == 0) {
+  // "Prepared ahead" (p3p_prepare_ahead, below): the models of this hypothesis may be there already
+  const bool have = st.prep_iter == st.iter && b < st.prep_n;
+  if (filter) {
+    if (have) p3p_filter_raw(F, n, s, nfa_to_beat, logalpha0, loge0, A.logc_n, A.logc_k, tid, kThreads);
+    else if (tid >= 64)  // (wave 0 is busy: its lane 0 solves the P3P below)
+      p3p_filter_raw(F, n, s, nfa_to_beat, logalpha0, loge0, A.logc_n, A.logc_k, tid - 64, kThreads - 64);
+  }
+  if (have) {
+    if (tid < 48) S.models[tid] = A.prep_models[48 * (size_t)b + tid];
+    if (tid == 0) S.nm = A.prep_nm[b];
+  } else if (tid == 0) {
     int32_t smp[3];
     ac_sample<3>(st.identity ? nullptr : A.vec_index, st.n_index, A.seed, STAGE_P3P, A.stream, (uint32_t)it, smp);
     double x[6], X[9];
@@ -1566,7 +1633,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     if (tid == 0) store_through(A.hyp_nfa + slot, pos_inf());
     return;
   }
-  if (tid < nm) p3p_kneip_model(S.prep, tid, S.models + 12 * tid);  // the four roots' models side by side
+  if (!have && tid < nm) p3p_kneip_model(S.prep, tid, S.models + 12 * tid);  // the four roots' models side by side
   if (filter) p3p_filter_scan(F, n);  // (two barriers inside: the models are visible behind them too)
   else __syncthreads();
   STAMP_P3P(stamp_round, b, 3);
@@ -1610,7 +1677,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     const int wv = tid >> 6, lane = tid & 63;
     const int my_model = single ? mdl : wv;
     const bool mine = single ? (wv == 0) : (wv < nm);
-    uint32_t *iw = S.idx + (size_t)wv * kP3pWaveSeg;
+    uint32_t *iw = S.idx + (size_t)wv * wave_seg;
     NfaBest r{pos_inf(), 0x7FFFFFFF};
     double r_err = pos_inf();
     if (mine && ((pass_mask >> my_model) & 1)) {
@@ -1620,40 +1687,53 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
       // (the lambda must not capture the kernel-argument struct: that would put all of it on the stack)
       const double *pt3d = A.pt3d, *xn = A.xn;
       const float *logc_n = A.logc_n, *logc_k = A.logc_k;
-#ifdef SFMLOC_STAMPS
-      auto run = [&M, &r, &r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b](auto e_tag) {
-#else
-      auto run = [&M, &r, &r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0](auto e_tag) {
+      if constexpr (kSmall) {
+        // (inlined: 152 VGPRs for the whole kernel, against 212 with the evaluation as a called function)
+#ifndef SFMLOC_STAMPS
+        const int stamp_round = 0;
 #endif
-        constexpr int E = decltype(e_tag)::value;
-        uint64_t key[E];
-        uint32_t idx[E];
-        float cn[E], ck[E];
-        nfa_tables_fetch<E>(cn, ck, n, logc_n, logc_k);  // in flight during the residuals and the sort
-        // the wave is alone on its SIMD: the E residuals of a lane are computed without branches (clamped index, then a
-        // select) so that their dependent f64 chains -- two divisions each -- interleave
-#pragma unroll
-        for (int rr = 0; rr < E; ++rr) {
-          const int p = (rr << 6) + lane;
-          const int pc = p < n ? p : n - 1;
-          const double e = err_resection(M, pt3d[3 * pc], pt3d[3 * pc + 1], pt3d[3 * pc + 2], xn[2 * pc], xn[2 * pc + 1]);
-          key[rr] = p < n ? d2u(e) : ~0ull;
-          idx[rr] = (uint32_t)p;
+        switch (P >> 6) {
+          case 1: p3p_eval_regs<1>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b); break;
+          case 2: p3p_eval_regs<2>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b); break;
+          case 4: p3p_eval_regs<4>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b); break;
+          default: p3p_eval_regs<8>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b); break;
         }
-        STAMP_P3P(stamp_round, b, 6);
-        wave_sort_fast<E>(key, idx, iw);
-        STAMP_P3P(stamp_round, b, 7);
+      } else {
+        // (a lambda the compiler keeps out of line -- the text of p3p_eval_regs once more: with a call to that function in
+        // it the compiler inlines all five instantiations and the kernel needs 256 VGPRs and a SIMD to itself)
+#ifdef SFMLOC_STAMPS
+        auto run = [&M, &r, &r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b](auto e_tag) {
+#else
+        auto run = [&M, &r, &r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0](auto e_tag) {
+#endif
+          constexpr int E = decltype(e_tag)::value;
+          uint64_t key[E];
+          uint32_t idx[E];
+          float cn[E], ck[E];
+          nfa_tables_fetch<E>(cn, ck, n, logc_n, logc_k);  // in flight during the residuals and the sort
 #pragma unroll
-        for (int rr = 0; rr < E; ++rr) iw[(rr << 6) + lane] = idx[rr];
-        r = best_nfa_regs_ilp<E>(key, n, 3, pos_inf(), logalpha0, 1.0, loge0, cn, ck);
-        if (r.k != 0x7FFFFFFF) r_err = u2d(sorted_key_at<E>(key, r.k - 1));
-      };
-      switch (P >> 6) {
-        case 1: run(std::integral_constant<int, 1>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        case 4: run(std::integral_constant<int, 4>{}); break;
-        case 8: run(std::integral_constant<int, 8>{}); break;
-        default: run(std::integral_constant<int, 16>{}); break;
+          for (int rr = 0; rr < E; ++rr) {
+            const int p = (rr << 6) + lane;
+            const int pc = p < n ? p : n - 1;
+            const double e = err_resection(M, pt3d[3 * pc], pt3d[3 * pc + 1], pt3d[3 * pc + 2], xn[2 * pc], xn[2 * pc + 1]);
+            key[rr] = p < n ? d2u(e) : ~0ull;
+            idx[rr] = (uint32_t)p;
+          }
+          STAMP_P3P(stamp_round, b, 6);
+          wave_sort_fast<E>(key, idx, iw);
+          STAMP_P3P(stamp_round, b, 7);
+#pragma unroll
+          for (int rr = 0; rr < E; ++rr) iw[(rr << 6) + lane] = idx[rr];
+          r = best_nfa_regs_ilp<E>(key, n, 3, pos_inf(), logalpha0, 1.0, loge0, cn, ck);
+          if (r.k != 0x7FFFFFFF) r_err = u2d(sorted_key_at<E>(key, r.k - 1));
+        };
+        switch (P >> 6) {
+          case 1: run(std::integral_constant<int, 1>{}); break;
+          case 2: run(std::integral_constant<int, 2>{}); break;
+          case 4: run(std::integral_constant<int, 4>{}); break;
+          case 8: run(std::integral_constant<int, 8>{}); break;
+          default: run(std::integral_constant<int, 16>{}); break;
+        }
       }
     }
     if (lane == 0) {
@@ -1674,7 +1754,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
       const int w_best = single ? 0 : best_m;
       best_err = S.red_err[w_best];
       int32_t *dst = A.hyp_inl + (size_t)slot * inl_stride;
-      const uint32_t *src = S.idx + (size_t)w_best * kP3pWaveSeg;
+      const uint32_t *src = S.idx + (size_t)w_best * wave_seg;
       for (int p = tid; p < best_k; p += kThreads) store_through(dst + p, (int32_t)src[p]);
     }
   } else
@@ -1914,6 +1994,7 @@ __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int
   const size_t inl_stride = p3p_inl_stride(st.n, A.max_n);
   // every thread replays the same scalar state machine; only the copies are cooperative
   long iter0 = st.iter, n_iter = st.n_iter, n_reserve = st.n_reserve;
+  const long switch_iter0 = st.switch_iter;
   const long n_iter_evaluated = n_iter;  // k_p3p_eval ran hypotheses iter0 <= it < min(iter0+batch, n_iter)
   double min_nfa = st.min_nfa, errmax = st.errmax;
   int n_in = st.n_in, n_index = st.n_index, identity = st.identity;
@@ -2021,9 +2102,23 @@ __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int
     // the index set switches to the inliers of a model found in an EARLIER round (end of the main phase)
     for (int p = tid; p < n_in; p += kThreads) A.vec_index[p] = A.best_inl[p];
   }
+  // (the index set is read again below -- "Prepared ahead" -- by other waves of this workgroup: the stores have left)
+  if (A.prep_ahead) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const bool done = (iter0 + processed >= n_iter);
+  const long iter_next = iter0 + processed;
+  const long switch_iter = (index_changed && identity0) ? iter_next : switch_iter0;
+  const int next_limit = p3p_next_batch_limit(A, identity, iter_next, switch_iter, st.n);
+  // how many of the coming round's hypotheses are solved here (none: every workgroup solves its own)
+  int n_prep = 0;
+  if (A.prep_ahead && !done) {
+    n_prep = next_limit < kP3pBatchMax ? next_limit : kP3pBatchMax;
+    n_prep = p3p_round_batch(st.n, n_prep);
+    if ((long)n_prep > n_iter - iter_next) n_prep = (int)(n_iter - iter_next);
+  }
   if (tid == 0) {
+    st.prep_iter = (int)iter_next;
+    st.prep_n = n_prep;
     st.iter = (int)(iter0 + processed);
     st.n_iter = (int)n_iter;
     st.n_reserve = (int)n_reserve;
@@ -2033,15 +2128,46 @@ __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int
     st.n_index = n_index;
     st.identity = identity;
     st.rounds += 1;
-    const long switch_iter = (index_changed && identity0) ? iter0 + processed : (long)st.switch_iter;
     st.switch_iter = (int)switch_iter;
-    st.batch_limit = p3p_next_batch_limit(A, identity, iter0 + processed, switch_iter, st.n);
+    st.batch_limit = next_limit;
     if (best_b >= 0)
       for (int q = 0; q < 12; ++q) st.model[q] = A.hyp_model[12 * best_slot + q];
     if (done) st.done = 1;
     st.arrive = 0u;  // the next round counts from zero
   }
   STAMP_SEL(stamp_round, 2);
+  // Prepared ahead.  In a round every workgroup spends its first 8-11 us with ONE lane solving its hypothesis's P3P --
+  // a chain of ~2 500 dependent f64 instructions -- while the other 255 lanes wait, and a lone lane costs its SIMD as
+  // many issue cycles as a full wave.  When the GPU is shared (prep_ahead) the workgroup that has just replayed the round
+  // solves the COMING round's hypotheses instead, one per lane (the same scalar code on the same inputs: the same bits):
+  // it knows the state they sample from, its 256 lanes take as long as one did, and the coming round's workgroups find
+  // their four models in memory (p3p_eval_hypothesis: `have`).  Whatever the coming launch does not cover by these
+  // (a larger batch, a state that moved on) is solved by its workgroup as before.  A query alone on the GPU keeps the
+  // old form: the four roots' models side by side are 5 us shorter than one lane doing them in turn.
+  if (n_prep > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the index set as this workgroup has just written it, not an L1 line
+    for (int h = tid; h < n_prep; h += kThreads) {
+      int32_t smp[3];
+      ac_sample<3>(identity ? nullptr : A.vec_index, n_index, A.seed, STAGE_P3P, A.stream, (uint32_t)(iter_next + h), smp);
+      double x[6], X[9];
+      for (int i = 0; i < 3; ++i) {
+        x[2 * i] = A.xn[2 * smp[i]];
+        x[2 * i + 1] = A.xn[2 * smp[i] + 1];
+        X[3 * i] = A.pt3d[3 * smp[i]];
+        X[3 * i + 1] = A.pt3d[3 * smp[i] + 1];
+        X[3 * i + 2] = A.pt3d[3 * smp[i] + 2];
+      }
+      P3pPrep prep;
+      const int nm = p3p_kneip_prepare(x, X, prep);
+      double *M = A.prep_models + 48 * (size_t)h;
+      for (int r = 0; r < nm; ++r) {
+        double Mr[12];
+        p3p_kneip_model(prep, r, Mr);
+        for (int q = 0; q < 12; ++q) M[12 * r + q] = Mr[q];
+      }
+      A.prep_nm[h] = nm;
+    }
+  }
 }
 
 // One round of P3P AC-RANSAC in one launch: every workgroup evaluates one hypothesis and delivers it (release fence +
@@ -2052,10 +2178,24 @@ __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int
 struct P3pRoundBody {
   static constexpr int kGangThreads = kThreads;
   static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
+    constexpr bool kSmall = false;
 #include "p3p_round.body.inc"
   }
 };
 __global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch, int wide) {
+  constexpr bool kSmall = false;
+#include "p3p_round.body.inc"
+}
+// the small form (above, at P3pShared): at most kP3pSmallN correspondences, a fraction of the registers
+struct P3pRoundSmallBody {
+  static constexpr int kGangThreads = kThreads;
+  static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
+    constexpr bool kSmall = true;
+#include "p3p_round.body.inc"
+  }
+};
+__global__ __launch_bounds__(kThreads) void k_p3p_round_small(P3pArgs A, int batch, int wide) {
+  constexpr bool kSmall = true;
 #include "p3p_round.body.inc"
 }
 
@@ -2373,11 +2513,21 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
     }
   }
   if (fast) {
-    const size_t lds2 = sizeof(F2Shared);
-    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(F2Shared));
-    SFM_HIP(attr2);
-    sfm_launch<FmatrixFastBody>(c, k_fmatrix_fast, dim3(n_sel), dim3(kF2Threads), (uint32_t)lds2, A);
+    // waves per view (F2SharedT): 16 for a query alone on the GPU, 4 when other contexts have work queued
+    static const int env_waves = [] { const char *e = getenv("SFMLOC_K3_WAVES_SHARED"); return e ? atoi(e) : 4; }();
+    static const int env_waves_alone = [] { const char *e = getenv("SFMLOC_K3_WAVES_ALONE"); return e ? atoi(e) : 16; }();
+    const int waves = c->k1_may_slice ? env_waves_alone : env_waves;
+    auto go = [&](auto w_tag) {
+      constexpr int W = decltype(w_tag)::value;
+      static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast<W>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(F2SharedT<W>));
+      if (attr2 != hipSuccess) return attr2;
+      sfm_launch<FmatrixFastBody<W>>(c, k_fmatrix_fast<W>, dim3(n_sel), dim3(W * 64), (uint32_t)sizeof(F2SharedT<W>), A);
+      return hipSuccess;
+    };
+    const hipError_t e2 = waves == 16 ? go(std::integral_constant<int, 16>{})
+                          : waves == 4 ? go(std::integral_constant<int, 4>{}) : go(std::integral_constant<int, 8>{});
+    SFM_HIP(e2);
     SFM_HIP(hipGetLastError());
   }
   const size_t lds = sizeof(FShared);
@@ -2577,6 +2727,8 @@ static P3pArgs make_p3p_args(Ctx *c) {
   A.hyp_k = c->d_hyp_k;
   A.hyp_err = c->d_hyp_err;
   A.hyp_model = c->d_hyp_model;
+  A.prep_models = c->d_prep_models;
+  A.prep_nm = c->d_prep_nm;
   A.hyp_inl = c->d_hyp_inl;
   A.pair_qfeat = c->d_pair_qfeat;
   A.pair_landmark = c->d_pair_landmark;
@@ -2603,6 +2755,9 @@ static P3pArgs make_p3p_args(Ctx *c) {
   static const int env_filter_p = [] { const char *e = getenv("SFMLOC_P3P_FILTER_MIN_P"); return e ? atoi(e) : 512; }();
   A.nfa_filter_min_p = env_filter_p;
   A.adaptive_batch = env_adaptive >= 0 ? env_adaptive : (c->k1_may_slice ? 0 : 1);
+  // (SFMLOC_P3P_PREP_AHEAD: 0 never, 1 when the GPU is shared -- the default --, 2 always: comparison runs and tests)
+  static const int env_prep = [] { const char *e = getenv("SFMLOC_P3P_PREP_AHEAD"); return e ? atoi(e) : 1; }();
+  A.prep_ahead = env_prep == 2 || (env_prep == 1 && A.adaptive_batch);
   static const int env_quarters = [] { const char *e = getenv("SFMLOC_P3P_ADAPT_QUARTERS"); return e ? atoi(e) : 12; }();
   static const int env_floor = [] { const char *e = getenv("SFMLOC_P3P_ADAPT_FLOOR"); return e ? atoi(e) : 64; }();
   A.adapt_quarters = env_quarters;
@@ -2638,7 +2793,13 @@ int launch_p3p_round(Ctx *c, int batch) {
   // host cannot know the match set's size when it queues the rounds.  Either launch shape gives the same bits.
   const int wide = (c->p3p_query_n > 512 && c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) ? 1 : 0;
   if (wide && batch > kP3pSlots / 4) batch = kP3pSlots / 4;
-  sfm_launch<P3pRoundBody>(c, k_p3p_round, dim3(wide ? 4 * batch : batch), dim3(kThreads), (uint32_t)lds, A, batch, wide);
+  // the small form (above, at P3pShared) when this query's rounds were queued on that prediction and nothing has refuted it
+  if (!wide && c->p3p_small) {
+    constexpr size_t lds_small = std::max(offsetof(P3pShared, idx) + 4 * kP3pSmallN * sizeof(uint32_t), sizeof(P3pReplayShared));
+    sfm_launch<P3pRoundSmallBody>(c, k_p3p_round_small, dim3(batch), dim3(kThreads), (uint32_t)lds_small, A, batch, 0);
+  } else {
+    sfm_launch<P3pRoundBody>(c, k_p3p_round, dim3(wide ? 4 * batch : batch), dim3(kThreads), (uint32_t)lds, A, batch, wide);
+  }
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -130,7 +130,7 @@ void free_ctx(Ctx *c) {
                   c->d_best64,    c->d_winner,    c->d_ms_n,       c->d_ms_qfeat,   c->d_ms_landmark, c->d_pt2d,
                   c->d_pt3d,      c->d_xn,        c->d_logc_n,     c->d_logc_k,     c->d_vec_index,  c->d_best_inl,
                   c->d_hyp_nfa,   c->d_hyp_err,   c->d_hyp_model,  c->d_hyp_k,      c->d_hyp_inl,
-                  c->d_inlier_idx,
+                  c->d_inlier_idx, c->d_prep_models, c->d_prep_nm,
                   c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters, c->d_flagmask, c->d_rows_scratch, c->d_rows_arrivals, c->d_flagged_desc,
                   c->d_geo_model, c->d_geo_j,     c->d_guided_row, c->d_geo_dist,
                   c->fl_key, c->fl_idx, c->fl_count, c->fl_list, c->fl_vec_index, c->fl_best_inl, c->fl_logc_n, c->fl_logc_k,
@@ -237,6 +237,8 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr, bool merge_only = false) {
   CTX_TRY(dev_alloc(acct, &c->d_hyp_err, (size_t)kP3pSlots));
   CTX_TRY(dev_alloc(acct, &c->d_hyp_model, (size_t)kP3pSlots * 12));
   CTX_TRY(dev_alloc(acct, &c->d_hyp_k, (size_t)kP3pSlots));
+  CTX_TRY(dev_alloc(acct, &c->d_prep_models, (size_t)kP3pBatchMax * 48));
+  CTX_TRY(dev_alloc(acct, &c->d_prep_nm, (size_t)kP3pBatchMax));
   CTX_TRY(dev_alloc(acct, &c->d_hyp_inl, (size_t)kP3pSlots * kP3pMaxN));
   CTX_TRY(dev_alloc(acct, &c->d_inlier_idx, (size_t)kP3pMaxN));
   // the regrowable P3P set as allocated above (ctx_p3p_reserve replaces it and keeps the accounts)
@@ -501,6 +503,12 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
   if (first_call) {
     rc = launch_p3p_init(c);
     if (rc) return rc;
+    // the form of this query's rounds (acransac.hip, at P3pShared: the small form holds sets of at most 512
+    // correspondences in a fraction of the registers): a prediction from the map's last queries -- or a certainty, when
+    // the query has no more features than that --; ctx_resection_wait corrects it if the set turns out larger
+    static const int env_small = [] { const char *e = getenv("SFMLOC_P3P_SMALL"); return e ? atoi(e) : 1; }();
+    c->p3p_small = env_small == 2 || (env_small == 1 && (c->p3p_query_n <= 512 ||
+                                                         c->map->p3p_small_credit.load(std::memory_order_relaxed) >= 8));
   }
   // typically 6-8 rounds end the stage (one per improvement of the model); rounds enqueued past the end return at
   // once but still cost two launches each, so the first call queues 9 and ctx_resection_wait adds more if needed
@@ -614,8 +622,12 @@ int ctx_resection_wait(Ctx *c) {
       // what the next queries' rounds look like (launch_p3p_round): this one's number of correspondences
       if (h->state.n > 512) c->map->p3p_wide_credit.store(64, std::memory_order_relaxed);
       else if (c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) c->map->p3p_wide_credit.fetch_sub(1, std::memory_order_relaxed);
+      if (h->state.n > 512) c->map->p3p_small_credit.store(0, std::memory_order_relaxed);
+      else if (c->map->p3p_small_credit.load(std::memory_order_relaxed) < 64) c->map->p3p_small_credit.fetch_add(1, std::memory_order_relaxed);
       return SFMLOC_OK;
     }
+    // (the small rounds of a set that turned out larger than the form holds all returned at once: the full form now)
+    if (c->p3p_small && h->state.n > 512) c->p3p_small = false;
     int rc;
     {
       EventScope ev(c, SFMLOC_K_P3P);

@@ -70,6 +70,9 @@ struct P3pState {
   int finished;     // the epilogue (pose, inlier pairs) has run (k_p3p_finish)
   int batch_limit;  // hypotheses the current round evaluates (<= the launch's grid); see p3p_next_batch_limit
   int switch_iter;  // iteration at which sampling switched to the best model's inliers
+  // hypotheses prep_iter .. prep_iter + prep_n - 1 have their P3P models in P3pArgs::prep_models already: the workgroup
+  // that replayed the previous round solved them, one hypothesis per lane (acransac.hip "Prepared ahead")
+  int prep_iter, prep_n;
   double min_nfa, errmax;
   double model[12];
 };
@@ -90,6 +93,9 @@ struct P3pArgs {
   int *hyp_k;
   double *hyp_err, *hyp_model;
   int32_t *hyp_inl;
+  double *prep_models;  // [kP3pBatchMax][4][12] models of the coming round's hypotheses ("Prepared ahead"), and how many
+  int *prep_nm;         // roots each has; prep_ahead = 0: every workgroup solves its own hypothesis
+  int prep_ahead;
   uint32_t *pair_qfeat, *pair_landmark, *inlier_idx;
   uint64_t *ws_key;  // [kP3pLargeBatch * max_n] sort segments for more than kP3pMaxN correspondences, or null
   uint32_t *ws_idx;
@@ -131,6 +137,9 @@ struct Map {
   // > 0 while recent queries had more than 512 2D-3D correspondences: K5's rounds are then launched wide (four
   // workgroups per hypothesis, acransac.hip).  Set to 64 by a finished query that had, counted down by the others.
   std::atomic<int> p3p_wide_credit{0};
+  // finished queries in a row whose 2D-3D set had at most 512 correspondences (acransac.hip kP3pSmallN): from 8 on a
+  // query's P3P rounds are queued in the small form (ctx_resection_enqueue)
+  std::atomic<int> p3p_small_credit{0};
   uint32_t n_views = 0;
   uint32_t n_landmarks = 0;
   std::vector<uint32_t> h_view_id, h_view_off, h_view_wh;
@@ -221,7 +230,8 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   double *d_xn = nullptr;                                                       // [kP3pMaxN*2]
   float *d_logc_n = nullptr, *d_logc_k = nullptr;                               // [kP3pMaxN+1]
   int32_t *d_vec_index = nullptr, *d_best_inl = nullptr;                        // [kP3pMaxN]
-  double *d_hyp_nfa = nullptr, *d_hyp_err = nullptr, *d_hyp_model = nullptr;
+  double *d_hyp_nfa = nullptr, *d_hyp_err = nullptr, *d_hyp_model = nullptr, *d_prep_models = nullptr;
+  int *d_prep_nm = nullptr;
   int *d_hyp_k = nullptr;
   int32_t *d_hyp_inl = nullptr;  // [kP3pBatchMax * kP3pMaxN]
   uint32_t *d_pair_qfeat = nullptr, *d_pair_landmark = nullptr, *d_inlier_idx = nullptr;  // [p3p_cap]
@@ -230,6 +240,7 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   // hypothesis gets a global-memory segment
   uint32_t p3p_cap = kP3pMaxN;
   uint64_t p3p_bytes = 0;  // bytes of the regrowable P3P arrays currently held (part of hbm_bytes)
+  bool p3p_small = false;  // this query's P3P rounds go out in the small form (decided when the first ones are queued)
   uint32_t p3p_query_n = 0;  // features of the query K5 is about to run for (ctx_p3p_reserve): launch shape of the rounds
   uint32_t *d_pair_qfeat_big = nullptr, *d_pair_landmark_big = nullptr;
   uint64_t *d_p3p_ws_key = nullptr;

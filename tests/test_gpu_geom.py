@@ -653,3 +653,69 @@ def test_shared_gpu_round_sizes_do_not_change_the_result():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert "every stage bit-exact" in r.stdout
 
+
+
+def test_small_p3p_rounds_prepared_hypotheses_and_the_fallback_to_the_full_form(oracle_c):
+    """Match sets of at most 512 correspondences take K5's small launch form (k_p3p_round_small: 152 VGPRs instead of
+    248, 11 KB of LDS instead of 50) when the query has no more features than that or the map's last 8 queries were that
+    small; the form is chosen before the set's size is known, a small round on a larger set leaves at once and the
+    query's rounds are queued again in the full form (acransac.hip kP3pSmallN, capi.hip ctx_resection_wait).  Ten small
+    queries (the prediction builds up), a large one (refuted), small ones again, the large one again: every result is
+    the oracle's, bit for bit.  Then whole campaigns in child processes with the forms forced (SFMLOC_P3P_SMALL = 2: every
+    query starts small, 0: never) and with the coming round's hypotheses solved by the replaying workgroup, one per lane,
+    always or never (SFMLOC_P3P_PREP_AHEAD = 2 / 0; by default only while the GPU is shared)."""
+    import os
+    import subprocess
+    import sys
+    m = synth.make_map(74, n_views=5, desc_per_view=1600, views_per_place=5, landmarks_per_place=1900, obs_per_view=1500,
+                       map_flips=8)
+    p3p_it = 300
+    dm = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, p3p_max_iteration=p3p_it),
+               view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+               landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    ctx = dm.context()
+    plan = [("small", 7400 + k) for k in range(10)] + [("large", 7420), ("small", 7421), ("small", 7422), ("large", 7423)]
+    sizes = []
+    for kind, seed in plan:
+        q = (synth.make_query(m, seed, n_feat=600, n_copies=260) if kind == "small" else
+             synth.make_query(m, seed, n_feat=1700, n_copies=1300, outlier_frac=0.1, query_flips=10))
+        exp = opipe.localize(m, q.desc, q.kpt_xy, (q.width, q.height), p3p_max_iteration=p3p_it)
+        sizes.append(len(exp["ms_qfeat"]))
+        dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)
+        ctx.begin(dq)
+        p, pq, pl = ctx.end()
+        dq.close()
+        assert bool(p.ok) == exp["ok"], (kind, seed)
+        if exp["ok"]:
+            np.testing.assert_array_equal(pq, exp["pair_qfeat"])
+            np.testing.assert_array_equal(pl, exp["pair_landmark"])
+            np.testing.assert_array_equal(bits(np.array(p.P)), bits(exp["P"].ravel()))
+    assert max(sizes[:10]) <= 512 and sizes[10] > 512 and sizes[13] > 512, sizes
+    ctx.close()
+    dm.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"SFMLOC_P3P_SMALL": "2", "SFMLOC_P3P_PREP_AHEAD": "2"}, {"SFMLOC_P3P_SMALL": "0", "SFMLOC_P3P_PREP_AHEAD": "2"},
+                  {"SFMLOC_P3P_SMALL": "2", "SFMLOC_P3P_PREP_AHEAD": "0"}):
+        env = dict(os.environ, **extra)
+        for tool, args, want in (("fuzz_p3p_large.py", ["8", "95000"], "bit-exact"), ("fuzz_parity.py", ["10", "78000"], "every stage bit-exact")):
+            r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", tool)] + args, env=env,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (extra, r.stdout[-2000:] + r.stderr[-2000:])
+            assert want in r.stdout
+
+
+def test_k3_waves_per_view_do_not_change_the_result():
+    """k_fmatrix_fast<W>: 16 waves per view for a query alone on the GPU, 4 while the GPU is shared (a 16-wave workgroup
+    is a compute unit's whole register file); 8 exists for comparison runs.  Same arithmetic, same replay: every stage
+    equals the oracle whichever W serves either situation (the choice is read when the library first runs: child
+    processes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for w in ("4", "8"):
+        env = dict(os.environ, SFMLOC_K3_WAVES_ALONE=w, SFMLOC_K3_WAVES_SHARED=w)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_parity.py"), "16", "79000"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (w, r.stdout[-2000:] + r.stderr[-2000:])
+        assert "every stage bit-exact" in r.stdout

@@ -1,0 +1,13 @@
+mkdir -p gpurun_out/r03_ab
+OUT=gpurun_out/r03_ab/ab.txt
+run() { label=$1; shift
+  env "$@" timeout -k 10 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline-phase --no-image-in $EXTRA_ARGS > gpurun_out/r03_ab/b.log 2> gpurun_out/r03_ab/b.err || { tail -30 gpurun_out/r03_ab/b.err; exit 1; }
+  python -c "
+import json; d=json.loads(open('gpurun_out/r03_ab/b.log').read().strip().splitlines()[-1]); print('$label:', round(d['value'],1), 'q/s |', round(1e6/d['value'],1), 'us/query | alone p50', round(d['latency_ms']['p50'],3), '| at throughput p50', round(d['latency_ms']['p50_at_throughput'],2), '| identical', d.get('identical_to_single_flight'))" | tee -a $OUT
+}
+rm -f $OUT
+run "K3: 16 waves alone, 8 shared (default)" X=1
+run "K3: 16 alone, 4 shared" SFMLOC_K3_WAVES_SHARED=4
+run "K3: 16 alone, 16 shared (old)" SFMLOC_K3_WAVES_SHARED=16
+run "default again" X=1
+EXTRA_ARGS="--in-flight 22" run "default, 22 in flight" X=1
