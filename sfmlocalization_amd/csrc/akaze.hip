@@ -793,6 +793,75 @@ struct OctaveResidentBody {
       // FED steps: A -> C -> A ...  The conductivity does not change within a level, so a thread keeps the four sums
       // (c + c_neighbour) of each of its pixels in registers; a neighbour outside the image is replaced by the pixel
       // itself, whose difference is +0 and gives the +0 flux the per-launch kernel writes there.
+      float *cur = A, *nxt = C;
+      // Round 3: when the image's rows cut into runs of kRun pixels give at most 1 024 runs (the 80 x 60 octave of a VGA
+      // image: 960), a thread owns ONE RUN: its pixels' values stay in registers from step to step, the neighbours
+      // inside the run are registers too, and a step reads 2 + 2 kRun values from LDS instead of 5 per pixel, at addresses
+      // fixed for the whole level (a missing neighbour's address is the pixel's own: the +0 difference again).  The
+      // workgroup is one compute unit's issue slots -- 99 of the schedule's steps run here -- and this form has about
+      // half the instructions per step; the arithmetic per pixel is the same expression in the same order.
+      constexpr int kRun = 5;
+      const int runs = (w + kRun - 1) / kRun;
+      if (h * runs <= 1024) {
+        const bool act = tid < h * runs;
+        const int y = act ? tid / runs : 0, x0 = act ? (tid - y * runs) * kRun : 0;
+        const int nx = act ? min(kRun, w - x0) : 0;
+        const int p0 = y * w + x0;
+        float cxp[kRun], cxn[kRun], cyp[kRun], cyn[kRun], v[kRun];
+        int iU[kRun], iD[kRun];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+          cxp[j] = cxn[j] = cyp[j] = cyn[j] = v[j] = 0.0f;
+          iU[j] = iD[j] = p0;
+          if (j < nx) {
+            const int p = p0 + j, x = x0 + j;
+            const float cc = B[p];
+            if (x + 1 < w) cxp[j] = cc + B[p + 1];
+            if (x > 0) cxn[j] = B[p - 1] + cc;
+            if (y + 1 < h) cyp[j] = cc + B[p + w];
+            if (y > 0) cyn[j] = B[p - w] + cc;
+            iU[j] = y > 0 ? p - w : p;
+            iD[j] = y + 1 < h ? p + w : p;
+            v[j] = cur[p];
+          }
+        }
+        const int iL = x0 > 0 ? p0 - 1 : p0;
+        const int iR = x0 + nx < w ? p0 + nx : p0 + (nx > 0 ? nx - 1 : 0);
+        for (int s = 0; s < R.nsteps[lv]; ++s) {
+          const float half_step = half_steps[R.step0[lv] + s];
+          if (act) {
+            const float left = cur[iL], right = cur[iR];
+            float up[kRun], dn[kRun];
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+              up[j] = cur[iU[j]];
+              dn[j] = cur[iD[j]];
+            }
+            float nv[kRun];
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+              const float vj = v[j];
+              const float vr = (j + 1 < kRun && j + 1 < nx) ? v[j + 1 < kRun ? j + 1 : j] : right;
+              const float vl = j > 0 ? v[j > 0 ? j - 1 : 0] : left;
+              const float xpos = cxp[j] * (vr - vj);
+              const float xneg = cxn[j] * (vj - vl);
+              const float ypos = cyp[j] * (dn[j] - vj);
+              const float yneg = cyn[j] * (vj - up[j]);
+              const float stp = half_step * (((xpos - xneg) + ypos) - yneg);
+              nv[j] = vj + stp;
+            }
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+              if (j < nx) nxt[p0 + j] = nv[j];
+              v[j] = nv[j];
+            }
+          }
+          __syncthreads();
+          float *const tswap = cur;
+          cur = nxt;
+          nxt = tswap;
+        }
+      } else {
       float cxp[kResidentPix], cxn[kResidentPix], cyp[kResidentPix], cyn[kResidentPix];
       int nb[kResidentPix];  // bit 0..3: neighbour x+1 / x-1 / y+1 / y-1 exists
 #pragma unroll
@@ -811,7 +880,6 @@ struct OctaveResidentBody {
           nb[k] = f;
         }
       }
-      float *cur = A, *nxt = C;
       for (int s = 0; s < R.nsteps[lv]; ++s) {
         const float half_step = half_steps[R.step0[lv] + s];
 #pragma unroll
@@ -832,6 +900,7 @@ struct OctaveResidentBody {
         float *const tswap = cur;
         cur = nxt;
         nxt = tswap;
+      }
       }
       float *const lt = Lt_all + R.off[lv];
       for (int p = tid; p < n; p += 1024) lt[p] = cur[p];
@@ -978,24 +1047,52 @@ struct SegScanBody {
                                              unsigned int *__restrict__ n_out) {
     __shared__ unsigned int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const unsigned int chunk = ((n_seg + 15u) / 16u + 63u) & ~63u;
+    // (four consecutive entries per lane and step -- one 16-byte load, a 1 KB line per wave --: a wave's walk is a chain of
+    // load -> shuffle scan -> store steps, and at one entry per lane a VGA image's 36 000 segments were 35 of them)
+    const unsigned int chunk = ((n_seg + 15u) / 16u + 255u) & ~255u;
     const unsigned int lo = min(n_seg, (unsigned int)wv * chunk), hi = min(n_seg, lo + chunk);
+    auto load4 = [&](unsigned int k, unsigned int (&c)[4]) {  // entries k .. k + 3, zero past hi (k is a multiple of 4)
+      if (k + 4 <= hi) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(seg_cnt + k);
+        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = k + u < hi ? seg_cnt[k + u] : 0u;
+      }
+    };
     unsigned int sum = 0;
-    for (unsigned int k = lo + lane; k < hi; k += 64) sum += seg_cnt[k];
+    for (unsigned int k = lo + 4 * lane; k < hi; k += 256) {
+      unsigned int c[4];
+      load4(k, c);
+      sum += (c[0] + c[1]) + (c[2] + c[3]);
+    }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if (lane == 0) wsum[wv] = sum;
     __syncthreads();
     unsigned int carry = 0;
     for (int q = 0; q < wv; ++q) carry += wsum[q];
-    for (unsigned int k0 = lo; k0 < hi; k0 += 64) {
-      const unsigned int k = k0 + lane;
-      const unsigned int c = k < hi ? seg_cnt[k] : 0u;
-      unsigned int inc = c;
+    for (unsigned int k0 = lo; k0 < hi; k0 += 256) {
+      const unsigned int k = k0 + 4 * lane;
+      unsigned int c[4] = {0u, 0u, 0u, 0u};
+      if (k < hi) load4(k, c);
+      const unsigned int mine = (c[0] + c[1]) + (c[2] + c[3]);
+      unsigned int inc = mine;
       for (int off = 1; off < 64; off <<= 1) {
         const unsigned int o = __shfl_up(inc, off, 64);
         if (lane >= off) inc += o;
       }
-      if (k < hi) seg_cnt[k] = carry + inc - c;
+      unsigned int run = carry + inc - mine;
+      if (k + 4 <= hi) {
+        uint4 o4;
+        o4.x = run; o4.y = run + c[0]; o4.z = run + c[0] + c[1]; o4.w = run + c[0] + c[1] + c[2];
+        *reinterpret_cast<uint4 *>(seg_cnt + k) = o4;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (k + u < hi) seg_cnt[k + u] = run;
+          run += c[u];
+        }
+      }
       carry += __shfl(inc, 63, 64);
     }
     if (tid == 0) {
@@ -1151,6 +1248,10 @@ struct SuppressBody {
         break;
       }
       // (b) the ready ones decide
+      // (tried in round 3: counting the decided candidates so that a round which decides everything ends the level --
+      // 33 -> 20 rounds on a sparse VGA frame, 34 -> 23 on a rich one -- and measured SLOWER, 77 -> 90 us and 250 -> 260 us:
+      // the closing round that finds nothing left costs less than the count's LDS atomics and the second exit cost every
+      // other round)
       for (unsigned int g = c0 + tid; g < c1; g += 1024) {
         if (st_c(g) != kUndecided || !rd_c(g)) continue;
         const uint32_t me = xy_c(g);
@@ -1432,6 +1533,20 @@ struct OrientDescribeBody {
                                         float2 *__restrict__ qkpt6 /*... and the same after the .feat text round trip*/) {
     __shared__ float resX[109], resY[109], Ang[109];
     __shared__ float vals[29 * 3];
+    // the M-LDB sample grid of the keypoint: positions (kk, l) in [-10, 10]^2, shared by the three cell grids
+    __shared__ float sDI[441], sDX[441], sDY[441];
+    __shared__ int8_t disc_i[109], disc_j[109];  // the q-th (i, j) of the orientation disc
+    if (threadIdx.x == 0) {
+      int cnt = 0;
+      for (int i = -6; i <= 6; ++i)
+        for (int j = -6; j <= 6; ++j)
+          if (i * i + j * j < 36) {
+            disc_i[cnt] = (int8_t)i;
+            disc_j[cnt] = (int8_t)j;
+            ++cnt;
+          }
+    }
+    __syncthreads();
     if (n_dev) n = (int)*n_dev;
     const int lane = threadIdx.x;
     // rows n .. the next multiple of 64 are zeroed: the descriptor array then IS a query block (sfmloc_query_create_view)
@@ -1448,16 +1563,7 @@ struct OrientDescribeBody {
     // --- orientation: 109 samples of the disc of radius 6 s ---
     for (int q = lane; q < 109; q += 64) {
       // q-th (i, j) of the double loop i = -6..6, j = -6..6 with i*i + j*j < 36
-      int cnt = 0, ii = 0, jj = 0;
-      for (int i = -6; i <= 6; ++i)
-        for (int j = -6; j <= 6; ++j)
-          if (i * i + j * j < 36) {
-            if (cnt == q) {
-              ii = i;
-              jj = j;
-            }
-            ++cnt;
-          }
+      const int ii = disc_i[q], jj = disc_j[q];
       const int iy = fround_d(yf + (float)(jj * s)), ix = fround_d(xf + (float)(ii * s));
       const int a = ii < 0 ? -ii : ii, b = jj < 0 ? -jj : jj;  // id[] = |.| mirrored table index
       const float g = gauss25[7 * a + b];
@@ -1517,6 +1623,26 @@ struct OrientDescribeBody {
     float si, co;
     det_sincosf(angle, &si, &co);
     const int scale = s;
+    // Round 3: the three cell grids (2 x 2 cells of 10 x 10 samples, 3 x 3 of 7 x 7, 4 x 4 of 5 x 5) sample the SAME
+    // positions (kk, l) of the rotated pattern; a cell's lane used to fetch its samples itself, one after the other --
+    // 100 dependent rounds of three global loads for a lane of the coarse grid, 50 us per keypoint whatever the machine
+    // does meanwhile.  Now the wave fetches the 21 x 21 positions once, side by side (7 per lane), and a cell's lane sums
+    // its samples from LDS -- the same values in the same (kk, l) order.
+    for (int t = lane; t < 441; t += 64) {
+      const int kk = t / 21 - 10, l = t - (t / 21) * 21 - 10;
+      const float sample_y = yf + ((float)l * co * (float)scale + (float)kk * si * (float)scale);
+      const float sample_x = xf + (-(float)l * si * (float)scale + (float)kk * co * (float)scale);
+      const int y1 = fround_d(sample_y), x1 = fround_d(sample_x);
+      const float ri = at_clamped(L.Lt, L.w, L.h, y1, x1);
+      const float rx = at_clamped(L.Lx, L.w, L.h, y1, x1) * L.sf;
+      const float ry = at_clamped(L.Ly, L.w, L.h, y1, x1) * L.sf;
+      const float rry = rx * co + ry * si;
+      const float rrx = -rx * si + ry * co;
+      sDI[t] = ri;
+      sDX[t] = rrx;
+      sDY[t] = rry;
+    }
+    __syncthreads();
     if (lane < 29) {
       int lvl, cell;
       if (lane < 4) {
@@ -1537,17 +1663,10 @@ struct OrientDescribeBody {
       int ns = 0;
       for (int kk = i0; kk < i0 + step; ++kk)
         for (int l = j0; l < j0 + step; ++l) {
-          const float sample_y = yf + ((float)l * co * (float)scale + (float)kk * si * (float)scale);
-          const float sample_x = xf + (-(float)l * si * (float)scale + (float)kk * co * (float)scale);
-          const int y1 = fround_d(sample_y), x1 = fround_d(sample_x);
-          const float ri = at_clamped(L.Lt, L.w, L.h, y1, x1);
-          const float rx = at_clamped(L.Lx, L.w, L.h, y1, x1) * L.sf;
-          const float ry = at_clamped(L.Ly, L.w, L.h, y1, x1) * L.sf;
-          di += ri;
-          const float rry = rx * co + ry * si;
-          const float rrx = -rx * si + ry * co;
-          dx += rrx;
-          dy += rry;
+          const int t = (kk + 10) * 21 + (l + 10);
+          di += sDI[t];
+          dx += sDX[t];
+          dy += sDY[t];
           ns++;
         }
       vals[lane * 3 + 0] = di / (float)ns;
@@ -1615,6 +1734,12 @@ struct Akaze : GangMember {  // (gang.h: `stream` reads as the stream to queue o
   float *d_resp = nullptr, *d_kp6 = nullptr;  // per keypoint: response; the six-float records of the C ABI
   float2 *d_qkpt = nullptr, *d_qkpt6 = nullptr;  // the keypoints as a query holds them: (x, y), and after the .feat round trip
   unsigned int *h_counts = nullptr;           // pinned copy of d_ncand
+  // sfmloc_akaze_detect_and_compute reads the counts and -- in the same transfer batch, before it knows the count -- the
+  // first spec_n keypoints and descriptors into pinned memory: an image with no more keypoints than that costs ONE
+  // synchronisation instead of two (~45 us); spec_n follows the last image's count
+  unsigned char *h_spec = nullptr;
+  unsigned int spec_n = 512;
+  static constexpr unsigned int kSpecMax = 4096;
   float *d_gauss25 = nullptr, *d_win = nullptr;
   uint16_t *d_pair = nullptr;
   float *d_kp = nullptr, *d_angle = nullptr;
@@ -1950,6 +2075,7 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (a->h_counts) hipHostFree(a->h_counts);
+  if (a->h_spec) hipHostFree(a->h_spec);
   if (a->own_stream) hipStreamDestroy(a->own_stream);
   delete a;
 }
@@ -2012,6 +2138,7 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   A((void **)&a->d_ckey, cc * sizeof(unsigned int));
   A((void **)&a->d_cslot, cc * sizeof(int));
   if (he == hipSuccess) he = hipHostMalloc((void **)&a->h_counts, 160 * sizeof(unsigned int), hipHostMallocDefault);
+  if (he == hipSuccess) he = hipHostMalloc((void **)&a->h_spec, (size_t)Akaze::kSpecMax * (6 * sizeof(float) + 64), hipHostMallocDefault);
   if (he == hipSuccess && ensure_kp_cap(a, a->cand_cap) != SFMLOC_OK) he = hipErrorOutOfMemory;  // (never regrown later)
   if (he == hipSuccess) {  // (k_suppress keeps two levels' candidates in LDS: more than the default 64 KB per workgroup)
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_suppress),
@@ -2150,11 +2277,28 @@ int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float
   hipStream_t s = a->stream;
   rc = akaze_counts_enqueue(a, s);
   if (rc) return rc;
+  // (speculative: the first spec_n records with the counts -- see Akaze::h_spec)
+  const unsigned int spec = a->spec_n < cap ? a->spec_n : cap;
+  float *const h_kp = reinterpret_cast<float *>(a->h_spec);
+  uint8_t *const h_desc = a->h_spec + (size_t)Akaze::kSpecMax * 6 * sizeof(float);
+  if (spec && kpts) SFM_HIP(hipMemcpyAsync(h_kp, a->d_kp6, (size_t)spec * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (spec && desc64) SFM_HIP(hipMemcpyAsync(h_desc, a->d_desc, (size_t)spec * 64, hipMemcpyDeviceToHost, s));
   SFM_HIP(hipStreamSynchronize(s));
   const double t_1 = timing ? now_s() : 0.0;
-  rc = akaze_outputs_enqueue(a, kpts, desc64, cap, n_out, s);
-  if (rc) return rc;
-  SFM_HIP(hipStreamSynchronize(s));
+  {
+    const unsigned int n = a->h_counts[1];
+    unsigned int next = ((n + n / 4 + 255u) / 256u) * 256u;  // a quarter of headroom, in steps of 256
+    a->spec_n = next < 256u ? 256u : (next > Akaze::kSpecMax ? Akaze::kSpecMax : next);
+    if (a->h_counts[0] <= a->cand_cap && n <= cap && n <= spec) {  // everything is here already
+      *n_out = n;
+      if (n && kpts) memcpy(kpts, h_kp, (size_t)n * 6 * sizeof(float));
+      if (n && desc64) memcpy(desc64, h_desc, (size_t)n * 64);
+    } else {
+      rc = akaze_outputs_enqueue(a, kpts, desc64, cap, n_out, s);
+      if (rc) return rc;
+      SFM_HIP(hipStreamSynchronize(s));
+    }
+  }
   if (timing)
     fprintf(stderr, "akaze %dx%d: device (scale space .. descriptors) %.3f ms, outputs %.3f ms (%u candidates -> %u keypoints, "
                     "%u suppression rounds: first pass %.1f us, second %.1f, sub-pixel + compaction %.1f)\n", a->w, a->h,

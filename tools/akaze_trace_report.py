@@ -11,7 +11,7 @@ prev_end = t0
 busy = 0
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sfmloc::(anonymous namespace)::", "").replace("sfmloc::", "")
+    name = r["Kernel_Name"].replace("void ", "").replace("sfmloc::(anonymous namespace)::", "").replace("sfmloc::", "").split("(")[0]
     print(f"{(s - t0) / 1e3:8.1f} us  +{(s - prev_end) / 1e3:6.1f} gap  {(e - s) / 1e3:7.1f} us  {name[:70]}  grid {r.get('Grid_Size_X', '')}x{r.get('Grid_Size_Y', '')} wg {r.get('Workgroup_Size_X', '')}")
     busy += e - s
     prev_end = max(prev_end, e)
