@@ -308,5 +308,87 @@ class LocalizeEngine {
   std::map<std::pair<int, int>, sfmloc_akaze *> mAkaze;
 };
 
+// One rank of a map sharded by view over N GPUs (include/sfmloc.h "A rank's whole batch per call"): the
+// contexts of the two stages and the batch entry points over them, for a C++ host that drives the exchange itself
+// (RCCL / MPI all-gathers of `keys` and `packed` between the calls; dist.py is the Python host of the same calls).
+//   stage 1 (every rank, every query of the batch): bowKeys -> [all-gather keys] -> stage1Bow -> [all-gather packed]
+//   stage 2 (the owner of a query, i mod N):        stage2 -> finish(k) per context
+// Every call is asynchronous; ordering against the caller's communication stream is by sfmloc_context_signal / _wait on
+// the contexts (context(i) / mergeContext(k)).  Results are those of the unsharded path (tests/test_gpu_gang.py,
+// tests/test_gpu_fullsize.py drive the same entry points).
+class ShardRank {
+ public:
+  // map: this rank's shard (opened with its view range); nStage1 contexts in sessions of `gang` (<= 32), nStage2 <= 32
+  ShardRank(sfmloc_map *map, uint32_t nStage1 = 32, uint32_t gang = 16, uint32_t nStage2 = 32) : mGang(gang) {
+    if (!map || gang < 1 || gang > 32 || nStage1 < gang || nStage1 % gang || nStage2 < 1 || nStage2 > 32)
+      throw std::invalid_argument("ShardRank: 1 <= gang <= 32, nStage1 a multiple of gang, 1 <= nStage2 <= 32");
+    try {
+      for (uint32_t i = 0; i < nStage1; ++i) {  // the first context of a session lends its stream to the others
+        sfmloc_context *c = nullptr;
+        sfmloc_context *lender = (i % gang) ? mStage1[i - i % gang] : nullptr;
+        if (lender ? sfmloc_context_create_sharing(map, lender, &c) : sfmloc_context_create(map, &c))
+          throw std::runtime_error(sfmloc_last_error());
+        mStage1.push_back(c);
+      }
+      for (uint32_t k = 0; k < nStage2; ++k) {  // stage 2 needs no matching workspace
+        sfmloc_context *c = nullptr;
+        if (sfmloc_context_create_merge(map, k ? mStage2[0] : nullptr, &c)) throw std::runtime_error(sfmloc_last_error());
+        mStage2.push_back(c);
+      }
+    } catch (...) {
+      destroy();
+      throw;
+    }
+  }
+  ShardRank(const ShardRank &) = delete;
+  ShardRank &operator=(const ShardRank &) = delete;
+  ~ShardRank() { destroy(); }
+
+  sfmloc_context *context(uint32_t i) const { return mStage1.at(i); }
+  sfmloc_context *mergeContext(uint32_t k) const { return mStage2.at(k); }
+  uint32_t stage2Capacity() const { return (uint32_t)mStage2.size(); }
+  static uint64_t packedBytes(uint32_t nQueries, uint32_t budget) { return sfmloc_packed_bytes(nQueries, budget); }
+
+  // every query's knn best views of this shard as 64-bit keys -> keysDev [nQueries][knn] (device memory)
+  void bowKeys(sfmloc_query *const *queries, uint32_t nQueries, uint32_t knn, void *keysDev) {
+    check(sfmloc_shard_batch_bow_keys(mStage1.data(), (uint32_t)mStage1.size(), mGang, queries, nQueries, knn, keysDev));
+  }
+  // stage 1 on this shard's part of the global shortlist (keysAllDev: the gathered keys of nParts ranks); the batch's
+  // candidates -> packedDev (packedBytes(nQueries, budget))
+  void stage1Bow(sfmloc_query *const *queries, uint32_t nQueries, const void *keysAllDev, uint32_t nParts, uint32_t knn,
+                 void *packedDev, uint32_t budget) {
+    check(sfmloc_shard_batch_begin_bow(mStage1.data(), (uint32_t)mStage1.size(), mGang, queries, nQueries, keysAllDev, nParts,
+                                       knn, packedDev, budget));
+  }
+  // ... without a shortlist: every view of the shard
+  void stage1(sfmloc_query *const *queries, uint32_t nQueries, void *packedDev, uint32_t budget) {
+    check(sfmloc_shard_batch_begin(mStage1.data(), (uint32_t)mStage1.size(), mGang, queries, nQueries, packedDev, budget));
+  }
+  // stage 2 of n <= stage2Capacity() queries this rank owns: merge context k takes batch query queryIndex[k], whose
+  // candidates lie in the gathered parts (packedAllDev: nParts parts, partStride bytes apart, 0 = back to back)
+  void stage2(sfmloc_query *const *queries, const uint32_t *queryIndex, uint32_t n, const void *packedAllDev, uint32_t nParts,
+              uint64_t partStride, uint32_t nQueries, uint32_t budget) {
+    if (n > mStage2.size()) throw std::invalid_argument("ShardRank::stage2: more queries than merge contexts");
+    check(sfmloc_merge_batch_begin(mStage2.data(), n, queries, queryIndex, packedAllDev, nParts, partStride, nQueries, budget));
+  }
+  // the result of merge context k's query (waits for it): pose + inlier pairs, as sfmloc_localize_end
+  void finish(uint32_t k, sfmloc_pose *pose, uint32_t *pairQfeat, uint32_t *pairLandmark, uint32_t cap) {
+    check(sfmloc_localize_end(mStage2.at(k), pose, pairQfeat, pairLandmark, cap));
+  }
+
+ private:
+  static void check(int rc) {
+    if (rc) throw std::runtime_error(sfmloc_last_error());
+  }
+  void destroy() {
+    for (size_t k = mStage2.size(); k-- > 0;) sfmloc_context_destroy(mStage2[k]);
+    for (size_t i = mStage1.size(); i-- > 0;) sfmloc_context_destroy(mStage1[i]);  // borrowers before their lenders
+    mStage2.clear();
+    mStage1.clear();
+  }
+  uint32_t mGang;
+  std::vector<sfmloc_context *> mStage1, mStage2;
+};
+
 }  // namespace sfmloc
 #endif  // SFMLOC_ENGINE_HPP

@@ -286,6 +286,13 @@ def test_engine_mirror_return_convention(toy):
     assert vfar == []
     vnear, _, _, _ = run_cpp("-", ["%r" % q.C_true[0], "%r" % q.C_true[1], "%r" % q.C_true[2], "1600"])
     assert vnear == near
+    # sfmloc::ShardRank (the same header): a rank's batch entry points from C++, world size 1 -- two copies of the query
+    # through a gang session of stage 1 and the merge contexts of stage 2 = the unsharded sfmloc_localize, bit for bit
+    shard_smoke = os.path.join(os.path.dirname(CLI_BIN), "shard_rank_smoke")
+    r = subprocess.run([shard_smoke, str(root / "sfm"), str(root / "matches"), qd, qf, "640", "480"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.split() == ["OK", str(len(inl))]
     e0.close()
     e1.close()
 
