@@ -2041,9 +2041,26 @@ int orient_describe(Akaze *a, const std::vector<float> &kin, unsigned int n, flo
 // for callers inside the library (imgbow.hip): see sfmloc_internal.h
 uint8_t *akaze_gray_dev(Akaze *a) { return a->d_gray; }
 uint8_t *akaze_desc_dev(Akaze *a) { return a->d_desc; }
-hipStream_t akaze_stream_now(Akaze *a) { return a->stream; }
+// The extractor's stream for work queued NOW: its own is created at the first call that needs one.  An extractor that
+// has worked in gang sessions before (on the leader's stream) must not overtake that work on its new stream.
+static int akaze_ensure_stream(Akaze *a) {
+  if (a->stream.own) return SFMLOC_OK;
+  if (!a->own_stream) {
+    SFM_HIP(hipSetDevice(a->device));
+    SFM_HIP(hipStreamCreateWithFlags(&a->own_stream, hipStreamNonBlocking));
+    if (a->ever_ganged) SFM_HIP(hipDeviceSynchronize());
+  }
+  a->stream.own = a->own_stream;
+  return SFMLOC_OK;
+}
+hipStream_t akaze_stream_now(Akaze *a) {
+  (void)akaze_ensure_stream(a);
+  return a->stream;
+}
 int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n) {
-  int rc = ensure_kp_cap(a, n);  // (before anything is queued: it may free and allocate)
+  int rc = akaze_ensure_stream(a);
+  if (rc) return rc;
+  rc = ensure_kp_cap(a, n);  // (before anything is queued: it may free and allocate)
   if (rc) return rc;
   rc = build_scale_space(a, nullptr);
   if (rc || n == 0) return rc;
@@ -2102,8 +2119,10 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   a->thres = threshold;
   make_plan(width, height, n_octaves, n_sublevels, a->plan);
   const size_t n0 = (size_t)width * height, tot = a->plan.total;
-  hipError_t he = hipStreamCreateWithFlags(&a->own_stream, hipStreamNonBlocking);
-  a->stream.own = a->own_stream;
+  // (no stream yet: akaze_ensure_stream creates one at the first call that needs it -- an extractor that is given a
+  // context's stream right away, or only ever works in sessions led by another, never needs one, and a stream that merely
+  // EXISTS shares a hardware queue with streams that work: DESIGN.md 4 Concurrency)
+  hipError_t he = hipSuccess;
   auto A = [&](void **p, size_t bytes) {
     if (he == hipSuccess) he = hipMalloc(p, bytes);
   };
@@ -2180,8 +2199,8 @@ int sfmloc_akaze_share_stream(sfmloc_akaze *ak, sfmloc_context *ctx) {
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   SFM_CHECK(!c || c->map->device == a->device, SFMLOC_EINVAL, "sfmloc_akaze_share_stream: extractor and context on different devices");
   hipSetDevice(a->device);
-  if (a->stream) hipStreamSynchronize(a->stream);
-  a->stream.own = c ? c->stream.own : a->own_stream;
+  if (a->stream.own) hipStreamSynchronize(a->stream);
+  a->stream.own = c ? c->stream.own : a->own_stream;  // (nullptr: created when first needed, akaze_ensure_stream)
   return SFMLOC_OK;
 }
 
@@ -2201,7 +2220,7 @@ int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt) {
   SFM_CHECK(ak, SFMLOC_EINVAL, "sfmloc_akaze_read_levels: null argument");
   Akaze *a = reinterpret_cast<Akaze *>(ak);
   SFM_HIP(hipSetDevice(a->device));
-  SFM_HIP(hipStreamSynchronize(a->stream));
+  if (a->stream.own) SFM_HIP(hipStreamSynchronize(a->stream));
   if (ldet) SFM_HIP(hipMemcpy(ldet, a->d_Ldet, a->plan.total * sizeof(float), hipMemcpyDeviceToHost));
   if (lt) SFM_HIP(hipMemcpy(lt, a->d_Lt, a->plan.total * sizeof(float), hipMemcpyDeviceToHost));
   return SFMLOC_OK;
@@ -2272,7 +2291,9 @@ int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float
   SFM_HIP(hipSetDevice(a->device));
   static const bool timing = getenv("SFMLOC_AKAZE_TIMING") != nullptr;
   const double t_0 = timing ? now_s() : 0.0;
-  int rc = akaze_detect_enqueue(a, gray);
+  int rc = akaze_ensure_stream(a);
+  if (rc) return rc;
+  rc = akaze_detect_enqueue(a, gray);
   if (rc) return rc;
   hipStream_t s = a->stream;
   rc = akaze_counts_enqueue(a, s);
@@ -2333,7 +2354,9 @@ int sfmloc_akaze_detect_and_compute_batch(sfmloc_akaze *const *aks, const uint8_
   SFM_HIP(hipSetDevice(first->device));
   static const bool timing = getenv("SFMLOC_AKAZE_TIMING") != nullptr;
   const double t_0 = timing ? now_s() : 0.0;
-  int rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
+  int rc = akaze_ensure_stream(first);
+  if (rc) return rc;
+  rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
   for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = akaze_detect_enqueue(reinterpret_cast<Akaze *>(aks[i]), grays[i]);
   const int rc_close = gang_close(first);
   if (rc == SFMLOC_OK) rc = rc_close;
@@ -2374,7 +2397,9 @@ int sfmloc_akaze_detect_resident_batch(sfmloc_akaze *const *aks, const uint8_t *
     ms[i] = a;
   }
   SFM_HIP(hipSetDevice(first->device));
-  int rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
+  int rc = akaze_ensure_stream(first);  // (the session runs on the first extractor's stream; the others need none)
+  if (rc) return rc;
+  rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
   for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) rc = akaze_detect_enqueue(reinterpret_cast<Akaze *>(aks[i]), grays[i]);
   const int rc_close = n > 1 ? gang_close(first) : SFMLOC_OK;
   if (rc == SFMLOC_OK) rc = rc_close;
@@ -2412,7 +2437,9 @@ int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin
   SFM_CHECK(ak && gray && (n == 0 || (kin && desc64)), SFMLOC_EINVAL, "sfmloc_akaze_compute: null argument");
   Akaze *a = reinterpret_cast<Akaze *>(ak);
   SFM_HIP(hipSetDevice(a->device));
-  int rc = build_scale_space(a, gray);
+  int rc = akaze_ensure_stream(a);
+  if (rc) return rc;
+  rc = build_scale_space(a, gray);
   if (rc) return rc;
   std::vector<float> k(kin, kin + (size_t)n * 4);
   for (uint32_t i = 0; i < n; ++i) {

@@ -821,11 +821,14 @@ int gang_open(GangMember *const *members, int n) {
     SFM_HIP(hipEventCreateWithFlags(&lead->gang_owned->done, hipEventDisableTiming));
   }
   GangState *g = lead->gang_owned;
+  SFM_CHECK(lead->stream.own, SFMLOC_EINVAL, "gang session: the leading member has no stream");
   g->stream = lead->stream.own;
   g->members.clear();
   for (int i = 0; i < n; ++i) {
     GangMember *c = members[i];
-    if (i > 0 && c->stream.dirty && c->stream.own != g->stream) {  // the member's own earlier work comes first
+    c->ever_ganged = true;
+    // (own == nullptr: a member that has no stream of its own yet -- an extractor that only ever worked in sessions)
+    if (i > 0 && c->stream.own && c->stream.dirty && c->stream.own != g->stream) {  // the member's own earlier work comes first
       if (!c->gang_ev) SFM_HIP(hipEventCreateWithFlags(&c->gang_ev, hipEventDisableTiming));
       SFM_HIP(hipEventRecord(c->gang_ev, c->stream.own));
       SFM_HIP(hipStreamWaitEvent(g->stream, c->gang_ev, 0));
@@ -845,11 +848,12 @@ int gang_close(GangMember *lead) {
   lead->stream.dirty = true;
   // the members' own streams continue after the gang's work
   bool any_own = false;
-  for (size_t i = 1; i < g->members.size(); ++i) any_own |= g->members[i]->stream.own != g->stream;
+  for (size_t i = 1; i < g->members.size(); ++i)
+    any_own |= g->members[i]->stream.own && g->members[i]->stream.own != g->stream;
   if (any_own) {
     SFM_HIP(hipEventRecord(g->done, g->stream));
     for (size_t i = 1; i < g->members.size(); ++i)
-      if (g->members[i]->stream.own != g->stream) {
+      if (g->members[i]->stream.own && g->members[i]->stream.own != g->stream) {
         SFM_HIP(hipStreamWaitEvent(g->members[i]->stream.own, g->done, 0));
         // the member's stream now carries a dependency on the session's work: a later session under ANOTHER leader
         // must order itself after it (gang_open records and waits only for dirty members) -- ADVICE r02
@@ -1963,8 +1967,9 @@ int sfmloc_bof_create(const sfmloc_bof_desc *d, int device, sfmloc_bof **out) {
   for (int l = 0; l < b->levels; ++l) b->cells += (l == 0) ? 1 : (l == 2 ? 3 : (l + 1) * (l + 1));
   uint64_t acct = 0;
   int rc = SFMLOC_OK;
-  hipError_t se = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-  if (se != hipSuccess) rc = SFMLOC_EHIP;
+  // (the model's own stream is created by the first sfmloc_bof_compute: a model inside a sfmloc_imgbow works on that
+  // object's stream and needs none -- an idle stream still shares a hardware queue with streams that work; the uploads
+  // here go through the null stream)
   if (!rc) rc = dev_upload(&acct, &b->d_centers, d->centers, (size_t)d->K * b->cdim, b->stream);
   if (!rc && d->n_pca > 0) {
     rc = dev_upload(&acct, &b->d_pca_mean, d->pca_mean, (size_t)d->in_dim, b->stream);
@@ -2012,11 +2017,12 @@ int sfmloc_bof_compute(sfmloc_bof *bof, const float *desc, const float *kpt_xy, 
     SFM_HIP(hipMalloc((void **)&b->d_kxy, (size_t)n * 2 * sizeof(float)));
     b->cap_n = (int)n;
   }
+  if (!b->stream) SFM_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   if (n) {
     SFM_HIP(hipMemcpyAsync(b->d_desc, desc, (size_t)n * b->in_dim * sizeof(float), hipMemcpyHostToDevice, b->stream));
     SFM_HIP(hipMemcpyAsync(b->d_kxy, kpt_xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, b->stream));
   }
-  int rc = launch_bof(b, b->stream, b->d_desc, b->d_kxy, (int)n, b->d_counts, b->d_out, nullptr);
+  int rc = launch_bof(b, b->stream, b->d_desc, b->d_kxy, (int)n, b->d_counts, b->d_out, nullptr);  // (stream: created above)
   if (rc) return rc;
   SFM_HIP(hipMemcpyAsync(out_bow, b->d_out, (size_t)b->K * b->cells * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   SFM_HIP(hipStreamSynchronize(b->stream));

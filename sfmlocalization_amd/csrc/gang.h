@@ -116,6 +116,7 @@ struct GangMember {
   std::vector<GangRec> gang_recs;  // launches recorded for the gang session in progress
   size_t gang_head = 0;
   bool gang_oom = false;            // a record could not be stored (host memory): the session's flush returns ENOMEM
+  bool ever_ganged = false;         // has taken part in a session (a stream created for it LATER must wait for that work)
   GangState *gang_owned = nullptr;  // this member has led a gang: its state (stream = this member's own)
   hipEvent_t gang_ev = nullptr;     // orders the gang's stream after this member's own earlier work
 };
