@@ -899,6 +899,39 @@ struct EmitMinBody {
       for (uint32_t k = threadIdx.x; k < np; k += 256) keys[k] = match_key[off + k];
       __syncthreads();
     }
+    // Round 3: from 128 putative matches on, "the last putative match with this query feature" is looked up in a hash
+    // table (query feature -> largest list position, open addressing in LDS, at most half full) instead of walked to: the
+    // walk is np / 2 dependent LDS reads per geometric match, and a frame that nearly duplicates a map view has 1 500 of
+    // each -- 270 us per frame in the image-in leg, a few us now.  Same answer: the entry with the largest position.
+    constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+    __shared__ uint32_t tab[2 * kFMaxM];  // (query feature << 11) | position; positions < kFMaxM = 2 048
+    static_assert(kFMaxM <= 2048, "a list position has 11 bits in the table's entries");
+    const bool hashed = staged && np >= 128u;
+    uint32_t tmask = 0;
+    if (hashed) {
+      uint32_t tsize = 256;
+      while (tsize < 2u * np) tsize <<= 1;
+      tmask = tsize - 1u;
+      for (uint32_t e = threadIdx.x; e < tsize; e += 256) tab[e] = kEmpty;
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < np; k += 256) {
+        const uint32_t jq = keys[k] & 0xFFFFu, val = (jq << 11) | k;
+        uint32_t hsh = (jq * 2654435761u) >> 7 & tmask;
+        for (;;) {
+          uint32_t cur = __hip_atomic_load(&tab[hsh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cur == kEmpty) {
+            cur = atomicCAS(&tab[hsh], kEmpty, val);
+            if (cur == kEmpty) break;
+          }
+          if ((cur >> 11) == jq) {
+            atomicMax(&tab[hsh], val);
+            break;
+          }
+          hsh = (hsh + 1u) & tmask;
+        }
+      }
+      __syncthreads();
+    }
     const uint64_t vkey = (uint64_t)(view_id[v] & 0xFFFFFFu) << 24;
     for (uint32_t p0 = (threadIdx.x >> 6) * 64; p0 < ng; p0 += 256) {
       const uint32_t p = p0 + lane;
@@ -913,7 +946,18 @@ struct EmitMinBody {
         j = match_key[off + pp] & 0xFFFFu;
       }
       uint16_t dist16 = kNoDist;
-      if (row_landmark[off + i] >= 0) {
+      if (row_landmark[off + i] >= 0 && hashed) {
+        uint32_t hsh = (j * 2654435761u) >> 7 & tmask;
+        for (;;) {
+          const uint32_t cur = tab[hsh];
+          if (cur == kEmpty) break;  // (no putative match of this view has this query feature: a guided match)
+          if ((cur >> 11) == j) {
+            dist16 = (uint16_t)(keys[cur & 2047u] >> 16);
+            break;
+          }
+          hsh = (hsh + 1u) & tmask;
+        }
+      } else if (row_landmark[off + i] >= 0) {
         for (int32_t k = (int32_t)np - 1; k >= 0; --k) {  // last putative match with the same query feature
           const uint32_t kk = staged ? keys[k] : match_key[off + k];
           if ((kk & 0xFFFFu) == j) {

@@ -327,10 +327,14 @@ __global__ __launch_bounds__(256) void k_bof_assign(const float *__restrict__ de
 // over its row of distances.  Used when the model fits the LDS layout (the reference's: 61 -> 32, K = 100); any other
 // model takes the form above.
 constexpr int kBofTile = 32;
+// (rows of the centre and distance tables are padded to an odd number of floats: with 32 floats per centre every lane of a
+// wave -- one centre each -- read the same LDS bank, 64 different addresses of it: the kernel took 107 us instead of 30)
 struct BofTileLds {   // sized by the launcher: floats
+  static __host__ __device__ int cen_stride(int cdim) { return cdim | 1; }
+  static __host__ __device__ int dist_stride(int K) { return K | 1; }
   static __host__ __device__ size_t floats(int in_dim, int n_pca, int cdim, int K) {
     return (size_t)kBofTile * in_dim + (n_pca > 0 ? (size_t)in_dim + (size_t)n_pca * in_dim + n_pca : 0) +
-           (size_t)kBofTile * cdim + (size_t)K * cdim + (size_t)kBofTile * K;
+           (size_t)kBofTile * cdim + (size_t)K * cen_stride(cdim) + (size_t)kBofTile * dist_stride(K);
   }
 };
 __global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restrict__ desc, const float *__restrict__ kxy,
@@ -347,8 +351,9 @@ __global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restric
   float *sevec = smean + (n_pca > 0 ? in_dim : 0);         // [n_pca][in_dim] }
   float *seval = sevec + (n_pca > 0 ? (size_t)n_pca * in_dim : 0);  // [n_pca]
   float *sy = seval + (n_pca > 0 ? n_pca : 0);             // [tile][cdim]
-  float *scen = sy + (size_t)kBofTile * cdim;              // [K][cdim]
-  float *sdist = scen + (size_t)K * cdim;                  // [tile][K]
+  const int cs = BofTileLds::cen_stride(cdim), ds = BofTileLds::dist_stride(K);
+  float *scen = sy + (size_t)kBofTile * cdim;              // [K][cs]
+  float *sdist = scen + (size_t)K * cs;                    // [tile][ds]
   const int tid = threadIdx.x;
   const int r0 = blockIdx.x * kBofTile;
   const int rows = min(kBofTile, n - r0);
@@ -361,7 +366,10 @@ __global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restric
     for (int e = tid; e < n_pca * in_dim; e += 256) sevec[e] = pca_evec[e];
     for (int e = tid; e < n_pca; e += 256) seval[e] = pca_eval[e];
   }
-  for (int e = tid; e < K * cdim; e += 256) scen[e] = centers[e];
+  for (int e = tid; e < K * cdim; e += 256) {
+    const int c = e / cdim;
+    scen[c * cs + (e - c * cdim)] = centers[e];
+  }
   __syncthreads();
   if (n_pca > 0) {
     for (int e = tid; e < rows * n_pca; e += 256) {
@@ -381,14 +389,14 @@ __global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restric
   __syncthreads();
   for (int e = tid; e < rows * K; e += 256) {
     const int r = e / K, c = e - r * K;
-    const float *y = sy + (size_t)r * cdim, *cen = scen + (size_t)c * cdim;
+    const float *y = sy + (size_t)r * cdim, *cen = scen + (size_t)c * cs;
     float sacc = 0.0f;
     for (int i = 0; i < cdim; ++i) {
       const float d = y[i] - cen[i];
       const float d2 = d * d;
       sacc = sacc + d2;
     }
-    sdist[e] = sacc;
+    sdist[r * ds + c] = sacc;
   }
   __syncthreads();
   if (tid < rows) {
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restric
     int best = 0;
     float bestd = INFINITY;
     for (int c = 0; c < K; ++c) {
-      const float sacc = sdist[(size_t)tid * K + c];
+      const float sacc = sdist[(size_t)tid * ds + c];
       if (sacc < bestd) {
         bestd = sacc;
         best = c;
@@ -425,8 +433,9 @@ __global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restric
 }
 
 // one thread per pyramid cell: counts -> /n -> per-cell normalisation, sequential in the reference's order
-__global__ void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, int cells, int norm_type,
-                             double *__restrict__ out, float *__restrict__ out_f32) {
+// one thread per cell (any K; the form below needs K doubles of LDS)
+__global__ void k_bof_finish_serial(const uint32_t *__restrict__ counts, int n, int K, int cells, int norm_type,
+                                    double *__restrict__ out, float *__restrict__ out_f32) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cells) return;
   double *h = out + (size_t)K * c;
@@ -445,6 +454,45 @@ __global__ void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, 
   }
   if (out_f32)
     for (int i = 0; i < K; ++i) out_f32[(size_t)K * c + i] = (float)h[i];  // BoFUtils.cpp:51-54 converts to CV_32F
+}
+
+// (round 3: one WAVE per cell.  The element-wise steps run side by side; the two sums stay what they were -- one lane
+// adding the K values in index order -- so every bit is the one-thread-per-cell result's, which took 62 us: four dependent
+// walks over global memory.)
+__global__ __launch_bounds__(64) void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, int cells, int norm_type,
+                                                   double *__restrict__ out, float *__restrict__ out_f32) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (c >= cells) return;
+  extern __shared__ double bof_h[];  // [K]
+  double *h = out + (size_t)K * c;
+  for (int i = lane; i < K; i += 64) bof_h[i] = (double)counts[(size_t)K * c + i] / (double)n;
+  __syncthreads();
+  __shared__ double s_norm;
+  if (norm_type == 2) {
+    if (lane == 0) {
+      double norm = 0.0;
+      for (int i = 0; i < K; ++i) norm += bof_h[i];
+      s_norm = norm;
+    }
+    __syncthreads();
+    const double norm = s_norm;
+    if (norm > 0.0)
+      for (int i = lane; i < K; i += 64) bof_h[i] = sqrt(bof_h[i] / norm);
+  } else if (norm_type == 1) {
+    if (lane == 0) {
+      double norm = 0.0;
+      for (int i = 0; i < K; ++i) norm += bof_h[i] * bof_h[i];
+      s_norm = sqrt(norm);
+    }
+    __syncthreads();
+    const double norm = s_norm;
+    if (norm > 0.0)
+      for (int i = lane; i < K; i += 64) bof_h[i] = bof_h[i] / norm;
+  }
+  for (int i = lane; i < K; i += 64) {  // (a lane reads back only what it wrote itself)
+    h[i] = bof_h[i];
+    if (out_f32) out_f32[(size_t)K * c + i] = (float)bof_h[i];  // BoFUtils.cpp:51-54 converts to CV_32F
+  }
 }
 
 }  // namespace
@@ -525,8 +573,12 @@ int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const floa
     }
     SFM_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_bof_finish, dim3(1), dim3(64), 0, s, d_counts, n > 0 ? n : 1, b->K, cells, b->norm_type, d_out,
-                     d_out_f32);
+  if ((size_t)b->K * sizeof(double) <= 48 * 1024)
+    hipLaunchKernelGGL(k_bof_finish, dim3(cells), dim3(64), (size_t)b->K * sizeof(double), s, d_counts, n > 0 ? n : 1, b->K,
+                       cells, b->norm_type, d_out, d_out_f32);
+  else
+    hipLaunchKernelGGL(k_bof_finish_serial, dim3(1), dim3(64), 0, s, d_counts, n > 0 ? n : 1, b->K, cells, b->norm_type, d_out,
+                       d_out_f32);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }
