@@ -512,6 +512,7 @@ struct FFilterArgs {
   uint32_t *large_count, *large_list;  // views with more than kFMaxM matches, queued for k_fmatrix_large (or null)
   int *status;
   int skip_le;  // k_fmatrix_filter leaves views with at most this many putative matches to k_fmatrix_fast
+  int fast_min;  // k_fmatrix_fast<W, M> takes the views with fast_min < matches <= M
   MergeMaskedArgs merge;  // enabled: k_fmatrix_fast first builds its view's putative list (K2 left to it)
 };
 
@@ -788,8 +789,12 @@ constexpr int kF2Batch = 32;   // uniform iterations solved speculatively per ba
 // and nothing else runs beside it; at 8 the Hamming scans of the other queries keep three of their waves per SIMD, at
 // 4 all of them.  Measured at 20 queries in flight: 16 / 8 / 4 waves 3 259 / 3 413 / 3 460 queries/s -- K3 costs the
 // others 13 us per query instead of 36.)
-template <int W>
+// (M = putative matches per view the form holds: 512 -- at most 8 residuals per lane in the register sort, 124 VGPRs --
+// or, round 3, 1 024 for the views of a query that nearly duplicates a map frame: 16 per lane, more registers, launched
+// only while such queries come, Map::k3_big_credit; they took the block-wide LDS form before, 0.4 ms per frame)
+template <int W, int MaxM = 512>
 struct F2SharedT {
+  static constexpr int kF2MaxM = MaxM;
   uint32_t idx[W][kF2MaxM];  // sorted match indices of the model each wave evaluated last
   double pts[4][kF2MaxM];  // normalised x, y of the map keypoint, u, w of the query keypoint (one plane each: a
                            // wave reading element p of 64 consecutive matches hits 64 different banks)
@@ -836,19 +841,19 @@ __device__ void bitonic_sort_wave(uint64_t *kw, uint32_t *iw, int P) {
   }
 }
 
-template <int W>
+template <int W, int MaxM = 512>
 struct FmatrixFastBody {
   static constexpr int kGangThreads = W * 64;
   static __device__ __forceinline__ void run(FFilterArgs A) {
-    constexpr int kF2Waves = W, kF2Threads = W * 64;
-    using F2Shared = F2SharedT<W>;
+    constexpr int kF2Waves = W, kF2Threads = W * 64, kF2MaxM = MaxM;
+    using F2Shared = F2SharedT<W, MaxM>;
 #include "fmatrix_fast.body.inc"
   }
 };
-template <int W>
+template <int W, int MaxM = 512>
 __global__ __launch_bounds__(W * 64) void k_fmatrix_fast(FFilterArgs A) {
-  constexpr int kF2Waves = W, kF2Threads = W * 64;
-  using F2Shared = F2SharedT<W>;
+  constexpr int kF2Waves = W, kF2Threads = W * 64, kF2MaxM = MaxM;
+  using F2Shared = F2SharedT<W, MaxM>;
 #include "fmatrix_fast.body.inc"
 }
 
@@ -887,6 +892,7 @@ struct EmitMinBody {
     if (threadIdx.x == 0) {  // the counts the reference prints (localization.cpp:416,458)
       if (put_count[v] >= min_putative) atomicAdd(&view_stats[0], 1u);
       if (ng > 0) atomicAdd(&view_stats[1], 1u);
+      if (put_count[v] > 512u) atomicMax(&view_stats[2], put_count[v]);  // (the host's hint for K3's launch forms)
     }
     if (ng == 0) return;
     const uint32_t off = view_off[v];
@@ -2546,6 +2552,7 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
     return !(e && atoi(e) == 0);
   }();
   A.skip_le = fast ? kF2MaxM : -1;
+  A.fast_min = -1;
   A.merge = MergeMaskedArgs{};
   if (c->merge_is_deferred) {  // K2 was left to this stage (launch_merge_ratio_compact)
     c->merge_is_deferred = false;
@@ -2573,6 +2580,28 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
                           : waves == 4 ? go(std::integral_constant<int, 4>{}) : go(std::integral_constant<int, 8>{});
     SFM_HIP(e2);
     SFM_HIP(hipGetLastError());
+    // views with 513 .. 1 024 putative matches (a query that nearly duplicates a map frame): the same kernel with 16
+    // residuals per lane -- while the map's queries have had such views lately (Map::k3_big_credit, set from the largest
+    // view of every finished query: a launch whose 100 workgroups all leave at once still costs a launch)
+    static const int env_big = [] { const char *e = getenv("SFMLOC_K3_BIG"); return e ? atoi(e) : 1; }();
+    if (env_big == 2 || (env_big == 1 && m->k3_big_credit.load(std::memory_order_relaxed) > 0)) {
+      FFilterArgs B = A;
+      B.merge.enabled = 0;  // (the lists exist: the launch above built them)
+      B.fast_min = kF2MaxM;
+      auto go_big = [&](auto w_tag) {
+        constexpr int W = decltype(w_tag)::value;
+        using Sh = F2SharedT<W, 1024>;
+        static const hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast<W, 1024>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh));
+        if (attr3 != hipSuccess) return attr3;
+        sfm_launch<FmatrixFastBody<W, 1024>>(c, k_fmatrix_fast<W, 1024>, dim3(n_sel), dim3(W * 64), (uint32_t)sizeof(Sh), B);
+        return hipSuccess;
+      };
+      const hipError_t e3 = c->k1_may_slice ? go_big(std::integral_constant<int, 8>{}) : go_big(std::integral_constant<int, 4>{});
+      SFM_HIP(e3);
+      SFM_HIP(hipGetLastError());
+      A.skip_le = 1024;
+    }
   }
   const size_t lds = sizeof(FShared);
   static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_filter),
@@ -2600,7 +2629,7 @@ int launch_emit_candidates(Ctx *c, const Query *q, uint32_t n_sel, bool all_view
   Map *m = c->map;
   if (!c->cleared) {
     SFM_HIP(hipMemsetAsync(c->d_cand_part, 0, kPartHeaderBytes, c->stream));
-    SFM_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
+    SFM_HIP(hipMemsetAsync(c->d_view_stats, 0, 3 * sizeof(uint32_t), c->stream));
     SFM_HIP(hipMemsetAsync(c->d_best64, 0xFF, (size_t)(q->n ? q->n : 1) * sizeof(unsigned long long), c->stream));
   }
   if (n_sel == 0 || q->n == 0) return SFMLOC_OK;

@@ -262,7 +262,7 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr, bool merge_only = false) {
   CTX_HIP(hipEventCreateWithFlags(&c->xev_in, hipEventDisableTiming));
   CTX_HIP(hipMemsetAsync(c->d_pose, 0, sizeof(Pose), c->stream));
   CTX_HIP(hipMemsetAsync(c->d_p3p_state, 0, sizeof(P3pState), c->stream));
-  CTX_HIP(hipMemsetAsync(c->d_view_stats, 0, 2 * sizeof(uint32_t), c->stream));
+  CTX_HIP(hipMemsetAsync(c->d_view_stats, 0, 3 * sizeof(uint32_t), c->stream));
   CTX_HIP(hipStreamSynchronize(c->stream));
 #undef CTX_TRY
 #undef CTX_HIP
@@ -710,6 +710,9 @@ int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *p
   out->status |= h->status;
   out->n_putative_views = (int32_t)h->view_stats[0];
   out->n_geometric_views = (int32_t)h->view_stats[1];
+  // the form of the next queries' K3 (launch_geometric_filter): did this one have a view with more than 512 matches?
+  if (h->view_stats[2] > 512u) c->map->k3_big_credit.store(64, std::memory_order_relaxed);
+  else if (c->map->k3_big_credit.load(std::memory_order_relaxed) > 0) c->map->k3_big_credit.fetch_sub(1, std::memory_order_relaxed);
   // (none of these can be reached with data the reference accepts: a view's matches beyond 65 536, an internal
   // inconsistency of the candidate part, more correspondences than the query has features)
   SFM_CHECK((out->status & 1) == 0, SFMLOC_ECAP, "a view has more than 65536 putative matches");

@@ -33,7 +33,7 @@ __device__ __forceinline__ void query_reset_items(const QueryResetArgs &R, uint3
       *R.n_flagged = 0;
       *R.status = 0;
       R.cand_header[0] = R.cand_header[1] = R.cand_header[2] = R.cand_header[3] = 0;  // kPartHeaderBytes = 16
-      R.view_stats[0] = R.view_stats[1] = 0;
+      R.view_stats[0] = R.view_stats[1] = R.view_stats[2] = 0;
       *R.ms_n = 0;
     }
   }

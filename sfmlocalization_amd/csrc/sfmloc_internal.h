@@ -115,7 +115,7 @@ struct HostResult {
   P3pState state;
   Pose pose;
   int status;
-  uint32_t view_stats[2];
+  uint32_t view_stats[3];  // views with >= min_putative matches, views passing the F filter, the largest view above 512
   uint32_t pair_qfeat[kP3pMaxN];
   uint32_t pair_landmark[kP3pMaxN];
 };
@@ -137,6 +137,7 @@ struct Map {
   // > 0 while recent queries had more than 512 2D-3D correspondences: K5's rounds are then launched wide (four
   // workgroups per hypothesis, acransac.hip).  Set to 64 by a finished query that had, counted down by the others.
   std::atomic<int> p3p_wide_credit{0};
+  std::atomic<int> k3_big_credit{0};  // finished queries ago that one had a view with more than 512 putative matches (64 = just now)
   // finished queries in a row whose 2D-3D set had at most 512 correspondences (acransac.hip kP3pSmallN): from 8 on a
   // query's P3P rounds are queued in the small form (ctx_resection_enqueue)
   std::atomic<int> p3p_small_credit{0};
@@ -249,7 +250,7 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   P3pState *d_p3p_state = nullptr;
   Pose *d_pose = nullptr;
   unsigned char *d_result = nullptr;  // one HostResult record; the six pointers below alias into it
-  uint32_t *d_view_stats = nullptr;  // [2] views with >= min_putative matches, views passing the F filter
+  uint32_t *d_view_stats = nullptr;  // [3] HostResult::view_stats
   float *d_bow_query = nullptr;      // [bow_dim]
   uint32_t *d_bow_dist = nullptr;    // [n_views]
   uint32_t *d_bow_cand = nullptr;    // [n_views]

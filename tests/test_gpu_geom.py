@@ -719,3 +719,35 @@ def test_k3_waves_per_view_do_not_change_the_result():
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (w, r.stdout[-2000:] + r.stderr[-2000:])
         assert "every stage bit-exact" in r.stdout
+
+
+def test_k3_register_form_for_513_to_1024_matches_per_view(oracle_c):
+    """A query that nearly duplicates map frames of ~1 000 features has views with 513 ... 1 024 putative matches: beyond
+    k_fmatrix_fast<W, 512>, which leaves them to the block-wide LDS form -- unless the map's recent queries had such views
+    (Map::k3_big_credit), in which case k_fmatrix_fast<W, 1024> takes them (16 residuals per lane in the register sort).
+    First query: the LDS form; the following ones: the register form.  Every stage equals the oracle either way, and a
+    whole large-set campaign with the form forced (SFMLOC_K3_BIG=2) and switched off (0) in child processes."""
+    import os
+    import subprocess
+    import sys
+    m = synth.make_map(75, n_views=4, desc_per_view=1100, views_per_place=4, landmarks_per_place=1300, obs_per_view=1000,
+                       map_flips=8)
+    p3p_it = 300
+    dm = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, p3p_max_iteration=p3p_it),
+               view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+               landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    seen = []
+    for k in range(4):
+        q = synth.make_query(m, 750 + k, n_feat=1200, n_copies=1000, outlier_frac=0.1, query_flips=10)
+        exp, pose = compare_stages(m, q, dm, p3p_max_iteration=p3p_it)
+        seen.append(int(exp["put_count"].max()))
+        assert exp["ok"]
+    assert all(512 < c <= 1024 for c in seen), seen
+    dm.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for form in ("2", "0"):
+        env = dict(os.environ, SFMLOC_K3_BIG=form)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_p3p_large.py"), "10", "98000"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (form, r.stdout[-2000:] + r.stderr[-2000:])
+        assert "bit-exact" in r.stdout
