@@ -110,6 +110,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
                                   scanning a head of its own*/) {
 #include "hamming_screen.body.inc"
 }
+// the per-query scan of a query that shares the GPU: the text of k_hamming_screen<8, 10, 1> under a name of its own, so
+// that a profile's per-kernel statistics keep the full-bank scan (k_hamming_screen<8, 10, 1>, the roofline kernel) and
+// the shortlist scans apart
+__global__ __launch_bounds__(8 * 64) void k_hamming_screen_shortlist(
+    const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
+    const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t lds_rows, const uint16_t *__restrict__ ratio_cnt,
+    unsigned long long *__restrict__ flagmask, uint2 *__restrict__ flagged, uint32_t *__restrict__ n_flagged,
+    unsigned long long *__restrict__ counters, uint32_t head, uint4 *__restrict__ flagged_desc, uint32_t flagged_desc_cap,
+    const uint2 *__restrict__ head_part) {
+  constexpr int WAVES = 8, NW = 10, kScreenBatch = 1;
+#include "hamming_screen.body.inc"
+}
 
 // Exact top-2 of the flagged rows.  64 flagged rows x all query rows is ~130 k pairs: on ONE compute unit that is
 // 25 us of popcounts, on the query's critical path.  So a chunk of 64 rows is spread over SLICES workgroups (one
@@ -327,9 +339,20 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
         lds_rows, m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged, c->d_k1_counters, head,            \
         c->d_flagged_desc, c->rows_chunk_cap * 64, head_part);                                                    \
     break;
-  if (nw == 10 && n_work_blocks < 16u * (uint32_t)m->n_cu) {  // fewer than four waves per SIMD: batched tail
+  // (the batched-tail form <.., 4> has 68 VGPRs against 48: while the GPU is shared the lean one leaves the other
+  // queries' latency-bound stages more of the register file, +1.6 % queries/s; alone the two are equal.
+  // SFMLOC_K1_SCREEN_BATCH = 4 / 1 forces one of them.)
+  static const int env_batch = [] { const char *e = getenv("SFMLOC_K1_SCREEN_BATCH"); return e ? atoi(e) : 0; }();
+  const bool batched_tail = env_batch ? env_batch == 4 : c->k1_may_slice;
+  if (nw == 10 && batched_tail && n_work_blocks < 16u * (uint32_t)m->n_cu) {  // fewer than four waves per SIMD: batched tail
     sfm_launch<HammingScreenBody<WAVES, 10, 4>>(
         c, k_hamming_screen<WAVES, 10, 4>, dim3((n_work_blocks + WAVES - 1) / WAVES, qsplit), dim3(WAVES * 64),
+        (uint32_t)lds_bytes, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks, q->d_desc, q->n, lds_rows,
+        m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged, c->d_k1_counters, head, c->d_flagged_desc,
+        c->rows_chunk_cap * 64, head_part);
+  } else if (nw == 10 && use_list && n_work_blocks < 16u * (uint32_t)m->n_cu) {  // a shortlist scan while the GPU is shared
+    sfm_launch<HammingScreenBody<WAVES, 10, 1>>(
+        c, k_hamming_screen_shortlist, dim3((n_work_blocks + WAVES - 1) / WAVES, qsplit), dim3(WAVES * 64),
         (uint32_t)lds_bytes, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks, q->d_desc, q->n, lds_rows,
         m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged, c->d_k1_counters, head, c->d_flagged_desc,
         c->rows_chunk_cap * 64, head_part);
