@@ -2244,7 +2244,9 @@ struct P3pRoundSmallBody {
 #include "p3p_round.body.inc"
   }
 };
-__global__ __launch_bounds__(kThreads) void k_p3p_round_small(P3pArgs A, int batch, int wide) {
+// (min. 4 waves per SIMD = at most 128 VGPRs: Kneip's solver spills -- one lane's chain, once per workgroup -- and the
+// round fits beside four workgroups of the lean shortlist scan, 4 x 96 VGPRs per SIMD, without evicting one)
+__global__ __launch_bounds__(kThreads, 4) void k_p3p_round_small(P3pArgs A, int batch, int wide) {
   constexpr bool kSmall = true;
 #include "p3p_round.body.inc"
 }
