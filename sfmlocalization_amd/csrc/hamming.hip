@@ -110,9 +110,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_hamming_screen(
                                   scanning a head of its own*/) {
 #include "hamming_screen.body.inc"
 }
-// the per-query scan of a query that shares the GPU: the text of k_hamming_screen<8, 10, 1> under a name of its own, so
-// that a profile's per-kernel statistics keep the full-bank scan (k_hamming_screen<8, 10, 1>, the roofline kernel) and
-// the shortlist scans apart
+// the scan of a view list (a shortlist; every such scan but the short one of a query alone on the GPU, which takes the
+// batched-tail form <8, 10, 4>): the text of k_hamming_screen<8, 10, 1> under a name of its own, so that a profile's
+// per-kernel statistics keep the full-bank scan (k_hamming_screen<8, 10, 1>, the roofline kernel) and these apart
 __global__ __launch_bounds__(8 * 64) void k_hamming_screen_shortlist(
     const uint4 *__restrict__ bank, const uint32_t *__restrict__ block_list, uint32_t n_work_blocks,
     const uint4 *__restrict__ qdesc, uint32_t nq, uint32_t lds_rows, const uint16_t *__restrict__ ratio_cnt,
@@ -350,7 +350,7 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
         (uint32_t)lds_bytes, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks, q->d_desc, q->n, lds_rows,
         m->d_ratio_cnt, c->d_flagmask, c->d_flagged, c->d_n_flagged, c->d_k1_counters, head, c->d_flagged_desc,
         c->rows_chunk_cap * 64, head_part);
-  } else if (nw == 10 && use_list && n_work_blocks < 16u * (uint32_t)m->n_cu) {  // a shortlist scan while the GPU is shared
+  } else if (nw == 10 && use_list) {  // any other scan of a view list (a shortlist while the GPU is shared, a long list)
     sfm_launch<HammingScreenBody<WAVES, 10, 1>>(
         c, k_hamming_screen_shortlist, dim3((n_work_blocks + WAVES - 1) / WAVES, qsplit), dim3(WAVES * 64),
         (uint32_t)lds_bytes, m->d_bank, use_list ? c->d_block_list : nullptr, n_work_blocks, q->d_desc, q->n, lds_rows,
