@@ -54,3 +54,23 @@ def test_gpus_flag_is_honoured(monkeypatch):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), "bench.py"), "--gpus", "4"],
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_plan_of_a_run():
+    """plan(): the default single-GPU shortlist run keeps 20 queries in flight on 4 host threads and asks for a hardware
+    queue per context + 2 (the 24-queue limit is why 22 contexts are slower); N ranks run gangs of 16 on 32 contexts per
+    slot; --replicas makes every rank a single-GPU run; the image-in leg's defaults are 10 workers, a worker's BoW
+    chains on one stream."""
+    a = bench.parse([])
+    shortlist, forced, sharded, gang, nctx, hwq = bench.plan(a, 1, False)
+    assert shortlist and not sharded and gang == 1 and nctx == 20 and a.threads == 4 and hwq == 22
+    assert a.image_workers == 10 and a.image_bow_worker_stream and a.image_bow_own_stream
+    a = bench.parse(["--gpus", "8"])
+    _, _, sharded, gang, nctx, hwq = bench.plan(a, 8, False)
+    assert sharded and gang == 16 and nctx == 32
+    a = bench.parse(["--gpus", "8", "--replicas"])
+    _, _, sharded, gang, nctx, _ = bench.plan(a, 8, True)
+    assert not sharded and gang == 1 and nctx == 20
+    a = bench.parse(["--bow-knn", "0", "--views", "1000"])
+    shortlist, _, _, _, nctx, _ = bench.plan(a, 1, False)
+    assert not shortlist and nctx == 4
