@@ -432,14 +432,19 @@ struct PreHistBody {
     __syncthreads();
     if (threadIdx.x == 0) ticket = atomicAdd(&hist_all[302], 1u);
     __syncthreads();
-    if (ticket != gridDim.x * gridDim.y - 1 || threadIdx.x != 0) return;
+    if (ticket != gridDim.x * gridDim.y - 1) return;
     __threadfence();
     // compute_k_percentile's tail (k_kcontrast), by the last workgroup; the histogram is read through atomics so that no
-    // stale cached word is used
-    const int npoints = (int)atomicAdd(&hist[300], 0u);
+    // stale cached word is used.  (Round 3: all of the workgroup's threads fetch the bins, side by side, and one lane walks
+    // them in LDS -- the walk used to be one lane's chain of up to 300 global atomic round trips, most of this kernel's
+    // 24 us.  Same integers, same k.)
+    for (int i = threadIdx.x; i < 301; i += blockDim.x) lh[i] = atomicAdd(&hist[i], 0u);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int npoints = (int)lh[300];
     const int nthreshold = (int)((float)npoints * 0.7f);
     int nelements = 0, k = 0;
-    for (k = 0; nelements < nthreshold && k < 300; k++) nelements += (int)atomicAdd(&hist[k], 0u);
+    for (k = 0; nelements < nthreshold && k < 300; k++) nelements += (int)lh[k];
     *kcontrast = (nelements < nthreshold) ? 0.03f : hmax * ((float)k / 300.0f);
   }
 };
