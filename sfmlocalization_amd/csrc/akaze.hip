@@ -1807,8 +1807,13 @@ LevelTab level_tab(const Akaze *a) {
 }
 
 // Create_Nonlinear_Scale_Space + Compute_Multiscale_Derivatives + Compute_Determinant_Hessian_Response
-int build_scale_space(Akaze *a, const uint8_t *gray /*host; null: the image is already in d_gray, written on a->stream*/) {
+// need: the levels [0, need) are built (0 = all of them) -- a description-only call builds no level above its keypoints'
+// highest (the dense BoW grid lives on levels 0 .. 3: three of the four octaves used to be evolved for nothing) and no
+// Hessian determinant (with_det = false); every level that IS built has the bits it always had.
+int build_scale_space(Akaze *a, const uint8_t *gray /*host; null: the image is already in d_gray, written on a->stream*/,
+                      int need = 0, bool with_det = true) {
   const AkPlan &P = a->plan;
+  const int nlev = (need > 0 && need < P.nlev) ? need : P.nlev;
   const int w = a->w, h = a->h;
   const size_t n0 = (size_t)w * h;
   // (nothing recorded for this image touches d_gray before the upload: it need not wait for a gang session's launches)
@@ -1849,13 +1854,13 @@ int build_scale_space(Akaze *a, const uint8_t *gray /*host; null: the image is a
     const char *e = getenv("SFMLOC_AKAZE_RESIDENT");
     return !(e && atoi(e) == 0);
   }();
-  for (int i = 1; i < P.nlev; ++i) {
+  for (int i = 1; i < nlev; ++i) {
     const AkLevel &L = P.lev[i], &Lp = P.lev[i - 1];
     float *Lt = a->d_Lt + L.off;
     // an octave whose image fits in LDS three times runs in one launch (k_octave_resident)
     {
       int j = i;
-      while (j + 1 < P.nlev && P.lev[j + 1].octave == L.octave) ++j;
+      while (j + 1 < nlev && P.lev[j + 1].octave == L.octave) ++j;
       const size_t lds = (size_t)3 * L.w * L.h * sizeof(float);
       const bool whole = i == 1 || Lp.octave != L.octave;  // the octave's first level of the loop
       if (kResident && whole && lds <= 150u * 1024u && j - i + 1 <= kOctaveRunMax && a->d_half_steps) {
@@ -1959,9 +1964,10 @@ int build_scale_space(Akaze *a, const uint8_t *gray /*host; null: the image is a
       AK_HIP(hipMemcpyAsync(Lt, start, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   const LevelTab T = level_tab(a);
-  const dim3 agrid((a->w + 127) / 128, T.row0[T.n]);
+  const dim3 agrid((a->w + 127) / 128, T.row0[nlev]);  // (the rows of the levels that were built: levels come in order)
   sfm_launch<ScharrXyAllBody>(a, k_scharr_xy_all, agrid, dim3(128), (uint32_t)0, a->d_Lsmooth, a->d_Lx, a->d_Ly, reinterpret_cast<const LevelTab *>(a->d_level_tab));
-  sfm_launch<HessianDetAllBody>(a, k_hessian_det_all, agrid, dim3(128), (uint32_t)0, a->d_Lx, a->d_Ly, a->d_Ldet, reinterpret_cast<const LevelTab *>(a->d_level_tab));
+  if (with_det)
+    sfm_launch<HessianDetAllBody>(a, k_hessian_det_all, agrid, dim3(128), (uint32_t)0, a->d_Lx, a->d_Ly, a->d_Ldet, reinterpret_cast<const LevelTab *>(a->d_level_tab));
   AK_HIP(hipGetLastError());
   return SFMLOC_OK;
 #undef s
@@ -2062,12 +2068,12 @@ hipStream_t akaze_stream_now(Akaze *a) {
   (void)akaze_ensure_stream(a);
   return a->stream;
 }
-int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n) {
+int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n, int need_levels) {
   int rc = akaze_ensure_stream(a);
   if (rc) return rc;
   rc = ensure_kp_cap(a, n);  // (before anything is queued: it may free and allocate)
   if (rc) return rc;
-  rc = build_scale_space(a, nullptr);
+  rc = build_scale_space(a, nullptr, need_levels, false);
   if (rc || n == 0) return rc;
   sfm_launch<OrientDescribeBody>(a, k_orient_describe, dim3(n), dim3(64), 0,
                                  reinterpret_cast<const DevLevels *>(a->d_dev_levels), d_kin, (int)n, a->d_gauss25, a->d_win,
@@ -2444,14 +2450,16 @@ int sfmloc_akaze_compute(sfmloc_akaze *ak, const uint8_t *gray, const float *kin
   SFM_HIP(hipSetDevice(a->device));
   int rc = akaze_ensure_stream(a);
   if (rc) return rc;
-  rc = build_scale_space(a, gray);
-  if (rc) return rc;
   std::vector<float> k(kin, kin + (size_t)n * 4);
+  int top = 0;
   for (uint32_t i = 0; i < n; ++i) {
     int lvl = (int)k[4 * i + 3];
     lvl = lvl < 0 ? 0 : (lvl >= a->plan.nlev ? a->plan.nlev - 1 : lvl);
     k[4 * i + 3] = (float)lvl;
+    top = lvl > top ? lvl : top;
   }
+  rc = build_scale_space(a, gray, top + 1, false);  // (no level above the keypoints' highest, no determinant)
+  if (rc) return rc;
   return orient_describe(a, k, n, angle_out, desc64);
 }
 

@@ -195,7 +195,7 @@ int sfmloc_imgbow_compute(sfmloc_imgbow *p, const uint8_t *image, sfmloc_query *
   SFM_HIP(hipEventRecord(ib->staged, s));
   ib->staged_pending = true;
   int rc = dense_gray_enqueue(&ib->plan, s, ib->d_src, akaze_gray_dev(a));
-  if (!rc) rc = akaze_compute_resident(a, ib->d_grid, ib->n_grid);
+  if (!rc) rc = akaze_compute_resident(a, ib->d_grid, ib->n_grid, 4);  // (the grid's four scales are levels 0 .. 3)
   if (rc) return rc;
   s = akaze_stream_now(a);
   rc = launch_bof(b, s, nullptr, ib->d_kxy, (int)ib->n_grid, ib->d_counts, ib->d_out, q ? q->d_bow : ib->d_out_f32,

@@ -384,7 +384,7 @@ uint8_t *akaze_desc_dev(Akaze *a);           // [n x 64] descriptors of the last
 hipStream_t akaze_stream_now(Akaze *a);      // the stream its work is queued on (its own or a context's)
 // scale space of the image ALREADY in akaze_gray_dev (written on akaze_stream_now) + orientation and M-LDB at the
 // device-resident keypoints d_kin [n x 4] (x, y, size, class_id); asynchronous
-int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n);
+int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n, int need_levels /*0: all*/);
 
 // acransac.hip
 int launch_fill_log10(double *d_L10, int n, hipStream_t s);
