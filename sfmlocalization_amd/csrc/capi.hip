@@ -203,8 +203,8 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr, bool merge_only = false) {
     CTX_TRY(dev_alloc(acct, &c->d_flagged_desc, (size_t)c->rows_chunk_cap * 4 * 64));
     CTX_HIP(hipMemset(c->d_rows_arrivals, 0, (size_t)c->rows_chunk_cap * sizeof(uint32_t)));
   }
-  CTX_TRY(dev_alloc(acct, &c->d_k1_counters, (size_t)2));
-  CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
+  CTX_TRY(dev_alloc(acct, &c->d_k1_counters, (size_t)2 * kK1CounterSlots));
+  CTX_HIP(hipMemset(c->d_k1_counters, 0, 2 * kK1CounterSlots * sizeof(unsigned long long)));
   CTX_TRY(dev_alloc(acct, &c->d_geo_count, (size_t)m->n_views + 1));
   if (full) CTX_TRY(dev_alloc(acct, &c->d_geo_idx, (size_t)m->n_rows));
   CTX_TRY(dev_alloc(acct, &c->d_geo_model, ((size_t)m->n_views + 1) * 10));
@@ -2166,8 +2166,12 @@ int sfmloc_stats_read(sfmloc_map *map, sfmloc_kernel_stats *out) {
     }
     out->hamming_pairs += c->stats.hamming_pairs;
     out->hamming_alg_bytes += c->stats.hamming_alg_bytes;
-    unsigned long long k1c[2] = {0, 0};
-    SFM_HIP(hipMemcpy(k1c, c->d_k1_counters, sizeof(k1c), hipMemcpyDeviceToHost));
+    unsigned long long k1s[2 * kK1CounterSlots], k1c[2] = {0, 0};
+    SFM_HIP(hipMemcpy(k1s, c->d_k1_counters, sizeof(k1s), hipMemcpyDeviceToHost));
+    for (int q = 0; q < kK1CounterSlots; ++q) {
+      k1c[0] += k1s[2 * q];
+      k1c[1] += k1s[2 * q + 1];
+    }
     out->hamming_lane_ops += c->stats.hamming_lane_ops + 64ull * k1c[0] * (uint64_t)c->k1_finish_ops;
     out->hamming_pairs_finished += 64ull * k1c[0];
     out->hamming_rows_flagged += k1c[1];
@@ -2193,7 +2197,7 @@ int sfmloc_stats_reset(sfmloc_map *map) {
     int rc = drain_events(c);
     if (rc) return rc;
     memset(&c->stats, 0, sizeof(c->stats));
-    SFM_HIP(hipMemset(c->d_k1_counters, 0, 2 * sizeof(unsigned long long)));
+    SFM_HIP(hipMemset(c->d_k1_counters, 0, 2 * kK1CounterSlots * sizeof(unsigned long long)));
   }
   return SFMLOC_OK;
 }

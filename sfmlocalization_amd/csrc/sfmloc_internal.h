@@ -48,6 +48,7 @@ void set_error(const char *fmt, ...);
 // contiguous, fully coalesced 1 KiB.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kBlockRows = 64;
+constexpr int kK1CounterSlots = 64;  // Ctx::d_k1_counters
 constexpr int kP3pMaxN = 4096;     // 2D-3D correspondences the P3P LDS sort holds
 constexpr int kP3pBatchMax = 512;  // hypotheses evaluated per round
 constexpr int kP3pSlots = 1024;    // result slots of a round: one per hypothesis, or (wide launches) four, one per model
@@ -202,7 +203,9 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   uint32_t *d_rows_arrivals = nullptr;  // [rows_chunk_cap] arrival counters of that pass (self-resetting)
   uint4 *d_flagged_desc = nullptr;      // [rows_chunk_cap][4][64] descriptors of the flagged rows (tiled like the bank)
   uint32_t rows_chunk_cap = 0;          // chunks of 64 flagged rows the sliced pass has scratch for (rest: fallback)
-  unsigned long long *d_k1_counters = nullptr;  // [2] finished wave-pairs, flagged rows (since stats reset)
+  // [kK1CounterSlots][2] finished wave-pairs, flagged rows (since stats reset): a wave adds to slot (its block & 63) -- one
+  // pair of words for every wave of a scan was 300 000 atomics on the same address per full-bank scan
+  unsigned long long *d_k1_counters = nullptr;
   int k1_finish_ops = 0;
 
   // --- geometric stages ---

@@ -1,12 +1,8 @@
 mkdir -p gpurun_out/r03_ab
 OUT=gpurun_out/r03_ab/ab.txt
-run() { label=$1; shift
-  env "$@" timeout -k 10 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline-phase --no-image-in $EXTRA_ARGS > gpurun_out/r03_ab/b.log 2> gpurun_out/r03_ab/b.err || { tail -30 gpurun_out/r03_ab/b.err; exit 1; }
-  python -c "
-import json; d=json.loads(open('gpurun_out/r03_ab/b.log').read().strip().splitlines()[-1]); print('$label:', round(d['value'],1), 'q/s | alone p50', round(d['latency_ms']['p50'],3), '| putMatch', round(d['latency_ms']['stage_seconds_last_query']['putMatch']*1e3,3), '| identical', d.get('identical_to_single_flight'))" | tee -a $OUT
-}
 rm -f $OUT
-run "default (512 alone, 128 shared)" X=1
-run "512 always" SFMLOC_K1_LDS_ROWS=512
-run "default again" X=1
-run "64 shared" SFMLOC_K1_LDS_ROWS=64
+for i in 1 2; do
+timeout -k 10 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-image-in > gpurun_out/r03_ab/b.log 2> gpurun_out/r03_ab/b.err || { tail -30 gpurun_out/r03_ab/b.err; exit 1; }
+python -c "
+import json; d=json.loads(open('gpurun_out/r03_ab/b.log').read().strip().splitlines()[-1]); r=d['roofline']; print('run $i:', round(d['value'],1), 'q/s | alone p50', round(d['latency_ms']['p50'],3), '| full scan', round(r['kernel_ms'],3), 'ms, valu frac', round(r['valu']['frac'],4), 'finished frac', r['valu']['pairs_finished_frac'], 'flagged', r['valu']['rows_flagged_per_scan'], '| hbm regime', round(r['hbm_bound_regime']['achieved']), '| identical', d.get('identical_to_single_flight'))" | tee -a $OUT
+done
