@@ -61,6 +61,19 @@ def test_batch_of_images_equals_one_at_a_time(shape):
         for e in exs[:3]:
             e.share_stream(None)
         c.close()
+    # an extractor that has only worked in sessions so far (it has no stream of its own yet: one is created at the first
+    # call that needs it, ordered after the sessions' work) now works alone, then leads a session, then follows again
+    kp, d = exs[5].detect_and_compute(imgs[1])
+    np.testing.assert_array_equal(bits32(kp), bits32(ref[1][0]))
+    np.testing.assert_array_equal(d, ref[1][1])
+    got = S.Akaze.detect_and_compute_batch([exs[5], exs[4], exs[6]], imgs[3:6])
+    for (kp, d), (rkp, rd) in zip(got, ref[3:6]):
+        np.testing.assert_array_equal(bits32(kp), bits32(rkp))
+        np.testing.assert_array_equal(d, rd)
+    got = S.Akaze.detect_and_compute_batch([exs[4], exs[5]], imgs[0:2])
+    for (kp, d), (rkp, rd) in zip(got, ref[0:2]):
+        np.testing.assert_array_equal(bits32(kp), bits32(rkp))
+        np.testing.assert_array_equal(d, rd)
     other = S.Akaze(shape[1] + 16, shape[0])
     with pytest.raises(S.SfmlocError):                                # one size per batch
         S.Akaze.detect_and_compute_batch([exs[0], other], [imgs[0], synth.texture_image(9, shape[0], shape[1] + 16)])
