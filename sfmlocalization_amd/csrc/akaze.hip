@@ -379,6 +379,8 @@ struct PreGradBody {
                                           unsigned int *hmax_bits) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     float m = 0.0f;
+    // (unrolled: a thread's rows are independent, and walked one after the other each row is a round trip to memory)
+#pragma unroll 4
     for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y) {
       if (x >= w) continue;
       float g = 0.0f;
@@ -392,7 +394,9 @@ struct PreGradBody {
     }
     unsigned int bits = __float_as_uint(m);  // non-negative floats order like their bit patterns
     for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off, 64));
-    if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(hmax_bits, bits);
+    // (only where it can still raise the maximum: a value read a moment ago is a lower bound of the current one)
+    if ((threadIdx.x & 63) == 0 && bits > __hip_atomic_load(hmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(hmax_bits, bits);
   }
 };
 __global__ __launch_bounds__(128) void k_pre_grad(const float *__restrict__ sm5, float *__restrict__ mag, int w, int h,
@@ -412,9 +416,23 @@ struct PreHistBody {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const float hmax = __uint_as_float(hist_all[0]);
     unsigned int mine = 0;
-    for (int y = blockIdx.y * kGradRows; y < min(h, (int)(blockIdx.y + 1) * kGradRows); ++y)
-      if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-        const float m = mag[(size_t)y * w + x];
+    // (the rows' magnitudes first, side by side; then the bins)
+    // (the launcher gives a workgroup as many chunks of kGradRows rows as keeps the grid near one workgroup per compute
+    // unit: every workgroup ends in ~100 atomics on the same 301 words, and 1 020 workgroups' worth of them were most of
+    // this kernel's 34 us at 1080p)
+    const int chunks = ((h + kGradRows - 1) / kGradRows + (int)gridDim.y - 1) / (int)gridDim.y;
+    for (int ch = 0; ch < chunks; ++ch) {
+      const int y0 = ((int)blockIdx.y * chunks + ch) * kGradRows;
+      if (y0 >= h) break;
+      float mv[kGradRows];
+#pragma unroll
+      for (int r = 0; r < kGradRows; ++r) {
+        const int y = y0 + r;
+        mv[r] = (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) ? mag[(size_t)y * w + x] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < kGradRows; ++r) {
+        const float m = mv[r];
         if (m != 0.0f) {
           int nbin = (int)floorf(300.0f * (m / hmax));
           if (nbin == 300) nbin--;
@@ -422,6 +440,7 @@ struct PreHistBody {
           ++mine;
         }
       }
+    }
     if (mine) atomicAdd(&lh[300], mine);
     __syncthreads();
     for (int i = threadIdx.x; i < 301; i += blockDim.x)
@@ -1832,7 +1851,11 @@ int build_scale_space(Akaze *a, const uint8_t *gray /*host; null: the image is a
     sfm_launch<PreRowsBody>(a, k_pre_rows, grid2(w, h), dim3(128), (uint32_t)0, a->d_gray, a->d_t3, a->d_t1, w, h, t2, a->d_hist);
     sfm_launch<PreColsBody>(a, k_pre_cols, grid2(w, h), dim3(128), (uint32_t)0, a->d_t3, a->d_t1, a->d_Lt, a->d_Lsmooth, a->d_t0, w, h, t2);
     sfm_launch<PreGradBody>(a, k_pre_grad, ggrid, dim3(128), (uint32_t)0, a->d_t0, a->d_t2, w, h, a->d_hist);
-    sfm_launch<PreHistBody>(a, k_pre_hist, ggrid, dim3(128), (uint32_t)0, a->d_t2, w, h, a->d_hist, a->d_kcontrast);
+    {
+      unsigned int hy = ggrid.y;
+      if (ggrid.x * hy > 256u) hy = std::max(1u, 256u / ggrid.x);
+      sfm_launch<PreHistBody>(a, k_pre_hist, dim3(ggrid.x, hy), dim3(128), (uint32_t)0, a->d_t2, w, h, a->d_hist, a->d_kcontrast);
+    }
     AK_HIP(hipGetLastError());
   } else {
   hipLaunchKernelGGL(k_u8_to_f32, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, a->d_gray, a->d_img, n0);
