@@ -961,16 +961,24 @@ __device__ __forceinline__ int level_of_row(const LevelTab &T, int row) {
   return i;
 }
 
+constexpr int kAllPix = 4;  // pixels of a row per thread in the all-level derivative kernels
 struct ScharrXyAllBody {
   static constexpr int kGangThreads = 256;
   static __device__ __forceinline__ void run(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly, const LevelTab *__restrict__ Tp) {
     const LevelTab &T = *Tp;  // (in device memory, one per extractor: a gang launch carries a pointer per frame, not a table)
     const int i = level_of_row(T, blockIdx.y);
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
-    if (x >= w) return;
+    const int y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
     const float *src = ls + T.off[i];
-    lx[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 1, T.sc[i], T.ws[i], T.wm[i]);
-    ly[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 0, T.sc[i], T.ws[i], T.wm[i]);
+    // (kAllPix pixels of the row per thread, blockDim apart: one pixel per thread made a 1080p frame's launch 121 000
+    // workgroups of two waves, most of them of the small levels and empty)
+#pragma unroll
+    for (int k = 0; k < kAllPix; ++k) {
+      const int x = (blockIdx.x * kAllPix + k) * blockDim.x + threadIdx.x;
+      if (x < w) {
+        lx[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 1, T.sc[i], T.ws[i], T.wm[i]);
+        ly[T.off[i] + (size_t)y * w + x] = scharr_at(src, w, h, x, y, 0, T.sc[i], T.ws[i], T.wm[i]);
+      }
+    }
   }
 };
 __global__ void k_scharr_xy_all(const float *__restrict__ ls, float *__restrict__ lx, float *__restrict__ ly,
@@ -984,16 +992,21 @@ struct HessianDetAllBody {
                           float *__restrict__ ldet, const LevelTab *__restrict__ Tp) {
     const LevelTab &T = *Tp;
     const int i = level_of_row(T, blockIdx.y);
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
-    if (x >= w) return;
+    const int y = blockIdx.y - T.row0[i], w = T.w[i], h = T.h[i];
     const float *lx = lx_all + T.off[i], *ly = ly_all + T.off[i];
     const int scale = T.sc[i];
     const float ws = T.ws[i], wm = T.wm[i], sf2 = (float)(scale * scale);
-    const float lxx = scharr_at(lx, w, h, x, y, 1, scale, ws, wm);
-    const float lyy = scharr_at(ly, w, h, x, y, 0, scale, ws, wm);
-    const float lxy = scharr_at(lx, w, h, x, y, 0, scale, ws, wm);
-    const float a = lxx * sf2, b = lxy * sf2, c = lyy * sf2;
-    ldet[T.off[i] + (size_t)y * w + x] = a * c - b * b;
+#pragma unroll
+    for (int k = 0; k < kAllPix; ++k) {
+      const int x = (blockIdx.x * kAllPix + k) * blockDim.x + threadIdx.x;
+      if (x < w) {
+        const float lxx = scharr_at(lx, w, h, x, y, 1, scale, ws, wm);
+        const float lyy = scharr_at(ly, w, h, x, y, 0, scale, ws, wm);
+        const float lxy = scharr_at(lx, w, h, x, y, 0, scale, ws, wm);
+        const float a = lxx * sf2, b = lxy * sf2, c = lyy * sf2;
+        ldet[T.off[i] + (size_t)y * w + x] = a * c - b * b;
+      }
+    }
   }
 };
 __global__ void k_hessian_det_all(const float *__restrict__ lx_all, const float *__restrict__ ly_all,
@@ -1987,7 +2000,8 @@ int build_scale_space(Akaze *a, const uint8_t *gray /*host; null: the image is a
       AK_HIP(hipMemcpyAsync(Lt, start, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   const LevelTab T = level_tab(a);
-  const dim3 agrid((a->w + 127) / 128, T.row0[nlev]);  // (the rows of the levels that were built: levels come in order)
+  // (the rows of the levels that were built: levels come in order; kAllPix pixels of a row per thread)
+  const dim3 agrid(((a->w + 127) / 128 + kAllPix - 1) / kAllPix, T.row0[nlev]);
   sfm_launch<ScharrXyAllBody>(a, k_scharr_xy_all, agrid, dim3(128), (uint32_t)0, a->d_Lsmooth, a->d_Lx, a->d_Ly, reinterpret_cast<const LevelTab *>(a->d_level_tab));
   if (with_det)
     sfm_launch<HessianDetAllBody>(a, k_hessian_det_all, agrid, dim3(128), (uint32_t)0, a->d_Lx, a->d_Ly, a->d_Ldet, reinterpret_cast<const LevelTab *>(a->d_level_tab));
