@@ -1038,6 +1038,7 @@ __global__ void k_hessian_det_all(const float *__restrict__ lx_all, const float 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kSegPx = 64;          // a segment = what one wave of the extrema kernels covers
 constexpr int kSegMax = kSegPx / 2; // strict 3x3 maxima are never horizontal neighbours
+constexpr int kSegPerWave = 4;      // segments of a row one wave of the extrema kernels takes
 
 __device__ __forceinline__ bool extremum_at(const float *__restrict__ D, int w, int h, int x, int y, float dthreshold,
                                             int sigma_size_, float (&p)[9]) {
@@ -1055,24 +1056,33 @@ __device__ __forceinline__ bool extremum_at(const float *__restrict__ D, int w, 
 
 struct ExtremaSegBody {
   static constexpr int kGangThreads = 128;
+  // (kSegPerWave segments of the row per wave: one each made a 1080p frame's launch 121 000 workgroups, most of them of the
+  // small levels and empty)
   static __device__ __forceinline__ void run(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp,
-                                             float dthreshold, uint8_t *__restrict__ seg_x, unsigned int *__restrict__ seg_cnt) {
+                                             float dthreshold, uint8_t *__restrict__ seg_x, unsigned int *__restrict__ seg_cnt,
+                                             unsigned int segs_per_row) {
     const LevelTab &T = *Tp;
     const int i = level_of_row(T, blockIdx.y);
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y - T.row0[i];
-    float p[9];
-    const bool is = extremum_at(ldet_all + T.off[i], T.w[i], T.h[i], x, y, dthreshold, T.sigma_size[i], p);
-    const unsigned long long m = __ballot(is);
+    const int y = blockIdx.y - T.row0[i];
     const int lane = threadIdx.x & 63;
-    const unsigned int seg = blockIdx.y * (gridDim.x * 2) + blockIdx.x * 2 + (threadIdx.x >> 6);
-    if (is) seg_x[(size_t)seg * kSegMax + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-    if (lane == 0) seg_cnt[seg] = (unsigned int)__popcll(m);
+#pragma unroll
+    for (int k = 0; k < kSegPerWave; ++k) {
+      const unsigned int sidx = (blockIdx.x * kSegPerWave + k) * 2u + (threadIdx.x >> 6);  // the segment of the row
+      if (sidx >= segs_per_row) break;
+      const int x = (int)sidx * kSegPx + lane;
+      float p[9];
+      const bool is = extremum_at(ldet_all + T.off[i], T.w[i], T.h[i], x, y, dthreshold, T.sigma_size[i], p);
+      const unsigned long long m = __ballot(is);
+      const unsigned int seg = blockIdx.y * segs_per_row + sidx;
+      if (is) seg_x[(size_t)seg * kSegMax + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+      if (lane == 0) seg_cnt[seg] = (unsigned int)__popcll(m);
+    }
   }
 };
 __global__ __launch_bounds__(128) void k_extrema_seg(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp,
                                                      float dthreshold, uint8_t *__restrict__ seg_x,
-                                                     unsigned int *__restrict__ seg_cnt) {
-  ExtremaSegBody::run(ldet_all, Tp, dthreshold, seg_x, seg_cnt);
+                                                     unsigned int *__restrict__ seg_cnt, unsigned int segs_per_row) {
+  ExtremaSegBody::run(ldet_all, Tp, dthreshold, seg_x, seg_cnt, segs_per_row);
 }
 
 // exclusive sum of seg_cnt[0 .. n_seg) in place, the total in seg_cnt[n_seg] and in *n_out.  Each of the 16 waves owns a
@@ -1157,35 +1167,40 @@ struct ExtremaPlaceBody {
   static constexpr int kGangThreads = 128;
   static __device__ __forceinline__ void run(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp,
                                              const uint8_t *__restrict__ seg_x, const unsigned int *__restrict__ seg_base,
-                                             unsigned int cap, CandArrays C) {
+                                             unsigned int cap, CandArrays C, unsigned int segs_per_row) {
     const LevelTab &T = *Tp;
     const int i = level_of_row(T, blockIdx.y);
     const int y = blockIdx.y - T.row0[i], w = T.w[i];
     const int lane = threadIdx.x & 63;
-    const unsigned int seg = blockIdx.y * (gridDim.x * 2) + blockIdx.x * 2 + (threadIdx.x >> 6);
-    const unsigned int base = seg_base[seg], cnt = seg_base[seg + 1] - base;
-    if ((unsigned int)lane >= cnt || base + lane >= cap) return;
-    const int x = blockIdx.x * blockDim.x + (threadIdx.x & ~63) + seg_x[(size_t)seg * kSegMax + lane];
     const float *D = ldet_all + T.off[i];
-    const unsigned int g = base + lane;
-    C.xy[g] = (uint32_t)x | ((uint32_t)y << 16);
-    C.level[g] = (uint8_t)i;
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) C.patch[(size_t)g * 9 + (dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
-    C.resp[g] = fabsf(D[(size_t)y * w + x]);
+#pragma unroll
+    for (int k = 0; k < kSegPerWave; ++k) {
+      const unsigned int sidx = (blockIdx.x * kSegPerWave + k) * 2u + (threadIdx.x >> 6);
+      if (sidx >= segs_per_row) break;
+      const unsigned int seg = blockIdx.y * segs_per_row + sidx;
+      const unsigned int base = seg_base[seg], cnt = seg_base[seg + 1] - base;
+      if ((unsigned int)lane >= cnt || base + lane >= cap) continue;
+      const int x = (int)sidx * kSegPx + seg_x[(size_t)seg * kSegMax + lane];
+      const unsigned int g = base + lane;
+      C.xy[g] = (uint32_t)x | ((uint32_t)y << 16);
+      C.level[g] = (uint8_t)i;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) C.patch[(size_t)g * 9 + (dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
+      C.resp[g] = fabsf(D[(size_t)y * w + x]);
+    }
   }
 };
 __global__ __launch_bounds__(128) void k_extrema_place(const float *__restrict__ ldet_all, const LevelTab *__restrict__ Tp,
                                                        const uint8_t *__restrict__ seg_x,
                                                        const unsigned int *__restrict__ seg_base, unsigned int cap,
-                                                       CandArrays C) {
-  ExtremaPlaceBody::run(ldet_all, Tp, seg_x, seg_base, cap, C);
+                                                       CandArrays C, unsigned int segs_per_row) {
+  ExtremaPlaceBody::run(ldet_all, Tp, seg_x, seg_base, cap, C, segs_per_row);
 }
 
 struct SuppressArgs {
   const LevelTab *T;
   const unsigned int *seg_base;  // [n_seg + 1]
-  unsigned int segs_per_row;     // 2 x the extrema kernels' gridDim.x
+  unsigned int segs_per_row;     // 64-pixel segments of an image row (2 x ceil(width / 128))
   unsigned int cap;
   CandArrays C;
   uint8_t *status;               // per candidate: 0 undecided, 1 holds a point of the list, 2 dropped, 3 taken over
@@ -2283,12 +2298,13 @@ static int akaze_detect_enqueue(Akaze *a, const uint8_t *gray) {
   int rc = build_scale_space(a, gray);
   if (rc) return rc;
   const LevelTab T = level_tab(a);
-  const dim3 egrid((a->w + 127) / 128, T.row0[T.n]);
+  const dim3 egrid(((a->w + 127) / 128 + kSegPerWave - 1) / kSegPerWave, T.row0[T.n]);  // (kSegPerWave segments per wave)
   const LevelTab *dT = reinterpret_cast<const LevelTab *>(a->d_level_tab);
   CandArrays C{a->d_cxy, a->d_clevel, a->d_cresp, a->d_cpatch};
-  sfm_launch<ExtremaSegBody>(a, k_extrema_seg, egrid, dim3(128), 0, a->d_Ldet, dT, a->thres, a->d_seg_x, a->d_seg);
+  sfm_launch<ExtremaSegBody>(a, k_extrema_seg, egrid, dim3(128), 0, a->d_Ldet, dT, a->thres, a->d_seg_x, a->d_seg, a->segs_per_row);
   sfm_launch<SegScanBody>(a, k_seg_scan, dim3(1), dim3(1024), 0, a->d_seg, a->n_seg, a->cand_cap, a->d_ncand);
-  sfm_launch<ExtremaPlaceBody>(a, k_extrema_place, egrid, dim3(128), 0, a->d_Ldet, dT, a->d_seg_x, a->d_seg, a->cand_cap, C);
+  sfm_launch<ExtremaPlaceBody>(a, k_extrema_place, egrid, dim3(128), 0, a->d_Ldet, dT, a->d_seg_x, a->d_seg, a->cand_cap, C,
+                               a->segs_per_row);
   SuppressArgs S;
   S.T = dT;
   S.seg_base = a->d_seg;
