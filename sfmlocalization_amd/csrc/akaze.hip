@@ -1151,6 +1151,102 @@ struct SegScanBody {
     (void)cap;
   }
 };
+// The same for a large image (a 1080p frame has 243 000 segments: 1 MB that ONE workgroup reads twice and writes once
+// -- 50 us, the reach of a single compute unit's memory path): two launches over chunks of kSegChunk entries.
+//   k_seg_sum    workgroup g adds up chunk g -> part[g]; the workgroup that arrives last turns part[] into the chunks'
+//                starting sums (exclusive scan) and writes the total (nobody waits: the k_pre_hist hand-over)
+//   k_seg_write  workgroup g scans chunk g from part[g]
+constexpr unsigned int kSegChunk = 4096;  // 4 entries per thread of a 1 024-thread workgroup
+__device__ __forceinline__ unsigned int block_scan_1024(unsigned int v, unsigned int *wtot /*[16] LDS*/, unsigned int *total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned int inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  __syncthreads();  // (wtot of a previous call is no longer read)
+  if (lane == 63) wtot[wv] = inc;
+  __syncthreads();
+  unsigned int before = 0, all = 0;
+  for (int q = 0; q < 16; ++q) {
+    if (q < wv) before += wtot[q];
+    all += wtot[q];
+  }
+  if (total) *total = all;
+  return before + inc - v;  // exclusive
+}
+struct SegSumBody {
+  static constexpr int kGangThreads = 1024;
+  static __device__ __forceinline__ void run(unsigned int *__restrict__ seg_cnt, unsigned int n_seg,
+                                             unsigned int *__restrict__ part /*[chunks] sums, [chunks] arrivals*/,
+                                             unsigned int *__restrict__ n_out) {
+    __shared__ unsigned int wtot[16];
+    __shared__ unsigned int s_ticket;
+    const unsigned int chunks = gridDim.x, k = blockIdx.x * kSegChunk + 4u * threadIdx.x;
+    unsigned int c = 0;
+    if (k + 4u <= n_seg) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(seg_cnt + k);
+      c = (v.x + v.y) + (v.z + v.w);
+    } else {
+      for (unsigned int u = 0; u < 4u; ++u) c += k + u < n_seg ? seg_cnt[k + u] : 0u;
+    }
+    unsigned int total = 0;
+    (void)block_scan_1024(c, wtot, &total);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&part[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_ticket = atomicAdd(&part[chunks], 1u);
+    }
+    __syncthreads();
+    if (s_ticket != chunks - 1u) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (chunks <= 1 024: the launcher's bound)
+    const unsigned int mine = threadIdx.x < chunks ? __hip_atomic_load(&part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    unsigned int all = 0;
+    const unsigned int before = block_scan_1024(mine, wtot, &all);
+    if (threadIdx.x < chunks) part[threadIdx.x] = before;
+    if (threadIdx.x == 0) {
+      part[chunks] = 0u;  // the next frame counts from zero
+      seg_cnt[n_seg] = all;
+      *n_out = all;
+    }
+  }
+};
+__global__ __launch_bounds__(1024) void k_seg_sum(unsigned int *__restrict__ seg_cnt, unsigned int n_seg,
+                                                  unsigned int *__restrict__ part, unsigned int *__restrict__ n_out) {
+  SegSumBody::run(seg_cnt, n_seg, part, n_out);
+}
+struct SegWriteBody {
+  static constexpr int kGangThreads = 1024;
+  static __device__ __forceinline__ void run(unsigned int *__restrict__ seg_cnt, unsigned int n_seg,
+                                             const unsigned int *__restrict__ part) {
+    __shared__ unsigned int wtot[16];
+    const unsigned int k = blockIdx.x * kSegChunk + 4u * threadIdx.x;
+    unsigned int c[4] = {0u, 0u, 0u, 0u};
+    if (k + 4u <= n_seg) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(seg_cnt + k);
+      c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+    } else {
+      for (unsigned int u = 0; u < 4u; ++u) c[u] = k + u < n_seg ? seg_cnt[k + u] : 0u;
+    }
+    unsigned int run = part[blockIdx.x] + block_scan_1024((c[0] + c[1]) + (c[2] + c[3]), wtot, nullptr);
+    if (k + 4u <= n_seg) {
+      uint4 o4;
+      o4.x = run; o4.y = run + c[0]; o4.z = run + c[0] + c[1]; o4.w = run + c[0] + c[1] + c[2];
+      *reinterpret_cast<uint4 *>(seg_cnt + k) = o4;
+    } else {
+      for (unsigned int u = 0; u < 4u; ++u) {
+        if (k + u < n_seg) seg_cnt[k + u] = run;
+        run += c[u];
+      }
+    }
+  }
+};
+__global__ __launch_bounds__(1024) void k_seg_write(unsigned int *__restrict__ seg_cnt, unsigned int n_seg,
+                                                    const unsigned int *__restrict__ part) {
+  SegWriteBody::run(seg_cnt, n_seg, part);
+}
+
 __global__ __launch_bounds__(1024) void k_seg_scan(unsigned int *__restrict__ seg_cnt, unsigned int n_seg, unsigned int cap,
                                                    unsigned int *__restrict__ n_out) {
   SegScanBody::run(seg_cnt, n_seg, cap, n_out);
@@ -1777,6 +1873,7 @@ struct Akaze : GangMember {  // (gang.h: `stream` reads as the stream to queue o
   unsigned int cand_cap = 1u << 16;
   unsigned int n_seg = 0, segs_per_row = 0;
   unsigned int *d_seg = nullptr;              // [n_seg + 1] counts, then (k_seg_scan) where each segment starts
+  unsigned int *d_seg_part = nullptr;         // [chunks + 1] k_seg_sum / k_seg_write: the chunks' sums, then arrivals
   uint8_t *d_seg_x = nullptr;                 // [n_seg x kSegMax]
   uint32_t *d_cxy = nullptr;
   uint8_t *d_clevel = nullptr, *d_cstatus = nullptr, *d_cready = nullptr;
@@ -2150,7 +2247,7 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   gang_member_free(a);
   void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
                   a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_level_tab, a->d_dev_levels, a->d_ncand,
-                  a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc, a->d_seg, a->d_seg_x, a->d_cxy,
+                  a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc, a->d_seg, a->d_seg_part, a->d_seg_x, a->d_cxy,
                   a->d_clevel, a->d_cstatus, a->d_cready, a->d_cresp, a->d_cpatch, a->d_ckey, a->d_cslot, a->d_resp, a->d_kp6, a->d_qkpt, a->d_qkpt6};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -2210,6 +2307,8 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   const size_t cc = a->cand_cap;
   A((void **)&a->d_ncand, 160 * sizeof(unsigned int));
   A((void **)&a->d_seg, ((size_t)a->n_seg + 1) * sizeof(unsigned int));
+  A((void **)&a->d_seg_part, 1025 * sizeof(unsigned int));
+  if (he == hipSuccess) he = hipMemset(a->d_seg_part, 0, 1025 * sizeof(unsigned int));
   A((void **)&a->d_seg_x, (size_t)a->n_seg * kSegMax);
   A((void **)&a->d_cxy, cc * sizeof(uint32_t));
   A((void **)&a->d_clevel, cc);
@@ -2302,7 +2401,15 @@ static int akaze_detect_enqueue(Akaze *a, const uint8_t *gray) {
   const LevelTab *dT = reinterpret_cast<const LevelTab *>(a->d_level_tab);
   CandArrays C{a->d_cxy, a->d_clevel, a->d_cresp, a->d_cpatch};
   sfm_launch<ExtremaSegBody>(a, k_extrema_seg, egrid, dim3(128), 0, a->d_Ldet, dT, a->thres, a->d_seg_x, a->d_seg, a->segs_per_row);
-  sfm_launch<SegScanBody>(a, k_seg_scan, dim3(1), dim3(1024), 0, a->d_seg, a->n_seg, a->cand_cap, a->d_ncand);
+  {
+    const unsigned int chunks = (a->n_seg + kSegChunk - 1u) / kSegChunk;
+    if (a->n_seg > 65536u && chunks <= 1024u && a->d_seg_part) {  // a large image: two launches over many compute units
+      sfm_launch<SegSumBody>(a, k_seg_sum, dim3(chunks), dim3(1024), 0, a->d_seg, a->n_seg, a->d_seg_part, a->d_ncand);
+      sfm_launch<SegWriteBody>(a, k_seg_write, dim3(chunks), dim3(1024), 0, a->d_seg, a->n_seg, (const unsigned int *)a->d_seg_part);
+    } else {
+      sfm_launch<SegScanBody>(a, k_seg_scan, dim3(1), dim3(1024), 0, a->d_seg, a->n_seg, a->cand_cap, a->d_ncand);
+    }
+  }
   sfm_launch<ExtremaPlaceBody>(a, k_extrema_place, egrid, dim3(128), 0, a->d_Ldet, dT, a->d_seg_x, a->d_seg, a->cand_cap, C,
                                a->segs_per_row);
   SuppressArgs S;
