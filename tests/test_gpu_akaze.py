@@ -115,3 +115,23 @@ def test_extracted_query_localises(oracle_c):
         shift = kp2[mj[:n], :2] - kp[mi[:n], :2]
         assert np.abs(np.median(shift, axis=0) - [10, 6]).max() < 0.05
     ak.close()
+
+
+def test_batch_of_1080p_frames_equals_one_at_a_time():
+    """Two 1920 x 1080 frames per call: the large-image forms of the tail (the segment scan as two launches over many
+    compute units, the all-level kernels with four pixels / segments per thread / wave) in their gang forms -- keypoints and
+    descriptors as from separate calls, resident outputs as the downloaded ones."""
+    shape = (1080, 1920)
+    imgs = [synth.texture_image(70 + k, *shape, n_blobs=2500, n_rects=1200) for k in range(2)]
+    one = S.Akaze(shape[1], shape[0])
+    ref = [one.detect_and_compute(g) for g in imgs]
+    exs = [S.Akaze(shape[1], shape[0]) for _ in range(2)]
+    got = S.Akaze.detect_and_compute_batch(exs, imgs)
+    for (kp, d), (rkp, rd) in zip(got, ref):
+        assert len(rkp) > 500
+        np.testing.assert_array_equal(bits32(kp), bits32(rkp))
+        np.testing.assert_array_equal(d, rd)
+    ns = S.Akaze.detect_resident_batch(exs, imgs[::-1])
+    assert list(ns) == [len(ref[1][0]), len(ref[0][0])]
+    for e in exs + [one]:
+        e.close()
