@@ -56,7 +56,8 @@ def test_bof_vector_matches_oracle(oracle_c):
     b2.close()
 
 
-@pytest.mark.parametrize("K,n_pca,n", [(100, 32, 9999), (100, 32, 31), (100, 32, 1), (37, 0, 5003), (400, 48, 3001), (7, 61, 650)])
+@pytest.mark.parametrize("K,n_pca,n", [(100, 32, 9999), (100, 32, 31), (100, 32, 1), (37, 0, 5003), (400, 48, 3001), (7, 61, 650),
+                                       (7000, 8, 400)])     # (a vocabulary too large for either LDS form: both fallbacks)
 def test_bof_assignment_forms_match_oracle(oracle_c, K, n_pca, n):
     """The LDS-tiled assignment (models that fit its layout: the reference's 61 -> 32, K = 100) and the
     thread-per-descriptor one (anything larger: K = 400 x 48 does not fit) give the oracle's vector bit for bit: ragged
