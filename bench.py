@@ -1114,14 +1114,69 @@ def main():
         # SFMLOC_BENCH_BACKEND=gloo: rehearse N ranks on fewer GPUs (ranks share devices, the exchange goes through the
         # host); the measured configuration is always nccl = RCCL, one rank per GPU
         backend = os.environ.get("SFMLOC_BENCH_BACKEND", "nccl")
+        # a collective that cannot complete (a wedged link, a rank that died) must end the run with a line, not sit for
+        # the default ten minutes: 120 s per collective, and the watchdog below for anything that never returns at all
+        from datetime import timedelta
+        coll_timeout = timedelta(seconds=float(os.environ.get("SFMLOC_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=coll_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=coll_timeout)
             local_rank = local_rank % max(1, torch.cuda.device_count())
         assert dist.get_world_size() == a.gpus, "process group size differs from --gpus"
     torch.cuda.set_device(local_rank)
 
+    watchdog = None
+    if dist is not None:
+        watchdog = Watchdog(float(os.environ.get("SFMLOC_BENCH_WATCHDOG_S", "900")), rank, a)
+    try:
+        out = run_all(a, rank, world, local_rank, dist, torch)
+    except BaseException as e:  # noqa: BLE001 -- incl. DistBackendError / a collective's timeout
+        if dist is None or isinstance(e, (SystemExit, KeyboardInterrupt)):
+            raise
+        fail(a, rank, f"{type(e).__name__}: {e}", 3)
+    if watchdog is not None:
+        watchdog.stop()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def fail(a, rank, why, code):
+    """A multi-rank run that cannot finish: one JSON line from rank 0 (so the driver records WHY instead of a silent
+    timeout), the traceback on stderr, and the process ends at once -- no destructor of a wedged process group is run,
+    and nothing is re-exec'ed (a process that has touched the GPU must not be replaced)."""
+    import traceback
+    traceback.print_exc()
+    print(f"[bench] rank {rank}: {why}", file=sys.stderr, flush=True)
+    if rank == 0:
+        print(json.dumps({"metric": "query images localized/sec", "value": None, "unit": "queries/s", "n_gpus": a.gpus,
+                          "steps": a.steps, "warmup": a.warmup, "error": why[:2000]}), flush=True)
+    sys.stdout.flush()
+    os._exit(code)
+
+
+class Watchdog:
+    """Ends a multi-rank run that makes no progress at all (a hang INSIDE a call, which no exception reports): every
+    phase of measure() completes well inside the limit on a healthy node."""
+
+    def __init__(self, limit_s, rank, a):
+        import threading
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, args=(limit_s, rank, a), daemon=True)
+        self._t.start()
+
+    def _run(self, limit_s, rank, a):
+        if not self._stop.wait(limit_s):
+            fail(a, rank, f"watchdog: the run did not finish within {limit_s:.0f} s (SFMLOC_BENCH_WATCHDOG_S)", 4)
+
+    def stop(self):
+        self._stop.set()
+
+
+def run_all(a, rank, world, local_rank, dist, torch):
     out = measure(argparse.Namespace(**vars(a)), rank, world, local_rank, dist, torch, a.replicas)
     if world > 1 and not a.replicas and not a.no_replica_leg and not a.image_in_only:
         # the comparison SCALE runs need: N independent replicas of the whole map, same queries, no exchange
@@ -1133,11 +1188,7 @@ def main():
             out["replicas"] = {k: rep[k] for k in ("value", "unit", "ms_per_step", "identical_to_single_flight", "latency_ms")}
             out["replicas"]["parallelism"] = rep["config"]["parallelism"]
             out["replicas"]["queries_localised"] = rep["config"]["queries_localised"]
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

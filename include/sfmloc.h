@@ -604,6 +604,9 @@ void sfmloc_matches_destroy(sfmloc_matches *m);
  * op: 0 log10, 1 sqrt+div, 2 cubic, 3 quartic, 4 seven-point, 5 P3P, 6 KRt_From_P, 7 sample,
  *     8 seven-point, wave-parallel form (K3's fast kernel; layout of op 4) */
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride);
+/* Test hook: allocation k (0..11) of the NEXT regrowth of a context's P3P workspace fails with SFMLOC_ENOMEM (one shot;
+ * -1 disarms).  The regrowth has no counterpart in the reference (localization.cpp:479-509 has no size limit). */
+void sfmloc_debug_fail_p3p_alloc(int k);
 
 /* ------------------------------------------------------------------------- */
 /* Measurement (params.profile = 1): accumulated HIP-event time per kernel on  */

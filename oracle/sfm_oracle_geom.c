@@ -667,6 +667,18 @@ void orc_logcombi_tables(int s, int n, float *logc_n, float *logc_k) {
   free(L10);
 }
 
+/* Optional trace of one acransac() run (tools/k5_policy_sim.py: which iterations improved the model decides what a
+ * round-by-round schedule of the device costs; the schedule never changes the result).  Entry = iteration << 2 |
+ * (index set changed) << 1 | (model improved); not thread-safe: set, run one estimation, read. */
+static int32_t *g_ac_trace = NULL;
+static int g_ac_trace_cap = 0, g_ac_trace_n = 0;
+void orc_acransac_trace(int32_t *buf, int cap) {
+  g_ac_trace = buf;
+  g_ac_trace_cap = cap;
+  g_ac_trace_n = 0;
+}
+int orc_acransac_trace_count(void) { return g_ac_trace_n; }
+
 /* returns {errorMax (normalised frame), minNFA}; inliers in vec_inliers order (ascending residual);
  * model = best model in the normalised frame */
 static void acransac(const ac_kernel *K, int n_iter_in, double max_threshold, uint64_t seed, uint32_t stream,
@@ -726,11 +738,13 @@ static void acransac(const ac_kernel *K, int n_iter_in, double max_threshold, ui
         memcpy(model, M, (size_t)K->model_size * sizeof(double));
       }
     }
+    int changed = 0;
     if ((better && min_nfa < 0.0) || (iter + 1 == n_iter && n_reserve)) {
       if (n_in == 0) {
         n_iter++;
         n_reserve--;
       } else {
+        changed = 1;
         memcpy(vec_index, vec_inliers, (size_t)n_in * sizeof(int32_t));
         n_index = n_in;
         if (n_reserve) {
@@ -739,6 +753,8 @@ static void acransac(const ac_kernel *K, int n_iter_in, double max_threshold, ui
         }
       }
     }
+    if ((better || changed) && g_ac_trace && g_ac_trace_n < g_ac_trace_cap)
+      g_ac_trace[g_ac_trace_n++] = (int32_t)((iter << 2) | (changed << 1) | better);
   }
   if (out_iters) *out_iters = (int)iter;
   if (min_nfa >= 0.0) n_in = 0;

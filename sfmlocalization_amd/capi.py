@@ -103,7 +103,7 @@ SYMBOLS = [
     "sfmloc_query_create", "sfmloc_query_destroy",
     "sfmloc_match_putative", "sfmloc_putative_read", "sfmloc_putative_read_rows", "sfmloc_sync",
     "sfmloc_geometric_filter", "sfmloc_geometric_read", "sfmloc_match_set", "sfmloc_match_set_read",
-    "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math",
+    "sfmloc_resection", "sfmloc_pose_read", "sfmloc_localize", "sfmloc_debug_math", "sfmloc_debug_fail_p3p_alloc",
     "sfmloc_context_create", "sfmloc_context_destroy", "sfmloc_localize_begin", "sfmloc_localize_end",
     "sfmloc_dense_gray", "sfmloc_bow_distances", "sfmloc_query_from_view", "sfmloc_match_one_to_one", "sfmloc_match_pairs", "sfmloc_track", "sfmloc_geometric_pairs",
     "sfmloc_matches_pairs", "sfmloc_matches_pair", "sfmloc_matches_read", "sfmloc_matches_destroy",
@@ -264,6 +264,8 @@ def _L():
         L.sfmloc_localize.argtypes = [C.c_void_p, C.c_void_p, U32P, C.c_uint32, C.POINTER(Pose), U32P, U32P,
                                       C.c_uint32]
         L.sfmloc_debug_math.argtypes = [C.c_int, C.c_int, F64P, C.c_int, C.c_int, F64P, C.c_int]
+        L.sfmloc_debug_fail_p3p_alloc.argtypes = [C.c_int]
+        L.sfmloc_debug_fail_p3p_alloc.restype = None
         L.sfmloc_context_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.sfmloc_context_destroy.restype = None
         L.sfmloc_context_destroy.argtypes = [C.c_void_p]
@@ -492,6 +494,11 @@ class Undistorter:
 
     def __exit__(self, *a):
         self.close()
+
+
+def debug_fail_p3p_alloc(k):
+    """sfmloc_debug_fail_p3p_alloc: allocation k of the next P3P workspace regrowth fails (one shot; -1 disarms)."""
+    _L().sfmloc_debug_fail_p3p_alloc(int(k))
 
 
 def debug_math(op, x, out_stride, device=0):

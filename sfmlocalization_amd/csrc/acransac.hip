@@ -1619,7 +1619,6 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   const int per_model = wide ? (int)(gridDim.x >> 2) : (int)gridDim.x;  // hypotheses of the launch
   const int b = (int)blockIdx.x % per_model;
   const int mdl = (int)blockIdx.x / per_model;
-  const int slot = wide ? 4 * b + mdl : b;
   const int n = st.n;
   if (b >= p3p_round_batch(n, batch) || b >= st.batch_limit) return;
   const long it = (long)st.iter + b;
@@ -1630,10 +1629,10 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   const int P = next_pow2(n);
   // one model per workgroup: a wide launch with enough correspondences (and the LDS forms: n <= kP3pMaxN)
   const bool single = !kSmall && wide && P >= 1024 && n <= kP3pMaxN;
-  if (wide && !single && mdl != 0) {  // this hypothesis is workgroup 4 b's alone
-    if (tid == 0) store_through(A.hyp_nfa + slot, pos_inf());
-    return;
-  }
+  // (a wide launch that is not in single mode runs workgroups 0 .. batch - 1 only -- p3p_round.body.inc -- and is a plain
+  // round: slot b, so that the inlier lists of a set above kP3pMaxN, whose stride is max_n, stay inside the 64 lists
+  // ctx_p3p_reserve sizes them for)
+  const int slot = single ? 4 * b + mdl : b;
 #ifdef SFMLOC_STAMPS
   const int stamp_round = st.rounds;
 #endif
@@ -2028,9 +2027,8 @@ struct P3pReplayShared {
 // a wide launch whose query turned out small wrote slot 4 b only, a plain launch slot b
 __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int wide4, int slot_mul, P3pReplayShared &RS);
 __device__ __forceinline__ void p3p_replay(const P3pArgs &A, int batch, int single_mode, P3pReplayShared &RS) {
-  // (gridDim.x is 4 x batch in a wide launch -- the kernel's `wide` argument -- and batch otherwise)
-  const int slot_mul = (int)gridDim.x == batch ? 1 : 4;
-  p3p_replay_impl(A, batch, single_mode, slot_mul, RS);
+  // (four result slots per hypothesis only in single mode; any other launch, wide or not, wrote slot b)
+  p3p_replay_impl(A, batch, single_mode, single_mode ? 4 : 1, RS);
 }
 __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int wide, int slot_mul, P3pReplayShared &RS) {
   P3pState &st = *A.state;

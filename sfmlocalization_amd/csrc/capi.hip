@@ -543,7 +543,9 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
 // session never gets here with work recorded -- the reserve is the first thing a query's stage does -- but if it does,
 // reading c->stream issues what was recorded first (gang.h), so stream order is still call order.
 namespace {
-int g_test_fail_alloc = -1;  // test hook (SFMLOC_TEST_FAIL_P3P_ALLOC=k): the k-th allocation of the next reserve fails
+// test hook (sfmloc_debug_fail_p3p_alloc(k)): the k-th allocation of the NEXT regrowth fails; one shot, consumed atomically
+// by the regrowth that sees it (no environment variable: a stray one must not be able to fail a production allocation)
+std::atomic<int> g_test_fail_alloc{-1};
 }
 int ctx_p3p_reserve(Ctx *c, uint32_t n) {
   c->p3p_query_n = n;
@@ -559,14 +561,13 @@ int ctx_p3p_reserve(Ctx *c, uint32_t n) {
                             (size_t)cap * sizeof(uint32_t),        (size_t)cap * sizeof(uint32_t),
                             (size_t)cap * sizeof(uint32_t),        large_batch * cap * sizeof(uint64_t),
                             large_batch * cap * sizeof(uint32_t),  ((size_t)cap / 2 + 2) * sizeof(double)};
-  const char *e_fail = getenv("SFMLOC_TEST_FAIL_P3P_ALLOC");
-  g_test_fail_alloc = e_fail ? atoi(e_fail) : -1;
+  const int test_fail_alloc = g_test_fail_alloc.exchange(-1, std::memory_order_relaxed);
   void *fresh[12] = {nullptr};
   uint64_t total = 0;
   for (int i = 0; i < 12; ++i) {
-    hipError_t err = (i == g_test_fail_alloc) ? hipErrorOutOfMemory : hipMalloc(&fresh[i], bytes[i]);
+    hipError_t err = (i == test_fail_alloc) ? hipErrorOutOfMemory : hipMalloc(&fresh[i], bytes[i]);
     if (err != hipSuccess) {
-      if (i != g_test_fail_alloc) (void)hipGetLastError();
+      if (i != test_fail_alloc) (void)hipGetLastError();
       for (int k = 0; k < i; ++k) (void)hipFree(fresh[k]);
       set_error("P3P workspace for %u correspondences: allocation %d of 12 (%zu bytes) failed: %s", cap, i, bytes[i],
                 hipGetErrorString(err));
@@ -2109,6 +2110,8 @@ int sfmloc_merge_batch_begin(sfmloc_context *const *ctxs, uint32_t n, sfmloc_que
   const int rc_end = n > 1 ? sfmloc_gang_end(ctxs, n) : SFMLOC_OK;
   return rc ? rc : rc_end;
 }
+
+void sfmloc_debug_fail_p3p_alloc(int k) { sfmloc::g_test_fail_alloc.store(k, std::memory_order_relaxed); }
 
 int sfmloc_debug_math(int device, int op, const double *in, int n, int in_stride, double *out, int out_stride) {
   SFM_CHECK(in && out && n > 0 && in_stride > 0 && out_stride > 0, SFMLOC_EINVAL, "sfmloc_debug_math: bad argument");

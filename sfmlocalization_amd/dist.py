@@ -241,20 +241,15 @@ class ShardedLocalizer:
 
     def reset_counters(self):
         self._coll_events = []
+        self._coll_stats = {}
         self._n_batches = self._n_queries = self._n_redo = 0
         self._bytes_parts = self._bytes_keys = self._bytes_feats = 0
         self._max_total = 0
 
     def counters(self):
         nb = max(1, self._n_batches)
-        coll = {}
-        for what, e0, e1 in self._coll_events:      # (every recorded collective has completed when this is read)
-            try:
-                e1.synchronize()
-                coll.setdefault(what, []).append(e0.elapsed_time(e1))
-            except Exception:  # noqa: BLE001
-                pass
-        coll_ms = {k: {"n": len(v), "mean_ms": float(np.mean(v)), "max_ms": float(np.max(v))} for k, v in coll.items()}
+        self._fold_coll_events()
+        coll_ms = {k: {"n": n, "mean_ms": tot / n, "max_ms": mx} for k, (n, tot, mx) in self._coll_stats.items() if n}
         return {"batches": self._n_batches, "queries": self._n_queries,
                 "process_group_size": int(self.dist.get_world_size(self.group)) if self.dist.is_initialized() else 1,
                 "collective_ms_on_the_comm_stream": coll_ms,
@@ -264,6 +259,22 @@ class ShardedLocalizer:
                 "budget_candidates_per_query": self.budget_per_query,
                 "max_candidates_of_one_shard_for_one_batch": int(self._max_total),
                 "batches_exchanged_again_with_a_larger_budget": self._n_redo}
+
+    _COLL_EVENTS_CAP = 256   # pending (start, end) event pairs; folded into running statistics beyond that
+
+    def _fold_coll_events(self, keep=0):
+        """Elapsed times of the recorded collectives -> running {what: (n, sum, max)}; the events are dropped, so a
+        service that never resets its counters holds at most _COLL_EVENTS_CAP pairs (oldest first: those have long
+        completed; synchronising on them does not stall the pipeline)."""
+        ev, self._coll_events = self._coll_events[:len(self._coll_events) - keep], self._coll_events[len(self._coll_events) - keep:]
+        for what, e0, e1 in ev:
+            try:
+                e1.synchronize()
+                ms = float(e0.elapsed_time(e1))
+            except Exception:  # noqa: BLE001
+                continue
+            n, tot, mx = self._coll_stats.get(what, (0, 0.0, 0.0))
+            self._coll_stats[what] = (n + 1, tot + ms, max(mx, ms))
 
     def owner(self, i):
         return i % self.world
@@ -302,6 +313,8 @@ class ShardedLocalizer:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(comm)
                 self._coll_events.append((what, t_start, ev))
+                if len(self._coll_events) > self._COLL_EVENTS_CAP:
+                    self._fold_coll_events(keep=self._COLL_EVENTS_CAP // 2)
             else:
                 ev = comm.record_event() if comm is not None else None
         return out, ev

@@ -413,7 +413,7 @@ def test_no_size_limits_near_duplicate_of_a_large_frame(oracle_c):
 
 def test_failed_regrowth_of_the_p3p_workspace_leaves_the_context_usable(monkeypatch):
     """ctx_p3p_reserve allocates the larger set before it lets go of the old one: when an allocation fails (injected:
-    SFMLOC_TEST_FAIL_P3P_ALLOC = index of the allocation that fails) the query gets SFMLOC_ENOMEM, the context keeps its
+    sfmloc_debug_fail_p3p_alloc(index of the allocation that fails), one shot) the query gets SFMLOC_ENOMEM, the context keeps its
     arrays and capacity, an ordinary query on it gives its usual result, the large query succeeds once memory is there,
     and the map's memory account grows only then."""
     m = synth.make_map(72, n_views=5, desc_per_view=1500, views_per_place=5, landmarks_per_place=1800, obs_per_view=1400)
@@ -430,12 +430,11 @@ def test_failed_regrowth_of_the_p3p_workspace_leaves_the_context_usable(monkeypa
     assert ref[0].ok
     bytes_before = dm.info()["hbm_bytes"]
     for k in (0, 5, 11):
-        monkeypatch.setenv("SFMLOC_TEST_FAIL_P3P_ALLOC", str(k))
+        capi.debug_fail_p3p_alloc(k)
         with pytest.raises(S.SfmlocError) as ei:
             ctx.begin(dqb)
         assert ei.value.code == capi.ENOMEM, ei.value
         assert dm.info()["hbm_bytes"] == bytes_before
-        monkeypatch.delenv("SFMLOC_TEST_FAIL_P3P_ALLOC")
         ctx.begin(dqs)
         got = ctx.end()
         assert capi.result_fingerprint(*got) == capi.result_fingerprint(*ref)
