@@ -1344,6 +1344,7 @@ struct P3pShared {
 // ctx_resection_wait queues that query's rounds again in the full form.  The partition into rounds and the form of a
 // launch change nothing in the result.
 constexpr int kP3pSmallN = 512;
+constexpr int kP3pCoopN = 1024;  // the coop form (k_p3p_round_coop, one workgroup per model): four runs of at most 256
 
 // A round's results go from the workgroup that computed them to the one that replays the round, which may sit on
 // another XCD (another L2): they are written through (agent-scope stores), so that delivering them needs no L2
@@ -1605,6 +1606,117 @@ __device__ __forceinline__ void p3p_eval_regs(const double (&M)[12], NfaBest &r,
   if (r.k != 0x7FFFFFFF) r_err = u2d(sorted_key_at<E>(key, r.k - 1));
 }
 
+// entries of a sorted run of L keys (L a power of two) that come before x: those < x, or (le) those <= x
+template <int L>
+__device__ __forceinline__ int run_count_before(const uint64_t *run, uint64_t x, bool le) {
+  int lo = 0, hi = L;
+  constexpr int kSteps = (L == 64 ? 7 : L == 128 ? 8 : 9);  // L + 1 possible answers
+  static_assert(L == 64 || L == 128 || L == 256, "run length");
+#pragma unroll
+  for (int it = 0; it < kSteps; ++it) {
+    const int mid = (lo + hi) >> 1;
+    const uint64_t v = run[mid < L ? mid : L - 1];
+    const bool open = lo < hi;
+    const bool before = le ? (v <= x) : (v < x);
+    lo = (open && before) ? mid + 1 : lo;
+    hi = (open && !before) ? mid : hi;
+  }
+  return lo;
+}
+
+// One model evaluated by the WHOLE workgroup (four waves; a "single" launch: one workgroup per model): wave j computes and
+// sorts the residuals of elements 64 E j .. 64 E (j + 1) - 1 in its registers (wave_sort_fast, E <= 4 per lane), the four
+// sorted runs are merged by rank through LDS -- an element's final position is its position in its own run plus, per
+// other run, the number of that run's elements that come before it in the (key, index) order: runs of lower element
+// indices win ties, which is the order of the one-wave sort -- and every thread takes its share of the NFA scan.  Up to
+// 1 024 correspondences; the same residuals, order, candidates and first minimum as p3p_eval_regs, in a quarter of the
+// dependent chain: one wave with 16 elements per lane sorts 1 024 residuals in ~16 us, four with 4 each in ~4 + ~2 for the
+// merge.  `runs`: 256 E u64 of LDS, `fidx`: 256 E u32 (the sort's parking space, then the merged element indices).
+// Every thread of the workgroup calls it (barriers inside) and gets the result.
+template <int E>
+__device__ __forceinline__ void p3p_eval_coop4(const double (&M)[12], NfaBest &res, double &res_err,
+                                               const double *__restrict__ pt3d, const double *__restrict__ xn,
+                                               const float *__restrict__ logc_n, const float *__restrict__ logc_k, int n,
+                                               double logalpha0, double loge0, uint64_t *runs, uint32_t *fidx, double *red_nfa,
+                                               int *red_k) {
+  constexpr int L = 64 * E;
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int base = j * L;
+  uint64_t key[E];
+  uint32_t idx[E];
+  float cn[E], ck[E];
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) {  // (the table entries of the merged positions this lane scans: in flight meanwhile)
+    const int kk = base + (rr << 6) + lane + 1;
+    cn[rr] = kk <= n ? logc_n[kk] : 0.0f;
+    ck[rr] = kk <= n ? logc_k[kk] : 0.0f;
+  }
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) {
+    const int p = base + (rr << 6) + lane;
+    const int pc = p < n ? p : n - 1;
+    const double e = err_resection(M, pt3d[3 * pc], pt3d[3 * pc + 1], pt3d[3 * pc + 2], xn[2 * pc], xn[2 * pc + 1]);
+    key[rr] = p < n ? d2u(e) : ~0ull;
+    idx[rr] = 0u;
+  }
+  wave_sort_fast<E>(key, idx, fidx + base);
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) runs[base + (rr << 6) + lane] = key[rr];
+  __syncthreads();
+  int rank[E];
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) rank[rr] = (rr << 6) + lane;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (u == j) continue;  // (uniform over the wave)
+#pragma unroll
+    for (int rr = 0; rr < E; ++rr) rank[rr] += run_count_before<L>(runs + u * L, key[rr], u < j);
+  }
+  __syncthreads();  // every rank is known: the runs may be overwritten
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) {
+    runs[rank[rr]] = key[rr];
+    fidx[rank[rr]] = (uint32_t)base + idx[rr];
+  }
+  __syncthreads();
+  constexpr int s = 3;
+  double lb = pos_inf();
+  int lk = 0x7FFFFFFF;
+  double l10[E];
+  uint64_t mk[E];
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) mk[rr] = runs[base + (rr << 6) + lane];
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) l10[rr] = det_log10_inline(u2d(mk[rr]) + (double)FLT_EPSILON);
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) {
+    const int kk = base + (rr << 6) + lane + 1;
+    if (kk > s && kk <= n) {
+      const double logalpha = logalpha0 + 1.0 * l10[rr];
+      const double nfa = loge0 + logalpha * (double)(kk - s) + (double)cn[rr] + (double)ck[rr];
+      if (nfa < lb) {
+        lb = nfa;
+        lk = kk;
+      }
+    }
+  }
+  const NfaBest wr = wave_reduce_nfa(lb, lk);
+  if (lane == 0) {
+    red_nfa[j] = wr.nfa;
+    red_k[j] = wr.k;
+  }
+  __syncthreads();
+  NfaBest r{red_nfa[0], red_k[0]};
+#pragma unroll
+  for (int u = 1; u < 4; ++u)
+    if (red_nfa[u] < r.nfa || (red_nfa[u] == r.nfa && red_k[u] < r.k)) {
+      r.nfa = red_nfa[u];
+      r.k = red_k[u];
+    }
+  res = r;
+  res_err = r.k != 0x7FFFFFFF ? u2d(runs[r.k - 1]) : pos_inf();
+}
+
 // one hypothesis: sample, solve, evaluate the (up to 4) models, leave the best one's NFA / inliers / model in the
 // round's result arrays.  Executed by one workgroup of k_p3p_round -- or, in a WIDE launch (four workgroups per
 // hypothesis: model m of hypothesis b is workgroup m * batch + b) and from 513 correspondences on, by four, one model each: a model's residuals are
@@ -1613,12 +1725,12 @@ __device__ __forceinline__ void p3p_eval_regs(const double (&M)[12], NfaBest &r,
 // hypothesis's models wait for each other; with a workgroup per model it is 8 per thread, four times as many waves on the
 // compute unit, and the four models of a hypothesis side by side.  Results go to slot 4 b + m; the replay takes the
 // best model of each hypothesis (the first on ties, as the sequential loop over a hypothesis's models does).
-template <bool kSmall>
-__device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch, int wide, unsigned char *smem_raw) {
+template <int kForm>  // 0: the full form (k_p3p_round), 1: small (k_p3p_round_small), 2: one workgroup per model (k_p3p_round_coop)
+__device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch, int wide, unsigned char *smem_raw, int b,
+                                                    int mdl) {
+  constexpr bool kSmall = kForm == 1;
+  constexpr bool kCoop = kForm == 2;
   const P3pState &st = *A.state;
-  const int per_model = wide ? (int)(gridDim.x >> 2) : (int)gridDim.x;  // hypotheses of the launch
-  const int b = (int)blockIdx.x % per_model;
-  const int mdl = (int)blockIdx.x / per_model;
   const int n = st.n;
   if (b >= p3p_round_batch(n, batch) || b >= st.batch_limit) return;
   const long it = (long)st.iter + b;
@@ -1628,7 +1740,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   constexpr int s = 3;
   const int P = next_pow2(n);
   // one model per workgroup: a wide launch with enough correspondences (and the LDS forms: n <= kP3pMaxN)
-  const bool single = !kSmall && wide && P >= 1024 && n <= kP3pMaxN;
+  const bool single = !kSmall && wide && n <= kP3pMaxN;
   // (a wide launch that is not in single mode runs workgroups 0 .. batch - 1 only -- p3p_round.body.inc -- and is a plain
   // round: slot b, so that the inlier lists of a set above kP3pMaxN, whose stride is max_n, stay inside the 64 lists
   // ctx_p3p_reserve sizes them for)
@@ -1650,7 +1762,10 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   // (from 257 correspondences on: below that a model's register sort costs about what the filter does)
   // (the small form has no LDS for the tables: its models are sorted, which gives the same result)
   const bool filter = !kSmall && A.nfa_filter && nfa_to_beat < pos_inf() && n <= kP3pMaxN && P >= A.nfa_filter_min_p;
-  P3pFilterLds &F = *reinterpret_cast<P3pFilterLds *>(S.key);
+  // (the coop form's LDS ends behind the filter's tables: S.idx[0 .. 1024) holds the merged indices, the sorted runs /
+  // merged keys and -- before them, in the same bytes -- the tables start at S.idx + 1024)
+  uint64_t *const coop_runs = kCoop ? reinterpret_cast<uint64_t *>(S.idx + 1024) : S.key;
+  P3pFilterLds &F = *reinterpret_cast<P3pFilterLds *>(coop_runs);
   // "Prepared ahead" (p3p_prepare_ahead, below): the models of this hypothesis may be there already
   const bool have = st.prep_iter == st.iter && b < st.prep_n;
   if (filter) {
@@ -1720,7 +1835,32 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   double best = pos_inf();
   int best_k = 0, best_m = -1;
   double best_err = pos_inf();
-  if (fast) {
+  if (single && P <= 1024) {
+    // one model per workgroup, up to 1 024 correspondences: the four waves share the model (p3p_eval_coop4)
+    if ((pass_mask >> mdl) & 1) {  // (uniform over the workgroup)
+      double M[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) M[q] = S.models[12 * mdl + q];
+      NfaBest r{pos_inf(), 0x7FFFFFFF};
+      double r_err = pos_inf();
+      const double *pt3d = A.pt3d, *xn = A.xn;
+      const float *logc_n = A.logc_n, *logc_k = A.logc_k;
+      if (P <= 256) p3p_eval_coop4<1>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, coop_runs, S.idx, S.red_nfa, S.red_k);
+      else if (P == 512) p3p_eval_coop4<2>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, coop_runs, S.idx, S.red_nfa, S.red_k);
+      else p3p_eval_coop4<4>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, coop_runs, S.idx, S.red_nfa, S.red_k);
+      if (r.nfa < best) {
+        best = r.nfa;
+        best_k = r.k;
+        best_m = mdl;
+        best_err = r_err;
+        int32_t *dst = A.hyp_inl + (size_t)slot * inl_stride;
+        for (int p = tid; p < best_k; p += kThreads) store_through(dst + p, (int32_t)S.idx[p]);
+      }
+    }
+    STAMP_P3P(stamp_round, b, 4);
+  } else if constexpr (kCoop) {
+    // (not reached: the coop form is launched wide and leaves sets above 1 024 correspondences untouched)
+  } else if (fast) {
     // register path: a model is evaluated by ONE wave, residuals sorted in its registers; the (up to 4) models of the
     // hypothesis side by side, one wave each -- or (one model per workgroup) wave 0 takes the workgroup's model
     const int wv = tid >> 6, lane = tid & 63;
@@ -2226,27 +2366,544 @@ __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int
 struct P3pRoundBody {
   static constexpr int kGangThreads = kThreads;
   static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
-    constexpr bool kSmall = false;
+    constexpr int kForm = 0;
 #include "p3p_round.body.inc"
   }
 };
 __global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch, int wide) {
-  constexpr bool kSmall = false;
+  constexpr int kForm = 0;
+#include "p3p_round.body.inc"
+}
+// the coop form: a WIDE launch (four workgroups per hypothesis, one per model) for sets of at most kP3pCoopN
+// correspondences, every model evaluated by its workgroup's four waves together (p3p_eval_coop4).  The full form can do
+// the same, but it holds every other evaluation path too: 248 VGPRs and 50 KB of LDS, i.e. two workgroups per compute
+// unit -- a round of 4 x 256 workgroups then takes two passes over the chip.  This text has the coop path only: 128 VGPRs,
+// 30 KB.  The form of a query alone on the GPU (a quarter of the dependent chain per model) and of match sets of 513 ..
+// 1 024 correspondences.
+struct P3pRoundCoopBody {
+  static constexpr int kGangThreads = kThreads;
+  static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
+    constexpr int kForm = 2;
+#include "p3p_round.body.inc"
+  }
+};
+__global__ __launch_bounds__(kThreads, 4) void k_p3p_round_coop(P3pArgs A, int batch, int wide) {
+  constexpr int kForm = 2;
 #include "p3p_round.body.inc"
 }
 // the small form (above, at P3pShared): at most kP3pSmallN correspondences, a fraction of the registers
 struct P3pRoundSmallBody {
   static constexpr int kGangThreads = kThreads;
   static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
-    constexpr bool kSmall = true;
+    constexpr int kForm = 1;
 #include "p3p_round.body.inc"
   }
 };
 // (min. 4 waves per SIMD = at most 128 VGPRs: Kneip's solver spills -- one lane's chain, once per workgroup -- and the
 // round fits beside four workgroups of the lean shortlist scan, 4 x 96 VGPRs per SIMD, without evicting one)
 __global__ __launch_bounds__(kThreads, 4) void k_p3p_round_small(P3pArgs A, int batch, int wide) {
-  constexpr bool kSmall = true;
+  constexpr int kForm = 1;
 #include "p3p_round.body.inc"
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5, the SEQUENTIAL form (k_p3p_seq): the whole AC-RANSAC of a query in ONE workgroup and ONE launch -- the form a
+// query takes while the GPU is shared.
+//
+// The round form above buys latency with speculation: a round evaluates 64-256 hypotheses side by side and everything
+// behind the round's first index-changing iteration is thrown away -- 1 040 hypotheses evaluated for the 410 iterations a
+// headline query needs (tools/k5_policy_sim.py: no schedule gets below 850), in 9 launches of 64+ workgroups whose waves
+// mostly wait on their own dependent f64 chains while holding a quarter of a SIMD's registers each.  When other queries
+// fill the chip that speculation is pure cost.  Here NW waves (8 or 16) walk the iterations in order, `slots` models per
+// step (a model is evaluated by W = next_pow2(n) / 256 waves: one wave's register sort up to 256 correspondences, W sorted
+// runs of 256 merged through LDS beyond), the sequential rule of OpenMVG's ACRANSAC (restated in
+// oracle/sfm_oracle_geom.c acransac()) is applied model by model in LDS, and a change of the index set costs a barrier, not a
+// launch: at most slots - 1 models are evaluated for nothing per change.  Hypotheses are solved (Kneip) kSeqPool at a
+// time, four lanes per hypothesis -- all four run the common part, each then its root's model.  Nobody waits for another
+// workgroup; the loop advances by at least one iteration per step and n_iter is bounded, so every wave reaches the end.
+// Same arithmetic per model as the round form (err_resection, the (key, index) order, det_log10, the first minimum),
+// same rule: the result is the round form's bit for bit (tests/test_gpu_geom.py, fuzz_parity with SFMLOC_P3P_SEQ=2,
+// bench.py's identical_to_single_flight: timed queries take this form, the single-flight reference the round form).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSeqPool = 64;          // hypotheses solved per refill (4 lanes each: the first four waves)
+constexpr int kSeqRun = 256;          // correspondences one wave sorts (E = 4 registers per lane)
+constexpr int kSeqPtsLds = 1024;      // up to this many correspondences the points live in LDS for the whole launch
+struct P3pSeqLds {
+  uint32_t pool, nm, res, key, low, vec, best, pts, ftab, hist, total;
+};
+__host__ __device__ inline P3pSeqLds p3p_seq_lds(int nw, int cap) {
+  P3pSeqLds L;
+  uint32_t o = 0;
+  const uint32_t cpts = cap < kSeqPtsLds ? (uint32_t)cap : (uint32_t)kSeqPtsLds;
+  L.pool = o; o += kSeqPool * 48 * sizeof(double);
+  L.nm = o;   o += kSeqPool * sizeof(int);
+  L.res = o;  o += 1024;                                          // per-slot results, reductions, the best model
+  L.key = o;  o += cap > kSeqRun ? (uint32_t)nw * kSeqRun * sizeof(uint64_t) : 0u;  // sorted runs / merged keys (W > 1 only)
+  L.low = o;  o += (uint32_t)nw * kSeqRun * sizeof(uint32_t);    // wave_sort_fast's parking space, then sorted indices
+  L.vec = o;  o += (uint32_t)cap * sizeof(int32_t);              // the index set sampling draws from
+  L.best = o; o += (uint32_t)cap * sizeof(int32_t);              // inliers of the best model so far
+  L.pts = o;  o += cpts * 5 * sizeof(double);                    // X | Y | Z | x | y of the correspondences (n <= kSeqPtsLds)
+  L.ftab = o; o += (kP3pFilterBins + 8) * sizeof(double);        // the NFA filter's thresholds T'
+  // its counts, one table per model slot: in the merged keys' space when there is one (the filter runs before the merge)
+  if (cap > kSeqRun) {
+    L.hist = L.key;
+  } else {
+    L.hist = o; o += ((uint32_t)nw * (kSeqRun + 1) + 8) * sizeof(uint32_t);
+  }
+  L.total = o;
+  return L;
+}
+struct P3pSeqRes {
+  double nfa[16], err[16], red_nfa[16], best_model[12];
+  int k[16], red_k[16];
+};
+static_assert(sizeof(P3pSeqRes) <= 1024, "P3pSeqLds::res");
+
+// entries of a sorted run of kSeqRun keys that come before x: those < x, or (le) those <= x
+__device__ __forceinline__ int seq_run_count(const uint64_t *run, uint64_t x, bool le) {
+  int lo = 0, hi = kSeqRun;
+#pragma unroll
+  for (int it = 0; it < 9; ++it) {  // kSeqRun + 1 = 257 possible answers: nine halvings
+    const int mid = (lo + hi) >> 1;
+    const uint64_t v = run[mid < kSeqRun ? mid : kSeqRun - 1];
+    const bool open = lo < hi;
+    const bool before = le ? (v <= x) : (v < x);
+    lo = (open && before) ? mid + 1 : lo;
+    hi = (open && !before) ? mid : hi;
+  }
+  return lo;
+}
+
+// one hypothesis of the pool by four lanes: all four sample and run Kneip's common part (the same bits in each), lane
+// `root` then its root's model.  Out of line: the solver's registers (~150) are not the loop's.
+__device__ __noinline__ void seq_solve(const int32_t *vec_index, int n_index, uint64_t seed, uint32_t stream, uint32_t it,
+                                       const double *__restrict__ xn, const double *__restrict__ pt3d, int root,
+                                       double *models_h, int *nm_h) {
+  int32_t smp[3];
+  ac_sample<3>(vec_index, n_index, seed, STAGE_P3P, stream, it, smp);
+  double x[6], X[9];
+  for (int i = 0; i < 3; ++i) {
+    x[2 * i] = xn[2 * smp[i]];
+    x[2 * i + 1] = xn[2 * smp[i] + 1];
+    X[3 * i] = pt3d[3 * smp[i]];
+    X[3 * i + 1] = pt3d[3 * smp[i] + 1];
+    X[3 * i + 2] = pt3d[3 * smp[i] + 2];
+  }
+  P3pPrep prep;
+  const int nm = p3p_kneip_prepare(x, X, prep);
+  if (root < nm) {
+    double Mr[12];
+    p3p_kneip_model(prep, root, Mr);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) models_h[12 * root + q] = Mr[q];
+  }
+  if (root == 0) *nm_h = nm;
+}
+
+// The NFA filter's thresholds for the sequential form (the table of "The NFA filter" above, same formula and margin):
+// T'[j] for the bins j = 0 .. nb - 1, recomputed whenever the best NFA B has changed.  All NT threads; barriers inside.
+template <int NT>
+__device__ __forceinline__ void seq_filter_table(double *T, int n, int s, double B, double logalpha0, double loge0,
+                                                 const float *__restrict__ logc_n, const float *__restrict__ logc_k) {
+  const int sh = p3p_filter_shift(n), w = 1 << sh;
+  const int nb = (n >> sh) + 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int jb = tid; jb < nb; jb += NT) {
+    double m = 0.0;
+    for (int k = jb << sh; k < (jb << sh) + w; ++k)
+      if (k > s && k <= n) {
+        const double x = (B - loge0 - (double)logc_n[k] - (double)logc_k[k]) / (double)(k - s) - logalpha0 + 1e-7;
+        const double t = x > 300.0 ? pos_inf() : exp10(x);
+        m = t > m ? t : m;
+      }
+    T[jb] = m;
+  }
+  __syncthreads();
+  if (tid < 64) {  // running maximum, one wave: a contiguous run of bins per lane, then across the lanes
+    const int per = (nb + 63) >> 6;
+    double run = 0.0;
+    for (int i = 0; i < per; ++i) {
+      const int jb = lane * per + i;
+      const double x = jb < nb ? T[jb] : 0.0;
+      run = x > run ? x : run;
+    }
+    double inc = run;
+    for (int off = 1; off < 64; off <<= 1) {
+      const double o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc = o > inc ? o : inc;
+    }
+    double before = __shfl_up(inc, 1, 64);
+    if (lane == 0) before = 0.0;
+    run = before;
+    for (int i = 0; i < per; ++i) {
+      const int jb = lane * per + i;
+      if (jb < nb) {
+        const double x = T[jb];
+        run = x > run ? x : run;
+        T[jb] = run;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <int NW>
+__device__ __forceinline__ void p3p_seq_run(const P3pArgs &A, int cap) {
+  P3pState &st = *A.state;
+  if (st.done) return;
+  const int n = st.n;
+  const int P = next_pow2(n);
+  const int W = P <= kSeqRun ? 1 : P / kSeqRun;  // waves per model
+  // a set this launch is not built for: not its business (nothing is touched; the host queues the round form)
+  if (n > cap || W > NW) return;
+  extern __shared__ unsigned char smem_raw[];
+  const P3pSeqLds L = p3p_seq_lds(NW, cap);
+  double *const s_pool = reinterpret_cast<double *>(smem_raw + L.pool);
+  int *const s_nm = reinterpret_cast<int *>(smem_raw + L.nm);
+  P3pSeqRes &R = *reinterpret_cast<P3pSeqRes *>(smem_raw + L.res);
+  uint64_t *const s_key = reinterpret_cast<uint64_t *>(smem_raw + L.key);
+  uint32_t *const s_low = reinterpret_cast<uint32_t *>(smem_raw + L.low);
+  int32_t *const s_vec = reinterpret_cast<int32_t *>(smem_raw + L.vec);
+  int32_t *const s_best = reinterpret_cast<int32_t *>(smem_raw + L.best);
+  double *const s_pts = reinterpret_cast<double *>(smem_raw + L.pts);
+  double *const s_T = reinterpret_cast<double *>(smem_raw + L.ftab);
+  uint32_t *const s_hist = reinterpret_cast<uint32_t *>(smem_raw + L.hist);
+  constexpr int NT = NW * 64;
+  constexpr int E = kSeqRun / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int slots = NW / W;          // models evaluated per step
+  const int grp = wv / W, j = wv - grp * W;  // this wave's model slot and its rank among the slot's waves
+  const int base = j * kSeqRun;      // first element of this wave's run
+  constexpr int s = 3;
+  const double logalpha0 = det_log10(3.14159265358979323846);
+  const double loge0 = det_log10(4.0 * (double)(n - s));
+  const double *const pt3d = A.pt3d, *const xn = A.xn;
+  const float *const logc_n = A.logc_n, *const logc_k = A.logc_k;
+  const bool pts_lds = n <= kSeqPtsLds && n <= cap;
+  const int np = pts_lds ? n : 0;
+  // the state machine (every thread carries it; uniform)
+  long iter = st.iter, n_iter = st.n_iter, n_reserve = st.n_reserve;
+  double min_nfa = st.min_nfa, errmax = st.errmax;
+  int n_in = st.n_in, n_index = st.n_index, identity = st.identity;
+  int better = 0, steps = 0;
+  // (a state some rounds have already advanced: its index set and best model)
+  if (!identity)
+    for (int p = tid; p < n_index; p += NT) s_vec[p] = A.vec_index[p];
+  for (int p = tid; p < n_in; p += NT) s_best[p] = A.best_inl[p];
+  if (tid < 12) R.best_model[tid] = st.model[tid];
+  for (int p = tid; p < np; p += NT) {
+    s_pts[p] = pt3d[3 * p];
+    s_pts[np + p] = pt3d[3 * p + 1];
+    s_pts[2 * np + p] = pt3d[3 * p + 2];
+    s_pts[3 * np + p] = xn[2 * p];
+    s_pts[4 * np + p] = xn[2 * p + 1];
+  }
+  // the two table entries of the sorted positions this lane reads in the NFA scan (k = position + 1)
+  float cn[E], ck[E];
+#pragma unroll
+  for (int rr = 0; rr < E; ++rr) {
+    const int kk = base + (rr << 6) + lane + 1;
+    cn[rr] = kk <= n ? logc_n[kk] : 0.0f;
+    ck[rr] = kk <= n ? logc_k[kk] : 0.0f;
+  }
+  // the NFA filter (section above): from the first finite best NFA on, a model is sorted only if it can beat it
+  const int f_sh = p3p_filter_shift(n);
+  const int f_nb = (n >> f_sh) + 1;
+  int f_steps = 0;
+  while ((1 << f_steps) < f_nb + 1) ++f_steps;
+  uint32_t *const hist = s_hist + (size_t)grp * (W * kSeqRun + 1);
+  double table_for = pos_inf();  // the best NFA the table in s_T was built for (+inf: none)
+  long pool_it0 = 0;
+  int pool_n = 0, g0 = 0;
+#ifdef SFMLOC_SEQ_TIMING  // diagnostic build (make EXTRA=-DSFMLOC_SEQ_TIMING ...): where a launch's time goes, by thread 0's clock
+  unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq0 = wall_clock64(), tq1;
+  int n_refill = 0, n_pass = 0;
+#define SEQ_T(k) do { tq1 = wall_clock64(); tq[k] += tq1 - tq0; tq0 = tq1; } while (0)
+#else
+#define SEQ_T(k) do {} while (0)
+#endif
+  __syncthreads();
+  SEQ_T(0);
+  while (iter < n_iter) {
+    if (g0 >= 4 * pool_n) {
+      // ---- solve the next hypotheses: iterations iter .. iter + pool_n - 1 from the current index set
+      pool_it0 = iter;
+      pool_n = (int)((n_iter - iter) < (long)kSeqPool ? (n_iter - iter) : (long)kSeqPool);
+      g0 = 0;
+      if (tid < 4 * pool_n)
+        seq_solve(identity ? nullptr : s_vec, n_index, A.seed, A.stream, (uint32_t)(pool_it0 + (tid >> 2)), xn, pt3d, tid & 3,
+                  s_pool + 48 * (tid >> 2), s_nm + (tid >> 2));
+      __syncthreads();
+      SEQ_T(1);
+#ifdef SFMLOC_SEQ_TIMING
+      ++n_refill;
+#endif
+    }
+    const bool filter = A.nfa_filter && min_nfa < pos_inf();
+    if (filter && table_for != min_nfa) {
+      seq_filter_table<NT>(s_T, n, s, min_nfa, logalpha0, loge0, logc_n, logc_k);
+      table_for = min_nfa;
+    }
+    // ---- evaluate models g0 .. g0 + slots - 1 (model m of pool hypothesis h is g = 4 h + m), one per slot
+    const int g_mine = g0 + grp;
+    const int h_mine = g_mine >> 2, m_mine = g_mine & 3;
+    const bool active = h_mine < pool_n && pool_it0 + h_mine < n_iter && m_mine < s_nm[h_mine < pool_n ? h_mine : 0];
+    uint64_t key[E];
+    uint32_t idx[E];
+    {
+      double M[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) M[q] = s_pool[48 * (active ? h_mine : 0) + 12 * m_mine + q];
+#pragma unroll
+      for (int rr = 0; rr < E; ++rr) {
+        const int p = base + (rr << 6) + lane;
+        const int pc = p < n ? p : n - 1;
+        double X, Y, Z, x, y;
+        if (pts_lds) {
+          X = s_pts[pc], Y = s_pts[np + pc], Z = s_pts[2 * np + pc], x = s_pts[3 * np + pc], y = s_pts[4 * np + pc];
+        } else {
+          X = pt3d[3 * pc], Y = pt3d[3 * pc + 1], Z = pt3d[3 * pc + 2], x = xn[2 * pc], y = xn[2 * pc + 1];
+        }
+        const double e = err_resection(M, X, Y, Z, x, y);
+        key[rr] = (active && p < n) ? d2u(e) : ~0ull;
+        idx[rr] = 0u;
+      }
+    }
+    bool pass = active;
+    SEQ_T(2);
+    if (filter) {  // (uniform)
+      for (int jb = j * 64 + lane; jb < f_nb; jb += W * 64) hist[jb] = 0u;
+      __syncthreads();
+      if (active) {
+        int lo[E], hi[E];
+        double rv[E];
+#pragma unroll
+        for (int rr = 0; rr < E; ++rr) {
+          rv[rr] = u2d(key[rr]) + (double)FLT_EPSILON;
+          lo[rr] = 0;
+          hi[rr] = f_nb;
+        }
+        // first bin whose threshold exceeds the residual (f_nb: none); T' is non-decreasing
+        for (int it = 0; it < f_steps; ++it) {
+#pragma unroll
+          for (int rr = 0; rr < E; ++rr) {
+            const int mid = (lo[rr] + hi[rr]) >> 1;
+            const bool below = mid < f_nb && rv[rr] < s_T[mid < f_nb ? mid : f_nb - 1];
+            const bool open = lo[rr] < hi[rr];
+            hi[rr] = (open && below) ? mid : hi[rr];
+            lo[rr] = (open && !below) ? mid + 1 : lo[rr];
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < E; ++rr)
+          if (base + (rr << 6) + lane < n && lo[rr] < f_nb) atomicAdd(&hist[lo[rr]], 1u);
+      }
+      __syncthreads();
+      // running counts over the slot's table (every wave of the slot walks it and reaches the same verdict): the model
+      // can beat the best NFA only if some bin's running count reaches the bin's lowest k
+      const int per = (f_nb + 63) >> 6;
+      uint32_t sum = 0;
+      for (int i = 0; i < per; ++i) {
+        const int jb = lane * per + i;
+        sum += jb < f_nb ? hist[jb] : 0u;
+      }
+      uint32_t inc = sum;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+      }
+      uint32_t run = inc - sum;
+      bool any = false;
+      for (int i = 0; i < per; ++i) {
+        const int jb = lane * per + i;
+        if (jb < f_nb) {
+          run += hist[jb];
+          const int k_lo = (jb << f_sh) > s + 1 ? (jb << f_sh) : s + 1;  // lowest k of the bin that NFA ranges over
+          const int k_hi = (jb << f_sh) + (1 << f_sh) - 1;
+          if (k_hi > s && k_lo <= n && run >= (uint32_t)k_lo) any = true;
+        }
+      }
+      pass = active && __ballot(any) != 0ull;
+    }
+    SEQ_T(3);
+#ifdef SFMLOC_SEQ_TIMING
+    n_pass += pass ? 1 : 0;
+#endif
+    if (W == 1) {
+      NfaBest r{pos_inf(), 0x7FFFFFFF};
+      double r_err = pos_inf();
+      if (pass) {
+        uint32_t *iw = s_low + (size_t)wv * kSeqRun;
+        wave_sort_fast<E>(key, idx, iw);
+#pragma unroll
+        for (int rr = 0; rr < E; ++rr) iw[(rr << 6) + lane] = idx[rr];
+        r = best_nfa_regs_ilp<E>(key, n, s, pos_inf(), logalpha0, 1.0, loge0, cn, ck);
+        if (r.k != 0x7FFFFFFF) r_err = u2d(sorted_key_at<E>(key, r.k - 1));
+      }
+      if (lane == 0) {
+        R.nfa[grp] = r.nfa;
+        R.k[grp] = r.k;
+        R.err[grp] = r_err;
+      }
+    } else if (__syncthreads_or(pass ? 1 : 0)) {
+      // W waves, one model: wave j sorts elements 256 j .. 256 j + 255 in its registers, the W sorted runs are merged
+      // by rank -- an element's final position is its position in its own run plus, per other run, the number of that
+      // run's elements that come before it in the (key, index) order: runs of lower element indices win ties.  (Every
+      // slot walks through the barriers; a slot whose model failed the filter reports +inf at the end.)
+      wave_sort_fast<E>(key, idx, s_low + (size_t)wv * kSeqRun);
+      uint64_t *const runs = s_key + (size_t)grp * W * kSeqRun;  // the slot's W runs, then its merged keys
+      uint32_t *const fidx = s_low + (size_t)grp * W * kSeqRun;  // the slot's merged element indices
+#pragma unroll
+      for (int rr = 0; rr < E; ++rr) runs[base + (rr << 6) + lane] = key[rr];
+      __syncthreads();
+      int rank[E];
+#pragma unroll
+      for (int rr = 0; rr < E; ++rr) rank[rr] = (rr << 6) + lane;
+      for (int u = 0; u < W; ++u) {
+        if (u == j) continue;  // (uniform over the wave)
+#pragma unroll
+        for (int rr = 0; rr < E; ++rr) rank[rr] += seq_run_count(runs + u * kSeqRun, key[rr], u < j);
+      }
+      __syncthreads();  // every rank is known: the runs may be overwritten
+#pragma unroll
+      for (int rr = 0; rr < E; ++rr) {
+        runs[rank[rr]] = key[rr];
+        fidx[rank[rr]] = (uint32_t)base + idx[rr];
+      }
+      __syncthreads();
+      // bestNFA over the merged order: position pos holds e_(pos + 1); the same candidates and the same first minimum
+      // as best_nfa_regs_ilp
+      double lb = pos_inf();
+      int lk = 0x7FFFFFFF;
+      if (pass) {
+#pragma unroll
+        for (int rr = 0; rr < E; ++rr) {
+          const int kk = base + (rr << 6) + lane + 1;
+          if (kk > s && kk <= n) {
+            const double ek = u2d(runs[kk - 1]);
+            const double logalpha = logalpha0 + 1.0 * det_log10_inline(ek + (double)FLT_EPSILON);
+            const double nfa = loge0 + logalpha * (double)(kk - s) + (double)cn[rr] + (double)ck[rr];
+            if (nfa < lb) {
+              lb = nfa;
+              lk = kk;
+            }
+          }
+        }
+      }
+      const NfaBest wr = wave_reduce_nfa(lb, lk);
+      if (lane == 0) {
+        R.red_nfa[wv] = wr.nfa;
+        R.red_k[wv] = wr.k;
+      }
+      __syncthreads();
+      if (j == 0 && lane == 0) {
+        NfaBest r{pos_inf(), 0x7FFFFFFF};
+        for (int u = 0; u < W; ++u) {
+          const double o = R.red_nfa[wv + u];
+          const int ok = R.red_k[wv + u];
+          if (o < r.nfa || (o == r.nfa && ok < r.k)) {
+            r.nfa = o;
+            r.k = ok;
+          }
+        }
+        R.nfa[grp] = r.nfa;
+        R.k[grp] = r.k;
+        R.err[grp] = r.k != 0x7FFFFFFF ? u2d(runs[r.k - 1]) : pos_inf();
+      }
+    } else if (j == 0 && lane == 0) {
+      R.nfa[grp] = pos_inf();  // no slot's model can beat the best NFA
+    }
+    __syncthreads();
+    SEQ_T(4);
+    // ---- the sequential rule over this step's models, in order (acransac(): per model "is it better", per hypothesis
+    // -- behind its last model -- "does the index set change / does the budget end")
+    int best_slot = -1;
+    bool index_changed = false;
+    for (int sl = 0; sl < slots; ++sl) {
+      const int g = g0 + sl;
+      const int h = g >> 2, m = g & 3;
+      const long it = pool_it0 + h;
+      if (h >= pool_n || it >= n_iter) break;
+      if (m < s_nm[h]) {
+        const double nfa = R.nfa[sl];
+        if (nfa < min_nfa) {
+          better = 1;
+          min_nfa = nfa;
+          n_in = R.k[sl];
+          errmax = R.err[sl];
+          best_slot = sl;
+        }
+      }
+      if (m == 3) {
+        if ((better && min_nfa < 0.0) || (it + 1 == n_iter && n_reserve)) {
+          if (n_in == 0) {
+            n_iter++;
+            n_reserve--;
+          } else {
+            index_changed = true;
+            n_index = n_in;
+            identity = 0;
+            if (n_reserve) {
+              n_iter = it + 1 + n_reserve;
+              n_reserve = 0;
+            }
+          }
+        }
+        better = 0;
+        iter = it + 1;
+        if (index_changed) break;
+      }
+    }
+    if (best_slot >= 0) {
+      const uint32_t *src = s_low + (size_t)best_slot * W * kSeqRun;
+      for (int p = tid; p < n_in; p += NT) s_best[p] = (int32_t)src[p];
+      const int g = g0 + best_slot;
+      if (tid < 12) R.best_model[tid] = s_pool[48 * (g >> 2) + 12 * (g & 3) + tid];
+    }
+    __syncthreads();
+    if (index_changed) {
+      for (int p = tid; p < n_in; p += NT) s_vec[p] = s_best[p];
+      pool_n = 0;  // what was solved ahead sampled from the old index set
+      g0 = 0;
+      __syncthreads();
+    } else {
+      g0 += slots;
+    }
+    ++steps;
+    SEQ_T(5);
+  }
+#ifdef SFMLOC_SEQ_TIMING
+  if (tid == 0)
+    printf("seq NW=%d n=%d W=%d: %d steps, %d refills, wave0 passed %d | us: setup %.1f refill %.1f resid %.1f filter %.1f sort+nfa %.1f replay %.1f\n",
+           NW, n, W, steps, n_refill, n_pass, tq[0] * 0.01, tq[1] * 0.01, tq[2] * 0.01, tq[3] * 0.01, tq[4] * 0.01, tq[5] * 0.01);
+#endif
+  // ---- the state k_p3p_finish reads
+  for (int p = tid; p < n_in; p += NT) A.best_inl[p] = s_best[p];
+  if (tid == 0) {
+    st.iter = (int)iter;
+    st.n_iter = (int)n_iter;
+    st.n_reserve = (int)n_reserve;
+    st.min_nfa = min_nfa;
+    st.errmax = errmax;
+    st.n_in = n_in;
+    st.n_index = n_index;
+    st.identity = identity;
+    st.rounds += steps;
+    st.prep_n = 0;
+    for (int q = 0; q < 12; ++q) st.model[q] = R.best_model[q];
+    st.done = 1;
+  }
+}
+template <int NW>
+struct P3pSeqBody {
+  static constexpr int kGangThreads = NW * 64;
+  static __device__ __forceinline__ void run(P3pArgs A, int cap) { p3p_seq_run<NW>(A, cap); }
+};
+// (min. 4 waves per SIMD = at most 128 VGPRs, whatever NW: the workgroup takes NW / 4 wave slots and NW / 4 x 128 registers of
+// each SIMD and leaves the rest of the compute unit to the scans)
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k_p3p_seq(P3pArgs A, int cap) {
+  p3p_seq_run<NW>(A, cap);
 }
 
 // ACRANSAC's epilogue + SfM_Localizer::Localize + localization.cpp:511-547, once per query after the last round
@@ -2864,17 +3521,68 @@ int launch_p3p_round(Ctx *c, int batch) {
   // -- and only while queries of this map HAVE had that many lately (Map::p3p_wide_credit, refreshed by every finished
   // query that did): the idle workgroups of a wide launch cost a small query ~15 us and 3 % of the throughput, and the
   // host cannot know the match set's size when it queues the rounds.  Either launch shape gives the same bits.
-  const int wide = (c->p3p_query_n > 512 && c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) ? 1 : 0;
+  // (SFMLOC_P3P_WIDE_ALONE=1: also for any query alone on the GPU -- measured and not the default: with 4 x 256 workgroups
+  // the chip is NOT idle, four waves per SIMD share its f64 pipe and a headline round takes 47 us instead of 29,
+  // profiles/r04_k5_forms.txt)
+  static const int env_wide_alone = [] { const char *e = getenv("SFMLOC_P3P_WIDE_ALONE"); return e ? atoi(e) : 0; }();
+  const int wide = ((c->p3p_query_n > 512 && c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) ||
+                    (env_wide_alone == 2 || (env_wide_alone == 1 && c->k1_may_slice && !c->stream.gang))) ? 1 : 0;
   if (wide && batch > kP3pSlots / 4) batch = kP3pSlots / 4;
+  // (a wide launch sized for fewer hypotheses than the nominal batch, each workgroup taking several in turn, was tried:
+  // the empty workgroups of a 4 x 256 launch cost ~20-50 us per round on large sets, but the loop cost the small form's
+  // text 10 % of a headline round; not kept, profiles/r04_k5_forms.txt)
+  const int wide_groups = batch;
+  if (wide && c->p3p_coop) {
+    // (S.idx[0 .. 1024) + the larger of the runs and the filter's tables behind it)
+    constexpr size_t lds_coop = offsetof(P3pShared, idx) + 1024 * sizeof(uint32_t) +
+                                std::max(sizeof(P3pFilterLds), (size_t)kP3pCoopN * sizeof(uint64_t));
+    static_assert(lds_coop >= sizeof(P3pReplayShared), "the replay reuses the round's LDS");
+    static_assert(lds_coop <= 48 * 1024, "default dynamic LDS limit");
+    sfm_launch<P3pRoundCoopBody>(c, k_p3p_round_coop, dim3(4 * wide_groups), dim3(kThreads), (uint32_t)lds_coop, A, batch, 1);
+    SFM_HIP(hipGetLastError());
+    return SFMLOC_OK;
+  }
   // the small form (above, at P3pShared) when this query's rounds were queued on that prediction and nothing has refuted it
   if (!wide && c->p3p_small) {
     constexpr size_t lds_small = std::max(offsetof(P3pShared, idx) + 4 * kP3pSmallN * sizeof(uint32_t), sizeof(P3pReplayShared));
     sfm_launch<P3pRoundSmallBody>(c, k_p3p_round_small, dim3(batch), dim3(kThreads), (uint32_t)lds_small, A, batch, 0);
   } else {
-    sfm_launch<P3pRoundBody>(c, k_p3p_round, dim3(wide ? 4 * batch : batch), dim3(kThreads), (uint32_t)lds, A, batch, wide);
+    sfm_launch<P3pRoundBody>(c, k_p3p_round, dim3(wide ? 4 * wide_groups : batch), dim3(kThreads), (uint32_t)lds, A, batch, wide);
   }
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
+}
+
+// the sequential form (k_p3p_seq): one workgroup of `nw` waves takes the query's whole AC-RANSAC.  cap bounds the LDS
+// index lists: the query's feature count rounded up (a query has at most one correspondence per feature).
+int p3p_seq_waves() {
+  static const int v = [] {
+    const char *e = getenv("SFMLOC_P3P_SEQ_WAVES");
+    const int w = e ? atoi(e) : 8;
+    return w == 16 ? 16 : (w == 4 ? 4 : 8);
+  }();
+  return v;
+}
+template <int NW>
+static int launch_p3p_seq_nw(Ctx *c, const P3pArgs &A, int cap) {
+  const uint32_t lds = p3p_seq_lds(NW, cap).total;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_p3p_seq<NW>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)p3p_seq_lds(NW, kP3pMaxN).total);
+  SFM_HIP(attr);
+  sfm_launch<P3pSeqBody<NW>>(c, k_p3p_seq<NW>, dim3(1), dim3(NW * 64), lds, A, cap);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+int launch_p3p_seq(Ctx *c) {
+  P3pArgs A = make_p3p_args(c);
+  int cap = 256;
+  while (cap < (int)c->p3p_query_n && cap < kP3pMaxN) cap <<= 1;
+  switch (p3p_seq_waves()) {
+    case 16: return launch_p3p_seq_nw<16>(c, A, cap);
+    case 4: return launch_p3p_seq_nw<4>(c, A, cap);
+    default: return launch_p3p_seq_nw<8>(c, A, cap);
+  }
 }
 
 int launch_p3p_finish(Ctx *c) {

@@ -509,6 +509,21 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
     static const int env_small = [] { const char *e = getenv("SFMLOC_P3P_SMALL"); return e ? atoi(e) : 1; }();
     c->p3p_small = env_small == 2 || (env_small == 1 && (c->p3p_query_n <= 512 ||
                                                          c->map->p3p_small_credit.load(std::memory_order_relaxed) >= 8));
+    // the coop form of a wide round (one workgroup per model, at most 1 024 correspondences): the same kind of prediction
+    static const int env_coop = [] { const char *e = getenv("SFMLOC_P3P_COOP"); return e ? atoi(e) : 1; }();
+    c->p3p_coop = env_coop == 2 || (env_coop == 1 && (c->p3p_query_n <= 1024 ||
+                                                      c->map->p3p_coop_credit.load(std::memory_order_relaxed) >= 8));
+    // The sequential form (acransac.hip, k_p3p_seq: the whole AC-RANSAC as ONE launch of one workgroup, no speculative
+    // hypotheses, no rounds) -- built, bit-exact, measured and NOT the default: one workgroup walks a headline query's 410
+    // iterations in 2.2-2.5 ms where the rounds take 0.25 (profiles/r04_k5_sequential_form.txt).  SFMLOC_P3P_SEQ: 0 never
+    // (default), 1 while the GPU is shared, 2 always.
+    static const int env_seq = [] { const char *e = getenv("SFMLOC_P3P_SEQ"); return e ? atoi(e) : 0; }();
+    c->p3p_seq = env_seq == 2 || (env_seq == 1 && (!c->k1_may_slice || c->stream.gang != nullptr));
+    if (c->p3p_seq) {
+      rc = launch_p3p_seq(c);
+      if (rc == SFMLOC_OK) rc = launch_p3p_finish(c);
+      return rc;
+    }
   }
   // typically 6-8 rounds end the stage (one per improvement of the model); rounds enqueued past the end return at
   // once but still cost two launches each, so the first call queues 9 and ctx_resection_wait adds more if needed
@@ -625,10 +640,15 @@ int ctx_resection_wait(Ctx *c) {
       else if (c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) c->map->p3p_wide_credit.fetch_sub(1, std::memory_order_relaxed);
       if (h->state.n > 512) c->map->p3p_small_credit.store(0, std::memory_order_relaxed);
       else if (c->map->p3p_small_credit.load(std::memory_order_relaxed) < 64) c->map->p3p_small_credit.fetch_add(1, std::memory_order_relaxed);
+      if (h->state.n > 1024) c->map->p3p_coop_credit.store(0, std::memory_order_relaxed);
+      else if (c->map->p3p_coop_credit.load(std::memory_order_relaxed) < 64) c->map->p3p_coop_credit.fetch_add(1, std::memory_order_relaxed);
       return SFMLOC_OK;
     }
     // (the small rounds of a set that turned out larger than the form holds all returned at once: the full form now)
     if (c->p3p_small && h->state.n > 512) c->p3p_small = false;
+    if (c->p3p_coop && h->state.n > 1024) c->p3p_coop = false;
+    // (a set the sequential launch is not built for -- more correspondences than its waves hold -- came back untouched)
+    c->p3p_seq = false;
     int rc;
     {
       EventScope ev(c, SFMLOC_K_P3P);

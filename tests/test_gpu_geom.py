@@ -703,6 +703,26 @@ def test_small_p3p_rounds_prepared_hypotheses_and_the_fallback_to_the_full_form(
             assert want in r.stdout
 
 
+def test_sequential_p3p_form_equals_the_round_form():
+    """k_p3p_seq (acransac.hip): while the GPU is shared a query's whole P3P AC-RANSAC runs in ONE workgroup of 4 / 8 / 16
+    waves -- the iterations in order, a model per wave up to 256 correspondences, W sorted runs of 256 merged through LDS
+    beyond -- instead of rounds of speculative hypotheses.  Forced for every query (SFMLOC_P3P_SEQ = 2) in child
+    processes: the localisation campaign (small sets, radial intrinsics, guided matching, the shortlist chain) and the
+    large-set campaign (600 ... 5 000 correspondences: every W, and sets the launch does not hold -- more than 256 x
+    waves, or more than 4 096 -- which come back untouched and take the round form) give the oracle's result bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for waves in ("8", "16", "4"):
+        env = dict(os.environ, SFMLOC_P3P_SEQ="2", SFMLOC_P3P_SEQ_WAVES=waves)
+        for tool, args, want in (("fuzz_p3p_large.py", ["8", "96000"], "bit-exact"), ("fuzz_parity.py", ["12", "76000"], "every stage bit-exact")):
+            r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", tool)] + args, env=env,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (waves, tool, r.stdout[-2000:] + r.stderr[-2000:])
+            assert want in r.stdout
+
+
 def test_k3_waves_per_view_do_not_change_the_result():
     """k_fmatrix_fast<W>: 16 waves per view for a query alone on the GPU, 4 while the GPU is shared (a 16-wave workgroup
     is a compute unit's whole register file); 8 exists for comparison runs.  Same arithmetic, same replay: every stage
