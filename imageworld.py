@@ -122,7 +122,7 @@ def cameras(rng, n, tile_xy, tile_m, height=(9.0, 11.0), tilt=0.12, margin=4.5):
 
 def build(S, seed, n_real_views, n_queries, tiles=4, tile_px=1600, px_per_m=100.0, focal=800.0, width=640, height=480,
           device=0, torch_device=None, n_pad_views=0, pad_desc_per_view=2000, dense_bow=None, extract_batch=8,
-          atlas_kw=None, progress=None):
+          atlas_kw=None, progress=None, render_slab=256):
     """The world: atlas -> n_real_views rendered map views -> K9 extraction (S = the sfmlocalization_amd package) ->
     SynthMap (one landmark per keypoint), padded with `n_pad_views` views of random descriptors without landmarks;
     n_queries query frames from new cameras over random tiles.  dense_bow: an engine.DenseBow -- every real view's .bow
@@ -152,26 +152,28 @@ def build(S, seed, n_real_views, n_queries, tiles=4, tile_px=1600, px_per_m=100.
         Rs.append(R[0])
         Cs.append(C[0])
     Rs, Cs = np.stack(Rs), np.stack(Cs)
-    imgs = render(atlas, px_per_m, Rs, Cs, focal, width, height)
-    lap(f"rendered {n_real_views} map views")
     exs = [S.Akaze(width, height, device=device) for _ in range(extract_batch)]
     desc_l, kp_l, X_l, off, bow_l = [], [], [], [0], []
-    for i0 in range(0, n_real_views, extract_batch):
-        chunk = imgs[i0:i0 + extract_batch]
-        feats = S.Akaze.detect_and_compute_batch(exs[:len(chunk)], list(chunk)) if len(chunk) > 1 else \
-            [exs[0].detect_and_compute(chunk[0])]
-        for k, (kp, desc) in enumerate(feats):
-            v = i0 + k
-            desc_l.append(desc)
-            kp_l.append(kp[:, :2].copy())
-            X_l.append(synth.backproject_to_plane(kp[:, :2].astype(np.float64), Rs[v], Cs[v], focal, width, height))
-            off.append(off[-1] + len(desc))
-            if dense_bow is not None:
-                g = chunk[k]
-                bow_l.append(dense_bow.compute(np.stack([g, g, g], 2)).astype(np.float32))
+    # rendered and extracted a slab of views at a time: 10 000 VGA views are 3 GB of pixels nobody needs afterwards
+    for r0 in range(0, n_real_views, render_slab):
+        imgs = render(atlas, px_per_m, Rs[r0:r0 + render_slab], Cs[r0:r0 + render_slab], focal, width, height)
+        for i0 in range(0, len(imgs), extract_batch):
+            chunk = imgs[i0:i0 + extract_batch]
+            feats = S.Akaze.detect_and_compute_batch(exs[:len(chunk)], list(chunk)) if len(chunk) > 1 else \
+                [exs[0].detect_and_compute(chunk[0])]
+            for k, (kp, desc) in enumerate(feats):
+                v = r0 + i0 + k
+                desc_l.append(desc)
+                kp_l.append(kp[:, :2].copy())
+                X_l.append(synth.backproject_to_plane(kp[:, :2].astype(np.float64), Rs[v], Cs[v], focal, width, height))
+                off.append(off[-1] + len(desc))
+                if dense_bow is not None:
+                    g = chunk[k]
+                    bow_l.append(dense_bow.compute(np.stack([g, g, g], 2)).astype(np.float32))
+        del imgs
     for e in exs:
         e.close()
-    lap(f"extracted {off[-1]} descriptors from {n_real_views} views" + (" + their .bow vectors" if dense_bow is not None else ""))
+    lap(f"rendered {n_real_views} map views, extracted {off[-1]} descriptors" + (" + their .bow vectors" if dense_bow is not None else ""))
     n_real_rows = off[-1]
     from sfmlocalization_amd import capi
     kpt_real = capi.feat_round_trip(np.concatenate(kp_l).astype(np.float32))   # what the map's .feat files hold

@@ -1344,7 +1344,6 @@ struct P3pShared {
 // ctx_resection_wait queues that query's rounds again in the full form.  The partition into rounds and the form of a
 // launch change nothing in the result.
 constexpr int kP3pSmallN = 512;
-constexpr int kP3pCoopN = 1024;  // the coop form (k_p3p_round_coop, one workgroup per model): four runs of at most 256
 
 // A round's results go from the workgroup that computed them to the one that replays the round, which may sit on
 // another XCD (another L2): they are written through (agent-scope stores), so that delivering them needs no L2
@@ -1717,6 +1716,97 @@ __device__ __forceinline__ void p3p_eval_coop4(const double (&M)[12], NfaBest &r
   res_err = r.k != 0x7FFFFFFF ? u2d(runs[r.k - 1]) : pos_inf();
 }
 
+// The same for 1 025 .. 4 096 correspondences: NR = P / 1 024 runs of 256 per wave, sorted one after the other in the wave's
+// registers and parked in LDS; then every element's rank among the 4 NR runs by binary search (a run of lower element
+// indices wins ties), the scatter into the merged order, and the NFA scan, P / 256 positions per thread.  Replaces the
+// block-wide bitonic sort in LDS for one-workgroup-per-model launches: 66 (78) barrier-separated stages over 2 048
+// (4 096) elements, 110 us (250 us) per model, against ~25 us (~45 us) this way.  runs: P u64 of LDS, fidx: P u32.
+template <int NR>
+__device__ __forceinline__ void p3p_eval_coop4_multi(const double (&M)[12], NfaBest &res, double &res_err,
+                                                     const double *__restrict__ pt3d, const double *__restrict__ xn,
+                                                     const float *__restrict__ logc_n, const float *__restrict__ logc_k, int n,
+                                                     double logalpha0, double loge0, uint64_t *runs, uint32_t *fidx,
+                                                     double *red_nfa, int *red_k) {
+  constexpr int E = 4, L = 256, R = 4 * NR;
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  uint64_t key[NR][E];
+  uint32_t gidx[NR][E];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    const int base = (j * NR + q) * L;
+    uint32_t idx[E];
+#pragma unroll
+    for (int rr = 0; rr < E; ++rr) {
+      const int p = base + (rr << 6) + lane;
+      const int pc = p < n ? p : n - 1;
+      const double e = err_resection(M, pt3d[3 * pc], pt3d[3 * pc + 1], pt3d[3 * pc + 2], xn[2 * pc], xn[2 * pc + 1]);
+      key[q][rr] = p < n ? d2u(e) : ~0ull;
+      idx[rr] = 0u;
+    }
+    wave_sort_fast<E>(key[q], idx, fidx + base);
+#pragma unroll
+    for (int rr = 0; rr < E; ++rr) {
+      runs[base + (rr << 6) + lane] = key[q][rr];
+      gidx[q][rr] = (uint32_t)base + idx[rr];
+    }
+  }
+  __syncthreads();
+  int rank[NR][E];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int rr = 0; rr < E; ++rr) rank[q][rr] = (rr << 6) + lane;
+  for (int u = 0; u < R; ++u) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int mine = j * NR + q;
+      if (u == mine) continue;  // (uniform over the wave)
+#pragma unroll
+      for (int rr = 0; rr < E; ++rr) rank[q][rr] += run_count_before<L>(runs + u * L, key[q][rr], u < mine);
+    }
+  }
+  __syncthreads();  // every rank is known: the runs may be overwritten
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int rr = 0; rr < E; ++rr) {
+      runs[rank[q][rr]] = key[q][rr];
+      fidx[rank[q][rr]] = gidx[q][rr];
+    }
+  __syncthreads();
+  constexpr int s = 3;
+  double lb = pos_inf();
+  int lk = 0x7FFFFFFF;
+  // merged positions tid, tid + 256, ...: k = position + 1 (any split of the candidates gives the same first minimum)
+  for (int pos = threadIdx.x; pos < n; pos += kThreads) {
+    const int kk = pos + 1;
+    if (kk > s) {
+      const double ek = u2d(runs[pos]);
+      const double logalpha = logalpha0 + 1.0 * det_log10_inline(ek + (double)FLT_EPSILON);
+      const double nfa = loge0 + logalpha * (double)(kk - s) + (double)logc_n[kk] + (double)logc_k[kk];
+      if (nfa < lb || (nfa == lb && kk < lk)) {
+        lb = nfa;
+        lk = kk;
+      }
+    }
+  }
+  const NfaBest wr = wave_reduce_nfa(lb, lk);
+  if (lane == 0) {
+    red_nfa[j] = wr.nfa;
+    red_k[j] = wr.k;
+  }
+  __syncthreads();
+  NfaBest r{red_nfa[0], red_k[0]};
+#pragma unroll
+  for (int u = 1; u < 4; ++u)
+    if (red_nfa[u] < r.nfa || (red_nfa[u] == r.nfa && red_k[u] < r.k)) {
+      r.nfa = red_nfa[u];
+      r.k = red_k[u];
+    }
+  res = r;
+  res_err = r.k != 0x7FFFFFFF ? u2d(runs[r.k - 1]) : pos_inf();
+}
+
 // one hypothesis: sample, solve, evaluate the (up to 4) models, leave the best one's NFA / inliers / model in the
 // round's result arrays.  Executed by one workgroup of k_p3p_round -- or, in a WIDE launch (four workgroups per
 // hypothesis: model m of hypothesis b is workgroup m * batch + b) and from 513 correspondences on, by four, one model each: a model's residuals are
@@ -1725,11 +1815,10 @@ __device__ __forceinline__ void p3p_eval_coop4(const double (&M)[12], NfaBest &r
 // hypothesis's models wait for each other; with a workgroup per model it is 8 per thread, four times as many waves on the
 // compute unit, and the four models of a hypothesis side by side.  Results go to slot 4 b + m; the replay takes the
 // best model of each hypothesis (the first on ties, as the sequential loop over a hypothesis's models does).
-template <int kForm>  // 0: the full form (k_p3p_round), 1: small (k_p3p_round_small), 2: one workgroup per model (k_p3p_round_coop)
+template <int kForm>  // 0: the full form (k_p3p_round), 1: small (k_p3p_round_small)
 __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch, int wide, unsigned char *smem_raw, int b,
                                                     int mdl) {
   constexpr bool kSmall = kForm == 1;
-  constexpr bool kCoop = kForm == 2;
   const P3pState &st = *A.state;
   const int n = st.n;
   if (b >= p3p_round_batch(n, batch) || b >= st.batch_limit) return;
@@ -1753,7 +1842,10 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   // where the block-wide sort of this hypothesis runs
   uint64_t *const skey = n > kP3pMaxN ? A.ws_key + (size_t)b * A.max_n : S.key;
   uint32_t *const sidx = n > kP3pMaxN ? A.ws_idx + (size_t)b * A.max_n : S.idx;
-  const bool fast = kSmall || P <= kP3pWaveSeg;
+  // (register path of the full form: up to 256 correspondences, 4 per lane.  The 8- and 16-per-lane instantiations it used
+  // to hold for plain launches on 257 .. 1 024 correspondences made the kernel 248 VGPRs for every launch; such sets take
+  // the small form, a wide launch -- p3p_eval_coop4 -- or, in a plain launch of this form, the block-wide sort)
+  const bool fast = kSmall || P <= 256;
   constexpr int wave_seg = kSmall ? kP3pSmallN : kP3pWaveSeg;  // entries of S.idx a wave owns
   const double logalpha0 = det_log10(3.14159265358979323846);
   const double loge0 = det_log10(4.0 * (double)(n - s));
@@ -1762,10 +1854,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   // (from 257 correspondences on: below that a model's register sort costs about what the filter does)
   // (the small form has no LDS for the tables: its models are sorted, which gives the same result)
   const bool filter = !kSmall && A.nfa_filter && nfa_to_beat < pos_inf() && n <= kP3pMaxN && P >= A.nfa_filter_min_p;
-  // (the coop form's LDS ends behind the filter's tables: S.idx[0 .. 1024) holds the merged indices, the sorted runs /
-  // merged keys and -- before them, in the same bytes -- the tables start at S.idx + 1024)
-  uint64_t *const coop_runs = kCoop ? reinterpret_cast<uint64_t *>(S.idx + 1024) : S.key;
-  P3pFilterLds &F = *reinterpret_cast<P3pFilterLds *>(coop_runs);
+  P3pFilterLds &F = *reinterpret_cast<P3pFilterLds *>(S.key);
   // "Prepared ahead" (p3p_prepare_ahead, below): the models of this hypothesis may be there already
   const bool have = st.prep_iter == st.iter && b < st.prep_n;
   if (filter) {
@@ -1835,8 +1924,8 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   double best = pos_inf();
   int best_k = 0, best_m = -1;
   double best_err = pos_inf();
-  if (single && P <= 1024) {
-    // one model per workgroup, up to 1 024 correspondences: the four waves share the model (p3p_eval_coop4)
+  if (single) {
+    // one model per workgroup: the four waves share the model (p3p_eval_coop4 / _multi; every set the LDS forms hold)
     if ((pass_mask >> mdl) & 1) {  // (uniform over the workgroup)
       double M[12];
 #pragma unroll
@@ -1845,9 +1934,11 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
       double r_err = pos_inf();
       const double *pt3d = A.pt3d, *xn = A.xn;
       const float *logc_n = A.logc_n, *logc_k = A.logc_k;
-      if (P <= 256) p3p_eval_coop4<1>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, coop_runs, S.idx, S.red_nfa, S.red_k);
-      else if (P == 512) p3p_eval_coop4<2>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, coop_runs, S.idx, S.red_nfa, S.red_k);
-      else p3p_eval_coop4<4>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, coop_runs, S.idx, S.red_nfa, S.red_k);
+      if (P <= 256) p3p_eval_coop4<1>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, S.key, S.idx, S.red_nfa, S.red_k);
+      else if (P == 512) p3p_eval_coop4<2>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, S.key, S.idx, S.red_nfa, S.red_k);
+      else if (P == 1024) p3p_eval_coop4<4>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, S.key, S.idx, S.red_nfa, S.red_k);
+      else if (P == 2048) p3p_eval_coop4_multi<2>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, S.key, S.idx, S.red_nfa, S.red_k);
+      else p3p_eval_coop4_multi<4>(M, r, r_err, pt3d, xn, logc_n, logc_k, n, logalpha0, loge0, S.key, S.idx, S.red_nfa, S.red_k);
       if (r.nfa < best) {
         best = r.nfa;
         best_k = r.k;
@@ -1858,8 +1949,6 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
       }
     }
     STAMP_P3P(stamp_round, b, 4);
-  } else if constexpr (kCoop) {
-    // (not reached: the coop form is launched wide and leaves sets above 1 024 correspondences untouched)
   } else if (fast) {
     // register path: a model is evaluated by ONE wave, residuals sorted in its registers; the (up to 4) models of the
     // hypothesis side by side, one wave each -- or (one model per workgroup) wave 0 takes the workgroup's model
@@ -1919,9 +2008,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
         switch (P >> 6) {
           case 1: run(std::integral_constant<int, 1>{}); break;
           case 2: run(std::integral_constant<int, 2>{}); break;
-          case 4: run(std::integral_constant<int, 4>{}); break;
-          case 8: run(std::integral_constant<int, 8>{}); break;
-          default: run(std::integral_constant<int, 16>{}); break;
+          default: run(std::integral_constant<int, 4>{}); break;
         }
       }
     }
@@ -2365,35 +2452,20 @@ __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int
 // once (st.done is written by the previous launch's last workgroup, i.e. before this launch starts).
 struct P3pRoundBody {
   static constexpr int kGangThreads = kThreads;
+  static constexpr int kGangMinWaves = 4;  // (128 VGPRs, as k_p3p_round)
   static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
     constexpr int kForm = 0;
 #include "p3p_round.body.inc"
   }
 };
-__global__ __launch_bounds__(kThreads) void k_p3p_round(P3pArgs A, int batch, int wide) {
+__global__ __launch_bounds__(kThreads, 4) void k_p3p_round(P3pArgs A, int batch, int wide) {
   constexpr int kForm = 0;
-#include "p3p_round.body.inc"
-}
-// the coop form: a WIDE launch (four workgroups per hypothesis, one per model) for sets of at most kP3pCoopN
-// correspondences, every model evaluated by its workgroup's four waves together (p3p_eval_coop4).  The full form can do
-// the same, but it holds every other evaluation path too: 248 VGPRs and 50 KB of LDS, i.e. two workgroups per compute
-// unit -- a round of 4 x 256 workgroups then takes two passes over the chip.  This text has the coop path only: 128 VGPRs,
-// 30 KB.  The form of a query alone on the GPU (a quarter of the dependent chain per model) and of match sets of 513 ..
-// 1 024 correspondences.
-struct P3pRoundCoopBody {
-  static constexpr int kGangThreads = kThreads;
-  static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
-    constexpr int kForm = 2;
-#include "p3p_round.body.inc"
-  }
-};
-__global__ __launch_bounds__(kThreads, 4) void k_p3p_round_coop(P3pArgs A, int batch, int wide) {
-  constexpr int kForm = 2;
 #include "p3p_round.body.inc"
 }
 // the small form (above, at P3pShared): at most kP3pSmallN correspondences, a fraction of the registers
 struct P3pRoundSmallBody {
   static constexpr int kGangThreads = kThreads;
+  static constexpr int kGangMinWaves = 4;
   static __device__ __forceinline__ void run(P3pArgs A, int batch, int wide) {
     constexpr int kForm = 1;
 #include "p3p_round.body.inc"
@@ -3162,6 +3234,7 @@ static int ensure_fmatrix_large(Ctx *c) {
   SFM_HIP(hipMalloc((void **)&c->fl_logc_n, n1 * sizeof(float)));
   SFM_HIP(hipMalloc((void **)&c->fl_logc_k, n1 * sizeof(float)));
   SFM_HIP(hipMalloc((void **)&c->fl_count, sizeof(uint32_t)));
+  SFM_HIP(hipMemset(c->fl_count, 0, sizeof(uint32_t)));  // (from the next query on the query's reset kernel clears it)
   SFM_HIP(hipMalloc((void **)&c->fl_list, ((size_t)m->n_views + 1) * sizeof(uint32_t)));
   c->hbm_bytes += n * 20 + n1 * 8 + ((size_t)m->n_views + 2) * 4;
   return SFMLOC_OK;
@@ -3196,9 +3269,13 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
   A.large_count = nullptr;
   A.large_list = nullptr;
   if (m->max_view_rows > (uint32_t)kFMaxM) {
+    const bool fresh = c->fl_key == nullptr;
     int rc = ensure_fmatrix_large(c);
     if (rc) return rc;
-    SFM_HIP(hipMemsetAsync(c->fl_count, 0, sizeof(uint32_t), c->stream));
+    // (a memset on the context's stream would end a gang session's recording: every real map has views above 2 048 rows,
+    // and with this line a session of image-in frames issued 93 launches, none of them shared -- the query's reset
+    // kernel clears the counter; only the staged API, which has no reset kernel, clears it here)
+    if (!c->cleared && !fresh) SFM_HIP(hipMemsetAsync(c->fl_count, 0, sizeof(uint32_t), c->stream));
     A.large_count = c->fl_count;
     A.large_list = c->fl_list;
   }
@@ -3532,16 +3609,6 @@ int launch_p3p_round(Ctx *c, int batch) {
   // the empty workgroups of a 4 x 256 launch cost ~20-50 us per round on large sets, but the loop cost the small form's
   // text 10 % of a headline round; not kept, profiles/r04_k5_forms.txt)
   const int wide_groups = batch;
-  if (wide && c->p3p_coop) {
-    // (S.idx[0 .. 1024) + the larger of the runs and the filter's tables behind it)
-    constexpr size_t lds_coop = offsetof(P3pShared, idx) + 1024 * sizeof(uint32_t) +
-                                std::max(sizeof(P3pFilterLds), (size_t)kP3pCoopN * sizeof(uint64_t));
-    static_assert(lds_coop >= sizeof(P3pReplayShared), "the replay reuses the round's LDS");
-    static_assert(lds_coop <= 48 * 1024, "default dynamic LDS limit");
-    sfm_launch<P3pRoundCoopBody>(c, k_p3p_round_coop, dim3(4 * wide_groups), dim3(kThreads), (uint32_t)lds_coop, A, batch, 1);
-    SFM_HIP(hipGetLastError());
-    return SFMLOC_OK;
-  }
   // the small form (above, at P3pShared) when this query's rounds were queued on that prediction and nothing has refuted it
   if (!wide && c->p3p_small) {
     constexpr size_t lds_small = std::max(offsetof(P3pShared, idx) + 4 * kP3pSmallN * sizeof(uint32_t), sizeof(P3pReplayShared));

@@ -309,6 +309,7 @@ QueryResetArgs make_reset_args(Ctx *c, const Query *q) {
   R.cand_header = reinterpret_cast<uint32_t *>(c->d_cand_part);
   R.view_stats = c->d_view_stats;
   R.ms_n = c->d_ms_n;
+  R.fl_count = c->fl_count;
   return R;
 }
 
@@ -509,10 +510,6 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
     static const int env_small = [] { const char *e = getenv("SFMLOC_P3P_SMALL"); return e ? atoi(e) : 1; }();
     c->p3p_small = env_small == 2 || (env_small == 1 && (c->p3p_query_n <= 512 ||
                                                          c->map->p3p_small_credit.load(std::memory_order_relaxed) >= 8));
-    // the coop form of a wide round (one workgroup per model, at most 1 024 correspondences): the same kind of prediction
-    static const int env_coop = [] { const char *e = getenv("SFMLOC_P3P_COOP"); return e ? atoi(e) : 1; }();
-    c->p3p_coop = env_coop == 2 || (env_coop == 1 && (c->p3p_query_n <= 1024 ||
-                                                      c->map->p3p_coop_credit.load(std::memory_order_relaxed) >= 8));
     // The sequential form (acransac.hip, k_p3p_seq: the whole AC-RANSAC as ONE launch of one workgroup, no speculative
     // hypotheses, no rounds) -- built, bit-exact, measured and NOT the default: one workgroup walks a headline query's 410
     // iterations in 2.2-2.5 ms where the rounds take 0.25 (profiles/r04_k5_sequential_form.txt).  SFMLOC_P3P_SEQ: 0 never
@@ -640,13 +637,10 @@ int ctx_resection_wait(Ctx *c) {
       else if (c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) c->map->p3p_wide_credit.fetch_sub(1, std::memory_order_relaxed);
       if (h->state.n > 512) c->map->p3p_small_credit.store(0, std::memory_order_relaxed);
       else if (c->map->p3p_small_credit.load(std::memory_order_relaxed) < 64) c->map->p3p_small_credit.fetch_add(1, std::memory_order_relaxed);
-      if (h->state.n > 1024) c->map->p3p_coop_credit.store(0, std::memory_order_relaxed);
-      else if (c->map->p3p_coop_credit.load(std::memory_order_relaxed) < 64) c->map->p3p_coop_credit.fetch_add(1, std::memory_order_relaxed);
       return SFMLOC_OK;
     }
     // (the small rounds of a set that turned out larger than the form holds all returned at once: the full form now)
     if (c->p3p_small && h->state.n > 512) c->p3p_small = false;
-    if (c->p3p_coop && h->state.n > 1024) c->p3p_coop = false;
     // (a set the sequential launch is not built for -- more correspondences than its waves hold -- came back untouched)
     c->p3p_seq = false;
     int rc;

@@ -20,6 +20,7 @@ struct QueryResetArgs {
   uint32_t *n_flagged;
   int *status;
   uint32_t *cand_header, *view_stats, *ms_n;
+  uint32_t *fl_count;  // K3's list of views for k_fmatrix_large (maps with views above 2 048 rows), or null
 };
 __device__ __forceinline__ void query_reset_items(const QueryResetArgs &R, uint32_t first, uint32_t stride) {
   const uint32_t n = (R.n_views + 1 > R.nq) ? R.n_views + 1 : R.nq;
@@ -32,6 +33,7 @@ __device__ __forceinline__ void query_reset_items(const QueryResetArgs &R, uint3
     if (t == 0) {
       *R.n_flagged = 0;
       *R.status = 0;
+      if (R.fl_count) *R.fl_count = 0;
       R.cand_header[0] = R.cand_header[1] = R.cand_header[2] = R.cand_header[3] = 0;  // kPartHeaderBytes = 16
       R.view_stats[0] = R.view_stats[1] = R.view_stats[2] = 0;
       *R.ms_n = 0;

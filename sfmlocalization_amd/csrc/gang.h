@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <atomic>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -59,9 +60,19 @@ __device__ __forceinline__ void gang_call(const Tup<Ts...> &t, std::index_sequen
   Body::run(tup_get<Is>(t)...);
 }
 
-// Body: struct { static constexpr int kGangThreads; __device__ static void run(Ts...); } -- the kernel's body
+// Body: struct { static constexpr int kGangThreads; __device__ static void run(Ts...); } -- the kernel's body; optionally
+// static constexpr int kGangMinWaves: waves per SIMD the gang form must leave room for (the second launch bound of the
+// kernel the body belongs to, so that a session's launch occupies the registers the single launch does)
+template <class Body, class = void>
+struct GangMinWaves {
+  static constexpr int value = 1;
+};
+template <class Body>
+struct GangMinWaves<Body, std::void_t<decltype(Body::kGangMinWaves)>> {
+  static constexpr int value = Body::kGangMinWaves;
+};
 template <class Body, int Cap, class... Ts>
-__global__ __launch_bounds__(Body::kGangThreads) void k_gang(GangArgs<Cap, Ts...> g) {
+__global__ __launch_bounds__(Body::kGangThreads, GangMinWaves<Body>::value) void k_gang(GangArgs<Cap, Ts...> g) {
   gang_call<Body, Ts...>(g.a[blockIdx.z], std::index_sequence_for<Ts...>{});
 }
 

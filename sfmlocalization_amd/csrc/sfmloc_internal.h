@@ -142,7 +142,6 @@ struct Map {
   // finished queries in a row whose 2D-3D set had at most 512 correspondences (acransac.hip kP3pSmallN): from 8 on a
   // query's P3P rounds are queued in the small form (ctx_resection_enqueue)
   std::atomic<int> p3p_small_credit{0};
-  std::atomic<int> p3p_coop_credit{0};  // the same for sets of at most 1 024 (the coop form of a wide round)
   uint32_t n_views = 0;
   uint32_t n_landmarks = 0;
   std::vector<uint32_t> h_view_id, h_view_off, h_view_wh;
@@ -246,7 +245,6 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   uint32_t p3p_cap = kP3pMaxN;
   uint64_t p3p_bytes = 0;  // bytes of the regrowable P3P arrays currently held (part of hbm_bytes)
   bool p3p_small = false;  // this query's P3P rounds go out in the small form (decided when the first ones are queued)
-  bool p3p_coop = false;   // this query's wide rounds go out in the coop form (at most 1 024 correspondences; acransac.hip)
   bool p3p_seq = false;    // this query's AC-RANSAC went out in the sequential form (one launch; acransac.hip k_p3p_seq)
   uint32_t p3p_query_n = 0;  // features of the query K5 is about to run for (ctx_p3p_reserve): launch shape of the rounds
   uint32_t *d_pair_qfeat_big = nullptr, *d_pair_landmark_big = nullptr;
