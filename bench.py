@@ -482,8 +482,10 @@ def image_in_phase(a, S, local_rank, log, hd=False):
                     ib.order_before(c)
         else:           # resident: features and BoW vector stay on the device, the query is a view over them
             if a.image_bow_own_stream:   # queued first, on its own stream: runs beside the extraction below
-                for i, ib in zip(idx, ibs):
-                    ib.compute(frames[i % nf], None, want_vector=False)
+                if n > 1:                # one gang session for the turn's frames: one launch per kernel of the chain
+                    S.ImgBow.compute_batch(ibs[:n], [frames[i % nf] for i in idx])
+                else:
+                    ibs[0].compute(frames[idx[0] % nf], None, want_vector=False)
             ns = S.Akaze.detect_resident_batch(es[:n], [frames[i % nf] for i in idx])
             fe = [(None, range(c)) for c in ns]
             t1 = time.perf_counter()

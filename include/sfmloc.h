@@ -552,6 +552,12 @@ void sfmloc_imgbow_destroy(sfmloc_imgbow *ib);
 int sfmloc_imgbow_dim(const sfmloc_imgbow *ib);
 int sfmloc_imgbow_share_stream(sfmloc_imgbow *ib, sfmloc_context *ctx); /* NULL: back on its own stream */
 int sfmloc_imgbow_compute(sfmloc_imgbow *ib, const uint8_t *image, sfmloc_query *query, double *out_bow);
+/* The vectors of n frames (1..32) in ONE gang session on the first extractor's stream: one launch per kernel for all of
+ * them; the float32 vectors stay on the device (sfmloc_imgbow_vector_dev of each extractor).  The reference computes the
+ * vector per query image (localization.cpp:346-361, LocalizeEngine.cc:205-232); same bits as n single calls. */
+int sfmloc_imgbow_compute_batch(sfmloc_imgbow *const *ibs, const uint8_t *const *images, uint32_t n);
+/* the reference's float64 vector of the extractor's last call (single or batch), after waiting for it */
+int sfmloc_imgbow_vector_read(sfmloc_imgbow *ib, double *out_bow);
 /* where the float32 vector of a call WITHOUT a query lands (device memory, [sfmloc_imgbow_dim] floats): the bow_dev of a
  * query view (sfmloc_query_create_view) over an extractor's resident outputs */
 const void *sfmloc_imgbow_vector_dev(const sfmloc_imgbow *ib);

@@ -121,7 +121,7 @@ SYMBOLS = [
     "sfmloc_geometric_read_pairs", "sfmloc_shard_begin_bow", "sfmloc_packed_bytes", "sfmloc_shard_export_packed", "sfmloc_merge_begin_packed",
     "sfmloc_gang_begin", "sfmloc_gang_end", "sfmloc_gang_counters", "sfmloc_context_create_sharing", "sfmloc_context_create_merge",
     "sfmloc_query_create_view", "sfmloc_feat_round_trip",
-    "sfmloc_imgbow_create", "sfmloc_imgbow_destroy", "sfmloc_imgbow_dim", "sfmloc_imgbow_share_stream", "sfmloc_imgbow_compute",
+    "sfmloc_imgbow_create", "sfmloc_imgbow_destroy", "sfmloc_imgbow_dim", "sfmloc_imgbow_share_stream", "sfmloc_imgbow_compute", "sfmloc_imgbow_compute_batch", "sfmloc_imgbow_vector_read",
     "sfmloc_shard_batch_bow_keys", "sfmloc_shard_batch_begin_bow", "sfmloc_shard_batch_begin", "sfmloc_merge_batch_begin",
     "sfmloc_imgbow_vector_dev", "sfmloc_imgbow_order_before", "sfmloc_akaze_detect_resident", "sfmloc_akaze_detect_resident_batch", "sfmloc_akaze_resident_arrays",
 ]
@@ -314,6 +314,8 @@ def _L():
         L.sfmloc_imgbow_dim.argtypes = [C.c_void_p]
         L.sfmloc_imgbow_share_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_imgbow_compute.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_void_p, F64P]
+        L.sfmloc_imgbow_compute_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint32]
+        L.sfmloc_imgbow_vector_read.argtypes = [C.c_void_p, F64P]
         VPP = C.POINTER(C.c_void_p)
         L.sfmloc_shard_batch_bow_keys.argtypes = [VPP, C.c_uint32, C.c_uint32, VPP, C.c_uint32, C.c_uint32, C.c_void_p]
         L.sfmloc_shard_batch_begin_bow.argtypes = [VPP, C.c_uint32, C.c_uint32, VPP, C.c_uint32, C.c_void_p, C.c_uint32,
@@ -937,6 +939,26 @@ class ImgBow:
         _check(_L().sfmloc_imgbow_compute(self._h, _ptr(img, C.c_uint8), None if query is None else query._h,
                                           _ptr(out, C.c_double)))
         return out
+
+    def vector_read(self):
+        """the float64 vector of the last compute() / compute_batch() this extractor took part in (synchronises)"""
+        out = np.zeros(self.dim, np.float64)
+        _check(_L().sfmloc_imgbow_vector_read(self._h, _ptr(out, C.c_double)))
+        return out
+
+    @staticmethod
+    def compute_batch(extractors, images):
+        """sfmloc_imgbow_compute_batch: the vectors of len(images) frames (one extractor each, same image size) in one gang
+        session on the first extractor's stream -- one launch per kernel for all of them.  The float32 vectors stay on the
+        device (vector_dev of each extractor); asynchronous."""
+        n = len(images)
+        assert 1 <= n <= len(extractors) and n <= GANG_MAX
+        imgs = [np.ascontiguousarray(g, np.uint8) for g in images]
+        for e, g in zip(extractors, imgs):
+            assert g.size == e.width * e.height * e.channels, g.shape
+        hs = (C.c_void_p * n)(*[e._h for e in extractors[:n]])
+        ps = (C.c_void_p * n)(*[g.ctypes.data for g in imgs])
+        _check(_L().sfmloc_imgbow_compute_batch(hs, ps, n))
 
     def close(self):
         if self._h is not None:

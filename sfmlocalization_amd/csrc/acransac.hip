@@ -3605,6 +3605,11 @@ int launch_p3p_round(Ctx *c, int batch) {
   const int wide = ((c->p3p_query_n > 512 && c->map->p3p_wide_credit.load(std::memory_order_relaxed) > 0) ||
                     (env_wide_alone == 2 || (env_wide_alone == 1 && c->k1_may_slice && !c->stream.gang))) ? 1 : 0;
   if (wide && batch > kP3pSlots / 4) batch = kP3pSlots / 4;
+  // (wide rounds are nominally 128 hypotheses, not 256: on large sets most rounds evaluate 16 .. 64 -- p3p_next_batch_limit --
+  // and every workgroup of the 4 x batch launched has to be dispatched with its LDS and registers even to find that it has
+  // nothing to do: image-in frames 0.86 -> 0.71 ms of PnP alone, 1 229 -> 1 302 images/s, profiles/r04_k5_forms.txt)
+  static const int env_wide_batch = [] { const char *e = getenv("SFMLOC_P3P_WIDE_BATCH"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 256 ? v : 128; }();
+  if (wide && batch > env_wide_batch) batch = env_wide_batch;
   // (a wide launch sized for fewer hypotheses than the nominal batch, each workgroup taking several in turn, was tried:
   // the empty workgroups of a 4 x 256 launch cost ~20-50 us per round on large sets, but the loop cost the small form's
   // text 10 % of a headline round; not kept, profiles/r04_k5_forms.txt)

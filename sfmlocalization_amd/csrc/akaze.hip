@@ -2204,7 +2204,7 @@ uint8_t *akaze_desc_dev(Akaze *a) { return a->d_desc; }
 // The extractor's stream for work queued NOW: its own is created at the first call that needs one.  An extractor that
 // has worked in gang sessions before (on the leader's stream) must not overtake that work on its new stream.
 static int akaze_ensure_stream(Akaze *a) {
-  if (a->stream.own) return SFMLOC_OK;
+  if (a->stream.own || a->stream.gang) return SFMLOC_OK;  // (recording for a session: the leader's stream carries it)
   if (!a->own_stream) {
     SFM_HIP(hipSetDevice(a->device));
     SFM_HIP(hipStreamCreateWithFlags(&a->own_stream, hipStreamNonBlocking));
@@ -2213,6 +2213,7 @@ static int akaze_ensure_stream(Akaze *a) {
   a->stream.own = a->own_stream;
   return SFMLOC_OK;
 }
+GangMember *akaze_member(Akaze *a) { return a; }
 hipStream_t akaze_stream_now(Akaze *a) {
   (void)akaze_ensure_stream(a);
   return a->stream;

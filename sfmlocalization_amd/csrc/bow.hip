@@ -337,7 +337,9 @@ struct BofTileLds {   // sized by the launcher: floats
            (size_t)kBofTile * cdim + (size_t)K * cen_stride(cdim) + (size_t)kBofTile * dist_stride(K);
   }
 };
-__global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restrict__ desc, const float *__restrict__ kxy,
+struct BofAssignTiledBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const float *__restrict__ desc, const float *__restrict__ kxy,
                                                           int n, int in_dim, const float *__restrict__ pca_mean,
                                                           const float *__restrict__ pca_evec,
                                                           const float *__restrict__ pca_eval, int n_pca,
@@ -431,6 +433,16 @@ __global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restric
     }
   }
 }
+};
+__global__ __launch_bounds__(256) void k_bof_assign_tiled(const float *__restrict__ desc, const float *__restrict__ kxy,
+                                                          int n, int in_dim, const float *__restrict__ pca_mean,
+                                                          const float *__restrict__ pca_evec,
+                                                          const float *__restrict__ pca_eval, int n_pca,
+                                                          const float *__restrict__ centers, int K, int resized,
+                                                          int levels, uint32_t *__restrict__ counts,
+                                                          const uint8_t *__restrict__ desc8) {
+  BofAssignTiledBody::run(desc, kxy, n, in_dim, pca_mean, pca_evec, pca_eval, n_pca, centers, K, resized, levels, counts, desc8);
+}
 
 // one thread per pyramid cell: counts -> /n -> per-cell normalisation, sequential in the reference's order
 // one thread per cell (any K; the form below needs K doubles of LDS)
@@ -459,7 +471,9 @@ __global__ void k_bof_finish_serial(const uint32_t *__restrict__ counts, int n, 
 // (round 3: one WAVE per cell.  The element-wise steps run side by side; the two sums stay what they were -- one lane
 // adding the K values in index order -- so every bit is the one-thread-per-cell result's, which took 62 us: four dependent
 // walks over global memory.)
-__global__ __launch_bounds__(64) void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, int cells, int norm_type,
+struct BofFinishBody {
+  static constexpr int kGangThreads = 64;
+  static __device__ __forceinline__ void run(const uint32_t *__restrict__ counts, int n, int K, int cells, int norm_type,
                                                    double *__restrict__ out, float *__restrict__ out_f32) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= cells) return;
@@ -493,6 +507,11 @@ __global__ __launch_bounds__(64) void k_bof_finish(const uint32_t *__restrict__ 
     h[i] = bof_h[i];
     if (out_f32) out_f32[(size_t)K * c + i] = (float)bof_h[i];  // BoFUtils.cpp:51-54 converts to CV_32F
   }
+}
+};
+__global__ __launch_bounds__(64) void k_bof_finish(const uint32_t *__restrict__ counts, int n, int K, int cells, int norm_type,
+                                                   double *__restrict__ out, float *__restrict__ out_f32) {
+  BofFinishBody::run(counts, n, K, cells, norm_type, out, out_f32);
 }
 
 }  // namespace
@@ -552,6 +571,36 @@ int launch_bow_merge_select(Ctx *c, const unsigned long long *d_keys, uint32_t n
   SFM_HIP(attr);
   sfm_launch<BowMergeSelectBody>(c, k_bow_merge_select, dim3(1), dim3(1024), (uint32_t)lds, d_keys, n_parts, part_stride_keys,
                                  k, m->d_view_id, m->n_views, n_pad, d_sel_out, C);
+  SFM_HIP(hipGetLastError());
+  return SFMLOC_OK;
+}
+
+struct BofZeroBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(uint32_t *__restrict__ counts, int n) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) counts[t] = 0u;
+  }
+};
+__global__ __launch_bounds__(256) void k_bof_zero(uint32_t *__restrict__ counts, int n) { BofZeroBody::run(counts, n); }
+
+// launch_bof on a gang member's stream -- or, while the member records for a session, into its record: every step a
+// kernel (the counters' memset included), so that a batch of frames shares each launch (sfmloc_imgbow_compute_batch).
+// Only the forms the reference's model takes (the tiled assignment, the one-wave-per-cell finish); -> SFMLOC_EINVAL for a
+// model that needs the others (the caller then takes the frames one at a time through launch_bof).
+int launch_bof_member(const BofModel *b, GangMember *m, const float *d_kxy, int n, uint32_t *d_counts, double *d_out,
+                      float *d_out_f32, const uint8_t *d_desc8) {
+  const int cells = b->cells;
+  const size_t lds = BofTileLds::floats(b->in_dim, b->n_pca, b->cdim, b->K) * sizeof(float);
+  if (n <= 0 || lds > 48 * 1024 || (size_t)b->K * sizeof(double) > 48 * 1024) return SFMLOC_EINVAL;
+  const int nc = b->K * cells;
+  sfm_launch<BofZeroBody>(m, k_bof_zero, dim3((nc + 255) / 256), dim3(256), 0, d_counts, nc);
+  sfm_launch<BofAssignTiledBody>(m, k_bof_assign_tiled, dim3((n + kBofTile - 1) / kBofTile), dim3(256), (uint32_t)lds,
+                                 (const float *)nullptr, d_kxy, n, b->in_dim, (const float *)b->d_pca_mean,
+                                 (const float *)b->d_pca_evec, (const float *)b->d_pca_eval, b->n_pca,
+                                 (const float *)b->d_centers, b->K, b->resized, b->levels, d_counts, d_desc8);
+  sfm_launch<BofFinishBody>(m, k_bof_finish, dim3(cells), dim3(64), (uint32_t)((size_t)b->K * sizeof(double)),
+                            (const uint32_t *)d_counts, n, b->K, cells, b->norm_type, d_out, d_out_f32);
   SFM_HIP(hipGetLastError());
   return SFMLOC_OK;
 }

@@ -43,6 +43,7 @@ struct ImgBow {
   hipEvent_t ordered = nullptr;    // sfmloc_imgbow_order_before
   hipEvent_t staged = nullptr;     // the previous call's H2D out of h_src has completed
   bool staged_pending = false;
+  hipStream_t last_stream = nullptr;  // where the last call's work was queued (a batch: the leading extractor's stream)
 };
 
 }  // namespace sfmloc
@@ -155,7 +156,8 @@ int sfmloc_imgbow_order_before(sfmloc_imgbow *p, sfmloc_context *ctx) {
   ImgBow *ib = reinterpret_cast<ImgBow *>(p);
   Ctx *c = reinterpret_cast<Ctx *>(ctx);
   SFM_HIP(hipSetDevice(ib->device));
-  hipStream_t s = akaze_stream_now(reinterpret_cast<Akaze *>(ib->ak));
+  // (an extractor that last worked as a member of a batch has its work on the batch's stream, and may have none of its own)
+  hipStream_t s = ib->last_stream ? ib->last_stream : akaze_stream_now(reinterpret_cast<Akaze *>(ib->ak));
   hipStream_t cs = c->stream;
   if (s == cs) return SFMLOC_OK;  // (shared: stream order already)
   if (!ib->ordered) SFM_HIP(hipEventCreateWithFlags(&ib->ordered, hipEventDisableTiming));
@@ -201,12 +203,74 @@ int sfmloc_imgbow_compute(sfmloc_imgbow *p, const uint8_t *image, sfmloc_query *
   rc = launch_bof(b, s, nullptr, ib->d_kxy, (int)ib->n_grid, ib->d_counts, ib->d_out, q ? q->d_bow : ib->d_out_f32,
                   akaze_desc_dev(a));
   if (rc) return rc;
+  ib->last_stream = s;
   if (out_bow) {
     SFM_HIP(hipMemcpyAsync(ib->h_out, ib->d_out, dim * sizeof(double), hipMemcpyDeviceToHost, s));
     SFM_HIP(hipStreamSynchronize(s));
     memcpy(out_bow, ib->h_out, dim * sizeof(double));
   }
   return SFMLOC_OK;
+}
+
+// the float64 vector of the extractor's last call (single or batch), after waiting for it
+int sfmloc_imgbow_vector_read(sfmloc_imgbow *p, double *out_bow) {
+  SFM_CHECK(p && out_bow, SFMLOC_EINVAL, "sfmloc_imgbow_vector_read: null argument");
+  ImgBow *ib = reinterpret_cast<ImgBow *>(p);
+  SFM_CHECK(ib->last_stream, SFMLOC_EINVAL, "sfmloc_imgbow_vector_read: nothing computed yet");
+  const BofModel *b = reinterpret_cast<const BofModel *>(ib->bof);
+  const size_t dim = (size_t)b->K * b->cells;
+  SFM_HIP(hipSetDevice(ib->device));
+  SFM_HIP(hipMemcpyAsync(ib->h_out, ib->d_out, dim * sizeof(double), hipMemcpyDeviceToHost, ib->last_stream));
+  SFM_HIP(hipStreamSynchronize(ib->last_stream));
+  memcpy(out_bow, ib->h_out, dim * sizeof(double));
+  return SFMLOC_OK;
+}
+
+// The BoW vectors of n frames, one launch per kernel for all of them: the extractors work as ONE gang session on the
+// first one's stream (gang.h) -- resize + gray + min-max, the 300 x 300 scale space, orientation + M-LDB at the grid, PCA /
+// words / pyramid histogram -- where n calls of sfmloc_imgbow_compute queue n chains of ~20 small kernels each.  The
+// vectors stay on the device (sfmloc_imgbow_vector_dev of each extractor); same kernels on the same inputs, so the same
+// bits as the single calls (tests/test_gpu_imgbow.py).  The reference computes the vector per query image
+// (localization.cpp:346-361); a batch is what a server with several frames in hand does.
+int sfmloc_imgbow_compute_batch(sfmloc_imgbow *const *ibs, const uint8_t *const *images, uint32_t n) {
+  SFM_CHECK(ibs && images && n >= 1 && n <= (uint32_t)kGangMembers, SFMLOC_EINVAL, "sfmloc_imgbow_compute_batch: 1..%d images",
+            kGangMembers);
+  GangMember *ms[kGangMembers];
+  ImgBow *first = reinterpret_cast<ImgBow *>(ibs[0]);
+  for (uint32_t i = 0; i < n; ++i) {
+    ImgBow *ib = reinterpret_cast<ImgBow *>(ibs[i]);
+    SFM_CHECK(ib && images[i], SFMLOC_EINVAL, "sfmloc_imgbow_compute_batch: null argument (image %u)", i);
+    SFM_CHECK(ib->device == first->device && ib->w == first->w && ib->h == first->h && ib->channels == first->channels,
+              SFMLOC_EINVAL, "sfmloc_imgbow_compute_batch: the extractors differ in device or image size");
+    for (uint32_t j = 0; j < i; ++j) SFM_CHECK(ibs[j] != ibs[i], SFMLOC_EINVAL, "extractor listed twice");
+    ms[i] = akaze_member(reinterpret_cast<Akaze *>(ib->ak));
+    SFM_CHECK(ms[i]->stream.gang == nullptr, SFMLOC_EINVAL, "sfmloc_imgbow_compute_batch: extractor %u is in a session", i);
+  }
+  SFM_HIP(hipSetDevice(first->device));
+  const size_t n_src = (size_t)first->w * first->h * first->channels;
+  for (uint32_t i = 0; i < n; ++i) {  // the frames into the pinned staging buffers (host work, before anything is queued)
+    ImgBow *ib = reinterpret_cast<ImgBow *>(ibs[i]);
+    if (ib->staged_pending) SFM_HIP(hipEventSynchronize(ib->staged));
+    memcpy(ib->h_src, images[i], n_src);
+  }
+  hipStream_t s0 = akaze_stream_now(reinterpret_cast<Akaze *>(first->ak));  // (the session's stream: the first extractor's)
+  int rc = n > 1 ? gang_open(ms, (int)n) : SFMLOC_OK;
+  for (uint32_t i = 0; i < n && rc == SFMLOC_OK; ++i) {
+    ImgBow *ib = reinterpret_cast<ImgBow *>(ibs[i]);
+    Akaze *a = reinterpret_cast<Akaze *>(ib->ak);
+    const BofModel *b = reinterpret_cast<const BofModel *>(ib->bof);
+    // the upload depends on nothing recorded so far: queued at once, ahead of the session's launches
+    hipStream_t su = ms[i]->stream.unordered();
+    SFM_HIP(hipMemcpyAsync(ib->d_src, ib->h_src, n_src, hipMemcpyHostToDevice, su));
+    SFM_HIP(hipEventRecord(ib->staged, su));
+    ib->staged_pending = true;
+    rc = dense_gray_enqueue_member(&ib->plan, ms[i], ib->d_src, akaze_gray_dev(a));
+    if (!rc) rc = akaze_compute_resident(a, ib->d_grid, ib->n_grid, 4);
+    if (!rc) rc = launch_bof_member(b, ms[i], ib->d_kxy, (int)ib->n_grid, ib->d_counts, ib->d_out, ib->d_out_f32, akaze_desc_dev(a));
+    ib->last_stream = s0;
+  }
+  const int rc_close = n > 1 ? gang_close(ms[0]) : SFMLOC_OK;
+  return rc ? rc : rc_close;
 }
 
 }  // extern "C"

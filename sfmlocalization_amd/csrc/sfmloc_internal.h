@@ -367,6 +367,8 @@ int launch_bow_merge_select(Ctx *c, const unsigned long long *d_keys, uint32_t n
 // d_desc8 non-null: the descriptors are rows of 64 bytes (a .desc row, the first in_dim bytes used) instead of floats
 int launch_bof(const BofModel *b, hipStream_t s, const float *d_desc, const float *d_kxy, int n, uint32_t *d_counts,
                double *d_out, float *d_out_f32, const uint8_t *d_desc8 = nullptr);
+int launch_bof_member(const BofModel *b, GangMember *m, const float *d_kxy, int n, uint32_t *d_counts, double *d_out,
+                      float *d_out_f32, const uint8_t *d_desc8);
 
 // dense.hip: the resize + gray + min-max front end with its tables resident (sfmloc_imgbow; sfmloc_dense_gray builds a
 // temporary one).  src: h x w x channels (3 = BGR, 1 = gray: a colour read of a gray file has three equal channels,
@@ -380,12 +382,14 @@ struct DenseGrayPlan {
 int dense_gray_plan_create(DenseGrayPlan *p, int w, int h, int channels, int size);
 void dense_gray_plan_destroy(DenseGrayPlan *p);
 int dense_gray_enqueue(const DenseGrayPlan *p, hipStream_t s, const uint8_t *d_src, uint8_t *d_gray_out);
+int dense_gray_enqueue_member(const DenseGrayPlan *p, GangMember *m, const uint8_t *d_src, uint8_t *d_gray_out);
 
 // akaze.hip: an extractor's device-resident pieces, for callers inside the library (imgbow.hip)
 struct Akaze;
 uint8_t *akaze_gray_dev(Akaze *a);           // [h*w] the image build_scale_space works on
 uint8_t *akaze_desc_dev(Akaze *a);           // [n x 64] descriptors of the last describe
 hipStream_t akaze_stream_now(Akaze *a);      // the stream its work is queued on (its own or a context's)
+GangMember *akaze_member(Akaze *a);          // the extractor as a gang member (its launches can be recorded for a session)
 // scale space of the image ALREADY in akaze_gray_dev (written on akaze_stream_now) + orientation and M-LDB at the
 // device-resident keypoints d_kin [n x 4] (x, y, size, class_id); asynchronous
 int akaze_compute_resident(Akaze *a, const float *d_kin, unsigned int n, int need_levels /*0: all*/);

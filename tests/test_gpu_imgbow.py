@@ -99,3 +99,25 @@ def test_vector_lands_in_the_query_slot_and_drives_the_shortlist(model):
         ib.share_stream(None)
         ctx.close()
     ib.close()
+
+
+def test_a_batch_of_frames_in_one_session_equals_the_single_calls(model):
+    """sfmloc_imgbow_compute_batch: the extractors of n frames record their chains for ONE gang session -- resize + gray +
+    min-max, the 300 x 300 scale space, orientation + M-LDB at the grid, PCA / words / histogram: one launch per kernel for
+    all frames -- and every frame's vector is the single call's, bit for bit; batches of different sizes on the same
+    extractors, single calls in between, extractors that never had a stream of their own, and the session's stream
+    ordered in front of a context (order_before) all work."""
+    bow_file, pca_file, pca, bowm = model
+    w, h = 640, 480
+    imgs = [synth.texture_image(500 + k, h, w, n_blobs=300 + 90 * k, n_rects=60 + 10 * k) for k in range(6)]
+    single = S.ImgBow.from_files(bow_file, pca_file, w, h, 1)
+    want = [single.compute(g) for g in imgs]
+    ibs = [S.ImgBow.from_files(bow_file, pca_file, w, h, 1) for _ in range(6)]
+    for n, first in ((6, 0), (3, 2), (1, 5), (4, 1)):
+        sel = [(first + k) % 6 for k in range(n)]
+        S.ImgBow.compute_batch(ibs[:n], [imgs[i] for i in sel])
+        for e, i in zip(ibs, sel):
+            np.testing.assert_array_equal(bits(e.vector_read()), bits(want[i]))
+        np.testing.assert_array_equal(bits(ibs[2].compute(imgs[4])), bits(want[4]))      # a single call on a member
+    for o in ibs + [single]:
+        o.close()
