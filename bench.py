@@ -397,7 +397,7 @@ def image_in_phase(a, S, local_rank, log, hd=False):
         # 240 texels per metre so that a 1080p pixel sees what a VGA pixel sees of the 100 texel/m plane, its density set for
         # 5-6 k AKAZE keypoints per frame (BASELINE: "1080p queries", 4-6 k features); 3 x 3 places of 16 m
         W, H, focal, px_per_m, tiles, tile_px = 1920, 1080, 2400.0, 240.0, 3, 3840
-        atlas_kw = {"blobs_per_tile": 14000, "rects_per_tile": 2200}
+        atlas_kw = {"blobs_per_tile": 4500, "rects_per_tile": 700}
         n_views, n_real = a.image_views_1080p, a.image_views_1080p
         batch, steps, n_oracle = a.batch_1080p, a.image_steps_1080p, min(4, a.image_oracle_frames)
     else:

@@ -312,3 +312,69 @@ def test_two_ranks_equal_unsharded():
             np.testing.assert_array_equal(got["pair_landmark"], exp["pair_landmark"])
             assert (np.array(got["P"]) == exp["P"]).all() and (np.array(got["center"]) == exp["center"]).all()
     assert n_ok >= 2
+
+
+_TIMEOUT_RANK = r'''
+import os, sys, time
+from datetime import timedelta
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as dist
+import bench
+rank = int(sys.argv[1])
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = sys.argv[2]
+a = bench.parse(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+dist.init_process_group("gloo", rank=rank, world_size=2, timeout=timedelta(seconds=4))
+x = torch.zeros(4)
+out = torch.zeros(8)
+dist.all_gather_into_tensor(out, x)          # both ranks: the group works
+if rank == 1:
+    time.sleep(30)                           # ... then this rank stops taking part
+    os._exit(0)
+try:
+    dist.all_gather_into_tensor(out, x)      # cannot complete: raises within the group's timeout
+except BaseException as e:
+    bench.fail(a, rank, f"{{type(e).__name__}}: {{e}}", 3)
+print("unreachable")
+'''
+
+
+def test_a_collective_that_cannot_complete_ends_the_run_with_a_line():
+    """bench.py at N > 1 (VERDICT r03 item 6): the process group is created with a timeout, and a rank whose collective
+    cannot complete -- here rank 1 stops taking part -- prints ONE JSON line with the reason (`error`, `value` null) and
+    exits non-zero at once instead of sitting out the default ten minutes in silence.  World 2 over gloo; the same
+    bench.fail() serves the watchdog of a run that hangs inside a call."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = _TIMEOUT_RANK.format(root=root)
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    out0, err0 = procs[0].communicate(timeout=120)
+    took = time.perf_counter() - t0
+    procs[1].kill()
+    procs[1].communicate()
+    assert procs[0].returncode == 3, (procs[0].returncode, out0[-500:], err0[-1500:])
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "unreachable" not in out0
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["error"] and d["metric"] == "query images localized/sec"
+    assert took < 60, took
+
+
+def test_watchdog_ends_a_run_that_makes_no_progress():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys, time; sys.path.insert(0, {root!r}); import bench; a = bench.parse(['--gpus', '2']); "
+            "w = bench.Watchdog(1.0, 0, a); time.sleep(20); print('unreachable')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 4 and '"error": "watchdog' in r.stdout and "unreachable" not in r.stdout
