@@ -52,7 +52,8 @@ K1_HEAD_ROWS = 64
 # HBM bytes per launch of the roofline kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
 # runs of this command, corrected as MI355X_MICROARCH.md prescribes; tools/run_profile.sh + tools/pmc_summary.py).
 # PMC cannot be collected from inside this process, so this one field is read from the committed summary.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary_fullscan.json")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary_fullscan.json") for r in (4, 3))
+                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc_summary_fullscan.json"))
 
 
 def parse(argv=None):
