@@ -83,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--gang", type=int, default=0,
                     help="--gpus > 1: queries per launch in both stages of the sharded path (gang sessions, "
                          "sfmloc_gang_begin/_end); 0 = 16 with more than one rank, 1 = one query per launch")
+    ap.add_argument("--queries-per-stream", type=int, default=int(os.environ.get("SFMLOC_BENCH_QUERIES_PER_STREAM", "1")),
+                    help="1 GPU: queries a context stream carries per turn, as one gang session (sfmloc_gang_begin/_end: one "
+                         "launch per kernel for all of them); in flight = --in-flight x this")
     ap.add_argument("--threads", type=int, default=0,
                     help="host threads driving the contexts (1 GPU, no shortlist collective): 0/1 = one thread round-robins "
                          "all contexts; N > 1 = N threads, each with its share of the contexts (the C ABI calls release the "
@@ -765,6 +768,10 @@ def measure(a, rank, world, local_rank, dist, torch, replicas):
         sharded = D.ShardedLocalizer(comp, rank=rank, world=world, always_gather=forced and dist is not None,
                                      n_views_global=a.views)
     ctxs = [dev_map.context() for _ in range(nctx)] if sharded is None else []
+    # queries per context STREAM (--queries-per-stream G > 1): every stream carries G contexts that take a query each through
+    # one gang session per turn -- G x nctx queries in flight on nctx hardware queues
+    G = max(1, int(getattr(a, "queries_per_stream", 1) or 1)) if sharded is None and not a.from_images else 1
+    members = [[c] + [dev_map.context(share=c) for _ in range(G - 1)] for c in ctxs]
     t_begin = [0.0] * nctx
     busy = [False] * nctx
 
@@ -804,6 +811,47 @@ def measure(a, rank, world, local_rank, dist, torch, replicas):
         nthr = min(a.threads, nctx)
         lock = threading.Lock()
 
+        def worker_gang(t):
+            # G queries per turn of a stream: one gang session (one launch per kernel for the G members)
+            from sfmlocalization_amd import capi
+            mine = list(range(t, nctx, nthr))
+            tb = {k: 0.0 for k in mine}
+            cur = {k: [] for k in mine}
+            lat_l, ok_l, fp_l = [], 0, []
+
+            def fin(k):
+                ok = 0
+                for c, i in zip(members[k], cur[k]):
+                    pose, pq, pl = c.end()
+                    lat_l.append(time.perf_counter() - tb[k])
+                    fp_l.append((i % len(dqs), fingerprint(pose, pq, pl)))
+                    ok += int(pose.ok)
+                cur[k] = []
+                return ok
+
+            todo = list(range(first + phase + t * stride, first + count, nthr * stride))
+            for n, j0 in enumerate(range(0, len(todo), G)):
+                k = mine[n % len(mine)]
+                if cur[k]:
+                    ok_l += fin(k)
+                idx = todo[j0:j0 + G]
+                tb[k] = time.perf_counter()
+                with capi.gang(members[k][:len(idx)]):
+                    for c, i in zip(members[k], idx):
+                        dq = dqs[i % len(dqs)]
+                        if shortlist:
+                            c.begin_bow(dq, None, a.bow_knn)
+                        else:
+                            c.begin(dq)
+                cur[k] = idx
+            for k in mine:
+                if cur[k]:
+                    ok_l += fin(k)
+            with lock:
+                lat.extend(lat_l)
+                n_ok[0] += ok_l
+                fps.extend(fp_l)
+
         def worker(t):
             mine = list(range(t, nctx, nthr))          # this thread's contexts
             tb = {k: 0.0 for k in mine}
@@ -833,7 +881,7 @@ def measure(a, rank, world, local_rank, dist, torch, replicas):
                 n_ok[0] += ok_l
                 fps.extend(fp_l)
 
-        ts = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
+        ts = [threading.Thread(target=worker_gang if G > 1 else worker, args=(t,)) for t in range(nthr)]
         for t in ts:
             t.start()
         for t in ts:
@@ -1137,6 +1185,9 @@ def measure(a, rank, world, local_rank, dist, torch, replicas):
         for e in img_mode["extractors"]:
             e.close()
         for c in img_mode["member_contexts"]:
+            c.close()
+    for ms in members:
+        for c in reversed(ms[1:]):
             c.close()
     for c in ctxs:
         c.close()
