@@ -1230,6 +1230,7 @@ __device__ void p3p_init_block(const P3pArgs &A, int n, int n_threads, double *s
     st.switch_iter = 0;
     st.prep_iter = -1;
     st.prep_n = 0;
+    st.first_hit = ~0u;
     st.min_nfa = pos_inf();
     st.errmax = pos_inf();
     for (int i = 0; i < 12; ++i) st.model[i] = 0.0;
@@ -1577,14 +1578,23 @@ __device__ __forceinline__ bool p3p_filter_model_block(P3pFilterLds &F, const do
 
 // one model evaluated by one wave in its registers: residuals of elements r * 64 + lane, register sort, NFA minimum;
 // the sorted indices go to iw[] (LDS).  -> r (NFA, k) and the k-th smallest residual.
+// first_hit (or null): P3pState::first_hit -- the wave gives up between its steps once an EARLIER hypothesis of the round
+// is known to change the index set (the replay will not look at this one); the value is read by every lane from the same
+// address and taken from the first lane, so the wave decides as one.
+__device__ __forceinline__ bool p3p_overtaken(const unsigned *first_hit, int b) {
+  if (!first_hit) return false;
+  const unsigned v = __hip_atomic_load(first_hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v) < (unsigned)b;
+}
 template <int E>
 __device__ __forceinline__ void p3p_eval_regs(const double (&M)[12], NfaBest &r, double &r_err, const double *__restrict__ pt3d,
                                               const double *__restrict__ xn, const float *__restrict__ logc_n,
                                               const float *__restrict__ logc_k, uint32_t *iw, int lane, int n, double logalpha0,
-                                              double loge0, int stamp_round, int b) {
+                                              double loge0, int stamp_round, int b, const unsigned *first_hit = nullptr) {
   uint64_t key[E];
   uint32_t idx[E];
   float cn[E], ck[E];
+  if (p3p_overtaken(first_hit, b)) return;  // (r stays "no model")
   nfa_tables_fetch<E>(cn, ck, n, logc_n, logc_k);  // in flight during the residuals and the sort
   // the wave is alone on its SIMD: the E residuals of a lane are computed without branches (clamped index, then a
   // select) so that their dependent f64 chains -- two divisions each -- interleave
@@ -1597,8 +1607,10 @@ __device__ __forceinline__ void p3p_eval_regs(const double (&M)[12], NfaBest &r,
     idx[rr] = (uint32_t)p;
   }
   STAMP_P3P(stamp_round, b, 6);
+  if (p3p_overtaken(first_hit, b)) return;
   wave_sort_fast<E>(key, idx, iw);
   STAMP_P3P(stamp_round, b, 7);
+  if (p3p_overtaken(first_hit, b)) return;
 #pragma unroll
   for (int rr = 0; rr < E; ++rr) iw[(rr << 6) + lane] = idx[rr];
   r = best_nfa_regs_ilp<E>(key, n, 3, pos_inf(), logalpha0, 1.0, loge0, cn, ck);
@@ -1828,6 +1840,13 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   const int tid = threadIdx.x;
   constexpr int s = 3;
   const int P = next_pow2(n);
+  // An earlier hypothesis of this round is already known to change the index set: whatever this one finds, the replay
+  // will not look at it (it stops at the FIRST such hypothesis, which is that one or an earlier one).  Nothing is
+  // evaluated, the slot reports "no model".  Only workgroups that start late see this -- i.e. while the GPU is shared.
+  // (ONE lane reads the word and the workgroup decides on that value: the waves' own reads could straddle an update and
+  // part of the workgroup would leave in front of the barriers below)
+  // (the decision is taken behind the barrier that follows the solver / the fetch of the prepared models, below)
+  __shared__ unsigned s_first_hit;
   // one model per workgroup: a wide launch with enough correspondences (and the LDS forms: n <= kP3pMaxN)
   const bool single = !kSmall && wide && n <= kP3pMaxN;
   // (a wide launch that is not in single mode runs workgroups 0 .. batch - 1 only -- p3p_round.body.inc -- and is a plain
@@ -1879,8 +1898,13 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     STAMP_P3P(stamp_round, b, 1);
     S.nm = p3p_kneip_prepare(x, X, S.prep);
   }
+  if (tid == 0) s_first_hit = __hip_atomic_load(&A.state->first_hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   STAMP_P3P(stamp_round, b, 2);
+  if (s_first_hit < (unsigned)b) {  // (uniform: one lane's read, seen by all behind the barrier)
+    if (tid == 0) store_through(A.hyp_nfa + slot, pos_inf());
+    return;
+  }
   const int nm = S.nm;
   if (single && mdl >= nm) {  // (uniform over the workgroup) no such root
     if (tid == 0) store_through(A.hyp_nfa + slot, pos_inf());
@@ -1926,6 +1950,11 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   double best_err = pos_inf();
   if (single) {
     // one model per workgroup: the four waves share the model (p3p_eval_coop4 / _multi; every set the LDS forms hold)
+    // (behind the filter once more: has an earlier hypothesis been found to change the index set meanwhile?)
+    __syncthreads();
+    if (tid == 0) s_first_hit = __hip_atomic_load(&A.state->first_hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_first_hit < (unsigned)b) pass_mask = 0;
     if ((pass_mask >> mdl) & 1) {  // (uniform over the workgroup)
       double M[12];
 #pragma unroll
@@ -1966,15 +1995,16 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
       const double *pt3d = A.pt3d, *xn = A.xn;
       const float *logc_n = A.logc_n, *logc_k = A.logc_k;
       if constexpr (kSmall) {
+        const unsigned *first_hit = &A.state->first_hit;
         // (inlined: 152 VGPRs for the whole kernel, against 212 with the evaluation as a called function)
 #ifndef SFMLOC_STAMPS
         const int stamp_round = 0;
 #endif
         switch (P >> 6) {
-          case 1: p3p_eval_regs<1>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b); break;
-          case 2: p3p_eval_regs<2>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b); break;
-          case 4: p3p_eval_regs<4>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b); break;
-          default: p3p_eval_regs<8>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b); break;
+          case 1: p3p_eval_regs<1>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b, first_hit); break;
+          case 2: p3p_eval_regs<2>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b, first_hit); break;
+          case 4: p3p_eval_regs<4>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b, first_hit); break;
+          default: p3p_eval_regs<8>(M, r, r_err, pt3d, xn, logc_n, logc_k, iw, lane, n, logalpha0, loge0, stamp_round, b, first_hit); break;
         }
       } else {
         // (a lambda the compiler keeps out of line -- the text of p3p_eval_regs once more: with a call to that function in
@@ -2063,6 +2093,8 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     STAMP_P3P(stamp_round, b, 4);
   }
   if (tid == 0) {
+    // (min_nfa < 0 from the switch on, so every improvement changes the index set; before it only a meaningful model does)
+    if (best < nfa_to_beat && best < 0.0) atomicMin(&A.state->first_hit, (unsigned)b);
     store_through(A.hyp_nfa + slot, best);
     store_through(A.hyp_k + slot, best_k);
     store_through(A.hyp_err + slot, best_err);
@@ -2405,6 +2437,7 @@ __device__ __forceinline__ void p3p_replay_impl(const P3pArgs &A, int batch, int
     st.rounds += 1;
     st.switch_iter = (int)switch_iter;
     st.batch_limit = next_limit;
+    st.first_hit = ~0u;
     if (best_b >= 0)
       for (int q = 0; q < 12; ++q) st.model[q] = A.hyp_model[12 * best_slot + q];
     if (done) st.done = 1;

@@ -74,6 +74,10 @@ struct P3pState {
   // hypotheses prep_iter .. prep_iter + prep_n - 1 have their P3P models in P3pArgs::prep_models already: the workgroup
   // that replayed the previous round solved them, one hypothesis per lane (acransac.hip "Prepared ahead")
   int prep_iter, prep_n;
+  // the lowest hypothesis index of the current round whose model is known to change the index set (NFA below the round's
+  // starting NFA and below 0), or ~0u: a workgroup that STARTS after that is known -- while the GPU is shared a round's
+  // workgroups trickle in -- evaluates nothing, because the replay throws everything behind that hypothesis away
+  unsigned first_hit;
   double min_nfa, errmax;
   double model[12];
 };
