@@ -5,6 +5,8 @@ backend is "nccl"; gloo on CPU in the tests), then the 2D-3D selection + P3P of 
 The collective layer is independent of what computes the parts: `HipShardCompute` drives the C ABI
 (sfmloc_shard_begin / _export / sfmloc_merge_begin); the CPU tests plug in a stand-in built on the oracle.
 """
+import os
+
 import numpy as np
 
 # one candidate as the C ABI lays it out (sfmloc_internal.h Candidate; 40 bytes) and the 16-byte part header
@@ -384,7 +386,7 @@ class ShardedLocalizer:
         gathered, keys_all, ev = self._stage1(queries, slot, budget, bow_knn)
         return (queries, gathered, keys_all, slot, bow_knn, ev, budget)
 
-    def _finish(self, state, gather_results):
+    def _finish(self, state, gather_results, split=False, turn=0):
         import torch
         queries, gathered, keys_all, slot, bow_knn, ev, budget = state
         B = len(queries)
@@ -408,7 +410,14 @@ class ShardedLocalizer:
         self._n_batches += 1
         self._n_queries += B
         mine = [i for i in range(B) if self.owner(i) == self.rank]
+        if split and hasattr(self.compute, "stage2_begin"):
+            # queued, not awaited: the caller collects the results later (localize_stream), so that the NEXT batch's stage 1
+            # can be queued while this batch's P3P rounds run
+            return ("pending", self.compute.stage2_begin(mine, gathered, slot, budget, turn), gather_results)
         local = self.compute.stage2(mine, gathered, slot, budget)
+        return self._collect(local, gather_results)
+
+    def _collect(self, local, gather_results):
         if not gather_results or self.world == 1:
             return local
         allres = [None] * self.world
@@ -417,6 +426,10 @@ class ShardedLocalizer:
         for d in allres:
             out.update(d)
         return out
+
+    def _finish_end(self, token):
+        _, pending, gather_results = token
+        return self._collect(self.compute.stage2_end(pending), gather_results)
 
     def localize_batch(self, queries, gather_results=True, bow_knn=0):
         return self._finish(self._begin(queries, 0, bow_knn), gather_results)
@@ -428,17 +441,41 @@ class ShardedLocalizer:
         scans.  Every rank must iterate the same batches."""
         prev = None
         slot = 0
+        # Three batches deep when the compute object can queue stage 2 without waiting for it (HipShardCompute): while the
+        # host waits for batch b - 1's poses the GPU already holds stage 1 of batch b + 1 and stage 2 of batch b.  (Two deep,
+        # the host sat in batch b's stage 2 for as long as its P3P rounds took and stage 1 of batch b + 2 was queued only
+        # then: 17 ms per 256-query batch for a rank of 8 whose scans take 8.)
+        deep = hasattr(self.compute, "stage2_begin") and os.environ.get("SFMLOC_SHARD_PIPELINE", "3") != "2"
+        queued = None      # batch b: stage 2 queued, results not collected
+        turn = 0
         for batch in batches:
             if self.n_slots < 2:
                 yield self.localize_batch(batch, gather_results, bow_knn)
                 continue
             cur = self._begin(batch, slot, bow_knn)
             if prev is not None:
-                yield self._finish(prev, gather_results)
+                if deep:
+                    token = self._finish(prev, gather_results, split=True, turn=turn)
+                    turn ^= 1
+                    if queued is not None:
+                        yield self._finish_end(queued)
+                    if isinstance(token, tuple) and token and token[0] == "pending":
+                        queued = token
+                    else:                   # (nothing of this batch is owned here, or the compute object did not split)
+                        queued = None
+                        yield token
+                else:
+                    yield self._finish(prev, gather_results)
             prev = cur
             slot ^= 1
         if prev is not None:
-            yield self._finish(prev, gather_results)
+            if deep:
+                token = self._finish(prev, gather_results, split=True, turn=turn)
+                if queued is not None:
+                    yield self._finish_end(queued)
+                yield self._finish_end(token) if isinstance(token, tuple) and token and token[0] == "pending" else token
+            else:
+                yield self._finish(prev, gather_results)
 
 
 class HipShardCompute:
@@ -608,6 +645,8 @@ class HipShardCompute:
         out = {}
         queries = self._queries[slot]
         B = len(queries)
+        if self.ctx2 is not None and len(indices) <= len(self.ctx2[0]) and len(self.ctx2) >= 2:
+            return self.stage2_end(self.stage2_begin(indices, gathered, slot, budget, 0))
         if self.ctx2 is not None:
             # gang sessions: the 2D-3D selection and every P3P round of up to len(ctx2) queries per launch
             # (two groups of contexts take turns, so that a session is queued while the one before it is awaited)
@@ -638,6 +677,34 @@ class HipShardCompute:
         for j, cj in pending:
             out[j] = _pose_tuple(cj.end())
         return out
+
+
+def _hip_stage2_begin(self, indices, gathered, slot=0, budget=0, turn=0):
+    """Stage 2 of a batch's own queries QUEUED (one gang session per group of contexts), nothing awaited: -> the list the
+    caller hands to stage2_end.  `turn` picks the group of contexts (consecutive batches alternate, so a batch's session is
+    queued while the previous batch's is still running).  Falls back to the blocking form when the batch's share does not
+    fit one group."""
+    from . import capi
+    world, pb = gathered.shape
+    queries = self._queries[slot]
+    B = len(queries)
+    if self.ctx2 is None or len(indices) > len(self.ctx2[0]):
+        return ("done", self.stage2(indices, gathered, slot, budget))
+    if not indices:
+        return ("done", {})
+    cs = self.ctx2[turn % len(self.ctx2)]
+    capi.merge_batch_begin(cs[:len(indices)], [queries[i] for i in indices], indices, gathered.data_ptr(), world, pb, B, budget)
+    return ("queued", list(zip(cs, indices)), gathered)      # (the gathered buffer must outlive the session)
+
+
+def _hip_stage2_end(self, pending):
+    if pending[0] == "done":
+        return pending[1]
+    return {i: _pose_tuple(c.end()) for c, i in pending[1]}
+
+
+HipShardCompute.stage2_begin = _hip_stage2_begin
+HipShardCompute.stage2_end = _hip_stage2_end
 
 
 def _pose_tuple(res):

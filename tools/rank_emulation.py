@@ -169,8 +169,9 @@ def main():
             host[name] = host.get(name, 0.0) + time.perf_counter() - t
             return r
         setattr(comp, name, g)
-    for name in ("bow_keys", "stage1_bow", "stage2"):
-        timed(name)
+    for name in ("bow_keys", "stage1_bow", "stage2", "stage2_begin", "stage2_end"):
+        if hasattr(comp, name):
+            timed(name)
     batch = [dqs0[i] for i in batch_ids]
 
     # ---- the emulated exchange is the real one: rank 0's queries against the unsharded path --------------------------
