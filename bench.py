@@ -532,6 +532,24 @@ def image_in_phase(a, S, local_rank, log, hd=False):
         for t in ts:
             t.join()
 
+    # K1 on a bank of REAL statistics: the full scan of this map -- every row a K9-extracted M-LDB descriptor -- by one
+    # frame's own features, one launch in flight (roofline.real_bank; the headline bank is uniform random bits, the best
+    # case of the screening bound)
+    real_bank = None
+    if not hd and not a.no_roofline_phase:
+        kp0, d0 = groups[0][1][0].detect_and_compute(frames[0])
+        dq0 = dev_map.query(d0, kp0[:, :2], W, H)
+        k1_ms, lane_ops, n_match, st_roof = roofline_phase(S, dev_map, dq0, int(m.n_rows), len(d0))
+        dev_map.set_profile(0)
+        dq0.close()
+        vf = valu_floor(int(m.n_rows), len(d0), k1_ms, lane_ops, st_roof)
+        real_bank = {"bank": f"{m.n_rows} rows: the image-in map, {n_real} of {m.n_views} views K9-extracted from rendered images",
+                     "bank_rows": int(m.n_rows), "nq": int(len(d0)), "kernel_ms": k1_ms, "emitted_matches": n_match,
+                     "ops_per_pair_issued": vf["ops_per_pair_issued"], "pairs_finished_frac": vf["pairs_finished_frac"],
+                     "pairs_per_s": vf["pairs_per_s"],
+                     "valu": {"achieved": vf["achieved"], "peak": vf["peak"], "unit": "T lane-ops/s", "frac": vf["frac"],
+                              "floor_ms": vf["floor_ms"]},
+                     "hbm_GBps": (64 * int(m.n_rows) + 64 * len(d0) + 12 * n_match) / (k1_ms * 1e-3) / 1e9}
     run(0, batch)                           # warm-up
     dev_map.sync()
     with lock:
@@ -598,24 +616,6 @@ def image_in_phase(a, S, local_rank, log, hd=False):
     dev_map.set_profile(0)
     path_shape = {"views_with_16_or_more_putative_matches": n_put_v / n_ps, "views_passing_the_F_matrix_filter": n_geo_v / n_ps,
                   "correspondences_2d3d": n_23 / n_ps, "inliers": n_inl / n_ps}
-    # K1 on a bank of REAL statistics: the full scan of this map -- every row a K9-extracted M-LDB descriptor -- by one
-    # frame's own features, one launch in flight (roofline.real_bank; the headline bank is uniform random bits, the best
-    # case of the screening bound)
-    real_bank = None
-    if not hd and not a.no_roofline_phase:
-        kp0, d0 = groups[0][1][0].detect_and_compute(frames[0])
-        dq0 = dev_map.query(d0, kp0[:, :2], W, H)
-        k1_ms, lane_ops, n_match, st_roof = roofline_phase(S, dev_map, dq0, int(m.n_rows), len(d0))
-        dev_map.set_profile(0)
-        dq0.close()
-        vf = valu_floor(int(m.n_rows), len(d0), k1_ms, lane_ops, st_roof)
-        real_bank = {"bank": f"{m.n_rows} rows: the image-in map, {n_real} of {m.n_views} views K9-extracted from rendered images",
-                     "bank_rows": int(m.n_rows), "nq": int(len(d0)), "kernel_ms": k1_ms, "emitted_matches": n_match,
-                     "ops_per_pair_issued": vf["ops_per_pair_issued"], "pairs_finished_frac": vf["pairs_finished_frac"],
-                     "pairs_per_s": vf["pairs_per_s"],
-                     "valu": {"achieved": vf["achieved"], "peak": vf["peak"], "unit": "T lane-ops/s", "frac": vf["frac"],
-                              "floor_ms": vf["floor_ms"]},
-                     "hbm_GBps": (64 * int(m.n_rows) + 64 * len(d0) + 12 * n_match) / (k1_ms * 1e-3) / 1e9}
     # a sample of the frames against the oracle, end to end
     checked, agree = 0, 0
     oracle_note = []
