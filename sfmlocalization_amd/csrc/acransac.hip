@@ -3268,6 +3268,7 @@ static int ensure_fmatrix_large(Ctx *c) {
   SFM_HIP(hipMalloc((void **)&c->fl_logc_k, n1 * sizeof(float)));
   SFM_HIP(hipMalloc((void **)&c->fl_count, sizeof(uint32_t)));
   SFM_HIP(hipMemset(c->fl_count, 0, sizeof(uint32_t)));  // (from the next query on the query's reset kernel clears it)
+  SFM_HIP(hipStreamSynchronize(nullptr));                // (null stream: not ordered with the context's stream otherwise)
   SFM_HIP(hipMalloc((void **)&c->fl_list, ((size_t)m->n_views + 1) * sizeof(uint32_t)));
   c->hbm_bytes += n * 20 + n1 * 8 + ((size_t)m->n_views + 2) * 4;
   return SFMLOC_OK;

@@ -2310,6 +2310,7 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   A((void **)&a->d_seg, ((size_t)a->n_seg + 1) * sizeof(unsigned int));
   A((void **)&a->d_seg_part, 1025 * sizeof(unsigned int));
   if (he == hipSuccess) he = hipMemset(a->d_seg_part, 0, 1025 * sizeof(unsigned int));
+  if (he == hipSuccess) he = hipStreamSynchronize(nullptr);  // (null stream: the extractor's streams are not ordered with it)
   A((void **)&a->d_seg_x, (size_t)a->n_seg * kSegMax);
   A((void **)&a->d_cxy, cc * sizeof(uint32_t));
   A((void **)&a->d_clevel, cc);

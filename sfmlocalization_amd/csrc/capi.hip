@@ -264,6 +264,11 @@ int make_ctx(Map *m, Ctx **out, Ctx *share = nullptr, bool merge_only = false) {
   CTX_HIP(hipMemsetAsync(c->d_p3p_state, 0, sizeof(P3pState), c->stream));
   CTX_HIP(hipMemsetAsync(c->d_view_stats, 0, 3 * sizeof(uint32_t), c->stream));
   CTX_HIP(hipStreamSynchronize(c->stream));
+  // (the two hipMemset above -- the arrival counters of k_hamming_rows, K1's statistics -- run on the NULL stream, which the
+  // context's non-blocking stream is not ordered with, and hipMemset of device memory may return before it has run: a first
+  // scan that overtook the memset found garbage arrival counters, merged nothing and left the head pass's seeds to K2 --
+  // the one wrong first scan of round 4, profiles/r04_pytest_gpu_failed_run_excerpt.txt)
+  CTX_HIP(hipStreamSynchronize(nullptr));
 #undef CTX_TRY
 #undef CTX_HIP
   *out = c;
