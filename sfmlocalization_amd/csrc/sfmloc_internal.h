@@ -51,7 +51,10 @@ constexpr uint32_t kBlockRows = 64;
 constexpr int kK1CounterSlots = 64;  // Ctx::d_k1_counters
 constexpr int kP3pMaxN = 4096;     // 2D-3D correspondences the P3P LDS sort holds
 constexpr int kP3pBatchMax = 512;  // hypotheses evaluated per round
-constexpr int kP3pSlots = 1024;    // result slots of a round: one per hypothesis, or (wide launches) four, one per model
+// result slots of a round: one per hypothesis (at most kP3pBatchMax), or (wide launches, at most kP3pSlots / 4 = 128
+// hypotheses -- their nominal size since round 4) four, one per model.  A slot's inlier list is kP3pMaxN ints: 8 MB per
+// context (16 MB while wide rounds could be 256 hypotheses: ADVICE r03)
+constexpr int kP3pSlots = 512;
 constexpr uint32_t kPartHeaderBytes = 16;  // candidate part: {u32 n_cand, pad[3]} then the candidates
 
 using Pose = sfmloc_pose;

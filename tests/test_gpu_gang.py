@@ -208,6 +208,42 @@ def test_sharded_layer_with_gangs_equals_without(gang):
             dq.close()
 
 
+def test_three_batches_in_flight_give_the_results_of_two(monkeypatch):
+    """ShardedLocalizer.localize_stream keeps three batches in flight when the compute object can queue stage 2 without
+    waiting for it (HipShardCompute.stage2_begin / _end: stage 2 of batch b is queued, stage 1 of batch b + 2 follows, the
+    poses of batch b are collected one batch later; two groups of stage-2 contexts take turns).  Five uneven batches, the
+    last one empty-handed for stage 2 on this rank's turn: the same results, in the same order, as the two-deep stream
+    (SFMLOC_SHARD_PIPELINE=2) and as batches run one at a time."""
+    import torch
+    from sfmlocalization_amd import dist as D
+    m, bow, place_bow = scene(47)
+    dev = torch.device("cuda", 0)
+    with device_map(m, bow) as dm:
+        qs = [synth.make_query(m, 900 + k, n_feat=600, n_copies=180, outlier_frac=0.3) for k in range(12)]
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in qs]
+        for dq, q in zip(dqs, qs):
+            dq.set_bow(place_bow[q.place])
+        batches = [dqs[:5], dqs[5:6], dqs[6:12], dqs[3:4], dqs[1:9]]
+        out = {}
+        for mode in ("3", "2", "one at a time"):
+            comp = D.HipShardCompute(dm, n_contexts=32, device=dev, gang=16)
+            loc = D.ShardedLocalizer(comp, rank=0, world=1, n_views_global=m.n_views)
+            if mode == "one at a time":
+                out[mode] = [loc.localize_batch(b, gather_results=False, bow_knn=15) for b in batches]
+            else:
+                monkeypatch.setenv("SFMLOC_SHARD_PIPELINE", mode)
+                out[mode] = list(loc.localize_stream(batches, bow_knn=15))
+            comp.close()
+        assert len(out["3"]) == len(out["2"]) == len(batches)
+        for a, b, c in zip(out["3"], out["2"], out["one at a time"]):
+            assert sorted(a) == sorted(b) == sorted(c)
+            for i in a:
+                assert a[i]["fingerprint"] == b[i]["fingerprint"] == c[i]["fingerprint"]
+        assert sum(int(r["ok"]) for r in out["3"][0].values()) >= 3
+        for dq in dqs:
+            dq.close()
+
+
 @pytest.mark.parametrize("gang", [1, 4])
 def test_queries_as_views_into_the_gathered_feature_blocks(gang):
     """images in on several ranks (dist.gather_queries): the owner packs a query's extracted features, the all-gather's
