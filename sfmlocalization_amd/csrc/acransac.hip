@@ -1898,7 +1898,8 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     STAMP_P3P(stamp_round, b, 1);
     S.nm = p3p_kneip_prepare(x, X, S.prep);
   }
-  if (tid == 0) s_first_hit = __hip_atomic_load(&A.state->first_hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0)
+    s_first_hit = A.skip_overtaken ? __hip_atomic_load(&A.state->first_hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
   __syncthreads();
   STAMP_P3P(stamp_round, b, 2);
   if (s_first_hit < (unsigned)b) {  // (uniform: one lane's read, seen by all behind the barrier)
@@ -1951,10 +1952,12 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
   if (single) {
     // one model per workgroup: the four waves share the model (p3p_eval_coop4 / _multi; every set the LDS forms hold)
     // (behind the filter once more: has an earlier hypothesis been found to change the index set meanwhile?)
-    __syncthreads();
-    if (tid == 0) s_first_hit = __hip_atomic_load(&A.state->first_hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_first_hit < (unsigned)b) pass_mask = 0;
+    if (A.skip_overtaken) {  // (uniform)
+      __syncthreads();
+      if (tid == 0) s_first_hit = __hip_atomic_load(&A.state->first_hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (s_first_hit < (unsigned)b) pass_mask = 0;
+    }
     if ((pass_mask >> mdl) & 1) {  // (uniform over the workgroup)
       double M[12];
 #pragma unroll
@@ -1995,7 +1998,7 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
       const double *pt3d = A.pt3d, *xn = A.xn;
       const float *logc_n = A.logc_n, *logc_k = A.logc_k;
       if constexpr (kSmall) {
-        const unsigned *first_hit = &A.state->first_hit;
+        const unsigned *first_hit = A.skip_overtaken ? &A.state->first_hit : nullptr;
         // (inlined: 152 VGPRs for the whole kernel, against 212 with the evaluation as a called function)
 #ifndef SFMLOC_STAMPS
         const int stamp_round = 0;
@@ -3601,6 +3604,8 @@ static P3pArgs make_p3p_args(Ctx *c) {
   A.prep_ahead = env_prep == 2 || (env_prep == 1 && A.adaptive_batch);
   static const int env_quarters = [] { const char *e = getenv("SFMLOC_P3P_ADAPT_QUARTERS"); return e ? atoi(e) : 12; }();
   static const int env_floor = [] { const char *e = getenv("SFMLOC_P3P_ADAPT_FLOOR"); return e ? atoi(e) : 64; }();
+  static const int env_skip = [] { const char *e = getenv("SFMLOC_P3P_SKIP_OVERTAKEN"); return e ? atoi(e) : 1; }();
+  A.skip_overtaken = env_skip;  // (0: every hypothesis of a round is evaluated, as before round 4 -- comparison runs)
   A.adapt_quarters = env_quarters;
   A.adapt_floor = env_floor;
   A.seed = m->params.seed;

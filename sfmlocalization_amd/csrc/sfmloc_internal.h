@@ -112,6 +112,7 @@ struct P3pArgs {
   int max_iteration, min_resection_points, min_inliers, max_n, refine_pose;
   int nfa_filter;      // 1 = models that cannot beat the round's starting NFA are not sorted (acransac.hip, "The NFA filter")
   int nfa_filter_min_p;  // ... for next_pow2(n) >= this
+  int skip_overtaken;  // 1: workgroups / waves give up behind a known index-changing hypothesis (P3pState::first_hit)
   int adaptive_batch;  // other queries share the GPU: trade rounds for fewer speculative hypotheses
   int adapt_quarters, adapt_floor;  // next batch = max(floor, quarters/4 * iterations since the switch)
   uint64_t seed;
