@@ -1985,8 +1985,9 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     // register path: a model is evaluated by ONE wave, residuals sorted in its registers; the (up to 4) models of the
     // hypothesis side by side, one wave each -- or (one model per workgroup) wave 0 takes the workgroup's model
     const int wv = tid >> 6, lane = tid & 63;
-    const int my_model = single ? mdl : wv;
-    const bool mine = single ? (wv == 0) : (wv < nm);
+    // (never in single mode: a one-model-per-workgroup launch took the branch above)
+    const int my_model = wv;
+    const bool mine = wv < nm;
     uint32_t *iw = S.idx + (size_t)wv * wave_seg;
     NfaBest r{pos_inf(), 0x7FFFFFFF};
     double r_err = pos_inf();
@@ -2052,15 +2053,14 @@ __device__ __forceinline__ void p3p_eval_hypothesis(const P3pArgs &A, int batch,
     }
     __syncthreads();
     STAMP_P3P(stamp_round, b, 4);
-    // (one model per workgroup: wave 0 holds the model's result, the other waves +inf)
-    for (int k = 0; k < (single ? 1 : nm); ++k)
+    for (int k = 0; k < nm; ++k)
       if (S.red_nfa[k] < best) {  // strict: the first model of the hypothesis wins ties, as the sequential loop does
         best = S.red_nfa[k];
         best_k = S.red_k[k];
-        best_m = single ? mdl : k;
+        best_m = k;
       }
     if (best_m >= 0) {
-      const int w_best = single ? 0 : best_m;
+      const int w_best = best_m;
       best_err = S.red_err[w_best];
       int32_t *dst = A.hyp_inl + (size_t)slot * inl_stride;
       const uint32_t *src = S.idx + (size_t)w_best * wave_seg;
