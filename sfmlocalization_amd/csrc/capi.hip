@@ -536,6 +536,13 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
     // all), 3-5 % more queries per second because fewer speculative hypotheses are evaluated for nothing
     return (v >= 16 && v <= kP3pBatchMax) ? v : 256;
   }();
+  // the first round's size while the GPU is shared (a query alone: 64): after the geometric filter the first hypothesis is
+  // nearly always the one that switches sampling to its inliers, and everything behind it is thrown away
+  static const int env_first_shared = [] {
+    const char *e = getenv("SFMLOC_P3P_FIRST_BATCH");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 4 && v <= 256) ? v : 64;
+  }();
   static const int env_rounds = [] {
     const char *e = getenv("SFMLOC_P3P_ROUNDS");
     const int v = e ? atoi(e) : 0;
@@ -545,7 +552,7 @@ int ctx_resection_enqueue(Ctx *c, bool first_call) {
   // them alone on the gang's stream: three more up front)
   const int rounds = first_call ? (c->stream.gang ? std::max(env_rounds, 12) : env_rounds) : 6;
   for (int r = 0; r < rounds && rc == SFMLOC_OK; ++r)
-    rc = launch_p3p_round(c, (first_call && r == 0) ? 64 : env_batch);
+    rc = launch_p3p_round(c, (first_call && r == 0) ? (c->k1_may_slice ? 64 : env_first_shared) : env_batch);
   if (rc == SFMLOC_OK) rc = launch_p3p_finish(c);  // pose + inlier pairs once the state says "done"; a no-op before
   return rc;
 }
