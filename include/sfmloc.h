@@ -496,6 +496,12 @@ int sfmloc_akaze_levels(const sfmloc_akaze *ak, int *n_levels, int *wh);
  * workers stop competing for queues (profiles/r02_image_in_sweep.txt).  The context must outlive the sharing. */
 int sfmloc_akaze_share_stream(sfmloc_akaze *ak, sfmloc_context *ctx);
 int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt);
+/* the duplicate suppression of the last call from the inside (kpts_aux of AKAZEFeatures.cpp, Find_Scale_Space_Extrema): out9 =
+ * extrema candidates, keypoints, rounds of the first pass, three in-kernel clocks (10 ns ticks: first pass, second pass,
+ * compaction), candidates whose A / P neighbour lists spilled (decided by band scans), whose N list spilled, levels decided
+ * out of the global arrays instead of LDS.  SFMLOC_AKAZE_SUPPRESS=spill / global (read by sfmloc_akaze_create) forces
+ * those forms; results are the same bits. */
+int sfmloc_akaze_suppress_stats(sfmloc_akaze *ak, uint32_t *out9);
 
 /* cv::imread of the query image, host side (AKAZEOpenCV.cpp:60 `imread(filename, IMREAD_GRAYSCALE)` for extraction;
  * DenseLocalFeatureWrapper.cpp:85 and localizeImage.cc:463 `IMREAD_COLOR` for the dense-BoW front end).  Decodes

@@ -110,7 +110,7 @@ SYMBOLS = [
     "sfmloc_localize_batch", "sfmloc_part_bytes", "sfmloc_shard_begin", "sfmloc_shard_export",
     "sfmloc_context_sync", "sfmloc_merge_begin", "sfmloc_bow_select", "sfmloc_bof_create", "sfmloc_bof_destroy",
     "sfmloc_bof_dim", "sfmloc_bof_compute", "sfmloc_akaze_create", "sfmloc_akaze_destroy",
-    "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels",
+    "sfmloc_akaze_detect_and_compute", "sfmloc_akaze_compute", "sfmloc_akaze_levels", "sfmloc_akaze_read_levels", "sfmloc_akaze_suppress_stats",
     "sfmloc_akaze_share_stream", "sfmloc_akaze_detect_and_compute_batch",
     "sfmloc_stats_read", "sfmloc_stats_reset", "sfmloc_set_profile", "sfmloc_image_decode", "sfmloc_image_read",
     "sfmloc_view_list_open", "sfmloc_view_list_get", "sfmloc_view_list_close", "sfmloc_localize_bow_begin", "sfmloc_localize_bow",
@@ -293,6 +293,7 @@ def _L():
         L.sfmloc_akaze_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.sfmloc_akaze_share_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.sfmloc_akaze_read_levels.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.sfmloc_akaze_suppress_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.sfmloc_localize_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32,
                                             C.POINTER(Pose), U32P, U32P, C.c_uint32]
         L.sfmloc_stats_read.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
@@ -1109,6 +1110,14 @@ class Akaze:
         lt = np.zeros(tot, np.float32)
         _check(_L().sfmloc_akaze_read_levels(self._h, _ptr(ldet, C.c_float), _ptr(lt, C.c_float)))
         return ldet, lt
+
+    def suppress_stats(self):
+        """The duplicate suppression of the last call (sfmloc_akaze_suppress_stats): counts and in-kernel clocks."""
+        out = np.zeros(9, np.uint32)
+        _check(_L().sfmloc_akaze_suppress_stats(self._h, _ptr(out, C.c_uint32)))
+        names = ("candidates", "keypoints", "rounds", "first_pass_ticks", "second_pass_ticks", "compaction_ticks",
+                 "spilled_ap", "spilled_n", "global_levels")
+        return dict(zip(names, (int(v) for v in out)))
 
     def close(self):
         if self._h is not None:

@@ -1147,6 +1147,8 @@ struct SegScanBody {
       for (int q = 0; q < 16; ++q) total += wsum[q];
       seg_cnt[n_seg] = total;
       *n_out = total;
+      n_out[6] = 0u;  // (k_suppress_nbr counts the spilled records of the frame here)
+      n_out[7] = 0u;
     }
     (void)cap;
   }
@@ -1209,6 +1211,8 @@ struct SegSumBody {
       part[chunks] = 0u;  // the next frame counts from zero
       seg_cnt[n_seg] = all;
       *n_out = all;
+      n_out[6] = 0u;  // (k_suppress_nbr counts the spilled records of the frame here)
+      n_out[7] = 0u;
     }
   }
 };
@@ -1254,9 +1258,9 @@ __global__ __launch_bounds__(1024) void k_seg_scan(unsigned int *__restrict__ se
 
 struct CandArrays {
   uint32_t *xy;           // level coordinates: x | y << 16
-  uint8_t *level;
+  uint8_t *level;         // the level; | 0x80: Do_Subpixel_Refinement rejects the candidate
   float *resp;            // |Ldet| at the candidate
-  float *patch;           // [n x 9] the 3 x 3 neighbourhood
+  float2 *sub;            // the sub-pixel offsets from the candidate's 3 x 3 neighbourhood
 };
 
 struct ExtremaPlaceBody {
@@ -1278,11 +1282,27 @@ struct ExtremaPlaceBody {
       if ((unsigned int)lane >= cnt || base + lane >= cap) continue;
       const int x = (int)sidx * kSegPx + seg_x[(size_t)seg * kSegMax + lane];
       const unsigned int g = base + lane;
-      C.xy[g] = (uint32_t)x | ((uint32_t)y << 16);
-      C.level[g] = (uint8_t)i;
+      float p[9];
       for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) C.patch[(size_t)g * 9 + (dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
-      C.resp[g] = fabsf(D[(size_t)y * w + x]);
+        for (int dx = -1; dx <= 1; ++dx) p[(dy + 1) * 3 + dx + 1] = D[(size_t)(y + dy) * w + x + dx];
+      // Do_Subpixel_Refinement's 2 x 2 system here, where the neighbourhood is at hand and every candidate has a thread
+      const float Dx = 0.5f * (p[5] - p[3]);
+      const float Dy = 0.5f * (p[7] - p[1]);
+      const float Dxx = (p[5] + p[3]) - 2.0f * p[4];
+      const float Dyy = (p[7] + p[1]) - 2.0f * p[4];
+      const float Dxy = 0.25f * (p[8] + p[0]) - 0.25f * (p[2] + p[6]);
+      const float det = Dxx * Dyy - Dxy * Dxy;
+      float d0 = 0.0f, d1 = 0.0f;
+      bool ok = false;
+      if (det != 0.0f) {
+        d0 = (-Dx * Dyy + Dy * Dxy) / det;
+        d1 = (-Dy * Dxx + Dx * Dxy) / det;
+        ok = fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f;
+      }
+      C.xy[g] = (uint32_t)x | ((uint32_t)y << 16);
+      C.level[g] = (uint8_t)(i | (ok ? 0 : 0x80));
+      C.sub[g] = make_float2(d0, d1);
+      C.resp[g] = fabsf(p[4]);
     }
   }
 };
@@ -1293,12 +1313,186 @@ __global__ __launch_bounds__(128) void k_extrema_place(const float *__restrict__
   ExtremaPlaceBody::run(ldet_all, Tp, seg_x, seg_base, cap, C, segs_per_row);
 }
 
+// ---- the suppression's neighbour lists ---------------------------------------------------------------------------------
+// Which candidates CAN interact is geometry, known before any of them is decided; only their statuses change during the
+// passes.  k_suppress_nbr finds, one wave per candidate and over the whole chip, the few candidates each one will ever look
+// at -- A: the earlier candidates of its level within 2 r (they decide when it is ready; those within r are also the only
+// points of its own level it can meet: a later candidate within r is blocked by it and still undecided when it decides),
+// P: the candidates of the previous level within r, N (second pass): the stronger candidates of the next level within r
+// -- with exactly the tests of the scans they replace, so that the one workgroup of k_suppress walks a handful of list
+// entries per candidate and round instead of bands of rows (a round of 1 000 candidates: 9 us of band scans).  A list that
+// does not fit its record (15 entries for A + P, 3 for N) or its 15 / 16-bit offsets is marked "spilled" and k_suppress
+// scans for that candidate as before.
+//   record (16 x u16): [0] = nA | nP << 4 | spilled << 15; A entries = (g - o) | within_r << 15; then P entries = o - p0
+//   record2 (4 x u16): [0] = nN | spilled << 15; N entries = o - n0          (p0 / n0: where the other level starts)
+constexpr int kNbrEntries = 15;
+constexpr int kNbr2Entries = 3;
+struct NbrBody {
+  static constexpr int kGangThreads = 256;
+  static __device__ __forceinline__ void run(const LevelTab *__restrict__ Tp, const unsigned int *__restrict__ seg_base,
+                                             unsigned int spr, unsigned int cap, const unsigned int *__restrict__ n_cand,
+                                             const uint32_t *__restrict__ cxy, const uint8_t *__restrict__ clevel,
+                                             const float *__restrict__ cresp, uint4 *__restrict__ nbr, uint2 *__restrict__ nbr2,
+                                             unsigned int *__restrict__ spilled /*[2] diagnostics*/, unsigned int force_spill) {
+    const LevelTab &T = *Tp;
+    const unsigned int N = min(*n_cand, cap);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned int n_waves = gridDim.x * (kGangThreads / 64);
+    auto row_start = [&](int lv, int yy) -> unsigned int { return min(seg_base[(unsigned int)(T.row0[lv] + yy) * spr], N); };
+    for (unsigned int g = blockIdx.x * (kGangThreads / 64) + (threadIdx.x >> 6); g < N; g += n_waves) {
+      const int l = clevel[g] & 0x7F;
+      const uint32_t me = cxy[g];
+      const int x = (int)(me & 0xFFFFu), y = (int)(me >> 16);
+      const float size = T.ksize[l];
+      const float ratio = (float)(1 << T.octave[l]);
+      const float px = (float)x * ratio, py = (float)y * ratio;
+      uint16_t *rec = reinterpret_cast<uint16_t *>(nbr + 2 * (size_t)g);
+      uint16_t *rec2 = reinterpret_cast<uint16_t *>(nbr2 + g);
+      unsigned int nA = 0, nP = 0, nN = 0;
+      bool spill = false, spill2 = false;
+      {  // A: earlier in raster order -- the rows above within reach, and this row up to the candidate itself
+        const float dep2 = 4.0f * size * size * 1.0001f + 0.01f;   // (2 r)^2 with slack: conservative
+        const int dep = (int)ceilf(2.0f * size / ratio) + 1;
+        const int hit = (int)ceilf(size / ratio) + 1;
+        const unsigned int from = row_start(l, max(y - dep, 0));
+        for (unsigned int o0 = from; o0 < g; o0 += 64) {
+          const unsigned int o = o0 + lane;
+          bool in = false, within = false;
+          if (o < g) {
+            const uint32_t q = cxy[o];
+            const int xo = (int)(q & 0xFFFFu), yo = (int)(q >> 16);
+            const int ddx = x - xo, ddy = y - yo;
+            if (ddx <= dep && ddx >= -dep) {
+              const float dx = (float)ddx * ratio, dy = (float)ddy * ratio;
+              in = dx * dx + dy * dy <= dep2;
+              if (in && ddx <= hit && ddx >= -hit && ddy <= hit) {  // (the band and the box of the decision's own-level scan)
+                const float ex = px - (float)xo * ratio, ey = py - (float)yo * ratio;
+                within = ex * ex + ey * ey <= size * size;
+              }
+            }
+          }
+          const unsigned long long m = __ballot(in);
+          const unsigned int d = g - o;
+          if (in) {
+            const unsigned int pos = nA + (unsigned int)__popcll(m & below);
+            if (pos < (unsigned int)kNbrEntries && d < 32768u) rec[1 + pos] = (uint16_t)(d | (within ? 0x8000u : 0u));
+          }
+          if (__ballot(in && d >= 32768u) != 0ull) spill = true;
+          nA += (unsigned int)__popcll(m);
+        }
+      }
+      if (l > 0) {  // P: the level before
+        const float r1 = (float)(1 << T.octave[l - 1]);
+        const int wp = T.w[l - 1], hp = T.h[l - 1];
+        const int x0 = max((int)floorf((px - size) / r1) - 1, 0), x1 = min((int)ceilf((px + size) / r1) + 1, wp - 1);
+        const int y0 = max((int)floorf((py - size) / r1) - 1, 0), y1 = min((int)ceilf((py + size) / r1) + 1, hp - 1);
+        if (x0 <= x1 && y0 <= y1) {
+          const unsigned int p0 = row_start(l - 1, 0), from = row_start(l - 1, y0), to = row_start(l - 1, y1 + 1);
+          for (unsigned int o0 = from; o0 < to; o0 += 64) {
+            const unsigned int o = o0 + lane;
+            bool in = false;
+            if (o < to) {
+              const uint32_t q = cxy[o];
+              const int xo = (int)(q & 0xFFFFu), yo = (int)(q >> 16);
+              if (xo >= x0 && xo <= x1) {
+                const float dx = px - (float)xo * r1, dy = py - (float)yo * r1;
+                in = dx * dx + dy * dy <= size * size;
+              }
+            }
+            const unsigned long long m = __ballot(in);
+            const unsigned int d = o - p0;
+            if (in) {
+              const unsigned int pos = nA + nP + (unsigned int)__popcll(m & below);
+              if (pos < (unsigned int)kNbrEntries && d < 65536u) rec[1 + pos] = (uint16_t)d;
+            }
+            if (__ballot(in && d >= 65536u) != 0ull) spill = true;
+            nP += (unsigned int)__popcll(m);
+          }
+        }
+      }
+      if (nA + nP > (unsigned int)kNbrEntries || force_spill) spill = true;
+      if (lane == 0) {
+        rec[0] = spill ? (uint16_t)0x8000u : (uint16_t)(nA | (nP << 4));
+        if (spill) atomicAdd(&spilled[0], 1u);
+      }
+      if (l + 1 < T.n) {  // N: the next level, stronger (the second pass)
+        const float rsp = cresp[g];
+        const float rn = (float)(1 << T.octave[l + 1]);
+        const int wn = T.w[l + 1], hn = T.h[l + 1];
+        const int x0 = max((int)floorf((px - size) / rn) - 1, 0), x1 = min((int)ceilf((px + size) / rn) + 1, wn - 1);
+        const int y0 = max((int)floorf((py - size) / rn) - 1, 0), y1 = min((int)ceilf((py + size) / rn) + 1, hn - 1);
+        if (x0 <= x1 && y0 <= y1) {
+          const unsigned int n0 = row_start(l + 1, 0), from = row_start(l + 1, y0), to = row_start(l + 1, y1 + 1);
+          for (unsigned int o0 = from; o0 < to; o0 += 64) {
+            const unsigned int o = o0 + lane;
+            bool in = false;
+            if (o < to) {
+              const uint32_t q = cxy[o];
+              const int xo = (int)(q & 0xFFFFu), yo = (int)(q >> 16);
+              if (xo >= x0 && xo <= x1) {
+                const float dx = px - (float)xo * rn, dy = py - (float)yo * rn;
+                in = dx * dx + dy * dy <= size * size && rsp < cresp[o];
+              }
+            }
+            const unsigned long long m = __ballot(in);
+            const unsigned int d = o - n0;
+            if (in) {
+              const unsigned int pos = nN + (unsigned int)__popcll(m & below);
+              if (pos < (unsigned int)kNbr2Entries && d < 65536u) rec2[1 + pos] = (uint16_t)d;
+            }
+            if (__ballot(in && d >= 65536u) != 0ull) spill2 = true;
+            nN += (unsigned int)__popcll(m);
+          }
+        }
+      }
+      if (nN > (unsigned int)kNbr2Entries || force_spill) spill2 = true;
+      if (lane == 0) {
+        rec2[0] = spill2 ? (uint16_t)0x8000u : (uint16_t)nN;
+        if (spill2) atomicAdd(&spilled[1], 1u);
+      }
+    }
+  }
+};
+__global__ __launch_bounds__(256) void k_suppress_nbr(const LevelTab *__restrict__ Tp, const unsigned int *__restrict__ seg_base,
+                                                      unsigned int spr, unsigned int cap, const unsigned int *__restrict__ n_cand,
+                                                      const uint32_t *__restrict__ cxy, const uint8_t *__restrict__ clevel,
+                                                      const float *__restrict__ cresp, uint4 *__restrict__ nbr,
+                                                      uint2 *__restrict__ nbr2, unsigned int *__restrict__ spilled,
+                                                      unsigned int force_spill) {
+  NbrBody::run(Tp, seg_base, spr, cap, n_cand, cxy, clevel, cresp, nbr, nbr2, spilled, force_spill);
+}
+// a record in registers: its u16 are taken from the bottom, one at a time (the whole record moves down 16 bits: indexing
+// registers by a run-time number would put the record into scratch memory, and unrolling the walks by 15 made the
+// kernel 17 000 instructions that spilled)
+struct NbrRec {
+  uint32_t w[8];
+  __device__ __forceinline__ void load(const uint4 *p) {
+    const uint4 a = p[0], b = p[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  }
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = 0u;
+  }
+  __device__ __forceinline__ uint32_t pop() {
+    const uint32_t e = w[0] & 0xFFFFu;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) w[j] = (w[j] >> 16) | (w[j + 1] << 16);
+    w[7] >>= 16;
+    return e;
+  }
+};
+
 struct SuppressArgs {
   const LevelTab *T;
   const unsigned int *seg_base;  // [n_seg + 1]
   unsigned int segs_per_row;     // 64-pixel segments of an image row (2 x ceil(width / 128))
   unsigned int cap;
   CandArrays C;
+  const uint4 *nbr;              // [cap x 2] k_suppress_nbr: the A and P lists
+  const uint2 *nbr2;             // [cap] the N lists
   uint8_t *status;               // per candidate: 0 undecided, 1 holds a point of the list, 2 dropped, 3 taken over
   uint8_t *ready;
   unsigned int *key;             // the list position a candidate holds (raster index of the candidate appended there)
@@ -1308,158 +1502,242 @@ struct SuppressArgs {
   unsigned int *n_kp;            // out
   unsigned int *n_cand;          // in (k_seg_scan)
   unsigned int *rounds_out;      // diagnostics: rounds the first pass took over all levels
+  unsigned int force_global;     // test hook: every level out of the global arrays (the form of a level above kSupLevelCap)
 };
 
 enum : uint8_t { kUndecided = 0, kHolds = 1, kDropped = 2, kTakenOver = 3 };
 
-// The first pass works out of LDS: per level the row starts (raster index of a row's first candidate), the packed
-// coordinates and the status bytes of the level and of the one before it; a band of rows is ONE contiguous index range.
-// A level with more candidates than the LDS arrays hold works on the global arrays through the same pointers.
+// The first pass works out of LDS: one packed word per candidate -- x | y << 12 | status << 24: a status is its own byte
+// (ds_write_b8), and a spilled candidate's scan fetches FOUR neighbours with one ds_read_b128 -- and the keys and
+// responses, of the level and of the one before it, plus the row starts (raster index of a row's first candidate; a band
+// of rows is ONE contiguous index range) for the spilled candidates' scans.  A level with more candidates than the LDS
+// arrays hold, or wider than 12 bits of x, works on the global arrays through the same code.
 constexpr int kSupMaxRows = 4096 + 1;  // level rows the row-start tables hold (sfmloc_akaze_create: height <= 4096)
 constexpr int kSupLevelCap = 4096;     // candidates of one level kept in LDS
+constexpr int kSupOwn = kSupLevelCap / 1024;  // candidates of an LDS level per thread: their records stay in registers
+constexpr int kSupMaxW = 4096;         // level width the packed word holds
 struct SuppressLds {
-  unsigned int row[2][kSupMaxRows];
-  uint32_t xy[2][kSupLevelCap];
+  alignas(16) uint32_t pk[2][kSupLevelCap];
   unsigned int key[2][kSupLevelCap];
   float resp[2][kSupLevelCap];
-  uint8_t st[2][kSupLevelCap];
-  uint8_t ready[kSupLevelCap];
+  unsigned int row[2][kSupMaxRows];
   unsigned int lvl[kMaxLevels + 1];   // where each level starts in the raster-ordered list
   unsigned int left[2];
   unsigned int wsum[16];
 };
-
 struct SuppressBody {
   static constexpr int kGangThreads = 1024;
 
-  // One level of the first pass.  CL / PL: this level's / the previous level's coordinates and status bytes are in LDS
-  // (slot b / b ^ 1, indexed by raster index minus c0 / p0) or in the global arrays -- compile-time, so that the LDS form
-  // is ds_read / ds_write and not a generic (flat) access, which costs a global-memory round trip even when it lands in LDS.
+  // candidates [from, to) of a level, four per step: f(o, x, y, status) -> true ends the scan.  LDS: the level's packed
+  // words (slot pk, index = raster index - base); otherwise the global arrays.
+  template <bool LDS, class F>
+  static __device__ __forceinline__ void scan(const SuppressArgs &A, const uint32_t *pk, unsigned int base, unsigned int from,
+                                              unsigned int to, F &&f) {
+    if (LDS) {
+      for (unsigned int o4 = base + ((from - base) & ~3u); o4 < to; o4 += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(pk + (o4 - base));
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned int o = o4 + u;
+          if (o < from || o >= to) continue;
+          if (f(o, (int)(q[u] & 0xFFFu), (int)((q[u] >> 12) & 0xFFFu), (uint8_t)(q[u] >> 24))) stop = true;
+        }
+        if (stop) break;
+      }
+    } else {
+      for (unsigned int o4 = from; o4 < to; o4 += 4) {
+        uint32_t q[4];
+        uint8_t sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // (the loads of a step issued together: the scan is a chain of latencies otherwise)
+          const unsigned int o = min(o4 + u, to - 1);
+          q[u] = A.C.xy[o];
+          sv[u] = A.status[o];
+        }
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned int o = o4 + u;
+          if (o >= to) continue;
+          if (f(o, (int)(q[u] & 0xFFFFu), (int)(q[u] >> 16), sv[u])) stop = true;
+        }
+        if (stop) break;
+      }
+    }
+  }
+
+  // One level of the first pass.  CL / PL: this level's / the previous level's tables are in LDS (slot b / b ^ 1, indexed
+  // by raster index minus c0 / p0) or in the global arrays -- compile-time, so that the LDS form is ds_read / ds_write and
+  // not a generic (flat) access, which costs a global-memory round trip even when it lands in LDS.  rc: the records of
+  // this thread's candidates (LDS form; the global form reads them as it goes).
   template <bool CL, bool PL>
   static __device__ __forceinline__ void level(const SuppressArgs &A, const LevelTab &T, SuppressLds &L, int l, int b,
-                                               unsigned int c0, unsigned int c1, unsigned int p0, unsigned int &rounds) {
+                                               unsigned int c0, unsigned int c1, unsigned int p0, unsigned int &rounds,
+                                               const NbrRec (&rc)[kSupOwn]) {
     const int tid = threadIdx.x;
     const int h = T.h[l];
     const unsigned int *R = L.row[b], *Rp = L.row[b ^ 1];
-    auto xy_c = [&](unsigned int g) -> uint32_t { return CL ? L.xy[b][g - c0] : A.C.xy[g]; };
-    auto st_c = [&](unsigned int g) -> uint8_t & { return CL ? L.st[b][g - c0] : A.status[g]; };
-    auto rd_c = [&](unsigned int g) -> uint8_t & { return CL ? L.ready[g - c0] : A.ready[g]; };
-    auto xy_p = [&](unsigned int g) -> uint32_t { return PL ? L.xy[b ^ 1][g - p0] : A.C.xy[g]; };
-    auto st_p = [&](unsigned int g) -> uint8_t & { return PL ? L.st[b ^ 1][g - p0] : A.status[g]; };
-    auto key_c = [&](unsigned int g) -> unsigned int & { return CL ? L.key[b][g - c0] : A.key[g]; };
-    auto key_p = [&](unsigned int g) -> unsigned int { return PL ? L.key[b ^ 1][g - p0] : A.key[g]; };
-    auto rsp_c = [&](unsigned int g) -> float { return CL ? L.resp[b][g - c0] : A.C.resp[g]; };
-    auto rsp_p = [&](unsigned int g) -> float { return PL ? L.resp[b ^ 1][g - p0] : A.C.resp[g]; };
+    const uint32_t *pk_c = L.pk[b], *pk_p = L.pk[b ^ 1];
+    auto st_c = [&](unsigned int g) __attribute__((always_inline)) -> uint8_t & {
+      return CL ? reinterpret_cast<uint8_t *>(&L.pk[b][g - c0])[3] : A.status[g];
+    };
+    auto st_p = [&](unsigned int g) __attribute__((always_inline)) -> uint8_t & {
+      return PL ? reinterpret_cast<uint8_t *>(&L.pk[b ^ 1][g - p0])[3] : A.status[g];
+    };
+    auto key_c = [&](unsigned int g) __attribute__((always_inline)) -> unsigned int & { return CL ? L.key[b][g - c0] : A.key[g]; };
+    auto key_p = [&](unsigned int g) __attribute__((always_inline)) -> unsigned int { return PL ? L.key[b ^ 1][g - p0] : A.key[g]; };
+    auto rsp_c = [&](unsigned int g) __attribute__((always_inline)) -> float { return CL ? L.resp[b][g - c0] : A.C.resp[g]; };
+    auto rsp_p = [&](unsigned int g) __attribute__((always_inline)) -> float { return PL ? L.resp[b ^ 1][g - p0] : A.C.resp[g]; };
+    // a thread's own candidate: coordinates and status
+    auto own = [&](unsigned int g, int &x, int &y) __attribute__((always_inline)) -> uint8_t {
+      if (CL) {
+        const uint32_t w = L.pk[b][g - c0];
+        x = (int)(w & 0xFFFu);
+        y = (int)((w >> 12) & 0xFFFu);
+        return (uint8_t)(w >> 24);
+      }
+      const uint32_t me = A.C.xy[g];
+      x = (int)(me & 0xFFFFu);
+      y = (int)(me >> 16);
+      return A.status[g];
+    };
+    // this thread's candidates in turn: f(g, record, k); k = which of the thread's (compile-time in the LDS form).  (A macro
+    // and not a function that takes f: a closure handed on as an argument kept everything it captures in scratch memory.)
+#define SFM_FOR_OWN(f)                                                   \
+  if constexpr (CL) {                                                    \
+    _Pragma("unroll") for (int k = 0; k < kSupOwn; ++k) {                \
+      const unsigned int g = c0 + tid + 1024u * k;                       \
+      if (g < c1) f(g, rc[k], k);                                        \
+    }                                                                    \
+  } else {                                                               \
+    for (unsigned int g = c0 + tid; g < c1; g += 1024) {                 \
+      NbrRec r;                                                          \
+      r.load(A.nbr + 2 * (size_t)g);                                     \
+      f(g, r, 0);                                                        \
+    }                                                                    \
+  }
     const float size = T.ksize[l];
     const float ratio = (float)(1 << T.octave[l]);
     const float dep2 = 4.0f * size * size * 1.0001f + 0.01f;   // (2 r)^2 with slack: conservative
     const int dep = (int)ceilf(2.0f * size / ratio) + 1;
     const int hit = (int)ceilf(size / ratio) + 1;
     const float r1 = l > 0 ? (float)(1 << T.octave[l - 1]) : 1.0f;
+    const int wp = l > 0 ? T.w[l - 1] : 0, hp = l > 0 ? T.h[l - 1] : 0;
+    const int lane = tid & 63;
+    unsigned long long ta = 0, tb = 0;
     for (; c0 != c1;) {
-      // (a) who is ready: no earlier undecided candidate of this level within 2 r; how many are undecided at all
-      unsigned int undecided = 0;
-      for (unsigned int g = c0 + tid; g < c1; g += 1024) {
-        if (st_c(g) != kUndecided) continue;
+      const unsigned long long t0 = wall_clock64();
+      // (a) who is ready: no earlier undecided candidate of this level within 2 r (its A list); is anybody undecided at all
+      // (the LDS form keeps a thread's "ready" bits in a register)
+      unsigned int undecided = 0, ready_bits = 0;
+      auto phase_a = [&](unsigned int g, const NbrRec &r, int k) __attribute__((always_inline)) {
+        int x, y;
+        if (own(g, x, y) != kUndecided) return;
         ++undecided;
-        const uint32_t me = xy_c(g);
-        const int x = (int)(me & 0xFFFFu), y = (int)(me >> 16);
         bool blocked = false;
-        // earlier in raster order: the rows above within reach, and this row up to the candidate itself
-        const unsigned int from = R[max(y - dep, 0)];
-        // (four neighbours per step, their loads issued together: the scan is a chain of LDS latencies otherwise)
-        for (unsigned int o4 = from; o4 < g && !blocked; o4 += 4) {
-          uint32_t q[4];
-          uint8_t sv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const unsigned int o = min(o4 + u, g - 1);
-            q[u] = xy_c(o);
-            sv[u] = st_c(o);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (o4 + u >= g) continue;
-            const int ddx = x - (int)(q[u] & 0xFFFFu), ddy = y - (int)(q[u] >> 16);
-            if (ddx > dep || ddx < -dep || sv[u] != kUndecided) continue;
+        NbrRec t = r;
+        const uint32_t hd = t.pop();
+        if (hd & 0x8000u) {  // spilled: the rows above within reach, and this row up to the candidate itself
+          scan<CL>(A, pk_c, c0, R[max(y - dep, 0)], g, [&](unsigned int, int xo, int yo, uint8_t sv) __attribute__((always_inline)) -> bool {
+            const int ddx = x - xo, ddy = y - yo;
+            if (ddx > dep || ddx < -dep || sv != kUndecided) return false;
             const float dx = (float)ddx * ratio, dy = (float)ddy * ratio;
             if (dx * dx + dy * dy <= dep2) blocked = true;
+            return blocked;
+          });
+        } else {
+          const int nA = (int)(hd & 15u);
+          for (int i = 0; __ballot(i < nA) != 0ull; ++i) {  // (as many steps as the longest list of the lanes that are here)
+            const uint32_t e = t.pop();
+            const unsigned int o = g - (i < nA ? (e & 0x7FFFu) : 0u);
+            const uint8_t sv = st_c(o);
+            if (i < nA && sv == kUndecided) blocked = true;
           }
         }
-        rd_c(g) = blocked ? 0 : 1;
-      }
-      if (undecided) atomicAdd(&L.left[rounds & 1], undecided);
+        if (CL) ready_bits |= (blocked ? 0u : 1u) << k;
+        else A.ready[g] = blocked ? 0 : 1;
+      };
+      SFM_FOR_OWN(phase_a)
+      // (one plain store per wave that has an undecided candidate: only "none left" is asked)
+      if (__ballot(undecided != 0) != 0ull && lane == 0) L.left[rounds & 1] = 1u;
       if (tid == 0) L.left[(rounds + 1) & 1] = 0u;
       __syncthreads();
+      const unsigned long long t1 = wall_clock64();
+      ta += t1 - t0;
       if (L.left[rounds & 1] == 0u) {
         ++rounds;
         break;
       }
-      // (b) the ready ones decide
+      // (b) the ready ones decide: the first point of the list (lowest key) among the holders within r -- of this level
+      // (A entries marked "within r") and of the level before (P entries)
       // (tried in round 3: counting the decided candidates so that a round which decides everything ends the level --
       // 33 -> 20 rounds on a sparse VGA frame, 34 -> 23 on a rich one -- and measured SLOWER, 77 -> 90 us and 250 -> 260 us:
       // the closing round that finds nothing left costs less than the count's LDS atomics and the second exit cost every
       // other round)
-      for (unsigned int g = c0 + tid; g < c1; g += 1024) {
-        if (st_c(g) != kUndecided || !rd_c(g)) continue;
-        const uint32_t me = xy_c(g);
-        const int x = (int)(me & 0xFFFFu), y = (int)(me >> 16);
+      auto phase_b = [&](unsigned int g, const NbrRec &r, int k) __attribute__((always_inline)) {
+        int x, y;
+        if (own(g, x, y) != kUndecided) return;
+        if (CL ? !((ready_bits >> k) & 1u) : !A.ready[g]) return;
         const float px = (float)x * ratio, py = (float)y * ratio;
         unsigned int first = 0xFFFFFFFFu, first_key = 0xFFFFFFFFu;
-        {  // this level: the band of rows within r
-          const unsigned int from = R[max(y - hit, 0)], to = R[min(y + hit, h - 1) + 1];
-          for (unsigned int o4 = from; o4 < to; o4 += 4) {
-            uint32_t q[4];
-            uint8_t sv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const unsigned int o = min(o4 + u, to - 1);
-              q[u] = xy_c(o);
-              sv[u] = st_c(o);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const unsigned int o = o4 + u;
-              const int ddx = x - (int)(q[u] & 0xFFFFu);
-              if (o >= to || ddx > hit || ddx < -hit || o == g || sv[u] != kHolds) continue;
-              const float dx = px - (float)(q[u] & 0xFFFFu) * ratio, dy = py - (float)(q[u] >> 16) * ratio;
-              if (dx * dx + dy * dy <= size * size) {
-                const unsigned int ko = key_c(o);
-                if (ko < first_key) {
-                  first_key = ko;
-                  first = o;
-                }
+        NbrRec t = r;
+        const uint32_t hd = t.pop();
+        if (hd & 0x8000u) {  // spilled: the bands of rows within r
+          scan<CL>(A, pk_c, c0, R[max(y - hit, 0)], R[min(y + hit, h - 1) + 1], [&](unsigned int o, int xo, int yo, uint8_t sv) __attribute__((always_inline)) -> bool {
+            const int ddx = x - xo;
+            if (ddx > hit || ddx < -hit || o == g || sv != kHolds) return false;
+            const float dx = px - (float)xo * ratio, dy = py - (float)yo * ratio;
+            if (dx * dx + dy * dy <= size * size) {
+              const unsigned int ko = key_c(o);
+              if (ko < first_key) {
+                first_key = ko;
+                first = o;
               }
             }
-          }
-        }
-        if (l > 0) {  // the level before
-          const int wp = T.w[l - 1], hp = T.h[l - 1];
-          const int x0 = max((int)floorf((px - size) / r1) - 1, 0), x1 = min((int)ceilf((px + size) / r1) + 1, wp - 1);
-          const int y0 = max((int)floorf((py - size) / r1) - 1, 0), y1 = min((int)ceilf((py + size) / r1) + 1, hp - 1);
-          if (x0 <= x1 && y0 <= y1) {
-            const unsigned int from = Rp[y0], to = Rp[y1 + 1];
-            for (unsigned int o4 = from; o4 < to; o4 += 4) {
-              uint32_t q[4];
-              uint8_t sv[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const unsigned int o = min(o4 + u, to - 1);
-                q[u] = xy_p(o);
-                sv[u] = st_p(o);
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const unsigned int o = o4 + u;
-                const int xo = (int)(q[u] & 0xFFFFu);
-                if (o >= to || xo < x0 || xo > x1 || sv[u] != kHolds) continue;
-                const float dx = px - (float)xo * r1, dy = py - (float)(q[u] >> 16) * r1;
+            return false;
+          });
+          if (l > 0) {  // the level before
+            const int x0 = max((int)floorf((px - size) / r1) - 1, 0), x1 = min((int)ceilf((px + size) / r1) + 1, wp - 1);
+            const int y0 = max((int)floorf((py - size) / r1) - 1, 0), y1 = min((int)ceilf((py + size) / r1) + 1, hp - 1);
+            if (x0 <= x1 && y0 <= y1) {
+              scan<PL>(A, pk_p, p0, Rp[y0], Rp[y1 + 1], [&](unsigned int o, int xo, int yo, uint8_t sv) __attribute__((always_inline)) -> bool {
+                if (xo < x0 || xo > x1 || sv != kHolds) return false;
+                const float dx = px - (float)xo * r1, dy = py - (float)yo * r1;
                 if (dx * dx + dy * dy <= size * size) {
                   const unsigned int ko = key_p(o);
                   if (ko < first_key) {
                     first_key = ko;
                     first = o;
                   }
+                }
+                return false;
+              });
+            }
+          }
+        } else {
+          const int nA = (int)(hd & 15u), nAP = nA + (int)((hd >> 4) & 15u);
+          for (int i = 0; __ballot(i < nAP) != 0ull; ++i) {
+            const uint32_t e = t.pop();
+            if (i < nA) {
+              if (e & 0x8000u) {
+                const unsigned int o = g - (e & 0x7FFFu);
+                if (st_c(o) == kHolds) {
+                  const unsigned int ko = key_c(o);
+                  if (ko < first_key) {
+                    first_key = ko;
+                    first = o;
+                  }
+                }
+              }
+            } else if (i < nAP) {
+              const unsigned int o = p0 + e;
+              if (st_p(o) == kHolds) {
+                const unsigned int ko = key_p(o);
+                if (ko < first_key) {
+                  first_key = ko;
+                  first = o;
                 }
               }
             }
@@ -1475,15 +1753,22 @@ struct SuppressBody {
         } else {
           st_c(g) = kDropped;
         }
-      }
+      };
+      SFM_FOR_OWN(phase_b)
       ++rounds;
       __syncthreads();
+      tb += wall_clock64() - t1;
     }
+    if (tid == 0 && A.rounds_out) {  // diagnostics: 10 ns ticks of the level's (a) and (b) phases
+      A.rounds_out[80 + 2 * l] = (unsigned int)ta;
+      A.rounds_out[81 + 2 * l] = (unsigned int)tb;
+    }
+#undef SFM_FOR_OWN
   }
 
   static __device__ __forceinline__ void run(SuppressArgs A) {
     const LevelTab &T = *A.T;
-    extern __shared__ unsigned char sup_smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sup_smem[];
     SuppressLds &L = *reinterpret_cast<SuppressLds *>(sup_smem);
     const int tid = threadIdx.x;
     const unsigned int N = min(*A.n_cand, A.cap);
@@ -1492,7 +1777,7 @@ struct SuppressBody {
       A.key[g] = g;
       A.slot[g] = -1;
     }
-    unsigned int rounds = 0;
+    unsigned int rounds = 0, global_levels = 0;
     const unsigned long long t_start = wall_clock64();
     if (tid < 2) L.left[tid] = 0u;
     if (tid <= T.n) L.lvl[tid] = min(A.seg_base[(unsigned int)T.row0[tid] * A.segs_per_row], N);
@@ -1506,32 +1791,42 @@ struct SuppressBody {
       const int b = l & 1;
       const int h = T.h[l];
       // the level's extent straight from the segment table (every thread the same two loads: no barrier in front of the
-      // fills), then row starts and coordinates under ONE barrier
+      // fills), then row starts, coordinates and the candidates' neighbour records under ONE barrier
       const unsigned long long t_l0 = wall_clock64();
       const unsigned int rounds_before = rounds;
       const unsigned int c0 = L.lvl[l], c1 = L.lvl[l + 1];
       for (int y = tid; y <= h; y += 1024) L.row[b][y] = min(A.seg_base[(unsigned int)(T.row0[l] + y) * A.segs_per_row], N);
-      const bool in_lds = c1 - c0 <= (unsigned int)kSupLevelCap;
-      if (in_lds)
-        for (unsigned int g = c0 + tid; g < c1; g += 1024) {
-          L.xy[b][g - c0] = A.C.xy[g];
-          L.resp[b][g - c0] = A.C.resp[g];
-          L.key[b][g - c0] = g;
-          L.st[b][g - c0] = kUndecided;
+      const bool in_lds = c1 - c0 <= (unsigned int)kSupLevelCap && T.w[l] <= kSupMaxW && !A.force_global;
+      if (!in_lds && c1 != c0) ++global_levels;
+      NbrRec rc[kSupOwn];
+      if (in_lds) {
+#pragma unroll
+        for (int k = 0; k < kSupOwn; ++k) {
+          const unsigned int g = c0 + tid + 1024u * k;
+          if (g < c1) {
+            const uint32_t me = A.C.xy[g];
+            L.pk[b][g - c0] = (me & 0xFFFu) | ((me >> 16) << 12) | ((uint32_t)kUndecided << 24);
+            L.resp[b][g - c0] = A.C.resp[g];
+            L.key[b][g - c0] = g;
+            rc[k].load(A.nbr + 2 * (size_t)g);
+          } else {
+            rc[k].clear();
+          }
         }
+      }
       __syncthreads();
       const unsigned long long t_l1 = wall_clock64();
       if (in_lds) {
-        if (prev_lds) level<true, true>(A, T, L, l, b, c0, c1, p0, rounds);
-        else level<true, false>(A, T, L, l, b, c0, c1, p0, rounds);
+        if (prev_lds) level<true, true>(A, T, L, l, b, c0, c1, p0, rounds, rc);
+        else level<true, false>(A, T, L, l, b, c0, c1, p0, rounds, rc);
       } else {
-        if (prev_lds) level<false, true>(A, T, L, l, b, c0, c1, p0, rounds);
-        else level<false, false>(A, T, L, l, b, c0, c1, p0, rounds);
+        if (prev_lds) level<false, true>(A, T, L, l, b, c0, c1, p0, rounds, rc);
+        else level<false, false>(A, T, L, l, b, c0, c1, p0, rounds, rc);
       }
       // the previous level is final now: its statuses go back to the global array (the second pass reads them there)
       if (prev_lds)
         for (unsigned int g = p0 + tid; g < p1; g += 1024) {
-          A.status[g] = L.st[b ^ 1][g - p0];
+          A.status[g] = (uint8_t)(L.pk[b ^ 1][g - p0] >> 24);
           A.key[g] = L.key[b ^ 1][g - p0];
         }
       const unsigned long long t_l2 = wall_clock64();
@@ -1549,57 +1844,55 @@ struct SuppressBody {
     }
     if (prev_lds)  // ... and the last level's
       for (unsigned int g = p0 + tid; g < p1; g += 1024) {
-        A.status[g] = L.st[(T.n - 1) & 1][g - p0];
+        A.status[g] = (uint8_t)(L.pk[(T.n - 1) & 1][g - p0] >> 24);
         A.key[g] = L.key[(T.n - 1) & 1][g - p0];
       }
     __syncthreads();
     const unsigned long long t_pass1 = wall_clock64();
-    // ---- second pass: a point with a stronger point of the NEXT level within its radius, further down the list ----
+    // ---- second pass: a point with a stronger point of the NEXT level within its radius, further down the list (its N
+    // list), is dropped; the survivors that Do_Subpixel_Refinement accepts take their places: slot[key] = the candidate ----
     for (unsigned int g = tid; g < N; g += 1024) {
       if (A.status[g] != kHolds) continue;
-      const int l = A.C.level[g];
+      const uint8_t lv = A.C.level[g];
+      if (lv & 0x80) continue;  // (rejected by the sub-pixel step whatever the second pass says)
+      const int l = lv & 0x7F;
       bool rep = false;
       if (l + 1 < T.n) {
-        const uint32_t me = A.C.xy[g];
-        const float size = T.ksize[l], ratio = (float)(1 << T.octave[l]);
-        const float px = (float)(me & 0xFFFFu) * ratio, py = (float)(me >> 16) * ratio, rsp = A.C.resp[g];
         const unsigned int kg = A.key[g];
-        const float rn = (float)(1 << T.octave[l + 1]);
-        const int wn = T.w[l + 1], hn = T.h[l + 1];
-        const int x0 = max((int)floorf((px - size) / rn) - 1, 0), x1 = min((int)ceilf((px + size) / rn) + 1, wn - 1);
-        const int y0 = max((int)floorf((py - size) / rn) - 1, 0), y1 = min((int)ceilf((py + size) / rn) + 1, hn - 1);
-        if (x0 <= x1 && y0 <= y1) {
-          const unsigned int from = min(A.seg_base[(unsigned int)(T.row0[l + 1] + y0) * A.segs_per_row], N);
-          const unsigned int to = min(A.seg_base[(unsigned int)(T.row0[l + 1] + y1 + 1) * A.segs_per_row], N);
-          for (unsigned int o = from; o < to; ++o) {
-            const uint32_t q = A.C.xy[o];
-            const int xo = (int)(q & 0xFFFFu);
-            if (xo < x0 || xo > x1 || A.status[o] != kHolds || A.key[o] <= kg) continue;
-            const float dx = px - (float)xo * rn, dy = py - (float)(q >> 16) * rn;
-            if (dx * dx + dy * dy <= size * size && rsp < A.C.resp[o]) rep = true;
+        const uint2 r2 = A.nbr2[g];
+        if (r2.x & 0x8000u) {  // spilled: the band of rows
+          const uint32_t me = A.C.xy[g];
+          const float size = T.ksize[l], ratio = (float)(1 << T.octave[l]);
+          const float px = (float)(me & 0xFFFFu) * ratio, py = (float)(me >> 16) * ratio, rsp = A.C.resp[g];
+          const float rn = (float)(1 << T.octave[l + 1]);
+          const int wn = T.w[l + 1], hn = T.h[l + 1];
+          const int x0 = max((int)floorf((px - size) / rn) - 1, 0), x1 = min((int)ceilf((px + size) / rn) + 1, wn - 1);
+          const int y0 = max((int)floorf((py - size) / rn) - 1, 0), y1 = min((int)ceilf((py + size) / rn) + 1, hn - 1);
+          if (x0 <= x1 && y0 <= y1) {
+            const unsigned int from = min(A.seg_base[(unsigned int)(T.row0[l + 1] + y0) * A.segs_per_row], N);
+            const unsigned int to = min(A.seg_base[(unsigned int)(T.row0[l + 1] + y1 + 1) * A.segs_per_row], N);
+            for (unsigned int o = from; o < to; ++o) {
+              const uint32_t q = A.C.xy[o];
+              const int xo = (int)(q & 0xFFFFu);
+              if (xo < x0 || xo > x1 || A.status[o] != kHolds || A.key[o] <= kg) continue;
+              const float dx = px - (float)xo * rn, dy = py - (float)(q >> 16) * rn;
+              if (dx * dx + dy * dy <= size * size && rsp < A.C.resp[o]) rep = true;
+            }
+          }
+        } else {
+          const unsigned int nN = r2.x & 3u, n0 = L.lvl[l + 1];
+          const unsigned int e[kNbr2Entries] = {r2.x >> 16, r2.y & 0xFFFFu, r2.y >> 16};
+#pragma unroll
+          for (int i = 0; i < kNbr2Entries; ++i) {
+            const unsigned int o = (unsigned int)i < nN ? n0 + e[i] : g;  // (own: holds, key not above its own)
+            if (A.status[o] == kHolds && A.key[o] > kg) rep = true;
           }
         }
       }
-      A.ready[g] = rep ? 1 : 0;  // (reused: "repeated")
+      if (!rep) A.slot[A.key[g]] = (int)g;
     }
     __syncthreads();
     const unsigned long long t_pass2 = wall_clock64();
-    // ---- Do_Subpixel_Refinement on the survivors; slot[key] = the candidate, or -1 ----
-    for (unsigned int g = tid; g < N; g += 1024) {
-      if (A.status[g] != kHolds || A.ready[g]) continue;
-      const float *p = A.C.patch + (size_t)g * 9;
-      const float Dx = 0.5f * (p[5] - p[3]);
-      const float Dy = 0.5f * (p[7] - p[1]);
-      const float Dxx = (p[5] + p[3]) - 2.0f * p[4];
-      const float Dyy = (p[7] + p[1]) - 2.0f * p[4];
-      const float Dxy = 0.25f * (p[8] + p[0]) - 0.25f * (p[2] + p[6]);
-      const float det = Dxx * Dyy - Dxy * Dxy;
-      if (det == 0.0f) continue;
-      const float d0 = (-Dx * Dyy + Dy * Dxy) / det;
-      const float d1 = (-Dy * Dxx + Dx * Dxy) / det;
-      if (fabsf(d0) <= 1.0f && fabsf(d1) <= 1.0f) A.slot[A.key[g]] = (int)g;
-    }
-    __syncthreads();
     // ---- ordered compaction over the keys: a wave per contiguous chunk, as k_seg_scan ----
     const int lane = tid & 63, wv = tid >> 6;
     const unsigned int chunk = ((N + 15u) / 16u + 63u) & ~63u;
@@ -1617,20 +1910,12 @@ struct SuppressBody {
       const unsigned long long m = __ballot(g >= 0);
       if (g >= 0) {
         const unsigned int pos = carry + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-        const int l = A.C.level[g];
+        const int l = A.C.level[g] & 0x7F;
         const uint32_t me = A.C.xy[g];
         const float ratio = (float)(1 << T.octave[l]);
-        const float *p = A.C.patch + (size_t)g * 9;
-        const float Dx = 0.5f * (p[5] - p[3]);
-        const float Dy = 0.5f * (p[7] - p[1]);
-        const float Dxx = (p[5] + p[3]) - 2.0f * p[4];
-        const float Dyy = (p[7] + p[1]) - 2.0f * p[4];
-        const float Dxy = 0.25f * (p[8] + p[0]) - 0.25f * (p[2] + p[6]);
-        const float det = Dxx * Dyy - Dxy * Dxy;
-        const float d0 = (-Dx * Dyy + Dy * Dxy) / det;
-        const float d1 = (-Dy * Dxx + Dx * Dxy) / det;
-        A.kp[4 * pos] = ((float)(me & 0xFFFFu) + d0) * ratio;
-        A.kp[4 * pos + 1] = ((float)(me >> 16) + d1) * ratio;
+        const float2 d = A.C.sub[g];
+        A.kp[4 * pos] = ((float)(me & 0xFFFFu) + d.x) * ratio;
+        A.kp[4 * pos + 1] = ((float)(me >> 16) + d.y) * ratio;
         A.kp[4 * pos + 2] = T.ksize[l] * 2.0f;
         A.kp[4 * pos + 3] = (float)l;
         A.resp_out[pos] = A.C.resp[g];
@@ -1641,6 +1926,7 @@ struct SuppressBody {
       unsigned int total = 0;
       for (int q = 0; q < 16; ++q) total += L.wsum[q];
       *A.n_kp = total;
+      if (A.rounds_out) A.rounds_out[6] = global_levels;
       if (A.rounds_out) {  // diagnostics (SFMLOC_AKAZE_TIMING): rounds, then 10 ns ticks of the first pass, the second, the rest
         A.rounds_out[0] = rounds;
         A.rounds_out[1] = (unsigned int)(t_pass1 - t_start);
@@ -1869,7 +2155,8 @@ struct Akaze : GangMember {  // (gang.h: `stream` reads as the stream to queue o
   void *d_level_tab = nullptr;                // the LevelTab of this image size (the all-level kernels read it by pointer)
   void *d_dev_levels = nullptr;               // the DevLevels of this extractor (k_orient_describe reads it by pointer)
   // detection tail (k_extrema_seg .. k_suppress): the raster-ordered candidate list and the suppression's state
-  unsigned int *d_ncand = nullptr;            // [0] candidates, [1] keypoints, [2] rounds of the first pass
+  unsigned int *d_ncand = nullptr;            // [0] candidates, [1] keypoints, [2] rounds of the first pass, [3..5] clocks,
+                                              // [6] spilled A/P records, [7] spilled N records, [8] levels out of global arrays
   unsigned int cand_cap = 1u << 16;
   unsigned int n_seg = 0, segs_per_row = 0;
   unsigned int *d_seg = nullptr;              // [n_seg + 1] counts, then (k_seg_scan) where each segment starts
@@ -1877,7 +2164,11 @@ struct Akaze : GangMember {  // (gang.h: `stream` reads as the stream to queue o
   uint8_t *d_seg_x = nullptr;                 // [n_seg x kSegMax]
   uint32_t *d_cxy = nullptr;
   uint8_t *d_clevel = nullptr, *d_cstatus = nullptr, *d_cready = nullptr;
-  float *d_cresp = nullptr, *d_cpatch = nullptr;
+  float *d_cresp = nullptr;
+  float2 *d_csub = nullptr;
+  unsigned int sup_force_spill = 0, sup_force_global = 0;  // test hooks (SFMLOC_AKAZE_SUPPRESS, read when the extractor is made)
+  uint4 *d_nbr = nullptr;                     // [cand_cap x 2] k_suppress_nbr: the A and P lists
+  uint2 *d_nbr2 = nullptr;                    // [cand_cap] the N lists
   unsigned int *d_ckey = nullptr;
   int *d_cslot = nullptr;
   float *d_resp = nullptr, *d_kp6 = nullptr;  // per keypoint: response; the six-float records of the C ABI
@@ -2249,7 +2540,7 @@ void sfmloc_akaze_destroy(sfmloc_akaze *ak) {
   void *ptrs[] = {a->d_gray, a->d_img, a->d_t0, a->d_t1, a->d_t2, a->d_t3, a->d_Lt, a->d_Lsmooth, a->d_Lx, a->d_Ly,
                   a->d_Ldet, a->d_hist, a->d_kcontrast, a->d_half_steps, a->d_level_tab, a->d_dev_levels, a->d_ncand,
                   a->d_gauss25, a->d_win, a->d_pair, a->d_kp, a->d_angle, a->d_desc, a->d_seg, a->d_seg_part, a->d_seg_x, a->d_cxy,
-                  a->d_clevel, a->d_cstatus, a->d_cready, a->d_cresp, a->d_cpatch, a->d_ckey, a->d_cslot, a->d_resp, a->d_kp6, a->d_qkpt, a->d_qkpt6};
+                  a->d_clevel, a->d_cstatus, a->d_cready, a->d_cresp, a->d_csub, a->d_nbr, a->d_nbr2, a->d_ckey, a->d_cslot, a->d_resp, a->d_kp6, a->d_qkpt, a->d_qkpt6};
   for (void *p : ptrs)
     if (p) hipFree(p);
   if (a->h_counts) hipHostFree(a->h_counts);
@@ -2317,7 +2608,13 @@ int sfmloc_akaze_create(int device, int width, int height, int n_octaves, int n_
   A((void **)&a->d_cstatus, cc);
   A((void **)&a->d_cready, cc);
   A((void **)&a->d_cresp, cc * sizeof(float));
-  A((void **)&a->d_cpatch, cc * 9 * sizeof(float));
+  A((void **)&a->d_csub, cc * sizeof(float2));
+  A((void **)&a->d_nbr, cc * 2 * sizeof(uint4));
+  A((void **)&a->d_nbr2, cc * sizeof(uint2));
+  if (const char *e = getenv("SFMLOC_AKAZE_SUPPRESS")) {  // test hooks: "spill" = every record spilled (the band scans
+    a->sup_force_spill = strstr(e, "spill") != nullptr;    // decide everything), "global" = no level in LDS
+    a->sup_force_global = strstr(e, "global") != nullptr;
+  }
   A((void **)&a->d_ckey, cc * sizeof(unsigned int));
   A((void **)&a->d_cslot, cc * sizeof(int));
   if (he == hipSuccess) he = hipHostMalloc((void **)&a->h_counts, 160 * sizeof(unsigned int), hipHostMallocDefault);
@@ -2390,6 +2687,15 @@ int sfmloc_akaze_read_levels(sfmloc_akaze *ak, float *ldet, float *lt) {
   return SFMLOC_OK;
 }
 
+int sfmloc_akaze_suppress_stats(sfmloc_akaze *ak, uint32_t *out9) {
+  SFM_CHECK(ak && out9, SFMLOC_EINVAL, "sfmloc_akaze_suppress_stats: null argument");
+  Akaze *a = reinterpret_cast<Akaze *>(ak);
+  SFM_HIP(hipSetDevice(a->device));
+  if (a->stream.own) SFM_HIP(hipStreamSynchronize(a->stream));
+  SFM_HIP(hipMemcpy(out9, a->d_ncand, 9 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return SFMLOC_OK;
+}
+
 // The whole of detectAndCompute on the device, launches only (an extractor that records for a gang session takes part in
 // ONE launch per kernel with the other images of the batch): scale space -> extrema, raster ordered -> duplicate
 // suppression + sub-pixel refinement (k_suppress) -> orientation + M-LDB of however many keypoints that left (the launch
@@ -2401,7 +2707,7 @@ static int akaze_detect_enqueue(Akaze *a, const uint8_t *gray) {
   const LevelTab T = level_tab(a);
   const dim3 egrid(((a->w + 127) / 128 + kSegPerWave - 1) / kSegPerWave, T.row0[T.n]);  // (kSegPerWave segments per wave)
   const LevelTab *dT = reinterpret_cast<const LevelTab *>(a->d_level_tab);
-  CandArrays C{a->d_cxy, a->d_clevel, a->d_cresp, a->d_cpatch};
+  CandArrays C{a->d_cxy, a->d_clevel, a->d_cresp, a->d_csub};
   sfm_launch<ExtremaSegBody>(a, k_extrema_seg, egrid, dim3(128), 0, a->d_Ldet, dT, a->thres, a->d_seg_x, a->d_seg, a->segs_per_row);
   {
     const unsigned int chunks = (a->n_seg + kSegChunk - 1u) / kSegChunk;
@@ -2414,8 +2720,18 @@ static int akaze_detect_enqueue(Akaze *a, const uint8_t *gray) {
   }
   sfm_launch<ExtremaPlaceBody>(a, k_extrema_place, egrid, dim3(128), 0, a->d_Ldet, dT, a->d_seg_x, a->d_seg, a->cand_cap, C,
                                a->segs_per_row);
+  {  // the neighbour lists: one wave per candidate, a fixed grid that strides over them (their number is on the device)
+    unsigned int ngrid = (unsigned int)((size_t)a->w * a->h / 384);
+    ngrid = ngrid < 256u ? 256u : (ngrid > 4096u ? 4096u : ngrid);
+    sfm_launch<NbrBody>(a, k_suppress_nbr, dim3(ngrid), dim3(256), 0, dT, (const unsigned int *)a->d_seg, a->segs_per_row,
+                        a->cand_cap, (const unsigned int *)a->d_ncand, (const uint32_t *)a->d_cxy, (const uint8_t *)a->d_clevel,
+                        (const float *)a->d_cresp, a->d_nbr, a->d_nbr2, a->d_ncand + 6, a->sup_force_spill);
+  }
   SuppressArgs S;
   S.T = dT;
+  S.nbr = a->d_nbr;
+  S.nbr2 = a->d_nbr2;
+  S.force_global = a->sup_force_global;
   S.seg_base = a->d_seg;
   S.segs_per_row = a->segs_per_row;
   S.cap = a->cand_cap;
@@ -2444,7 +2760,7 @@ static int akaze_detect_enqueue(Akaze *a, const uint8_t *gray) {
 // the counts of one or more extractions (asynchronous on stream s; the caller synchronises), then their outputs
 static int akaze_counts_enqueue(Akaze *a, hipStream_t s) {
   static const bool timing_counts = getenv("SFMLOC_AKAZE_TIMING") != nullptr;
-  SFM_HIP(hipMemcpyAsync(a->h_counts, a->d_ncand, (timing_counts ? 160 : 6) * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  SFM_HIP(hipMemcpyAsync(a->h_counts, a->d_ncand, (timing_counts ? 160 : 9) * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   return SFMLOC_OK;
 }
 static int akaze_outputs_enqueue(Akaze *a, float *kpts, uint8_t *desc64, uint32_t cap, uint32_t *n_out, hipStream_t s) {
@@ -2500,8 +2816,8 @@ int sfmloc_akaze_detect_and_compute(sfmloc_akaze *ak, const uint8_t *gray, float
             a->h_counts[4] * 0.01, a->h_counts[5] * 0.01);
   if (timing) {
     for (int l = 0; l < a->plan.nlev; ++l)
-      fprintf(stderr, "  level %2d: %5u candidates, %2u rounds, fill %.1f us, rounds %.1f us\n", l, a->h_counts[10 + 4 * l],
-              a->h_counts[11 + 4 * l], a->h_counts[12 + 4 * l] * 0.01, a->h_counts[13 + 4 * l] * 0.01);
+      fprintf(stderr, "  level %2d: %5u candidates, %2u rounds, fill %.1f us, rounds %.1f us (a %.1f b %.1f)\n", l, a->h_counts[10 + 4 * l],
+              a->h_counts[11 + 4 * l], a->h_counts[12 + 4 * l] * 0.01, a->h_counts[13 + 4 * l] * 0.01, a->h_counts[82 + 2 * l] * 0.01, a->h_counts[83 + 2 * l] * 0.01);
   }
   return SFMLOC_OK;
 }

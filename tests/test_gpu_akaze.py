@@ -29,6 +29,46 @@ def test_detect_and_compute_matches_oracle(oracle_c, shape, seed):
     ak.close()
 
 
+def dense_image(seed, shape, block):
+    """Random two-level blocks of a few pixels: thousands of extrema per level, many within each other's radius."""
+    rng = np.random.Generator(np.random.PCG64(2000 + seed))
+    h, w = shape
+    small = rng.integers(0, 2, ((h + block - 1) // block, (w + block - 1) // block))
+    return (30 + 195 * np.kron(small, np.ones((block, block), np.int64))[:h, :w]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("form", ["", "spill", "global", "spill,global"])
+def test_duplicate_suppression_forms_on_dense_frames(oracle_c, form, monkeypatch):
+    """k_suppress decides out of neighbour lists (k_suppress_nbr) in LDS; a candidate whose lists do not fit its record is
+    decided by band scans, a level above 4 096 candidates out of the global arrays.  Dense frames reach both by themselves
+    (asserted), SFMLOC_AKAZE_SUPPRESS forces either for every candidate / level: always the oracle's keypoints, bit for bit."""
+    if form:
+        monkeypatch.setenv("SFMLOC_AKAZE_SUPPRESS", form)
+    else:
+        monkeypatch.delenv("SFMLOC_AKAZE_SUPPRESS", raising=False)
+    seen = {"spilled_ap": 0, "spilled_n": 0, "global_levels": 0, "candidates": 0}
+    for shape, seed, block in (((240, 320), 11, 3), ((300, 400), 12, 5), ((480, 640), 13, 4)):
+        g = dense_image(seed, shape, block)
+        ekp, edesc = oracle_c.akaze_detect_and_compute(g, cap=60000)[:2]
+        ak = S.Akaze(shape[1], shape[0])
+        kp, desc = ak.detect_and_compute(g)
+        st = ak.suppress_stats()
+        ak.close()
+        assert st["candidates"] < 65536
+        assert len(kp) == len(ekp) and len(kp) > 200
+        np.testing.assert_array_equal(bits32(kp), bits32(ekp), err_msg=f"keypoints, form {form!r}, blocks of {block}: {st}")
+        np.testing.assert_array_equal(desc[:, :61], edesc)
+        for k in seen:
+            seen[k] = max(seen[k], st[k])
+        if "spill" in form:
+            assert st["spilled_ap"] == st["candidates"] and st["spilled_n"] == st["candidates"]
+        if "global" in form:
+            assert st["global_levels"] >= 3
+        print(form, shape, block, st)
+    if not form:  # the largest frame has a level above the LDS arrays without being told to
+        assert seen["global_levels"] > 0, seen
+
+
 @pytest.mark.parametrize("shape", [(480, 640), (270, 481)])
 def test_batch_of_images_equals_one_at_a_time(shape):
     """sfmloc_akaze_detect_and_compute_batch (one launch per kernel for all the frames, the stages after the extrema taken
