@@ -495,6 +495,20 @@ __device__ __forceinline__ int next_pow2(int n) {
 constexpr int kFMaxM = 2048;  // putative matches per view the LDS sort holds
 constexpr int kFPre = 64;     // hypotheses solved speculatively per batch while sampling is still uniform
 
+// (a write-through store: see "A round's results go from the workgroup that computed them ..." at K5)
+template <typename T>
+__device__ __forceinline__ void store_through(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// what a workgroup of k_fmatrix_fast's wide form delivers for its iteration of the first batch: the models and their
+// (NFA, inlier count)
+struct K3Spec {
+  double models[27];
+  double nfa[3];
+  int k[3];
+  int nm;
+};
 struct FFilterArgs {
   const uint32_t *view_sel;
   uint32_t n_sel;
@@ -514,6 +528,8 @@ struct FFilterArgs {
   int skip_le;  // k_fmatrix_filter leaves views with at most this many putative matches to k_fmatrix_fast
   int fast_min;  // k_fmatrix_fast<W, M> takes the views with fast_min < matches <= M
   MergeMaskedArgs merge;  // enabled: k_fmatrix_fast first builds its view's putative list (K2 left to it)
+  K3Spec *spec;           // wide form: [view slot][kF2Batch] results of the first batch; per view slot the arrivals
+  unsigned int *spec_arrive;
 };
 
 // small per-view state of the block-wide form (always in LDS)
@@ -783,6 +799,7 @@ __global__ __launch_bounds__(kThreads) void k_fmatrix_large(FFilterArgs A, FLarg
 // ---------------------------------------------------------------------------------------------------
 constexpr int kF2MaxM = 512;   // putative matches per view (one wave sorts one model's residuals)
 constexpr int kF2Batch = 32;   // uniform iterations solved speculatively per batch
+constexpr int kK3WideViews = 256;  // view lists the wide form takes (its result slots: 2 MB per context)
 
 // (W = waves per view: 16 for a query alone on the GPU -- a view's latency --, 4 when the GPU is shared: a workgroup of 16
 // waves at 124 VGPRs is a compute unit's whole register file, i.e. it starts only on a compute unit nothing else runs on
@@ -841,18 +858,20 @@ __device__ void bitonic_sort_wave(uint64_t *kw, uint32_t *iw, int P) {
   }
 }
 
-template <int W, int MaxM = 512>
+template <int W, int MaxM = 512, bool Wide = false>
 struct FmatrixFastBody {
   static constexpr int kGangThreads = W * 64;
   static __device__ __forceinline__ void run(FFilterArgs A) {
     constexpr int kF2Waves = W, kF2Threads = W * 64, kF2MaxM = MaxM;
+    constexpr bool kF2Wide = Wide;
     using F2Shared = F2SharedT<W, MaxM>;
 #include "fmatrix_fast.body.inc"
   }
 };
-template <int W, int MaxM = 512>
+template <int W, int MaxM = 512, bool Wide = false>
 __global__ __launch_bounds__(W * 64) void k_fmatrix_fast(FFilterArgs A) {
   constexpr int kF2Waves = W, kF2Threads = W * 64, kF2MaxM = MaxM;
+  constexpr bool kF2Wide = Wide;
   using F2Shared = F2SharedT<W, MaxM>;
 #include "fmatrix_fast.body.inc"
 }
@@ -1351,10 +1370,6 @@ constexpr int kP3pSmallN = 512;
 // write-back -- only the stores' completion: every storing wave runs s_waitcnt vmcnt(0) after its last store and the
 // workgroup's barrier then orders all of those waits in front of the one lane that adds to the counter
 // (p3p_round.body.inc; the barrier alone does not wait on vmcnt).
-template <typename T>
-__device__ __forceinline__ void store_through(T *p, T v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // The NFA filter.  A model of this round can only matter to the replay if its NFA is below the best NFA the round
@@ -3325,16 +3340,44 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
   A.skip_le = fast ? kF2MaxM : -1;
   A.fast_min = -1;
   A.merge = MergeMaskedArgs{};
+  // The wide form (one workgroup per iteration of a view's first batch, fmatrix_fast.body.inc) for a query alone on the GPU
+  // with a short view list: its 1 024-match instance takes every view the register forms hold, in one launch.
+  // SFMLOC_K3_WIDE = 0 never, 2 always (tests, campaigns).
+  static const int env_wide = [] { const char *e = getenv("SFMLOC_K3_WIDE"); return e ? atoi(e) : 1; }();
+  const int n_uniform = m->params.ransac_round - m->params.ransac_round / 10;
+  const int wide_b0 = n_uniform < kF2Batch ? n_uniform : kF2Batch;
+  const bool wide = fast && wide_b0 >= 2 && n_sel <= (uint32_t)kK3WideViews &&
+                    (env_wide == 2 || (env_wide == 1 && c->k1_may_slice && c->stream.gang == nullptr));
+  A.spec = nullptr;
+  A.spec_arrive = nullptr;
   if (c->merge_is_deferred) {  // K2 was left to this stage (launch_merge_ratio_compact)
     c->merge_is_deferred = false;
-    if (fast) {
+    if (fast && !wide) {
       A.merge = c->deferred_merge;  // k_fmatrix_fast runs on every selected view, whatever its size
-    } else {
+    } else {  // (the wide form's workgroups of a view all need the view's lists: K2 as a launch of its own)
       int rc = launch_merge_masked_now(c, n_sel);
       if (rc) return rc;
     }
   }
-  if (fast) {
+  if (wide) {
+    if (!c->d_k3_spec) {
+      SFM_HIP(hipMalloc((void **)&c->d_k3_spec, (size_t)kK3WideViews * kF2Batch * sizeof(K3Spec)));
+      SFM_HIP(hipMalloc((void **)&c->d_k3_arrive, (size_t)kK3WideViews * sizeof(unsigned int)));
+      SFM_HIP(hipMemset(c->d_k3_arrive, 0, (size_t)kK3WideViews * sizeof(unsigned int)));  // (the last arrival clears its slot)
+      SFM_HIP(hipStreamSynchronize(nullptr));  // (null stream: not ordered with the context's stream otherwise)
+      c->hbm_bytes += (size_t)kK3WideViews * (kF2Batch * sizeof(K3Spec) + sizeof(unsigned int));
+    }
+    A.spec = reinterpret_cast<K3Spec *>(c->d_k3_spec);
+    A.spec_arrive = c->d_k3_arrive;
+    using Sh = F2SharedT<4, 1024>;
+    static const hipError_t attrw = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast<4, 1024, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh));
+    SFM_HIP(attrw);
+    sfm_launch<FmatrixFastBody<4, 1024, true>>(c, k_fmatrix_fast<4, 1024, true>, dim3(n_sel, (unsigned)wide_b0), dim3(256),
+                                               (uint32_t)sizeof(Sh), A);
+    SFM_HIP(hipGetLastError());
+    A.skip_le = 1024;
+  } else if (fast) {
     // waves per view (F2SharedT): 16 for a query alone on the GPU, 4 when other contexts have work queued
     static const int env_waves = [] { const char *e = getenv("SFMLOC_K3_WAVES_SHARED"); return e ? atoi(e) : 4; }();
     static const int env_waves_alone = [] { const char *e = getenv("SFMLOC_K3_WAVES_ALONE"); return e ? atoi(e) : 16; }();

@@ -227,6 +227,8 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   // K3 for views with more putative matches than its LDS form holds (acransac.hip k_fmatrix_large): allocated on first use
   uint64_t *fl_key = nullptr;
   uint32_t *fl_idx = nullptr, *fl_count = nullptr, *fl_list = nullptr;
+  void *d_k3_spec = nullptr;            // k_fmatrix_fast's wide form: the first batch's results per view slot (lazily)
+  unsigned int *d_k3_arrive = nullptr;  // ... and the arrivals
   int32_t *fl_vec_index = nullptr, *fl_best_inl = nullptr;
   float *fl_logc_n = nullptr, *fl_logc_k = nullptr;
   int fl_slot_m = 0;

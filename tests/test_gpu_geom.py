@@ -740,6 +740,26 @@ def test_k3_waves_per_view_do_not_change_the_result():
         assert "every stage bit-exact" in r.stdout
 
 
+def test_k3_wide_form_and_plain_form_give_the_same_results():
+    """k_fmatrix_fast<4, 1024, wide>: a query alone on the GPU with a short view list takes gridDim.y workgroups per view,
+    one per iteration of the first uniform batch; the last to arrive replays.  The suite's lone queries take it by default;
+    here whole campaigns with the form forced for every query (SFMLOC_K3_WIDE=2: shared GPU, gang sessions, long lists up
+    to 256 views) and switched off (0: the plain forms, as before round 4), small and large match sets, in child processes
+    (the choice is read when the library first runs)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for wide in ("2", "0"):
+        env = dict(os.environ, SFMLOC_K3_WIDE=wide)
+        for tool, args in (("fuzz_parity.py", ["24", "83000"]), ("fuzz_p3p_large.py", ["4", "84000"]),
+                           ("fuzz_gang.py", ["40", "85000"])):
+            r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", tool)] + args, env=env,
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, (wide, tool, r.stdout[-2000:] + r.stderr[-2000:])
+            assert r.stdout.strip().splitlines()[-1].startswith("OK"), (wide, tool, r.stdout[-500:])
+
+
 def test_k3_register_form_for_513_to_1024_matches_per_view(oracle_c):
     """A query that nearly duplicates map frames of ~1 000 features has views with 513 ... 1 024 putative matches: beyond
     k_fmatrix_fast<W, 512>, which leaves them to the block-wide LDS form -- unless the map's recent queries had such views
