@@ -411,6 +411,36 @@ def test_no_size_limits_near_duplicate_of_a_large_frame(oracle_c):
     dm.close()
 
 
+def test_wide_p3p_rounds_above_16384_features(oracle_c):
+    """a query with more than 16 384 features (P3P workspace cap 32 768) and more than 4 096 correspondences,
+    run after a query with more than 512 correspondences on the same map -- the map's recent queries then ask for WIDE
+    rounds (four workgroups per hypothesis), and beyond the LDS forms a wide launch must keep its inlier lists in the plain
+    slots (slot = hypothesis): with slot = 4 x hypothesis the lists of hypotheses >= 32 lay past the allocation.  Every
+    stage equal to the oracle."""
+    m = synth.make_map(73, n_views=2, desc_per_view=17000, views_per_place=2, landmarks_per_place=18000, obs_per_view=16500,
+                       map_flips=8)
+    p3p_it = 300
+    dm = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, p3p_max_iteration=p3p_it),
+               view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+               landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    q0 = synth.make_query(m, 730, n_feat=2500, n_copies=1500, outlier_frac=0.1, query_flips=10)
+    exp0, _ = compare_stages(m, q0, dm, p3p_max_iteration=p3p_it)
+    assert 512 < len(exp0["ms_qfeat"]) <= 4096, len(exp0["ms_qfeat"])   # (wide rounds from now on)
+    q = synth.make_query(m, 731, n_feat=17000, n_copies=9000, outlier_frac=0.05, query_flips=10)
+    assert q.desc.shape[0] > 16384
+    exp, pose = compare_stages(m, q, dm, p3p_max_iteration=p3p_it)
+    assert len(exp["ms_qfeat"]) > 4096, len(exp["ms_qfeat"])
+    assert exp["ok"] and pose.ok
+    dq = dm.query(q.desc, q.kpt_xy, q.width, q.height)   # ... and the whole path in one call
+    p1, pq1, pl1 = dm.localize(dq)
+    assert p1.ok and p1.n_inliers == exp["n_inliers"]
+    np.testing.assert_array_equal(pq1, exp["pair_qfeat"])
+    np.testing.assert_array_equal(pl1, exp["pair_landmark"])
+    np.testing.assert_array_equal(bits(np.array(p1.P)), bits(exp["P"].ravel()))
+    dq.close()
+    dm.close()
+
+
 def test_failed_regrowth_of_the_p3p_workspace_leaves_the_context_usable(monkeypatch):
     """ctx_p3p_reserve allocates the larger set before it lets go of the old one: when an allocation fails (injected:
     sfmloc_debug_fail_p3p_alloc(index of the allocation that fails), one shot) the query gets SFMLOC_ENOMEM, the context keeps its
