@@ -2,10 +2,12 @@
 # rocprofv3 kernel-trace stats of the same command, PMC passes of the roofline kernel (separate runs, as the guide
 # prescribes), per-frame / per-query kernel time from the trace, AKAZE times.  ROUND=r04 tags the output; copy what is to
 # be judged into profiles/ under that prefix.  (GPU_MAX_HW_QUEUES is exported here: under rocprofv3 the runtime is up
-# before bench.py's own setdefault runs -- ADVICE r03.)
+# before bench.py's own setdefault runs -- ADVICE r03.  The value is the one bench.plan() chooses for the default run, 22 =
+# 20 contexts + 2: with 24 exported the image-in legs lose 8 - 15 % and even the lone full scan of the real bank runs at
+# 29.6 instead of 26.7 ms -- two runs each way, profiles/r04_hw_queues_22_vs_24.txt.)
 R=${ROUND:-r04}; O=gpurun_out/${R}_final; mkdir -p $O
 ROOT=$GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-24}
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-22}
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=$?; echo "pytest exit $rc" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 900 python bench.py > $O/bench_default.json 2> $O/bench_default.log || exit 1
