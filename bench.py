@@ -715,7 +715,12 @@ def plan(a, world, replicas):
     # first context with them (two slots + the two stage-2 groups)
     # (+2: the map's own stream and torch's; measured: 8 contexts on 8 queues lose 20 % to two streams sharing one)
     n_streams = (2 * -(-nctx // gang) + 2) if gang > 1 else (2 * nctx if sharded_mode else nctx)
-    return shortlist, forced, sharded_mode, gang, nctx, min(24, max(8, n_streams + 2))
+    hwq = min(24, max(8, n_streams + 2))
+    # (a sharded rank's gang sessions: 16 queues whatever the count of streams says -- one emulated rank of 2 / 4 / 8 with
+    # 8, 12, 16, 24 queues: 5.5 / 6.0 / 6.0 / 6.0, 11.3 / 12.7 / 12.9 / 11.3 and 18.4 / 18.4 / 18.3 / 16.1 k queries/s)
+    if sharded_mode and gang > 1:
+        hwq = 16
+    return shortlist, forced, sharded_mode, gang, nctx, hwq
 
 
 

@@ -67,7 +67,7 @@ def test_plan_of_a_run():
     assert a.image_workers == 10 and a.image_bow_worker_stream and a.image_bow_own_stream
     a = bench.parse(["--gpus", "8"])
     _, _, sharded, gang, nctx, hwq = bench.plan(a, 8, False)
-    assert sharded and gang == 32 and nctx == 64
+    assert sharded and gang == 32 and nctx == 64 and hwq == 16
     a = bench.parse(["--gpus", "8", "--replicas"])
     _, _, sharded, gang, nctx, _ = bench.plan(a, 8, True)
     assert not sharded and gang == 1 and nctx == 20

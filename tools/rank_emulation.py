@@ -41,7 +41,9 @@ def main():
     ap.add_argument("--extract-workers", type=int, default=4, help="host threads (one extractor and stream each)")
     a = ap.parse_args()
     N, B = a.of, a.batch
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, 2 * a.in_flight + 2))))
+    # (hardware queues as bench.plan() sets them for a sharded run with gang sessions: 16 -- with 24 an emulated rank of
+    # 8 drops from 18.4 k to 16.1 k queries/s, with 8 a rank of 2 from 6.0 k to 5.5 k)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if a.gang > 1 else str(min(24, max(8, 2 * a.in_flight + 2))))
     import numpy as np
     import torch
     import bench
