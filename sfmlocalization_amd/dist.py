@@ -688,13 +688,26 @@ def _hip_stage2_begin(self, indices, gathered, slot=0, budget=0, turn=0):
     world, pb = gathered.shape
     queries = self._queries[slot]
     B = len(queries)
-    if self.ctx2 is None or len(indices) > len(self.ctx2[0]):
+    if self.ctx2 is None:
         return ("done", self.stage2(indices, gathered, slot, budget))
     if not indices:
         return ("done", {})
-    cs = self.ctx2[turn % len(self.ctx2)]
-    capi.merge_batch_begin(cs[:len(indices)], [queries[i] for i in indices], indices, gathered.data_ptr(), world, pb, B, budget)
-    return ("queued", list(zip(cs, indices)), gathered)      # (the gathered buffer must outlive the session)
+    # a batch's share larger than a group (a rank of 2 owns 128 of a batch's 256 queries, a group holds GANG_MAX): one
+    # session per group of contexts, as many groups as it takes -- made when first needed --, all queued, none awaited.
+    # (Until round 4 such a share went through the blocking form: the host sat in stage 2 for 42 of a rank of 2's 47 ms
+    # per batch and the next batch's stage 1 was queued only then.)  Group 2 j + (turn & 1) takes the j-th session.
+    n = len(self.ctx2[0])
+    need = -(-len(indices) // n)
+    while len(self.ctx2) < 2 * need:
+        lead = self.map.context(merge_only=True)
+        self.ctx2.append([lead] + [self.map.context(share=lead, merge_only=True) for _ in range(n - 1)])
+    pending = []
+    for j in range(need):
+        cs = self.ctx2[2 * j + (turn & 1)]
+        chunk = indices[j * n:(j + 1) * n]
+        capi.merge_batch_begin(cs[:len(chunk)], [queries[i] for i in chunk], chunk, gathered.data_ptr(), world, pb, B, budget)
+        pending += list(zip(cs, chunk))
+    return ("queued", pending, gathered)      # (the gathered buffer must outlive the sessions)
 
 
 def _hip_stage2_end(self, pending):
