@@ -244,6 +244,40 @@ def test_three_batches_in_flight_give_the_results_of_two(monkeypatch):
             dq.close()
 
 
+def test_a_share_of_stage_2_larger_than_one_group_of_contexts():
+    """A rank of 2 owns 128 of a batch's 256 queries and a group of stage-2 contexts holds GANG_MAX = 32: stage2_begin
+    queues the share as several sessions on groups made on demand (nothing awaited), where the blocking form alternated two
+    groups.  Batches of 40 and 70 queries owned by this one rank (two and three sessions), a small one between them: the
+    stream's results = the batches one at a time (blocking form), in order."""
+    import torch
+    from sfmlocalization_amd import dist as D
+    m, bow, place_bow = scene(48)
+    dev = torch.device("cuda", 0)
+    with device_map(m, bow) as dm:
+        qs = [synth.make_query(m, 950 + k, n_feat=500, n_copies=170, outlier_frac=0.3) for k in range(12)]
+        dqs = [dm.query(q.desc, q.kpt_xy, q.width, q.height) for q in qs]
+        for dq, q in zip(dqs, qs):
+            dq.set_bow(place_bow[q.place])
+        batches = [[dqs[i % 12] for i in range(40)], dqs[:5], [dqs[(5 * i) % 12] for i in range(70)], [dqs[i % 12] for i in range(33)]]
+        out = {}
+        for mode in ("stream", "one at a time"):
+            comp = D.HipShardCompute(dm, n_contexts=32, device=dev, gang=16)
+            loc = D.ShardedLocalizer(comp, rank=0, world=1, n_views_global=m.n_views)
+            if mode == "stream":
+                out[mode] = list(loc.localize_stream(batches, bow_knn=15))
+                assert len(comp.ctx2) == 6          # three sessions x two turns
+            else:
+                out[mode] = [loc.localize_batch(b, gather_results=False, bow_knn=15) for b in batches]
+            comp.close()
+        for a, b, batch in zip(out["stream"], out["one at a time"], batches):
+            assert sorted(a) == sorted(b) == list(range(len(batch)))
+            for i in a:
+                assert a[i]["fingerprint"] == b[i]["fingerprint"]
+        assert sum(int(r["ok"]) for r in out["stream"][0].values()) >= 20
+        for dq in dqs:
+            dq.close()
+
+
 @pytest.mark.parametrize("gang", [1, 4])
 def test_queries_as_views_into_the_gathered_feature_blocks(gang):
     """images in on several ranks (dist.gather_queries): the owner packs a query's extracted features, the all-gather's
