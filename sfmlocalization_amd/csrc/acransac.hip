@@ -826,6 +826,7 @@ struct F2SharedT {
   double best_model[9];
   int iter_end[kF2Batch];  // flattened index one past the last model of each iteration of the batch
   uint8_t flat_b[kF2Batch * 3], flat_k[kF2Batch * 3];
+  unsigned int wide_ticket;  // the wide form: this workgroup's arrival number
 };
 
 __device__ __forceinline__ void wave_lds_sync() {

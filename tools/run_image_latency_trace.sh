@@ -1,9 +1,11 @@
 # The launches of ONE image-world frame taken alone (K9 -> BoW chain -> shortlist -> path), from a rocprofv3 kernel trace
 # of the image-in leg on a small map: start, duration and gap of every launch -> gpurun_out/image_frame_alone_timeline.txt
-# (BENCH_ARGS adds options, e.g. "--image-in-1080p-only")
+# (LEG=1080p: the 1080p leg runs after the VGA one and the LAST frame alone is a 1080p frame -> ..._1080p.txt)
+if [ "$LEG" = 1080p ]; then LEG_ARGS="--image-views-1080p 300 --image-steps-1080p 1 --batch-1080p 32"; SFX=_1080p; else LEG_ARGS="--no-image-in-1080p"; SFX=""; fi
+export SFX
 mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp
 d=$GRAFT_REPO_ROOT/gpurun_out/prof_img_lat; rm -rf $d
-rocprofv3 --kernel-trace --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py --image-in-only --no-image-in-1080p --views 1000 --image-views 1000 --image-steps 1 --batch 64 --image-oracle-frames 0 --no-cpu-baseline $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/image_lat_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/image_lat_bench.log || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $d -- python3 $GRAFT_REPO_ROOT/bench.py --image-in-only $LEG_ARGS --views 1000 --image-views 1000 --image-steps 1 --batch 64 --image-oracle-frames 0 --no-cpu-baseline $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/image_lat_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/image_lat_bench.log || exit 1
 cd $GRAFT_REPO_ROOT; python3 - <<'PY'
 import csv, glob, re
 f = glob.glob("gpurun_out/prof_img_lat/*/*kernel_trace.csv")[0]
@@ -23,5 +25,6 @@ for r in rows:
     out.append(f"{(s - t0) / 1e3:9.1f} us  +{(s - prev) / 1e3:7.1f} gap {(e - s) / 1e3:8.1f} us  {name(r)[:60]}  grid {r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']} wg {r['Workgroup_Size_X']}")
     busy += e - s; prev = max(prev, e)
 out.append(f"total {(prev - t0) / 1e3:.1f} us, kernels {busy / 1e3:.1f} us, launches {len(rows)}")
-open("gpurun_out/image_frame_alone_timeline.txt", "w").write("\n".join(out) + "\n")
+import os
+open("gpurun_out/image_frame_alone_timeline" + os.environ.get("SFX", "") + ".txt", "w").write("\n".join(out) + "\n")
 PY
