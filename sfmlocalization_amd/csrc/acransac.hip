@@ -309,17 +309,19 @@ __device__ __forceinline__ void packed_network(uint64_t (&key)[E], int lane) {
 template <int E>
 __device__ __forceinline__ void wave_sort_fast(uint64_t (&key)[E], uint32_t (&idx)[E], uint32_t *low) {
   const int lane = threadIdx.x & 63;
+  constexpr uint64_t kMask = E > 16 ? ((1ull << (kPackBits + 1)) - 1) : kPackMask;  // (the index of 64 E elements)
+  static_assert(E <= 32, "the packed index holds 11 bits at most");
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const uint32_t p = (uint32_t)((r << 6) + lane);
-    low[p] = (uint32_t)(key[r] & kPackMask);
-    key[r] = (key[r] & ~kPackMask) | p;
+    low[p] = (uint32_t)(key[r] & kMask);
+    key[r] = (key[r] & ~kMask) | p;
   }
   packed_network<E, 64 * E>(key, lane);
 #pragma unroll
   for (int r = 0; r < E; ++r) {
-    idx[r] = (uint32_t)(key[r] & kPackMask);
-    key[r] = (key[r] & ~kPackMask) | low[idx[r]];
+    idx[r] = (uint32_t)(key[r] & kMask);
+    key[r] = (key[r] & ~kMask) | low[idx[r]];
   }
   // Keys that agree above the packed bits were ordered by index; that is the exact order unless their displaced bits
   // descend somewhere, i.e. unless the restored keys are not ascending.  (Equal keys -- the +inf residuals of a
@@ -3370,14 +3372,25 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
     }
     A.spec = reinterpret_cast<K3Spec *>(c->d_k3_spec);
     A.spec_arrive = c->d_k3_arrive;
-    using Sh = F2SharedT<4, 1024>;
-    static const hipError_t attrw = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast<4, 1024, true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh));
-    SFM_HIP(attrw);
-    sfm_launch<FmatrixFastBody<4, 1024, true>>(c, k_fmatrix_fast<4, 1024, true>, dim3(n_sel, (unsigned)wide_b0), dim3(256),
-                                               (uint32_t)sizeof(Sh), A);
+    // (views of 1 025 .. 2 048 matches -- 32 residuals per lane in the register sort, one workgroup per compute unit --
+    // only while the map's queries have had such views lately, Map::k3_huge_credit; SFMLOC_K3_WIDE_2048 = 0 never, 2 always:
+    // k_fmatrix_filter's block-wide sort took 0.6 of a lone 1080p frame's 0.95 ms in this stage)
+    static const int env_2048 = [] { const char *e = getenv("SFMLOC_K3_WIDE_2048"); return e ? atoi(e) : 1; }();
+    const bool huge = env_2048 == 2 || (env_2048 == 1 && m->k3_huge_credit.load(std::memory_order_relaxed) > 0);
+    auto go_wide = [&](auto m_tag) {
+      constexpr int MaxM = decltype(m_tag)::value;
+      using Sh = F2SharedT<4, MaxM>;
+      static const hipError_t attrw = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast<4, MaxM, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh));
+      if (attrw != hipSuccess) return attrw;
+      sfm_launch<FmatrixFastBody<4, MaxM, true>>(c, k_fmatrix_fast<4, MaxM, true>, dim3(n_sel, (unsigned)wide_b0), dim3(256),
+                                                 (uint32_t)sizeof(Sh), A);
+      return hipSuccess;
+    };
+    const hipError_t ew = huge ? go_wide(std::integral_constant<int, 2048>{}) : go_wide(std::integral_constant<int, 1024>{});
+    SFM_HIP(ew);
     SFM_HIP(hipGetLastError());
-    A.skip_le = 1024;
+    A.skip_le = huge ? 2048 : 1024;
   } else if (fast) {
     // waves per view (F2SharedT): 16 for a query alone on the GPU, 4 when other contexts have work queued
     static const int env_waves = [] { const char *e = getenv("SFMLOC_K3_WAVES_SHARED"); return e ? atoi(e) : 4; }();

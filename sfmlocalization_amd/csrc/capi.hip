@@ -740,6 +740,8 @@ int ctx_localize_end(Ctx *c, sfmloc_pose *out, uint32_t *pair_qfeat, uint32_t *p
   // the form of the next queries' K3 (launch_geometric_filter): was this one's largest view one for the 1 024-match
   // register form?  (A query with a still larger view gains nothing from it: the launches run one after the other, and
   // the block-wide form of its largest view is what it waits for either way -- measured on the dense lab frames, +0.2 ms.)
+  if (h->view_stats[2] > 1024u && h->view_stats[2] <= 2048u) c->map->k3_huge_credit.store(64, std::memory_order_relaxed);
+  else if (c->map->k3_huge_credit.load(std::memory_order_relaxed) > 0) c->map->k3_huge_credit.fetch_sub(1, std::memory_order_relaxed);
   if (h->view_stats[2] > 1024u) c->map->k3_big_credit.store(0, std::memory_order_relaxed);
   else if (h->view_stats[2] > 512u) c->map->k3_big_credit.store(64, std::memory_order_relaxed);
   else if (c->map->k3_big_credit.load(std::memory_order_relaxed) > 0) c->map->k3_big_credit.fetch_sub(1, std::memory_order_relaxed);

@@ -146,6 +146,7 @@ struct Map {
   // > 0 while recent queries had more than 512 2D-3D correspondences: K5's rounds are then launched wide (four
   // workgroups per hypothesis, acransac.hip).  Set to 64 by a finished query that had, counted down by the others.
   std::atomic<int> p3p_wide_credit{0};
+  std::atomic<int> k3_huge_credit{0};  // ... with 1 025 .. 2 048 (the wide form's 2 048-match instance, a query alone)
   std::atomic<int> k3_big_credit{0};  // finished queries ago that one had a view with more than 512 putative matches (64 = just now)
   // finished queries in a row whose 2D-3D set had at most 512 correspondences (acransac.hip kP3pSmallN): from 8 on a
   // query's P3P rounds are queued in the small form (ctx_resection_enqueue)

@@ -781,13 +781,35 @@ def test_k3_wide_form_and_plain_form_give_the_same_results():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for wide in ("2", "0"):
-        env = dict(os.environ, SFMLOC_K3_WIDE=wide)
-        for tool, args in (("fuzz_parity.py", ["24", "83000"]), ("fuzz_p3p_large.py", ["4", "84000"]),
+        env = dict(os.environ, SFMLOC_K3_WIDE=wide, SFMLOC_K3_WIDE_2048=wide)
+        for tool, args in (("fuzz_parity.py", ["24", "83000"]), ("fuzz_p3p_large.py", ["6", "84000"]),
                            ("fuzz_gang.py", ["40", "85000"])):
             r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", tool)] + args, env=env,
                                capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, (wide, tool, r.stdout[-2000:] + r.stderr[-2000:])
             assert r.stdout.strip().splitlines()[-1].startswith("OK"), (wide, tool, r.stdout[-500:])
+
+
+def test_k3_wide_form_for_1025_to_2048_matches_per_view(oracle_c):
+    """A query alone whose views have 1 025 ... 2 048 putative matches: the first one finds them in k_fmatrix_filter (the
+    block-wide LDS sort), the following ones -- Map::k3_huge_credit -- in k_fmatrix_fast<4, 2048, wide> (32 residuals per
+    lane in the register sort).  Every stage equals the oracle either way; a smaller query afterwards too."""
+    m = synth.make_map(77, n_views=3, desc_per_view=2100, views_per_place=3, landmarks_per_place=2500, obs_per_view=2000,
+                       map_flips=8)
+    p3p_it = 200
+    dm = S.Map(m.view_id, m.view_off, m.desc, params=S.default_params(ransac_round=25, p3p_max_iteration=p3p_it),
+               view_wh=m.view_wh, kpt_xy=m.kpt_xy, row_landmark=m.row_landmark, landmark_id=m.landmark_id,
+               landmark_X=m.landmark_X, intrinsic=m.intrinsic)
+    seen = []
+    for k in range(3):
+        q = synth.make_query(m, 770 + k, n_feat=2300, n_copies=2000, outlier_frac=0.1, query_flips=10)
+        exp, pose = compare_stages(m, q, dm, p3p_max_iteration=p3p_it)
+        seen.append(int(exp["put_count"].max()))
+        assert exp["ok"]
+    assert all(1024 < c <= 2048 for c in seen), seen
+    q = synth.make_query(m, 779, n_feat=700, n_copies=300, outlier_frac=0.2)
+    compare_stages(m, q, dm, p3p_max_iteration=p3p_it)
+    dm.close()
 
 
 def test_k3_register_form_for_513_to_1024_matches_per_view(oracle_c):
