@@ -51,12 +51,34 @@ struct BlocksArgs {
   uint32_t bound;
   unsigned long long *flagmask;
 };
+// inclusive scan of one value per thread over a 1024-thread workgroup, OP = max or +: shuffles inside a wave, the sixteen
+// wave totals through LDS (two barriers; the log-step scan through LDS this replaces took twenty, twice per call -- 10 of
+// k_bow_topk's 28 us on a lone query's shortlist)
+template <bool kMax>
+__device__ __forceinline__ uint32_t chain_block_scan_1024(uint32_t v, uint32_t *wave_tot /*[16] LDS*/) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= (uint32_t)off) inc = kMax ? max(inc, o) : inc + o;
+  }
+  __syncthreads();  // wave_tot of an earlier call is no longer read
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16; ++w) {
+    const uint32_t t = wave_tot[w];
+    if (w < wave) before = kMax ? max(before, t) : before + t;
+  }
+  return kMax ? max(inc, before) : inc + before;
+}
 __device__ __forceinline__ void blocks_from_views_block(const BlocksArgs &B) {
   constexpr uint32_t kRows = 64;
-  __shared__ uint32_t s_last[1024];  // inclusive running max of (last block + 1) over the non-empty views so far
-  __shared__ uint32_t s_cnt[1024];   // inclusive scan of the blocks each view adds
+  __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry_last, s_carry_cnt;
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid == 0) s_carry_last = 0, s_carry_cnt = 0;
   __syncthreads();
   for (uint32_t base = 0; base < B.n_sel; base += 1024) {
@@ -69,37 +91,30 @@ __device__ __forceinline__ void blocks_from_views_block(const BlocksArgs &B) {
     }
     const bool nonempty = r1 > r0;
     const uint32_t b0 = r0 / kRows, b1 = nonempty ? (r1 - 1) / kRows : 0;
-    s_last[tid] = nonempty ? b1 + 1 : 0;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive max-scan
-      const uint32_t o = tid >= off ? s_last[tid - off] : 0;
-      __syncthreads();
-      s_last[tid] = max(s_last[tid], o);
-      __syncthreads();
-    }
+    // inclusive running max of (last block + 1) over the non-empty views so far
+    const uint32_t last_inc = chain_block_scan_1024<true>(nonempty ? b1 + 1 : 0u, s_wave);
     // last block (+1) of the nearest earlier non-empty selected view: views ascend, so it is the running maximum
-    const uint32_t prev = max(s_carry_last, tid ? s_last[tid - 1] : 0u);
+    uint32_t last_before = __shfl_up(last_inc, 1, 64);  // (the thread before me; lane 0: the waves before mine)
+    if (lane == 0) {
+      last_before = 0;
+      for (uint32_t w = 0; w < (tid >> 6); ++w) last_before = max(last_before, s_wave[w]);
+    }
+    const uint32_t prev = max(s_carry_last, last_before);
     const bool share = nonempty && prev != 0 && prev - 1 == b0;
     const uint32_t add = nonempty ? (b1 - b0 + 1 - (share ? 1u : 0u)) : 0u;
-    s_cnt[tid] = add;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive sum-scan
-      const uint32_t o = tid >= off ? s_cnt[tid - off] : 0;
-      __syncthreads();
-      s_cnt[tid] += o;
-      __syncthreads();
-    }
-    const uint32_t start = s_carry_cnt + s_cnt[tid] - add;
+    // inclusive scan of the blocks each view adds
+    const uint32_t cnt_inc = chain_block_scan_1024<false>(add, s_wave);
+    const uint32_t start = s_carry_cnt + cnt_inc - add;
     if (k < B.n_sel) {
       B.view_sel_out[k] = v;
       B.widx0[k] = nonempty ? (share ? start - 1 : start) : 0u;
       for (uint32_t b = b0 + (share ? 1u : 0u), w = start; nonempty && b <= b1; ++b, ++w)
         if (w < B.bound) B.block_list[w] = b;
     }
-    __syncthreads();
+    __syncthreads();  // (every thread has read the carries)
     if (tid == 1023) {
-      s_carry_last = max(s_carry_last, s_last[1023]);
-      s_carry_cnt += s_cnt[1023];
+      s_carry_last = max(s_carry_last, last_inc);
+      s_carry_cnt += cnt_inc;
     }
     __syncthreads();
   }
