@@ -85,15 +85,34 @@ struct BowTopkBody {
     uint32_t prefix = 0, rank = k;  // the k-th smallest (1-based) within the elements matching `prefix`
     const int shifts[3] = {21, 10, 0};
     const uint32_t widths[3] = {11, 11, 10};
+    // (up to kRegVals values per thread -- 16 384 views -- are fetched ONCE, side by side, and the three passes count from
+    // registers: as a loop over global memory each pass was a chain of n / 1024 load -> LDS-atomic steps, ~6 us of a lone
+    // query's 27 us in this kernel per pass)
+    constexpr uint32_t kRegVals = 16;
+    const bool in_regs = n <= kRegVals * 1024u;
+    uint32_t xs[kRegVals];
+    if (in_regs) {
+#pragma unroll
+      for (uint32_t u = 0; u < kRegVals; ++u) xs[u] = tid + 1024u * u < n ? dist_bits[tid + 1024u * u] : 0u;
+    }
     for (int pass = 0; pass < 3; ++pass) {
       const uint32_t bins = 1u << widths[pass];
       for (uint32_t b = tid; b < bins; b += 1024) hist[b] = 0;
       __syncthreads();
       const uint32_t hi_shift = shifts[pass] + widths[pass];
-      for (uint32_t i = tid; i < n; i += 1024) {
-        const uint32_t x = dist_bits[i];
-        const bool match = (pass == 0) || ((x >> hi_shift) == (prefix >> hi_shift));
-        if (match) atomicAdd(&hist[(x >> shifts[pass]) & (bins - 1)], 1u);
+      if (in_regs) {
+#pragma unroll
+        for (uint32_t u = 0; u < kRegVals; ++u) {
+          const uint32_t x = xs[u];
+          const bool match = (pass == 0) || ((x >> hi_shift) == (prefix >> hi_shift));
+          if (tid + 1024u * u < n && match) atomicAdd(&hist[(x >> shifts[pass]) & (bins - 1)], 1u);
+        }
+      } else {
+        for (uint32_t i = tid; i < n; i += 1024) {
+          const uint32_t x = dist_bits[i];
+          const bool match = (pass == 0) || ((x >> hi_shift) == (prefix >> hi_shift));
+          if (match) atomicAdd(&hist[(x >> shifts[pass]) & (bins - 1)], 1u);
+        }
       }
       __syncthreads();
       // the bin holding the rank-th element: thread t owns bins 2t, 2t+1 (1024 bins in the last pass: bin t, and 0)
