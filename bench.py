@@ -82,7 +82,7 @@ def parse(argv=None):
                          "gang session on the worker's one stream; 1 = a frame at a time")
     ap.add_argument("--gang", type=int, default=0,
                     help="--gpus > 1: queries per launch in both stages of the sharded path (gang sessions, "
-                         "sfmloc_gang_begin/_end); 0 = 28 with more than one rank, 1 = one query per launch")
+                         "sfmloc_gang_begin/_end); 0 = 32 with more than one rank, 1 = one query per launch")
     ap.add_argument("--queries-per-stream", type=int, default=int(os.environ.get("SFMLOC_BENCH_QUERIES_PER_STREAM", "1")),
                     help="1 GPU: queries a context stream carries per turn, as one gang session (sfmloc_gang_begin/_end: one "
                          "launch per kernel for all of them); in flight = --in-flight x this")
@@ -701,13 +701,13 @@ def plan(a, world, replicas):
     # (N ranks: a rank scans 1/N of the map per query but issues every query's launches, and a device serves few
     # hardware queues well -- 16 queries per launch on 2 streams per slot instead of 8 streams with a query each:
     # tools/rank_emulation.py, profiles/r02_rank_emulation.jsonl)
-    # (round 4: 28 queries per launch and 84 contexts per slot.  A rank's scan of 16 queries' shortlisted views is 784
+    # (round 4: 32 queries per launch and 96 contexts per slot.  A rank's scan of 16 queries' shortlisted views is 784
     # workgroups for 1 024 places and the next session's scan waits behind this one's chain of latency-bound launches: more
-    # queries per launch, three sessions per slot.  28 and not 32: K3's argument list is 280 bytes, a gang launch of it holds
-    # 14 members, and a session of 32 went out as 14 + 14 + 4 -- three launches of ~250 us one after the other.  One emulated
-    # rank of 2 / 4 / 8: 6.3 / 13.4 / 20.5 k queries/s (16 / 32 contexts: 6.1 / 10.1 / 14.5 k; 32 / 64: 6.4 / 12.9 / 18.5 k),
-    # profiles/r04_rank_emulation.jsonl)
-    gang = a.gang if a.gang > 0 else (28 if (world > 1 and not replicas) else int(os.environ.get("SFMLOC_GANG", "1")))
+    # queries per launch, three sessions per slot.  K3's argument list was 280 bytes and a gang launch of it held 14 members
+    # -- a session of 32 went out as 14 + 14 + 4, three launches of ~250 us one after the other --: the list's constant part
+    # now lives on the device (FFilterStatic) and a launch holds 32.  One emulated rank of 2 / 4 / 8: 6.4 / 14.0 / 21.3 k
+    # queries/s (16 per launch on 32 contexts: 6.1 / 10.1 / 14.5 k), profiles/r04_rank_emulation.jsonl)
+    gang = a.gang if a.gang > 0 else (32 if (world > 1 and not replicas) else int(os.environ.get("SFMLOC_GANG", "1")))
     gang = gang if sharded_mode else 1
     nctx = a.in_flight if a.in_flight > 0 else (4 if a.from_images else
                                                 (((3 * gang if gang > 1 else 8) if sharded_mode else 20) if shortlist else 4))

@@ -15,6 +15,7 @@
 // the first hypothesis that changes the index set.  Samples come from a counter-based generator
 // (Philox4x32-10 keyed by seed/stage/stream/iteration), so iteration i draws the same sample no matter
 // which round evaluates it.  All arithmetic is f64, in the operation order of geom_device.h.
+#include <string.h>
 #include <float.h>
 
 #include <type_traits>
@@ -533,6 +534,72 @@ struct FFilterArgs {
   K3Spec *spec;           // wide form: [view slot][kF2Batch] results of the first batch; per view slot the arrivals
   unsigned int *spec_arrive;
 };
+// How the list reaches a kernel.  As kernel arguments it is 280 bytes, and a gang launch -- the members' lists side by
+// side in the 4 KB argument segment -- held 14 of them: a session of 32 queries went out as 14 + 14 + 4, three launches one
+// after the other for each of K3's forms.  Most of the list never changes for a context (the map's tables, the context's
+// own buffers, the parameters): that part lives on the device (FFilterStatic, written when it changes -- in practice
+// once), the kernels get a pointer to it and what does change per launch (84 bytes: 32 members a launch), and put the list
+// together again first thing.
+struct FFilterStatic {
+  const uint32_t *view_off, *view_id, *view_wh;
+  const uint32_t *put_count, *match_i, *match_key;
+  const float2 *map_kpt;
+  double precision;
+  int n_iter;
+  uint64_t seed;
+  const double *L10;
+  uint32_t *geo_count, *geo_idx;
+  double *geo_model;
+  uint32_t *large_count, *large_list;
+  int *status;
+  MergeMaskedArgs merge;  // (enabled, view_sel, view_widx0: per launch, below)
+};
+struct FFilterArgsPacked {
+  const FFilterStatic *st;
+  const uint32_t *view_sel;
+  const float2 *q_kpt6;
+  const uint32_t *merge_view_sel, *merge_view_widx0;
+  K3Spec *spec;
+  unsigned int *spec_arrive;
+  uint32_t n_sel, qw, qh;
+  int min_putative, skip_le, fast_min, merge_enabled;
+};
+__device__ __forceinline__ FFilterArgs ffilter_expand(const FFilterArgsPacked &P) {
+  const FFilterStatic &T = *P.st;
+  FFilterArgs A;
+  A.view_sel = P.view_sel;
+  A.n_sel = P.n_sel;
+  A.view_off = T.view_off;
+  A.view_id = T.view_id;
+  A.view_wh = T.view_wh;
+  A.put_count = T.put_count;
+  A.match_i = T.match_i;
+  A.match_key = T.match_key;
+  A.map_kpt = T.map_kpt;
+  A.q_kpt6 = P.q_kpt6;
+  A.qw = P.qw;
+  A.qh = P.qh;
+  A.precision = T.precision;
+  A.n_iter = T.n_iter;
+  A.seed = T.seed;
+  A.min_putative = P.min_putative;
+  A.L10 = T.L10;
+  A.geo_count = T.geo_count;
+  A.geo_idx = T.geo_idx;
+  A.geo_model = T.geo_model;
+  A.large_count = T.large_count;
+  A.large_list = T.large_list;
+  A.status = T.status;
+  A.skip_le = P.skip_le;
+  A.fast_min = P.fast_min;
+  A.merge = T.merge;
+  A.merge.enabled = P.merge_enabled;
+  A.merge.view_sel = P.merge_view_sel;
+  A.merge.view_widx0 = P.merge_view_widx0;
+  A.spec = P.spec;
+  A.spec_arrive = P.spec_arrive;
+  return A;
+}
 
 // small per-view state of the block-wide form (always in LDS)
 struct FSmall {
@@ -731,7 +798,8 @@ __device__ bool fmatrix_filter_view(const FFilterArgs &A, uint32_t v, Store st, 
 
 struct FmatrixFilterBody {
   static constexpr int kGangThreads = kThreads;
-  static __device__ __forceinline__ void run(FFilterArgs A) {
+  static __device__ __forceinline__ void run(FFilterArgsPacked P) {
+    const FFilterArgs A = ffilter_expand(P);
     extern __shared__ unsigned char smem_raw[];
     FShared &S = *reinterpret_cast<FShared *>(smem_raw);
     const uint32_t v = A.view_sel ? A.view_sel[blockIdx.x] : blockIdx.x;
@@ -751,8 +819,8 @@ struct FmatrixFilterBody {
     }
   }
 };
-__global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgs A) {
-  FmatrixFilterBody::run(A);
+__global__ __launch_bounds__(kThreads) void k_fmatrix_filter(FFilterArgsPacked P) {
+  FmatrixFilterBody::run(P);
 }
 
 // The views k_fmatrix_filter queued (more than kFMaxM putative matches): kFLargeSlots persistent workgroups, each
@@ -767,7 +835,8 @@ struct FLargeArgs {
 };
 struct FmatrixLargeBody {
   static constexpr int kGangThreads = kThreads;
-  static __device__ __forceinline__ void run(FFilterArgs A, FLargeArgs W) {
+  static __device__ __forceinline__ void run(FFilterArgsPacked P, FLargeArgs W) {
+    const FFilterArgs A = ffilter_expand(P);
     __shared__ FSmall S;
     const uint32_t n = *A.large_count;
     const size_t o = (size_t)blockIdx.x * W.slot_m;
@@ -783,8 +852,8 @@ struct FmatrixLargeBody {
     }
   }
 };
-__global__ __launch_bounds__(kThreads) void k_fmatrix_large(FFilterArgs A, FLargeArgs W) {
-  FmatrixLargeBody::run(A, W);
+__global__ __launch_bounds__(kThreads) void k_fmatrix_large(FFilterArgsPacked P, FLargeArgs W) {
+  FmatrixLargeBody::run(P, W);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -864,7 +933,8 @@ __device__ void bitonic_sort_wave(uint64_t *kw, uint32_t *iw, int P) {
 template <int W, int MaxM = 512, bool Wide = false>
 struct FmatrixFastBody {
   static constexpr int kGangThreads = W * 64;
-  static __device__ __forceinline__ void run(FFilterArgs A) {
+  static __device__ __forceinline__ void run(FFilterArgsPacked packed) {
+    const FFilterArgs A = ffilter_expand(packed);
     constexpr int kF2Waves = W, kF2Threads = W * 64, kF2MaxM = MaxM;
     constexpr bool kF2Wide = Wide;
     using F2Shared = F2SharedT<W, MaxM>;
@@ -872,7 +942,8 @@ struct FmatrixFastBody {
   }
 };
 template <int W, int MaxM = 512, bool Wide = false>
-__global__ __launch_bounds__(W * 64) void k_fmatrix_fast(FFilterArgs A) {
+__global__ __launch_bounds__(W * 64) void k_fmatrix_fast(FFilterArgsPacked packed) {
+  const FFilterArgs A = ffilter_expand(packed);
   constexpr int kF2Waves = W, kF2Threads = W * 64, kF2MaxM = MaxM;
   constexpr bool kF2Wide = Wide;
   using F2Shared = F2SharedT<W, MaxM>;
@@ -3295,6 +3366,64 @@ static int ensure_fmatrix_large(Ctx *c) {
   return SFMLOC_OK;
 }
 
+// the argument list as the kernels take it (FFilterArgsPacked): the context's block on the device is rewritten when its
+// content changes -- the first query, and the query after a lazily made buffer appeared -- and the host waits for that
+// write (the block is read by launches queued behind it; a second change must not overtake them)
+static_assert(sizeof(FFilterStatic) <= sizeof(Ctx::k3_static_host), "Ctx::k3_static_host holds an FFilterStatic");
+static int k3_pack(Ctx *c, const FFilterArgs &A, FFilterArgsPacked *P) {
+  FFilterStatic T;
+  memset(&T, 0, sizeof(T));
+  T.view_off = A.view_off;
+  T.view_id = A.view_id;
+  T.view_wh = A.view_wh;
+  T.put_count = A.put_count;
+  T.match_i = A.match_i;
+  T.match_key = A.match_key;
+  T.map_kpt = A.map_kpt;
+  T.precision = A.precision;
+  T.n_iter = A.n_iter;
+  T.seed = A.seed;
+  T.L10 = A.L10;
+  T.geo_count = A.geo_count;
+  T.geo_idx = A.geo_idx;
+  T.geo_model = A.geo_model;
+  T.large_count = A.large_count;
+  T.large_list = A.large_list;
+  T.status = A.status;
+  // (a launch that does not merge leaves the block's merge pointers as they are: queries that alternate between the two
+  // do not rewrite it)
+  if (A.merge.enabled) T.merge = A.merge;
+  else if (c->k3_static_valid) T.merge = reinterpret_cast<const FFilterStatic *>(c->k3_static_host)->merge;
+  T.merge.enabled = 0;
+  T.merge.view_sel = nullptr;
+  T.merge.view_widx0 = nullptr;
+  if (!c->d_k3_static) SFM_HIP(hipMalloc(&c->d_k3_static, sizeof(c->k3_static_host)));
+  if (!c->k3_static_valid || memcmp(&T, c->k3_static_host, sizeof(T)) != 0) {
+    memcpy(c->k3_static_host, &T, sizeof(T));
+    // (ahead of whatever a recording member has recorded -- nothing recorded reads the block before this call's launches
+    // -- and without issuing it: a plain use of the stream would end the session's sharing for this member)
+    hipStream_t s = c->stream.unordered();
+    SFM_HIP(hipMemcpyAsync(c->d_k3_static, c->k3_static_host, sizeof(T), hipMemcpyHostToDevice, s));
+    SFM_HIP(hipStreamSynchronize(s));
+    c->k3_static_valid = true;
+  }
+  P->st = reinterpret_cast<const FFilterStatic *>(c->d_k3_static);
+  P->view_sel = A.view_sel;
+  P->q_kpt6 = A.q_kpt6;
+  P->merge_view_sel = A.merge.view_sel;
+  P->merge_view_widx0 = A.merge.view_widx0;
+  P->spec = A.spec;
+  P->spec_arrive = A.spec_arrive;
+  P->n_sel = A.n_sel;
+  P->qw = A.qw;
+  P->qh = A.qh;
+  P->min_putative = A.min_putative;
+  P->skip_le = A.skip_le;
+  P->fast_min = A.fast_min;
+  P->merge_enabled = A.merge.enabled;
+  return SFMLOC_OK;
+}
+
 int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views, int min_putative) {
   Map *m = c->map;
   if (n_sel == 0) return SFMLOC_OK;
@@ -3383,8 +3512,10 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
       static const hipError_t attrw = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast<4, MaxM, true>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh));
       if (attrw != hipSuccess) return attrw;
+      FFilterArgsPacked P;
+      if (k3_pack(c, A, &P) != SFMLOC_OK) return hipErrorOutOfMemory;
       sfm_launch<FmatrixFastBody<4, MaxM, true>>(c, k_fmatrix_fast<4, MaxM, true>, dim3(n_sel, (unsigned)wide_b0), dim3(256),
-                                                 (uint32_t)sizeof(Sh), A);
+                                                 (uint32_t)sizeof(Sh), P);
       return hipSuccess;
     };
     const hipError_t ew = huge ? go_wide(std::integral_constant<int, 2048>{}) : go_wide(std::integral_constant<int, 1024>{});
@@ -3401,7 +3532,9 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
       static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast<W>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(F2SharedT<W>));
       if (attr2 != hipSuccess) return attr2;
-      sfm_launch<FmatrixFastBody<W>>(c, k_fmatrix_fast<W>, dim3(n_sel), dim3(W * 64), (uint32_t)sizeof(F2SharedT<W>), A);
+      FFilterArgsPacked P;
+      if (k3_pack(c, A, &P) != SFMLOC_OK) return hipErrorOutOfMemory;
+      sfm_launch<FmatrixFastBody<W>>(c, k_fmatrix_fast<W>, dim3(n_sel), dim3(W * 64), (uint32_t)sizeof(F2SharedT<W>), P);
       return hipSuccess;
     };
     const hipError_t e2 = waves == 16 ? go(std::integral_constant<int, 16>{})
@@ -3422,7 +3555,9 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
         static const hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fmatrix_fast<W, 1024>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh));
         if (attr3 != hipSuccess) return attr3;
-        sfm_launch<FmatrixFastBody<W, 1024>>(c, k_fmatrix_fast<W, 1024>, dim3(n_sel), dim3(W * 64), (uint32_t)sizeof(Sh), B);
+        FFilterArgsPacked P;
+        if (k3_pack(c, B, &P) != SFMLOC_OK) return hipErrorOutOfMemory;
+        sfm_launch<FmatrixFastBody<W, 1024>>(c, k_fmatrix_fast<W, 1024>, dim3(n_sel), dim3(W * 64), (uint32_t)sizeof(Sh), P);
         return hipSuccess;
       };
       const hipError_t e3 = c->k1_may_slice ? go_big(std::integral_constant<int, 8>{}) : go_big(std::integral_constant<int, 4>{});
@@ -3436,7 +3571,12 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FShared));
   SFM_HIP(attr1);
   A.merge.enabled = 0;  // (the lists exist by now)
-  sfm_launch<FmatrixFilterBody>(c, k_fmatrix_filter, dim3(n_sel), dim3(kThreads), (uint32_t)lds, A);
+  FFilterArgsPacked PF;
+  {
+    int rc = k3_pack(c, A, &PF);
+    if (rc) return rc;
+  }
+  sfm_launch<FmatrixFilterBody>(c, k_fmatrix_filter, dim3(n_sel), dim3(kThreads), (uint32_t)lds, PF);
   SFM_HIP(hipGetLastError());
   if (A.large_list) {  // some view of this map can have more than kFMaxM matches: the queue's consumer
     FLargeArgs W;
@@ -3447,7 +3587,7 @@ int launch_fmatrix_filter(Ctx *c, const Query *q, uint32_t n_sel, bool all_views
     W.logc_n = c->fl_logc_n;
     W.logc_k = c->fl_logc_k;
     W.slot_m = c->fl_slot_m;
-    sfm_launch<FmatrixLargeBody>(c, k_fmatrix_large, dim3(kFLargeSlots), dim3(kThreads), 0, A, W);
+    sfm_launch<FmatrixLargeBody>(c, k_fmatrix_large, dim3(kFLargeSlots), dim3(kThreads), 0, PF, W);
     SFM_HIP(hipGetLastError());
   }
   return SFMLOC_OK;

@@ -133,7 +133,7 @@ void free_ctx(Ctx *c) {
                   c->d_inlier_idx, c->d_prep_models, c->d_prep_nm,
                   c->d_bow_query, c->d_bow_dist,  c->d_bow_cand,   c->d_bow_sel,    c->d_flagged,    c->d_n_flagged,  c->d_k1_counters, c->d_flagmask, c->d_rows_scratch, c->d_rows_arrivals, c->d_flagged_desc,
                   c->d_geo_model, c->d_geo_j,     c->d_guided_row, c->d_geo_dist,
-                  c->fl_key, c->fl_idx, c->fl_count, c->fl_list, c->d_k3_spec, c->d_k3_arrive, c->fl_vec_index, c->fl_best_inl, c->fl_logc_n, c->fl_logc_k,
+                  c->fl_key, c->fl_idx, c->fl_count, c->fl_list, c->d_k3_spec, c->d_k3_arrive, c->d_k3_static, c->fl_vec_index, c->fl_best_inl, c->fl_logc_n, c->fl_logc_k,
                   c->d_pair_qfeat_big, c->d_pair_landmark_big, c->d_p3p_ws_key, c->d_p3p_ws_idx, c->d_p3p_terms};
   for (void *p : ptrs)
     if (p) hipFree(p);

@@ -228,6 +228,9 @@ struct Ctx : GangMember {  // (gang.h: stream, gang_recs, gang_head)
   // K3 for views with more putative matches than its LDS form holds (acransac.hip k_fmatrix_large): allocated on first use
   uint64_t *fl_key = nullptr;
   uint32_t *fl_idx = nullptr, *fl_count = nullptr, *fl_list = nullptr;
+  void *d_k3_static = nullptr;          // K3's per-context argument block on the device (FFilterStatic, acransac.hip) ...
+  unsigned char k3_static_host[256] = {};  // ... and what was last written there
+  bool k3_static_valid = false;
   void *d_k3_spec = nullptr;            // k_fmatrix_fast's wide form: the first batch's results per view slot (lazily)
   unsigned int *d_k3_arrive = nullptr;  // ... and the arrivals
   int32_t *fl_vec_index = nullptr, *fl_best_inl = nullptr;

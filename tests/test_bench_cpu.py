@@ -58,7 +58,7 @@ def test_gpus_flag_is_honoured(monkeypatch):
 
 def test_plan_of_a_run():
     """plan(): the default single-GPU shortlist run keeps 20 queries in flight on 4 host threads and asks for a hardware
-    queue per context + 2 (the 24-queue limit is why 22 contexts are slower); N ranks run gangs of 28 on 84 contexts per
+    queue per context + 2 (the 24-queue limit is why 22 contexts are slower); N ranks run gangs of 32 on 96 contexts per
     slot; --replicas makes every rank a single-GPU run; the image-in leg's defaults are 10 workers, a worker's BoW
     chains on one stream."""
     a = bench.parse([])
@@ -67,7 +67,7 @@ def test_plan_of_a_run():
     assert a.image_workers == 10 and a.image_bow_worker_stream and a.image_bow_own_stream
     a = bench.parse(["--gpus", "8"])
     _, _, sharded, gang, nctx, hwq = bench.plan(a, 8, False)
-    assert sharded and gang == 28 and nctx == 84 and hwq == 16
+    assert sharded and gang == 32 and nctx == 96 and hwq == 16
     a = bench.parse(["--gpus", "8", "--replicas"])
     _, _, sharded, gang, nctx, _ = bench.plan(a, 8, True)
     assert not sharded and gang == 1 and nctx == 20
