@@ -317,9 +317,30 @@ static int launch_hamming_screened(Ctx *c, const Query *q, uint32_t n_work_block
   // costs no head of its own.  Four slices remain the optimum all the same (profiles/r02_k1_qsplit_sweep.txt: a
   // shortlisted query takes 0.95 / 0.93 / 0.89 / 1.02 / 1.29 ms with 1 / 2 / 4 / 8 / 16 slices): a workgroup's fixed
   // costs -- its bank rows, its query slice into LDS, two barriers -- stop amortising below ~500 query rows per slice.
+  // Round 4: HOW MANY slices is chosen for the launch's last generation of workgroups.  A lone query's 3 150 blocks in four
+  // slices are 1 576 workgroups for 768 places (three of the batched form per compute unit): two full generations and 40
+  // stragglers that start when the second ends and run a third of a generation alone -- 48 of the scan's 268 us.  With s
+  // slices a workgroup takes 1 / s of the time and the launch G(s) generations, the last one -- a fraction r of the places
+  // -- about 0.45 + 0.55 r of a full one (fewer waves per SIMD run faster, not proportionally); each slice costs its
+  // workgroups' fixed part (~1 %).  Measured on the headline's lone query, putMatch with 4 / 5 / 7 / 8 / 10 / 14 slices:
+  // 0.323 / 0.301 / 0.291 / 0.300 / 0.296 / 0.294 ms.
   uint32_t qsplit = 1;
-  while (qsplit < 4 && (uint64_t)n_work_blocks * qsplit < 32ull * (uint64_t)m->n_cu && (q->n - head) / (qsplit * 2) >= 6 * head)
-    qsplit *= 2;
+  if ((uint64_t)n_work_blocks < 32ull * (uint64_t)m->n_cu) {
+    const uint32_t wg_per_slice = (n_work_blocks + WAVES - 1) / WAVES;
+    const bool batched = n_work_blocks < 16u * (uint32_t)m->n_cu;  // (the form chosen below: 68 VGPRs, three per compute unit)
+    const double places = (double)((batched ? 3 : 4) * m->n_cu);
+    double best = 1e30;
+    for (uint32_t s = 1; s <= 8; ++s) {
+      if (s > 1 && (q->n - head) / s < 3 * head) break;  // (a slice keeps at least three heads of query rows)
+      const double g = (double)wg_per_slice * s / places;
+      const double full = floor(g), r = g - full;
+      const double cost = (full + (r > 0.0 ? 0.45 + 0.55 * r : 0.0)) / s * (1.0 + 0.012 * s);
+      if (cost < best) {
+        best = cost;
+        qsplit = s;
+      }
+    }
+  }
   if (!c->k1_may_slice) qsplit = 1;  // other queries are queued on the GPU: their scans fill it, slices only add work
   if (qsplit_env >= 1 && qsplit_env <= 16) qsplit = (uint32_t)qsplit_env;
   const uint2 *head_part = nullptr;
